@@ -1,0 +1,209 @@
+/*
+ * orbslam3_hip.h -- C-ABI of the MI355X (gfx950) local-bundle-adjustment and
+ * ORB Hamming-match hot path of ORB-SLAM3.
+ *
+ * This is the drop-in boundary: plain pointers and sizes only, no C++/torch
+ * types.  The C++ host layer (orb_slam3_study_kr_amd/csrc/host/) that mirrors
+ * the reference's own interface
+ *     ORB_SLAM3::Optimizer::LocalBundleAdjustment   include/Optimizer.h:57   (src/Optimizer.cc:1116-1498)
+ *     ORB_SLAM3::Optimizer::LocalInertialBA         include/Optimizer.h:86   (src/Optimizer.cc:2387-2964)
+ *     ORB_SLAM3::ORBmatcher::SearchByProjection     include/ORBmatcher.h:45-60 (src/ORBmatcher.cc:43,1676,1889)
+ *     ORB_SLAM3::ORBmatcher::DescriptorDistance     include/ORBmatcher.h:42  (src/ORBmatcher.cc:2058-2074)
+ * walks the KeyFrame/MapPoint graph, packs it into the flat arrays below and
+ * calls these entry points.  Citations are relative to /root/reference.
+ *
+ * What each entry point replaces in the reference:
+ *   osh_lba_*      g2o::SparseOptimizer::initializeOptimization + optimize(10)
+ *                  as driven from src/Optimizer.cc:1410-1411, i.e.
+ *                  Thirdparty/g2o/g2o/core/sparse_optimizer.cpp:354-419,
+ *                  optimization_algorithm_levenberg.cpp:61-169,
+ *                  block_solver.hpp:354-604, base_binary_edge.hpp:55-120,
+ *                  types/types_six_dof_expmap.{h,cpp}, src/OptimizableTypes.cpp:139-160
+ *   osh_orb_*      the candidate loop + DescriptorDistance of
+ *                  src/ORBmatcher.cc:84-120, 1743-1768, 1949-1964, 2058-2074
+ */
+#ifndef ORBSLAM3_HIP_H
+#define ORBSLAM3_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status */
+#define OSH_OK                0
+#define OSH_ERR_INVALID      -1   /* bad argument / inconsistent sizes           */
+#define OSH_ERR_DEVICE       -2   /* HIP runtime error (see osh_last_error())    */
+#define OSH_ERR_UNSUPPORTED  -3   /* valid graph the device path cannot take yet */
+#define OSH_ERR_NO_DEVICE    -4   /* no gfx950 device visible                    */
+
+/* Thread-local text of the last error raised by any osh_* call on this thread. */
+const char* osh_last_error(void);
+/* Library version string ("orbslam3_hip x.y gfx950"). */
+const char* osh_version(void);
+/* Number of visible HIP devices (0 when none / runtime unavailable). */
+int osh_device_count(void);
+
+/* --------------------------------------------------------- local BA: input */
+/* Edge kinds (the three visual edge types of src/Optimizer.cc:1302-1400). */
+#define OSH_EDGE_MONO    0   /* ORB_SLAM3::EdgeSE3ProjectXYZ      include/OptimizableTypes.h:88-115      */
+#define OSH_EDGE_STEREO  1   /* g2o::EdgeStereoSE3ProjectXYZ      types_six_dof_expmap.h:146-175         */
+
+/*
+ * One local-BA window as flat structure-of-arrays.
+ *
+ * Pose order  : optimisable poses first, in Hessian order (ascending vertex id,
+ *               sparse_optimizer.cpp:166-190), then the fixed poses.
+ * Point order : Hessian order (ascending vertex id).
+ * Edge order  : g2o insertion order (src/Optimizer.cc:1293-1402); any order is
+ *               accepted, the solver re-sorts landmark-major internally.
+ * Every number the reference stores as float (poses, points, pixel
+ * observations, invSigma2, intrinsics, bf) is expected already widened to
+ * double exactly as src/Optimizer.cc:1217-1218,1286,1309,1316,1352-1356 does.
+ */
+typedef struct osh_lba_problem {
+  int32_t n_free;        /* P: optimisable keyframe poses                         */
+  int32_t n_fixed;       /* F: fixed keyframe poses                               */
+  int32_t n_points;      /* L: map points (all marginalised, Optimizer.cc:1289)   */
+  int32_t n_edges;       /* E                                                     */
+  const double*  pose_qt;    /* [(P+F)*7] qx qy qz qw tx ty tz of Tcw (SE3Quat)    */
+  const double*  pose_cam;   /* [(P+F)*5] fx fy cx cy bf of that keyframe          */
+  const double*  points;     /* [L*3] world position                              */
+  const int32_t* edge_pose;  /* [E] index into pose order above                    */
+  const int32_t* edge_point; /* [E] index into point order above                   */
+  const uint8_t* edge_kind;  /* [E] OSH_EDGE_*                                     */
+  const double*  edge_obs;   /* [E*3] u v ur  (ur ignored for mono)                */
+  const double*  edge_info;  /* [E] invSigma2 (information = invSigma2 * I)        */
+  double huber_mono;         /* Huber delta, (double)(float)sqrt(5.991)  Optimizer.cc:1275 */
+  double huber_stereo;       /* Huber delta, (double)(float)sqrt(7.815)  Optimizer.cc:1276 */
+  double lambda_init;        /* >0: setUserLambdaInit (Optimizer.cc:1197-1198); else tau*max diag */
+  int32_t max_iterations;    /* optimizer.optimize(N), 10 at Optimizer.cc:1411     */
+  const volatile unsigned char* stop_flag; /* pbStopFlag (may be NULL); polled once per LM trial */
+} osh_lba_problem;
+
+/* -------------------------------------------------------- local BA: output */
+#define OSH_LBA_MAX_TRACE 128
+typedef struct osh_lba_result {
+  /* caller-allocated arrays (any of them may be NULL to skip) */
+  double*  pose_qt;          /* [P*7] optimised poses (free poses only, same order)      */
+  double*  points;           /* [L*3]                                                   */
+  double*  edge_chi2;        /* [E] e->chi2() as the reference sees it after optimize():  */
+                             /*     error of the LAST evaluated state (stale after a      */
+                             /*     rejected final trial, levenberg.cpp:123-147)          */
+  uint8_t* edge_depth_pos;   /* [E] isDepthPositive() from the FINAL estimates            */
+  /* scalars filled by the solver */
+  int32_t status;            /* OSH_OK or error                                            */
+  int32_t iterations;        /* return value of SparseOptimizer::optimize                  */
+  int32_t trials;            /* total LM trials (linear solves) executed                   */
+  int32_t n_trace;           /* number of valid entries below (= iterations run)           */
+  double  chi2_trace[OSH_LBA_MAX_TRACE];   /* currentChi after each iteration              */
+  double  lambda_trace[OSH_LBA_MAX_TRACE]; /* _currentLambda after each iteration          */
+  int32_t trials_trace[OSH_LBA_MAX_TRACE]; /* qmax of each iteration                       */
+  double  chi2_initial;      /* activeRobustChi2 before the first iteration                */
+} osh_lba_result;
+
+/* ----------------------------------------------------- local BA: device API */
+typedef struct osh_lba_ctx osh_lba_ctx;
+
+/* Create a solver context bound to HIP device `device` (its own stream). */
+int  osh_lba_create(int device, osh_lba_ctx** out);
+void osh_lba_destroy(osh_lba_ctx* ctx);
+
+/* Pack + copy a batch of independent windows to HBM and build the index
+ * structure (landmark-major edge order, per-pose edge lists; the role of
+ * BlockSolver::buildStructure, block_solver.hpp:143-295).  Replaces any batch
+ * previously held by the context. */
+int osh_lba_upload(osh_lba_ctx* ctx, int32_t n_windows, const osh_lba_problem* problems);
+
+/* Run SparseOptimizer::optimize(max_iterations) for every uploaded window,
+ * entirely from HBM-resident data: resets the estimates to the uploaded
+ * initial values, then iterates the Levenberg-Marquardt controller until every
+ * window has terminated.  Synchronous on return.  May be called repeatedly. */
+int osh_lba_optimize(osh_lba_ctx* ctx);
+
+/* Copy results of the last osh_lba_optimize back to the host. */
+int osh_lba_download(osh_lba_ctx* ctx, int32_t n_windows, osh_lba_result* results);
+
+/* Convenience: upload + optimize + download. */
+int osh_lba_solve(osh_lba_ctx* ctx, int32_t n_windows,
+                  const osh_lba_problem* problems, osh_lba_result* results);
+
+/* Evaluate one linearisation of window 0..n-1 at the uploaded estimates and
+ * return the assembled blocks (parity/debug aid; what BlockSolver::buildSystem
+ * leaves behind, block_solver.hpp:502-560).  Arrays may be NULL.
+ *   Hpp  [P*36] full symmetric 6x6 row-major,  bp [P*6]
+ *   Hll  [L*9]  full symmetric 3x3,            bl [L*3]
+ *   Hpl  [E*18] 6x3 row-major per edge in INPUT edge order (zeros for fixed-pose edges)
+ *   chi2 [E]    per-edge chi2,  robust_chi2: sum of rho(chi2)               */
+int osh_lba_linearize(osh_lba_ctx* ctx, int32_t window,
+                      double* Hpp, double* bp, double* Hll, double* bl,
+                      double* Hpl, double* chi2, double* robust_chi2);
+
+/* Kernel timing (HIP events on the context's stream).  Kernel ids: */
+#define OSH_K_LINEARIZE   0   /* residual + Jacobians + Hll/bl/Hpl                */
+#define OSH_K_POSE_HESS   1   /* Hpp / bp per optimisable pose                    */
+#define OSH_K_SCHUR       2   /* Schur complement rows + reduced rhs              */
+#define OSH_K_SOLVE       3   /* dense LDL^T of the reduced camera system         */
+#define OSH_K_BACKSUB     4   /* landmark back-substitution + state update        */
+#define OSH_K_RESIDUAL    5   /* residual / robust chi2 of the trial state        */
+#define OSH_K_CONTROL     6   /* LM controller                                    */
+#define OSH_K_COUNT       7
+int osh_lba_set_profiling(osh_lba_ctx* ctx, int enable);
+/* launches[k], total_ms[k] accumulated since profiling was (re)enabled */
+int osh_lba_get_profile(osh_lba_ctx* ctx, int64_t launches[OSH_K_COUNT], double total_ms[OSH_K_COUNT]);
+const char* osh_lba_kernel_name(int kernel_id);
+
+/* --------------------------------------------------------- ORB matching API */
+/*
+ * Nearest / second-nearest 256-bit Hamming search (the candidate loops of
+ * ORBmatcher::SearchByProjection, src/ORBmatcher.cc:84-120).
+ *
+ * For query q the candidates are cand_idx[cand_off[q] .. cand_off[q+1]) in the
+ * order Frame::GetFeaturesInArea returns them (src/Frame.cc:658-722); with
+ * cand_off == NULL every query is compared with train 0..n_train-1 in index
+ * order (brute force).  Results follow the reference's strict-'<' left-to-right
+ * scan: best = first minimum, second = next in (distance, position) order.
+ *   best_idx  [n_query]  train index of the best candidate, -1 if none (<256)
+ *   best_dist [n_query]  its distance, 256 if none
+ *   second_dist[n_query] second-best distance, 256 if none
+ *   best_level / second_level [n_query]  train_level[] of those, -1 if none
+ * A batch holds n_pairs independent frame pairs laid out back to back with the
+ * same n_query / n_train (candidate lists, if any, are per pair:
+ * cand_off has n_pairs*(n_query+1) entries, offsets relative to the pair's
+ * own slice of cand_idx given by pair_cand_base[pair]).
+ */
+typedef struct osh_orb_ctx osh_orb_ctx;
+int  osh_orb_create(int device, osh_orb_ctx** out);
+void osh_orb_destroy(osh_orb_ctx* ctx);
+
+typedef struct osh_orb_batch {
+  int32_t n_pairs, n_query, n_train;
+  const uint8_t* query_desc;   /* [n_pairs*n_query*32] */
+  const uint8_t* train_desc;   /* [n_pairs*n_train*32] */
+  const int32_t* train_level;  /* [n_pairs*n_train] octave of each train keypoint (may be NULL -> 0) */
+  const int32_t* cand_off;     /* NULL (brute force) or [n_pairs*(n_query+1)]                        */
+  const int32_t* cand_idx;     /* concatenated candidate lists                                       */
+  const int64_t* pair_cand_base; /* [n_pairs] start of each pair's slice in cand_idx (NULL if brute) */
+} osh_orb_batch;
+
+/* Upload a batch (descriptors become HBM resident). */
+int osh_orb_upload(osh_orb_ctx* ctx, const osh_orb_batch* batch);
+/* Run the search on the resident batch; synchronous. */
+int osh_orb_match(osh_orb_ctx* ctx);
+/* Copy the per-query results back. Each array has n_pairs*n_query entries. */
+int osh_orb_download(osh_orb_ctx* ctx, int32_t* best_idx, int32_t* best_dist,
+                     int32_t* second_dist, int32_t* best_level, int32_t* second_level);
+/* Average duration of the match kernel over the launches since the last upload. */
+int osh_orb_get_profile(osh_orb_ctx* ctx, int64_t* launches, double* total_ms);
+int osh_orb_set_profiling(osh_orb_ctx* ctx, int enable);
+
+/* Full n x m distance matrix (ORBmatcher::DescriptorDistance for every pair),
+ * out[n*m] int32.  Used by parity tests. */
+int osh_orb_distance_matrix(osh_orb_ctx* ctx, int32_t n, int32_t m,
+                            const uint8_t* a, const uint8_t* b, int32_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBSLAM3_HIP_H */

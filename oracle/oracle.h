@@ -1,0 +1,47 @@
+/*
+ * oracle.h -- entry points of the CPU oracle (TEST INFRASTRUCTURE ONLY, see
+ * lba_oracle.c / orb_oracle.c headers).  Built into oracle/liboracle.so by
+ * oracle/Makefile; loaded with ctypes from oracle/binding.py.
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+#include <stdint.h>
+#include "../include/orbslam3_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- local BA (lba_oracle.c) ---- */
+int  oracle_lba_solve(const osh_lba_problem* p, osh_lba_result* res);
+int  oracle_lba_linearize(const osh_lba_problem* p, double* Hpp, double* bp, double* Hll, double* bl,
+                          double* Hpl, double* chi2, double* robust_chi2);
+int  oracle_lba_schur_step(const osh_lba_problem* p, double lambda, double* S, double* bs, double* x);
+void oracle_pose_oplus(const double update[6], double qt[7]);
+void oracle_edge_error(int kind, const double qt[7], const double cam[5], const double X[3],
+                       const double obs[3], double err[3]);
+void oracle_edge_jacobians(int kind, const double qt[7], const double cam[5], const double X[3],
+                           double Jxi[9], double Jxj[18]);
+int  oracle_edge_depth_positive(const double qt[7], const double X[3]);
+void oracle_huber(double e, double delta, double rho[3]);
+int  oracle_ldlt_solve(int n, double* A, const double* b, double* x, double* tmp);
+
+/* ---- ORB matching (orb_oracle.c) ---- */
+int  oracle_descriptor_distance(const uint8_t* a, const uint8_t* b);
+void oracle_distance_matrix(int n, int m, const uint8_t* a, const uint8_t* b, int32_t* out);
+void oracle_orb_search(int n_query, int n_train, const uint8_t* query_desc, const uint8_t* train_desc,
+                       const int32_t* train_level, const int32_t* cand_off, const int32_t* cand_idx,
+                       const uint8_t* occupied,
+                       int32_t* best_idx, int32_t* best_dist, int32_t* second_dist,
+                       int32_t* best_level, int32_t* second_level);
+int  oracle_orb_match_local_points(int n_query, int n_train, const uint8_t* query_desc,
+                                   const uint8_t* train_desc, const int32_t* train_level,
+                                   const int32_t* cand_off, const int32_t* cand_idx,
+                                   float nn_ratio, int th_high, uint8_t* occupied, int32_t* assignment);
+int  oracle_orb_match_last_frame(int n_query, int n_train, const uint8_t* query_desc,
+                                 const uint8_t* train_desc, const int32_t* cand_off, const int32_t* cand_idx,
+                                 const float* query_angle, const float* train_angle,
+                                 int th_high, int check_orientation, uint8_t* occupied, int32_t* assignment);
+#ifdef __cplusplus
+}
+#endif
+#endif

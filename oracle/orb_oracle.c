@@ -1,0 +1,177 @@
+/*
+ * orb_oracle.c -- CPU restatement of the Hamming search inside
+ * ORB_SLAM3::ORBmatcher::SearchByProjection.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE (see lba_oracle.c header).
+ * PARITY UNPINNED against a reference binary (OpenCV absent, reference cannot
+ * be built); pinned by known-answer vectors (d(a,a)=0, d(a,~a)=256, SWAR ==
+ * popcount) and hand-built tie-break / occupancy cases in tests/.
+ *
+ * Paths relative to /root/reference.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include "oracle.h"
+
+/* ORBmatcher::DescriptorDistance, src/ORBmatcher.cc:2058-2074 (SWAR popcount
+ * over 8 x int32). */
+int oracle_descriptor_distance(const uint8_t* a, const uint8_t* b) {
+  int dist = 0;
+  for (int i = 0; i < 8; i++) {
+    int32_t pa, pb;
+    memcpy(&pa, a + 4 * i, 4);
+    memcpy(&pb, b + 4 * i, 4);
+    unsigned int v = (unsigned int)(pa ^ pb);
+    v = v - ((v >> 1) & 0x55555555);
+    v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+    dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+  }
+  return dist;
+}
+
+void oracle_distance_matrix(int n, int m, const uint8_t* a, const uint8_t* b, int32_t* out) {
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < m; ++j) out[(size_t)i * m + j] = oracle_descriptor_distance(a + 32 * (size_t)i, b + 32 * (size_t)j);
+}
+
+/* The candidate loop of src/ORBmatcher.cc:84-120 for one query: strict '<'
+ * left-to-right scan keeping best and second best with their levels.
+ * `occupied` (may be NULL) marks slots skipped by the test at :88-90. */
+static void scan_one(const uint8_t* qd, const uint8_t* train_desc, const int32_t* train_level,
+                     const int32_t* cand, int ncand, int n_train, const uint8_t* occupied,
+                     int* bestIdx, int* bestDist, int* bestDist2, int* bestLevel, int* bestLevel2) {
+  *bestDist = 256; *bestLevel = -1; *bestDist2 = 256; *bestLevel2 = -1; *bestIdx = -1;
+  const int n = cand ? ncand : n_train;
+  for (int c = 0; c < n; ++c) {
+    const int idx = cand ? cand[c] : c;
+    if (occupied && occupied[idx]) continue;
+    const int dist = oracle_descriptor_distance(qd, train_desc + 32 * (size_t)idx);
+    const int lev = train_level ? train_level[idx] : 0;
+    if (dist < *bestDist) {
+      *bestDist2 = *bestDist;
+      *bestDist = dist;
+      *bestLevel2 = *bestLevel;
+      *bestLevel = lev;
+      *bestIdx = idx;
+    } else if (dist < *bestDist2) {
+      *bestLevel2 = lev;
+      *bestDist2 = dist;
+    }
+  }
+}
+
+/* Per-query best/second over (optionally windowed) candidate lists, no
+ * acceptance logic: what the device kernel must reproduce bit for bit. */
+void oracle_orb_search(int n_query, int n_train, const uint8_t* query_desc, const uint8_t* train_desc,
+                       const int32_t* train_level, const int32_t* cand_off, const int32_t* cand_idx,
+                       const uint8_t* occupied,
+                       int32_t* best_idx, int32_t* best_dist, int32_t* second_dist,
+                       int32_t* best_level, int32_t* second_level) {
+  for (int q = 0; q < n_query; ++q) {
+    int bi, bd, bd2, bl, bl2;
+    const int32_t* cand = cand_off ? cand_idx + cand_off[q] : NULL;
+    const int nc = cand_off ? cand_off[q + 1] - cand_off[q] : n_train;
+    scan_one(query_desc + 32 * (size_t)q, train_desc, train_level, cand, nc, n_train, occupied, &bi, &bd, &bd2, &bl, &bl2);
+    best_idx[q] = bi; best_dist[q] = bd; second_dist[q] = bd2; best_level[q] = bl; second_level[q] = bl2;
+  }
+}
+
+/* SearchByProjection(Frame&, const vector<MapPoint*>&, th, ...) for the
+ * monocular/rectified-stereo case (F.Nleft == -1), src/ORBmatcher.cc:43-141:
+ * sequential over queries; a slot taken by an earlier accepted query is
+ * skipped (:88-90, local map points have Observations()>0); ratio test in
+ * float (:125,128).  occupied[n_train] is read and updated; assignment[t] =
+ * query index stored into F.mvpMapPoints[t] (caller pre-fills with -1).
+ * The stereo ur window test (:92-97) is a static per-pair filter and is
+ * expected to be already applied to the candidate lists. */
+int oracle_orb_match_local_points(int n_query, int n_train, const uint8_t* query_desc,
+                                  const uint8_t* train_desc, const int32_t* train_level,
+                                  const int32_t* cand_off, const int32_t* cand_idx,
+                                  float nn_ratio, int th_high, uint8_t* occupied, int32_t* assignment) {
+  int nmatches = 0;
+  for (int q = 0; q < n_query; ++q) {
+    const int32_t* cand = cand_off ? cand_idx + cand_off[q] : NULL;
+    const int nc = cand_off ? cand_off[q + 1] - cand_off[q] : n_train;
+    if (cand_off && nc == 0) continue; /* vIndices.empty() :74 */
+    int bi, bd, bd2, bl, bl2;
+    scan_one(query_desc + 32 * (size_t)q, train_desc, train_level, cand, nc, n_train, occupied, &bi, &bd, &bd2, &bl, &bl2);
+    if (bd <= th_high) {
+      if (bl == bl2 && bd > nn_ratio * bd2) continue;
+      if (bl != bl2 || bd <= nn_ratio * bd2) {
+        assignment[bi] = q;
+        occupied[bi] = 1;
+        nmatches++;
+      }
+    }
+  }
+  return nmatches;
+}
+
+/* ORBmatcher::ComputeThreeMaxima, src/ORBmatcher.cc:2012-2053 (on bin sizes). */
+static void three_maxima(const int* sizes, int L, int* ind1, int* ind2, int* ind3) {
+  int max1 = 0, max2 = 0, max3 = 0;
+  for (int i = 0; i < L; i++) {
+    const int s = sizes[i];
+    if (s > max1) {
+      max3 = max2; max2 = max1; max1 = s;
+      *ind3 = *ind2; *ind2 = *ind1; *ind1 = i;
+    } else if (s > max2) {
+      max3 = max2; max2 = s;
+      *ind3 = *ind2; *ind2 = i;
+    } else if (s > max3) {
+      max3 = s; *ind3 = i;
+    }
+  }
+  if (max2 < 0.1f * (float)max1) { *ind2 = -1; *ind3 = -1; }
+  else if (max3 < 0.1f * (float)max1) { *ind3 = -1; }
+}
+
+/* SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono),
+ * src/ORBmatcher.cc:1676-1887, left-camera case: best only (:1743-1768),
+ * accept <= TH_HIGH (:1770), rotation histogram with factor 1.0f/HISTO_LENGTH
+ * (:1684,1784-1791), keep the three dominant bins (:1863-1884). */
+int oracle_orb_match_last_frame(int n_query, int n_train, const uint8_t* query_desc,
+                                const uint8_t* train_desc, const int32_t* cand_off, const int32_t* cand_idx,
+                                const float* query_angle, const float* train_angle,
+                                int th_high, int check_orientation, uint8_t* occupied, int32_t* assignment) {
+  enum { HISTO_LENGTH = 30 };
+  int nmatches = 0;
+  int* hist[HISTO_LENGTH];
+  int hsize[HISTO_LENGTH];
+  for (int i = 0; i < HISTO_LENGTH; ++i) { hist[i] = (int*)malloc(sizeof(int) * (size_t)(n_query + 1)); hsize[i] = 0; }
+  const float factor = 1.0f / HISTO_LENGTH;
+  for (int q = 0; q < n_query; ++q) {
+    const int32_t* cand = cand_off ? cand_idx + cand_off[q] : NULL;
+    const int nc = cand_off ? cand_off[q + 1] - cand_off[q] : n_train;
+    if (cand_off && nc == 0) continue;
+    int bi, bd, bd2, bl, bl2;
+    scan_one(query_desc + 32 * (size_t)q, train_desc, NULL, cand, nc, n_train, occupied, &bi, &bd, &bd2, &bl, &bl2);
+    if (bd <= th_high) {
+      assignment[bi] = q;
+      occupied[bi] = 1;
+      nmatches++;
+      if (check_orientation) {
+        float rot = query_angle[q] - train_angle[bi];
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)roundf(rot * factor);
+        if (bin == HISTO_LENGTH) bin = 0;
+        hist[bin][hsize[bin]++] = bi;
+      }
+    }
+  }
+  if (check_orientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(hsize, HISTO_LENGTH, &ind1, &ind2, &ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i != ind1 && i != ind2 && i != ind3) {
+        for (int j = 0; j < hsize[i]; j++) {
+          assignment[hist[i][j]] = -1; /* slot stays "occupied" only within this call */
+          nmatches--;
+        }
+      }
+    }
+  }
+  for (int i = 0; i < HISTO_LENGTH; ++i) free(hist[i]);
+  return nmatches;
+}

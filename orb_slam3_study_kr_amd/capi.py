@@ -1,0 +1,151 @@
+"""ctypes mirror of include/orbslam3_hip.h and loader of the HIP shared library.
+
+The product path has NO CPU fallback: if the gfx950 library is missing or fails
+to load, :func:`load_library` raises.  (The CPU oracle under ``oracle/`` is test
+infrastructure and is never imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+PKG_DIR = Path(__file__).resolve().parent
+REPO_ROOT = PKG_DIR.parent
+LIB_PATH = PKG_DIR / "csrc" / "liborbslam3_hip.so"
+
+OSH_OK = 0
+OSH_ERR_INVALID = -1
+OSH_ERR_DEVICE = -2
+OSH_ERR_UNSUPPORTED = -3
+OSH_ERR_NO_DEVICE = -4
+OSH_EDGE_MONO = 0
+OSH_EDGE_STEREO = 1
+OSH_LBA_MAX_TRACE = 128
+OSH_K_COUNT = 7
+KERNEL_NAMES = ["linearize", "pose_hess", "schur", "solve", "backsub", "residual", "control"]
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+c_uint8_p = C.POINTER(C.c_uint8)
+c_int64_p = C.POINTER(C.c_int64)
+c_float_p = C.POINTER(C.c_float)
+
+
+class LbaProblem(C.Structure):
+    """``osh_lba_problem`` (include/orbslam3_hip.h)."""
+
+    _fields_ = [
+        ("n_free", C.c_int32), ("n_fixed", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32),
+        ("pose_qt", c_double_p), ("pose_cam", c_double_p), ("points", c_double_p),
+        ("edge_pose", c_int32_p), ("edge_point", c_int32_p), ("edge_kind", c_uint8_p),
+        ("edge_obs", c_double_p), ("edge_info", c_double_p),
+        ("huber_mono", C.c_double), ("huber_stereo", C.c_double),
+        ("lambda_init", C.c_double), ("max_iterations", C.c_int32),
+        ("stop_flag", c_uint8_p),
+    ]
+
+
+class LbaResult(C.Structure):
+    """``osh_lba_result`` (include/orbslam3_hip.h)."""
+
+    _fields_ = [
+        ("pose_qt", c_double_p), ("points", c_double_p), ("edge_chi2", c_double_p), ("edge_depth_pos", c_uint8_p),
+        ("status", C.c_int32), ("iterations", C.c_int32), ("trials", C.c_int32), ("n_trace", C.c_int32),
+        ("chi2_trace", C.c_double * OSH_LBA_MAX_TRACE),
+        ("lambda_trace", C.c_double * OSH_LBA_MAX_TRACE),
+        ("trials_trace", C.c_int32 * OSH_LBA_MAX_TRACE),
+        ("chi2_initial", C.c_double),
+    ]
+
+
+class OrbBatch(C.Structure):
+    """``osh_orb_batch`` (include/orbslam3_hip.h)."""
+
+    _fields_ = [
+        ("n_pairs", C.c_int32), ("n_query", C.c_int32), ("n_train", C.c_int32),
+        ("query_desc", c_uint8_p), ("train_desc", c_uint8_p), ("train_level", c_int32_p),
+        ("cand_off", c_int32_p), ("cand_idx", c_int32_p), ("pair_cand_base", c_int64_p),
+    ]
+
+
+def ptr(a, typ):
+    """Pointer of ctypes type `typ` to the data of numpy array `a` (None -> NULL)."""
+    if a is None:
+        return C.cast(None, typ)
+    assert a.flags["C_CONTIGUOUS"], "array must be C-contiguous"
+    return a.ctypes.data_as(typ)
+
+
+# Every symbol include/orbslam3_hip.h declares, with its signature.
+_SIGNATURES = {
+    "osh_last_error": (C.c_char_p, []),
+    "osh_version": (C.c_char_p, []),
+    "osh_device_count": (C.c_int, []),
+    "osh_lba_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "osh_lba_destroy": (None, [C.c_void_p]),
+    "osh_lba_upload": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(LbaProblem)]),
+    "osh_lba_optimize": (C.c_int, [C.c_void_p]),
+    "osh_lba_download": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(LbaResult)]),
+    "osh_lba_solve": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(LbaProblem), C.POINTER(LbaResult)]),
+    "osh_lba_linearize": (C.c_int, [C.c_void_p, C.c_int32] + [c_double_p] * 7),
+    "osh_lba_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "osh_lba_get_profile": (C.c_int, [C.c_void_p, c_int64_p, c_double_p]),
+    "osh_lba_kernel_name": (C.c_char_p, [C.c_int]),
+    "osh_orb_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "osh_orb_destroy": (None, [C.c_void_p]),
+    "osh_orb_upload": (C.c_int, [C.c_void_p, C.POINTER(OrbBatch)]),
+    "osh_orb_match": (C.c_int, [C.c_void_p]),
+    "osh_orb_download": (C.c_int, [C.c_void_p] + [c_int32_p] * 5),
+    "osh_orb_get_profile": (C.c_int, [C.c_void_p, c_int64_p, c_double_p]),
+    "osh_orb_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "osh_orb_distance_matrix": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_uint8_p, c_uint8_p, c_int32_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load_library(path: os.PathLike | None = None) -> C.CDLL:
+    """Load liborbslam3_hip.so (built by ``__graft_entry__.build()``); raise if absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = Path(path) if path else LIB_PATH
+    if not p.exists():
+        raise RuntimeError(
+            f"{p} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback for the product path)."
+        )
+    lib = C.CDLL(str(p))
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def last_error(lib=None) -> str:
+    lib = lib or load_library()
+    s = lib.osh_last_error()
+    return s.decode() if s else ""
+
+
+class OshError(RuntimeError):
+    def __init__(self, code: int, where: str, msg: str):
+        super().__init__(f"{where} failed with code {code}: {msg}")
+        self.code = code
+
+
+def check(code: int, where: str, lib=None):
+    if code != OSH_OK:
+        raise OshError(code, where, last_error(lib))
+
+
+def np_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)

@@ -1,0 +1,68 @@
+"""Generates the committed golden fixtures under tests/golden/.
+
+The reference ships no golden vectors for this path and cannot be built here
+(SURVEY.md section 8c), so the expected outputs come from the INDEPENDENT numpy
+implementation oracle/lm_numpy.py (dense normal equations, matrix-exponential
+updates) for local BA and from numpy.unpackbits popcounts for Hamming distances.
+Run from the repo root:  python tests/golden/make_golden.py
+"""
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+
+from orb_slam3_study_kr_amd import synth  # noqa: E402
+from oracle import lm_numpy  # noqa: E402
+
+OUT = Path(__file__).resolve().parent
+
+
+def window_arrays(w):
+    return dict(n_free=w.n_free, n_fixed=w.n_fixed, pose_qt=w.pose_qt, pose_cam=w.pose_cam, points=w.points,
+                edge_pose=w.edge_pose, edge_point=w.edge_point, edge_kind=w.edge_kind, edge_obs=w.edge_obs,
+                edge_info=w.edge_info, huber_mono=w.huber_mono, huber_stereo=w.huber_stereo,
+                lambda_init=w.lambda_init, max_iterations=w.max_iterations)
+
+
+def lba_fixture(name, w):
+    st0 = lm_numpy.State(w)
+    errs = lm_numpy.errors(w, st0)
+    chi0, per_edge0 = lm_numpy.robust_chi2(w, errs)
+    H, b = lm_numpy.build_dense_system(w, st0, errs)
+    lam = 1e-5 * np.max(np.abs(np.diag(H)))
+    x = np.linalg.solve(H + lam * np.eye(H.shape[0]), b)
+    st, trace, per_edge = lm_numpy.lm_optimize(w)
+    np.savez_compressed(
+        OUT / f"{name}.npz", **window_arrays(w),
+        exp_chi2_initial=chi0, exp_edge_chi2_initial=per_edge0, exp_H=H, exp_b=b, exp_lambda0=lam, exp_x0=x,
+        exp_T=st.T[:w.n_free], exp_points=st.X, exp_chi2_trace=np.array(trace["chi2"]),
+        exp_lambda_trace=np.array(trace["lam"]), exp_trials_trace=np.array(trace["trials"]),
+        exp_iterations=trace["iterations"], exp_edge_chi2_final=per_edge)
+    print(name, "edges", w.n_edges, "iters", trace["iterations"], "trials", trace["trials"], "chi2", chi0, "->", trace["chi2"][-1])
+
+
+def orb_fixture():
+    rng = np.random.Generator(np.random.PCG64(2024))
+    a = rng.integers(0, 256, (64, 32), dtype=np.uint8)
+    b = rng.integers(0, 256, (64, 32), dtype=np.uint8)
+    b[5] = a[7]                      # distance 0
+    b[9] = ~a[3]                     # distance 256
+    b[11] = a[2]; b[11, 0] ^= 0x81   # distance 2
+    dist = (np.unpackbits(a[:, None, :] ^ b[None, :, :], axis=2).sum(axis=2)).astype(np.int32)
+    np.savez_compressed(OUT / "orb_64x64.npz", a=a, b=b, dist=dist)
+    print("orb_64x64", dist.min(), dist.max())
+
+
+if __name__ == "__main__":
+    lba_fixture("lba_tiny_mono", synth.make_window(11, n_free=3, n_fixed=2, n_points=40, stereo=False, track_len=(2, 5)))
+    lba_fixture("lba_tiny_stereo", synth.make_window(12, n_free=3, n_fixed=2, n_points=40, stereo=True, track_len=(2, 5)))
+    lba_fixture("lba_tiny_mixed", synth.make_window(13, n_free=4, n_fixed=1, n_points=30, stereo=True, track_len=(2, 5),
+                                                     mixed_mono_frac=0.4, outlier_frac=0.1))
+    # genuine LM rejections (large initial error, small user lambda): trials_trace > 1
+    rej = dict(n_free=3, n_fixed=2, n_points=40, track_len=(2, 5), pose_noise=(0.08, 0.4), point_noise=1.5, lambda_init=1e-4)
+    lba_fixture("lba_tiny_reject_stereo", synth.make_window(40, stereo=True, **rej))
+    lba_fixture("lba_tiny_reject_mono", synth.make_window(51, stereo=False, **rej))
+    orb_fixture()

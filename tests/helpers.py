@@ -1,0 +1,50 @@
+"""Shared helpers for the parity tests."""
+from pathlib import Path
+
+import numpy as np
+
+from orb_slam3_study_kr_amd import synth
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+LBA_FIXTURES = ["lba_tiny_mono", "lba_tiny_stereo", "lba_tiny_mixed", "lba_tiny_reject_stereo", "lba_tiny_reject_mono"]
+
+
+def load_lba_fixture(name):
+    z = np.load(GOLDEN / f"{name}.npz")
+    w = synth.LbaWindow(
+        n_free=int(z["n_free"]), n_fixed=int(z["n_fixed"]), pose_qt=z["pose_qt"], pose_cam=z["pose_cam"],
+        points=z["points"], edge_pose=z["edge_pose"], edge_point=z["edge_point"], edge_kind=z["edge_kind"],
+        edge_obs=z["edge_obs"], edge_info=z["edge_info"], huber_mono=float(z["huber_mono"]),
+        huber_stereo=float(z["huber_stereo"]), lambda_init=float(z["lambda_init"]),
+        max_iterations=int(z["max_iterations"])).normalise()
+    return w, z
+
+
+def quat_to_R(q):
+    return synth.quat_to_R(np.asarray(q) / np.linalg.norm(q))
+
+
+def rel_translation_error(a_qt, b_qt):
+    """max_i |t_a - t_b| / max(|t_b|, 1e-12)  -- the north_star tolerance is on SE3 translations."""
+    ta, tb = np.asarray(a_qt)[:, 4:], np.asarray(b_qt)[:, 4:]
+    return float(np.max(np.linalg.norm(ta - tb, axis=1) / np.maximum(np.linalg.norm(tb, axis=1), 1e-12)))
+
+
+def rotation_error(a_qt, b_qt):
+    out = 0.0
+    for qa, qb in zip(np.asarray(a_qt)[:, :4], np.asarray(b_qt)[:, :4]):
+        out = max(out, float(np.abs(quat_to_R(qa) - quat_to_R(qb)).max()))
+    return out
+
+
+def dense_blocks_from_H(H, b, w):
+    """Split the dense (6P+3L)^2 system of oracle/lm_numpy.py into g2o's block layout."""
+    P, L, E = w.n_free, w.n_points, w.n_edges
+    Hpp = np.stack([H[6 * i:6 * i + 6, 6 * i:6 * i + 6] for i in range(P)]) if P else np.zeros((0, 6, 6))
+    Hll = np.stack([H[6 * P + 3 * j:6 * P + 3 * j + 3, 6 * P + 3 * j:6 * P + 3 * j + 3] for j in range(L)])
+    Hpl = np.zeros((E, 6, 3))
+    for e in range(E):
+        ip, il = w.edge_pose[e], w.edge_point[e]
+        if ip < P:
+            Hpl[e] = H[6 * ip:6 * ip + 6, 6 * P + 3 * il:6 * P + 3 * il + 3]
+    return Hpp, b[:6 * P].reshape(P, 6), Hll, b[6 * P:].reshape(L, 3), Hpl

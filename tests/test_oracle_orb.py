@@ -1,0 +1,100 @@
+"""CPU tests of the matcher oracle (oracle/orb_oracle.c); known-answer vectors of SURVEY.md 8c(4,5)."""
+import numpy as np
+
+from helpers import GOLDEN
+from oracle import binding as ob
+from orb_slam3_study_kr_amd import synth
+
+
+def test_descriptor_distance_known_answers():
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, 32, dtype=np.uint8)
+    assert ob.descriptor_distance(a, a) == 0
+    assert ob.descriptor_distance(a, ~a) == 256
+    b = a.copy()
+    b[31] ^= 0x80
+    assert ob.descriptor_distance(a, b) == 1
+
+
+def test_swar_equals_popcount_on_random_pairs():
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, 256, (1000, 32), dtype=np.uint8)
+    b = rng.integers(0, 256, (1000, 32), dtype=np.uint8)
+    d = ob.distance_matrix(a, b)
+    ref = np.unpackbits(a[:, None, :] ^ b[None, :, :], axis=2).sum(axis=2)
+    np.testing.assert_array_equal(d, ref)
+
+
+def test_distance_matrix_golden():
+    z = np.load(GOLDEN / "orb_64x64.npz")
+    np.testing.assert_array_equal(ob.distance_matrix(z["a"], z["b"]), z["dist"])
+    assert z["dist"][7, 5] == 0 and z["dist"][3, 9] == 256 and z["dist"][2, 11] == 2
+
+
+def test_tie_break_first_minimum_wins_and_second_is_next_in_scan_order():
+    q = np.zeros((1, 32), dtype=np.uint8)
+    t = np.zeros((5, 32), dtype=np.uint8)
+    t[0, 0] = 0b111      # 3
+    t[1, 0] = 0b11       # 2  <- best (first of the two 2s)
+    t[2, 1] = 0b11       # 2  <- second (equal distance, later)
+    t[3, 0] = 0b1111     # 4
+    t[4, 0] = 0xFF       # 8
+    lev = np.array([0, 1, 2, 3, 4], dtype=np.int32)
+    r = ob.orb_search(q, t, lev)
+    assert (r["best_idx"][0], r["best_dist"][0], r["second_dist"][0]) == (1, 2, 2)
+    assert (r["best_level"][0], r["second_level"][0]) == (1, 2)
+    # candidate list order overrides index order
+    off = np.array([0, 3], dtype=np.int32)
+    idx = np.array([2, 1, 0], dtype=np.int32)
+    r = ob.orb_search(q, t, lev, off, idx)
+    assert (r["best_idx"][0], r["second_level"][0]) == (2, 1)
+    # empty list and all-256 give "none"
+    r = ob.orb_search(q, t, lev, np.array([0, 0], dtype=np.int32), np.zeros(0, dtype=np.int32))
+    assert (r["best_idx"][0], r["best_dist"][0], r["second_dist"][0], r["best_level"][0]) == (-1, 256, 256, -1)
+    r = ob.orb_search(q, (~q).repeat(2, axis=0), None)
+    assert (r["best_idx"][0], r["best_dist"][0]) == (-1, 256)
+
+
+def test_sequential_occupancy_and_ratio_rules():
+    # two identical queries compete for the same train descriptor: the first takes it,
+    # the second must fall back to its next candidate (ORBmatcher.cc:88-90)
+    rng = np.random.default_rng(4)
+    t = rng.integers(0, 256, (6, 32), dtype=np.uint8)
+    q = np.stack([t[2], t[2]])
+    q[1, 0] ^= 1
+    n, assign, occ = ob.orb_match_local_points(q, t, np.arange(6, dtype=np.int32))  # all levels differ -> no ratio test
+    assert assign[2] == 0 and n == 1 or n == 2
+    assert occ[2] == 1
+    # same level: ratio test best <= 0.8 * second (float) must hold
+    lev = np.zeros(6, dtype=np.int32)
+    t2 = t.copy()
+    t2[3] = t2[2]
+    t2[3, 5] ^= 0xFF          # second best at distance 8 from t[2]
+    qq = t2[2:3].copy()
+    qq[0, 9] ^= 0x7F          # best distance 7 -> 7 > 0.8*15? second = 15 -> 7 <= 12 accept
+    n, assign, _ = ob.orb_match_local_points(qq, t2, lev)
+    assert n == 1 and assign[2] == 0
+    qq[0, 10] ^= 0xFF         # best 15, second 23: 15 <= 18.4 accept
+    qq[0, 11] ^= 0xFF         # best 23, second 31: 23 <= 24.8 accept
+    n, _, _ = ob.orb_match_local_points(qq, t2, lev)
+    assert n == 1
+
+
+def test_config3_bruteforce_and_windowed_shapes():
+    p = synth.make_orb_pair(7, 300, 300, windowed=True, same_level=False)
+    r = ob.orb_search(p.query_desc, p.train_desc, p.train_level)
+    d = np.unpackbits(p.query_desc[:, None, :] ^ p.train_desc[None, :, :], axis=2).sum(axis=2)
+    np.testing.assert_array_equal(r["best_dist"], d.min(axis=1))
+    np.testing.assert_array_equal(r["best_idx"], d.argmin(axis=1))
+    srt = np.sort(d, axis=1)
+    np.testing.assert_array_equal(r["second_dist"], srt[:, 1])
+    rw = ob.orb_search(p.query_desc, p.train_desc, p.train_level, p.cand_off, p.cand_idx)
+    for qi in range(300):
+        c = p.cand_idx[p.cand_off[qi]:p.cand_off[qi + 1]]
+        if len(c) == 0:
+            assert rw["best_idx"][qi] == -1
+        else:
+            assert rw["best_dist"][qi] == d[qi, c].min()
+            assert rw["best_idx"][qi] == c[np.argmin(d[qi, c])]
+    n, assign, _ = ob.orb_match_last_frame(p.query_desc, p.train_desc, p.cand_off, p.cand_idx, p.query_angle, p.train_angle)
+    assert n == np.count_nonzero(assign >= 0)
