@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py -- local-BA windows/sec (+ ORB matches/sec) on N MI355X GPUs of one node.
+
+  python bench.py --gpus N --steps K --warmup W          (N=1 directly; N>1 via torch.distributed.run)
+
+A "step" is one pass of the hot path over one batch of synthetic input that is already resident
+in HBM: osh_lba_optimize() on `--windows` independent config-2 windows (BASELINE.json configs[1]:
+50 optimisable + 10 fixed keyframes, ~10k landmarks, ~75k stereo edges, <=10 LM iterations with
+the reference's early-stop rules).  Multi-GPU: weak scaling, window w -> rank w mod G, no
+data-path collective; barrier + max-over-ranks timing via torch.distributed (RCCL).
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+from orb_slam3_study_kr_amd import dist as osh_dist  # noqa: E402
+from orb_slam3_study_kr_amd import synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def _make_cfg2(seed):
+    return synth.make_config2(seed)
+
+
+def generate_windows(seeds, workers=8):
+    if len(seeds) <= 2 or workers <= 1:
+        return [_make_cfg2(s) for s in seeds]
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(min(workers, len(seeds))) as pool:
+        return pool.map(_make_cfg2, seeds)
+
+
+def kernel_algorithmic_bytes(windows, results):
+    """Algorithmic bytes each kernel moved over one optimize(), per SURVEY.md 8(d):
+    per-window byte formulas x the number of times the reference loop runs for that window
+    (linearise: once per iteration; Schur / back-substitution / trial residual: once per LM trial)."""
+    tot = dict(linearize=0, pose_hess=0, schur=0, solve=0, backsub=0, residual=0)
+    for w, r in zip(windows, results):
+        b = w.algorithmic_bytes()
+        P, Ef = w.n_free, w.n_free_edges
+        it, tr = int(r.iterations), int(r.trials)
+        d_free = int(np.where(w.edge_kind[w.edge_pose < P] == 0, 2, 3).sum())
+        tot["linearize"] += it * (b["lin"] - P * 216)                     # edges+points+poses in, Hpl/Hll/b_l out
+        tot["pose_hess"] += it * (8 * d_free + 16 * Ef + Ef * 24 + P * (56 + 216))
+        tot["schur"] += tr * b["schur"]
+        tot["solve"] += tr * ((6 * P) * (6 * P + 1) * 8 + 2 * 6 * P * 8 + 2 * P * 56)
+        tot["backsub"] += tr * (b["back"] + 2 * w.n_points * 24)
+        tot["residual"] += tr * b["resid"]
+    return tot
+
+
+def make_lba_inputs(args, rank, world):
+    """Pure-numpy input generation; runs BEFORE anything touches the GPU (it forks worker processes)."""
+    my = osh_dist.shard_indices(args.windows * world, rank, world)   # window w -> rank w mod G
+    seeds = [100 + w for w in my]
+    return generate_windows(seeds, workers=max(1, min(8, (os.cpu_count() or 8) // max(1, world))))
+
+
+def run_lba(args, info, windows):
+    from orb_slam3_study_kr_amd import lba
+    solver = lba.LbaSolver(info.local_rank)
+    t0 = time.perf_counter()
+    solver.upload(windows)
+    upload_s = time.perf_counter() - t0
+    import torch
+    for _ in range(args.warmup):
+        solver.optimize()
+    torch.cuda.synchronize()
+    osh_dist.barrier(info)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        solver.optimize()                 # synchronous: returns after the context's stream is idle
+    torch.cuda.synchronize()
+    osh_dist.barrier(info)
+    elapsed = osh_dist.all_reduce_max(info, time.perf_counter() - t0)
+    results = solver.download()
+    # per-kernel HIP-event timing of one more (untimed) step
+    solver.set_profiling(True)
+    solver.optimize()
+    prof = solver.profile()
+    solver.set_profiling(False)
+    alg = kernel_algorithmic_bytes(windows, results)
+    solver.close()
+    return dict(windows=windows, results=results, elapsed=elapsed, upload_s=upload_s, prof=prof, alg=alg)
+
+
+def run_orb(args, info):
+    from orb_slam3_study_kr_amd import orb
+    n_pairs = args.orb_pairs
+    my = osh_dist.shard_indices(n_pairs * info.world, info.rank, info.world)
+    base = synth.make_orb_pair(7, 2000, 2000)
+    rng = np.random.Generator(np.random.PCG64(7000 + info.rank))
+    pairs = []
+    for _ in my:  # distinct query sets per pair (cheap variation of the config-3 pair)
+        q = base.query_desc ^ np.packbits(rng.uniform(0, 1, (2000, 256)) < 0.01, axis=1)
+        pairs.append(synth.OrbPair(np.ascontiguousarray(q), base.train_desc, base.train_level))
+    m = orb.OrbMatcher(info.local_rank)
+    m.upload(pairs)
+    import torch
+    for _ in range(max(1, args.warmup)):
+        m.match()
+    torch.cuda.synchronize()
+    osh_dist.barrier(info)
+    steps = max(args.steps, 5)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.match()
+    torch.cuda.synchronize()
+    osh_dist.barrier(info)
+    elapsed = osh_dist.all_reduce_max(info, time.perf_counter() - t0)
+    res = m.download()
+    accepted = int(sum(orb.accept_local_points(res, i).sum() for i in range(len(pairs))))
+    m.set_profiling(True)
+    m.match()
+    launches, ms = m.profile()
+    m.close()
+    tot = osh_dist.all_reduce_sum(info, [float(accepted), float(len(pairs))])
+    per_step_s = elapsed / steps
+    return dict(matches_per_s=tot[0] / per_step_s, pair_evals_per_s=tot[1] * 4.0e6 / per_step_s,
+                frame_pairs_per_s=tot[1] / per_step_s, accepted_per_pair=tot[0] / max(tot[1], 1),
+                kernel_ms=ms / max(launches, 1), pairs_per_gpu=len(pairs), pair0=pairs[0], res=res)
+
+
+def cpu_baseline(windows, budget_s=12.0):
+    """The oracle (kind "port": CPU restatement of the g2o path, oracle/lba_oracle.c) timed single
+    threaded on this host, rebuilt here with -O3 -march=native like the reference's own flags."""
+    from oracle import binding as ob
+    try:
+        ob.load(native=True)
+        native = True
+    except Exception:
+        native = False
+    n, t0 = 0, time.perf_counter()
+    for w in windows:
+        ob.lba_solve(w, native=native)
+        n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit="windows/s", cores=1, kind="port",
+                sample=f"{n} of the same config-2 windows, one at a time on one thread ({dt:.1f} s)",
+                march="native" if native else "x86-64-v3")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--windows", type=int, default=32, help="config-2 windows resident per GPU (one step solves them all)")
+    ap.add_argument("--orb-pairs", type=int, default=64, help="2000x2000 frame pairs per GPU per ORB step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-orb", action="store_true")
+    args = ap.parse_args()
+
+    env_rank, env_world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    windows = make_lba_inputs(args, env_rank, env_world)
+    info = osh_dist.init_from_env()
+    if info.world != args.gpus and info.rank == 0 and info.world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={info.world}", file=sys.stderr)
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(info.local_rank)
+
+    lba_out = run_lba(args, info, windows)
+    orb_out = None if args.no_orb else run_orb(args, info)
+
+    n_gpus = info.world
+    ms_per_step = lba_out["elapsed"] / args.steps * 1e3
+    value = args.windows * n_gpus / (ms_per_step * 1e-3)
+
+    # roofline of the dominant kernel (largest total HIP-event time in one optimize())
+    prof, alg = lba_out["prof"], lba_out["alg"]
+    dom = max((k for k in alg), key=lambda k: prof[k][1])
+    launches, total_ms = prof[dom]
+    avg_ms = total_ms / max(launches, 1)
+    achieved = (alg[dom] / max(launches, 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=achieved / HBM_PEAK_GBS, traffic=None,
+                    avg_launch_ms=avg_ms, launches=launches, algorithmic_bytes_per_launch=alg[dom] / max(launches, 1))
+    kernels = {k: dict(launches=prof[k][0], total_ms=round(prof[k][1], 4),
+                       alg_GBps=(alg[k] / (prof[k][1] * 1e-3) / 1e9) if (k in alg and prof[k][1] > 0) else None)
+               for k in prof}
+    whole_bytes = sum(alg.values())
+    res = lba_out["results"]
+    out = {
+        "metric": "local-BA windows/sec (50 KF, 10k pts, 10 LM iters) + ORB matches/sec; 1/2/4/8 GPU",
+        "value": value, "unit": "windows/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[1]: synthetic stereo local BA, 50 optimisable + 10 fixed KF, "
+                               "10k landmarks (~75k stereo edges), optimize(10) with the reference's stop rules",
+                   "windows_per_gpu": args.windows, "global_windows": args.windows * n_gpus,
+                   "parallelism": f"independent windows, w mod {n_gpus}", "lm_iterations_mean": float(np.mean([r.iterations for r in res])),
+                   "lm_trials_mean": float(np.mean([r.trials for r in res]))},
+        "roofline": roofline,
+        "kernels": kernels,
+        "whole_job_alg_GBps_per_gpu": whole_bytes / (ms_per_step * 1e-3) / 1e9,
+        "upload_s_per_batch": lba_out["upload_s"],
+    }
+    if orb_out is not None:
+        out["orb"] = {"metric": "ORB matches/sec (SearchByProjection 256-bit Hamming, 2000x2000 per frame pair)",
+                      "matches_per_s": orb_out["matches_per_s"], "pair_evals_per_s": orb_out["pair_evals_per_s"],
+                      "frame_pairs_per_s": orb_out["frame_pairs_per_s"], "accepted_per_pair": orb_out["accepted_per_pair"],
+                      "kernel_ms_per_launch": orb_out["kernel_ms"], "pairs_per_gpu": orb_out["pairs_per_gpu"], "dtype": "u32 popcount"}
+    if info.rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(lba_out["windows"])
+        out["speedup_vs_cpu_1thread"] = value / out["cpu_baseline"]["value"]
+        if orb_out is not None:
+            from oracle import binding as ob
+            p = orb_out["pair0"]
+            t0 = time.perf_counter()
+            ob.orb_search(p.query_desc, p.train_desc, p.train_level)
+            dt = time.perf_counter() - t0
+            out["orb"]["cpu_baseline"] = dict(value=4.0e6 / dt, unit="pair-evals/s", cores=1, kind="port",
+                                              sample="one 2000x2000 frame pair, SWAR popcount restatement")
+    if info.rank == 0:
+        print(json.dumps(out))
+    osh_dist.finalize(info)
+
+
+if __name__ == "__main__":
+    main()

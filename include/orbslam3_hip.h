@@ -140,6 +140,14 @@ int osh_lba_linearize(osh_lba_ctx* ctx, int32_t window,
                       double* Hpp, double* bp, double* Hll, double* bl,
                       double* Hpl, double* chi2, double* robust_chi2);
 
+/* Parity/debug aid: one LM trial of the uploaded batch at the initial estimates
+ * with lambda forced to `lambda` (setLambda + BlockSolver::solve,
+ * block_solver.hpp:354-486).  Exports for `window`:
+ *   S  [(6P)^2] Schur complement, row-major, upper triangle valid
+ *   bs [6P]     reduced right-hand side
+ *   x  [6P+3L]  solution (pose increments, then landmark increments)        */
+int osh_lba_debug_trial(osh_lba_ctx* ctx, int32_t window, double lambda, double* S, double* bs, double* x);
+
 /* Kernel timing (HIP events on the context's stream).  Kernel ids: */
 #define OSH_K_LINEARIZE   0   /* residual + Jacobians + Hll/bl/Hpl                */
 #define OSH_K_POSE_HESS   1   /* Hpp / bp per optimisable pose                    */

@@ -1,0 +1,1272 @@
+// lba_device.hip -- local bundle adjustment on MI355X (gfx950): HIP kernels + C-ABI driver.
+//
+// Replaces, for a batch of independent windows, what
+//   optimizer.initializeOptimization(); optimizer.optimize(10);     src/Optimizer.cc:1410-1411
+// does on one CPU thread in the reference (g2o LM + Schur block solver).  See
+// DESIGN.md for the data layout and the roofline of each kernel.
+//
+// Kernel map (reference loop -> kernel), "g2o/" = Thirdparty/g2o/g2o/:
+//   k_linearize   computeActiveErrors + activeRobustChi2 + buildSystem for the landmark side
+//                 g2o/core/sparse_optimizer.cpp:61-114, block_solver.hpp:502-560,
+//                 base_binary_edge.hpp:55-120  (Hll, b_l, Hpl;  also residual-only mode)
+//   k_pose_hess   the pose side of buildSystem (Hpp, b_p), one wavefront per optimisable pose
+//   k_schur       BlockSolver::solve Schur part, block_solver.hpp:367-439, one wavefront per
+//                 pose ROW of S (LDS-resident 6 x 6P row block, no atomics)
+//   k_solve       LinearSolverEigen::solve -> dense blocked LDL^T, g2o/solvers/linear_solver_eigen.h:94-124,
+//                 + pose update (VertexSE3Expmap::oplusImpl)
+//   k_backsub     landmark back-substitution block_solver.hpp:461-483 + VertexSBAPointXYZ::oplusImpl
+//                 + computeScale partials (optimization_algorithm_levenberg.cpp:187-194)
+//   k_control     the Levenberg-Marquardt controller, optimization_algorithm_levenberg.cpp:61-169,
+//                 and the optimize() loop conditions, sparse_optimizer.cpp:354-419
+//   k_finalize    per-edge chi2 / isDepthPositive for the outlier test, src/Optimizer.cc:1413-1460
+#include "common.h"
+#include "lba_math.h"
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace osh {
+
+constexpr int kBlock = 256;        // threads per block of the edge/landmark kernels
+constexpr int kChunkEdges = 256;   // edges handled per pass of a chunk (== kBlock)
+constexpr double kTau = 1e-5;      // OptimizationAlgorithmLevenberg::_tau
+constexpr int kMaxTrials = 10;     // maxTrialsAfterFailure
+
+struct WinDesc {
+  int P, F, L, E;
+  int pose_off;    // first pose of the window in the pose arrays (P+F poses per window)
+  int fpose_off;   // first optimisable pose in the per-free-pose arrays
+  int pt_off;      // first landmark
+  int edge_off;    // first (sorted) edge
+  int lmoff_off;   // start of this window's L+1 landmark->edge offsets
+  int peloff_off;  // start of this window's P+1 pose->edge-list offsets
+  int pel_off;     // start of this window's pose edge list
+  int chunk_off, n_chunks;
+  int n;           // 6P
+  int max_iter;
+  long long S_off; // doubles
+  double huber_mono, huber_stereo, lambda_init;
+};
+
+struct LmState {
+  double lambda, ni, currentChi, iniChi, tempChi, rho, scale_pose, chi2_initial;
+  int iter;           // index of the running solve() call
+  int qmax;           // trials of the running iteration
+  int nBad;
+  int active;         // window still inside optimize()
+  int need_lin;       // next round opens a new iteration (linearise at cur)
+  int sel;            // state buffer holding the current estimates
+  int last_eval_sel;  // buffer whose errors computeActiveErrors saw last
+  int iterations;     // cjIterations
+  int trials;
+  int solve_ok;
+  int stop;           // host stop flag snapshot
+  int n_trace;
+  double chi2_trace[OSH_LBA_MAX_TRACE];
+  double lambda_trace[OSH_LBA_MAX_TRACE];
+  int trials_trace[OSH_LBA_MAX_TRACE];
+};
+
+struct Chunk { int win, lm0, lm1; };
+
+// Everything the kernels need, passed by value.
+struct BatchView {
+  int n_windows, n_chunks, n_fposes;
+  const WinDesc* win;
+  LmState* lm;
+  const Chunk* chunks;
+  const int* fpose_win;      // [n_fposes] window of each optimisable pose
+  // state: [2] buffers
+  double* pose_state[2];     // [NP*7]
+  double* pt_state[2];       // [NL*3]
+  const double* pose_cam;    // [NP*5]
+  // sorted edges (landmark-major, poses ascending inside a landmark, free poses first)
+  const int* e_pose;         // [NE] window-local pose index
+  const int* e_point;        // [NE] window-local landmark index
+  const unsigned char* e_kind;
+  const double* e_obs;       // [NE*3]
+  const double* e_info;      // [NE]
+  const int* e_orig;         // [NE] index in the caller's edge order
+  const int* lm_off;         // per window L+1 offsets (window-local edge index)
+  const int* lm_nfree;       // [NL] free-pose edges of each landmark
+  const int* pel_off;        // per window P+1
+  const int* pel_edge;       // [NEfree] window-local sorted edge index, landmark order
+  // system
+  double* Hpl;               // [NE*18] 6x3 row-major per sorted edge
+  double* Hll;               // [NL*6] upper: 00 01 02 11 12 22
+  double* bl;                // [NL*3]
+  double* Hpp;               // [NFP*36]
+  double* bp;                // [NFP*6]
+  double* S;                 // per window (6P)^2, upper triangle valid
+  double* bs;                // [NFP*6]
+  double* xp;                // [NFP*6]
+  double* chi_part;          // [n_chunks]
+  double* scale_part;        // [n_chunks]
+  double* dmax_part;         // [n_chunks]
+  double* dmax_pose;         // [NFP]
+  int* n_active;             // [1]
+  // outputs
+  double* out_chi2;          // [NE] caller order
+  unsigned char* out_depth;  // [NE]
+};
+
+// --------------------------------------------------------------------------------------------
+// block-wide deterministic reductions (4 wavefronts of 64)
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum(double v, double* sh4) {
+  v = dev::wave_sum(v);
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sh4[wv] = v;
+  __syncthreads();
+  const double r = (sh4[0] + sh4[1]) + (sh4[2] + sh4[3]);
+  __syncthreads();
+  return r;
+}
+__device__ __forceinline__ double block_max(double v, double* sh4) {
+  v = dev::wave_max(v);
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sh4[wv] = v;
+  __syncthreads();
+  const double r = fmax(fmax(sh4[0], sh4[1]), fmax(sh4[2], sh4[3]));
+  __syncthreads();
+  return r;
+}
+
+// --------------------------------------------------------------------------------------------
+// k_linearize: one block per chunk of consecutive landmarks (<= 256 edges per pass).
+//   mode 0: linearise at the current estimates (windows opening an iteration)
+//   mode 1: residual + robust chi2 only, at the trial estimates (every active window)
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_linearize(BatchView bv, int mode) {
+  __shared__ double sh_c[9 * kChunkEdges];
+  __shared__ double sh4[4];
+  const Chunk ch = bv.chunks[blockIdx.x];
+  const WinDesc& wd = bv.win[ch.win];
+  const LmState& st = bv.lm[ch.win];
+  if (!st.active) return;
+  if (mode == 0 && !st.need_lin) return;
+  const int sel = (mode == 0) ? st.sel : (st.sel ^ 1);
+  const double* poses = bv.pose_state[sel] + (size_t)wd.pose_off * 7;
+  const double* pts = bv.pt_state[sel] + (size_t)wd.pt_off * 3;
+  const double* cams = bv.pose_cam + (size_t)wd.pose_off * 5;
+  const int* lmo = bv.lm_off + wd.lmoff_off;
+  const int tid = threadIdx.x;
+  const int e0 = lmo[ch.lm0], e1 = lmo[ch.lm1];
+  const int nl = ch.lm1 - ch.lm0;
+  double chi_acc = 0.0;
+  double acc[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+  int my_lo = 0, my_hi = 0;
+  if (tid < nl) { my_lo = lmo[ch.lm0 + tid]; my_hi = lmo[ch.lm0 + tid + 1]; }
+
+  for (int base = e0; base < e1; base += kChunkEdges) {
+    const int e = base + tid;
+    double contrib[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) contrib[k] = 0.0;
+    if (e < e1) {
+      const size_t ge = (size_t)wd.edge_off + e;
+      const int ip = bv.e_pose[ge], il = bv.e_point[ge];
+      const int kind = bv.e_kind[ge];
+      const double info = bv.e_info[ge];
+      double qt[7], cam[5], X[3], obs[3], r[3], Xc[3];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) qt[k] = poses[(size_t)ip * 7 + k];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) cam[k] = cams[(size_t)ip * 5 + k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { X[k] = pts[(size_t)il * 3 + k]; obs[k] = bv.e_obs[ge * 3 + k]; }
+      const double chi2 = dev::edge_residual(kind, qt, cam, X, obs, info, r, Xc);
+      double rho0, rho1;
+      dev::huber(chi2, kind == OSH_EDGE_MONO ? wd.huber_mono : wd.huber_stereo, rho0, rho1);
+      chi_acc += rho0;
+      if (mode == 0) {
+        double JX[9], Jp[18];
+        dev::edge_jacobians(kind, qt, cam, Xc, JX, Jp);
+        const double ww = rho1 * info;                       // robustInformation (first order only)
+        const double wr[3] = {-(info * r[0]) * rho1, -(info * r[1]) * rho1, -(info * r[2]) * rho1};
+        // landmark side: upper(JX^T W JX) and JX^T (-rho' Omega r)
+        double AtW[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) AtW[i * 3 + k] = JX[k * 3 + i] * ww;
+        contrib[0] = AtW[0] * JX[0] + AtW[1] * JX[3] + AtW[2] * JX[6];
+        contrib[1] = AtW[0] * JX[1] + AtW[1] * JX[4] + AtW[2] * JX[7];
+        contrib[2] = AtW[0] * JX[2] + AtW[1] * JX[5] + AtW[2] * JX[8];
+        contrib[3] = AtW[3] * JX[1] + AtW[4] * JX[4] + AtW[5] * JX[7];
+        contrib[4] = AtW[3] * JX[2] + AtW[4] * JX[5] + AtW[5] * JX[8];
+        contrib[5] = AtW[6] * JX[2] + AtW[7] * JX[5] + AtW[8] * JX[8];
+        contrib[6] = JX[0] * wr[0] + JX[3] * wr[1] + JX[6] * wr[2];
+        contrib[7] = JX[1] * wr[0] + JX[4] * wr[1] + JX[7] * wr[2];
+        contrib[8] = JX[2] * wr[0] + JX[5] * wr[1] + JX[8] * wr[2];
+        if (ip < wd.P) {
+          // Hpl block = Jp^T W JX  (6x3, pose row x landmark col)
+          double* H = bv.Hpl + ge * 18;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            const double b0 = Jp[i] * ww, b1 = Jp[6 + i] * ww, b2 = Jp[12 + i] * ww;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) H[i * 3 + j] = b0 * JX[j] + b1 * JX[3 + j] + b2 * JX[6 + j];
+          }
+        }
+      }
+    }
+    if (mode == 0) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) sh_c[k * kChunkEdges + tid] = contrib[k];
+      __syncthreads();
+      if (tid < nl) {
+        const int lo = max(my_lo, base), hi = min(my_hi, base + kChunkEdges);
+        for (int x = lo; x < hi; ++x) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) acc[k] += sh_c[k * kChunkEdges + (x - base)];
+        }
+      }
+      __syncthreads();
+    }
+  }
+  double dmax = 0.0;
+  if (mode == 0 && tid < nl) {
+    const size_t gl = (size_t)wd.pt_off + ch.lm0 + tid;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) bv.Hll[gl * 6 + k] = acc[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) bv.bl[gl * 3 + k] = acc[6 + k];
+    dmax = fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5])));
+  }
+  const double chi = block_sum(chi_acc, sh4);
+  if (mode == 0) {
+    const double dm = block_max(dmax, sh4);
+    if (tid == 0) bv.dmax_part[blockIdx.x] = dm;
+  }
+  if (tid == 0) bv.chi_part[blockIdx.x] = chi;
+}
+
+// --------------------------------------------------------------------------------------------
+// k_pose_hess: one wavefront per optimisable pose, lanes stride the pose's edge list.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_pose_hess(BatchView bv) {
+  const int gp = blockIdx.x;
+  const int w = bv.fpose_win[gp];
+  const WinDesc& wd = bv.win[w];
+  const LmState& st = bv.lm[w];
+  if (!st.active || !st.need_lin) return;
+  const int i = gp - wd.fpose_off;
+  const int lane = threadIdx.x;
+  const double* pts = bv.pt_state[st.sel] + (size_t)wd.pt_off * 3;
+  double qt[7], cam[5];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) qt[k] = bv.pose_state[st.sel][((size_t)wd.pose_off + i) * 7 + k];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) cam[k] = bv.pose_cam[((size_t)wd.pose_off + i) * 5 + k];
+  const int* po = bv.pel_off + wd.peloff_off;
+  const int lo = po[i], hi = po[i + 1];
+  double H[21], b[6];
+#pragma unroll
+  for (int k = 0; k < 21; ++k) H[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) b[k] = 0.0;
+  for (int idx = lo + lane; idx < hi; idx += 64) {
+    const int e = bv.pel_edge[(size_t)wd.pel_off + idx];
+    const size_t ge = (size_t)wd.edge_off + e;
+    const int il = bv.e_point[ge];
+    const int kind = bv.e_kind[ge];
+    const double info = bv.e_info[ge];
+    double X[3], obs[3], r[3], Xc[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { X[k] = pts[(size_t)il * 3 + k]; obs[k] = bv.e_obs[ge * 3 + k]; }
+    const double chi2 = dev::edge_residual(kind, qt, cam, X, obs, info, r, Xc);
+    double rho0, rho1;
+    dev::huber(chi2, kind == OSH_EDGE_MONO ? wd.huber_mono : wd.huber_stereo, rho0, rho1);
+    double JX[9], Jp[18];
+    dev::edge_jacobians(kind, qt, cam, Xc, JX, Jp);
+    const double ww = rho1 * info;
+    const double wr[3] = {-(info * r[0]) * rho1, -(info * r[1]) * rho1, -(info * r[2]) * rho1};
+    int m = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const double a0 = Jp[a] * ww, a1 = Jp[6 + a] * ww, a2 = Jp[12 + a] * ww;
+#pragma unroll
+      for (int c = a; c < 6; ++c) { H[m] += a0 * Jp[c] + a1 * Jp[6 + c] + a2 * Jp[12 + c]; ++m; }
+      b[a] += Jp[a] * wr[0] + Jp[6 + a] * wr[1] + Jp[12 + a] * wr[2];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 21; ++k) H[k] = dev::wave_sum(H[k]);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) b[k] = dev::wave_sum(b[k]);
+  if (lane == 0) {
+    double* Ho = bv.Hpp + (size_t)gp * 36;
+    int m = 0;
+    double dm = 0.0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int c = a; c < 6; ++c) {
+        Ho[a * 6 + c] = H[m];
+        Ho[c * 6 + a] = H[m];
+        if (a == c) dm = fmax(dm, fabs(H[m]));
+        ++m;
+      }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) bv.bp[(size_t)gp * 6 + k] = b[k];
+    bv.dmax_pose[gp] = dm;
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// k_schur: one wavefront per pose row i of S.  The 6 x 6P row block lives in LDS; lane
+// (slot s = lane/6, column c = lane%6) owns column c of the 6x6 product for partner edge
+// e+s of the current landmark, so no two lanes touch the same LDS word in one step.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_schur(BatchView bv) {
+  extern __shared__ __attribute__((aligned(16))) double sh_row[];  // [6][n]
+  const int gp = blockIdx.x;
+  const int w = bv.fpose_win[gp];
+  const WinDesc& wd = bv.win[w];
+  const LmState& st = bv.lm[w];
+  if (!st.active) return;
+  const int i = gp - wd.fpose_off;
+  const int n = wd.n;
+  const int lane = threadIdx.x;
+  const double lambda = st.lambda;
+  for (int k = lane; k < 6 * n; k += 64) sh_row[k] = 0.0;
+  __syncthreads();
+  if (lane < 36) {
+    const int r = lane / 6, c = lane % 6;
+    sh_row[r * n + 6 * i + c] = bv.Hpp[(size_t)gp * 36 + lane] + ((r == c) ? lambda : 0.0);  // setLambda on Hpp
+  }
+  __syncthreads();
+  const int* lmo = bv.lm_off + wd.lmoff_off;
+  const int* po = bv.pel_off + wd.peloff_off;
+  const int lo = po[i], hi = po[i + 1];
+  const int slot = lane / 6, col = lane - slot * 6;
+  double ci[6] = {0, 0, 0, 0, 0, 0};
+  for (int idx = lo; idx < hi; ++idx) {
+    const int e = bv.pel_edge[(size_t)wd.pel_off + idx];
+    const size_t ge = (size_t)wd.edge_off + e;
+    const int j = bv.e_point[ge];
+    const size_t gl = (size_t)wd.pt_off + j;
+    const int end = lmo[j] + bv.lm_nfree[gl];  // free-pose edges of landmark j: [lmo[j], end), poses ascending
+    const double* hl = bv.Hll + gl * 6;
+    double Dinv[9];
+    dev::inv3_sym(hl[0] + lambda, hl[1], hl[2], hl[3] + lambda, hl[4], hl[5] + lambda, Dinv);  // setLambda on Hll
+    const double b0 = bv.bl[gl * 3], b1 = bv.bl[gl * 3 + 1], b2 = bv.bl[gl * 3 + 2];
+    const double db0 = Dinv[0] * b0 + Dinv[1] * b1 + Dinv[2] * b2;
+    const double db1 = Dinv[3] * b0 + Dinv[4] * b1 + Dinv[5] * b2;
+    const double db2 = Dinv[6] * b0 + Dinv[7] * b1 + Dinv[8] * b2;
+    const double* Be = bv.Hpl + ge * 18;
+    double BD[18];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const double x0 = Be[r * 3], x1 = Be[r * 3 + 1], x2 = Be[r * 3 + 2];
+      BD[r * 3 + 0] = x0 * Dinv[0] + x1 * Dinv[3] + x2 * Dinv[6];
+      BD[r * 3 + 1] = x0 * Dinv[1] + x1 * Dinv[4] + x2 * Dinv[7];
+      BD[r * 3 + 2] = x0 * Dinv[2] + x1 * Dinv[5] + x2 * Dinv[8];
+      ci[r] += x0 * db0 + x1 * db1 + x2 * db2;
+    }
+    for (int qb = e; qb < end; qb += 10) {
+      const int q = qb + slot;
+      if (slot < 10 && q < end) {
+        const size_t gq = (size_t)wd.edge_off + q;
+        const int i2 = bv.e_pose[gq];
+        const double* Bq = bv.Hpl + gq * 18 + col * 3;
+        const double y0 = Bq[0], y1 = Bq[1], y2 = Bq[2];
+        double* dst = sh_row + 6 * i2 + col;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) dst[r * n] -= BD[r * 3] * y0 + BD[r * 3 + 1] * y1 + BD[r * 3 + 2] * y2;
+      }
+    }
+  }
+  __syncthreads();
+  double* S = bv.S + wd.S_off;
+  for (int c = 6 * i + lane; c < n; c += 64) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) S[(size_t)(6 * i + r) * n + c] = sh_row[r * n + c];
+  }
+  if (lane < 6) {
+    double v = ci[0];
+    if (lane == 1) v = ci[1]; else if (lane == 2) v = ci[2]; else if (lane == 3) v = ci[3];
+    else if (lane == 4) v = ci[4]; else if (lane == 5) v = ci[5];
+    bv.bs[(size_t)gp * 6 + lane] = bv.bp[(size_t)gp * 6 + lane] - v;
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// k_solve: dense blocked LDL^T (no pivoting, upper storage) of the reduced camera system of
+// one window per block, forward elimination fused (rhs carried as an extra column), blocked
+// back-substitution, then the pose update T <- exp(x) T and the pose part of computeScale.
+// LDS: U panel [nb][W] (unscaled rows), L panel [nb][W] (rows / pivot), x [n], d [nb].
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_solve(BatchView bv, int nb, int W) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];   // all LDS scratch is dynamic (16-B aligned base)
+  const int w = blockIdx.x;
+  const WinDesc& wd = bv.win[w];
+  LmState& st = bv.lm[w];
+  if (!st.active) return;
+  const int n = wd.n;
+  const int tid = threadIdx.x;
+  double* U = sh;                    // [nb][W]
+  double* Lp = sh + (size_t)nb * W;  // [nb][W]
+  double* xs = Lp + (size_t)nb * W;  // [W]
+  double* dd = xs + W;               // [nb]
+  double* part = dd + nb;            // [nb]
+  double* sh4 = part + nb;           // [4]
+  int& sh_ok = *reinterpret_cast<int*>(sh4 + 4);
+  double* A = bv.S + wd.S_off;
+  double* rhs = bv.bs + (size_t)wd.fpose_off * 6;
+  if (tid == 0) sh_ok = 1;
+  __syncthreads();
+
+  for (int k0 = 0; k0 < n; k0 += nb) {
+    const int kb = min(nb, n - k0);
+    const int m = n - k0;  // local columns 0..m-1, rhs at local column m
+    for (int idx = tid; idx < kb * (m + 1); idx += kBlock) {
+      const int r = idx / (m + 1), jj = idx - r * (m + 1);
+      double v;
+      if (jj == m) v = rhs[k0 + r];
+      else v = (jj >= r) ? A[(size_t)(k0 + r) * n + k0 + jj] : 0.0;
+      U[r * W + jj] = v;
+    }
+    __syncthreads();
+    // factor the panel rows against each other
+    for (int k = 0; k < kb; ++k) {
+      const double d = U[k * W + k];
+      if (d == 0.0) { if (tid == 0) sh_ok = 0; }
+      const int wc = m - k;  // columns k+1..m
+      const int cnt = (kb - k - 1) * wc;
+      for (int idx = tid; idx < cnt; idx += kBlock) {
+        const int ri = idx / wc, cj = idx - ri * wc;
+        const int ii = k + 1 + ri, jj = k + 1 + cj;
+        if (jj >= ii) U[ii * W + jj] -= (U[k * W + ii] / d) * U[k * W + jj];
+      }
+      __syncthreads();
+    }
+    if (!sh_ok) break;
+    // scaled rows L[k][jj] = U[k][jj] / d_k
+    for (int idx = tid; idx < kb * (m + 1); idx += kBlock) {
+      const int r = idx / (m + 1), jj = idx - r * (m + 1);
+      const double d = U[r * W + r];
+      Lp[r * W + jj] = (jj > r) ? U[r * W + jj] / d : 0.0;
+      if (jj == r) dd[r] = d;
+    }
+    __syncthreads();
+    // trailing update of rows k0+kb .. n-1 (upper part) and of the rhs column
+    const int tr = m - kb;  // trailing rows
+    if (tr > 0) {
+      const int wc = tr + 1;  // columns kb..m (m = rhs)
+      for (int idx = tid; idx < tr * wc; idx += kBlock) {
+        const int ri = idx / wc, cj = idx - ri * wc;
+        const int ii = kb + ri, jj = kb + cj;
+        if (jj < ii) continue;
+        double s = 0.0;
+        for (int k = 0; k < kb; ++k) s += Lp[k * W + ii] * U[k * W + jj];
+        if (jj == m) rhs[k0 + ii] -= s;
+        else A[(size_t)(k0 + ii) * n + k0 + jj] -= s;
+      }
+    }
+    // write the factor back: L rows, pivots on the diagonal, forward-substituted rhs
+    for (int idx = tid; idx < kb * (m + 1); idx += kBlock) {
+      const int r = idx / (m + 1), jj = idx - r * (m + 1);
+      if (jj == m) rhs[k0 + r] = U[r * W + m];
+      else if (jj == r) A[(size_t)(k0 + r) * n + k0 + r] = dd[r];
+      else if (jj > r) A[(size_t)(k0 + r) * n + k0 + jj] = Lp[r * W + jj];
+    }
+    __syncthreads();
+  }
+  const int ok = sh_ok;
+  double* xp = bv.xp + (size_t)wd.fpose_off * 6;
+  if (ok) {
+    // back substitution  L^T x = D^-1 y, panels in reverse
+    const int npanel = (n + nb - 1) / nb;
+    for (int pi = npanel - 1; pi >= 0; --pi) {
+      const int k0 = pi * nb;
+      const int kb = min(nb, n - k0);
+      const int tail0 = k0 + kb;  // x known for indices >= tail0
+      // part[r] = sum_{j>=tail0} L[k0+r][j] x[j] : one wavefront per group of rows
+      const int wv = tid >> 6, lane = tid & 63;
+      for (int r = wv; r < kb; r += 4) {
+        double s = 0.0;
+        const double* row = A + (size_t)(k0 + r) * n;
+        for (int j = tail0 + lane; j < n; j += 64) s += row[j] * xs[j];
+        s = dev::wave_sum(s);
+        if (lane == 0) part[r] = s;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        for (int r = kb - 1; r >= 0; --r) {
+          const double* row = A + (size_t)(k0 + r) * n;
+          double s = rhs[k0 + r] / row[k0 + r] - part[r];
+          for (int j = r + 1; j < kb; ++j) s -= row[k0 + j] * xs[k0 + j];
+          xs[k0 + r] = s;
+        }
+      }
+      __syncthreads();
+    }
+    for (int k = tid; k < n; k += kBlock) xp[k] = xs[k];
+  } else {
+    // zero pivot: LinearSolverEigen::solve returns false; the step is rejected by the controller
+    for (int k = tid; k < n; k += kBlock) { xs[k] = 0.0; xp[k] = 0.0; }
+  }
+  __syncthreads();
+  // pose update into the trial buffer + pose part of computeScale
+  const int cur = st.sel, tr_sel = st.sel ^ 1;
+  const double lambda = st.lambda;
+  double sc = 0.0;
+  for (int i = tid; i < wd.P; i += kBlock) {
+    double u[6], qin[7], qout[7];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) u[k] = xs[6 * i + k];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) qin[k] = bv.pose_state[cur][((size_t)wd.pose_off + i) * 7 + k];
+    dev::pose_oplus(u, qin, qout);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) bv.pose_state[tr_sel][((size_t)wd.pose_off + i) * 7 + k] = qout[k];
+    const double* bpi = bv.bp + ((size_t)wd.fpose_off + i) * 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) sc += u[k] * (lambda * u[k] + bpi[k]);
+  }
+  sc = block_sum(sc, sh4);
+  if (tid == 0) { st.scale_pose = sc; st.solve_ok = ok; }
+}
+
+// --------------------------------------------------------------------------------------------
+// k_backsub: x_l = Dinv (b_l - Hpl^T x_p), X_trial = X + x_l, landmark part of computeScale.
+// Same chunking as k_linearize: lane per edge for the Hpl^T x_p products, lane per landmark
+// for the ordered sum.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_backsub(BatchView bv) {
+  extern __shared__ __attribute__((aligned(16))) double sh_bs[];  // [3*256] partials, [4] reduce, [n] x_p
+  double* sh_c = sh_bs;
+  double* sh4 = sh_bs + 3 * kChunkEdges;
+  double* sh_dyn = sh4 + 4;
+  const Chunk ch = bv.chunks[blockIdx.x];
+  const WinDesc& wd = bv.win[ch.win];
+  const LmState& st = bv.lm[ch.win];
+  if (!st.active) return;
+  const int tid = threadIdx.x;
+  const int n = wd.n;
+  const double* xp = bv.xp + (size_t)wd.fpose_off * 6;
+  for (int k = tid; k < n; k += kBlock) sh_dyn[k] = xp[k];
+  __syncthreads();
+  const int* lmo = bv.lm_off + wd.lmoff_off;
+  const int e0 = lmo[ch.lm0], e1 = lmo[ch.lm1];
+  const int nl = ch.lm1 - ch.lm0;
+  const double lambda = st.lambda;
+  double acc[3] = {0, 0, 0};
+  int my_lo = 0, my_hi = 0;
+  if (tid < nl) { my_lo = lmo[ch.lm0 + tid]; my_hi = lmo[ch.lm0 + tid + 1]; }
+  for (int base = e0; base < e1; base += kChunkEdges) {
+    const int e = base + tid;
+    double c0 = 0, c1 = 0, c2 = 0;
+    if (e < e1) {
+      const size_t ge = (size_t)wd.edge_off + e;
+      const int ip = bv.e_pose[ge];
+      if (ip < wd.P) {
+        const double* B = bv.Hpl + ge * 18;
+        const double* x = sh_dyn + 6 * ip;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          const double mx = -x[r];  // rightMultiply with cp = -xp
+          c0 += B[r * 3] * mx; c1 += B[r * 3 + 1] * mx; c2 += B[r * 3 + 2] * mx;
+        }
+      }
+    }
+    sh_c[tid] = c0; sh_c[kChunkEdges + tid] = c1; sh_c[2 * kChunkEdges + tid] = c2;
+    __syncthreads();
+    if (tid < nl) {
+      const int lo = max(my_lo, base), hi = min(my_hi, base + kChunkEdges);
+      for (int x = lo; x < hi; ++x) {
+        acc[0] += sh_c[x - base]; acc[1] += sh_c[kChunkEdges + x - base]; acc[2] += sh_c[2 * kChunkEdges + x - base];
+      }
+    }
+    __syncthreads();
+  }
+  double sc = 0.0;
+  if (tid < nl) {
+    const size_t gl = (size_t)wd.pt_off + ch.lm0 + tid;
+    const double* hl = bv.Hll + gl * 6;
+    double Dinv[9];
+    dev::inv3_sym(hl[0] + lambda, hl[1], hl[2], hl[3] + lambda, hl[4], hl[5] + lambda, Dinv);
+    const double b0 = bv.bl[gl * 3], b1 = bv.bl[gl * 3 + 1], b2 = bv.bl[gl * 3 + 2];
+    const double c0 = b0 + acc[0], c1 = b1 + acc[1], c2 = b2 + acc[2];
+    double xl[3];
+    if (st.solve_ok) {
+      xl[0] = Dinv[0] * c0 + Dinv[1] * c1 + Dinv[2] * c2;
+      xl[1] = Dinv[3] * c0 + Dinv[4] * c1 + Dinv[5] * c2;
+      xl[2] = Dinv[6] * c0 + Dinv[7] * c1 + Dinv[8] * c2;
+    } else {
+      xl[0] = xl[1] = xl[2] = 0.0;
+    }
+    const double* Xc = bv.pt_state[st.sel] + gl * 3;
+    double* Xt = bv.pt_state[st.sel ^ 1] + gl * 3;
+    Xt[0] = Xc[0] + xl[0]; Xt[1] = Xc[1] + xl[1]; Xt[2] = Xc[2] + xl[2];
+    sc = xl[0] * (lambda * xl[0] + b0) + xl[1] * (lambda * xl[1] + b1) + xl[2] * (lambda * xl[2] + b2);
+  }
+  sc = block_sum(sc, sh4);
+  if (tid == 0) bv.scale_part[blockIdx.x] = sc;
+}
+
+// --------------------------------------------------------------------------------------------
+// k_control: one wavefront per window.
+//   phase 0 (after linearise): open the iteration (currentChi, lambda init).
+//   phase 1 (after the trial residual): gain ratio, accept / reject, stop rules.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_control(BatchView bv, int phase) {
+  const int w = blockIdx.x;
+  const WinDesc& wd = bv.win[w];
+  LmState& st = bv.lm[w];
+  const int lane = threadIdx.x;
+  if (!st.active) return;
+  // robust chi2 of the state evaluated last = sum of the chunk partials (fixed order)
+  double chi = 0.0;
+  for (int c = lane; c < wd.n_chunks; c += 64) chi += bv.chi_part[wd.chunk_off + c];
+  chi = dev::wave_sum(chi);
+  if (phase == 0) {
+    if (!st.need_lin) return;
+    double dm = 0.0;
+    if (st.iter == 0) {
+      for (int c = lane; c < wd.n_chunks; c += 64) dm = fmax(dm, bv.dmax_part[wd.chunk_off + c]);
+      for (int p = lane; p < wd.P; p += 64) dm = fmax(dm, bv.dmax_pose[wd.fpose_off + p]);
+      dm = dev::wave_max(dm);
+    }
+    if (lane == 0) {
+      st.currentChi = chi; st.tempChi = chi; st.iniChi = chi;
+      if (st.iter == 0) {
+        st.chi2_initial = chi;
+        st.lambda = (wd.lambda_init > 0) ? wd.lambda_init : kTau * dm;  // computeLambdaInit
+        st.ni = 2.0; st.nBad = 0;
+      }
+      st.rho = 0.0; st.qmax = 0; st.need_lin = 0;
+      st.last_eval_sel = st.sel;
+    }
+    return;
+  }
+  // ---- phase 1
+  double sc = 0.0;
+  for (int c = lane; c < wd.n_chunks; c += 64) sc += bv.scale_part[wd.chunk_off + c];
+  sc = dev::wave_sum(sc);
+  if (lane != 0) return;
+  double tempChi = chi;
+  if (!st.solve_ok) tempChi = DBL_MAX;
+  st.tempChi = tempChi;
+  st.last_eval_sel = st.sel ^ 1;  // computeActiveErrors just ran on the trial estimates
+  double rho = st.currentChi - tempChi;
+  double scale = st.scale_pose + sc;
+  scale += 1e-3;
+  rho /= scale;
+  if (rho > 0 && isfinite(tempChi)) {
+    double alpha = 1. - pow((2 * rho - 1), 3);
+    alpha = fmin(alpha, 2. / 3.);
+    const double scaleFactor = fmax(1. / 3., alpha);
+    st.lambda *= scaleFactor;
+    st.ni = 2;
+    st.currentChi = tempChi;
+    st.sel ^= 1;  // discardTop: the trial estimates become current
+  } else {
+    st.lambda *= st.ni;
+    st.ni *= 2;  // pop: trial buffer is simply abandoned
+  }
+  st.rho = rho;
+  st.qmax++;
+  st.trials++;
+  const bool again = (rho < 0) && (st.qmax < kMaxTrials) && !st.stop;
+  if (!again) {
+    // the iteration is over
+    st.iterations++;
+    if (st.n_trace < OSH_LBA_MAX_TRACE) {
+      st.chi2_trace[st.n_trace] = st.currentChi;
+      st.lambda_trace[st.n_trace] = st.lambda;
+      st.trials_trace[st.n_trace] = st.qmax;
+      st.n_trace++;
+    }
+    bool ok = true;
+    if (st.qmax == kMaxTrials || rho == 0) ok = false;  // Terminate
+    else {
+      if ((st.iniChi - st.currentChi) * 1e3 < st.iniChi) st.nBad++; else st.nBad = 0;  // Raul's stop
+      if (st.nBad >= 3) ok = false;
+    }
+    st.iter++;
+    if (!ok || st.iter >= wd.max_iter || st.stop) st.active = 0;
+    else st.need_lin = 1;
+  }
+  if (st.active) atomicAdd(bv.n_active, 1);
+}
+
+// reset the controller before optimize()
+__global__ void k_reset(BatchView bv, const unsigned char* stop) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= bv.n_windows) return;
+  const WinDesc& wd = bv.win[w];
+  LmState& st = bv.lm[w];
+  st.lambda = -1.0; st.ni = 2.0; st.currentChi = 0; st.iniChi = 0; st.tempChi = 0; st.rho = 0; st.scale_pose = 0;
+  st.chi2_initial = 0;
+  st.iter = 0; st.qmax = 0; st.nBad = 0;
+  st.stop = stop ? stop[w] : 0;
+  st.active = (wd.max_iter > 0 && !st.stop && wd.E > 0) ? 1 : 0;
+  st.need_lin = st.active;
+  st.sel = 0; st.last_eval_sel = 0; st.iterations = 0; st.trials = 0; st.solve_ok = 1; st.n_trace = 0;
+  if (st.active) atomicAdd(bv.n_active, 1);
+}
+
+__global__ void k_set_stop(BatchView bv, const unsigned char* stop) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= bv.n_windows) return;
+  bv.lm[w].stop = stop[w];
+}
+
+// --------------------------------------------------------------------------------------------
+// k_finalize: per-edge chi2 of the LAST evaluated errors (stale after a rejected final trial,
+// levenberg.cpp:123-147) and isDepthPositive from the FINAL estimates (Optimizer.cc:1425).
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_finalize(BatchView bv) {
+  const Chunk ch = bv.chunks[blockIdx.x];
+  const WinDesc& wd = bv.win[ch.win];
+  const LmState& st = bv.lm[ch.win];
+  const int* lmo = bv.lm_off + wd.lmoff_off;
+  const int e0 = lmo[ch.lm0], e1 = lmo[ch.lm1];
+  const bool evaluated = st.iterations > 0;
+  for (int e = e0 + threadIdx.x; e < e1; e += kBlock) {
+    const size_t ge = (size_t)wd.edge_off + e;
+    const int ip = bv.e_pose[ge], il = bv.e_point[ge];
+    const int kind = bv.e_kind[ge];
+    double qt[7], cam[5], X[3], obs[3], r[3], Xc[3];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) cam[k] = bv.pose_cam[((size_t)wd.pose_off + ip) * 5 + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) obs[k] = bv.e_obs[ge * 3 + k];
+    double chi2 = 0.0;
+    if (evaluated) {
+      const int s = st.last_eval_sel;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) qt[k] = bv.pose_state[s][((size_t)wd.pose_off + ip) * 7 + k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) X[k] = bv.pt_state[s][((size_t)wd.pt_off + il) * 3 + k];
+      chi2 = dev::edge_residual(kind, qt, cam, X, obs, bv.e_info[ge], r, Xc);
+    }
+    const int f = st.sel;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) qt[k] = bv.pose_state[f][((size_t)wd.pose_off + ip) * 7 + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) X[k] = bv.pt_state[f][((size_t)wd.pt_off + il) * 3 + k];
+    double rot[3];
+    dev::quat_rotate(qt, X, rot);
+    const size_t go = (size_t)wd.edge_off + bv.e_orig[ge];
+    bv.out_chi2[go] = chi2;
+    bv.out_depth[go] = (rot[2] + qt[6] > 0.0) ? 1 : 0;
+  }
+}
+
+}  // namespace osh
+
+// =============================================================================================
+// Host driver
+// =============================================================================================
+using namespace osh;
+
+struct osh_lba_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  KernelTimer timer;
+  // host-side batch description
+  int n_windows = 0;
+  std::vector<WinDesc> h_win;
+  std::vector<const volatile unsigned char*> stop_ptr;
+  bool any_stop = false;
+  size_t NP = 0, NFP = 0, NL = 0, NE = 0, NEf = 0, n_chunks = 0;
+  size_t S_total = 0;
+  int n_max = 0, solve_nb = 24, solve_W = 0;
+  size_t solve_lds = 0, schur_lds = 0, backsub_lds = 0;
+  // device buffers
+  DevBuf d_win, d_lm, d_chunks, d_fpose_win, d_pose_init, d_pose[2], d_pt_init, d_pt[2], d_cam;
+  DevBuf d_e_pose, d_e_point, d_e_kind, d_e_obs, d_e_info, d_e_orig, d_lm_off, d_lm_nfree, d_pel_off, d_pel_edge;
+  DevBuf d_Hpl, d_Hll, d_bl, d_Hpp, d_bp, d_S, d_bs, d_xp, d_chi, d_scale, d_dmaxc, d_dmaxp, d_nactive, d_out_chi2, d_out_depth, d_stop;
+  int* h_nactive = nullptr;          // pinned
+  unsigned char* h_stop = nullptr;   // pinned [n_windows]
+  size_t h_stop_cap = 0;
+  std::vector<int> h_e_orig;         // for debug export
+  BatchView bv{};
+  bool optimized = false;
+};
+
+static int launch_check(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("kernel launch %s failed: %s", what, hipGetErrorString(e)); return OSH_ERR_DEVICE; }
+  return OSH_OK;
+}
+
+#define OSH_TRY(expr) do { int _rc = (expr); if (_rc != OSH_OK) return _rc; } while (0)
+
+extern "C" int osh_lba_create(int device, osh_lba_ctx** out) {
+  if (!out) { set_error("osh_lba_create: out is NULL"); return OSH_ERR_INVALID; }
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_error("no HIP device visible"); return OSH_ERR_NO_DEVICE; }
+  if (device < 0 || device >= n) { set_error("device %d out of range (have %d)", device, n); return OSH_ERR_INVALID; }
+  OSH_HIP(hipSetDevice(device));
+  osh_lba_ctx* c = new osh_lba_ctx();
+  c->device = device;
+  OSH_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  OSH_HIP(hipHostMalloc((void**)&c->h_nactive, sizeof(int)));
+  *out = c;
+  return OSH_OK;
+}
+
+extern "C" void osh_lba_destroy(osh_lba_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  DevBuf* bufs[] = {&c->d_win, &c->d_lm, &c->d_chunks, &c->d_fpose_win, &c->d_pose_init, &c->d_pose[0], &c->d_pose[1],
+                    &c->d_pt_init, &c->d_pt[0], &c->d_pt[1], &c->d_cam, &c->d_e_pose, &c->d_e_point, &c->d_e_kind,
+                    &c->d_e_obs, &c->d_e_info, &c->d_e_orig, &c->d_lm_off, &c->d_lm_nfree, &c->d_pel_off, &c->d_pel_edge,
+                    &c->d_Hpl, &c->d_Hll, &c->d_bl, &c->d_Hpp, &c->d_bp, &c->d_S, &c->d_bs, &c->d_xp, &c->d_chi,
+                    &c->d_scale, &c->d_dmaxc, &c->d_dmaxp, &c->d_nactive, &c->d_out_chi2, &c->d_out_depth, &c->d_stop};
+  for (DevBuf* b : bufs) b->release();
+  c->timer.destroy();
+  if (c->h_nactive) (void)hipHostFree(c->h_nactive);
+  if (c->h_stop) (void)hipHostFree(c->h_stop);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+template <class T>
+static int upload_vec(DevBuf& b, const std::vector<T>& v, hipStream_t s) {
+  OSH_TRY(b.reserve(std::max<size_t>(v.size(), 1) * sizeof(T)));
+  if (!v.empty()) OSH_HIP(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+  return OSH_OK;
+}
+
+extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem* pr) {
+  if (!c || nw <= 0 || !pr) { set_error("osh_lba_upload: bad arguments"); return OSH_ERR_INVALID; }
+  OSH_HIP(hipSetDevice(c->device));
+  OSH_HIP(hipStreamSynchronize(c->stream));
+  c->optimized = false;
+  c->n_windows = nw;
+  c->h_win.assign(nw, WinDesc{});
+  c->stop_ptr.assign(nw, nullptr);
+  c->any_stop = false;
+  size_t NP = 0, NFP = 0, NL = 0, NE = 0, NEf = 0, NLO = 0, NPO = 0, S_total = 0;
+  int n_max = 0;
+  // ---- pass 1: validate + offsets
+  for (int w = 0; w < nw; ++w) {
+    const osh_lba_problem& p = pr[w];
+    if (p.n_free < 0 || p.n_fixed < 0 || p.n_points < 0 || p.n_edges < 0 ||
+        (p.n_edges > 0 && (!p.edge_pose || !p.edge_point || !p.edge_kind || !p.edge_obs || !p.edge_info)) ||
+        ((p.n_free + p.n_fixed) > 0 && (!p.pose_qt || !p.pose_cam)) || (p.n_points > 0 && !p.points)) {
+      set_error("window %d: negative size or NULL array", w);
+      return OSH_ERR_INVALID;
+    }
+    if (p.max_iterations > OSH_LBA_MAX_TRACE) { set_error("window %d: max_iterations > %d", w, OSH_LBA_MAX_TRACE); return OSH_ERR_INVALID; }
+    WinDesc& d = c->h_win[w];
+    d.P = p.n_free; d.F = p.n_fixed; d.L = p.n_points; d.E = p.n_edges;
+    d.pose_off = (int)NP; d.fpose_off = (int)NFP; d.pt_off = (int)NL; d.edge_off = (int)NE;
+    d.lmoff_off = (int)NLO; d.peloff_off = (int)NPO; d.pel_off = (int)NEf;
+    d.n = 6 * p.n_free; d.max_iter = p.max_iterations; d.S_off = (long long)S_total;
+    d.huber_mono = p.huber_mono; d.huber_stereo = p.huber_stereo; d.lambda_init = p.lambda_init;
+    c->stop_ptr[w] = p.stop_flag;
+    if (p.stop_flag) c->any_stop = true;
+    NP += (size_t)p.n_free + p.n_fixed; NFP += p.n_free; NL += p.n_points; NE += p.n_edges;
+    NLO += (size_t)p.n_points + 1; NPO += (size_t)p.n_free + 1;
+    S_total += (size_t)d.n * d.n;
+    n_max = std::max(n_max, d.n);
+    size_t nfree_e = 0;
+    for (int e = 0; e < p.n_edges; ++e) {
+      const int ip = p.edge_pose[e], il = p.edge_point[e];
+      if (ip < 0 || ip >= p.n_free + p.n_fixed || il < 0 || il >= p.n_points || p.edge_kind[e] > OSH_EDGE_STEREO) {
+        set_error("window %d edge %d: index or kind out of range", w, e);
+        return OSH_ERR_INVALID;
+      }
+      if (ip < p.n_free) ++nfree_e;
+    }
+    NEf += nfree_e;
+  }
+  if (NP > 0x7fffff00u || NL > 0x7fffff00u || NE > 0x7fffff00u) { set_error("batch too large for 32-bit offsets"); return OSH_ERR_UNSUPPORTED; }
+  c->NP = NP; c->NFP = NFP; c->NL = NL; c->NE = NE; c->NEf = NEf; c->S_total = S_total; c->n_max = n_max;
+
+  // ---- pass 2: build sorted structure
+  std::vector<double> h_pose(NP * 7), h_cam(NP * 5), h_pt(NL * 3), h_obs(NE * 3), h_info(NE);
+  std::vector<int> h_epose(NE), h_epoint(NE), h_eorig(NE), h_lmoff(NLO), h_lmnfree(NL), h_peloff(NPO), h_pel(NEf), h_fpw(NFP);
+  std::vector<unsigned char> h_kind(NE);
+  std::vector<Chunk> h_chunks;
+  std::vector<int> cnt, fill, order;
+  for (int w = 0; w < nw; ++w) {
+    const osh_lba_problem& p = pr[w];
+    WinDesc& d = c->h_win[w];
+    const int NPw = p.n_free + p.n_fixed;
+    for (int i = 0; i < NPw; ++i) {
+      double q[4] = {p.pose_qt[7 * i], p.pose_qt[7 * i + 1], p.pose_qt[7 * i + 2], p.pose_qt[7 * i + 3]};
+      // g2o::SE3Quat(q,t) constructor: normalizeRotation (se3quat.h:61-63,280-285)
+      if (q[3] < 0) { q[0] *= -1; q[1] *= -1; q[2] *= -1; q[3] *= -1; }
+      const double nrm = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+      double* o = &h_pose[((size_t)d.pose_off + i) * 7];
+      for (int k = 0; k < 4; ++k) o[k] = q[k] / nrm;
+      for (int k = 0; k < 3; ++k) o[4 + k] = p.pose_qt[7 * i + 4 + k];
+      for (int k = 0; k < 5; ++k) h_cam[((size_t)d.pose_off + i) * 5 + k] = p.pose_cam[5 * i + k];
+    }
+    if (p.n_points) std::memcpy(&h_pt[(size_t)d.pt_off * 3], p.points, sizeof(double) * 3 * p.n_points);
+    for (int i = 0; i < p.n_free; ++i) h_fpw[(size_t)d.fpose_off + i] = w;
+    // counting sort by landmark (stable), then order poses inside each landmark
+    cnt.assign((size_t)p.n_points + 1, 0);
+    for (int e = 0; e < p.n_edges; ++e) cnt[p.edge_point[e] + 1]++;
+    for (int j = 0; j < p.n_points; ++j) cnt[j + 1] += cnt[j];
+    fill.assign(cnt.begin(), cnt.end() - 1);
+    order.resize(p.n_edges);
+    for (int e = 0; e < p.n_edges; ++e) order[fill[p.edge_point[e]]++] = e;
+    int* lmo = &h_lmoff[d.lmoff_off];
+    for (int j = 0; j <= p.n_points; ++j) lmo[j] = cnt[j];
+    for (int j = 0; j < p.n_points; ++j) {
+      int lo = cnt[j], hi = cnt[j + 1];
+      std::stable_sort(order.begin() + lo, order.begin() + hi, [&](int a, int b) { return p.edge_pose[a] < p.edge_pose[b]; });
+      int nf = 0;
+      for (int x = lo; x < hi; ++x) {
+        if (p.edge_pose[order[x]] < p.n_free) ++nf;
+        if (x > lo && p.edge_pose[order[x]] == p.edge_pose[order[x - 1]]) {
+          set_error("window %d: landmark %d is observed twice by pose %d (two edges on one Hessian block); "
+                    "not supported by the device path yet", w, j, p.edge_pose[order[x]]);
+          return OSH_ERR_UNSUPPORTED;
+        }
+      }
+      h_lmnfree[(size_t)d.pt_off + j] = nf;
+    }
+    for (int x = 0; x < p.n_edges; ++x) {
+      const int e = order[x];
+      const size_t g = (size_t)d.edge_off + x;
+      h_epose[g] = p.edge_pose[e]; h_epoint[g] = p.edge_point[e]; h_kind[g] = p.edge_kind[e]; h_eorig[g] = e;
+      h_info[g] = p.edge_info[e];
+      for (int k = 0; k < 3; ++k) h_obs[g * 3 + k] = p.edge_obs[3 * e + k];
+    }
+    // per-pose edge lists (landmark order)
+    int* po = &h_peloff[d.peloff_off];
+    for (int i = 0; i <= p.n_free; ++i) po[i] = 0;
+    for (int x = 0; x < p.n_edges; ++x) { const int ip = h_epose[(size_t)d.edge_off + x]; if (ip < p.n_free) po[ip + 1]++; }
+    for (int i = 0; i < p.n_free; ++i) po[i + 1] += po[i];
+    fill.assign(po, po + p.n_free);
+    for (int x = 0; x < p.n_edges; ++x) {
+      const int ip = h_epose[(size_t)d.edge_off + x];
+      if (ip < p.n_free) h_pel[(size_t)d.pel_off + fill[ip]++] = x;
+    }
+    // chunks: consecutive landmarks, <= kChunkEdges edges and <= kBlock landmarks (a single
+    // landmark with more edges gets its own multi-pass chunk)
+    d.chunk_off = (int)h_chunks.size();
+    int j = 0;
+    while (j < p.n_points) {
+      int j1 = j + 1;
+      while (j1 < p.n_points && (j1 - j) < kBlock && (lmo[j1 + 1] - lmo[j]) <= kChunkEdges) ++j1;
+      h_chunks.push_back(Chunk{w, j, j1});
+      j = j1;
+    }
+    d.n_chunks = (int)h_chunks.size() - d.chunk_off;
+  }
+  c->n_chunks = h_chunks.size();
+  c->h_e_orig = h_eorig;
+
+  // ---- LDS budgets
+  c->schur_lds = (size_t)6 * n_max * sizeof(double);
+  c->backsub_lds = (size_t)(3 * kChunkEdges + 4 + std::max(n_max, 1)) * sizeof(double);
+  {
+    const size_t budget = 150 * 1024;
+    int nb = 24;
+    auto need = [&](int b) { return ((size_t)2 * b * (n_max + 2) + (n_max + 2) + 2 * b + 8) * sizeof(double); };
+    while (nb > 6 && need(nb) > budget) nb -= 6;
+    if (need(nb) > budget || c->schur_lds > budget) {
+      set_error("window with %d optimisable poses exceeds the LDS budget of the reduced-system kernels", n_max / 6);
+      return OSH_ERR_UNSUPPORTED;
+    }
+    c->solve_nb = nb;
+    c->solve_W = n_max + 2;
+    c->solve_lds = need(nb);
+  }
+
+  // ---- device copies
+  hipStream_t s = c->stream;
+  OSH_TRY(upload_vec(c->d_win, c->h_win, s));
+  OSH_TRY(upload_vec(c->d_chunks, h_chunks, s));
+  OSH_TRY(upload_vec(c->d_fpose_win, h_fpw, s));
+  OSH_TRY(upload_vec(c->d_pose_init, h_pose, s));
+  OSH_TRY(upload_vec(c->d_pt_init, h_pt, s));
+  OSH_TRY(upload_vec(c->d_cam, h_cam, s));
+  OSH_TRY(upload_vec(c->d_e_pose, h_epose, s));
+  OSH_TRY(upload_vec(c->d_e_point, h_epoint, s));
+  OSH_TRY(upload_vec(c->d_e_kind, h_kind, s));
+  OSH_TRY(upload_vec(c->d_e_obs, h_obs, s));
+  OSH_TRY(upload_vec(c->d_e_info, h_info, s));
+  OSH_TRY(upload_vec(c->d_e_orig, h_eorig, s));
+  OSH_TRY(upload_vec(c->d_lm_off, h_lmoff, s));
+  OSH_TRY(upload_vec(c->d_lm_nfree, h_lmnfree, s));
+  OSH_TRY(upload_vec(c->d_pel_off, h_peloff, s));
+  OSH_TRY(upload_vec(c->d_pel_edge, h_pel, s));
+  auto R = [&](DevBuf& b, size_t bytes) { return b.reserve(std::max<size_t>(bytes, 8)); };
+  OSH_TRY(R(c->d_lm, nw * sizeof(LmState)));
+  for (int k = 0; k < 2; ++k) { OSH_TRY(R(c->d_pose[k], NP * 7 * 8)); OSH_TRY(R(c->d_pt[k], NL * 3 * 8)); }
+  OSH_TRY(R(c->d_Hpl, NE * 18 * 8)); OSH_TRY(R(c->d_Hll, NL * 6 * 8)); OSH_TRY(R(c->d_bl, NL * 3 * 8));
+  OSH_TRY(R(c->d_Hpp, NFP * 36 * 8)); OSH_TRY(R(c->d_bp, NFP * 6 * 8)); OSH_TRY(R(c->d_S, S_total * 8));
+  OSH_TRY(R(c->d_bs, NFP * 6 * 8)); OSH_TRY(R(c->d_xp, NFP * 6 * 8));
+  OSH_TRY(R(c->d_chi, c->n_chunks * 8)); OSH_TRY(R(c->d_scale, c->n_chunks * 8)); OSH_TRY(R(c->d_dmaxc, c->n_chunks * 8));
+  OSH_TRY(R(c->d_dmaxp, NFP * 8)); OSH_TRY(R(c->d_nactive, sizeof(int)));
+  OSH_TRY(R(c->d_out_chi2, NE * 8)); OSH_TRY(R(c->d_out_depth, NE)); OSH_TRY(R(c->d_stop, nw));
+  if (c->h_stop_cap < (size_t)nw) {
+    if (c->h_stop) (void)hipHostFree(c->h_stop);
+    OSH_HIP(hipHostMalloc((void**)&c->h_stop, nw));
+    c->h_stop_cap = nw;
+  }
+  OSH_HIP(hipMemsetAsync(c->d_xp.p, 0, std::max<size_t>(NFP * 6 * 8, 8), s));
+  OSH_HIP(hipMemsetAsync(c->d_Hpl.p, 0, std::max<size_t>(NE * 18 * 8, 8), s));
+
+  BatchView& bv = c->bv;
+  bv.n_windows = nw; bv.n_chunks = (int)c->n_chunks; bv.n_fposes = (int)NFP;
+  bv.win = c->d_win.as<WinDesc>(); bv.lm = c->d_lm.as<LmState>(); bv.chunks = c->d_chunks.as<Chunk>();
+  bv.fpose_win = c->d_fpose_win.as<int>();
+  for (int k = 0; k < 2; ++k) { bv.pose_state[k] = c->d_pose[k].as<double>(); bv.pt_state[k] = c->d_pt[k].as<double>(); }
+  bv.pose_cam = c->d_cam.as<double>();
+  bv.e_pose = c->d_e_pose.as<int>(); bv.e_point = c->d_e_point.as<int>(); bv.e_kind = c->d_e_kind.as<unsigned char>();
+  bv.e_obs = c->d_e_obs.as<double>(); bv.e_info = c->d_e_info.as<double>(); bv.e_orig = c->d_e_orig.as<int>();
+  bv.lm_off = c->d_lm_off.as<int>(); bv.lm_nfree = c->d_lm_nfree.as<int>();
+  bv.pel_off = c->d_pel_off.as<int>(); bv.pel_edge = c->d_pel_edge.as<int>();
+  bv.Hpl = c->d_Hpl.as<double>(); bv.Hll = c->d_Hll.as<double>(); bv.bl = c->d_bl.as<double>();
+  bv.Hpp = c->d_Hpp.as<double>(); bv.bp = c->d_bp.as<double>(); bv.S = c->d_S.as<double>();
+  bv.bs = c->d_bs.as<double>(); bv.xp = c->d_xp.as<double>();
+  bv.chi_part = c->d_chi.as<double>(); bv.scale_part = c->d_scale.as<double>();
+  bv.dmax_part = c->d_dmaxc.as<double>(); bv.dmax_pose = c->d_dmaxp.as<double>();
+  bv.n_active = c->d_nactive.as<int>();
+  bv.out_chi2 = c->d_out_chi2.as<double>(); bv.out_depth = c->d_out_depth.as<unsigned char>();
+  OSH_HIP(hipStreamSynchronize(s));
+
+  // opt in to large dynamic LDS once per process
+  static bool attr_done = false;
+  if (!attr_done) {
+    OSH_HIP(hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    OSH_HIP(hipFuncSetAttribute((const void*)k_schur, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    OSH_HIP(hipFuncSetAttribute((const void*)k_backsub, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    attr_done = true;
+  }
+  return OSH_OK;
+}
+
+static bool snapshot_stop(osh_lba_ctx* c) {
+  bool any = false;
+  for (int w = 0; w < c->n_windows; ++w) {
+    const volatile unsigned char* f = c->stop_ptr[w];
+    c->h_stop[w] = (f && *f) ? 1 : 0;
+    any |= c->h_stop[w] != 0;
+  }
+  return any;
+}
+
+#define LAUNCH(kid, name, grid, block, lds, ...)                                              \
+  do {                                                                                        \
+    if ((grid) > 0) {                                                                         \
+      const bool _t = c->timer.begin(kid, s);                                                 \
+      hipLaunchKernelGGL(name, dim3((unsigned)(grid)), dim3(block), (lds), s, __VA_ARGS__);   \
+      if (_t) c->timer.end(s);                                                                \
+      OSH_TRY(launch_check(#name));                                                           \
+    }                                                                                         \
+  } while (0)
+
+static int reset_state(osh_lba_ctx* c) {
+  hipStream_t s = c->stream;
+  for (int k = 0; k < 2; ++k) {
+    if (c->NP) OSH_HIP(hipMemcpyAsync(c->d_pose[k].p, c->d_pose_init.p, c->NP * 7 * 8, hipMemcpyDeviceToDevice, s));
+    if (c->NL) OSH_HIP(hipMemcpyAsync(c->d_pt[k].p, c->d_pt_init.p, c->NL * 3 * 8, hipMemcpyDeviceToDevice, s));
+  }
+  OSH_HIP(hipMemsetAsync(c->d_nactive.p, 0, sizeof(int), s));
+  const unsigned char* dstop = nullptr;
+  if (c->any_stop) {
+    snapshot_stop(c);
+    OSH_HIP(hipMemcpyAsync(c->d_stop.p, c->h_stop, c->n_windows, hipMemcpyHostToDevice, s));
+    dstop = c->d_stop.as<unsigned char>();
+  }
+  hipLaunchKernelGGL(k_reset, dim3((c->n_windows + 63) / 64), dim3(64), 0, s, c->bv, dstop);
+  OSH_TRY(launch_check("k_reset"));
+  return OSH_OK;
+}
+
+static int read_nactive(osh_lba_ctx* c, int* out) {
+  OSH_HIP(hipMemcpyAsync(c->h_nactive, c->d_nactive.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  OSH_HIP(hipStreamSynchronize(c->stream));
+  *out = *c->h_nactive;
+  return OSH_OK;
+}
+
+extern "C" int osh_lba_optimize(osh_lba_ctx* c) {
+  if (!c || c->n_windows <= 0) { set_error("osh_lba_optimize: nothing uploaded"); return OSH_ERR_INVALID; }
+  OSH_HIP(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  if (c->timer.enabled) OSH_TRY(c->timer.init());
+  OSH_TRY(reset_state(c));
+  int n_active = 0;
+  OSH_TRY(read_nactive(c, &n_active));
+  int max_iter = 0;
+  for (const WinDesc& d : c->h_win) max_iter = std::max(max_iter, d.max_iter);
+  const long max_rounds = (long)max_iter * kMaxTrials + 1;
+  for (long round = 0; round < max_rounds && n_active > 0; ++round) {
+    LAUNCH(OSH_K_LINEARIZE, k_linearize, c->n_chunks, kBlock, 0, c->bv, 0);
+    LAUNCH(OSH_K_POSE_HESS, k_pose_hess, c->NFP, 64, 0, c->bv);
+    LAUNCH(OSH_K_CONTROL, k_control, c->n_windows, 64, 0, c->bv, 0);
+    LAUNCH(OSH_K_SCHUR, k_schur, c->NFP, 64, c->schur_lds, c->bv);
+    LAUNCH(OSH_K_SOLVE, k_solve, c->n_windows, kBlock, c->solve_lds, c->bv, c->solve_nb, c->solve_W);
+    LAUNCH(OSH_K_BACKSUB, k_backsub, c->n_chunks, kBlock, c->backsub_lds, c->bv);
+    LAUNCH(OSH_K_RESIDUAL, k_linearize, c->n_chunks, kBlock, 0, c->bv, 1);
+    if (c->any_stop) {
+      // terminate() is polled after every trial (levenberg.cpp:149) and before every iteration
+      snapshot_stop(c);
+      OSH_HIP(hipMemcpyAsync(c->d_stop.p, c->h_stop, c->n_windows, hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(k_set_stop, dim3((c->n_windows + 63) / 64), dim3(64), 0, s, c->bv, c->d_stop.as<unsigned char>());
+      OSH_TRY(launch_check("k_set_stop"));
+    }
+    OSH_HIP(hipMemsetAsync(c->d_nactive.p, 0, sizeof(int), s));
+    LAUNCH(OSH_K_CONTROL, k_control, c->n_windows, 64, 0, c->bv, 1);
+    OSH_TRY(read_nactive(c, &n_active));
+    if (c->timer.enabled) c->timer.collect();
+  }
+  if (c->n_chunks) {
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)c->n_chunks), dim3(kBlock), 0, s, c->bv);
+    OSH_TRY(launch_check("k_finalize"));
+  }
+  OSH_HIP(hipStreamSynchronize(s));
+  if (c->timer.enabled) c->timer.collect();
+  c->optimized = true;
+  return OSH_OK;
+}
+
+extern "C" int osh_lba_download(osh_lba_ctx* c, int32_t nw, osh_lba_result* res) {
+  if (!c || !res || nw != c->n_windows) { set_error("osh_lba_download: bad arguments"); return OSH_ERR_INVALID; }
+  if (!c->optimized) { set_error("osh_lba_download: call osh_lba_optimize first"); return OSH_ERR_INVALID; }
+  OSH_HIP(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  std::vector<LmState> h_lm(nw);
+  OSH_HIP(hipMemcpyAsync(h_lm.data(), c->d_lm.p, nw * sizeof(LmState), hipMemcpyDeviceToHost, s));
+  OSH_HIP(hipStreamSynchronize(s));
+  for (int w = 0; w < nw; ++w) {
+    const WinDesc& d = c->h_win[w];
+    const LmState& st = h_lm[w];
+    osh_lba_result& r = res[w];
+    const int sel = st.sel;
+    if (r.pose_qt && d.P) OSH_HIP(hipMemcpyAsync(r.pose_qt, c->d_pose[sel].as<double>() + (size_t)d.pose_off * 7, (size_t)d.P * 7 * 8, hipMemcpyDeviceToHost, s));
+    if (r.points && d.L) OSH_HIP(hipMemcpyAsync(r.points, c->d_pt[sel].as<double>() + (size_t)d.pt_off * 3, (size_t)d.L * 3 * 8, hipMemcpyDeviceToHost, s));
+    if (r.edge_chi2 && d.E) OSH_HIP(hipMemcpyAsync(r.edge_chi2, c->d_out_chi2.as<double>() + d.edge_off, (size_t)d.E * 8, hipMemcpyDeviceToHost, s));
+    if (r.edge_depth_pos && d.E) OSH_HIP(hipMemcpyAsync(r.edge_depth_pos, c->d_out_depth.as<unsigned char>() + d.edge_off, (size_t)d.E, hipMemcpyDeviceToHost, s));
+    r.status = OSH_OK; r.iterations = st.iterations; r.trials = st.trials; r.n_trace = st.n_trace;
+    r.chi2_initial = st.chi2_initial;
+    for (int k = 0; k < st.n_trace; ++k) { r.chi2_trace[k] = st.chi2_trace[k]; r.lambda_trace[k] = st.lambda_trace[k]; r.trials_trace[k] = st.trials_trace[k]; }
+  }
+  OSH_HIP(hipStreamSynchronize(s));
+  return OSH_OK;
+}
+
+extern "C" int osh_lba_solve(osh_lba_ctx* c, int32_t nw, const osh_lba_problem* pr, osh_lba_result* res) {
+  OSH_TRY(osh_lba_upload(c, nw, pr));
+  OSH_TRY(osh_lba_optimize(c));
+  return osh_lba_download(c, nw, res);
+}
+
+// Debug / parity aid: one linearisation of `window` at the uploaded estimates.
+extern "C" int osh_lba_linearize(osh_lba_ctx* c, int32_t window, double* Hpp, double* bp, double* Hll, double* bl,
+                                 double* Hpl, double* chi2, double* robust_chi2) {
+  if (!c || window < 0 || window >= c->n_windows) { set_error("osh_lba_linearize: bad window"); return OSH_ERR_INVALID; }
+  OSH_HIP(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  OSH_TRY(reset_state(c));
+  hipLaunchKernelGGL(k_linearize, dim3((unsigned)c->n_chunks), dim3(kBlock), 0, s, c->bv, 0);
+  OSH_TRY(launch_check("k_linearize"));
+  if (c->NFP) { hipLaunchKernelGGL(k_pose_hess, dim3((unsigned)c->NFP), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_pose_hess")); }
+  hipLaunchKernelGGL(k_control, dim3((unsigned)c->n_windows), dim3(64), 0, s, c->bv, 0);
+  OSH_TRY(launch_check("k_control"));
+  // per-edge chi2 through k_finalize needs "evaluated" semantics: emulate by a residual pass bookkeeping
+  OSH_HIP(hipStreamSynchronize(s));
+  const WinDesc& d = c->h_win[window];
+  std::vector<LmState> h_lm(c->n_windows);
+  OSH_HIP(hipMemcpy(h_lm.data(), c->d_lm.p, c->n_windows * sizeof(LmState), hipMemcpyDeviceToHost));
+  if (robust_chi2) *robust_chi2 = h_lm[window].chi2_initial;
+  if (Hpp && d.P) OSH_HIP(hipMemcpy(Hpp, c->d_Hpp.as<double>() + (size_t)d.fpose_off * 36, (size_t)d.P * 36 * 8, hipMemcpyDeviceToHost));
+  if (bp && d.P) OSH_HIP(hipMemcpy(bp, c->d_bp.as<double>() + (size_t)d.fpose_off * 6, (size_t)d.P * 6 * 8, hipMemcpyDeviceToHost));
+  if (bl && d.L) OSH_HIP(hipMemcpy(bl, c->d_bl.as<double>() + (size_t)d.pt_off * 3, (size_t)d.L * 3 * 8, hipMemcpyDeviceToHost));
+  if (Hll && d.L) {
+    std::vector<double> up((size_t)d.L * 6);
+    OSH_HIP(hipMemcpy(up.data(), c->d_Hll.as<double>() + (size_t)d.pt_off * 6, up.size() * 8, hipMemcpyDeviceToHost));
+    for (int j = 0; j < d.L; ++j) {
+      const double* u = &up[(size_t)j * 6];
+      double* o = Hll + (size_t)j * 9;
+      o[0] = u[0]; o[1] = u[1]; o[2] = u[2]; o[3] = u[1]; o[4] = u[3]; o[5] = u[4]; o[6] = u[2]; o[7] = u[4]; o[8] = u[5];
+    }
+  }
+  if (Hpl && d.E) {
+    std::vector<double> hs((size_t)d.E * 18);
+    OSH_HIP(hipMemcpy(hs.data(), c->d_Hpl.as<double>() + (size_t)d.edge_off * 18, hs.size() * 8, hipMemcpyDeviceToHost));
+    for (int x = 0; x < d.E; ++x) std::memcpy(Hpl + (size_t)c->h_e_orig[(size_t)d.edge_off + x] * 18, &hs[(size_t)x * 18], 18 * 8);
+  }
+  if (chi2 && d.E) {
+    // mark every window evaluated so k_finalize emits chi2 of the current state
+    for (auto& st : h_lm) { st.iterations = 1; st.last_eval_sel = st.sel; }
+    OSH_HIP(hipMemcpy(c->d_lm.p, h_lm.data(), c->n_windows * sizeof(LmState), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)c->n_chunks), dim3(kBlock), 0, s, c->bv);
+    OSH_TRY(launch_check("k_finalize"));
+    OSH_HIP(hipStreamSynchronize(s));
+    OSH_HIP(hipMemcpy(chi2, c->d_out_chi2.as<double>() + d.edge_off, (size_t)d.E * 8, hipMemcpyDeviceToHost));
+  }
+  c->optimized = false;
+  return OSH_OK;
+}
+
+// Debug / parity aid: one LM trial of every window at the uploaded estimates with lambda
+// forced to `lambda`; exports S (dense, upper valid), the reduced rhs and x = (x_p, x_l).
+extern "C" int osh_lba_debug_trial(osh_lba_ctx* c, int32_t window, double lambda, double* S, double* bs, double* x) {
+  if (!c || window < 0 || window >= c->n_windows) { set_error("osh_lba_debug_trial: bad window"); return OSH_ERR_INVALID; }
+  OSH_HIP(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  OSH_TRY(reset_state(c));
+  hipLaunchKernelGGL(k_linearize, dim3((unsigned)c->n_chunks), dim3(kBlock), 0, s, c->bv, 0);
+  OSH_TRY(launch_check("k_linearize"));
+  if (c->NFP) { hipLaunchKernelGGL(k_pose_hess, dim3((unsigned)c->NFP), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_pose_hess")); }
+  hipLaunchKernelGGL(k_control, dim3((unsigned)c->n_windows), dim3(64), 0, s, c->bv, 0);
+  OSH_TRY(launch_check("k_control"));
+  OSH_HIP(hipStreamSynchronize(s));
+  std::vector<LmState> h_lm(c->n_windows);
+  OSH_HIP(hipMemcpy(h_lm.data(), c->d_lm.p, c->n_windows * sizeof(LmState), hipMemcpyDeviceToHost));
+  for (auto& st : h_lm) st.lambda = lambda;
+  OSH_HIP(hipMemcpy(c->d_lm.p, h_lm.data(), c->n_windows * sizeof(LmState), hipMemcpyHostToDevice));
+  const WinDesc& d = c->h_win[window];
+  if (c->NFP) { hipLaunchKernelGGL(k_schur, dim3((unsigned)c->NFP), dim3(64), c->schur_lds, s, c->bv); OSH_TRY(launch_check("k_schur")); }
+  OSH_HIP(hipStreamSynchronize(s));
+  if (S && d.n) OSH_HIP(hipMemcpy(S, c->d_S.as<double>() + d.S_off, (size_t)d.n * d.n * 8, hipMemcpyDeviceToHost));
+  if (bs && d.n) OSH_HIP(hipMemcpy(bs, c->d_bs.as<double>() + (size_t)d.fpose_off * 6, (size_t)d.n * 8, hipMemcpyDeviceToHost));
+  hipLaunchKernelGGL(k_solve, dim3((unsigned)c->n_windows), dim3(kBlock), c->solve_lds, s, c->bv, c->solve_nb, c->solve_W);
+  OSH_TRY(launch_check("k_solve"));
+  hipLaunchKernelGGL(k_backsub, dim3((unsigned)c->n_chunks), dim3(kBlock), c->backsub_lds, s, c->bv);
+  OSH_TRY(launch_check("k_backsub"));
+  OSH_HIP(hipStreamSynchronize(s));
+  if (x) {
+    if (d.n) OSH_HIP(hipMemcpy(x, c->d_xp.as<double>() + (size_t)d.fpose_off * 6, (size_t)d.n * 8, hipMemcpyDeviceToHost));
+    // x_l = X_trial - X_cur
+    std::vector<double> a((size_t)d.L * 3), b((size_t)d.L * 3);
+    if (d.L) {
+      OSH_HIP(hipMemcpy(a.data(), c->d_pt[1].as<double>() + (size_t)d.pt_off * 3, a.size() * 8, hipMemcpyDeviceToHost));
+      OSH_HIP(hipMemcpy(b.data(), c->d_pt[0].as<double>() + (size_t)d.pt_off * 3, b.size() * 8, hipMemcpyDeviceToHost));
+      for (size_t k = 0; k < a.size(); ++k) x[d.n + k] = a[k] - b[k];
+    }
+  }
+  c->optimized = false;
+  return OSH_OK;
+}
+
+extern "C" int osh_lba_set_profiling(osh_lba_ctx* c, int enable) {
+  if (!c) return OSH_ERR_INVALID;
+  OSH_HIP(hipSetDevice(c->device));
+  if (enable) OSH_TRY(c->timer.init());
+  c->timer.enabled = enable != 0;
+  c->timer.reset();
+  return OSH_OK;
+}
+
+extern "C" int osh_lba_get_profile(osh_lba_ctx* c, int64_t launches[OSH_K_COUNT], double total_ms[OSH_K_COUNT]) {
+  if (!c || !launches || !total_ms) return OSH_ERR_INVALID;
+  for (int k = 0; k < OSH_K_COUNT; ++k) { launches[k] = c->timer.launches[k]; total_ms[k] = c->timer.total_ms[k]; }
+  return OSH_OK;
+}
+
+extern "C" const char* osh_lba_kernel_name(int k) {
+  static const char* names[OSH_K_COUNT] = {"k_linearize", "k_pose_hess", "k_schur", "k_solve", "k_backsub", "k_linearize(residual)", "k_control"};
+  return (k >= 0 && k < OSH_K_COUNT) ? names[k] : "?";
+}

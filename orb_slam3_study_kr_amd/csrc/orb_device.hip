@@ -1,0 +1,351 @@
+// orb_device.hip -- 256-bit Hamming nearest / second-nearest search on MI355X (gfx950).
+//
+// Replaces the candidate loops of ORB_SLAM3::ORBmatcher::SearchByProjection
+// (src/ORBmatcher.cc:84-120, 1743-1768, 1949-1964) and ORBmatcher::DescriptorDistance
+// (src/ORBmatcher.cc:2058-2074).  Bit-exact contract: the reference scans the candidates left
+// to right with a strict '<', i.e. it keeps the two smallest (distance, position) pairs in
+// lexicographic order; a candidate at distance 256 can never win (bestDist starts at 256).
+// Both are reproduced with one packed integer key  (distance << 22) | position  and min/max
+// selection, which is associative and therefore order independent.
+//
+// Integer-VALU bound: per descriptor pair 8 v_xor_b32 + 8 v_bcnt_u32_b32 and
+// 4 select ops; the 32-byte train rows are staged in LDS and read as wave-wide broadcasts.
+#include "common.h"
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+namespace osh {
+
+constexpr int kPosBits = 22;
+constexpr unsigned kPosMask = (1u << kPosBits) - 1;
+constexpr unsigned kKeyNone = 0xFFFFFFFFu;
+constexpr int kQBlock = 256;     // queries per block (one per thread)
+constexpr int kTrainTile = 1024; // train descriptors staged in LDS per tile (32 KiB)
+
+struct OrbView {
+  int n_pairs, n_query, n_train, n_split;
+  const uint4* query;        // [n_pairs*n_query][2]
+  const uint4* train;        // [n_pairs*n_train][2]
+  const int* train_level;    // [n_pairs*n_train] or null
+  const int* cand_off;       // [n_pairs*(n_query+1)] or null
+  const int* cand_idx;
+  const long long* pair_cand_base;
+  unsigned* part_keys;       // [n_split][n_pairs*n_query][2] (brute force partials)
+  int* best_idx; int* best_dist; int* second_dist; int* best_level; int* second_level;
+};
+
+__device__ __forceinline__ unsigned hamming256(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1) {
+  unsigned d = __builtin_popcount(a0.x ^ b0.x);
+  d += __builtin_popcount(a0.y ^ b0.y);
+  d += __builtin_popcount(a0.z ^ b0.z);
+  d += __builtin_popcount(a0.w ^ b0.w);
+  d += __builtin_popcount(a1.x ^ b1.x);
+  d += __builtin_popcount(a1.y ^ b1.y);
+  d += __builtin_popcount(a1.z ^ b1.z);
+  d += __builtin_popcount(a1.w ^ b1.w);
+  return d;
+}
+
+// keep the two smallest keys
+__device__ __forceinline__ void top2_insert(unsigned key, unsigned& best, unsigned& second) {
+  second = min(second, max(best, key));
+  best = min(best, key);
+}
+__device__ __forceinline__ void top2_merge(unsigned b2, unsigned s2, unsigned& best, unsigned& second) {
+  const unsigned nb = min(best, b2);
+  const unsigned ns = min(max(best, b2), min(second, s2));
+  best = nb; second = ns;
+}
+
+__device__ __forceinline__ void emit(const OrbView& v, size_t gq, size_t train_base, unsigned best, unsigned second,
+                                     const int* cand /* null: position == train index */) {
+  const unsigned bd = best >> kPosBits, sd = second >> kPosBits;
+  int bi = -1, bl = -1, sl = -1;
+  int bdist = 256, sdist = 256;
+  if (best != kKeyNone && bd < 256) {
+    const int pos = (int)(best & kPosMask);
+    bi = cand ? cand[pos] : pos;
+    bdist = (int)bd;
+    bl = v.train_level ? v.train_level[train_base + bi] : 0;
+    if (second != kKeyNone && sd < 256) {
+      const int pos2 = (int)(second & kPosMask);
+      const int si = cand ? cand[pos2] : pos2;
+      sdist = (int)sd;
+      sl = v.train_level ? v.train_level[train_base + si] : 0;
+    }
+  }
+  v.best_idx[gq] = bi; v.best_dist[gq] = bdist; v.second_dist[gq] = sdist;
+  v.best_level[gq] = bl; v.second_level[gq] = sl;
+}
+
+// Brute force: block = 256 queries of one pair x one slice of the train set.
+// grid.x = n_pairs * ceil(n_query/256), grid.y = n_split.
+__global__ __launch_bounds__(kQBlock) void k_orb_bruteforce(OrbView v) {
+  __shared__ uint4 sh_train[kTrainTile * 2];
+  const int qblocks = (v.n_query + kQBlock - 1) / kQBlock;
+  const int pair = blockIdx.x / qblocks;
+  const int qb = blockIdx.x - pair * qblocks;
+  const int q = qb * kQBlock + threadIdx.x;
+  const bool valid = q < v.n_query;
+  const size_t gq = (size_t)pair * v.n_query + (valid ? q : 0);
+  const uint4 a0 = v.query[gq * 2], a1 = v.query[gq * 2 + 1];
+  // slice of the train set handled by this block
+  const int per = (v.n_train + v.n_split - 1) / v.n_split;
+  const int t_begin = blockIdx.y * per;
+  const int t_end = min(v.n_train, t_begin + per);
+  const uint4* tr = v.train + (size_t)pair * v.n_train * 2;
+  unsigned best = kKeyNone, second = kKeyNone;
+  for (int t0 = t_begin; t0 < t_end; t0 += kTrainTile) {
+    const int nt = min(kTrainTile, t_end - t0);
+    __syncthreads();
+    for (int k = threadIdx.x; k < nt * 2; k += kQBlock) sh_train[k] = tr[(size_t)t0 * 2 + k];
+    __syncthreads();
+#pragma unroll 4
+    for (int t = 0; t < nt; ++t) {
+      const uint4 b0 = sh_train[2 * t], b1 = sh_train[2 * t + 1];  // wave-wide broadcast reads
+      const unsigned d = hamming256(a0, a1, b0, b1);
+      top2_insert((d << kPosBits) | (unsigned)(t0 + t), best, second);
+    }
+  }
+  if (!valid) return;
+  if (v.n_split == 1) {
+    emit(v, gq, (size_t)pair * v.n_train, best, second, nullptr);
+  } else {
+    const size_t nq_total = (size_t)v.n_pairs * v.n_query;
+    unsigned* o = v.part_keys + ((size_t)blockIdx.y * nq_total + gq) * 2;
+    o[0] = best; o[1] = second;
+  }
+}
+
+__global__ void k_orb_merge(OrbView v) {
+  const size_t nq_total = (size_t)v.n_pairs * v.n_query;
+  const size_t gq = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gq >= nq_total) return;
+  unsigned best = kKeyNone, second = kKeyNone;
+  for (int s = 0; s < v.n_split; ++s) {
+    const unsigned* o = v.part_keys + ((size_t)s * nq_total + gq) * 2;
+    top2_merge(o[0], o[1], best, second);
+  }
+  const int pair = (int)(gq / v.n_query);
+  emit(v, gq, (size_t)pair * v.n_train, best, second, nullptr);
+}
+
+// Windowed search: one wavefront per query, lanes stride the candidate list
+// (Frame::GetFeaturesInArea order, src/Frame.cc:658-722); 64-lane butterfly top-2 merge.
+__global__ __launch_bounds__(kQBlock) void k_orb_windowed(OrbView v) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t gq = (size_t)blockIdx.x * (kQBlock / 64) + wave;
+  const size_t nq_total = (size_t)v.n_pairs * v.n_query;
+  if (gq >= nq_total) return;
+  const int pair = (int)(gq / v.n_query);
+  const int q = (int)(gq - (size_t)pair * v.n_query);
+  const int* off = v.cand_off + (size_t)pair * (v.n_query + 1);
+  const int* cand = v.cand_idx + v.pair_cand_base[pair] + off[q];
+  const int nc = off[q + 1] - off[q];
+  const uint4 a0 = v.query[gq * 2], a1 = v.query[gq * 2 + 1];
+  const uint4* tr = v.train + (size_t)pair * v.n_train * 2;
+  unsigned best = kKeyNone, second = kKeyNone;
+  for (int c = lane; c < nc; c += 64) {
+    const int idx = cand[c];
+    const uint4 b0 = tr[(size_t)idx * 2], b1 = tr[(size_t)idx * 2 + 1];
+    const unsigned d = hamming256(a0, a1, b0, b1);
+    top2_insert((d << kPosBits) | (unsigned)c, best, second);
+  }
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) {
+    const unsigned ob = __shfl_xor(best, m, 64), os = __shfl_xor(second, m, 64);
+    top2_merge(ob, os, best, second);
+  }
+  if (lane == 0) emit(v, gq, (size_t)pair * v.n_train, best, second, cand);
+}
+
+__global__ void k_orb_distance_matrix(int n, int m, const uint4* a, const uint4* b, int* out) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)n * m) return;
+  const int i = (int)(idx / m), j = (int)(idx - (size_t)i * m);
+  out[idx] = (int)hamming256(a[2 * (size_t)i], a[2 * (size_t)i + 1], b[2 * (size_t)j], b[2 * (size_t)j + 1]);
+}
+
+}  // namespace osh
+
+using namespace osh;
+
+struct osh_orb_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  KernelTimer timer;
+  DevBuf d_query, d_train, d_level, d_off, d_idx, d_base, d_part, d_out[5], d_a, d_b, d_dm;
+  OrbView v{};
+  bool uploaded = false, matched = false, windowed = false;
+};
+
+#define OSH_TRY(expr) do { int _rc = (expr); if (_rc != OSH_OK) return _rc; } while (0)
+
+extern "C" int osh_orb_create(int device, osh_orb_ctx** out) {
+  if (!out) { set_error("osh_orb_create: out is NULL"); return OSH_ERR_INVALID; }
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_error("no HIP device visible"); return OSH_ERR_NO_DEVICE; }
+  if (device < 0 || device >= n) { set_error("device %d out of range (have %d)", device, n); return OSH_ERR_INVALID; }
+  OSH_HIP(hipSetDevice(device));
+  osh_orb_ctx* c = new osh_orb_ctx();
+  c->device = device;
+  OSH_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  *out = c;
+  return OSH_OK;
+}
+
+extern "C" void osh_orb_destroy(osh_orb_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  DevBuf* bufs[] = {&c->d_query, &c->d_train, &c->d_level, &c->d_off, &c->d_idx, &c->d_base, &c->d_part,
+                    &c->d_out[0], &c->d_out[1], &c->d_out[2], &c->d_out[3], &c->d_out[4], &c->d_a, &c->d_b, &c->d_dm};
+  for (DevBuf* b : bufs) b->release();
+  c->timer.destroy();
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" int osh_orb_upload(osh_orb_ctx* c, const osh_orb_batch* b) {
+  if (!c || !b || b->n_pairs <= 0 || b->n_query < 0 || b->n_train < 0 || !b->query_desc || !b->train_desc) {
+    set_error("osh_orb_upload: bad arguments");
+    return OSH_ERR_INVALID;
+  }
+  if (b->n_train > (int)kPosMask) { set_error("n_train exceeds %u", kPosMask); return OSH_ERR_UNSUPPORTED; }
+  if (b->cand_off && (!b->cand_idx || !b->pair_cand_base)) { set_error("cand_off without cand_idx/pair_cand_base"); return OSH_ERR_INVALID; }
+  OSH_HIP(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  OSH_HIP(hipStreamSynchronize(s));
+  const size_t nq = (size_t)b->n_pairs * b->n_query, nt = (size_t)b->n_pairs * b->n_train;
+  OSH_TRY(c->d_query.reserve(std::max<size_t>(nq * 32, 32)));
+  OSH_TRY(c->d_train.reserve(std::max<size_t>(nt * 32, 32)));
+  if (nq) OSH_HIP(hipMemcpyAsync(c->d_query.p, b->query_desc, nq * 32, hipMemcpyHostToDevice, s));
+  if (nt) OSH_HIP(hipMemcpyAsync(c->d_train.p, b->train_desc, nt * 32, hipMemcpyHostToDevice, s));
+  OrbView& v = c->v;
+  v = OrbView{};
+  v.n_pairs = b->n_pairs; v.n_query = b->n_query; v.n_train = b->n_train;
+  v.query = c->d_query.as<uint4>(); v.train = c->d_train.as<uint4>();
+  if (b->train_level) {
+    OSH_TRY(c->d_level.reserve(std::max<size_t>(nt * 4, 4)));
+    if (nt) OSH_HIP(hipMemcpyAsync(c->d_level.p, b->train_level, nt * 4, hipMemcpyHostToDevice, s));
+    v.train_level = c->d_level.as<int>();
+  }
+  c->windowed = b->cand_off != nullptr;
+  if (c->windowed) {
+    const size_t noff = (size_t)b->n_pairs * (b->n_query + 1);
+    // validate candidate lists on the host: an out-of-range index would fault the GPU
+    long long total = 0;
+    for (int p = 0; p < b->n_pairs; ++p) {
+      const int32_t* off = b->cand_off + (size_t)p * (b->n_query + 1);
+      if (off[0] != 0) { set_error("pair %d: cand_off[0] != 0", p); return OSH_ERR_INVALID; }
+      for (int q = 0; q < b->n_query; ++q)
+        if (off[q + 1] < off[q]) { set_error("pair %d: cand_off not monotone at %d", p, q); return OSH_ERR_INVALID; }
+      if (b->pair_cand_base[p] != total) { set_error("pair %d: pair_cand_base must be the running total of list lengths", p); return OSH_ERR_INVALID; }
+      const int32_t* idx = b->cand_idx + total;
+      for (int k = 0; k < off[b->n_query]; ++k)
+        if (idx[k] < 0 || idx[k] >= b->n_train) { set_error("pair %d: candidate index %d out of range", p, idx[k]); return OSH_ERR_INVALID; }
+      if (off[b->n_query] > 0) {
+        int longest = 0;
+        for (int q = 0; q < b->n_query; ++q) longest = std::max(longest, off[q + 1] - off[q]);
+        if ((unsigned)longest > kPosMask) { set_error("candidate list too long"); return OSH_ERR_UNSUPPORTED; }
+      }
+      total += off[b->n_query];
+    }
+    OSH_TRY(c->d_off.reserve(noff * 4));
+    OSH_TRY(c->d_idx.reserve(std::max<size_t>((size_t)total * 4, 4)));
+    OSH_TRY(c->d_base.reserve((size_t)b->n_pairs * 8));
+    OSH_HIP(hipMemcpyAsync(c->d_off.p, b->cand_off, noff * 4, hipMemcpyHostToDevice, s));
+    if (total) OSH_HIP(hipMemcpyAsync(c->d_idx.p, b->cand_idx, (size_t)total * 4, hipMemcpyHostToDevice, s));
+    OSH_HIP(hipMemcpyAsync(c->d_base.p, b->pair_cand_base, (size_t)b->n_pairs * 8, hipMemcpyHostToDevice, s));
+    v.cand_off = c->d_off.as<int>(); v.cand_idx = c->d_idx.as<int>(); v.pair_cand_base = c->d_base.as<long long>();
+    v.n_split = 1;
+  } else {
+    const int qblocks = (b->n_query + kQBlock - 1) / kQBlock;
+    const long blocks = (long)b->n_pairs * std::max(qblocks, 1);
+    int split = (int)std::min<long>(8, std::max<long>(1, (1024 + blocks - 1) / blocks));
+    split = std::min(split, std::max(1, (b->n_train + 255) / 256));
+    v.n_split = split;
+    if (split > 1) OSH_TRY(c->d_part.reserve((size_t)split * std::max<size_t>(nq, 1) * 8));
+    v.part_keys = c->d_part.as<unsigned>();
+  }
+  for (int k = 0; k < 5; ++k) OSH_TRY(c->d_out[k].reserve(std::max<size_t>(nq * 4, 4)));
+  v.best_idx = c->d_out[0].as<int>(); v.best_dist = c->d_out[1].as<int>(); v.second_dist = c->d_out[2].as<int>();
+  v.best_level = c->d_out[3].as<int>(); v.second_level = c->d_out[4].as<int>();
+  OSH_HIP(hipStreamSynchronize(s));
+  c->uploaded = true; c->matched = false;
+  return OSH_OK;
+}
+
+extern "C" int osh_orb_match(osh_orb_ctx* c) {
+  if (!c || !c->uploaded) { set_error("osh_orb_match: nothing uploaded"); return OSH_ERR_INVALID; }
+  OSH_HIP(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const OrbView& v = c->v;
+  const size_t nq = (size_t)v.n_pairs * v.n_query;
+  if (nq == 0) { c->matched = true; return OSH_OK; }
+  if (c->timer.enabled) OSH_TRY(c->timer.init());
+  const bool t = c->timer.begin(0, s);
+  if (c->windowed) {
+    const unsigned grid = (unsigned)((nq + (kQBlock / 64) - 1) / (kQBlock / 64));
+    hipLaunchKernelGGL(k_orb_windowed, dim3(grid), dim3(kQBlock), 0, s, v);
+  } else {
+    const int qblocks = (v.n_query + kQBlock - 1) / kQBlock;
+    hipLaunchKernelGGL(k_orb_bruteforce, dim3((unsigned)(v.n_pairs * qblocks), (unsigned)v.n_split), dim3(kQBlock), 0, s, v);
+    if (v.n_split > 1) hipLaunchKernelGGL(k_orb_merge, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, v);
+  }
+  if (t) c->timer.end(s);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("orb kernel launch failed: %s", hipGetErrorString(e)); return OSH_ERR_DEVICE; }
+  OSH_HIP(hipStreamSynchronize(s));
+  if (c->timer.enabled) c->timer.collect();
+  c->matched = true;
+  return OSH_OK;
+}
+
+extern "C" int osh_orb_download(osh_orb_ctx* c, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist,
+                                int32_t* best_level, int32_t* second_level) {
+  if (!c || !c->matched) { set_error("osh_orb_download: call osh_orb_match first"); return OSH_ERR_INVALID; }
+  OSH_HIP(hipSetDevice(c->device));
+  const size_t nq = (size_t)c->v.n_pairs * c->v.n_query;
+  int32_t* outs[5] = {best_idx, best_dist, second_dist, best_level, second_level};
+  for (int k = 0; k < 5; ++k)
+    if (outs[k] && nq) OSH_HIP(hipMemcpyAsync(outs[k], c->d_out[k].p, nq * 4, hipMemcpyDeviceToHost, c->stream));
+  OSH_HIP(hipStreamSynchronize(c->stream));
+  return OSH_OK;
+}
+
+extern "C" int osh_orb_set_profiling(osh_orb_ctx* c, int enable) {
+  if (!c) return OSH_ERR_INVALID;
+  OSH_HIP(hipSetDevice(c->device));
+  if (enable) OSH_TRY(c->timer.init());
+  c->timer.enabled = enable != 0;
+  c->timer.reset();
+  return OSH_OK;
+}
+
+extern "C" int osh_orb_get_profile(osh_orb_ctx* c, int64_t* launches, double* total_ms) {
+  if (!c || !launches || !total_ms) return OSH_ERR_INVALID;
+  *launches = c->timer.launches[0];
+  *total_ms = c->timer.total_ms[0];
+  return OSH_OK;
+}
+
+extern "C" int osh_orb_distance_matrix(osh_orb_ctx* c, int32_t n, int32_t m, const uint8_t* a, const uint8_t* b, int32_t* out) {
+  if (!c || n < 0 || m < 0 || !a || !b || !out) { set_error("osh_orb_distance_matrix: bad arguments"); return OSH_ERR_INVALID; }
+  if (n == 0 || m == 0) return OSH_OK;
+  OSH_HIP(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  OSH_TRY(c->d_a.reserve((size_t)n * 32));
+  OSH_TRY(c->d_b.reserve((size_t)m * 32));
+  OSH_TRY(c->d_dm.reserve((size_t)n * m * 4));
+  OSH_HIP(hipMemcpyAsync(c->d_a.p, a, (size_t)n * 32, hipMemcpyHostToDevice, s));
+  OSH_HIP(hipMemcpyAsync(c->d_b.p, b, (size_t)m * 32, hipMemcpyHostToDevice, s));
+  const size_t tot = (size_t)n * m;
+  hipLaunchKernelGGL(k_orb_distance_matrix, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, n, m, c->d_a.as<uint4>(), c->d_b.as<uint4>(), c->d_dm.as<int>());
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("k_orb_distance_matrix launch failed: %s", hipGetErrorString(e)); return OSH_ERR_DEVICE; }
+  OSH_HIP(hipMemcpyAsync(out, c->d_dm.p, tot * 4, hipMemcpyDeviceToHost, s));
+  OSH_HIP(hipStreamSynchronize(s));
+  return OSH_OK;
+}

@@ -1,0 +1,95 @@
+"""Python driver over the local-BA C-ABI (include/orbslam3_hip.h, osh_lba_*).
+
+Thin plumbing only: every number is computed by the HIP kernels in csrc/lba_device.hip.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .synth import LbaResultArrays, LbaWindow
+
+
+class LbaSolver:
+    """Owns one ``osh_lba_ctx`` (one HIP device + stream)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = capi.load_library()
+        self.ctx = C.c_void_p()
+        capi.check(self.lib.osh_lba_create(device, C.byref(self.ctx)), "osh_lba_create", self.lib)
+        self._windows: list[LbaWindow] = []
+        self._problems = None
+
+    def close(self):
+        if self.ctx:
+            self.lib.osh_lba_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- batch life cycle -------------------------------------------------------------------
+    def upload(self, windows: list[LbaWindow]):
+        self._windows = list(windows)
+        arr = (capi.LbaProblem * len(windows))()
+        for i, w in enumerate(windows):
+            arr[i] = w.as_struct()
+        self._problems = arr
+        capi.check(self.lib.osh_lba_upload(self.ctx, len(windows), arr), "osh_lba_upload", self.lib)
+
+    def optimize(self):
+        capi.check(self.lib.osh_lba_optimize(self.ctx), "osh_lba_optimize", self.lib)
+
+    def download(self) -> list[LbaResultArrays]:
+        n = len(self._windows)
+        outs = [LbaResultArrays(w) for w in self._windows]
+        arr = (capi.LbaResult * n)()
+        for i, o in enumerate(outs):
+            o.bind(arr[i])
+        capi.check(self.lib.osh_lba_download(self.ctx, n, arr), "osh_lba_download", self.lib)
+        return [o.read_scalars(arr[i]) for i, o in enumerate(outs)]
+
+    def solve(self, windows: list[LbaWindow]) -> list[LbaResultArrays]:
+        self.upload(windows)
+        self.optimize()
+        return self.download()
+
+    # -- parity / debug aids ------------------------------------------------------------------
+    def linearize(self, window: int = 0) -> dict:
+        w = self._windows[window]
+        P, L, E = w.n_free, w.n_points, w.n_edges
+        out = dict(Hpp=np.zeros((P, 6, 6)), bp=np.zeros((P, 6)), Hll=np.zeros((L, 3, 3)), bl=np.zeros((L, 3)),
+                   Hpl=np.zeros((E, 6, 3)), chi2=np.zeros(E))
+        rc = C.c_double(0)
+        d = capi.c_double_p
+        capi.check(self.lib.osh_lba_linearize(self.ctx, window, capi.ptr(out["Hpp"], d), capi.ptr(out["bp"], d),
+                                              capi.ptr(out["Hll"], d), capi.ptr(out["bl"], d), capi.ptr(out["Hpl"], d),
+                                              capi.ptr(out["chi2"], d), C.cast(C.byref(rc), d)),
+                   "osh_lba_linearize", self.lib)
+        out["robust_chi2"] = rc.value
+        return out
+
+    def debug_trial(self, window: int, lam: float):
+        w = self._windows[window]
+        n = 6 * w.n_free
+        S, bs, x = np.zeros((n, n)), np.zeros(n), np.zeros(n + 3 * w.n_points)
+        d = capi.c_double_p
+        capi.check(self.lib.osh_lba_debug_trial(self.ctx, window, lam, capi.ptr(S, d), capi.ptr(bs, d), capi.ptr(x, d)),
+                   "osh_lba_debug_trial", self.lib)
+        return S, bs, x
+
+    # -- profiling ------------------------------------------------------------------------------
+    def set_profiling(self, enable: bool):
+        capi.check(self.lib.osh_lba_set_profiling(self.ctx, int(enable)), "osh_lba_set_profiling", self.lib)
+
+    def profile(self) -> dict:
+        launches = np.zeros(capi.OSH_K_COUNT, dtype=np.int64)
+        ms = np.zeros(capi.OSH_K_COUNT, dtype=np.float64)
+        capi.check(self.lib.osh_lba_get_profile(self.ctx, capi.ptr(launches, capi.c_int64_p), capi.ptr(ms, capi.c_double_p)),
+                   "osh_lba_get_profile", self.lib)
+        return {capi.KERNEL_NAMES[k]: (int(launches[k]), float(ms[k])) for k in range(capi.OSH_K_COUNT)}

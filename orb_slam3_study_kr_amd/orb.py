@@ -1,0 +1,95 @@
+"""Python driver over the ORB matching C-ABI (include/orbslam3_hip.h, osh_orb_*)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .synth import OrbPair
+
+
+class OrbMatcher:
+    def __init__(self, device: int = 0):
+        self.lib = capi.load_library()
+        self.ctx = C.c_void_p()
+        capi.check(self.lib.osh_orb_create(device, C.byref(self.ctx)), "osh_orb_create", self.lib)
+        self._shape = None
+        self._keep = None
+
+    def close(self):
+        if self.ctx:
+            self.lib.osh_orb_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def upload(self, pairs: list[OrbPair], windowed: bool = False):
+        n_pairs = len(pairs)
+        nq, nt = pairs[0].query_desc.shape[0], pairs[0].train_desc.shape[0]
+        q = np.ascontiguousarray(np.stack([p.query_desc for p in pairs]), dtype=np.uint8)
+        t = np.ascontiguousarray(np.stack([p.train_desc for p in pairs]), dtype=np.uint8)
+        lev = np.ascontiguousarray(np.stack([p.train_level for p in pairs]), dtype=np.int32)
+        b = capi.OrbBatch()
+        b.n_pairs, b.n_query, b.n_train = n_pairs, nq, nt
+        b.query_desc, b.train_desc = capi.ptr(q, capi.c_uint8_p), capi.ptr(t, capi.c_uint8_p)
+        b.train_level = capi.ptr(lev, capi.c_int32_p)
+        keep = [q, t, lev]
+        if windowed:
+            off = np.ascontiguousarray(np.stack([p.cand_off for p in pairs]), dtype=np.int32)
+            idx = np.ascontiguousarray(np.concatenate([p.cand_idx for p in pairs]), dtype=np.int32)
+            lens = np.array([p.cand_idx.shape[0] for p in pairs], dtype=np.int64)
+            base = np.ascontiguousarray(np.concatenate([[0], np.cumsum(lens)[:-1]]), dtype=np.int64)
+            if idx.size == 0:
+                idx = np.zeros(1, dtype=np.int32)
+            b.cand_off, b.cand_idx = capi.ptr(off, capi.c_int32_p), capi.ptr(idx, capi.c_int32_p)
+            b.pair_cand_base = capi.ptr(base, capi.c_int64_p)
+            keep += [off, idx, base]
+        self._keep = keep
+        self._shape = (n_pairs, nq)
+        capi.check(self.lib.osh_orb_upload(self.ctx, C.byref(b)), "osh_orb_upload", self.lib)
+
+    def match(self):
+        capi.check(self.lib.osh_orb_match(self.ctx), "osh_orb_match", self.lib)
+
+    def download(self) -> dict:
+        names = ["best_idx", "best_dist", "second_dist", "best_level", "second_level"]
+        outs = [np.zeros(self._shape, dtype=np.int32) for _ in names]
+        capi.check(self.lib.osh_orb_download(self.ctx, *[capi.ptr(o, capi.c_int32_p) for o in outs]), "osh_orb_download", self.lib)
+        return dict(zip(names, outs))
+
+    def search(self, pairs: list[OrbPair], windowed: bool = False) -> dict:
+        self.upload(pairs, windowed)
+        self.match()
+        return self.download()
+
+    def distance_matrix(self, a: np.ndarray, b: np.ndarray) -> np.ndarray:
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        b = np.ascontiguousarray(b, dtype=np.uint8)
+        out = np.zeros((a.shape[0], b.shape[0]), dtype=np.int32)
+        capi.check(self.lib.osh_orb_distance_matrix(self.ctx, a.shape[0], b.shape[0], capi.ptr(a, capi.c_uint8_p),
+                                                    capi.ptr(b, capi.c_uint8_p), capi.ptr(out, capi.c_int32_p)),
+                   "osh_orb_distance_matrix", self.lib)
+        return out
+
+    def set_profiling(self, enable: bool):
+        capi.check(self.lib.osh_orb_set_profiling(self.ctx, int(enable)), "osh_orb_set_profiling", self.lib)
+
+    def profile(self):
+        n, ms = C.c_int64(0), C.c_double(0)
+        capi.check(self.lib.osh_orb_get_profile(self.ctx, C.byref(n), C.byref(ms)), "osh_orb_get_profile", self.lib)
+        return int(n.value), float(ms.value)
+
+
+def accept_local_points(res: dict, pair_index: int, nn_ratio: float = 0.8, th_high: int = 100) -> np.ndarray:
+    """Acceptance rule of SearchByProjection(Frame&, vector<MapPoint*>&), src/ORBmatcher.cc:123-139,
+    applied independently per query (no occupancy): bool mask of accepted queries."""
+    bd = res["best_dist"][pair_index]
+    sd = res["second_dist"][pair_index]
+    bl, sl = res["best_level"][pair_index], res["second_level"][pair_index]
+    ratio_fail = (bl == sl) & (bd.astype(np.float32) > np.float32(nn_ratio) * sd.astype(np.float32))
+    return (bd <= th_high) & ~ratio_fail

@@ -1,0 +1,99 @@
+"""GPU parity tests of the Hamming search: bit-exact distances and match indices vs the CPU oracle."""
+import numpy as np
+import pytest
+
+from helpers import GOLDEN
+from orb_slam3_study_kr_amd import orb, synth
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("best_idx", "best_dist", "second_dist", "best_level", "second_level")
+
+
+@pytest.fixture(scope="module")
+def matcher(hip_lib):
+    with orb.OrbMatcher(0) as m:
+        yield m
+
+
+@pytest.fixture(scope="module")
+def ob():
+    from oracle import binding
+    return binding
+
+
+def test_distance_matrix_golden_and_known_answers(matcher):
+    z = np.load(GOLDEN / "orb_64x64.npz")
+    np.testing.assert_array_equal(matcher.distance_matrix(z["a"], z["b"]), z["dist"])
+    a = z["a"][:4]
+    d = matcher.distance_matrix(a, np.concatenate([a, ~a]))
+    assert all(d[i, i] == 0 and d[i, 4 + i] == 256 for i in range(4))
+
+
+def test_config3_bruteforce_2000x2000_bit_exact(matcher, ob):
+    p = synth.make_orb_pair(7, 2000, 2000, same_level=False)
+    got = matcher.search([p])
+    exp = ob.orb_search(p.query_desc, p.train_desc, p.train_level)
+    for k in KEYS:
+        np.testing.assert_array_equal(got[k][0], exp[k], err_msg=k)
+    # accepted matches under the M2 rules agree with the sequential oracle wherever no slot is contested
+    n, assign, _ = ob.orb_match_local_points(p.query_desc, p.train_desc, p.train_level)
+    acc = orb.accept_local_points(got, 0)
+    uncontested = np.bincount(got["best_idx"][0][acc], minlength=2000) <= 1
+    for t in np.nonzero(assign >= 0)[0]:
+        if uncontested[t]:
+            assert acc[assign[t]] and got["best_idx"][0][assign[t]] == t
+
+
+def test_batched_pairs_and_odd_sizes(matcher, ob):
+    pairs = [synth.make_orb_pair(20 + i, 333, 777, same_level=False) for i in range(5)]
+    got = matcher.search(pairs)
+    for i, p in enumerate(pairs):
+        exp = ob.orb_search(p.query_desc, p.train_desc, p.train_level)
+        for k in KEYS:
+            np.testing.assert_array_equal(got[k][i], exp[k], err_msg=f"{k} pair {i}")
+
+
+def test_large_batch_uses_unsplit_path(matcher, ob):
+    pairs = [synth.make_orb_pair(100 + i, 512, 300) for i in range(40)]
+    got = matcher.search(pairs)
+    for i in (0, 17, 39):
+        exp = ob.orb_search(pairs[i].query_desc, pairs[i].train_desc, pairs[i].train_level)
+        for k in KEYS:
+            np.testing.assert_array_equal(got[k][i], exp[k])
+
+
+def test_windowed_candidate_lists_bit_exact(matcher, ob):
+    pairs = [synth.make_orb_pair(50 + i, 400, 600, windowed=True, same_level=False) for i in range(3)]
+    got = matcher.search(pairs, windowed=True)
+    for i, p in enumerate(pairs):
+        exp = ob.orb_search(p.query_desc, p.train_desc, p.train_level, p.cand_off, p.cand_idx)
+        for k in KEYS:
+            np.testing.assert_array_equal(got[k][i], exp[k], err_msg=f"{k} pair {i}")
+
+
+def test_tie_break_and_none_cases(matcher, ob):
+    q = np.zeros((3, 32), dtype=np.uint8)
+    t = np.zeros((5, 32), dtype=np.uint8)
+    t[0, 0] = 0b111
+    t[1, 0] = 0b11
+    t[2, 1] = 0b11
+    t[3, 0] = 0b1111
+    t[4, 0] = 0xFF
+    q[2] = 0xFF  # distance 256 - k from everything but never 256... make it exact complement of t[3]
+    q[2] = ~t[3]
+    p = synth.OrbPair(q, t, np.arange(5, dtype=np.int32))
+    got = matcher.search([p])
+    exp = ob.orb_search(q, t, p.train_level)
+    for k in KEYS:
+        np.testing.assert_array_equal(got[k][0], exp[k], err_msg=k)
+    assert got["best_idx"][0][0] == 1 and got["second_level"][0][0] == 2
+    # explicit list order + an empty list
+    p.cand_off = np.array([0, 3, 3, 5], dtype=np.int32)
+    p.cand_idx = np.array([2, 1, 0, 3, 3], dtype=np.int32)[:5]
+    got = matcher.search([p], windowed=True)
+    exp = ob.orb_search(q, t, p.train_level, p.cand_off, p.cand_idx)
+    for k in KEYS:
+        np.testing.assert_array_equal(got[k][0], exp[k], err_msg=k)
+    assert got["best_idx"][0][0] == 2 and got["best_idx"][0][1] == -1
+    assert got["best_idx"][0][2] == -1 and got["best_dist"][0][2] == 256  # only candidate is at distance 256
