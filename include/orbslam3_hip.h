@@ -176,6 +176,9 @@ const char* osh_lba_kernel_name(int kernel_id);
  *   best_dist [n_query]  its distance, 256 if none
  *   second_dist[n_query] second-best distance, 256 if none
  *   best_level / second_level [n_query]  train_level[] of those, -1 if none
+ *   second_idx [n_query] train index of the second-best candidate, -1 if none
+ *              (lets the host replay the sequential "slot already taken" rule,
+ *               src/ORBmatcher.cc:88-90, and re-scan only contested queries)
  * A batch holds n_pairs independent frame pairs laid out back to back with the
  * same n_query / n_train (candidate lists, if any, are per pair:
  * cand_off has n_pairs*(n_query+1) entries, offsets relative to the pair's
@@ -201,7 +204,8 @@ int osh_orb_upload(osh_orb_ctx* ctx, const osh_orb_batch* batch);
 int osh_orb_match(osh_orb_ctx* ctx);
 /* Copy the per-query results back. Each array has n_pairs*n_query entries. */
 int osh_orb_download(osh_orb_ctx* ctx, int32_t* best_idx, int32_t* best_dist,
-                     int32_t* second_dist, int32_t* best_level, int32_t* second_level);
+                     int32_t* second_dist, int32_t* best_level, int32_t* second_level,
+                     int32_t* second_idx);
 /* Average duration of the match kernel over the launches since the last upload. */
 int osh_orb_get_profile(osh_orb_ctx* ctx, int64_t* launches, double* total_ms);
 int osh_orb_set_profiling(osh_orb_ctx* ctx, int enable);

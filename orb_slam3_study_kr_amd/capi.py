@@ -99,7 +99,7 @@ _SIGNATURES = {
     "osh_orb_destroy": (None, [C.c_void_p]),
     "osh_orb_upload": (C.c_int, [C.c_void_p, C.POINTER(OrbBatch)]),
     "osh_orb_match": (C.c_int, [C.c_void_p]),
-    "osh_orb_download": (C.c_int, [C.c_void_p] + [c_int32_p] * 5),
+    "osh_orb_download": (C.c_int, [C.c_void_p] + [c_int32_p] * 6),
     "osh_orb_get_profile": (C.c_int, [C.c_void_p, c_int64_p, c_double_p]),
     "osh_orb_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "osh_orb_distance_matrix": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_uint8_p, c_uint8_p, c_int32_p]),

@@ -433,40 +433,70 @@ __global__ __launch_bounds__(kBlock) void k_solve(BatchView bv, int nb, int W) {
       U[r * W + jj] = v;
     }
     __syncthreads();
-    // factor the panel rows against each other
+    // factor the panel rows against each other (right-looking inside the panel)
     for (int k = 0; k < kb; ++k) {
       const double d = U[k * W + k];
       if (d == 0.0) { if (tid == 0) sh_ok = 0; }
+      if (tid < kb) part[tid] = (tid > k) ? U[k * W + tid] / d : 0.0;  // l_ik for the rows below k
+      __syncthreads();
       const int wc = m - k;  // columns k+1..m
       const int cnt = (kb - k - 1) * wc;
       for (int idx = tid; idx < cnt; idx += kBlock) {
         const int ri = idx / wc, cj = idx - ri * wc;
         const int ii = k + 1 + ri, jj = k + 1 + cj;
-        if (jj >= ii) U[ii * W + jj] -= (U[k * W + ii] / d) * U[k * W + jj];
+        if (jj >= ii) U[ii * W + jj] -= part[ii] * U[k * W + jj];
       }
       __syncthreads();
     }
     if (!sh_ok) break;
-    // scaled rows L[k][jj] = U[k][jj] / d_k
-    for (int idx = tid; idx < kb * (m + 1); idx += kBlock) {
-      const int r = idx / (m + 1), jj = idx - r * (m + 1);
+    // scaled rows L[k][jj] = U[k][jj] / d_k (zero padded so 4-wide tiles may over-read)
+    for (int idx = tid; idx < kb * (m + 5); idx += kBlock) {
+      const int r = idx / (m + 5), jj = idx - r * (m + 5);
       const double d = U[r * W + r];
-      Lp[r * W + jj] = (jj > r) ? U[r * W + jj] / d : 0.0;
+      Lp[r * W + jj] = (jj > r && jj <= m) ? U[r * W + jj] / d : 0.0;
       if (jj == r) dd[r] = d;
+      if (jj > m) U[r * W + jj] = 0.0;
     }
     __syncthreads();
-    // trailing update of rows k0+kb .. n-1 (upper part) and of the rhs column
+    // trailing update of rows k0+kb .. n-1 (upper part) and of the rhs column: 4x4 register tiles
     const int tr = m - kb;  // trailing rows
     if (tr > 0) {
-      const int wc = tr + 1;  // columns kb..m (m = rhs)
-      for (int idx = tid; idx < tr * wc; idx += kBlock) {
-        const int ri = idx / wc, cj = idx - ri * wc;
-        const int ii = kb + ri, jj = kb + cj;
-        if (jj < ii) continue;
-        double s = 0.0;
-        for (int k = 0; k < kb; ++k) s += Lp[k * W + ii] * U[k * W + jj];
-        if (jj == m) rhs[k0 + ii] -= s;
-        else A[(size_t)(k0 + ii) * n + k0 + jj] -= s;
+      const int Tr = (tr + 3) >> 2, Tc = (tr + 1 + 3) >> 2;  // column tiles include the rhs column
+      const int ntile = Tr * Tc - Tr * (Tr - 1) / 2;
+      for (int t = tid; t < ntile; t += kBlock) {
+        const float bq = (float)(2 * Tc + 1);
+        int ti = (int)((bq - sqrtf(fmaxf(bq * bq - 8.0f * (float)t, 0.0f))) * 0.5f);
+        ti = max(0, min(ti, Tr - 1));
+        while (ti > 0 && ti * Tc - ti * (ti - 1) / 2 > t) --ti;
+        while (ti + 1 < Tr && (ti + 1) * Tc - (ti + 1) * ti / 2 <= t) ++ti;
+        const int tj = ti + (t - (ti * Tc - ti * (ti - 1) / 2));
+        const int i0 = kb + 4 * ti, j0 = kb + 4 * tj;
+        double acc[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c2 = 0; c2 < 4; ++c2) acc[r][c2] = 0.0;
+        for (int k = 0; k < kb; ++k) {
+          double a[4], b[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { a[r] = Lp[k * W + i0 + r]; b[r] = U[k * W + j0 + r]; }
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c2 = 0; c2 < 4; ++c2) acc[r][c2] += a[r] * b[c2];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ii = i0 + r;
+          if (ii >= m) continue;
+#pragma unroll
+          for (int c2 = 0; c2 < 4; ++c2) {
+            const int jj = j0 + c2;
+            if (jj < ii || jj > m) continue;
+            if (jj == m) rhs[k0 + ii] -= acc[r][c2];
+            else A[(size_t)(k0 + ii) * n + k0 + jj] -= acc[r][c2];
+          }
+        }
       }
     }
     // write the factor back: L rows, pivots on the diagonal, forward-substituted rhs
@@ -483,27 +513,35 @@ __global__ __launch_bounds__(kBlock) void k_solve(BatchView bv, int nb, int W) {
   if (ok) {
     // back substitution  L^T x = D^-1 y, panels in reverse
     const int npanel = (n + nb - 1) / nb;
+    const int wv = tid >> 6, lane = tid & 63;
     for (int pi = npanel - 1; pi >= 0; --pi) {
       const int k0 = pi * nb;
       const int kb = min(nb, n - k0);
       const int tail0 = k0 + kb;  // x known for indices >= tail0
       // part[r] = sum_{j>=tail0} L[k0+r][j] x[j] : one wavefront per group of rows
-      const int wv = tid >> 6, lane = tid & 63;
       for (int r = wv; r < kb; r += 4) {
-        double s = 0.0;
+        double sacc = 0.0;
         const double* row = A + (size_t)(k0 + r) * n;
-        for (int j = tail0 + lane; j < n; j += 64) s += row[j] * xs[j];
-        s = dev::wave_sum(s);
-        if (lane == 0) part[r] = s;
+        for (int j = tail0 + lane; j < n; j += 64) sacc += row[j] * xs[j];
+        sacc = dev::wave_sum(sacc);
+        if (lane == 0) part[r] = sacc;
       }
+      // diagonal block of the factor (L above the diagonal, pivots on it) and the rhs into LDS
+      for (int idx = tid; idx < kb * kb; idx += kBlock) {
+        const int r = idx / kb, c2 = idx - r * kb;
+        U[r * W + c2] = (c2 >= r) ? A[(size_t)(k0 + r) * n + k0 + c2] : 0.0;
+      }
+      if (tid < kb) dd[tid] = rhs[k0 + tid];
       __syncthreads();
-      if (tid == 0) {
-        for (int r = kb - 1; r >= 0; --r) {
-          const double* row = A + (size_t)(k0 + r) * n;
-          double s = rhs[k0 + r] / row[k0 + r] - part[r];
-          for (int j = r + 1; j < kb; ++j) s -= row[k0 + j] * xs[k0 + j];
-          xs[k0 + r] = s;
+      if (wv == 0) {
+        // lane r holds s_r; columns are eliminated right to left
+        double sv = 0.0;
+        if (lane < kb) sv = dd[lane] / U[lane * W + lane] - part[lane];
+        for (int c2 = kb - 1; c2 >= 0; --c2) {
+          const double xc = __shfl(sv, c2, 64);
+          if (lane < c2) sv -= U[lane * W + c2] * xc;
         }
+        if (lane < kb) xs[k0 + lane] = sv;
       }
       __syncthreads();
     }
@@ -969,14 +1007,14 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   {
     const size_t budget = 150 * 1024;
     int nb = 24;
-    auto need = [&](int b) { return ((size_t)2 * b * (n_max + 2) + (n_max + 2) + 2 * b + 8) * sizeof(double); };
+    auto need = [&](int b) { return ((size_t)2 * b * (n_max + 8) + (n_max + 8) + 2 * b + 8) * sizeof(double); };
     while (nb > 6 && need(nb) > budget) nb -= 6;
     if (need(nb) > budget || c->schur_lds > budget) {
       set_error("window with %d optimisable poses exceeds the LDS budget of the reduced-system kernels", n_max / 6);
       return OSH_ERR_UNSUPPORTED;
     }
     c->solve_nb = nb;
-    c->solve_W = n_max + 2;
+    c->solve_W = n_max + 8;
     c->solve_lds = need(nb);
   }
 

@@ -32,7 +32,7 @@ struct OrbView {
   const int* cand_idx;
   const long long* pair_cand_base;
   unsigned* part_keys;       // [n_split][n_pairs*n_query][2] (brute force partials)
-  int* best_idx; int* best_dist; int* second_dist; int* best_level; int* second_level;
+  int* best_idx; int* best_dist; int* second_dist; int* best_level; int* second_level; int* second_idx;
 };
 
 __device__ __forceinline__ unsigned hamming256(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1) {
@@ -61,7 +61,7 @@ __device__ __forceinline__ void top2_merge(unsigned b2, unsigned s2, unsigned& b
 __device__ __forceinline__ void emit(const OrbView& v, size_t gq, size_t train_base, unsigned best, unsigned second,
                                      const int* cand /* null: position == train index */) {
   const unsigned bd = best >> kPosBits, sd = second >> kPosBits;
-  int bi = -1, bl = -1, sl = -1;
+  int bi = -1, bl = -1, sl = -1, si_out = -1;
   int bdist = 256, sdist = 256;
   if (best != kKeyNone && bd < 256) {
     const int pos = (int)(best & kPosMask);
@@ -72,11 +72,12 @@ __device__ __forceinline__ void emit(const OrbView& v, size_t gq, size_t train_b
       const int pos2 = (int)(second & kPosMask);
       const int si = cand ? cand[pos2] : pos2;
       sdist = (int)sd;
+      si_out = si;
       sl = v.train_level ? v.train_level[train_base + si] : 0;
     }
   }
   v.best_idx[gq] = bi; v.best_dist[gq] = bdist; v.second_dist[gq] = sdist;
-  v.best_level[gq] = bl; v.second_level[gq] = sl;
+  v.best_level[gq] = bl; v.second_level[gq] = sl; v.second_idx[gq] = si_out;
 }
 
 // Brute force: block = 256 queries of one pair x one slice of the train set.
@@ -175,7 +176,7 @@ struct osh_orb_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   KernelTimer timer;
-  DevBuf d_query, d_train, d_level, d_off, d_idx, d_base, d_part, d_out[5], d_a, d_b, d_dm;
+  DevBuf d_query, d_train, d_level, d_off, d_idx, d_base, d_part, d_out[6], d_a, d_b, d_dm;
   OrbView v{};
   bool uploaded = false, matched = false, windowed = false;
 };
@@ -200,7 +201,7 @@ extern "C" void osh_orb_destroy(osh_orb_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DevBuf* bufs[] = {&c->d_query, &c->d_train, &c->d_level, &c->d_off, &c->d_idx, &c->d_base, &c->d_part,
-                    &c->d_out[0], &c->d_out[1], &c->d_out[2], &c->d_out[3], &c->d_out[4], &c->d_a, &c->d_b, &c->d_dm};
+                    &c->d_out[0], &c->d_out[1], &c->d_out[2], &c->d_out[3], &c->d_out[4], &c->d_out[5], &c->d_a, &c->d_b, &c->d_dm};
   for (DevBuf* b : bufs) b->release();
   c->timer.destroy();
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -269,9 +270,9 @@ extern "C" int osh_orb_upload(osh_orb_ctx* c, const osh_orb_batch* b) {
     if (split > 1) OSH_TRY(c->d_part.reserve((size_t)split * std::max<size_t>(nq, 1) * 8));
     v.part_keys = c->d_part.as<unsigned>();
   }
-  for (int k = 0; k < 5; ++k) OSH_TRY(c->d_out[k].reserve(std::max<size_t>(nq * 4, 4)));
+  for (int k = 0; k < 6; ++k) OSH_TRY(c->d_out[k].reserve(std::max<size_t>(nq * 4, 4)));
   v.best_idx = c->d_out[0].as<int>(); v.best_dist = c->d_out[1].as<int>(); v.second_dist = c->d_out[2].as<int>();
-  v.best_level = c->d_out[3].as<int>(); v.second_level = c->d_out[4].as<int>();
+  v.best_level = c->d_out[3].as<int>(); v.second_level = c->d_out[4].as<int>(); v.second_idx = c->d_out[5].as<int>();
   OSH_HIP(hipStreamSynchronize(s));
   c->uploaded = true; c->matched = false;
   return OSH_OK;
@@ -304,12 +305,12 @@ extern "C" int osh_orb_match(osh_orb_ctx* c) {
 }
 
 extern "C" int osh_orb_download(osh_orb_ctx* c, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist,
-                                int32_t* best_level, int32_t* second_level) {
+                                int32_t* best_level, int32_t* second_level, int32_t* second_idx) {
   if (!c || !c->matched) { set_error("osh_orb_download: call osh_orb_match first"); return OSH_ERR_INVALID; }
   OSH_HIP(hipSetDevice(c->device));
   const size_t nq = (size_t)c->v.n_pairs * c->v.n_query;
-  int32_t* outs[5] = {best_idx, best_dist, second_dist, best_level, second_level};
-  for (int k = 0; k < 5; ++k)
+  int32_t* outs[6] = {best_idx, best_dist, second_dist, best_level, second_level, second_idx};
+  for (int k = 0; k < 6; ++k)
     if (outs[k] && nq) OSH_HIP(hipMemcpyAsync(outs[k], c->d_out[k].p, nq * 4, hipMemcpyDeviceToHost, c->stream));
   OSH_HIP(hipStreamSynchronize(c->stream));
   return OSH_OK;

@@ -57,7 +57,7 @@ class OrbMatcher:
         capi.check(self.lib.osh_orb_match(self.ctx), "osh_orb_match", self.lib)
 
     def download(self) -> dict:
-        names = ["best_idx", "best_dist", "second_dist", "best_level", "second_level"]
+        names = ["best_idx", "best_dist", "second_dist", "best_level", "second_level", "second_idx"]
         outs = [np.zeros(self._shape, dtype=np.int32) for _ in names]
         capi.check(self.lib.osh_orb_download(self.ctx, *[capi.ptr(o, capi.c_int32_p) for o in outs]), "osh_orb_download", self.lib)
         return dict(zip(names, outs))
@@ -93,3 +93,33 @@ def accept_local_points(res: dict, pair_index: int, nn_ratio: float = 0.8, th_hi
     bl, sl = res["best_level"][pair_index], res["second_level"][pair_index]
     ratio_fail = (bl == sl) & (bd.astype(np.float32) > np.float32(nn_ratio) * sd.astype(np.float32))
     return (bd <= th_high) & ~ratio_fail
+
+
+def replay_local_points(res: dict, pair_index: int, rescan, nn_ratio: float = 0.8, th_high: int = 100,
+                        occupied: np.ndarray | None = None, n_train: int | None = None):
+    """Host side of SearchByProjection(Frame&, vector<MapPoint*>&) (src/ORBmatcher.cc:43-141) on top of the
+    device search (SURVEY.md 8a "bit-exactness rule"): walk the queries in order; a query whose best or
+    second-best slot was claimed by an earlier accepted query is re-scanned by `rescan(q, occupied)`
+    -> (best_idx, best_dist, second_dist, best_level, second_level); occupancy only ever removes candidates,
+    so every other query keeps its device result.  Returns (nmatches, assignment[n_train], n_rescans)."""
+    bi, bd, sd = res["best_idx"][pair_index], res["best_dist"][pair_index], res["second_dist"][pair_index]
+    bl, sl, si = res["best_level"][pair_index], res["second_level"][pair_index], res["second_idx"][pair_index]
+    n_train = int(n_train if n_train is not None else max(int(bi.max()), int(si.max())) + 1)
+    occ = np.zeros(n_train, dtype=np.uint8) if occupied is None else occupied
+    pre_occupied = bool(occ.any())
+    assign = -np.ones(n_train, dtype=np.int32)
+    nmatches = rescans = 0
+    ratio = np.float32(nn_ratio)
+    for q in range(bi.shape[0]):
+        b, d1, d2, l1, l2 = int(bi[q]), int(bd[q]), int(sd[q]), int(bl[q]), int(sl[q])
+        if pre_occupied or (b >= 0 and occ[b]) or (si[q] >= 0 and occ[si[q]]):
+            b, d1, d2, l1, l2 = rescan(q, occ)
+            rescans += 1
+        if b < 0 or d1 > th_high:
+            continue
+        if l1 == l2 and np.float32(d1) > ratio * np.float32(d2):
+            continue
+        assign[b] = q
+        occ[b] = 1
+        nmatches += 1
+    return nmatches, assign, rescans

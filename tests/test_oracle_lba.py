@@ -171,9 +171,11 @@ def test_stop_flag_and_zero_iterations():
 
 def test_landmark_seen_only_by_fixed_keyframes_and_unobserved_pose():
     w = synth.make_window(6, n_free=3, n_fixed=2, n_points=40, track_len=(2, 5))
-    # re-point every edge of landmark 0 at a fixed keyframe
-    sel = w.edge_point == 0
-    w.edge_pose[sel] = w.n_free
+    fixed_seen = np.unique(w.edge_point[w.edge_pose >= w.n_free])
+    j = int(fixed_seen[0])
+    keep = ~((w.edge_point == j) & (w.edge_pose < w.n_free))
+    for name in ("edge_pose", "edge_point", "edge_kind", "edge_obs", "edge_info"):
+        setattr(w, name, np.ascontiguousarray(getattr(w, name)[keep]))
     r = ob.lba_solve(w)
     assert r.iterations > 0 and np.all(np.isfinite(r.pose_qt)) and np.all(np.isfinite(r.points))
 
