@@ -156,7 +156,8 @@ int osh_lba_debug_trial(osh_lba_ctx* ctx, int32_t window, double lambda, double*
 #define OSH_K_BACKSUB     4   /* landmark back-substitution + state update        */
 #define OSH_K_RESIDUAL    5   /* residual / robust chi2 of the trial state        */
 #define OSH_K_CONTROL     6   /* LM controller                                    */
-#define OSH_K_COUNT       7
+#define OSH_K_DINV        7   /* per-trial landmark block inverses                */
+#define OSH_K_COUNT       8
 int osh_lba_set_profiling(osh_lba_ctx* ctx, int enable);
 /* launches[k], total_ms[k] accumulated since profiling was (re)enabled */
 int osh_lba_get_profile(osh_lba_ctx* ctx, int64_t launches[OSH_K_COUNT], double total_ms[OSH_K_COUNT]);

@@ -73,7 +73,7 @@ struct Chunk { int win, lm0, lm1; };
 
 // Everything the kernels need, passed by value.
 struct BatchView {
-  int n_windows, n_chunks, n_fposes;
+  int n_windows, n_chunks, n_fposes, n_srows;
   const WinDesc* win;
   LmState* lm;
   const Chunk* chunks;
@@ -93,6 +93,12 @@ struct BatchView {
   const int* lm_nfree;       // [NL] free-pose edges of each landmark
   const int* pel_off;        // per window P+1
   const int* pel_edge;       // [NEfree] window-local sorted edge index, landmark order
+  const int4* srow;          // [n_srows] {window, pose row i, first partner pose base, record offset}
+  const int* srow_nrec;      // [n_srows] records of that (row, partner group)
+  const int4* srec;          // {row edge e, first partner edge q0, partner mask | first<<16, 0}
+  double* dinv;              // [NL*9] per trial: sym (Hll+lambda I)^-1 (00 01 02 11 12 22) + Dinv*b_l (3)
+  double* BD;                // [NE*18] per trial: B_e * Dinv_j per sorted free edge (6x3 row-major)
+  double* cdb;               // [NE*6]  per trial: B_e * (Dinv_j b_l)
   // system
   double* Hpl;               // [NE*18] 6x3 row-major per sorted edge
   double* Hll;               // [NL*6] upper: 00 01 02 11 12 22
@@ -319,80 +325,158 @@ __global__ __launch_bounds__(64) void k_pose_hess(BatchView bv) {
 }
 
 // --------------------------------------------------------------------------------------------
-// k_schur: one wavefront per pose row i of S.  The 6 x 6P row block lives in LDS; lane
-// (slot s = lane/6, column c = lane%6) owns column c of the 6x6 product for partner edge
-// e+s of the current landmark, so no two lanes touch the same LDS word in one step.
+// k_bdinv: per trial.  Landmark side: Dinv = (Hll + lambda I)^-1 (setLambda on Hll, then
+// Matrix3d::inverse, block_solver.hpp:389,582-587) and db = Dinv b_l.  Edge side: for every
+// optimisable-pose edge BD_e = B_e Dinv_j ("BDinv", block_solver.hpp:403) and B_e db
+// (the _coefficients term, :404-409).  Same chunking as k_linearize.
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_schur(BatchView bv) {
-  extern __shared__ __attribute__((aligned(16))) double sh_row[];  // [6][n]
-  const int gp = blockIdx.x;
-  const int w = bv.fpose_win[gp];
-  const WinDesc& wd = bv.win[w];
-  const LmState& st = bv.lm[w];
+__global__ __launch_bounds__(kBlock) void k_bdinv(BatchView bv) {
+  __shared__ double sh_d[9 * kBlock];
+  const Chunk ch = bv.chunks[blockIdx.x];
+  const WinDesc& wd = bv.win[ch.win];
+  const LmState& st = bv.lm[ch.win];
   if (!st.active) return;
-  const int i = gp - wd.fpose_off;
-  const int n = wd.n;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
+  const int nl = ch.lm1 - ch.lm0;
   const double lambda = st.lambda;
-  for (int k = lane; k < 6 * n; k += 64) sh_row[k] = 0.0;
-  __syncthreads();
-  if (lane < 36) {
-    const int r = lane / 6, c = lane % 6;
-    sh_row[r * n + 6 * i + c] = bv.Hpp[(size_t)gp * 36 + lane] + ((r == c) ? lambda : 0.0);  // setLambda on Hpp
+  if (tid < nl) {
+    const size_t gl = (size_t)wd.pt_off + ch.lm0 + tid;
+    const double* hl = bv.Hll + gl * 6;
+    double Dinv[9];
+    dev::inv3_sym(hl[0] + lambda, hl[1], hl[2], hl[3] + lambda, hl[4], hl[5] + lambda, Dinv);
+    const double b0 = bv.bl[gl * 3], b1 = bv.bl[gl * 3 + 1], b2 = bv.bl[gl * 3 + 2];
+    double o[9];
+    o[0] = Dinv[0]; o[1] = Dinv[1]; o[2] = Dinv[2]; o[3] = Dinv[4]; o[4] = Dinv[5]; o[5] = Dinv[8];
+    o[6] = Dinv[0] * b0 + Dinv[1] * b1 + Dinv[2] * b2;
+    o[7] = Dinv[3] * b0 + Dinv[4] * b1 + Dinv[5] * b2;
+    o[8] = Dinv[6] * b0 + Dinv[7] * b1 + Dinv[8] * b2;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { bv.dinv[gl * 9 + k] = o[k]; sh_d[k * kBlock + tid] = o[k]; }
   }
   __syncthreads();
   const int* lmo = bv.lm_off + wd.lmoff_off;
-  const int* po = bv.pel_off + wd.peloff_off;
-  const int lo = po[i], hi = po[i + 1];
-  const int slot = lane / 6, col = lane - slot * 6;
-  double ci[6] = {0, 0, 0, 0, 0, 0};
-  for (int idx = lo; idx < hi; ++idx) {
-    const int e = bv.pel_edge[(size_t)wd.pel_off + idx];
+  const int e0 = lmo[ch.lm0], e1 = lmo[ch.lm1];
+  for (int e = e0 + tid; e < e1; e += kBlock) {
     const size_t ge = (size_t)wd.edge_off + e;
-    const int j = bv.e_point[ge];
-    const size_t gl = (size_t)wd.pt_off + j;
-    const int end = lmo[j] + bv.lm_nfree[gl];  // free-pose edges of landmark j: [lmo[j], end), poses ascending
-    const double* hl = bv.Hll + gl * 6;
-    double Dinv[9];
-    dev::inv3_sym(hl[0] + lambda, hl[1], hl[2], hl[3] + lambda, hl[4], hl[5] + lambda, Dinv);  // setLambda on Hll
-    const double b0 = bv.bl[gl * 3], b1 = bv.bl[gl * 3 + 1], b2 = bv.bl[gl * 3 + 2];
-    const double db0 = Dinv[0] * b0 + Dinv[1] * b1 + Dinv[2] * b2;
-    const double db1 = Dinv[3] * b0 + Dinv[4] * b1 + Dinv[5] * b2;
-    const double db2 = Dinv[6] * b0 + Dinv[7] * b1 + Dinv[8] * b2;
-    const double* Be = bv.Hpl + ge * 18;
-    double BD[18];
+    if (bv.e_pose[ge] >= wd.P) continue;
+    const int ls = bv.e_point[ge] - ch.lm0;
+    double D[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) D[k] = sh_d[k * kBlock + ls];
+    const double* B = bv.Hpl + ge * 18;
+    double* o = bv.BD + ge * 18;
+    double* oc = bv.cdb + ge * 6;
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-      const double x0 = Be[r * 3], x1 = Be[r * 3 + 1], x2 = Be[r * 3 + 2];
-      BD[r * 3 + 0] = x0 * Dinv[0] + x1 * Dinv[3] + x2 * Dinv[6];
-      BD[r * 3 + 1] = x0 * Dinv[1] + x1 * Dinv[4] + x2 * Dinv[7];
-      BD[r * 3 + 2] = x0 * Dinv[2] + x1 * Dinv[5] + x2 * Dinv[8];
-      ci[r] += x0 * db0 + x1 * db1 + x2 * db2;
+      const double x0 = B[r * 3], x1 = B[r * 3 + 1], x2 = B[r * 3 + 2];
+      o[r * 3 + 0] = x0 * D[0] + x1 * D[1] + x2 * D[2];
+      o[r * 3 + 1] = x0 * D[1] + x1 * D[3] + x2 * D[4];
+      o[r * 3 + 2] = x0 * D[2] + x1 * D[4] + x2 * D[5];
+      oc[r] = x0 * D[6] + x1 * D[7] + x2 * D[8];
     }
-    for (int qb = e; qb < end; qb += 10) {
-      const int q = qb + slot;
-      if (slot < 10 && q < end) {
-        const size_t gq = (size_t)wd.edge_off + q;
-        const int i2 = bv.e_pose[gq];
-        const double* Bq = bv.Hpl + gq * 18 + col * 3;
-        const double y0 = Bq[0], y1 = Bq[1], y2 = Bq[2];
-        double* dst = sh_row + 6 * i2 + col;
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// k_schur: one wavefront per (pose row i, group of 10 partner poses base..base+9) of S
+// (block_solver.hpp:381-432).  Lane (t = lane/6, col = lane%6) OWNS column `col` of the 6x6
+// block S(i, base+t) and keeps its 6 entries in registers, so the row is accumulated in
+// landmark order with no atomics and no LDS.  The work list is a stream of records
+// {row edge e, first partner edge q0, mask of the partner poses present}; everything that is
+// the same for all lanes (the record, BD_e = B_e Dinv_j, B_e db) comes in through scalar loads,
+// each lane only fetches its own 3 doubles B_q[col][0..2] of its partner block.
+// --------------------------------------------------------------------------------------------
+constexpr int kSchurPF = 4;  // records kept in flight by the vector loads
+
+// value of `x` in lane `src` (compile-time constant) as a wave-uniform double (2 x v_readlane_b32)
+__device__ __forceinline__ double lane_bcast(double x, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
+  return __hiloint2double(hi, lo);
+}
+
+struct SchurSlot { double ux, uy, y0, y1, y2; };
+
+__global__ __launch_bounds__(64) void k_schur(BatchView bv) {
+  const int4 row = bv.srow[blockIdx.x];
+  const int w = row.x, i = row.y, base = row.z;
+  const WinDesc& wd = bv.win[w];
+  const LmState& st = bv.lm[w];
+  if (!st.active) return;
+  const int nrec = bv.srow_nrec[blockIdx.x];
+  const int n = wd.n;
+  const int lane = threadIdx.x;
+  const int t = lane / 6, col = lane - t * 6;
+  const int i2 = base + t;
+  const bool owner = (t < 10) && (i2 < wd.P);
+  const double lambda = st.lambda;
+  const int4* __restrict__ recs = bv.srec + row.w;
+  const double* __restrict__ Hpl = bv.Hpl + (size_t)wd.edge_off * 18;
+  const double* __restrict__ BDa = bv.BD + (size_t)wd.edge_off * 18;
+  const double* __restrict__ cdb = bv.cdb + (size_t)wd.edge_off * 6;
+  const int gp = wd.fpose_off + i;
+  // v[r] = entry (r, col) of S(i, i2); starts from Hpp + lambda on the diagonal block (setLambda)
+  double v[6];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) dst[r * n] -= BD[r * 3] * y0 + BD[r * 3 + 1] * y1 + BD[r * 3 + 2] * y2;
+  for (int r = 0; r < 6; ++r) v[r] = 0.0;
+  if (owner && i2 == i) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) v[r] = bv.Hpp[(size_t)gp * 36 + r * 6 + col] + ((r == col) ? lambda : 0.0);
+  }
+  double ci[6] = {0, 0, 0, 0, 0, 0};  // B_e db summed over the row (wave-uniform), group 0 only
+  const unsigned below = (1u << t) - 1u;
+  const unsigned mybit = (t < 10) ? (1u << t) : 0u;
+
+  // One record in flight per slot: lanes 0-8 fetch the nine 16-byte units of BD_e, lanes 9-11 those of
+  // B_e db (first record of a landmark only), every owner lane its 3 doubles of the partner block.
+  auto fetch = [&](int k, SchurSlot& sl) {
+    sl.ux = sl.uy = sl.y0 = sl.y1 = sl.y2 = 0.0;
+    if (k < nrec) {
+      const int4 rc = recs[k];  // wave-uniform -> scalar load
+      const unsigned mask = (unsigned)rc.z & 0xffffu;
+      const double2* src = nullptr;
+      if (lane < 9) src = reinterpret_cast<const double2*>(BDa + (size_t)rc.x * 18) + lane;
+      else if (lane < 12 && (rc.z & 0x10000)) src = reinterpret_cast<const double2*>(cdb + (size_t)rc.x * 6) + (lane - 9);
+      if (src) { const double2 u = *src; sl.ux = u.x; sl.uy = u.y; }
+      if (mask & mybit) {
+        const double* q = Hpl + (size_t)(rc.y + __builtin_popcount(mask & below)) * 18 + col * 3;
+        sl.y0 = q[0]; sl.y1 = q[1]; sl.y2 = q[2];
+      }
+    }
+  };
+  SchurSlot slot[kSchurPF];
+#pragma unroll
+  for (int p = 0; p < kSchurPF; ++p) fetch(p, slot[p]);
+  for (int k0 = 0; k0 < nrec; k0 += kSchurPF) {
+#pragma unroll
+    for (int p = 0; p < kSchurPF; ++p) {
+      const int k = k0 + p;
+      if (k < nrec) {
+        const SchurSlot sl = slot[p];
+        fetch(k + kSchurPF, slot[p]);  // refill: the loads fly while the FMAs below run
+        double bd[18];
+#pragma unroll
+        for (int m = 0; m < 18; ++m) bd[m] = lane_bcast((m & 1) ? sl.uy : sl.ux, m >> 1);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) v[r] -= bd[r * 3] * sl.y0 + bd[r * 3 + 1] * sl.y1 + bd[r * 3 + 2] * sl.y2;
+        if (base == i) {
+          // lanes 9-11 hold zeros unless this is the first record of the landmark
+#pragma unroll
+          for (int r = 0; r < 6; ++r) ci[r] += lane_bcast((r & 1) ? sl.uy : sl.ux, 9 + (r >> 1));
+        }
       }
     }
   }
-  __syncthreads();
-  double* S = bv.S + wd.S_off;
-  for (int c = 6 * i + lane; c < n; c += 64) {
+  if (owner) {
+    double* S = bv.S + wd.S_off;
 #pragma unroll
-    for (int r = 0; r < 6; ++r) S[(size_t)(6 * i + r) * n + c] = sh_row[r * n + c];
+    for (int r = 0; r < 6; ++r) S[(size_t)(6 * i + r) * n + 6 * i2 + col] = v[r];
   }
-  if (lane < 6) {
-    double v = ci[0];
-    if (lane == 1) v = ci[1]; else if (lane == 2) v = ci[2]; else if (lane == 3) v = ci[3];
-    else if (lane == 4) v = ci[4]; else if (lane == 5) v = ci[5];
-    bv.bs[(size_t)gp * 6 + lane] = bv.bp[(size_t)gp * 6 + lane] - v;
+  if (base == i && lane < 6) {
+    double c = ci[0];
+    if (lane == 1) c = ci[1]; else if (lane == 2) c = ci[2]; else if (lane == 3) c = ci[3];
+    else if (lane == 4) c = ci[4]; else if (lane == 5) c = ci[5];
+    bv.bs[(size_t)gp * 6 + lane] = bv.bp[(size_t)gp * 6 + lane] - c;
   }
 }
 
@@ -627,16 +711,14 @@ __global__ __launch_bounds__(kBlock) void k_backsub(BatchView bv) {
   double sc = 0.0;
   if (tid < nl) {
     const size_t gl = (size_t)wd.pt_off + ch.lm0 + tid;
-    const double* hl = bv.Hll + gl * 6;
-    double Dinv[9];
-    dev::inv3_sym(hl[0] + lambda, hl[1], hl[2], hl[3] + lambda, hl[4], hl[5] + lambda, Dinv);
+    const double* D = bv.dinv + gl * 9;  // sym 00 01 02 11 12 22
     const double b0 = bv.bl[gl * 3], b1 = bv.bl[gl * 3 + 1], b2 = bv.bl[gl * 3 + 2];
     const double c0 = b0 + acc[0], c1 = b1 + acc[1], c2 = b2 + acc[2];
     double xl[3];
     if (st.solve_ok) {
-      xl[0] = Dinv[0] * c0 + Dinv[1] * c1 + Dinv[2] * c2;
-      xl[1] = Dinv[3] * c0 + Dinv[4] * c1 + Dinv[5] * c2;
-      xl[2] = Dinv[6] * c0 + Dinv[7] * c1 + Dinv[8] * c2;
+      xl[0] = D[0] * c0 + D[1] * c1 + D[2] * c2;
+      xl[1] = D[1] * c0 + D[3] * c1 + D[4] * c2;
+      xl[2] = D[2] * c0 + D[4] * c1 + D[5] * c2;
     } else {
       xl[0] = xl[1] = xl[2] = 0.0;
     }
@@ -815,13 +897,13 @@ struct osh_lba_ctx {
   std::vector<WinDesc> h_win;
   std::vector<const volatile unsigned char*> stop_ptr;
   bool any_stop = false;
-  size_t NP = 0, NFP = 0, NL = 0, NE = 0, NEf = 0, n_chunks = 0;
+  size_t NP = 0, NFP = 0, NL = 0, NE = 0, NEf = 0, NR = 0, n_srows = 0, n_chunks = 0;
   size_t S_total = 0;
   int n_max = 0, solve_nb = 24, solve_W = 0;
   size_t solve_lds = 0, schur_lds = 0, backsub_lds = 0;
   // device buffers
   DevBuf d_win, d_lm, d_chunks, d_fpose_win, d_pose_init, d_pose[2], d_pt_init, d_pt[2], d_cam;
-  DevBuf d_e_pose, d_e_point, d_e_kind, d_e_obs, d_e_info, d_e_orig, d_lm_off, d_lm_nfree, d_pel_off, d_pel_edge;
+  DevBuf d_e_pose, d_e_point, d_e_kind, d_e_obs, d_e_info, d_e_orig, d_lm_off, d_lm_nfree, d_pel_off, d_pel_edge, d_srow, d_srow_nrec, d_srec, d_dinv, d_BD, d_cdb;
   DevBuf d_Hpl, d_Hll, d_bl, d_Hpp, d_bp, d_S, d_bs, d_xp, d_chi, d_scale, d_dmaxc, d_dmaxp, d_nactive, d_out_chi2, d_out_depth, d_stop;
   int* h_nactive = nullptr;          // pinned
   unsigned char* h_stop = nullptr;   // pinned [n_windows]
@@ -859,7 +941,7 @@ extern "C" void osh_lba_destroy(osh_lba_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DevBuf* bufs[] = {&c->d_win, &c->d_lm, &c->d_chunks, &c->d_fpose_win, &c->d_pose_init, &c->d_pose[0], &c->d_pose[1],
                     &c->d_pt_init, &c->d_pt[0], &c->d_pt[1], &c->d_cam, &c->d_e_pose, &c->d_e_point, &c->d_e_kind,
-                    &c->d_e_obs, &c->d_e_info, &c->d_e_orig, &c->d_lm_off, &c->d_lm_nfree, &c->d_pel_off, &c->d_pel_edge,
+                    &c->d_e_obs, &c->d_e_info, &c->d_e_orig, &c->d_lm_off, &c->d_lm_nfree, &c->d_pel_off, &c->d_pel_edge, &c->d_srow, &c->d_srow_nrec, &c->d_srec, &c->d_dinv, &c->d_BD, &c->d_cdb,
                     &c->d_Hpl, &c->d_Hll, &c->d_bl, &c->d_Hpp, &c->d_bp, &c->d_S, &c->d_bs, &c->d_xp, &c->d_chi,
                     &c->d_scale, &c->d_dmaxc, &c->d_dmaxp, &c->d_nactive, &c->d_out_chi2, &c->d_out_depth, &c->d_stop};
   for (DevBuf* b : bufs) b->release();
@@ -929,6 +1011,10 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   std::vector<int> h_epose(NE), h_epoint(NE), h_eorig(NE), h_lmoff(NLO), h_lmnfree(NL), h_peloff(NPO), h_pel(NEf), h_fpw(NFP);
   std::vector<unsigned char> h_kind(NE);
   std::vector<Chunk> h_chunks;
+  std::vector<int4> h_srow, h_rec;
+  std::vector<int> h_srow_nrec;
+  h_rec.reserve(NEf + NEf / 4 + 16);
+  std::vector<std::vector<int4>> grp_recs;
   std::vector<int> cnt, fill, order;
   for (int w = 0; w < nw; ++w) {
     const osh_lba_problem& p = pr[w];
@@ -986,6 +1072,33 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
       const int ip = h_epose[(size_t)d.edge_off + x];
       if (ip < p.n_free) h_pel[(size_t)d.pel_off + fill[ip]++] = x;
     }
+    // Schur work lists: for pose row i and every group of 10 partner poses [i+10h, i+10h+10) the records
+    // {row edge e, first partner edge q0 in the group, mask of the partner poses present | first<<16}
+    for (int i = 0; i < p.n_free; ++i) {
+      const int ngrp = (p.n_free - i + 9) / 10;
+      if ((int)grp_recs.size() < ngrp) grp_recs.resize(ngrp);
+      for (int h = 0; h < ngrp; ++h) grp_recs[h].clear();
+      for (int k = po[i]; k < po[i + 1]; ++k) {
+        const int e = h_pel[(size_t)d.pel_off + k];
+        const int j = h_epoint[(size_t)d.edge_off + e];
+        const int end = lmo[j] + h_lmnfree[(size_t)d.pt_off + j];
+        int cur_h = -1, q0 = 0;
+        unsigned mask = 0;
+        for (int q = e; q <= end; ++q) {
+          const int hq = (q < end) ? (h_epose[(size_t)d.edge_off + q] - i) / 10 : -2;
+          if (hq != cur_h) {
+            if (cur_h >= 0) grp_recs[cur_h].push_back(make_int4(e, q0, (int)(mask | (cur_h == 0 ? 0x10000u : 0u)), 0));
+            cur_h = hq; q0 = q; mask = 0;
+          }
+          if (q < end) mask |= 1u << ((h_epose[(size_t)d.edge_off + q] - i) % 10);
+        }
+      }
+      for (int h = 0; h < ngrp; ++h) {
+        h_srow.push_back(make_int4(w, i, i + 10 * h, (int)h_rec.size()));
+        h_srow_nrec.push_back((int)grp_recs[h].size());
+        h_rec.insert(h_rec.end(), grp_recs[h].begin(), grp_recs[h].end());
+      }
+    }
     // chunks: consecutive landmarks, <= kChunkEdges edges and <= kBlock landmarks (a single
     // landmark with more edges gets its own multi-pass chunk)
     d.chunk_off = (int)h_chunks.size();
@@ -999,10 +1112,13 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
     d.n_chunks = (int)h_chunks.size() - d.chunk_off;
   }
   c->n_chunks = h_chunks.size();
+  c->NR = h_rec.size();
+  c->n_srows = h_srow.size();
+  if (h_rec.size() > 0x7fffff00u) { set_error("batch too large for 32-bit record offsets"); return OSH_ERR_UNSUPPORTED; }
   c->h_e_orig = h_eorig;
 
   // ---- LDS budgets
-  c->schur_lds = (size_t)6 * n_max * sizeof(double);
+  c->schur_lds = 0;
   c->backsub_lds = (size_t)(3 * kChunkEdges + 4 + std::max(n_max, 1)) * sizeof(double);
   {
     const size_t budget = 150 * 1024;
@@ -1036,9 +1152,13 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   OSH_TRY(upload_vec(c->d_lm_nfree, h_lmnfree, s));
   OSH_TRY(upload_vec(c->d_pel_off, h_peloff, s));
   OSH_TRY(upload_vec(c->d_pel_edge, h_pel, s));
+  OSH_TRY(upload_vec(c->d_srow, h_srow, s));
+  OSH_TRY(upload_vec(c->d_srow_nrec, h_srow_nrec, s));
+  OSH_TRY(upload_vec(c->d_srec, h_rec, s));
   auto R = [&](DevBuf& b, size_t bytes) { return b.reserve(std::max<size_t>(bytes, 8)); };
   OSH_TRY(R(c->d_lm, nw * sizeof(LmState)));
   for (int k = 0; k < 2; ++k) { OSH_TRY(R(c->d_pose[k], NP * 7 * 8)); OSH_TRY(R(c->d_pt[k], NL * 3 * 8)); }
+  OSH_TRY(R(c->d_dinv, NL * 9 * 8)); OSH_TRY(R(c->d_BD, NE * 18 * 8)); OSH_TRY(R(c->d_cdb, NE * 6 * 8));
   OSH_TRY(R(c->d_Hpl, NE * 18 * 8)); OSH_TRY(R(c->d_Hll, NL * 6 * 8)); OSH_TRY(R(c->d_bl, NL * 3 * 8));
   OSH_TRY(R(c->d_Hpp, NFP * 36 * 8)); OSH_TRY(R(c->d_bp, NFP * 6 * 8)); OSH_TRY(R(c->d_S, S_total * 8));
   OSH_TRY(R(c->d_bs, NFP * 6 * 8)); OSH_TRY(R(c->d_xp, NFP * 6 * 8));
@@ -1063,6 +1183,9 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   bv.e_obs = c->d_e_obs.as<double>(); bv.e_info = c->d_e_info.as<double>(); bv.e_orig = c->d_e_orig.as<int>();
   bv.lm_off = c->d_lm_off.as<int>(); bv.lm_nfree = c->d_lm_nfree.as<int>();
   bv.pel_off = c->d_pel_off.as<int>(); bv.pel_edge = c->d_pel_edge.as<int>();
+  bv.srow = c->d_srow.as<int4>(); bv.srow_nrec = c->d_srow_nrec.as<int>(); bv.srec = c->d_srec.as<int4>();
+  bv.dinv = c->d_dinv.as<double>(); bv.BD = c->d_BD.as<double>(); bv.cdb = c->d_cdb.as<double>();
+  bv.n_srows = (int)c->n_srows;
   bv.Hpl = c->d_Hpl.as<double>(); bv.Hll = c->d_Hll.as<double>(); bv.bl = c->d_bl.as<double>();
   bv.Hpp = c->d_Hpp.as<double>(); bv.bp = c->d_bp.as<double>(); bv.S = c->d_S.as<double>();
   bv.bs = c->d_bs.as<double>(); bv.xp = c->d_xp.as<double>();
@@ -1076,7 +1199,6 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   static bool attr_done = false;
   if (!attr_done) {
     OSH_HIP(hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-    OSH_HIP(hipFuncSetAttribute((const void*)k_schur, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     OSH_HIP(hipFuncSetAttribute((const void*)k_backsub, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     attr_done = true;
   }
@@ -1143,7 +1265,8 @@ extern "C" int osh_lba_optimize(osh_lba_ctx* c) {
     LAUNCH(OSH_K_LINEARIZE, k_linearize, c->n_chunks, kBlock, 0, c->bv, 0);
     LAUNCH(OSH_K_POSE_HESS, k_pose_hess, c->NFP, 64, 0, c->bv);
     LAUNCH(OSH_K_CONTROL, k_control, c->n_windows, 64, 0, c->bv, 0);
-    LAUNCH(OSH_K_SCHUR, k_schur, c->NFP, 64, c->schur_lds, c->bv);
+    LAUNCH(OSH_K_DINV, k_bdinv, c->n_chunks, kBlock, 0, c->bv);
+    LAUNCH(OSH_K_SCHUR, k_schur, c->n_srows, 64, 0, c->bv);
     LAUNCH(OSH_K_SOLVE, k_solve, c->n_windows, kBlock, c->solve_lds, c->bv, c->solve_nb, c->solve_W);
     LAUNCH(OSH_K_BACKSUB, k_backsub, c->n_chunks, kBlock, c->backsub_lds, c->bv);
     LAUNCH(OSH_K_RESIDUAL, k_linearize, c->n_chunks, kBlock, 0, c->bv, 1);
@@ -1266,7 +1389,8 @@ extern "C" int osh_lba_debug_trial(osh_lba_ctx* c, int32_t window, double lambda
   for (auto& st : h_lm) st.lambda = lambda;
   OSH_HIP(hipMemcpy(c->d_lm.p, h_lm.data(), c->n_windows * sizeof(LmState), hipMemcpyHostToDevice));
   const WinDesc& d = c->h_win[window];
-  if (c->NFP) { hipLaunchKernelGGL(k_schur, dim3((unsigned)c->NFP), dim3(64), c->schur_lds, s, c->bv); OSH_TRY(launch_check("k_schur")); }
+  if (c->n_chunks) { hipLaunchKernelGGL(k_bdinv, dim3((unsigned)c->n_chunks), dim3(kBlock), 0, s, c->bv); OSH_TRY(launch_check("k_bdinv")); }
+  if (c->n_srows) { hipLaunchKernelGGL(k_schur, dim3((unsigned)c->n_srows), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_schur")); }
   OSH_HIP(hipStreamSynchronize(s));
   if (S && d.n) OSH_HIP(hipMemcpy(S, c->d_S.as<double>() + d.S_off, (size_t)d.n * d.n * 8, hipMemcpyDeviceToHost));
   if (bs && d.n) OSH_HIP(hipMemcpy(bs, c->d_bs.as<double>() + (size_t)d.fpose_off * 6, (size_t)d.n * 8, hipMemcpyDeviceToHost));
@@ -1305,6 +1429,6 @@ extern "C" int osh_lba_get_profile(osh_lba_ctx* c, int64_t launches[OSH_K_COUNT]
 }
 
 extern "C" const char* osh_lba_kernel_name(int k) {
-  static const char* names[OSH_K_COUNT] = {"k_linearize", "k_pose_hess", "k_schur", "k_solve", "k_backsub", "k_linearize(residual)", "k_control"};
+  static const char* names[OSH_K_COUNT] = {"k_linearize", "k_pose_hess", "k_schur", "k_solve", "k_backsub", "k_linearize(residual)", "k_control", "k_bdinv"};
   return (k >= 0 && k < OSH_K_COUNT) ? names[k] : "?";
 }
