@@ -33,6 +33,7 @@ constexpr int kBlock = 256;        // threads per block of the edge/landmark ker
 constexpr int kChunkEdges = 256;   // edges handled per pass of a chunk (== kBlock)
 constexpr double kTau = 1e-5;      // OptimizationAlgorithmLevenberg::_tau
 constexpr int kMaxTrials = 10;     // maxTrialsAfterFailure
+constexpr size_t kBdinvLds = (9 * 256 + 2 * 12 * 256) * sizeof(double);  // k_bdinv dynamic LDS (66 KiB)
 
 struct WinDesc {
   int P, F, L, E;
@@ -95,10 +96,10 @@ struct BatchView {
   const int* pel_edge;       // [NEfree] window-local sorted edge index, landmark order
   const int4* srow;          // [n_srows] {window, pose row i, first partner pose base, record offset}
   const int* srow_nrec;      // [n_srows] records of that (row, partner group)
+  const int* srow_perm;      // [n_sblocks] blockIdx -> srow index (or -1): all rows of a window share blockIdx%8 (one XCD / one L2)
   const int4* srec;          // {row edge e, first partner edge q0, partner mask | first<<16, 0}
   double* dinv;              // [NL*9] per trial: sym (Hll+lambda I)^-1 (00 01 02 11 12 22) + Dinv*b_l (3)
-  double* BD;                // [NE*18] per trial: B_e * Dinv_j per sorted free edge (6x3 row-major)
-  double* cdb;               // [NE*6]  per trial: B_e * (Dinv_j b_l)
+  double* bdc;               // [NE*24] per trial, per sorted edge: B_e Dinv_j (6x3 row-major) | B_e (Dinv_j b_l) (6)
   // system
   double* Hpl;               // [NE*18] 6x3 row-major per sorted edge
   double* Hll;               // [NL*6] upper: 00 01 02 11 12 22
@@ -331,7 +332,9 @@ __global__ __launch_bounds__(64) void k_pose_hess(BatchView bv) {
 // (the _coefficients term, :404-409).  Same chunking as k_linearize.
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_bdinv(BatchView bv) {
-  __shared__ double sh_d[9 * kBlock];
+  extern __shared__ __attribute__((aligned(16))) double sh_bd[];
+  double* sh_d = sh_bd;                                               // [9][256] Dinv sym + db per landmark
+  double2* sh_B = reinterpret_cast<double2*>(sh_bd + 9 * kBlock);     // [256][12] Hpl block -> BD block (9 units) | B_e db (3 units)
   const Chunk ch = bv.chunks[blockIdx.x];
   const WinDesc& wd = bv.win[ch.win];
   const LmState& st = bv.lm[ch.win];
@@ -353,27 +356,37 @@ __global__ __launch_bounds__(kBlock) void k_bdinv(BatchView bv) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) { bv.dinv[gl * 9 + k] = o[k]; sh_d[k * kBlock + tid] = o[k]; }
   }
-  __syncthreads();
   const int* lmo = bv.lm_off + wd.lmoff_off;
   const int e0 = lmo[ch.lm0], e1 = lmo[ch.lm1];
-  for (int e = e0 + tid; e < e1; e += kBlock) {
-    const size_t ge = (size_t)wd.edge_off + e;
-    if (bv.e_pose[ge] >= wd.P) continue;
-    const int ls = bv.e_point[ge] - ch.lm0;
-    double D[9];
+  for (int base = e0; base < e1; base += kChunkEdges) {
+    const int ne = min(kChunkEdges, e1 - base);
+    const size_t gb = (size_t)wd.edge_off + base;
+    // coalesced: the chunk's Hpl blocks are one contiguous run of 16-byte units
+    const double2* src = reinterpret_cast<const double2*>(bv.Hpl + gb * 18);
+    __syncthreads();
+    for (int u = tid; u < ne * 9; u += kBlock) { const int ed = u / 9; sh_B[ed * 12 + (u - ed * 9)] = src[u]; }
+    __syncthreads();
+    if (tid < ne) {
+      const size_t ge = gb + tid;
+      const bool free_pose = bv.e_pose[ge] < wd.P;
+      const int ls = bv.e_point[ge] - ch.lm0;
+      double D[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) D[k] = sh_d[k * kBlock + ls];
-    const double* B = bv.Hpl + ge * 18;
-    double* o = bv.BD + ge * 18;
-    double* oc = bv.cdb + ge * 6;
+      for (int k = 0; k < 9; ++k) D[k] = sh_d[k * kBlock + ls];
+      double* B = reinterpret_cast<double*>(sh_B + tid * 12);
+      double* C = B + 18;
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      const double x0 = B[r * 3], x1 = B[r * 3 + 1], x2 = B[r * 3 + 2];
-      o[r * 3 + 0] = x0 * D[0] + x1 * D[1] + x2 * D[2];
-      o[r * 3 + 1] = x0 * D[1] + x1 * D[3] + x2 * D[4];
-      o[r * 3 + 2] = x0 * D[2] + x1 * D[4] + x2 * D[5];
-      oc[r] = x0 * D[6] + x1 * D[7] + x2 * D[8];
+      for (int r = 0; r < 6; ++r) {
+        const double x0 = free_pose ? B[r * 3] : 0.0, x1 = free_pose ? B[r * 3 + 1] : 0.0, x2 = free_pose ? B[r * 3 + 2] : 0.0;
+        B[r * 3 + 0] = x0 * D[0] + x1 * D[1] + x2 * D[2];
+        B[r * 3 + 1] = x0 * D[1] + x1 * D[3] + x2 * D[4];
+        B[r * 3 + 2] = x0 * D[2] + x1 * D[4] + x2 * D[5];
+        C[r] = x0 * D[6] + x1 * D[7] + x2 * D[8];
+      }
     }
+    __syncthreads();
+    double2* dB = reinterpret_cast<double2*>(bv.bdc + gb * 24);
+    for (int u = tid; u < ne * 12; u += kBlock) dB[u] = sh_B[u];
   }
 }
 
@@ -386,24 +399,20 @@ __global__ __launch_bounds__(kBlock) void k_bdinv(BatchView bv) {
 // the same for all lanes (the record, BD_e = B_e Dinv_j, B_e db) comes in through scalar loads,
 // each lane only fetches its own 3 doubles B_q[col][0..2] of its partner block.
 // --------------------------------------------------------------------------------------------
-constexpr int kSchurPF = 4;  // records kept in flight by the vector loads
-
-// value of `x` in lane `src` (compile-time constant) as a wave-uniform double (2 x v_readlane_b32)
-__device__ __forceinline__ double lane_bcast(double x, int src) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
-  return __hiloint2double(hi, lo);
-}
+constexpr int kSchurPF = 4;  // records kept in flight by the vector loads (power of two)
 
 struct SchurSlot { double ux, uy, y0, y1, y2; };
 
 __global__ __launch_bounds__(64) void k_schur(BatchView bv) {
-  const int4 row = bv.srow[blockIdx.x];
+  __shared__ double2 sh_u[kSchurPF * 12];  // per in-flight record: BD_e (9 units) | B_e db (3 units)
+  const int sb = bv.srow_perm[blockIdx.x];
+  if (sb < 0) return;
+  const int4 row = bv.srow[sb];
   const int w = row.x, i = row.y, base = row.z;
   const WinDesc& wd = bv.win[w];
   const LmState& st = bv.lm[w];
   if (!st.active) return;
-  const int nrec = bv.srow_nrec[blockIdx.x];
+  const int nrec = bv.srow_nrec[sb];
   const int n = wd.n;
   const int lane = threadIdx.x;
   const int t = lane / 6, col = lane - t * 6;
@@ -411,9 +420,8 @@ __global__ __launch_bounds__(64) void k_schur(BatchView bv) {
   const bool owner = (t < 10) && (i2 < wd.P);
   const double lambda = st.lambda;
   const int4* __restrict__ recs = bv.srec + row.w;
-  const double* __restrict__ Hpl = bv.Hpl + (size_t)wd.edge_off * 18;
-  const double* __restrict__ BDa = bv.BD + (size_t)wd.edge_off * 18;
-  const double* __restrict__ cdb = bv.cdb + (size_t)wd.edge_off * 6;
+  const char* __restrict__ Hpl = reinterpret_cast<const char*>(bv.Hpl + (size_t)wd.edge_off * 18);
+  const char* __restrict__ bdc = reinterpret_cast<const char*>(bv.bdc + (size_t)wd.edge_off * 24);
   const int gp = wd.fpose_off + i;
   // v[r] = entry (r, col) of S(i, i2); starts from Hpp + lambda on the diagonal block (setLambda)
   double v[6];
@@ -423,23 +431,31 @@ __global__ __launch_bounds__(64) void k_schur(BatchView bv) {
 #pragma unroll
     for (int r = 0; r < 6; ++r) v[r] = bv.Hpp[(size_t)gp * 36 + r * 6 + col] + ((r == col) ? lambda : 0.0);
   }
-  double ci[6] = {0, 0, 0, 0, 0, 0};  // B_e db summed over the row (wave-uniform), group 0 only
+  // lanes 9-11 sum the B_e db units of the row in landmark order (the _coefficients term)
+  double cx = 0.0, cy = 0.0;
   const unsigned below = (1u << t) - 1u;
   const unsigned mybit = (t < 10) ? (1u << t) : 0u;
+  const unsigned lane16 = (unsigned)lane * 16u, col24 = (unsigned)col * 24u;
+  const bool first_group = (base == i);
+  const int unit_lanes = first_group ? 12 : 9;
 
-  // One record in flight per slot: lanes 0-8 fetch the nine 16-byte units of BD_e, lanes 9-11 those of
-  // B_e db (first record of a landmark only), every owner lane its 3 doubles of the partner block.
+  // The 64 records of a block are fetched with one coalesced vector load (a record per lane) and handed
+  // out with v_readlane, so no scalar-load latency sits in front of the dependent address arithmetic.
+  int4 rr = (lane < nrec) ? recs[lane] : make_int4(0, 0, 0, 0);
+  int4 rr_next = (64 + lane < nrec) ? recs[64 + lane] : make_int4(0, 0, 0, 0);
   auto fetch = [&](int k, SchurSlot& sl) {
     sl.ux = sl.uy = sl.y0 = sl.y1 = sl.y2 = 0.0;
     if (k < nrec) {
-      const int4 rc = recs[k];  // wave-uniform -> scalar load
-      const unsigned mask = (unsigned)rc.z & 0xffffu;
-      const double2* src = nullptr;
-      if (lane < 9) src = reinterpret_cast<const double2*>(BDa + (size_t)rc.x * 18) + lane;
-      else if (lane < 12 && (rc.z & 0x10000)) src = reinterpret_cast<const double2*>(cdb + (size_t)rc.x * 6) + (lane - 9);
-      if (src) { const double2 u = *src; sl.ux = u.x; sl.uy = u.y; }
+      const int src = k & 63;
+      const int e = __builtin_amdgcn_readlane(rr.x, src), q0 = __builtin_amdgcn_readlane(rr.y, src);
+      const unsigned mask = (unsigned)__builtin_amdgcn_readlane(rr.z, src) & 0xffffu;
+      if (lane < unit_lanes) {
+        const double2 u = *reinterpret_cast<const double2*>(bdc + ((unsigned)e * 192u + lane16));
+        sl.ux = u.x; sl.uy = u.y;
+      }
       if (mask & mybit) {
-        const double* q = Hpl + (size_t)(rc.y + __builtin_popcount(mask & below)) * 18 + col * 3;
+        const unsigned off = (unsigned)(q0 + __builtin_popcount(mask & below)) * 144u + col24;
+        const double* q = reinterpret_cast<const double*>(Hpl + off);
         sl.y0 = q[0]; sl.y1 = q[1]; sl.y2 = q[2];
       }
     }
@@ -447,23 +463,31 @@ __global__ __launch_bounds__(64) void k_schur(BatchView bv) {
   SchurSlot slot[kSchurPF];
 #pragma unroll
   for (int p = 0; p < kSchurPF; ++p) fetch(p, slot[p]);
+  // stage record 0 in LDS
+  if (lane < 12) sh_u[lane] = make_double2(slot[0].ux, slot[0].uy);
   for (int k0 = 0; k0 < nrec; k0 += kSchurPF) {
 #pragma unroll
     for (int p = 0; p < kSchurPF; ++p) {
       const int k = k0 + p;
       if (k < nrec) {
         const SchurSlot sl = slot[p];
-        fetch(k + kSchurPF, slot[p]);  // refill: the loads fly while the FMAs below run
+        // stage the NEXT record's units while this one is consumed (same wave: LDS ops stay in order)
+        const SchurSlot& nx = slot[(p + 1) & (kSchurPF - 1)];
+        if (lane < 12) sh_u[((p + 1) & (kSchurPF - 1)) * 12 + lane] = make_double2(nx.ux, nx.uy);
+        // broadcast BD_e: nine 16-byte LDS reads with the same address in every lane
         double bd[18];
 #pragma unroll
-        for (int m = 0; m < 18; ++m) bd[m] = lane_bcast((m & 1) ? sl.uy : sl.ux, m >> 1);
+        for (int m = 0; m < 9; ++m) { const double2 u = sh_u[p * 12 + m]; bd[2 * m] = u.x; bd[2 * m + 1] = u.y; }
 #pragma unroll
         for (int r = 0; r < 6; ++r) v[r] -= bd[r * 3] * sl.y0 + bd[r * 3 + 1] * sl.y1 + bd[r * 3 + 2] * sl.y2;
-        if (base == i) {
-          // lanes 9-11 hold zeros unless this is the first record of the landmark
-#pragma unroll
-          for (int r = 0; r < 6; ++r) ci[r] += lane_bcast((r & 1) ? sl.uy : sl.ux, 9 + (r >> 1));
+        cx += sl.ux; cy += sl.uy;  // meaningful in lanes 9-11 of the first group only
+        // refill this slot with record k + kSchurPF; switch record blocks every 64 records
+        const int kn = k + kSchurPF;
+        if ((kn & 63) == 0) {
+          rr = rr_next;
+          rr_next = (kn + 64 + lane < nrec) ? recs[kn + 64 + lane] : make_int4(0, 0, 0, 0);
         }
+        fetch(kn, slot[p]);
       }
     }
   }
@@ -472,11 +496,10 @@ __global__ __launch_bounds__(64) void k_schur(BatchView bv) {
 #pragma unroll
     for (int r = 0; r < 6; ++r) S[(size_t)(6 * i + r) * n + 6 * i2 + col] = v[r];
   }
-  if (base == i && lane < 6) {
-    double c = ci[0];
-    if (lane == 1) c = ci[1]; else if (lane == 2) c = ci[2]; else if (lane == 3) c = ci[3];
-    else if (lane == 4) c = ci[4]; else if (lane == 5) c = ci[5];
-    bv.bs[(size_t)gp * 6 + lane] = bv.bp[(size_t)gp * 6 + lane] - c;
+  if (first_group && lane >= 9 && lane < 12) {
+    const int r0 = (lane - 9) * 2;
+    bv.bs[(size_t)gp * 6 + r0] = bv.bp[(size_t)gp * 6 + r0] - cx;
+    bv.bs[(size_t)gp * 6 + r0 + 1] = bv.bp[(size_t)gp * 6 + r0 + 1] - cy;
   }
 }
 
@@ -897,13 +920,13 @@ struct osh_lba_ctx {
   std::vector<WinDesc> h_win;
   std::vector<const volatile unsigned char*> stop_ptr;
   bool any_stop = false;
-  size_t NP = 0, NFP = 0, NL = 0, NE = 0, NEf = 0, NR = 0, n_srows = 0, n_chunks = 0;
+  size_t NP = 0, NFP = 0, NL = 0, NE = 0, NEf = 0, NR = 0, n_srows = 0, n_sblocks = 0, n_chunks = 0;
   size_t S_total = 0;
   int n_max = 0, solve_nb = 24, solve_W = 0;
   size_t solve_lds = 0, schur_lds = 0, backsub_lds = 0;
   // device buffers
   DevBuf d_win, d_lm, d_chunks, d_fpose_win, d_pose_init, d_pose[2], d_pt_init, d_pt[2], d_cam;
-  DevBuf d_e_pose, d_e_point, d_e_kind, d_e_obs, d_e_info, d_e_orig, d_lm_off, d_lm_nfree, d_pel_off, d_pel_edge, d_srow, d_srow_nrec, d_srec, d_dinv, d_BD, d_cdb;
+  DevBuf d_e_pose, d_e_point, d_e_kind, d_e_obs, d_e_info, d_e_orig, d_lm_off, d_lm_nfree, d_pel_off, d_pel_edge, d_srow, d_srow_nrec, d_srow_perm, d_srec, d_dinv, d_bdc;
   DevBuf d_Hpl, d_Hll, d_bl, d_Hpp, d_bp, d_S, d_bs, d_xp, d_chi, d_scale, d_dmaxc, d_dmaxp, d_nactive, d_out_chi2, d_out_depth, d_stop;
   int* h_nactive = nullptr;          // pinned
   unsigned char* h_stop = nullptr;   // pinned [n_windows]
@@ -941,7 +964,7 @@ extern "C" void osh_lba_destroy(osh_lba_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DevBuf* bufs[] = {&c->d_win, &c->d_lm, &c->d_chunks, &c->d_fpose_win, &c->d_pose_init, &c->d_pose[0], &c->d_pose[1],
                     &c->d_pt_init, &c->d_pt[0], &c->d_pt[1], &c->d_cam, &c->d_e_pose, &c->d_e_point, &c->d_e_kind,
-                    &c->d_e_obs, &c->d_e_info, &c->d_e_orig, &c->d_lm_off, &c->d_lm_nfree, &c->d_pel_off, &c->d_pel_edge, &c->d_srow, &c->d_srow_nrec, &c->d_srec, &c->d_dinv, &c->d_BD, &c->d_cdb,
+                    &c->d_e_obs, &c->d_e_info, &c->d_e_orig, &c->d_lm_off, &c->d_lm_nfree, &c->d_pel_off, &c->d_pel_edge, &c->d_srow, &c->d_srow_nrec, &c->d_srow_perm, &c->d_srec, &c->d_dinv, &c->d_bdc,
                     &c->d_Hpl, &c->d_Hll, &c->d_bl, &c->d_Hpp, &c->d_bp, &c->d_S, &c->d_bs, &c->d_xp, &c->d_chi,
                     &c->d_scale, &c->d_dmaxc, &c->d_dmaxp, &c->d_nactive, &c->d_out_chi2, &c->d_out_depth, &c->d_stop};
   for (DevBuf* b : bufs) b->release();
@@ -1114,6 +1137,20 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   c->n_chunks = h_chunks.size();
   c->NR = h_rec.size();
   c->n_srows = h_srow.size();
+  // XCD-aware launch order (MI355X: 8 XCDs, blocks dealt round-robin, one private L2 each): every row of
+  // window w is given a blockIdx with blockIdx % 8 == w % 8, so the rows that re-read the same Hpl / BD
+  // blocks share one L2.  Speed only, never correctness.
+  std::vector<int> h_perm;
+  {
+    std::vector<std::vector<int>> per_xcd(8);
+    for (size_t r = 0; r < h_srow.size(); ++r) per_xcd[h_srow[r].x & 7].push_back((int)r);
+    size_t longest = 0;
+    for (auto& v : per_xcd) longest = std::max(longest, v.size());
+    h_perm.assign(longest * 8, -1);
+    for (int x = 0; x < 8; ++x)
+      for (size_t k = 0; k < per_xcd[x].size(); ++k) h_perm[k * 8 + x] = per_xcd[x][k];
+  }
+  c->n_sblocks = h_perm.size();
   if (h_rec.size() > 0x7fffff00u) { set_error("batch too large for 32-bit record offsets"); return OSH_ERR_UNSUPPORTED; }
   c->h_e_orig = h_eorig;
 
@@ -1154,11 +1191,12 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   OSH_TRY(upload_vec(c->d_pel_edge, h_pel, s));
   OSH_TRY(upload_vec(c->d_srow, h_srow, s));
   OSH_TRY(upload_vec(c->d_srow_nrec, h_srow_nrec, s));
+  OSH_TRY(upload_vec(c->d_srow_perm, h_perm, s));
   OSH_TRY(upload_vec(c->d_srec, h_rec, s));
   auto R = [&](DevBuf& b, size_t bytes) { return b.reserve(std::max<size_t>(bytes, 8)); };
   OSH_TRY(R(c->d_lm, nw * sizeof(LmState)));
   for (int k = 0; k < 2; ++k) { OSH_TRY(R(c->d_pose[k], NP * 7 * 8)); OSH_TRY(R(c->d_pt[k], NL * 3 * 8)); }
-  OSH_TRY(R(c->d_dinv, NL * 9 * 8)); OSH_TRY(R(c->d_BD, NE * 18 * 8)); OSH_TRY(R(c->d_cdb, NE * 6 * 8));
+  OSH_TRY(R(c->d_dinv, NL * 9 * 8)); OSH_TRY(R(c->d_bdc, NE * 24 * 8));
   OSH_TRY(R(c->d_Hpl, NE * 18 * 8)); OSH_TRY(R(c->d_Hll, NL * 6 * 8)); OSH_TRY(R(c->d_bl, NL * 3 * 8));
   OSH_TRY(R(c->d_Hpp, NFP * 36 * 8)); OSH_TRY(R(c->d_bp, NFP * 6 * 8)); OSH_TRY(R(c->d_S, S_total * 8));
   OSH_TRY(R(c->d_bs, NFP * 6 * 8)); OSH_TRY(R(c->d_xp, NFP * 6 * 8));
@@ -1183,8 +1221,8 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   bv.e_obs = c->d_e_obs.as<double>(); bv.e_info = c->d_e_info.as<double>(); bv.e_orig = c->d_e_orig.as<int>();
   bv.lm_off = c->d_lm_off.as<int>(); bv.lm_nfree = c->d_lm_nfree.as<int>();
   bv.pel_off = c->d_pel_off.as<int>(); bv.pel_edge = c->d_pel_edge.as<int>();
-  bv.srow = c->d_srow.as<int4>(); bv.srow_nrec = c->d_srow_nrec.as<int>(); bv.srec = c->d_srec.as<int4>();
-  bv.dinv = c->d_dinv.as<double>(); bv.BD = c->d_BD.as<double>(); bv.cdb = c->d_cdb.as<double>();
+  bv.srow = c->d_srow.as<int4>(); bv.srow_nrec = c->d_srow_nrec.as<int>(); bv.srow_perm = c->d_srow_perm.as<int>(); bv.srec = c->d_srec.as<int4>();
+  bv.dinv = c->d_dinv.as<double>(); bv.bdc = c->d_bdc.as<double>();
   bv.n_srows = (int)c->n_srows;
   bv.Hpl = c->d_Hpl.as<double>(); bv.Hll = c->d_Hll.as<double>(); bv.bl = c->d_bl.as<double>();
   bv.Hpp = c->d_Hpp.as<double>(); bv.bp = c->d_bp.as<double>(); bv.S = c->d_S.as<double>();
@@ -1200,6 +1238,7 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   if (!attr_done) {
     OSH_HIP(hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     OSH_HIP(hipFuncSetAttribute((const void*)k_backsub, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    OSH_HIP(hipFuncSetAttribute((const void*)k_bdinv, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     attr_done = true;
   }
   return OSH_OK;
@@ -1265,8 +1304,8 @@ extern "C" int osh_lba_optimize(osh_lba_ctx* c) {
     LAUNCH(OSH_K_LINEARIZE, k_linearize, c->n_chunks, kBlock, 0, c->bv, 0);
     LAUNCH(OSH_K_POSE_HESS, k_pose_hess, c->NFP, 64, 0, c->bv);
     LAUNCH(OSH_K_CONTROL, k_control, c->n_windows, 64, 0, c->bv, 0);
-    LAUNCH(OSH_K_DINV, k_bdinv, c->n_chunks, kBlock, 0, c->bv);
-    LAUNCH(OSH_K_SCHUR, k_schur, c->n_srows, 64, 0, c->bv);
+    LAUNCH(OSH_K_DINV, k_bdinv, c->n_chunks, kBlock, kBdinvLds, c->bv);
+    LAUNCH(OSH_K_SCHUR, k_schur, c->n_sblocks, 64, 0, c->bv);
     LAUNCH(OSH_K_SOLVE, k_solve, c->n_windows, kBlock, c->solve_lds, c->bv, c->solve_nb, c->solve_W);
     LAUNCH(OSH_K_BACKSUB, k_backsub, c->n_chunks, kBlock, c->backsub_lds, c->bv);
     LAUNCH(OSH_K_RESIDUAL, k_linearize, c->n_chunks, kBlock, 0, c->bv, 1);
@@ -1389,8 +1428,8 @@ extern "C" int osh_lba_debug_trial(osh_lba_ctx* c, int32_t window, double lambda
   for (auto& st : h_lm) st.lambda = lambda;
   OSH_HIP(hipMemcpy(c->d_lm.p, h_lm.data(), c->n_windows * sizeof(LmState), hipMemcpyHostToDevice));
   const WinDesc& d = c->h_win[window];
-  if (c->n_chunks) { hipLaunchKernelGGL(k_bdinv, dim3((unsigned)c->n_chunks), dim3(kBlock), 0, s, c->bv); OSH_TRY(launch_check("k_bdinv")); }
-  if (c->n_srows) { hipLaunchKernelGGL(k_schur, dim3((unsigned)c->n_srows), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_schur")); }
+  if (c->n_chunks) { hipLaunchKernelGGL(k_bdinv, dim3((unsigned)c->n_chunks), dim3(kBlock), kBdinvLds, s, c->bv); OSH_TRY(launch_check("k_bdinv")); }
+  if (c->n_sblocks) { hipLaunchKernelGGL(k_schur, dim3((unsigned)c->n_sblocks), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_schur")); }
   OSH_HIP(hipStreamSynchronize(s));
   if (S && d.n) OSH_HIP(hipMemcpy(S, c->d_S.as<double>() + d.S_off, (size_t)d.n * d.n * 8, hipMemcpyDeviceToHost));
   if (bs && d.n) OSH_HIP(hipMemcpy(bs, c->d_bs.as<double>() + (size_t)d.fpose_off * 6, (size_t)d.n * 8, hipMemcpyDeviceToHost));
