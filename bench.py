@@ -66,8 +66,32 @@ def make_lba_inputs(args, rank, world):
     """Pure-numpy input generation; runs BEFORE anything touches the GPU (it forks worker processes)."""
     my = osh_dist.shard_indices(args.windows * world, rank, world)   # window w -> rank w mod G
     seeds = [100 + w for w in my]
+    cache = Path(args.cache_inputs) if args.cache_inputs else None
+    if cache is not None and cache.exists():
+        import pickle
+        with open(cache, "rb") as f:          # written by this script (own file), see --prepare-only
+            got = pickle.load(f)
+        if got["seeds"] == seeds:
+            return got["windows"]
     workers = args.workers if args.workers > 0 else max(1, min(16, (os.cpu_count() or 8) // max(1, world)))
-    return generate_windows(seeds, workers=workers)
+    windows = generate_windows(seeds, workers=workers)
+    if cache is not None:
+        import pickle
+        with open(cache, "wb") as f:
+            pickle.dump({"seeds": seeds, "windows": windows}, f)
+    return windows
+
+
+def measured_traffic(kernel, windows_per_gpu):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/traffic.json:
+    FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, separate --pmc passes), or None."""
+    f = ROOT / "profiles" / "traffic.json"
+    if not f.exists():
+        return None
+    t = json.loads(f.read_text())
+    if t.get("windows_per_gpu") != windows_per_gpu:
+        return None
+    return t.get("bytes_per_launch", {}).get(kernel)
 
 
 def run_lba(args, info, windows):
@@ -163,12 +187,16 @@ def main():
     ap.add_argument("--orb-pairs", type=int, default=64, help="2000x2000 frame pairs per GPU per ORB step")
     ap.add_argument("--workers", type=int, default=0, help="input-generation processes (0 = auto; use 1 under rocprofv3: "
                     "the profiler's signal handler hangs on the pool's worker teardown)")
+    ap.add_argument("--cache-inputs", default="", help="pickle file to store / reuse the generated windows")
+    ap.add_argument("--prepare-only", action="store_true", help="generate (and cache) the inputs, then exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-orb", action="store_true")
     args = ap.parse_args()
 
     env_rank, env_world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     windows = make_lba_inputs(args, env_rank, env_world)
+    if args.prepare_only:
+        return
     info = osh_dist.init_from_env()
     if info.world != args.gpus and info.rank == 0 and info.world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={info.world}", file=sys.stderr)
@@ -191,7 +219,7 @@ def main():
     avg_ms = total_ms / max(launches, 1)
     achieved = (alg[dom] / max(launches, 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=achieved / HBM_PEAK_GBS, traffic=None,
+                    frac=achieved / HBM_PEAK_GBS, traffic=measured_traffic(dom, args.windows),
                     avg_launch_ms=avg_ms, launches=launches, algorithmic_bytes_per_launch=alg[dom] / max(launches, 1))
     kernels = {k: dict(launches=prof[k][0], total_ms=round(prof[k][1], 4),
                        alg_GBps=(alg[k] / (prof[k][1] * 1e-3) / 1e9) if (k in alg and prof[k][1] > 0) else None)

@@ -33,6 +33,7 @@ constexpr int kBlock = 256;        // threads per block of the edge/landmark ker
 constexpr int kChunkEdges = 256;   // edges handled per pass of a chunk (== kBlock)
 constexpr double kTau = 1e-5;      // OptimizationAlgorithmLevenberg::_tau
 constexpr int kMaxTrials = 10;     // maxTrialsAfterFailure
+constexpr int kSolveThreads = 512;  // one block per window in k_solve: 2 waves per SIMD (1024 would spill: 128-VGPR cap)
 constexpr size_t kBdinvLds = (9 * 256 + 2 * 12 * 256) * sizeof(double);  // k_bdinv dynamic LDS (66 KiB)
 
 struct WinDesc {
@@ -509,7 +510,9 @@ __global__ __launch_bounds__(64) void k_schur(BatchView bv) {
 // back-substitution, then the pose update T <- exp(x) T and the pose part of computeScale.
 // LDS: U panel [nb][W] (unscaled rows), L panel [nb][W] (rows / pivot), x [n], d [nb].
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_solve(BatchView bv, int nb, int W) {
+template <int NB>
+__global__ __launch_bounds__(kSolveThreads) void k_solve(BatchView bv, int W) {
+  constexpr int nb = NB;
   extern __shared__ __attribute__((aligned(16))) double sh[];   // all LDS scratch is dynamic (16-B aligned base)
   const int w = blockIdx.x;
   const WinDesc& wd = bv.win[w];
@@ -517,13 +520,13 @@ __global__ __launch_bounds__(kBlock) void k_solve(BatchView bv, int nb, int W) {
   if (!st.active) return;
   const int n = wd.n;
   const int tid = threadIdx.x;
-  double* U = sh;                    // [nb][W]
-  double* Lp = sh + (size_t)nb * W;  // [nb][W]
+  double* U = sh;                    // [nb][W]  unscaled panel rows  (d_k * l_jk)
+  double* Lp = sh + (size_t)nb * W;  // [nb][W]  scaled panel rows    (l_jk)
   double* xs = Lp + (size_t)nb * W;  // [W]
   double* dd = xs + W;               // [nb]
   double* part = dd + nb;            // [nb]
-  double* sh4 = part + nb;           // [4]
-  int& sh_ok = *reinterpret_cast<int*>(sh4 + 4);
+  double* shw = part + nb;           // [kSolveThreads/64] cross-wave reduction
+  int& sh_ok = *reinterpret_cast<int*>(shw + kSolveThreads / 64);
   double* A = bv.S + wd.S_off;
   double* rhs = bv.bs + (size_t)wd.fpose_off * 6;
   if (tid == 0) sh_ok = 1;
@@ -532,45 +535,67 @@ __global__ __launch_bounds__(kBlock) void k_solve(BatchView bv, int nb, int W) {
   for (int k0 = 0; k0 < n; k0 += nb) {
     const int kb = min(nb, n - k0);
     const int m = n - k0;  // local columns 0..m-1, rhs at local column m
-    for (int idx = tid; idx < kb * (m + 1); idx += kBlock) {
-      const int r = idx / (m + 1), jj = idx - r * (m + 1);
-      double v;
-      if (jj == m) v = rhs[k0 + r];
-      else v = (jj >= r) ? A[(size_t)(k0 + r) * n + k0 + jj] : 0.0;
-      U[r * W + jj] = v;
+    // ---- 1. diagonal block: load, then factor it with ONE wavefront (LDS ops of a wave stay in order)
+    for (int idx = tid; idx < kb * kb; idx += kSolveThreads) {
+      const int r = idx / kb, c2 = idx - r * kb;
+      U[r * W + c2] = (c2 >= r) ? A[(size_t)(k0 + r) * n + k0 + c2] : 0.0;
     }
     __syncthreads();
-    // factor the panel rows against each other (right-looking inside the panel)
-    for (int k = 0; k < kb; ++k) {
-      const double d = U[k * W + k];
-      if (d == 0.0) { if (tid == 0) sh_ok = 0; }
-      if (tid < kb) part[tid] = (tid > k) ? U[k * W + tid] / d : 0.0;  // l_ik for the rows below k
-      __syncthreads();
-      const int wc = m - k;  // columns k+1..m
-      const int cnt = (kb - k - 1) * wc;
-      for (int idx = tid; idx < cnt; idx += kBlock) {
-        const int ri = idx / wc, cj = idx - ri * wc;
-        const int ii = k + 1 + ri, jj = k + 1 + cj;
-        if (jj >= ii) U[ii * W + jj] -= part[ii] * U[k * W + jj];
+    if (tid < 64) {
+      for (int k = 0; k < kb; ++k) {
+        const double d = U[k * W + k];
+        if (d == 0.0 && tid == 0) sh_ok = 0;
+        const int rows = kb - k - 1;
+        for (int idx = tid; idx < rows * kb; idx += 64) {
+          const int ii = k + 1 + idx / kb, jj = idx - (idx / kb) * kb;
+          if (jj >= ii) U[ii * W + jj] -= (U[k * W + ii] / d) * U[k * W + jj];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
       }
-      __syncthreads();
-    }
-    if (!sh_ok) break;
-    // scaled rows L[k][jj] = U[k][jj] / d_k (zero padded so 4-wide tiles may over-read)
-    for (int idx = tid; idx < kb * (m + 5); idx += kBlock) {
-      const int r = idx / (m + 5), jj = idx - r * (m + 5);
-      const double d = U[r * W + r];
-      Lp[r * W + jj] = (jj > r && jj <= m) ? U[r * W + jj] / d : 0.0;
-      if (jj == r) dd[r] = d;
-      if (jj > m) U[r * W + jj] = 0.0;
+      for (int idx = tid; idx < kb * kb; idx += 64) {
+        const int r = idx / kb, c2 = idx - r * kb;
+        const double d = U[r * W + r];
+        Lp[r * W + c2] = (c2 > r) ? U[r * W + c2] / d : 0.0;
+        if (c2 == r) dd[r] = d;
+      }
     }
     __syncthreads();
-    // trailing update of rows k0+kb .. n-1 (upper part) and of the rhs column: 4x4 register tiles
+    if (!sh_ok) break;
+    // ---- 2. row panel: every thread forward-substitutes whole columns (incl. the rhs column m) in registers
+    for (int jj = kb + tid; jj <= m; jj += kSolveThreads) {
+      double wv[NB];
+#pragma unroll
+      for (int r = 0; r < NB; ++r) {
+        wv[r] = 0.0;
+        if (r < kb) wv[r] = (jj == m) ? rhs[k0 + r] : A[(size_t)(k0 + r) * n + k0 + jj];
+      }
+#pragma unroll
+      for (int r = 1; r < NB; ++r) {
+        if (r < kb) {
+          double acc = wv[r];
+#pragma unroll
+          for (int k = 0; k < r; ++k) acc -= Lp[k * W + r] * wv[k];
+          wv[r] = acc;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < NB; ++r) {
+        if (r < kb) { U[r * W + jj] = wv[r]; Lp[r * W + jj] = (jj < m) ? wv[r] / dd[r] : 0.0; }
+      }
+    }
+    // zero padding so the 4-wide tiles below may over-read
+    for (int idx = tid; idx < kb * 4; idx += kSolveThreads) {
+      const int r = idx >> 2, jj = m + 1 + (idx & 3);
+      U[r * W + jj] = 0.0; Lp[r * W + jj] = 0.0;
+    }
+    __syncthreads();
+    // ---- 3. trailing update of rows k0+kb .. n-1 (upper part) and of the rhs column: 4x4 register tiles
     const int tr = m - kb;  // trailing rows
     if (tr > 0) {
       const int Tr = (tr + 3) >> 2, Tc = (tr + 1 + 3) >> 2;  // column tiles include the rhs column
       const int ntile = Tr * Tc - Tr * (Tr - 1) / 2;
-      for (int t = tid; t < ntile; t += kBlock) {
+      for (int t = tid; t < ntile; t += kSolveThreads) {
         const float bq = (float)(2 * Tc + 1);
         int ti = (int)((bq - sqrtf(fmaxf(bq * bq - 8.0f * (float)t, 0.0f))) * 0.5f);
         ti = max(0, min(ti, Tr - 1));
@@ -578,6 +603,16 @@ __global__ __launch_bounds__(kBlock) void k_solve(BatchView bv, int nb, int W) {
         while (ti + 1 < Tr && (ti + 1) * Tc - (ti + 1) * ti / 2 <= t) ++ti;
         const int tj = ti + (t - (ti * Tc - ti * (ti - 1) / 2));
         const int i0 = kb + 4 * ti, j0 = kb + 4 * tj;
+        // old values first: their latency hides under the FMAs
+        double old[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c2 = 0; c2 < 4; ++c2) {
+            const int ii = i0 + r, jj = j0 + c2;
+            old[r][c2] = 0.0;
+            if (ii < m && jj >= ii && jj <= m) old[r][c2] = (jj == m) ? rhs[k0 + ii] : A[(size_t)(k0 + ii) * n + k0 + jj];
+          }
         double acc[4][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -600,14 +635,14 @@ __global__ __launch_bounds__(kBlock) void k_solve(BatchView bv, int nb, int W) {
           for (int c2 = 0; c2 < 4; ++c2) {
             const int jj = j0 + c2;
             if (jj < ii || jj > m) continue;
-            if (jj == m) rhs[k0 + ii] -= acc[r][c2];
-            else A[(size_t)(k0 + ii) * n + k0 + jj] -= acc[r][c2];
+            if (jj == m) rhs[k0 + ii] = old[r][c2] - acc[r][c2];
+            else A[(size_t)(k0 + ii) * n + k0 + jj] = old[r][c2] - acc[r][c2];
           }
         }
       }
     }
-    // write the factor back: L rows, pivots on the diagonal, forward-substituted rhs
-    for (int idx = tid; idx < kb * (m + 1); idx += kBlock) {
+    // ---- 4. write the factor back: L rows, pivots on the diagonal, forward-substituted rhs
+    for (int idx = tid; idx < kb * (m + 1); idx += kSolveThreads) {
       const int r = idx / (m + 1), jj = idx - r * (m + 1);
       if (jj == m) rhs[k0 + r] = U[r * W + m];
       else if (jj == r) A[(size_t)(k0 + r) * n + k0 + r] = dd[r];
@@ -626,7 +661,7 @@ __global__ __launch_bounds__(kBlock) void k_solve(BatchView bv, int nb, int W) {
       const int kb = min(nb, n - k0);
       const int tail0 = k0 + kb;  // x known for indices >= tail0
       // part[r] = sum_{j>=tail0} L[k0+r][j] x[j] : one wavefront per group of rows
-      for (int r = wv; r < kb; r += 4) {
+      for (int r = wv; r < kb; r += kSolveThreads / 64) {
         double sacc = 0.0;
         const double* row = A + (size_t)(k0 + r) * n;
         for (int j = tail0 + lane; j < n; j += 64) sacc += row[j] * xs[j];
@@ -634,7 +669,7 @@ __global__ __launch_bounds__(kBlock) void k_solve(BatchView bv, int nb, int W) {
         if (lane == 0) part[r] = sacc;
       }
       // diagonal block of the factor (L above the diagonal, pivots on it) and the rhs into LDS
-      for (int idx = tid; idx < kb * kb; idx += kBlock) {
+      for (int idx = tid; idx < kb * kb; idx += kSolveThreads) {
         const int r = idx / kb, c2 = idx - r * kb;
         U[r * W + c2] = (c2 >= r) ? A[(size_t)(k0 + r) * n + k0 + c2] : 0.0;
       }
@@ -652,17 +687,17 @@ __global__ __launch_bounds__(kBlock) void k_solve(BatchView bv, int nb, int W) {
       }
       __syncthreads();
     }
-    for (int k = tid; k < n; k += kBlock) xp[k] = xs[k];
+    for (int k = tid; k < n; k += kSolveThreads) xp[k] = xs[k];
   } else {
     // zero pivot: LinearSolverEigen::solve returns false; the step is rejected by the controller
-    for (int k = tid; k < n; k += kBlock) { xs[k] = 0.0; xp[k] = 0.0; }
+    for (int k = tid; k < n; k += kSolveThreads) { xs[k] = 0.0; xp[k] = 0.0; }
   }
   __syncthreads();
   // pose update into the trial buffer + pose part of computeScale
   const int cur = st.sel, tr_sel = st.sel ^ 1;
   const double lambda = st.lambda;
   double sc = 0.0;
-  for (int i = tid; i < wd.P; i += kBlock) {
+  for (int i = tid; i < wd.P; i += kSolveThreads) {
     double u[6], qin[7], qout[7];
 #pragma unroll
     for (int k = 0; k < 6; ++k) u[k] = xs[6 * i + k];
@@ -675,8 +710,14 @@ __global__ __launch_bounds__(kBlock) void k_solve(BatchView bv, int nb, int W) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) sc += u[k] * (lambda * u[k] + bpi[k]);
   }
-  sc = block_sum(sc, sh4);
-  if (tid == 0) { st.scale_pose = sc; st.solve_ok = ok; }
+  sc = dev::wave_sum(sc);
+  if ((tid & 63) == 0) shw[tid >> 6] = sc;
+  __syncthreads();
+  if (tid == 0) {
+    double tot = 0.0;
+    for (int k = 0; k < kSolveThreads / 64; ++k) tot += shw[k];
+    st.scale_pose = tot; st.solve_ok = ok;
+  }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1160,8 +1201,8 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   {
     const size_t budget = 150 * 1024;
     int nb = 24;
-    auto need = [&](int b) { return ((size_t)2 * b * (n_max + 8) + (n_max + 8) + 2 * b + 8) * sizeof(double); };
-    while (nb > 6 && need(nb) > budget) nb -= 6;
+    auto need = [&](int b) { return ((size_t)2 * b * (n_max + 8) + (n_max + 8) + 2 * b + kSolveThreads / 64 + 8) * sizeof(double); };
+    while (nb > 6 && need(nb) > budget) nb /= 2;  // 24 -> 12 -> 6 (template instantiations of k_solve)
     if (need(nb) > budget || c->schur_lds > budget) {
       set_error("window with %d optimisable poses exceeds the LDS budget of the reduced-system kernels", n_max / 6);
       return OSH_ERR_UNSUPPORTED;
@@ -1236,7 +1277,9 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   // opt in to large dynamic LDS once per process
   static bool attr_done = false;
   if (!attr_done) {
-    OSH_HIP(hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    OSH_HIP(hipFuncSetAttribute((const void*)k_solve<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    OSH_HIP(hipFuncSetAttribute((const void*)k_solve<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    OSH_HIP(hipFuncSetAttribute((const void*)k_solve<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     OSH_HIP(hipFuncSetAttribute((const void*)k_backsub, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     OSH_HIP(hipFuncSetAttribute((const void*)k_bdinv, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     attr_done = true;
@@ -1306,7 +1349,9 @@ extern "C" int osh_lba_optimize(osh_lba_ctx* c) {
     LAUNCH(OSH_K_CONTROL, k_control, c->n_windows, 64, 0, c->bv, 0);
     LAUNCH(OSH_K_DINV, k_bdinv, c->n_chunks, kBlock, kBdinvLds, c->bv);
     LAUNCH(OSH_K_SCHUR, k_schur, c->n_sblocks, 64, 0, c->bv);
-    LAUNCH(OSH_K_SOLVE, k_solve, c->n_windows, kBlock, c->solve_lds, c->bv, c->solve_nb, c->solve_W);
+    if (c->solve_nb == 24) LAUNCH(OSH_K_SOLVE, k_solve<24>, c->n_windows, kSolveThreads, c->solve_lds, c->bv, c->solve_W);
+    else if (c->solve_nb == 12) LAUNCH(OSH_K_SOLVE, k_solve<12>, c->n_windows, kSolveThreads, c->solve_lds, c->bv, c->solve_W);
+    else LAUNCH(OSH_K_SOLVE, k_solve<6>, c->n_windows, kSolveThreads, c->solve_lds, c->bv, c->solve_W);
     LAUNCH(OSH_K_BACKSUB, k_backsub, c->n_chunks, kBlock, c->backsub_lds, c->bv);
     LAUNCH(OSH_K_RESIDUAL, k_linearize, c->n_chunks, kBlock, 0, c->bv, 1);
     if (c->any_stop) {
@@ -1433,7 +1478,9 @@ extern "C" int osh_lba_debug_trial(osh_lba_ctx* c, int32_t window, double lambda
   OSH_HIP(hipStreamSynchronize(s));
   if (S && d.n) OSH_HIP(hipMemcpy(S, c->d_S.as<double>() + d.S_off, (size_t)d.n * d.n * 8, hipMemcpyDeviceToHost));
   if (bs && d.n) OSH_HIP(hipMemcpy(bs, c->d_bs.as<double>() + (size_t)d.fpose_off * 6, (size_t)d.n * 8, hipMemcpyDeviceToHost));
-  hipLaunchKernelGGL(k_solve, dim3((unsigned)c->n_windows), dim3(kBlock), c->solve_lds, s, c->bv, c->solve_nb, c->solve_W);
+  if (c->solve_nb == 24) hipLaunchKernelGGL(k_solve<24>, dim3((unsigned)c->n_windows), dim3(kSolveThreads), c->solve_lds, s, c->bv, c->solve_W);
+  else if (c->solve_nb == 12) hipLaunchKernelGGL(k_solve<12>, dim3((unsigned)c->n_windows), dim3(kSolveThreads), c->solve_lds, s, c->bv, c->solve_W);
+  else hipLaunchKernelGGL(k_solve<6>, dim3((unsigned)c->n_windows), dim3(kSolveThreads), c->solve_lds, s, c->bv, c->solve_W);
   OSH_TRY(launch_check("k_solve"));
   hipLaunchKernelGGL(k_backsub, dim3((unsigned)c->n_chunks), dim3(kBlock), c->backsub_lds, s, c->bv);
   OSH_TRY(launch_check("k_backsub"));
