@@ -1,0 +1,38 @@
+/* Frame.h -- members of ORB_SLAM3::Frame used by ORBmatcher::SearchByProjection
+ * (reference include/Frame.h:112,144,213-246,250-252,281-290,326-329; src/Frame.cc:397-417,658-736).
+ * Minimal test double for the monocular / rectified-stereo layout (Nleft == -1). */
+#ifndef FRAME_H
+#define FRAME_H
+#include <vector>
+#include "CameraModels/GeometricCamera.h"
+#include "MapPoint.h"
+#include "orbslam3_compat.h"
+#define FRAME_GRID_ROWS 48
+#define FRAME_GRID_COLS 64
+namespace ORB_SLAM3 {
+class Frame {
+ public:
+  Frame() {}
+  // candidate generator (src/Frame.cc:658-722): cells ix-major then iy, insertion order inside a cell
+  std::vector<size_t> GetFeaturesInArea(const float& x, const float& y, const float& r, const int minLevel = -1,
+                                        const int maxLevel = -1, const bool bRight = false) const;
+  void AssignFeaturesToGrid();   // src/Frame.cc:397-417 with PosInGrid :726-736
+  Sophus::SE3f GetPose() const { return mTcw; }
+
+  int N = 0;
+  int Nleft = -1, Nright = -1;
+  float mbf = 0, mb = 0;
+  std::vector<cv::KeyPoint> mvKeys, mvKeysUn, mvKeysRight;
+  std::vector<float> mvuRight;
+  std::vector<MapPoint*> mvpMapPoints;
+  std::vector<bool> mvbOutlier;
+  cv::Mat mDescriptors;
+  std::vector<float> mvScaleFactors;
+  GeometricCamera* mpCamera = nullptr;
+  std::vector<std::size_t> mGrid[FRAME_GRID_COLS][FRAME_GRID_ROWS];
+  float mnMinX = 0, mnMaxX = 752, mnMinY = 0, mnMaxY = 480;   // static in the reference
+  float mfGridElementWidthInv = 64.f / 752.f, mfGridElementHeightInv = 48.f / 480.f;
+  Sophus::SE3f mTcw;
+};
+}  // namespace ORB_SLAM3
+#endif

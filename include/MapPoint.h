@@ -1,0 +1,43 @@
+/* MapPoint.h -- members of ORB_SLAM3::MapPoint used on the hot path (reference include/MapPoint.h;
+ * src/MapPoint.cc:118-127,168-201,204,302,426-494,560).  Minimal test double: same names and meaning,
+ * no locking (the real getters copy under mMutexPos / mMutexFeatures). */
+#ifndef MAPPOINT_H
+#define MAPPOINT_H
+#include <map>
+#include <tuple>
+#include "orbslam3_compat.h"
+namespace ORB_SLAM3 {
+class KeyFrame;
+class Map;
+class MapPoint {
+ public:
+  MapPoint(long unsigned int id, const Eigen::Vector3f& Pos, Map* pMap) : mnId(id), mWorldPos(Pos), mpMap(pMap) {}
+  void SetWorldPos(const Eigen::Vector3f& Pos) { mWorldPos = Pos; }
+  Eigen::Vector3f GetWorldPos() { return mWorldPos; }
+  std::map<KeyFrame*, std::tuple<int, int>> GetObservations() { return mObservations; }
+  int Observations() { return nObs; }
+  void AddObservation(KeyFrame* pKF, int idx);
+  void EraseObservation(KeyFrame* pKF);
+  bool isBad() { return mbBad; }
+  Map* GetMap() { return mpMap; }
+  void UpdateNormalAndDepth() { ++mnNormalUpdates; }
+  cv::Mat GetDescriptor() { return mDescriptor.clone(); }
+
+  long unsigned int mnId;
+  long unsigned int mnBALocalForKF = 0;
+  // tracking scratch written by Frame::isInFrustum (src/Frame.cc:513-587), read by SearchByProjection
+  float mTrackProjX = 0, mTrackProjY = 0, mTrackDepth = 0, mTrackProjXR = 0;
+  bool mbTrackInView = false, mbTrackInViewR = false;
+  int mnTrackScaleLevel = 0;
+  float mTrackViewCos = 1.f;
+  // test-double state
+  Eigen::Vector3f mWorldPos;
+  std::map<KeyFrame*, std::tuple<int, int>> mObservations;
+  int nObs = 0;
+  bool mbBad = false;
+  Map* mpMap;
+  cv::Mat mDescriptor;
+  int mnNormalUpdates = 0;
+};
+}  // namespace ORB_SLAM3
+#endif

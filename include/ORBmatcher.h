@@ -1,0 +1,31 @@
+/* ORBmatcher.h -- the SearchByProjection entry points of ORB_SLAM3::ORBmatcher on the hot path, with the
+ * reference's signatures (include/ORBmatcher.h:36-102). */
+#ifndef ORBMATCHER_H
+#define ORBMATCHER_H
+#include <vector>
+#include "Frame.h"
+#include "MapPoint.h"
+#include "orbslam3_compat.h"
+namespace ORB_SLAM3 {
+class ORBmatcher {
+ public:
+  ORBmatcher(float nnratio = 0.6, bool checkOri = true);
+  // src/ORBmatcher.cc:2058-2074 (kept on the host for single pairs; batches go through osh_orb_*)
+  static int DescriptorDistance(const cv::Mat& a, const cv::Mat& b);
+  // src/ORBmatcher.cc:43-213 (TrackLocalMap): device nearest/second-nearest search + host replay of the
+  // sequential "slot already taken" rule.  Nleft == -1 layouts only (fisheye stereo pass = next).
+  int SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th = 3, const bool bFarPoints = false,
+                         const float thFarPoints = 50.0f);
+  // src/ORBmatcher.cc:1676-1887 (TrackWithMotionModel)
+  int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono);
+  static const int TH_LOW;
+  static const int TH_HIGH;
+  static const int HISTO_LENGTH;
+ protected:
+  float RadiusByViewingCos(const float& viewCos);
+  void ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3);
+  float mfNNratio;
+  bool mbCheckOrientation;
+};
+}  // namespace ORB_SLAM3
+#endif

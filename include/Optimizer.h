@@ -1,0 +1,19 @@
+/* Optimizer.h -- the two entry points of ORB_SLAM3::Optimizer that form the local-BA hot path, with the
+ * reference's signatures (include/Optimizer.h:57,86).  Drop-in: same mangled symbols, same side effects. */
+#ifndef OPTIMIZER_H
+#define OPTIMIZER_H
+#include "KeyFrame.h"
+#include "Map.h"
+#include "MapPoint.h"
+namespace ORB_SLAM3 {
+class Optimizer {
+ public:
+  // src/Optimizer.cc:1116-1498.  num_MPs is never assigned by the reference either.
+  void static LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF, int& num_OptKF,
+                                    int& num_MPs, int& num_edges);
+  // src/Optimizer.cc:2387-2964 -- NOT built yet; declared so callers link, aborts loudly.
+  void static LocalInertialBA(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF, int& num_OptKF, int& num_MPs,
+                              int& num_edges, bool bLarge = false, bool bRecInit = false);
+};
+}  // namespace ORB_SLAM3
+#endif

@@ -1,0 +1,108 @@
+/*
+ * orbslam3_compat.h -- tiny stand-ins for the third-party types that appear in the signatures
+ * of the hot path's interface (Eigen::Vector3f/Quaternionf, Sophus::SE3f, cv::KeyPoint, cv::Mat),
+ * so that the host layer of THIS repository compiles in an image without Eigen/Sophus/OpenCV.
+ *
+ * They expose only the members the local-BA / matcher boundary touches.  Inside a
+ * real ORB-SLAM3 tree define ORBSLAM3_HIP_USE_REAL_HEADERS and the genuine headers are used
+ * instead; csrc/host/Optimizer.cc and ORBmatcher.cc only rely on the common subset
+ * (operator(), x()/y()/z()/w(), cast<T>(), unit_quaternion(), translation(), pt/octave/angle,
+ * ptr<T>(row), rows/cols).
+ */
+#ifndef ORBSLAM3_COMPAT_H
+#define ORBSLAM3_COMPAT_H
+
+#ifdef ORBSLAM3_HIP_USE_REAL_HEADERS
+#include <Eigen/Core>
+#include <Eigen/Geometry>
+#include <opencv2/core/core.hpp>
+#include <sophus/se3.hpp>
+#else
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+namespace Eigen {
+template <class T, int R, int C = 1>
+struct Matrix {
+  T v[R * C];
+  Matrix() { for (int i = 0; i < R * C; ++i) v[i] = T(0); }
+  Matrix(T a, T b) { static_assert(R * C == 2, "size"); v[0] = a; v[1] = b; }
+  Matrix(T a, T b, T c) { static_assert(R * C == 3, "size"); v[0] = a; v[1] = b; v[2] = c; }
+  T& operator()(int i) { return v[i]; }
+  const T& operator()(int i) const { return v[i]; }
+  T& operator[](int i) { return v[i]; }
+  const T& operator[](int i) const { return v[i]; }
+  T& operator()(int r, int c) { return v[r * C + c]; }
+  const T& operator()(int r, int c) const { return v[r * C + c]; }
+  template <class U> Matrix<U, R, C> cast() const { Matrix<U, R, C> o; for (int i = 0; i < R * C; ++i) o.v[i] = (U)v[i]; return o; }
+};
+using Vector2d = Matrix<double, 2>;
+using Vector3d = Matrix<double, 3>;
+using Vector3f = Matrix<float, 3>;
+using Vector2f = Matrix<float, 2>;
+
+template <class T>
+struct Quaternion {
+  T qx, qy, qz, qw;
+  Quaternion() : qx(0), qy(0), qz(0), qw(1) {}
+  Quaternion(T w, T x, T y, T z) : qx(x), qy(y), qz(z), qw(w) {}   // Eigen order: w first
+  T x() const { return qx; } T y() const { return qy; } T z() const { return qz; } T w() const { return qw; }
+  template <class U> Quaternion<U> cast() const { return Quaternion<U>((U)qw, (U)qx, (U)qy, (U)qz); }
+  void normalize() { const T n = std::sqrt(qx * qx + qy * qy + qz * qz + qw * qw); qx /= n; qy /= n; qz /= n; qw /= n; }
+};
+using Quaternionf = Quaternion<float>;
+using Quaterniond = Quaternion<double>;
+}  // namespace Eigen
+
+namespace Sophus {
+// SE3 as unit quaternion + translation (the storage KeyFrame::GetPose / SetPose exchange).
+template <class T>
+class SE3 {
+ public:
+  SE3() {}
+  SE3(const Eigen::Quaternion<T>& q, const Eigen::Matrix<T, 3>& t) : q_(q), t_(t) { q_.normalize(); }  // SO3 ctor normalises
+  const Eigen::Quaternion<T>& unit_quaternion() const { return q_; }
+  const Eigen::Matrix<T, 3>& translation() const { return t_; }
+  // p_out = R p + t
+  Eigen::Matrix<T, 3> operator*(const Eigen::Matrix<T, 3>& p) const {
+    const T x = q_.x(), y = q_.y(), z = q_.z(), w = q_.w();
+    const T uvx = T(2) * (y * p(2) - z * p(1)), uvy = T(2) * (z * p(0) - x * p(2)), uvz = T(2) * (x * p(1) - y * p(0));
+    return Eigen::Matrix<T, 3>(p(0) + w * uvx + (y * uvz - z * uvy) + t_(0), p(1) + w * uvy + (z * uvx - x * uvz) + t_(1),
+                               p(2) + w * uvz + (x * uvy - y * uvx) + t_(2));
+  }
+ private:
+  Eigen::Quaternion<T> q_;
+  Eigen::Matrix<T, 3> t_;
+};
+using SE3f = SE3<float>;
+}  // namespace Sophus
+
+namespace cv {
+struct Point2f { float x = 0, y = 0; };
+struct KeyPoint { Point2f pt; float size = 0, angle = -1, response = 0; int octave = 0, class_id = -1; };
+// Row-major byte matrix (only CV_8U descriptor matrices N x 32 cross this boundary).
+class Mat {
+ public:
+  int rows = 0, cols = 0;
+  Mat() {}
+  Mat(int r, int c) : rows(r), cols(c), buf_(new std::vector<uint8_t>((size_t)r * c, 0)), off_(0) {}
+  bool empty() const { return rows == 0; }
+  template <class T> T* ptr(int r = 0) { return reinterpret_cast<T*>(buf_->data() + off_ + (size_t)r * cols); }
+  template <class T> const T* ptr(int r = 0) const { return reinterpret_cast<const T*>(buf_->data() + off_ + (size_t)r * cols); }
+  Mat row(int r) const { Mat m; m.rows = 1; m.cols = cols; m.buf_ = buf_; m.off_ = off_ + (size_t)r * cols; return m; }
+  Mat clone() const { Mat m(rows, cols); if (rows) std::memcpy(m.buf_->data(), buf_->data() + off_, (size_t)rows * cols); return m; }
+ private:
+  std::shared_ptr<std::vector<uint8_t>> buf_;
+  size_t off_ = 0;
+};
+}  // namespace cv
+
+#ifndef EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+#define EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+#endif
+#endif /* ORBSLAM3_HIP_USE_REAL_HEADERS */
+#endif

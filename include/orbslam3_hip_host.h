@@ -1,0 +1,68 @@
+/*
+ * orbslam3_hip_host.h -- C entry points of the C++ host layer (csrc/host/), for tests and bindings.
+ *
+ * The drop-in itself is C++: ORB_SLAM3::Optimizer::LocalBundleAdjustment (include/Optimizer.h) and
+ * ORB_SLAM3::ORBmatcher::SearchByProjection (include/ORBmatcher.h), same signatures as the reference.
+ * These C wrappers build a KeyFrame / MapPoint / Map (or Frame) graph from flat arrays, call the C++
+ * entry points and read the graph back, so the boundary can be exercised from ctypes.
+ */
+#ifndef ORBSLAM3_HIP_HOST_H
+#define ORBSLAM3_HIP_HOST_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct osh_host_graph osh_host_graph;
+
+/* Build a map: n_kf keyframes (ids kf_id, poses Tcw as qx qy qz qw tx ty tz floats, one shared pinhole
+ * fx fy cx cy + bf), n_mp map points, n_obs observations (keyframe index, point index, u v ur with ur<0 for
+ * monocular, octave).  Keypoint k of a keyframe is its k-th observation in array order. */
+osh_host_graph* osh_host_graph_create(int32_t n_kf, const int64_t* kf_id, const float* kf_pose_qt, const float* cam5,
+                                      const float* inv_level_sigma2, int32_t n_levels,
+                                      int32_t n_mp, const int64_t* mp_id, const float* mp_pos,
+                                      int32_t n_obs, const int32_t* obs_kf, const int32_t* obs_mp, const float* obs_uvr,
+                                      const int32_t* obs_octave, int64_t init_kf_id, int32_t inertial);
+void osh_host_graph_destroy(osh_host_graph* g);
+/* covisibility list returned by KeyFrame::GetVectorCovisibleKeyFrames() of keyframe kf_index */
+int osh_host_graph_set_covisible(osh_host_graph* g, int32_t kf_index, int32_t n, const int32_t* kf_indices);
+
+/* Steps 1-6 of Optimizer::LocalBundleAdjustment only (graph -> osh_lba_problem arrays); no GPU needed.
+ * sizes = {P, F, L, E, num_fixedKF}; every array may be NULL.  Returns 0, 1 (no fixed keyframe) or <0. */
+int osh_host_pack_lba(osh_host_graph* g, int32_t kf_index, int32_t sizes[5], double* pose_qt, double* pose_cam,
+                      double* points, int32_t* edge_pose, int32_t* edge_point, uint8_t* edge_kind, double* edge_obs,
+                      double* edge_info, int64_t* pose_kf_id, int64_t* point_mp_id);
+/* ORB_SLAM3::Optimizer::LocalBundleAdjustment(kf, stop_flag, map, ...); counts = num_fixedKF, num_OptKF, num_MPs, num_edges */
+int osh_host_run_lba(osh_host_graph* g, int32_t kf_index, unsigned char* stop_flag, int32_t counts[4]);
+
+void osh_host_get_kf_pose(osh_host_graph* g, int32_t kf_index, float out_qt[7]);
+void osh_host_get_mp_pos(osh_host_graph* g, int32_t mp_index, float out[3]);
+int  osh_host_mp_num_observations(osh_host_graph* g, int32_t mp_index);   /* size of GetObservations() */
+int  osh_host_mp_is_bad(osh_host_graph* g, int32_t mp_index);
+int  osh_host_kf_num_matches(osh_host_graph* g, int32_t kf_index);        /* non-null GetMapPointMatches() */
+int  osh_host_kf_observes(osh_host_graph* g, int32_t kf_index, int32_t mp_index);
+int  osh_host_map_change_index(osh_host_graph* g);
+int  osh_host_kf_pose_sets(osh_host_graph* g, int32_t kf_index);
+
+/* ---- matcher ---- */
+typedef struct osh_host_frame osh_host_frame;
+/* A frame with n keypoints (x y, octave, angle, uRight (<=0: none), 32-byte descriptor), pose Tcw. */
+osh_host_frame* osh_host_frame_create(int32_t n, const float* kp_xy, const int32_t* octave, const float* angle,
+                                      const float* uright, const uint8_t* desc, const float pose_qt[7],
+                                      const float cam4[4], float mbf, float mb, int32_t n_levels, float scale_factor);
+void osh_host_frame_destroy(osh_host_frame* f);
+/* ORBmatcher(nnratio).SearchByProjection(F, vpMapPoints, th): map points given by their tracking scratch
+ * (mTrackProjX/Y/XR, mnTrackScaleLevel, mTrackViewCos, mTrackDepth), descriptor and Observations().
+ * assignment[k] = index of the map point stored in F.mvpMapPoints[k] or -1.  Returns nmatches (<0: error). */
+int osh_host_search_local_points(osh_host_frame* f, int32_t n_mp, const uint8_t* mp_desc, const float* proj_xy,
+                                 const float* proj_xr, const int32_t* level, const float* viewcos, const float* depth,
+                                 const int32_t* n_observations, float nnratio, float th, int32_t* assignment);
+/* ORBmatcher(nnratio, check_ori).SearchByProjection(Current, Last, th, bMono): last_mp[k] = map point index held by
+ * keypoint k of the last frame (-1 none); map points given by world position + descriptor. */
+int osh_host_search_last_frame(osh_host_frame* cur, osh_host_frame* last, const int32_t* last_mp, int32_t n_mp,
+                               const float* mp_pos, const uint8_t* mp_desc, float th, int32_t b_mono, int32_t check_ori,
+                               int32_t* assignment);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -107,6 +107,34 @@ _SIGNATURES = {
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
+# include/orbslam3_hip_host.h (C wrappers of the C++ host layer)
+c_float_p = C.POINTER(C.c_float)
+_HOST_SIGNATURES = {
+    "osh_host_graph_create": (C.c_void_p, [C.c_int32, c_int64_p, c_float_p, c_float_p, c_float_p, C.c_int32, C.c_int32, c_int64_p,
+                                           c_float_p, C.c_int32, c_int32_p, c_int32_p, c_float_p, c_int32_p, C.c_int64, C.c_int32]),
+    "osh_host_graph_destroy": (None, [C.c_void_p]),
+    "osh_host_graph_set_covisible": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_int32_p]),
+    "osh_host_pack_lba": (C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_double_p, c_double_p, c_double_p, c_int32_p, c_int32_p,
+                                    c_uint8_p, c_double_p, c_double_p, c_int64_p, c_int64_p]),
+    "osh_host_run_lba": (C.c_int, [C.c_void_p, C.c_int32, c_uint8_p, c_int32_p]),
+    "osh_host_get_kf_pose": (None, [C.c_void_p, C.c_int32, c_float_p]),
+    "osh_host_get_mp_pos": (None, [C.c_void_p, C.c_int32, c_float_p]),
+    "osh_host_mp_num_observations": (C.c_int, [C.c_void_p, C.c_int32]),
+    "osh_host_mp_is_bad": (C.c_int, [C.c_void_p, C.c_int32]),
+    "osh_host_kf_num_matches": (C.c_int, [C.c_void_p, C.c_int32]),
+    "osh_host_kf_observes": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "osh_host_map_change_index": (C.c_int, [C.c_void_p]),
+    "osh_host_kf_pose_sets": (C.c_int, [C.c_void_p, C.c_int32]),
+    "osh_host_frame_create": (C.c_void_p, [C.c_int32, c_float_p, c_int32_p, c_float_p, c_float_p, c_uint8_p, c_float_p, c_float_p,
+                                           C.c_float, C.c_float, C.c_int32, C.c_float]),
+    "osh_host_frame_destroy": (None, [C.c_void_p]),
+    "osh_host_search_local_points": (C.c_int, [C.c_void_p, C.c_int32, c_uint8_p, c_float_p, c_float_p, c_int32_p, c_float_p, c_float_p,
+                                               c_int32_p, C.c_float, C.c_float, c_int32_p]),
+    "osh_host_search_last_frame": (C.c_int, [C.c_void_p, C.c_void_p, c_int32_p, C.c_int32, c_float_p, c_uint8_p, C.c_float, C.c_int32,
+                                             C.c_int32, c_int32_p]),
+}
+HOST_EXPORTED_SYMBOLS = tuple(_HOST_SIGNATURES)
+
 _lib = None
 
 
@@ -122,7 +150,7 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
             "(there is no CPU fallback for the product path)."
         )
     lib = C.CDLL(str(p))
-    for name, (res, args) in _SIGNATURES.items():
+    for name, (res, args) in list(_SIGNATURES.items()) + list(_HOST_SIGNATURES.items()):
         fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
         fn.restype = res
         fn.argtypes = args

@@ -1,0 +1,264 @@
+// ORBmatcher.cc -- ORB_SLAM3::ORBmatcher::SearchByProjection on MI355X (host side).
+//
+// The candidate loops of the reference (src/ORBmatcher.cc:84-120, 1743-1768) run on the GPU as one batched
+// nearest / second-nearest Hamming search (osh_orb_*); what stays on the host is the geometry that builds the
+// candidate lists (the reference's own Frame::GetFeaturesInArea, a "next" row of SURVEY.md 8f) and the
+// sequential "this slot was just taken" rule, replayed exactly as SURVEY.md 8a prescribes: occupancy only ever
+// removes candidates, so only a query whose best or second-best slot was claimed earlier in the same call is
+// re-scanned with the reference's left-to-right loop.
+#include "ORBmatcher.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "orbslam3_hip.h"
+
+namespace ORB_SLAM3 {
+
+const int ORBmatcher::TH_HIGH = 100;
+const int ORBmatcher::TH_LOW = 50;
+const int ORBmatcher::HISTO_LENGTH = 30;
+
+ORBmatcher::ORBmatcher(float nnratio, bool checkOri) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+
+// src/ORBmatcher.cc:2058-2074: 8 x 32-bit popcount of a XOR b
+int ORBmatcher::DescriptorDistance(const cv::Mat& a, const cv::Mat& b) {
+  const uint32_t* pa = a.ptr<uint32_t>();
+  const uint32_t* pb = b.ptr<uint32_t>();
+  int dist = 0;
+  for (int i = 0; i < 8; ++i) dist += __builtin_popcount(pa[i] ^ pb[i]);
+  return dist;
+}
+
+float ORBmatcher::RadiusByViewingCos(const float& viewCos) { return viewCos > 0.998 ? 2.5 : 4.0; }  // :215-221
+
+namespace {
+
+osh_orb_ctx* thread_ctx() {
+  static thread_local osh_orb_ctx* ctx = nullptr;
+  if (!ctx) {
+    const char* dev = std::getenv("ORBSLAM3_HIP_DEVICE");
+    if (osh_orb_create(dev ? std::atoi(dev) : 0, &ctx) != OSH_OK) {
+      std::fprintf(stderr, "ORBmatcher: cannot create the HIP matcher context: %s\n", osh_last_error());
+      ctx = nullptr;
+    }
+  }
+  return ctx;
+}
+
+struct Search {
+  std::vector<uint8_t> qdesc;            // [nq*32]
+  std::vector<int32_t> off{0}, idx;      // candidate lists (static filters already applied)
+  std::vector<int32_t> best_idx, best_dist, second_dist, best_level, second_level, second_idx;
+  int nq() const { return (int)off.size() - 1; }
+};
+
+// one batched device search of all queries against the frame's descriptors
+bool device_search(Search& s, const cv::Mat& train, const std::vector<int32_t>& level) {
+  const int nq = s.nq();
+  for (auto* v : {&s.best_idx, &s.best_dist, &s.second_dist, &s.best_level, &s.second_level, &s.second_idx}) v->assign(nq, -1);
+  if (nq == 0) return true;
+  osh_orb_ctx* ctx = thread_ctx();
+  if (!ctx) return false;
+  if (s.idx.empty()) s.idx.push_back(0);
+  const int64_t base = 0;
+  osh_orb_batch b;
+  b.n_pairs = 1; b.n_query = nq; b.n_train = train.rows;
+  b.query_desc = s.qdesc.data(); b.train_desc = train.ptr<uint8_t>(0); b.train_level = level.data();
+  b.cand_off = s.off.data(); b.cand_idx = s.idx.data(); b.pair_cand_base = &base;
+  if (osh_orb_upload(ctx, &b) != OSH_OK || osh_orb_match(ctx) != OSH_OK ||
+      osh_orb_download(ctx, s.best_idx.data(), s.best_dist.data(), s.second_dist.data(), s.best_level.data(),
+                       s.second_level.data(), s.second_idx.data()) != OSH_OK) {
+    std::fprintf(stderr, "ORBmatcher: device search failed: %s\n", osh_last_error());
+    return false;
+  }
+  return true;
+}
+
+// the reference's scan of one candidate list with the current occupancy (only for contested queries)
+void rescan(const Search& s, int q, const cv::Mat& train, const std::vector<int32_t>& level, const std::vector<uint8_t>& occupied,
+            int& bestIdx, int& bestDist, int& bestDist2, int& bestLevel, int& bestLevel2) {
+  bestDist = 256; bestLevel = -1; bestDist2 = 256; bestLevel2 = -1; bestIdx = -1;
+  const uint32_t* qd = reinterpret_cast<const uint32_t*>(&s.qdesc[(size_t)q * 32]);
+  for (int c = s.off[q]; c < s.off[q + 1]; ++c) {
+    const int idx = s.idx[c];
+    if (occupied[idx]) continue;
+    const uint32_t* td = train.ptr<uint32_t>(idx);
+    int dist = 0;
+    for (int k = 0; k < 8; ++k) dist += __builtin_popcount(qd[k] ^ td[k]);
+    if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = level[idx]; bestIdx = idx; }
+    else if (dist < bestDist2) { bestLevel2 = level[idx]; bestDist2 = dist; }
+  }
+}
+
+}  // namespace
+
+// src/ORBmatcher.cc:43-213, Nleft == -1 layouts (monocular, rectified stereo, RGB-D).
+int ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th, const bool bFarPoints,
+                                   const float thFarPoints) {
+  if (F.Nleft != -1) {
+    std::fprintf(stderr, "ORBmatcher::SearchByProjection: fisheye-stereo frames (Nleft != -1) are not supported by the MI355X path yet\n");
+    std::abort();  // no silent CPU fallback
+  }
+  const bool bFactor = th != 1.0;
+  std::vector<int32_t> level(F.N);
+  std::vector<uint8_t> occupied(F.N, 0);
+  for (int i = 0; i < F.N; ++i) {
+    level[i] = F.mvKeysUn[i].octave;
+    occupied[i] = (F.mvpMapPoints[i] && F.mvpMapPoints[i]->Observations() > 0) ? 1 : 0;   // :88-90 at call entry
+  }
+  Search s;
+  std::vector<MapPoint*> qMP;
+  for (size_t iMP = 0; iMP < vpMapPoints.size(); iMP++) {
+    MapPoint* pMP = vpMapPoints[iMP];
+    if (!pMP->mbTrackInView && !pMP->mbTrackInViewR) continue;
+    if (bFarPoints && pMP->mTrackDepth > thFarPoints) continue;
+    if (pMP->isBad()) continue;
+    if (!pMP->mbTrackInView) continue;
+    const int nPredictedLevel = pMP->mnTrackScaleLevel;
+    float r = RadiusByViewingCos(pMP->mTrackViewCos);   // window size depends on the viewing direction (:66-72)
+    if (bFactor) r *= th;
+    const float win = r * F.mvScaleFactors[nPredictedLevel];
+    const std::vector<size_t> vIndices = F.GetFeaturesInArea(pMP->mTrackProjX, pMP->mTrackProjY, win, nPredictedLevel - 1, nPredictedLevel);
+    if (vIndices.empty()) continue;
+    for (const size_t idx : vIndices) {
+      if (occupied[idx]) continue;                                  // slots taken before this call
+      if (F.mvuRight[idx] > 0) {                                    // stereo consistency window (:92-97)
+        const float er = std::fabs(pMP->mTrackProjXR - F.mvuRight[idx]);
+        if (er > win) continue;
+      }
+      s.idx.push_back((int32_t)idx);
+    }
+    s.off.push_back((int32_t)s.idx.size());
+    const cv::Mat d = pMP->GetDescriptor();
+    const uint8_t* dp = d.ptr<uint8_t>(0);
+    s.qdesc.insert(s.qdesc.end(), dp, dp + 32);
+    qMP.push_back(pMP);
+  }
+  if (!device_search(s, F.mDescriptors, level)) return 0;
+
+  int nmatches = 0;
+  std::vector<uint8_t> taken(F.N, 0);  // slots claimed during this call
+  for (int q = 0; q < s.nq(); ++q) {
+    int bestIdx = s.best_idx[q], bestDist = s.best_dist[q], bestDist2 = s.second_dist[q];
+    int bestLevel = s.best_level[q], bestLevel2 = s.second_level[q];
+    if ((bestIdx >= 0 && taken[bestIdx]) || (s.second_idx[q] >= 0 && taken[s.second_idx[q]]))
+      rescan(s, q, F.mDescriptors, level, taken, bestIdx, bestDist, bestDist2, bestLevel, bestLevel2);
+    // ratio to the second match only if both are in the same scale level; the product is a float (:123-139)
+    if (bestDist <= TH_HIGH) {
+      if (bestLevel == bestLevel2 && bestDist > mfNNratio * bestDist2) continue;
+      if (bestLevel != bestLevel2 || bestDist <= mfNNratio * bestDist2) {
+        F.mvpMapPoints[bestIdx] = qMP[q];
+        if (qMP[q]->Observations() > 0) taken[bestIdx] = 1;
+        nmatches++;
+      }
+    }
+  }
+  return nmatches;
+}
+
+// src/ORBmatcher.cc:2012-2053
+void ORBmatcher::ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3) {
+  int max1 = 0, max2 = 0, max3 = 0;
+  for (int i = 0; i < L; i++) {
+    const int n = (int)histo[i].size();
+    if (n > max1) { max3 = max2; max2 = max1; max1 = n; ind3 = ind2; ind2 = ind1; ind1 = i; }
+    else if (n > max2) { max3 = max2; max2 = n; ind3 = ind2; ind2 = i; }
+    else if (n > max3) { max3 = n; ind3 = i; }
+  }
+  if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+  else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+// src/ORBmatcher.cc:1676-1887, Nleft == -1 layouts.
+int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono) {
+  if (CurrentFrame.Nleft != -1 || LastFrame.Nleft != -1) {
+    std::fprintf(stderr, "ORBmatcher::SearchByProjection: fisheye-stereo frames are not supported by the MI355X path yet\n");
+    std::abort();
+  }
+  std::vector<int> rotHist[30];
+  for (int i = 0; i < HISTO_LENGTH; i++) rotHist[i].reserve(500);
+  const float factor = 1.0f / HISTO_LENGTH;
+  const Sophus::SE3f Tcw = CurrentFrame.GetPose();
+  // twc = -Rcw^T tcw ; tlc = Tlw * twc  (forward / backward motion test, :1686-1693)
+  const Eigen::Quaternionf qc = Tcw.unit_quaternion();
+  const Sophus::SE3f Twc_rot(Eigen::Quaternionf(qc.w(), -qc.x(), -qc.y(), -qc.z()), Eigen::Vector3f(0, 0, 0));
+  const Eigen::Vector3f mt(-Tcw.translation()(0), -Tcw.translation()(1), -Tcw.translation()(2));
+  const Eigen::Vector3f twc = Twc_rot * mt;
+  const Eigen::Vector3f tlc = LastFrame.GetPose() * twc;
+  const bool bForward = tlc(2) > CurrentFrame.mb && !bMono;
+  const bool bBackward = -tlc(2) > CurrentFrame.mb && !bMono;
+
+  std::vector<int32_t> level(CurrentFrame.N);
+  std::vector<uint8_t> occupied(CurrentFrame.N, 0);
+  for (int i = 0; i < CurrentFrame.N; ++i) {
+    level[i] = CurrentFrame.mvKeysUn[i].octave;
+    occupied[i] = (CurrentFrame.mvpMapPoints[i] && CurrentFrame.mvpMapPoints[i]->Observations() > 0) ? 1 : 0;
+  }
+  Search s;
+  std::vector<int> qLast;  // index in LastFrame of every query
+  for (int i = 0; i < LastFrame.N; i++) {
+    MapPoint* pMP = LastFrame.mvpMapPoints[i];
+    if (!pMP || LastFrame.mvbOutlier[i]) continue;
+    const Eigen::Vector3f x3Dc = Tcw * pMP->GetWorldPos();
+    const float invzc = 1.0 / x3Dc(2);
+    if (invzc < 0) continue;
+    const Eigen::Vector2f uv = CurrentFrame.mpCamera->project(x3Dc);
+    if (uv(0) < CurrentFrame.mnMinX || uv(0) > CurrentFrame.mnMaxX) continue;
+    if (uv(1) < CurrentFrame.mnMinY || uv(1) > CurrentFrame.mnMaxY) continue;
+    const int nLastOctave = LastFrame.mvKeys[i].octave;
+    const float radius = th * CurrentFrame.mvScaleFactors[nLastOctave];   // window scales with the octave
+    std::vector<size_t> vIndices2;
+    if (bForward) vIndices2 = CurrentFrame.GetFeaturesInArea(uv(0), uv(1), radius, nLastOctave);
+    else if (bBackward) vIndices2 = CurrentFrame.GetFeaturesInArea(uv(0), uv(1), radius, 0, nLastOctave);
+    else vIndices2 = CurrentFrame.GetFeaturesInArea(uv(0), uv(1), radius, nLastOctave - 1, nLastOctave + 1);
+    if (vIndices2.empty()) continue;
+    for (const size_t i2 : vIndices2) {
+      if (occupied[i2]) continue;
+      if (CurrentFrame.mvuRight[i2] > 0) {
+        const float ur = uv(0) - CurrentFrame.mbf * invzc;
+        const float er = std::fabs(ur - CurrentFrame.mvuRight[i2]);
+        if (er > radius) continue;
+      }
+      s.idx.push_back((int32_t)i2);
+    }
+    s.off.push_back((int32_t)s.idx.size());
+    const cv::Mat d = pMP->GetDescriptor();
+    const uint8_t* dp = d.ptr<uint8_t>(0);
+    s.qdesc.insert(s.qdesc.end(), dp, dp + 32);
+    qLast.push_back(i);
+  }
+  if (!device_search(s, CurrentFrame.mDescriptors, level)) return 0;
+
+  int nmatches = 0;
+  std::vector<uint8_t> taken(CurrentFrame.N, 0);
+  for (int q = 0; q < s.nq(); ++q) {
+    int bestIdx2 = s.best_idx[q], bestDist = s.best_dist[q], d2, l1, l2;
+    if (bestIdx2 >= 0 && taken[bestIdx2]) rescan(s, q, CurrentFrame.mDescriptors, level, taken, bestIdx2, bestDist, d2, l1, l2);
+    if (bestDist > TH_HIGH) continue;
+    MapPoint* pMP = LastFrame.mvpMapPoints[qLast[q]];
+    CurrentFrame.mvpMapPoints[bestIdx2] = pMP;
+    if (pMP->Observations() > 0) taken[bestIdx2] = 1;
+    nmatches++;
+    if (mbCheckOrientation) {
+      float rot = LastFrame.mvKeysUn[qLast[q]].angle - CurrentFrame.mvKeysUn[bestIdx2].angle;
+      if (rot < 0.0) rot += 360.0f;
+      int bin = (int)std::round(rot * factor);   // factor = 1/30 (sic): only bins 0..12 are ever hit
+      if (bin == HISTO_LENGTH) bin = 0;
+      rotHist[bin].push_back(bestIdx2);
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (const int slot : rotHist[i]) { CurrentFrame.mvpMapPoints[slot] = nullptr; nmatches--; }
+    }
+  }
+  return nmatches;
+}
+
+}  // namespace ORB_SLAM3

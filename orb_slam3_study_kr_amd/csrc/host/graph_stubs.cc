@@ -1,0 +1,73 @@
+// graph_stubs.cc -- bodies of the few KeyFrame / MapPoint / Frame methods of the minimal test doubles in include/
+// (a real ORB-SLAM3 tree supplies its own; only Optimizer.cc / ORBmatcher.cc are the drop-in).
+#include <algorithm>
+#include <cmath>
+#include "Frame.h"
+#include "KeyFrame.h"
+#include "MapPoint.h"
+
+namespace ORB_SLAM3 {
+
+// src/KeyFrame.cc:309-332 (index looked up through the point's observation)
+void KeyFrame::EraseMapPointMatch(MapPoint* pMP) {
+  for (size_t i = 0; i < mvpMapPoints.size(); ++i)
+    if (mvpMapPoints[i] == pMP) mvpMapPoints[i] = nullptr;
+}
+
+void MapPoint::AddObservation(KeyFrame* pKF, int idx) {
+  if (mObservations.count(pKF)) return;
+  mObservations[pKF] = std::make_tuple(idx, -1);
+  nObs += (pKF->mvuRight[idx] >= 0) ? 2 : 1;   // src/MapPoint.cc:150-165
+}
+
+// src/MapPoint.cc:168-201: drop the observation; a point left with <= 2 observations goes bad
+void MapPoint::EraseObservation(KeyFrame* pKF) {
+  auto it = mObservations.find(pKF);
+  if (it == mObservations.end()) return;
+  const int leftIndex = std::get<0>(it->second);
+  if (leftIndex != -1) nObs -= (pKF->mvuRight[leftIndex] >= 0) ? 2 : 1;
+  mObservations.erase(it);
+  if (nObs <= 2) mbBad = true;
+}
+
+// src/Frame.cc:397-417 + PosInGrid :726-736
+void Frame::AssignFeaturesToGrid() {
+  for (int i = 0; i < FRAME_GRID_COLS; ++i)
+    for (int j = 0; j < FRAME_GRID_ROWS; ++j) mGrid[i][j].clear();
+  for (int i = 0; i < N; ++i) {
+    const cv::KeyPoint& kp = mvKeysUn[i];
+    const int posX = (int)std::round((kp.pt.x - mnMinX) * mfGridElementWidthInv);
+    const int posY = (int)std::round((kp.pt.y - mnMinY) * mfGridElementHeightInv);
+    if (posX < 0 || posX >= FRAME_GRID_COLS || posY < 0 || posY >= FRAME_GRID_ROWS) continue;
+    mGrid[posX][posY].push_back(i);
+  }
+}
+
+// Candidate generator with the semantics of src/Frame.cc:658-722: a square window |dx| < r, |dy| < r
+// (strict), optional octave band, results ordered by grid column, then grid row, then insertion order.
+std::vector<size_t> Frame::GetFeaturesInArea(const float& x, const float& y, const float& r, const int minLevel,
+                                             const int maxLevel, const bool) const {
+  std::vector<size_t> hits;
+  hits.reserve(N);
+  // first / last grid cell touched along one axis, or false when the window misses the grid
+  auto cell_span = [](float centre, float origin, float radius, float inv, int ncell, int& lo, int& hi) {
+    lo = std::max(0, (int)std::floor((centre - origin - radius) * inv));
+    if (lo >= ncell) return false;
+    hi = std::min(ncell - 1, (int)std::ceil((centre - origin + radius) * inv));
+    return hi >= 0;
+  };
+  int c0, c1, r0, r1;
+  if (!cell_span(x, mnMinX, r, mfGridElementWidthInv, FRAME_GRID_COLS, c0, c1)) return hits;
+  if (!cell_span(y, mnMinY, r, mfGridElementHeightInv, FRAME_GRID_ROWS, r0, r1)) return hits;
+  const bool band = (minLevel > 0) || (maxLevel >= 0);
+  for (int gc = c0; gc <= c1; ++gc)
+    for (int gr = r0; gr <= r1; ++gr)
+      for (const size_t k : mGrid[gc][gr]) {
+        const cv::KeyPoint& kp = mvKeysUn[k];
+        if (band && (kp.octave < minLevel || (maxLevel >= 0 && kp.octave > maxLevel))) continue;
+        if (std::fabs(kp.pt.x - x) < r && std::fabs(kp.pt.y - y) < r) hits.push_back(k);
+      }
+  return hits;
+}
+
+}  // namespace ORB_SLAM3

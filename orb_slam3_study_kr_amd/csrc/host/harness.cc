@@ -1,0 +1,206 @@
+// harness.cc -- extern "C" wrappers around the C++ host layer (include/orbslam3_hip_host.h).
+#include <cmath>
+#include <memory>
+#include <vector>
+
+#include "Frame.h"
+#include "ORBmatcher.h"
+#include "Optimizer.h"
+#include "host_pack.h"
+#include "orbslam3_hip_host.h"
+
+using namespace ORB_SLAM3;
+
+struct osh_host_graph {
+  Map map;
+  std::unique_ptr<Pinhole> cam;
+  std::vector<std::unique_ptr<KeyFrame>> kfs;
+  std::vector<std::unique_ptr<MapPoint>> mps;
+};
+
+static Sophus::SE3f pose_from(const float* qt) {
+  return Sophus::SE3f(Eigen::Quaternionf(qt[3], qt[0], qt[1], qt[2]), Eigen::Vector3f(qt[4], qt[5], qt[6]));
+}
+
+extern "C" osh_host_graph* osh_host_graph_create(int32_t n_kf, const int64_t* kf_id, const float* kf_pose_qt, const float* cam5,
+                                                 const float* inv_level_sigma2, int32_t n_levels, int32_t n_mp,
+                                                 const int64_t* mp_id, const float* mp_pos, int32_t n_obs, const int32_t* obs_kf,
+                                                 const int32_t* obs_mp, const float* obs_uvr, const int32_t* obs_octave,
+                                                 int64_t init_kf_id, int32_t inertial) {
+  osh_host_graph* g = new osh_host_graph();
+  g->map.mnInitKFid = (unsigned long)init_kf_id;
+  g->map.mbIsInertial = inertial != 0;
+  g->cam.reset(new Pinhole(std::vector<float>{cam5[0], cam5[1], cam5[2], cam5[3]}));
+  for (int i = 0; i < n_kf; ++i) {
+    std::unique_ptr<KeyFrame> kf(new KeyFrame((unsigned long)kf_id[i], &g->map));
+    kf->SetPose(pose_from(kf_pose_qt + 7 * i));
+    kf->mnPoseSets = 0;
+    kf->fx = cam5[0]; kf->fy = cam5[1]; kf->cx = cam5[2]; kf->cy = cam5[3]; kf->mbf = cam5[4];
+    kf->mpCamera = g->cam.get();
+    kf->mvInvLevelSigma2.assign(inv_level_sigma2, inv_level_sigma2 + n_levels);
+    g->kfs.push_back(std::move(kf));
+  }
+  for (int j = 0; j < n_mp; ++j)
+    g->mps.emplace_back(new MapPoint((unsigned long)mp_id[j], Eigen::Vector3f(mp_pos[3 * j], mp_pos[3 * j + 1], mp_pos[3 * j + 2]), &g->map));
+  for (int o = 0; o < n_obs; ++o) {
+    KeyFrame* kf = g->kfs[obs_kf[o]].get();
+    MapPoint* mp = g->mps[obs_mp[o]].get();
+    cv::KeyPoint kp;
+    kp.pt.x = obs_uvr[3 * o]; kp.pt.y = obs_uvr[3 * o + 1]; kp.octave = obs_octave[o];
+    const int idx = (int)kf->mvKeysUn.size();
+    kf->mvKeysUn.push_back(kp);
+    kf->mvuRight.push_back(obs_uvr[3 * o + 2]);
+    kf->mvpMapPoints.push_back(mp);
+    kf->N = idx + 1;
+    mp->AddObservation(kf, idx);
+  }
+  return g;
+}
+
+extern "C" void osh_host_graph_destroy(osh_host_graph* g) { delete g; }
+
+extern "C" int osh_host_graph_set_covisible(osh_host_graph* g, int32_t kf_index, int32_t n, const int32_t* kf_indices) {
+  if (!g || kf_index < 0 || kf_index >= (int)g->kfs.size()) return -1;
+  auto& v = g->kfs[kf_index]->mvpOrderedConnectedKeyFrames;
+  v.clear();
+  for (int i = 0; i < n; ++i) v.push_back(g->kfs[kf_indices[i]].get());
+  return 0;
+}
+
+extern "C" int osh_host_pack_lba(osh_host_graph* g, int32_t kf_index, int32_t sizes[5], double* pose_qt, double* pose_cam,
+                                 double* points, int32_t* edge_pose, int32_t* edge_point, uint8_t* edge_kind, double* edge_obs,
+                                 double* edge_info, int64_t* pose_kf_id, int64_t* point_mp_id) {
+  if (!g || kf_index < 0 || kf_index >= (int)g->kfs.size()) return -1;
+  LbaPack pk;
+  const bool ok = PackLocalBA(g->kfs[kf_index].get(), &g->map, pk);
+  // PackLocalBA marks the graph like the reference does; undo so the call can be repeated
+  for (auto& kf : g->kfs) { kf->mnBALocalForKF = 0; kf->mnBAFixedForKF = 0; }
+  for (auto& mp : g->mps) mp->mnBALocalForKF = 0;
+  sizes[0] = pk.n_free; sizes[1] = pk.n_fixed; sizes[2] = (int32_t)pk.vPointMPs.size(); sizes[3] = (int32_t)pk.edge_pose.size();
+  sizes[4] = pk.num_fixedKF;
+  if (!ok) return 1;
+  if (pk.unsupported) return -3;
+  auto cp = [](auto* dst, const auto& src) { if (dst) std::copy(src.begin(), src.end(), dst); };
+  cp(pose_qt, pk.pose_qt); cp(pose_cam, pk.pose_cam); cp(points, pk.points); cp(edge_pose, pk.edge_pose);
+  cp(edge_point, pk.edge_point); cp(edge_kind, pk.edge_kind); cp(edge_obs, pk.edge_obs); cp(edge_info, pk.edge_info);
+  if (pose_kf_id) for (size_t i = 0; i < pk.vPoseKFs.size(); ++i) pose_kf_id[i] = (int64_t)pk.vPoseKFs[i]->mnId;
+  if (point_mp_id) for (size_t j = 0; j < pk.vPointMPs.size(); ++j) point_mp_id[j] = (int64_t)pk.vPointMPs[j]->mnId;
+  return 0;
+}
+
+extern "C" int osh_host_run_lba(osh_host_graph* g, int32_t kf_index, unsigned char* stop_flag, int32_t counts[4]) {
+  if (!g || kf_index < 0 || kf_index >= (int)g->kfs.size()) return -1;
+  static_assert(sizeof(bool) == 1, "bool is one byte");
+  int a = -1, b = -1, c = -1, d = -1;
+  Optimizer::LocalBundleAdjustment(g->kfs[kf_index].get(), reinterpret_cast<bool*>(stop_flag), &g->map, a, b, c, d);
+  counts[0] = a; counts[1] = b; counts[2] = c; counts[3] = d;
+  return 0;
+}
+
+extern "C" void osh_host_get_kf_pose(osh_host_graph* g, int32_t i, float o[7]) {
+  const Sophus::SE3f T = g->kfs[i]->GetPose();
+  o[0] = T.unit_quaternion().x(); o[1] = T.unit_quaternion().y(); o[2] = T.unit_quaternion().z(); o[3] = T.unit_quaternion().w();
+  o[4] = T.translation()(0); o[5] = T.translation()(1); o[6] = T.translation()(2);
+}
+extern "C" void osh_host_get_mp_pos(osh_host_graph* g, int32_t j, float o[3]) {
+  const Eigen::Vector3f p = g->mps[j]->GetWorldPos();
+  o[0] = p(0); o[1] = p(1); o[2] = p(2);
+}
+extern "C" int osh_host_mp_num_observations(osh_host_graph* g, int32_t j) { return (int)g->mps[j]->GetObservations().size(); }
+extern "C" int osh_host_mp_is_bad(osh_host_graph* g, int32_t j) { return g->mps[j]->isBad() ? 1 : 0; }
+extern "C" int osh_host_kf_num_matches(osh_host_graph* g, int32_t i) {
+  int n = 0;
+  for (MapPoint* p : g->kfs[i]->GetMapPointMatches()) n += p != nullptr;
+  return n;
+}
+extern "C" int osh_host_kf_observes(osh_host_graph* g, int32_t i, int32_t j) {
+  return g->mps[j]->GetObservations().count(g->kfs[i].get()) ? 1 : 0;
+}
+extern "C" int osh_host_map_change_index(osh_host_graph* g) { return g->map.GetMapChangeIndex(); }
+extern "C" int osh_host_kf_pose_sets(osh_host_graph* g, int32_t i) { return g->kfs[i]->mnPoseSets; }
+
+// ------------------------------------------------------------------------------------------ matcher
+struct osh_host_frame {
+  Frame F;
+  std::unique_ptr<Pinhole> cam;
+  Map map;
+};
+
+extern "C" osh_host_frame* osh_host_frame_create(int32_t n, const float* kp_xy, const int32_t* octave, const float* angle,
+                                                 const float* uright, const uint8_t* desc, const float pose_qt[7],
+                                                 const float cam4[4], float mbf, float mb, int32_t n_levels, float scale_factor) {
+  osh_host_frame* f = new osh_host_frame();
+  Frame& F = f->F;
+  f->cam.reset(new Pinhole(std::vector<float>{cam4[0], cam4[1], cam4[2], cam4[3]}));
+  F.mpCamera = f->cam.get();
+  F.N = n; F.mbf = mbf; F.mb = mb;
+  F.mTcw = pose_from(pose_qt);
+  F.mvScaleFactors.assign(n_levels, 1.0f);
+  for (int l = 1; l < n_levels; ++l) F.mvScaleFactors[l] = F.mvScaleFactors[l - 1] * scale_factor;  // src/ORBextractor.cc:414-422
+  F.mDescriptors = cv::Mat(n, 32);
+  for (int i = 0; i < n; ++i) {
+    cv::KeyPoint kp;
+    kp.pt.x = kp_xy[2 * i]; kp.pt.y = kp_xy[2 * i + 1]; kp.octave = octave[i]; kp.angle = angle ? angle[i] : 0.f;
+    F.mvKeys.push_back(kp); F.mvKeysUn.push_back(kp);
+    F.mvuRight.push_back(uright ? uright[i] : -1.f);
+    std::memcpy(F.mDescriptors.ptr<uint8_t>(i), desc + 32 * (size_t)i, 32);
+  }
+  F.mvpMapPoints.assign(n, nullptr);
+  F.mvbOutlier.assign(n, false);
+  F.AssignFeaturesToGrid();
+  return f;
+}
+extern "C" void osh_host_frame_destroy(osh_host_frame* f) { delete f; }
+
+static std::vector<std::unique_ptr<MapPoint>> make_points(Map* map, int32_t n_mp, const uint8_t* mp_desc, const float* pos,
+                                                          const int32_t* n_observations) {
+  std::vector<std::unique_ptr<MapPoint>> v;
+  for (int j = 0; j < n_mp; ++j) {
+    Eigen::Vector3f p(0, 0, 0);
+    if (pos) p = Eigen::Vector3f(pos[3 * j], pos[3 * j + 1], pos[3 * j + 2]);
+    v.emplace_back(new MapPoint((unsigned long)j, p, map));
+    v.back()->mDescriptor = cv::Mat(1, 32);
+    std::memcpy(v.back()->mDescriptor.ptr<uint8_t>(0), mp_desc + 32 * (size_t)j, 32);
+    v.back()->nObs = n_observations ? n_observations[j] : 1;
+  }
+  return v;
+}
+
+extern "C" int osh_host_search_local_points(osh_host_frame* f, int32_t n_mp, const uint8_t* mp_desc, const float* proj_xy,
+                                            const float* proj_xr, const int32_t* level, const float* viewcos, const float* depth,
+                                            const int32_t* n_observations, float nnratio, float th, int32_t* assignment) {
+  if (!f) return -1;
+  auto pts = make_points(&f->map, n_mp, mp_desc, nullptr, n_observations);
+  std::vector<MapPoint*> vp;
+  for (int j = 0; j < n_mp; ++j) {
+    MapPoint* p = pts[j].get();
+    p->mbTrackInView = true;
+    p->mTrackProjX = proj_xy[2 * j]; p->mTrackProjY = proj_xy[2 * j + 1];
+    p->mTrackProjXR = proj_xr ? proj_xr[j] : 0.f;
+    p->mnTrackScaleLevel = level[j];
+    p->mTrackViewCos = viewcos ? viewcos[j] : 1.f;
+    p->mTrackDepth = depth ? depth[j] : 1.f;
+    vp.push_back(p);
+  }
+  f->F.mvpMapPoints.assign(f->F.N, nullptr);
+  ORBmatcher matcher(nnratio);
+  const int n = matcher.SearchByProjection(f->F, vp, th);
+  for (int k = 0; k < f->F.N; ++k) assignment[k] = f->F.mvpMapPoints[k] ? (int32_t)f->F.mvpMapPoints[k]->mnId : -1;
+  f->F.mvpMapPoints.assign(f->F.N, nullptr);
+  return n;
+}
+
+extern "C" int osh_host_search_last_frame(osh_host_frame* cur, osh_host_frame* last, const int32_t* last_mp, int32_t n_mp,
+                                          const float* mp_pos, const uint8_t* mp_desc, float th, int32_t b_mono, int32_t check_ori,
+                                          int32_t* assignment) {
+  if (!cur || !last) return -1;
+  auto pts = make_points(&cur->map, n_mp, mp_desc, mp_pos, nullptr);
+  for (int k = 0; k < last->F.N; ++k) last->F.mvpMapPoints[k] = last_mp[k] >= 0 ? pts[last_mp[k]].get() : nullptr;
+  cur->F.mvpMapPoints.assign(cur->F.N, nullptr);
+  ORBmatcher matcher(0.9f, check_ori != 0);
+  const int n = matcher.SearchByProjection(cur->F, last->F, th, b_mono != 0);
+  for (int k = 0; k < cur->F.N; ++k) assignment[k] = cur->F.mvpMapPoints[k] ? (int32_t)cur->F.mvpMapPoints[k]->mnId : -1;
+  cur->F.mvpMapPoints.assign(cur->F.N, nullptr);
+  last->F.mvpMapPoints.assign(last->F.N, nullptr);
+  return n;
+}

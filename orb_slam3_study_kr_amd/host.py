@@ -1,0 +1,154 @@
+"""ctypes driver of the C++ host layer (include/orbslam3_hip_host.h): builds the reference's pointer graph
+(KeyFrame / MapPoint / Map, Frame) from flat arrays and calls ORB_SLAM3::Optimizer::LocalBundleAdjustment /
+ORB_SLAM3::ORBmatcher::SearchByProjection through their own C++ signatures."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi, synth
+from .synth import LbaWindow
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class HostGraph:
+    """A map built from a synthetic LbaWindow: keyframe k <-> pose index k of the window, point j <-> point j.
+
+    Keyframe ids: optimisable poses get ids 100+i (ascending with the pose index, so the Hessian order of the
+    reference equals the window's order), fixed poses get ids 10+i (older keyframes).  The current keyframe is
+    the newest optimisable one; every other optimisable keyframe is covisible with it."""
+
+    def __init__(self, w: LbaWindow, init_kf_fixed: bool = False, inertial: bool = False):
+        self.lib = capi.load_library()
+        self.w = w
+        P, F = w.n_free, w.n_fixed
+        self.kf_id = np.array([100 + i for i in range(P)] + [10 + i for i in range(F)], dtype=np.int64)
+        self.mp_id = np.arange(w.n_points, dtype=np.int64) + 1000
+        pose = _f32(w.pose_qt)
+        cam5 = _f32(w.pose_cam[0])
+        inv = _f32(synth.INV_LEVEL_SIGMA2)
+        octave = _i32(np.round(np.log(1.0 / w.edge_info) / np.log(1.44)).astype(np.int32))
+        obs = _f32(w.edge_obs)
+        obs[w.edge_kind == capi.OSH_EDGE_MONO, 2] = -1.0
+        init_id = int(self.kf_id[0]) if init_kf_fixed else -1 & 0x7FFFFFFF
+        self.init_kf_fixed = init_kf_fixed
+        mp_pos = _f32(w.points)
+        self._keep = [pose, cam5, inv, octave, obs, mp_pos]
+        self.g = C.c_void_p(self.lib.osh_host_graph_create(
+            P + F, capi.ptr(self.kf_id, capi.c_int64_p), capi.ptr(pose, capi.c_float_p), capi.ptr(cam5, capi.c_float_p),
+            capi.ptr(inv, capi.c_float_p), len(inv), w.n_points, capi.ptr(self.mp_id, capi.c_int64_p),
+            capi.ptr(mp_pos, capi.c_float_p), w.n_edges, capi.ptr(_i32(w.edge_pose), capi.c_int32_p),
+            capi.ptr(_i32(w.edge_point), capi.c_int32_p), capi.ptr(obs, capi.c_float_p), capi.ptr(octave, capi.c_int32_p),
+            init_id, int(inertial)))
+        self.cur = P - 1
+        cov = _i32([i for i in range(P) if i != self.cur])
+        self.lib.osh_host_graph_set_covisible(self.g, self.cur, len(cov), capi.ptr(cov, capi.c_int32_p))
+
+    def close(self):
+        if self.g:
+            self.lib.osh_host_graph_destroy(self.g)
+            self.g = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def pack(self):
+        sizes = np.zeros(5, dtype=np.int32)
+        null = [None] * 10
+        rc = self.lib.osh_host_pack_lba(self.g, self.cur, capi.ptr(sizes, capi.c_int32_p), *[C.cast(None, t) for t in (
+            capi.c_double_p, capi.c_double_p, capi.c_double_p, capi.c_int32_p, capi.c_int32_p, capi.c_uint8_p, capi.c_double_p,
+            capi.c_double_p, capi.c_int64_p, capi.c_int64_p)])
+        del null
+        if rc != 0:
+            return rc, sizes, None
+        P, F, L, E = (int(x) for x in sizes[:4])
+        out = dict(pose_qt=np.zeros((P + F, 7)), pose_cam=np.zeros((P + F, 5)), points=np.zeros((L, 3)),
+                   edge_pose=np.zeros(E, dtype=np.int32), edge_point=np.zeros(E, dtype=np.int32), edge_kind=np.zeros(E, dtype=np.uint8),
+                   edge_obs=np.zeros((E, 3)), edge_info=np.zeros(E), pose_kf_id=np.zeros(P + F, dtype=np.int64),
+                   point_mp_id=np.zeros(L, dtype=np.int64))
+        d, i32, u8, i64 = capi.c_double_p, capi.c_int32_p, capi.c_uint8_p, capi.c_int64_p
+        rc = self.lib.osh_host_pack_lba(self.g, self.cur, capi.ptr(sizes, i32), capi.ptr(out["pose_qt"], d), capi.ptr(out["pose_cam"], d),
+                                        capi.ptr(out["points"], d), capi.ptr(out["edge_pose"], i32), capi.ptr(out["edge_point"], i32),
+                                        capi.ptr(out["edge_kind"], u8), capi.ptr(out["edge_obs"], d), capi.ptr(out["edge_info"], d),
+                                        capi.ptr(out["pose_kf_id"], i64), capi.ptr(out["point_mp_id"], i64))
+        return rc, sizes, out
+
+    def packed_window(self) -> LbaWindow:
+        """The osh_lba_problem the host layer builds for the current keyframe, as an LbaWindow (for the oracle)."""
+        rc, sizes, o = self.pack()
+        assert rc == 0, rc
+        return LbaWindow(n_free=int(sizes[0]), n_fixed=int(sizes[1]), pose_qt=o["pose_qt"], pose_cam=o["pose_cam"], points=o["points"],
+                         edge_pose=o["edge_pose"], edge_point=o["edge_point"], edge_kind=o["edge_kind"], edge_obs=o["edge_obs"],
+                         edge_info=o["edge_info"], lambda_init=0.0, max_iterations=10).normalise(), o
+
+    def run_lba(self, stop_flag: np.ndarray | None = None):
+        counts = np.zeros(4, dtype=np.int32)
+        rc = self.lib.osh_host_run_lba(self.g, self.cur, capi.ptr(stop_flag, capi.c_uint8_p) if stop_flag is not None else
+                                       C.cast(None, capi.c_uint8_p), capi.ptr(counts, capi.c_int32_p))
+        assert rc == 0
+        return counts
+
+    def kf_pose(self, i):
+        o = np.zeros(7, dtype=np.float32)
+        self.lib.osh_host_get_kf_pose(self.g, i, capi.ptr(o, capi.c_float_p))
+        return o
+
+    def mp_pos(self, j):
+        o = np.zeros(3, dtype=np.float32)
+        self.lib.osh_host_get_mp_pos(self.g, j, capi.ptr(o, capi.c_float_p))
+        return o
+
+
+class HostFrame:
+    def __init__(self, xy, octave, desc, angle=None, uright=None, pose_qt=None, mbf=float(synth.BF), mb=0.110078):
+        self.lib = capi.load_library()
+        n = len(octave)
+        self.n = n
+        pose = _f32(pose_qt if pose_qt is not None else [0, 0, 0, 1, 0, 0, 0])
+        cam4 = _f32([synth.FX, synth.FY, synth.CX, synth.CY])
+        a = _f32(angle) if angle is not None else None
+        u = _f32(uright) if uright is not None else None
+        self.f = C.c_void_p(self.lib.osh_host_frame_create(
+            n, capi.ptr(_f32(xy), capi.c_float_p), capi.ptr(_i32(octave), capi.c_int32_p),
+            capi.ptr(a, capi.c_float_p) if a is not None else C.cast(None, capi.c_float_p),
+            capi.ptr(u, capi.c_float_p) if u is not None else C.cast(None, capi.c_float_p),
+            capi.ptr(np.ascontiguousarray(desc, dtype=np.uint8), capi.c_uint8_p), capi.ptr(pose, capi.c_float_p),
+            capi.ptr(cam4, capi.c_float_p), mbf, mb, synth.N_LEVELS, np.float32(synth.SCALE_FACTOR)))
+
+    def close(self):
+        if self.f:
+            self.lib.osh_host_frame_destroy(self.f)
+            self.f = C.c_void_p()
+
+    def search_local_points(self, mp_desc, proj_xy, level, viewcos=None, proj_xr=None, depth=None, n_obs=None, nnratio=0.8, th=1.0):
+        n_mp = len(level)
+        assign = -np.ones(self.n, dtype=np.int32)
+        fp = capi.c_float_p
+
+        def opt(a, typ, conv):
+            return capi.ptr(conv(a), typ) if a is not None else C.cast(None, typ)
+        keep = [np.ascontiguousarray(mp_desc, dtype=np.uint8), _f32(proj_xy), _i32(level)]
+        n = self.lib.osh_host_search_local_points(self.f, n_mp, capi.ptr(keep[0], capi.c_uint8_p), capi.ptr(keep[1], fp),
+                                                  opt(proj_xr, fp, _f32), capi.ptr(keep[2], capi.c_int32_p), opt(viewcos, fp, _f32),
+                                                  opt(depth, fp, _f32), opt(n_obs, capi.c_int32_p, _i32), nnratio, th,
+                                                  capi.ptr(assign, capi.c_int32_p))
+        return n, assign
+
+    def search_last_frame(self, last: "HostFrame", last_mp, mp_pos, mp_desc, th=15.0, mono=True, check_ori=True):
+        assign = -np.ones(self.n, dtype=np.int32)
+        keep = [_i32(last_mp), _f32(mp_pos), np.ascontiguousarray(mp_desc, dtype=np.uint8)]
+        n = self.lib.osh_host_search_last_frame(self.f, last.f, capi.ptr(keep[0], capi.c_int32_p), len(mp_pos),
+                                                capi.ptr(keep[1], capi.c_float_p), capi.ptr(keep[2], capi.c_uint8_p), th, int(mono),
+                                                int(check_ori), capi.ptr(assign, capi.c_int32_p))
+        return n, assign

@@ -1,0 +1,80 @@
+"""CPU tests of the C++ host layer: the graph walk + packing of Optimizer::LocalBundleAdjustment
+(steps 1-6, src/Optimizer.cc:1118-1404) against the synthetic window it was built from; no GPU involved."""
+import re
+from pathlib import Path
+
+import numpy as np
+
+from orb_slam3_study_kr_amd import capi, host, synth
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_host_header_symbols_exported():
+    text = re.sub(r"/\*.*?\*/", "", (ROOT / "include" / "orbslam3_hip_host.h").read_text(), flags=re.S)
+    declared = sorted(set(re.findall(r"\b(osh_host_[a-z0-9_]+)\s*\(", text)))
+    assert declared == sorted(capi.HOST_EXPORTED_SYMBOLS)
+    lib = capi.load_library()
+    for name in declared:
+        assert hasattr(lib, name)
+
+
+def _check_pack(w, g):
+    rc, sizes, o = g.pack()
+    assert rc == 0
+    P, F, L, E = (int(x) for x in sizes[:4])
+    assert (P, F, L, E) == (w.n_free, w.n_fixed, w.n_points, w.n_edges)
+    assert sizes[4] == w.n_fixed                       # num_fixedKF = |lFixedCameras| (no init keyframe in the window)
+    # optimisable poses come first in ascending keyframe id (Hessian order), fixed ones after
+    assert np.all(np.diff(o["pose_kf_id"][:P]) > 0) and np.all(o["pose_kf_id"][:P] >= 100) and np.all(o["pose_kf_id"][P:] < 100)
+    assert np.all(np.diff(o["point_mp_id"]) > 0)
+    kf_of_pose = {int(i): k for k, i in enumerate(g.kf_id)}
+    order = np.array([kf_of_pose[int(i)] for i in o["pose_kf_id"]])
+    # float32 storage widened to double (src/Optimizer.cc:1217-1218,1286)
+    exp_qt = w.pose_qt[order].astype(np.float32).astype(np.float64)
+    np.testing.assert_array_equal(o["pose_qt"][:, 4:], exp_qt[:, 4:])
+    # Sophus::SE3f re-normalises the float quaternion it is constructed from (one float ulp)
+    np.testing.assert_allclose(o["pose_qt"][:, :4], exp_qt[:, :4], rtol=0, atol=2e-7)
+    np.testing.assert_array_equal(o["points"], w.points.astype(np.float32).astype(np.float64))
+    np.testing.assert_array_equal(o["pose_cam"], w.pose_cam[order])
+    # same edge multiset: (keyframe, point, kind, obs, info); order is landmark-list x std::map<KeyFrame*> order
+    def key(pose, point, kind, obs, info):
+        return sorted(zip(pose.tolist(), point.tolist(), kind.tolist(), map(tuple, np.round(obs, 4).tolist()), info.tolist()))
+    obs_w = w.edge_obs.copy()
+    got = key(order[o["edge_pose"]], o["edge_point"], o["edge_kind"], o["edge_obs"], o["edge_info"])
+    exp = key(w.edge_pose, w.edge_point, w.edge_kind, obs_w, w.edge_info)
+    assert got == exp
+
+
+def test_pack_matches_window_stereo_and_mono():
+    for stereo in (True, False):
+        w = synth.make_window(31, n_free=6, n_fixed=3, n_points=200, stereo=stereo)
+        with host.HostGraph(w) as g:
+            _check_pack(w, g)
+
+
+def test_pack_mixed_kinds_and_repeatability():
+    w = synth.make_window(32, n_free=5, n_fixed=2, n_points=150, stereo=True, mixed_mono_frac=0.4)
+    with host.HostGraph(w) as g:
+        _check_pack(w, g)
+        _check_pack(w, g)   # marks are reset by the harness, a second call sees the same window
+
+
+def test_init_keyframe_is_a_fixed_vertex():
+    w = synth.make_window(33, n_free=5, n_fixed=2, n_points=150)
+    with host.HostGraph(w, init_kf_fixed=True) as g:
+        rc, sizes, o = g.pack()
+        assert rc == 0
+        assert (int(sizes[0]), int(sizes[1])) == (w.n_free - 1, w.n_fixed + 1)   # vSE3->setFixed(mnId==InitKFid) :1220
+        assert int(sizes[4]) == w.n_fixed + 1                                     # num_fixedKF counts it (:1143-1146,1179)
+        assert int(o["pose_kf_id"][int(sizes[0])]) == int(g.kf_id[0])             # first of the fixed block
+
+
+def test_window_without_fixed_keyframe_aborts():
+    w = synth.make_window(34, n_free=5, n_fixed=2, n_points=150)
+    keep = w.edge_pose < w.n_free
+    for name in ("edge_pose", "edge_point", "edge_kind", "edge_obs", "edge_info"):
+        setattr(w, name, np.ascontiguousarray(getattr(w, name)[keep]))
+    with host.HostGraph(w) as g:
+        rc, sizes, _ = g.pack()
+        assert rc == 1 and sizes[4] == 0      # "LM-LBA: There are 0 fixed KF" path (:1182-1186)
