@@ -163,6 +163,69 @@ int osh_lba_set_profiling(osh_lba_ctx* ctx, int enable);
 int osh_lba_get_profile(osh_lba_ctx* ctx, int64_t launches[OSH_K_COUNT], double total_ms[OSH_K_COUNT]);
 const char* osh_lba_kernel_name(int kernel_id);
 
+/* ----------------------------------------------- local inertial BA (config 4) */
+/*
+ * One Optimizer::LocalInertialBA window (src/Optimizer.cc:2387-2964) as flat arrays.
+ *
+ * Keyframe order ("pose index"):  the n_opt temporal keyframes in Hessian order (ascending id; each carries
+ * VertexPose + VertexVelocity + VertexGyroBias + VertexAccBias, ids :2538-2553), then n_fixed_imu (0 or 1) fixed
+ * predecessor with the same four vertices fixed (:2570-2591), then n_fixed pose-only fixed observers (:2485-2506).
+ * Reduced state order = g2o's: the 6-dof poses of the n_opt keyframes, then (v, bg, ba) per keyframe.
+ * Poses use the ImuCamPose parameterisation (src/G2oTypes.cc:25-71,187-220): body-frame right update
+ *   twb += Rwb*ut ; Rwb = Rwb*ExpSO3(ur) ; Rcw = Rcb*Rbw ; tcw = Rcb*tbw + tcb.
+ * link l is one EdgeInertial (+ EdgeGyroRW + EdgeAccRW) between keyframes link_prev[l] -> link_cur[l] (:2600-2667).
+ */
+#define OSH_PREINT_FLOATS 72
+/* layout of one preintegration record (IMU::Preintegrated members, all float32, src/ImuTypes.cc:147-237):
+ *  [0] dT  [1..9] dR  [10..12] dV  [13..15] dP  [16..24] JRg  [25..33] JVg  [34..42] JVa  [43..51] JPg  [52..60] JPa
+ *  [61..66] linearisation bias b = bax bay baz bwx bwy bwz   [67..71] unused */
+typedef struct osh_liba_problem {
+  int32_t n_opt, n_fixed_imu, n_fixed;
+  int32_t n_points, n_edges, n_links;
+  const double* pose_Rcw;   /* [K*9] row-major, K = n_opt+n_fixed_imu+n_fixed: KeyFrame::GetRotation()          */
+  const double* pose_tcw;   /* [K*3] KeyFrame::GetTranslation()                                              */
+  const double* pose_Rwb;   /* [K*9] KeyFrame::GetImuRotation()                                              */
+  const double* pose_twb;   /* [K*3] KeyFrame::GetImuPosition()                                              */
+  const double* Rcb;        /* [9]  mImuCalib.mTcb rotation   */
+  const double* tcb;        /* [3]  mImuCalib.mTcb translation */
+  const double* tbc;        /* [3]  mImuCalib.mTbc translation */
+  const double* cam;        /* [5]  fx fy cx cy bf (pinhole, shared by the window)                            */
+  const double* vel;        /* [(n_opt+n_fixed_imu)*3] KeyFrame::GetVelocity()                               */
+  const double* bias_g;     /* [(n_opt+n_fixed_imu)*3] KeyFrame::GetGyroBias()                               */
+  const double* bias_a;     /* [(n_opt+n_fixed_imu)*3] KeyFrame::GetAccBias()                                */
+  const double* points;     /* [L*3]                                                                          */
+  const int32_t* edge_pose; const int32_t* edge_point; const uint8_t* edge_kind;   /* as osh_lba_problem        */
+  const double* edge_obs;   /* [E*3] */
+  const double* edge_info;  /* [E] invSigma2/unc2 (:2739-2742)                                                */
+  const int32_t* link_prev; /* [n_links] pose index of the earlier keyframe (< n_opt+n_fixed_imu)            */
+  const int32_t* link_cur;  /* [n_links] pose index of the later keyframe  (< n_opt)                         */
+  const float*  link_preint;/* [n_links*OSH_PREINT_FLOATS]                                                   */
+  const double* link_info;  /* [n_links*81] EdgeInertial information (G2oTypes.cc:500-508, x1e-2 on the oldest link) */
+  const double* link_info_g;/* [n_links*9]  EdgeGyroRW information  C.block<3,3>(9,9)^-1   (:2653)           */
+  const double* link_info_a;/* [n_links*9]  EdgeAccRW information   C.block<3,3>(12,12)^-1 (:2660)           */
+  const uint8_t* link_robust;/* [n_links] 1: Huber(sqrt(16.92)) on the inertial edge (:2636-2647)             */
+  double huber_mono, huber_stereo, huber_inertial;
+  double lambda_init;       /* 1e0, or 1e-2 when bLarge (:2517-2528)                                          */
+  int32_t max_iterations;   /* opt_it: 10, or 4 when bLarge                                                   */
+} osh_liba_problem;
+
+typedef struct osh_liba_result {
+  double* pose_Rcw;  double* pose_tcw;     /* [n_opt*9], [n_opt*3]  VP->estimate().Rcw[0], tcw[0] (:2914)        */
+  double* pose_Rwb;  double* pose_twb;     /* [n_opt*9], [n_opt*3]                                              */
+  double* vel; double* bias_g; double* bias_a;  /* [n_opt*3] each                                               */
+  double* points;                          /* [L*3]                                                             */
+  double* edge_chi2; uint8_t* edge_depth_pos;   /* [E]                                                           */
+  int32_t status, iterations, trials, n_trace;
+  double  chi2_trace[OSH_LBA_MAX_TRACE];
+  double  lambda_trace[OSH_LBA_MAX_TRACE];
+  int32_t trials_trace[OSH_LBA_MAX_TRACE];
+  double  chi2_initial;     /* optimizer.activeRobustChi2() before optimize(): `err` (:2845)                   */
+  double  chi2_final;       /* activeRobustChi2() after optimize(): `err_end` (:2848)                          */
+} osh_liba_result;
+
+/* Solve one batch of inertial windows on the device (upload + optimize + download). */
+int osh_liba_solve(osh_lba_ctx* ctx, int32_t n_windows, const osh_liba_problem* problems, osh_liba_result* results);
+
 /* --------------------------------------------------------- ORB matching API */
 /*
  * Nearest / second-nearest 256-bit Hamming search (the candidate loops of

@@ -66,6 +66,16 @@ def load(native: bool = False) -> C.CDLL:
     lib.oracle_orb_match_last_frame.restype = C.c_int
     lib.oracle_orb_match_last_frame.argtypes = [C.c_int, C.c_int, u8, u8, i32, i32, capi.c_float_p, capi.c_float_p,
                                                 C.c_int, C.c_int, u8, i32]
+    lib.oracle_liba_solve.restype = C.c_int
+    lib.oracle_liba_solve.argtypes = [C.POINTER(capi.LibaProblem), C.POINTER(capi.LibaResult)]
+    lib.oracle_liba_linearize.restype = C.c_int
+    lib.oracle_liba_linearize.argtypes = [C.POINTER(capi.LibaProblem), d, d, d, d, d]
+    lib.oracle_liba_inertial_edge.restype = C.c_int
+    lib.oracle_liba_inertial_edge.argtypes = [C.POINTER(capi.LibaProblem), C.c_int, d, d]
+    lib.oracle_exp_so3.restype = None
+    lib.oracle_exp_so3.argtypes = [d, d]
+    lib.oracle_log_so3.restype = None
+    lib.oracle_log_so3.argtypes = [d, d]
     _libs[key] = lib
     return lib
 
@@ -211,3 +221,50 @@ def orb_match_last_frame(query, train, cand_off, cand_idx, query_angle, train_an
                                         capi.ptr(qa, capi.c_float_p), capi.ptr(ta, capi.c_float_p), th_high,
                                         int(check_orientation), _u8(occ), _i32(assign))
     return int(n), assign, occ
+
+
+# ------------------------------------------------------------------ local inertial BA
+def liba_solve(w, native: bool = False):
+    from orb_slam3_study_kr_amd.synth_inertial import LibaResultArrays
+    lib = load(native)
+    res = LibaResultArrays(w)
+    prob = w.as_struct()
+    rc = lib.oracle_liba_solve(C.byref(prob), C.byref(res.struct))
+    if rc != 0:
+        raise RuntimeError(f"oracle_liba_solve failed: {rc}")
+    return res.read_scalars(res.struct)
+
+
+def liba_linearize(w):
+    lib = load()
+    n = 15 * w.n_opt
+    H, b = np.zeros((n, n)), np.zeros(n + 3 * w.n_points)
+    Hll, Hpl = np.zeros((w.n_points, 3, 3)), np.zeros((w.n_edges, 6, 3))
+    chi = C.c_double(0)
+    prob = w.as_struct()
+    lib.oracle_liba_linearize(C.byref(prob), _d(H), _d(b), _d(Hll), _d(Hpl), C.cast(C.byref(chi), capi.c_double_p))
+    return dict(H=H, b=b, Hll=Hll, Hpl=Hpl, chi2=chi.value)
+
+
+def liba_inertial_edge(w, link):
+    lib = load()
+    r, J = np.zeros(9), np.zeros((9, 24))
+    prob = w.as_struct()
+    lib.oracle_liba_inertial_edge(C.byref(prob), int(link), _d(r), _d(J))
+    return r, J
+
+
+def exp_so3(wv):
+    lib = load()
+    wv = np.ascontiguousarray(wv, dtype=np.float64)
+    R = np.zeros((3, 3))
+    lib.oracle_exp_so3(_d(wv), _d(R))
+    return R
+
+
+def log_so3(R):
+    lib = load()
+    R = np.ascontiguousarray(R, dtype=np.float64)
+    o = np.zeros(3)
+    lib.oracle_log_so3(_d(R), _d(o))
+    return o

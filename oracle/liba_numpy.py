@@ -1,0 +1,176 @@
+"""Independent numpy check of the stereo-inertial local-BA maths (TEST INFRASTRUCTURE ONLY).
+
+Pins oracle/liba_oracle.c without the (unbuildable) reference: residuals are re-derived with numpy (rotation
+matrices, numpy float32 for the preintegration getters, real SVD for NormalizeRotation) and EVERY Jacobian is
+numeric (central differences through the vertices' own oplus, g2o's recipe base_multi_edge.hpp:114-169), so
+nothing is shared with the analytic Jacobians of the C restatement.  PARITY UNPINNED (see liba_oracle.c).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+f32 = np.float32
+G = np.array([0.0, 0.0, -float(f32(9.81))])
+
+
+def hat(v):
+    return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0.0]])
+
+
+def normalize(R):
+    u, _, vt = np.linalg.svd(R)
+    return u @ vt
+
+
+def exp_so3(w):
+    d2 = float(w @ w)
+    d = np.sqrt(d2)
+    W = hat(w)
+    if d < 1e-5:
+        return normalize(np.eye(3) + W + 0.5 * W @ W)
+    return normalize(np.eye(3) + W * np.sin(d) / d + W @ W * (1.0 - np.cos(d)) / d2)
+
+
+def log_so3(R):
+    w = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) / 2
+    c = (np.trace(R) - 1.0) * 0.5
+    if c > 1 or c < -1:
+        return w
+    th = np.arccos(c)
+    s = np.sin(th)
+    return w if abs(s) < 1e-5 else th * w / s
+
+
+def so3f_exp(v):
+    v = v.astype(f32)
+    th2 = f32(v @ v)
+    if th2 < f32(1e-5) * f32(1e-5):
+        im = f32(0.5) - f32(1.0 / 48.0) * th2
+        re = f32(1) - f32(1.0 / 8.0) * th2
+    else:
+        th = f32(np.sqrt(th2))
+        im = f32(np.sin(f32(0.5) * th)) / th
+        re = f32(np.cos(f32(0.5) * th))
+    x, y, z, w = (im * v[0], im * v[1], im * v[2], re)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]], dtype=f32)
+
+
+class State:
+    def __init__(self, w):
+        self.w = w
+        self.Rwb, self.twb = w.pose_Rwb.reshape(-1, 3, 3).copy(), w.pose_twb.reshape(-1, 3).copy()
+        self.Rcw, self.tcw = w.pose_Rcw.reshape(-1, 3, 3).copy(), w.pose_tcw.reshape(-1, 3).copy()
+        self.vel, self.bg, self.ba = w.vel.reshape(-1, 3).copy(), w.bias_g.reshape(-1, 3).copy(), w.bias_a.reshape(-1, 3).copy()
+        self.X = w.points.copy()
+
+    def copy(self):
+        s = State.__new__(State)
+        s.w = self.w
+        for k in ("Rwb", "twb", "Rcw", "tcw", "vel", "bg", "ba", "X"):
+            setattr(s, k, getattr(self, k).copy())
+        return s
+
+    def oplus(self, x):
+        w, N = self.w, self.w.n_opt
+        Rcb, tcb = w.Rcb.reshape(3, 3), w.tcb
+        for k in range(N):
+            ur, ut = x[6 * k:6 * k + 3], x[6 * k + 3:6 * k + 6]
+            if np.any(ur != 0) or np.any(ut != 0):
+                self.twb[k] = self.twb[k] + self.Rwb[k] @ ut
+                self.Rwb[k] = self.Rwb[k] @ exp_so3(ur)
+                Rbw = self.Rwb[k].T
+                self.Rcw[k] = Rcb @ Rbw
+                self.tcw[k] = Rcb @ (-Rbw @ self.twb[k]) + tcb
+            o = 6 * N + 9 * k
+            self.vel[k] += x[o:o + 3]; self.bg[k] += x[o + 3:o + 6]; self.ba[k] += x[o + 6:o + 9]
+        self.X = self.X + x[15 * N:].reshape(-1, 3)
+
+
+def inertial_residual(st, l):
+    w = st.w
+    rec = w.link_preint[l]
+    a, c = int(w.link_prev[l]), int(w.link_cur[l])
+    dT = float(rec[0])
+    dR, dV, dP = rec[1:10].reshape(3, 3), rec[10:13], rec[13:16]
+    JRg, JVg, JVa, JPg, JPa = (rec[o:o + 9].reshape(3, 3) for o in (16, 25, 34, 43, 52))
+    b = rec[61:67]
+    bg1, ba1 = st.bg[a].astype(f32), st.ba[a].astype(f32)     # IMU::Bias holds floats
+    dbg, dba = (bg1 - b[3:6]).astype(f32), (ba1 - b[0:3]).astype(f32)
+    u, _, vt = np.linalg.svd((dR @ so3f_exp(JRg @ dbg)).astype(f32))
+    dRb = (u @ vt).astype(np.float64)
+    dVb = (dV + JVg @ dbg + JVa @ dba).astype(f32).astype(np.float64)
+    dPb = (dP + JPg @ dbg + JPa @ dba).astype(f32).astype(np.float64)
+    R1, R2 = st.Rwb[a], st.Rwb[c]
+    er = log_so3(dRb.T @ R1.T @ R2)
+    ev = R1.T @ (st.vel[c] - st.vel[a] - G * dT) - dVb
+    ep = R1.T @ (st.twb[c] - st.twb[a] - st.vel[a] * dT - G * dT * dT / 2) - dPb
+    return np.concatenate([er, ev, ep])
+
+
+def visual_residual(st, e):
+    w = st.w
+    k, l = int(w.edge_pose[e]), int(w.edge_point[e])
+    fx, fy, cx, cy, bf = w.cam
+    Xc = st.Rcw[k] @ st.X[l] + st.tcw[k]
+    u, v = fx * Xc[0] / Xc[2] + cx, fy * Xc[1] / Xc[2] + cy
+    if w.edge_kind[e] == 0:
+        return np.array([w.edge_obs[e, 0] - u, w.edge_obs[e, 1] - v])
+    return np.array([w.edge_obs[e, 0] - u, w.edge_obs[e, 1] - v, w.edge_obs[e, 2] - (u - bf / Xc[2])])
+
+
+def huber(c, delta):
+    d2 = delta * delta
+    if c <= d2:
+        return c, 1.0
+    s = np.sqrt(c)
+    return 2 * s * delta - d2, delta / s
+
+
+def all_residual_blocks(st):
+    """[(residual, information, huber delta or None)] in g2o edge order: inertial links first, then visual."""
+    w = st.w
+    out = []
+    for l in range(w.n_links):
+        a, c = int(w.link_prev[l]), int(w.link_cur[l])
+        out.append((inertial_residual(st, l), w.link_info[l].reshape(9, 9), w.huber_inertial if w.link_robust[l] else None))
+        out.append((st.bg[c] - st.bg[a], w.link_info_g[l].reshape(3, 3), None))
+        out.append((st.ba[c] - st.ba[a], w.link_info_a[l].reshape(3, 3), None))
+    for e in range(w.n_edges):
+        r = visual_residual(st, e)
+        out.append((r, np.eye(len(r)) * w.edge_info[e], w.huber_mono if w.edge_kind[e] == 0 else w.huber_stereo))
+    return out
+
+
+def robust_chi2(st):
+    chi = 0.0
+    for r, Om, delta in all_residual_blocks(st):
+        c = float(r @ Om @ r)
+        chi += huber(c, delta)[0] if delta is not None else c
+    return chi
+
+
+def numeric_dense_system(st, delta_pose=1e-6, delta_bias=2e-3):
+    """Dense H, b over (poses, v/bg/ba, points) from central-difference Jacobians of every residual block."""
+    w = st.w
+    N = w.n_opt
+    nall = 15 * N + 3 * w.n_points
+    blocks0 = all_residual_blocks(st)
+    H, b = np.zeros((nall, nall)), np.zeros(nall)
+    # which state entries can influence anything: all optimisable ones
+    J = [np.zeros((len(r), nall)) for r, _, _ in blocks0]
+    for j in range(nall):
+        is_bias = 6 * N <= j < 15 * N and ((j - 6 * N) % 9) >= 3
+        d = delta_bias if is_bias else delta_pose
+        e = np.zeros(nall); e[j] = d
+        sp, sm = st.copy(), st.copy()
+        sp.oplus(e); sm.oplus(-e)
+        bp, bm = all_residual_blocks(sp), all_residual_blocks(sm)
+        for i in range(len(blocks0)):
+            J[i][:, j] = (bp[i][0] - bm[i][0]) / (2 * d)
+    for (r, Om, delta), Ji in zip(blocks0, J):
+        rho1 = huber(float(r @ Om @ r), delta)[1] if delta is not None else 1.0
+        H += Ji.T @ (rho1 * Om) @ Ji
+        b += -Ji.T @ (rho1 * Om @ r)
+    return H, b

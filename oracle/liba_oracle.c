@@ -1,0 +1,685 @@
+/*
+ * liba_oracle.c -- CPU restatement (plain C) of the g2o path behind
+ * ORB_SLAM3::Optimizer::LocalInertialBA (src/Optimizer.cc:2387-2964).
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE (see lba_oracle.c).  PARITY UNPINNED against a reference
+ * binary (Eigen/OpenCV/Sophus-on-Eigen absent); pinned by oracle/liba_numpy.py (independent numpy
+ * re-derivation with numeric Jacobians) and tests/test_oracle_liba.py.
+ *
+ * Restated pieces (paths relative to /root/reference, "g2o/" = Thirdparty/g2o/g2o/):
+ *   ImuCamPose::Update / Project / ProjectStereo / isDepthPositive      src/G2oTypes.cc:170-220
+ *   EdgeMono / EdgeStereo computeError + linearizeOplus                 include/G2oTypes.h:342-463, src/G2oTypes.cc:349-427
+ *   EdgeInertial computeError / linearizeOplus                          src/G2oTypes.cc:513-594
+ *   EdgeGyroRW / EdgeAccRW                                              include/G2oTypes.h:635-704
+ *   ExpSO3 / LogSO3 / RightJacobianSO3 / InverseRightJacobianSO3        src/G2oTypes.cc:777-861
+ *   IMU::Preintegrated::GetDeltaRotation/Velocity/Position/GetDeltaBias (float32)  src/ImuTypes.cc:277-309
+ *   Sophus::SO3f::exp                                                   Thirdparty/Sophus/sophus/so3.hpp:583-619
+ *   BaseMultiEdge::constructQuadraticForm                               g2o/core/base_multi_edge.hpp:171-222
+ *   LM controller / block solver                                        as in lba_oracle.c
+ * Eigen::JacobiSVD-based NormalizeRotation (U V^T) is restated as the orthogonal polar factor computed by
+ * Newton iteration (same matrix up to rounding).
+ */
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include "oracle.h"
+
+/* ------------------------------------------------------------------ 3x3 helpers (row-major) */
+static void m3_mul(const double* A, const double* B, double* C) {
+  double T[9];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+  memcpy(C, T, sizeof(T));
+}
+static void m3_tmul(const double* A, const double* B, double* C) { /* A^T B */
+  double T[9];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T[i * 3 + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
+  memcpy(C, T, sizeof(T));
+}
+static void m3_vec(const double* A, const double* v, double* o) {
+  double t0 = A[0] * v[0] + A[1] * v[1] + A[2] * v[2], t1 = A[3] * v[0] + A[4] * v[1] + A[5] * v[2], t2 = A[6] * v[0] + A[7] * v[1] + A[8] * v[2];
+  o[0] = t0; o[1] = t1; o[2] = t2;
+}
+static void m3_tvec(const double* A, const double* v, double* o) { /* A^T v */
+  double t0 = A[0] * v[0] + A[3] * v[1] + A[6] * v[2], t1 = A[1] * v[0] + A[4] * v[1] + A[7] * v[2], t2 = A[2] * v[0] + A[5] * v[1] + A[8] * v[2];
+  o[0] = t0; o[1] = t1; o[2] = t2;
+}
+static void m3_hat(const double* v, double* W) { W[0] = 0; W[1] = -v[2]; W[2] = v[1]; W[3] = v[2]; W[4] = 0; W[5] = -v[0]; W[6] = -v[1]; W[7] = v[0]; W[8] = 0; }
+static void m3_inv(const double* m, double* inv) {
+  const double c00 = m[4] * m[8] - m[5] * m[7], c10 = m[5] * m[6] - m[3] * m[8], c20 = m[3] * m[7] - m[4] * m[6];
+  const double id = 1.0 / (m[0] * c00 + m[1] * c10 + m[2] * c20);
+  double T[9] = {c00 * id, (m[2] * m[7] - m[1] * m[8]) * id, (m[1] * m[5] - m[2] * m[4]) * id,
+                 c10 * id, (m[0] * m[8] - m[2] * m[6]) * id, (m[2] * m[3] - m[0] * m[5]) * id,
+                 c20 * id, (m[1] * m[6] - m[0] * m[7]) * id, (m[0] * m[4] - m[1] * m[3]) * id};
+  memcpy(inv, T, sizeof(T));
+}
+/* NormalizeRotation: U V^T of the SVD == orthogonal polar factor (include/G2oTypes.h:67-71) */
+static void normalize_rotation(double* R) {
+  for (int it = 0; it < 12; ++it) {
+    double Ri[9], d = 0;
+    m3_inv(R, Ri);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+      const double n = 0.5 * (R[i * 3 + j] + Ri[j * 3 + i]);
+      d = fmax(d, fabs(n - R[i * 3 + j]));
+      R[i * 3 + j] = n;
+    }
+    if (d < 1e-16) break;
+  }
+}
+static void normalize_rotation_f(float* R) { /* IMU::NormalizeRotation, src/ImuTypes.cc:34-37, float32 */
+  for (int it = 0; it < 12; ++it) {
+    const float c00 = R[4] * R[8] - R[5] * R[7], c10 = R[5] * R[6] - R[3] * R[8], c20 = R[3] * R[7] - R[4] * R[6];
+    const float id = 1.0f / (R[0] * c00 + R[1] * c10 + R[2] * c20);
+    const float Ri[9] = {c00 * id, (R[2] * R[7] - R[1] * R[8]) * id, (R[1] * R[5] - R[2] * R[4]) * id,
+                         c10 * id, (R[0] * R[8] - R[2] * R[6]) * id, (R[2] * R[3] - R[0] * R[5]) * id,
+                         c20 * id, (R[1] * R[6] - R[0] * R[7]) * id, (R[0] * R[4] - R[1] * R[3]) * id};
+    float d = 0;
+    float N[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+      N[i * 3 + j] = 0.5f * (R[i * 3 + j] + Ri[j * 3 + i]);
+      d = fmaxf(d, fabsf(N[i * 3 + j] - R[i * 3 + j]));
+    }
+    memcpy(R, N, sizeof(N));
+    if (d < 1e-7f) break;
+  }
+}
+
+/* src/G2oTypes.cc:782-798 */
+void oracle_exp_so3(const double* w, double* R) {
+  const double x = w[0], y = w[1], z = w[2];
+  const double d2 = x * x + y * y + z * z, d = sqrt(d2);
+  double W[9], W2[9];
+  m3_hat(w, W);
+  m3_mul(W, W, W2);
+  for (int i = 0; i < 9; ++i) {
+    const double I = (i % 4 == 0) ? 1.0 : 0.0;
+    if (d < 1e-5) R[i] = I + W[i] + 0.5 * W2[i];
+    else R[i] = I + W[i] * sin(d) / d + W2[i] * (1.0 - cos(d)) / d2;
+  }
+  normalize_rotation(R);
+}
+/* src/G2oTypes.cc:800-813 (note the 0.5f literal and the un-scaled small-sin branch) */
+void oracle_log_so3(const double* R, double* w) {
+  const double tr = R[0] + R[4] + R[8];
+  w[0] = (R[7] - R[5]) / 2; w[1] = (R[2] - R[6]) / 2; w[2] = (R[3] - R[1]) / 2;
+  const double costheta = (tr - 1.0) * 0.5f;
+  if (costheta > 1 || costheta < -1) return;
+  const double theta = acos(costheta), s = sin(theta);
+  if (fabs(s) < 1e-5) return;
+  w[0] = theta * w[0] / s; w[1] = theta * w[1] / s; w[2] = theta * w[2] / s;
+}
+static void inv_right_jac(const double* v, double* J) { /* :820-833 */
+  const double d2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2], d = sqrt(d2);
+  double W[9], W2[9];
+  m3_hat(v, W); m3_mul(W, W, W2);
+  for (int i = 0; i < 9; ++i) {
+    const double I = (i % 4 == 0) ? 1.0 : 0.0;
+    J[i] = (d < 1e-5) ? I : I + W[i] / 2 + W2[i] * (1.0 / d2 - (1.0 + cos(d)) / (2.0 * d * sin(d)));
+  }
+}
+static void right_jac(const double* v, double* J) { /* :840-853 */
+  const double d2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2], d = sqrt(d2);
+  double W[9], W2[9];
+  m3_hat(v, W); m3_mul(W, W, W2);
+  for (int i = 0; i < 9; ++i) {
+    const double I = (i % 4 == 0) ? 1.0 : 0.0;
+    J[i] = (d < 1e-5) ? I : I - W[i] * (1.0 - cos(d)) / d2 + W2[i] * (d - sin(d)) / (d2 * d);
+  }
+}
+
+/* ------------------------------------------------------------------ float32 preintegration getters */
+typedef struct { float dT, dR[9], dV[3], dP[3], JRg[9], JVg[9], JVa[9], JPg[9], JPa[9], b[6]; } preint_t;
+static void preint_load(const float* p, preint_t* o) {
+  o->dT = p[0];
+  memcpy(o->dR, p + 1, 36); memcpy(o->dV, p + 10, 12); memcpy(o->dP, p + 13, 12);
+  memcpy(o->JRg, p + 16, 36); memcpy(o->JVg, p + 25, 36); memcpy(o->JVa, p + 34, 36);
+  memcpy(o->JPg, p + 43, 36); memcpy(o->JPa, p + 52, 36); memcpy(o->b, p + 61, 24);
+}
+/* Sophus::SO3f::exp(v).matrix() in float32 (so3.hpp:583-619 + Eigen toRotationMatrix) */
+static void so3f_exp_matrix(const float* v, float* R) {
+  const float theta_sq = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+  float imag, real;
+  if (theta_sq < 1e-5f * 1e-5f) {
+    const float theta_po4 = theta_sq * theta_sq;
+    imag = 0.5f - (float)(1.0 / 48.0) * theta_sq + (float)(1.0 / 3840.0) * theta_po4;
+    real = 1.0f - (float)(1.0 / 8.0) * theta_sq + (float)(1.0 / 384.0) * theta_po4;
+  } else {
+    const float theta = sqrtf(theta_sq), half = 0.5f * theta;
+    imag = sinf(half) / theta;
+    real = cosf(half);
+  }
+  const float x = imag * v[0], y = imag * v[1], z = imag * v[2], w = real;
+  const float tx = 2 * x, ty = 2 * y, tz = 2 * z, twx = tx * w, twy = ty * w, twz = tz * w;
+  const float txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+  R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+/* b1 = IMU::Bias built from the DOUBLE estimates -> rounded to float (src/G2oTypes.cc:522) */
+static void preint_deltas(const preint_t* p, const double* bg, const double* ba, double* dR, double* dV, double* dP, double* dbg_out) {
+  const float bwx = (float)bg[0], bwy = (float)bg[1], bwz = (float)bg[2], bax = (float)ba[0], bay = (float)ba[1], baz = (float)ba[2];
+  const float dbg[3] = {bwx - p->b[3], bwy - p->b[4], bwz - p->b[5]};
+  const float dba[3] = {bax - p->b[0], bay - p->b[1], baz - p->b[2]};
+  float w[3], E[9], M[9];
+  for (int i = 0; i < 3; ++i) w[i] = p->JRg[i * 3] * dbg[0] + p->JRg[i * 3 + 1] * dbg[1] + p->JRg[i * 3 + 2] * dbg[2];
+  so3f_exp_matrix(w, E);
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) M[i * 3 + j] = p->dR[i * 3] * E[j] + p->dR[i * 3 + 1] * E[3 + j] + p->dR[i * 3 + 2] * E[6 + j];
+  normalize_rotation_f(M);
+  for (int i = 0; i < 9; ++i) dR[i] = (double)M[i];
+  for (int i = 0; i < 3; ++i) {
+    const float jv = p->JVg[i * 3] * dbg[0] + p->JVg[i * 3 + 1] * dbg[1] + p->JVg[i * 3 + 2] * dbg[2];
+    const float ja = p->JVa[i * 3] * dba[0] + p->JVa[i * 3 + 1] * dba[1] + p->JVa[i * 3 + 2] * dba[2];
+    dV[i] = (double)(p->dV[i] + jv + ja);
+    const float pv = p->JPg[i * 3] * dbg[0] + p->JPg[i * 3 + 1] * dbg[1] + p->JPg[i * 3 + 2] * dbg[2];
+    const float pa = p->JPa[i * 3] * dba[0] + p->JPa[i * 3 + 1] * dba[1] + p->JPa[i * 3 + 2] * dba[2];
+    dP[i] = (double)(p->dP[i] + pv + pa);
+    if (dbg_out) dbg_out[i] = (double)dbg[i];
+  }
+}
+
+/* ------------------------------------------------------------------ state */
+typedef struct {
+  const osh_liba_problem* pr;
+  int N, NV, K, L, E, NL, n;        /* n = 15 N */
+  double *Rcw, *tcw, *Rwb, *twb;    /* K */
+  double *vel, *bg, *ba;            /* NV */
+  double* X;                        /* L */
+  double* bak;                      /* backup of everything */
+  size_t bak_len;
+  double *err;                      /* E*3 visual errors */
+  double *ierr;                     /* NL*9 inertial, then NL*3 gyro rw, NL*3 acc rw */
+  double *H, *b;                    /* n*n dense (symmetric), n + 3L */
+  double *Hll, *Hpl;                /* L*9, E*18 (per visual edge with optimisable pose) */
+  int *col_off, *blk_edge;          /* CCS of Hpl by landmark: edges sorted by pose */
+  double *S, *bs, *coeff, *x, *Dinv, *tmp;
+} istate;
+
+static const double kG = (double)9.81f; /* g << 0,0,-IMU::GRAVITY_VALUE (float 9.81) */
+
+static void cam_from_body(istate* s, int k) { /* ImuCamPose::Update tail, :212-218 */
+  const osh_liba_problem* p = s->pr;
+  double Rbw[9], tbw[3], t[3];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rbw[i * 3 + j] = s->Rwb[9 * k + j * 3 + i];
+  m3_vec(Rbw, s->twb + 3 * k, tbw);
+  tbw[0] = -tbw[0]; tbw[1] = -tbw[1]; tbw[2] = -tbw[2];
+  m3_mul(p->Rcb, Rbw, s->Rcw + 9 * k);
+  m3_vec(p->Rcb, tbw, t);
+  for (int i = 0; i < 3; ++i) s->tcw[3 * k + i] = t[i] + p->tcb[i];
+}
+
+/* EdgeMono / EdgeStereo computeError (include/G2oTypes.h:355-361,438-444) */
+static void vis_error(const istate* s, int e, double* r) {
+  const osh_liba_problem* p = s->pr;
+  const int k = p->edge_pose[e], l = p->edge_point[e];
+  double Xc[3];
+  m3_vec(s->Rcw + 9 * k, s->X + 3 * l, Xc);
+  for (int i = 0; i < 3; ++i) Xc[i] += s->tcw[3 * k + i];
+  const double u = p->cam[0] * Xc[0] / Xc[2] + p->cam[2], v = p->cam[1] * Xc[1] / Xc[2] + p->cam[3];
+  r[0] = p->edge_obs[3 * e] - u;
+  r[1] = p->edge_obs[3 * e + 1] - v;
+  r[2] = 0;
+  if (p->edge_kind[e] == OSH_EDGE_STEREO) {
+    const double invZ = 1 / Xc[2];            /* ProjectStereo: double invZ (src/G2oTypes.cc:181) */
+    r[2] = p->edge_obs[3 * e + 2] - (u - p->cam[4] * invZ);
+  }
+}
+static double vis_chi2(const istate* s, int e) {
+  const double w = s->pr->edge_info[e];
+  const double* r = s->err + 3 * e;
+  return (s->pr->edge_kind[e] == OSH_EDGE_MONO) ? r[0] * (w * r[0]) + r[1] * (w * r[1]) : r[0] * (w * r[0]) + r[1] * (w * r[1]) + r[2] * (w * r[2]);
+}
+/* linearizeOplus of EdgeMono / EdgeStereo (src/G2oTypes.cc:349-373,397-427): JX 3x3, Jp 3x6 (row 2 zero for mono) */
+static void vis_jac(const istate* s, int e, double* JX, double* Jp) {
+  const osh_liba_problem* p = s->pr;
+  const int k = p->edge_pose[e], l = p->edge_point[e];
+  double Xc[3], Xb[3], Rbc[9];
+  m3_vec(s->Rcw + 9 * k, s->X + 3 * l, Xc);
+  for (int i = 0; i < 3; ++i) Xc[i] += s->tcw[3 * k + i];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rbc[i * 3 + j] = p->Rcb[j * 3 + i];
+  m3_vec(Rbc, Xc, Xb);
+  for (int i = 0; i < 3; ++i) Xb[i] += p->tbc[i];
+  double pj[9];
+  memset(pj, 0, sizeof(pj));
+  pj[0] = p->cam[0] / Xc[2]; pj[2] = -p->cam[0] * Xc[0] / (Xc[2] * Xc[2]);
+  pj[4] = p->cam[1] / Xc[2]; pj[5] = -p->cam[1] * Xc[1] / (Xc[2] * Xc[2]);
+  if (p->edge_kind[e] == OSH_EDGE_STEREO) {
+    pj[6] = pj[0]; pj[7] = pj[1]; pj[8] = pj[2] + p->cam[4] * (1.0 / (Xc[2] * Xc[2]));
+  }
+  double M[9];
+  m3_mul(pj, s->Rcw + 9 * k, M);
+  for (int i = 0; i < 9; ++i) JX[i] = -M[i];
+  const double x = Xb[0], y = Xb[1], z = Xb[2];
+  const double D[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
+  m3_mul(pj, p->Rcb, M);
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 6; ++j) Jp[i * 6 + j] = M[i * 3] * D[j] + M[i * 3 + 1] * D[6 + j] + M[i * 3 + 2] * D[12 + j];
+}
+
+/* EdgeInertial::computeError (src/G2oTypes.cc:513-533); also returns pieces for the Jacobians */
+static void inertial_error(const istate* s, int l, double* r) {
+  const osh_liba_problem* p = s->pr;
+  preint_t pi;
+  preint_load(p->link_preint + (size_t)l * OSH_PREINT_FLOATS, &pi);
+  const int a = p->link_prev[l], c = p->link_cur[l];
+  const double dt = (double)pi.dT;
+  double dR[9], dV[3], dP[3];
+  preint_deltas(&pi, s->bg + 3 * a, s->ba + 3 * a, dR, dV, dP, NULL);
+  const double* Rwb1 = s->Rwb + 9 * a; const double* Rwb2 = s->Rwb + 9 * c;
+  double T[9], eR[9], Rbw1[9];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rbw1[i * 3 + j] = Rwb1[j * 3 + i];
+  m3_tmul(dR, Rbw1, T); /* dR^T Rbw1 */
+  m3_mul(T, Rwb2, eR);
+  oracle_log_so3(eR, r);
+  double t[3];
+  for (int i = 0; i < 3; ++i) t[i] = s->vel[3 * c + i] - s->vel[3 * a + i] - (i == 2 ? -kG : 0.0) * dt;
+  m3_tvec(Rwb1, t, t);
+  for (int i = 0; i < 3; ++i) r[3 + i] = t[i] - dV[i];
+  for (int i = 0; i < 3; ++i) t[i] = s->twb[3 * c + i] - s->twb[3 * a + i] - s->vel[3 * a + i] * dt - (i == 2 ? -kG : 0.0) * dt * dt / 2;
+  m3_tvec(Rwb1, t, t);
+  for (int i = 0; i < 3; ++i) r[6 + i] = t[i] - dP[i];
+}
+/* EdgeInertial::linearizeOplus (src/G2oTypes.cc:535-594): J[v] 9 x dim(v) for v = P1(6) V1(3) G1(3) A1(3) P2(6) V2(3), packed 9 x 24 */
+static void inertial_jac(const istate* s, int l, double* J) {
+  const osh_liba_problem* p = s->pr;
+  preint_t pi;
+  preint_load(p->link_preint + (size_t)l * OSH_PREINT_FLOATS, &pi);
+  const int a = p->link_prev[l], c = p->link_cur[l];
+  const double dt = (double)pi.dT;
+  double dR[9], dV[3], dP[3], dbg[3];
+  preint_deltas(&pi, s->bg + 3 * a, s->ba + 3 * a, dR, dV, dP, dbg);
+  const double* Rwb1 = s->Rwb + 9 * a; const double* Rwb2 = s->Rwb + 9 * c;
+  double Rbw1[9], eR[9], T[9], er[3], invJr[9];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rbw1[i * 3 + j] = Rwb1[j * 3 + i];
+  m3_tmul(dR, Rbw1, T); m3_mul(T, Rwb2, eR);
+  oracle_log_so3(eR, er);
+  inv_right_jac(er, invJr);
+  memset(J, 0, sizeof(double) * 9 * 24);
+#define JB(row, col) (J + (row) * 24 + (col))
+#define PUT(r0, c0, M, sgn) for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) JB(r0 + i, c0 + j)[0] = (sgn) * (M)[i * 3 + j]
+  double M[9], v[3], W[9];
+  /* Pose 1 */
+  m3_tmul(Rwb2, Rwb1, M); m3_mul(invJr, M, M); PUT(0, 0, M, -1.0);
+  for (int i = 0; i < 3; ++i) v[i] = s->vel[3 * c + i] - s->vel[3 * a + i] - (i == 2 ? -kG : 0.0) * dt;
+  m3_vec(Rbw1, v, v); m3_hat(v, W); PUT(3, 0, W, 1.0);
+  for (int i = 0; i < 3; ++i) v[i] = s->twb[3 * c + i] - s->twb[3 * a + i] - s->vel[3 * a + i] * dt - 0.5 * (i == 2 ? -kG : 0.0) * dt * dt;
+  m3_vec(Rbw1, v, v); m3_hat(v, W); PUT(6, 0, W, 1.0);
+  { const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; PUT(6, 3, I, -1.0); }
+  /* Velocity 1 */
+  PUT(3, 6, Rbw1, -1.0);
+  for (int i = 0; i < 9; ++i) M[i] = Rbw1[i] * dt;
+  PUT(6, 6, M, -1.0);
+  /* Gyro 1 */
+  double JRg[9], JVg[9], JPg[9], JVa[9], JPa[9], rj[9], w[3];
+  for (int i = 0; i < 9; ++i) { JRg[i] = pi.JRg[i]; JVg[i] = pi.JVg[i]; JPg[i] = pi.JPg[i]; JVa[i] = pi.JVa[i]; JPa[i] = pi.JPa[i]; }
+  m3_vec(JRg, dbg, w); right_jac(w, rj);
+  { double eRt[9]; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) eRt[i * 3 + j] = eR[j * 3 + i];
+    m3_mul(invJr, eRt, M); m3_mul(M, rj, M); m3_mul(M, JRg, M); PUT(0, 9, M, -1.0); }
+  PUT(3, 9, JVg, -1.0); PUT(6, 9, JPg, -1.0);
+  /* Acc 1 */
+  PUT(3, 12, JVa, -1.0); PUT(6, 12, JPa, -1.0);
+  /* Pose 2 */
+  PUT(0, 15, invJr, 1.0);
+  m3_mul(Rbw1, Rwb2, M); PUT(6, 18, M, 1.0);
+  /* Velocity 2 */
+  PUT(3, 21, Rbw1, 1.0);
+#undef PUT
+#undef JB
+}
+
+static int lnk_off(const istate* s, int v /*0..5 vertex of the inertial edge*/, int l, int* dim) {
+  /* reduced-state offset of edge vertex v, or -1 when fixed */
+  const osh_liba_problem* p = s->pr;
+  const int a = p->link_prev[l], c = p->link_cur[l], N = s->N;
+  static const int dims[6] = {6, 3, 3, 3, 6, 3};
+  *dim = dims[v];
+  const int kf = (v < 4) ? a : c;
+  if (kf >= N) return -1;
+  switch (v) {
+    case 0: case 4: return 6 * kf;
+    case 1: case 5: return 6 * N + 9 * kf;
+    case 2: return 6 * N + 9 * kf + 3;
+    default: return 6 * N + 9 * kf + 6;
+  }
+}
+
+static void compute_errors(istate* s) {
+  for (int e = 0; e < s->E; ++e) vis_error(s, e, s->err + 3 * e);
+  const osh_liba_problem* p = s->pr;
+  for (int l = 0; l < s->NL; ++l) {
+    inertial_error(s, l, s->ierr + 9 * l);
+    const int a = p->link_prev[l], c = p->link_cur[l];
+    for (int i = 0; i < 3; ++i) {
+      s->ierr[9 * s->NL + 3 * l + i] = s->bg[3 * c + i] - s->bg[3 * a + i];          /* EdgeGyroRW */
+      s->ierr[12 * s->NL + 3 * l + i] = s->ba[3 * c + i] - s->ba[3 * a + i];         /* EdgeAccRW  */
+    }
+  }
+}
+static double quad(const double* r, const double* Om, int d) {
+  double c = 0;
+  for (int i = 0; i < d; ++i) { double t = 0; for (int j = 0; j < d; ++j) t += Om[i * d + j] * r[j]; c += r[i] * t; }
+  return c;
+}
+static double robust_chi2(const istate* s) {
+  const osh_liba_problem* p = s->pr;
+  double chi = 0, rho[3];
+  /* inertial edges were added first (edge ids), then visual (src/Optimizer.cc:2648-2662, 2750...) */
+  for (int l = 0; l < s->NL; ++l) {
+    const double c = quad(s->ierr + 9 * l, p->link_info + 81 * (size_t)l, 9);
+    if (p->link_robust[l]) { oracle_huber(c, p->huber_inertial, rho); chi += rho[0]; } else chi += c;
+    chi += quad(s->ierr + 9 * s->NL + 3 * l, p->link_info_g + 9 * (size_t)l, 3);
+    chi += quad(s->ierr + 12 * s->NL + 3 * l, p->link_info_a + 9 * (size_t)l, 3);
+  }
+  for (int e = 0; e < s->E; ++e) {
+    oracle_huber(vis_chi2(s, e), p->edge_kind[e] == OSH_EDGE_MONO ? p->huber_mono : p->huber_stereo, rho);
+    chi += rho[0];
+  }
+  return chi;
+}
+
+/* H += Ja^T W Jb for two column ranges of a d-row Jacobian (both optimisable) */
+static void add_block(istate* s, const double* J, int ld, int d, const double* W /*d x d*/, int ca, int da, int oa, int cb, int db, int ob) {
+  for (int i = 0; i < da; ++i)
+    for (int j = 0; j < db; ++j) {
+      double acc = 0;
+      for (int k = 0; k < d; ++k) {
+        double t = 0;
+        for (int m = 0; m < d; ++m) t += W[k * d + m] * J[m * ld + cb + j];
+        acc += J[k * ld + ca + i] * t;
+      }
+      s->H[(size_t)(oa + i) * s->n + ob + j] += acc;
+      if (oa != ob) s->H[(size_t)(ob + j) * s->n + oa + i] += acc;
+    }
+}
+
+static void build_system(istate* s) {
+  const osh_liba_problem* p = s->pr;
+  const int n = s->n;
+  memset(s->H, 0, sizeof(double) * (size_t)n * n);
+  memset(s->b, 0, sizeof(double) * ((size_t)n + 3 * s->L));
+  memset(s->Hll, 0, sizeof(double) * 9 * (size_t)s->L);
+  memset(s->Hpl, 0, sizeof(double) * 18 * (size_t)s->E);
+  /* inertial links (BaseMultiEdge::constructQuadraticForm, robust or not) */
+  for (int l = 0; l < s->NL; ++l) {
+    double J[9 * 24], W[81], wr[9];
+    inertial_jac(s, l, J);
+    const double* Om = p->link_info + 81 * (size_t)l;
+    double rho1 = 1.0;
+    if (p->link_robust[l]) { double rho[3]; oracle_huber(quad(s->ierr + 9 * l, Om, 9), p->huber_inertial, rho); rho1 = rho[1]; }
+    for (int i = 0; i < 81; ++i) W[i] = rho1 * Om[i];
+    for (int i = 0; i < 9; ++i) { double t = 0; for (int j = 0; j < 9; ++j) t += Om[i * 9 + j] * s->ierr[9 * l + j]; wr[i] = -t * rho1; }
+    static const int col[6] = {0, 6, 9, 12, 15, 21};
+    for (int va = 0; va < 6; ++va) {
+      int da, oa = lnk_off(s, va, l, &da);
+      if (oa < 0) continue;
+      for (int i = 0; i < da; ++i) { double t = 0; for (int k = 0; k < 9; ++k) t += J[k * 24 + col[va] + i] * wr[k]; s->b[oa + i] += t; }
+      for (int vb = va; vb < 6; ++vb) {
+        int db, ob = lnk_off(s, vb, l, &db);
+        if (ob < 0) continue;
+        add_block(s, J, 24, 9, W, col[va], da, oa, col[vb], db, ob);
+      }
+    }
+    /* random walks: r = b2 - b1, J = [-I, I], no robust kernel */
+    for (int which = 0; which < 2; ++which) {
+      const double* Og = (which == 0 ? p->link_info_g : p->link_info_a) + 9 * (size_t)l;
+      const double* r = s->ierr + (which == 0 ? 9 : 12) * s->NL + 3 * l;
+      const int a = p->link_prev[l], c = p->link_cur[l];
+      const int o1 = (a < s->N) ? 6 * s->N + 9 * a + (which == 0 ? 3 : 6) : -1;
+      const int o2 = 6 * s->N + 9 * c + (which == 0 ? 3 : 6);
+      double Or[3];
+      for (int i = 0; i < 3; ++i) Or[i] = -(Og[i * 3] * r[0] + Og[i * 3 + 1] * r[1] + Og[i * 3 + 2] * r[2]);
+      for (int i = 0; i < 3; ++i) {
+        if (o1 >= 0) s->b[o1 + i] += -Or[i];
+        s->b[o2 + i] += Or[i];
+        for (int j = 0; j < 3; ++j) {
+          if (o1 >= 0) {
+            s->H[(size_t)(o1 + i) * n + o1 + j] += Og[i * 3 + j];
+            s->H[(size_t)(o1 + i) * n + o2 + j] += -Og[i * 3 + j];
+            s->H[(size_t)(o2 + j) * n + o1 + i] += -Og[i * 3 + j];
+          }
+          s->H[(size_t)(o2 + i) * n + o2 + j] += Og[i * 3 + j];
+        }
+      }
+    }
+  }
+  /* visual edges (binary, robust) */
+  double* bl = s->b + n;
+  for (int e = 0; e < s->E; ++e) {
+    const int k = p->edge_pose[e], l = p->edge_point[e];
+    double A[9], B[18], rho[3];
+    vis_jac(s, e, A, B);
+    const double w = p->edge_info[e];
+    const double* r = s->err + 3 * e;
+    oracle_huber(vis_chi2(s, e), p->edge_kind[e] == OSH_EDGE_MONO ? p->huber_mono : p->huber_stereo, rho);
+    const double ww = rho[1] * w;
+    const double wr[3] = {-(w * r[0]) * rho[1], -(w * r[1]) * rho[1], -(w * r[2]) * rho[1]};
+    for (int i = 0; i < 3; ++i) {
+      bl[3 * l + i] += A[i] * wr[0] + A[3 + i] * wr[1] + A[6 + i] * wr[2];
+      for (int j = 0; j < 3; ++j) s->Hll[9 * l + i * 3 + j] += (A[i] * ww) * A[j] + (A[3 + i] * ww) * A[3 + j] + (A[6 + i] * ww) * A[6 + j];
+    }
+    if (k < s->N) {
+      for (int i = 0; i < 6; ++i) {
+        s->b[6 * k + i] += B[i] * wr[0] + B[6 + i] * wr[1] + B[12 + i] * wr[2];
+        for (int j = 0; j < 6; ++j)
+          s->H[(size_t)(6 * k + i) * n + 6 * k + j] += (B[i] * ww) * B[j] + (B[6 + i] * ww) * B[6 + j] + (B[12 + i] * ww) * B[12 + j];
+        for (int j = 0; j < 3; ++j)
+          s->Hpl[18 * (size_t)e + i * 3 + j] += (B[i] * ww) * A[j] + (B[6 + i] * ww) * A[3 + j] + (B[12 + i] * ww) * A[6 + j];
+      }
+    }
+  }
+}
+
+static int block_solve(istate* s, double lambda) {
+  const int n = s->n;
+  const osh_liba_problem* p = s->pr;
+  memcpy(s->S, s->H, sizeof(double) * (size_t)n * n);
+  for (int i = 0; i < n; ++i) s->S[(size_t)i * n + i] += lambda;     /* setLambda on every pose-side diagonal */
+  memset(s->coeff, 0, sizeof(double) * n);
+  const double* bl = s->b + n;
+  for (int j = 0; j < s->L; ++j) {
+    double D[9];
+    memcpy(D, s->Hll + 9 * j, sizeof(D));
+    D[0] += lambda; D[4] += lambda; D[8] += lambda;
+    double* Dinv = s->Dinv + 9 * j;
+    m3_inv(D, Dinv);
+    double db[3];
+    m3_vec(Dinv, bl + 3 * j, db);
+    for (int a = s->col_off[j]; a < s->col_off[j + 1]; ++a) {
+      const int ea = s->blk_edge[a], i1 = p->edge_pose[ea];
+      const double* Bi = s->Hpl + 18 * (size_t)ea;
+      double BD[18];
+      for (int r = 0; r < 6; ++r) for (int c = 0; c < 3; ++c) BD[r * 3 + c] = Bi[r * 3] * Dinv[c] + Bi[r * 3 + 1] * Dinv[3 + c] + Bi[r * 3 + 2] * Dinv[6 + c];
+      for (int r = 0; r < 6; ++r) s->coeff[6 * i1 + r] += Bi[r * 3] * db[0] + Bi[r * 3 + 1] * db[1] + Bi[r * 3 + 2] * db[2];
+      for (int a2 = a; a2 < s->col_off[j + 1]; ++a2) {
+        const int eb = s->blk_edge[a2], i2 = p->edge_pose[eb];
+        const double* Bj = s->Hpl + 18 * (size_t)eb;
+        for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) {
+          const double v = BD[r * 3] * Bj[c * 3] + BD[r * 3 + 1] * Bj[c * 3 + 1] + BD[r * 3 + 2] * Bj[c * 3 + 2];
+          s->S[(size_t)(6 * i1 + r) * n + 6 * i2 + c] -= v;
+        }
+      }
+    }
+  }
+  for (int i = 0; i < n; ++i) s->bs[i] = s->b[i] - s->coeff[i];
+  if (!oracle_ldlt_solve(n, s->S, s->bs, s->x, s->tmp)) return 0;
+  double* xl = s->x + n;
+  for (int j = 0; j < s->L; ++j) {
+    double cl[3] = {bl[3 * j], bl[3 * j + 1], bl[3 * j + 2]};
+    for (int a = s->col_off[j]; a < s->col_off[j + 1]; ++a) {
+      const int ea = s->blk_edge[a];
+      const double* Bi = s->Hpl + 18 * (size_t)ea;
+      const double* xp = s->x + 6 * p->edge_pose[ea];
+      for (int c = 0; c < 3; ++c) { double acc = 0; for (int r = 0; r < 6; ++r) acc += Bi[r * 3 + c] * (-xp[r]); cl[c] += acc; }
+    }
+    m3_vec(s->Dinv + 9 * j, cl, xl + 3 * j);
+  }
+  return 1;
+}
+
+static void apply_update(istate* s) {
+  const int N = s->N;
+  for (int k = 0; k < N; ++k) {   /* VertexPose::oplusImpl -> ImuCamPose::Update (src/G2oTypes.cc:187-220) */
+    const double* pu = s->x + 6 * k;
+    double t[3], E[9];
+    m3_vec(s->Rwb + 9 * k, pu + 3, t);
+    for (int i = 0; i < 3; ++i) s->twb[3 * k + i] += t[i];
+    oracle_exp_so3(pu, E);
+    m3_mul(s->Rwb + 9 * k, E, s->Rwb + 9 * k);
+    cam_from_body(s, k);
+  }
+  for (int k = 0; k < N; ++k)
+    for (int i = 0; i < 3; ++i) {
+      s->vel[3 * k + i] += s->x[6 * N + 9 * k + i];
+      s->bg[3 * k + i] += s->x[6 * N + 9 * k + 3 + i];
+      s->ba[3 * k + i] += s->x[6 * N + 9 * k + 6 + i];
+    }
+  for (int i = 0; i < 3 * s->L; ++i) s->X[i] += s->x[s->n + i];
+}
+
+static void state_pack(istate* s, double* dst) {
+  size_t o = 0;
+#define CP(ptr, cnt) memcpy(dst + o, ptr, sizeof(double) * (cnt)); o += (cnt)
+  CP(s->Rcw, 9 * (size_t)s->K); CP(s->tcw, 3 * (size_t)s->K); CP(s->Rwb, 9 * (size_t)s->K); CP(s->twb, 3 * (size_t)s->K);
+  CP(s->vel, 3 * (size_t)s->NV); CP(s->bg, 3 * (size_t)s->NV); CP(s->ba, 3 * (size_t)s->NV); CP(s->X, 3 * (size_t)s->L);
+#undef CP
+}
+static void state_unpack(istate* s, const double* src) {
+  size_t o = 0;
+#define CP(ptr, cnt) memcpy(ptr, src + o, sizeof(double) * (cnt)); o += (cnt)
+  CP(s->Rcw, 9 * (size_t)s->K); CP(s->tcw, 3 * (size_t)s->K); CP(s->Rwb, 9 * (size_t)s->K); CP(s->twb, 3 * (size_t)s->K);
+  CP(s->vel, 3 * (size_t)s->NV); CP(s->bg, 3 * (size_t)s->NV); CP(s->ba, 3 * (size_t)s->NV); CP(s->X, 3 * (size_t)s->L);
+#undef CP
+}
+
+static void* zalloc(size_t n, size_t sz) { return calloc(n ? n : 1, sz); }
+
+static int istate_init(istate* s, const osh_liba_problem* p) {
+  memset(s, 0, sizeof(*s));
+  s->pr = p;
+  s->N = p->n_opt; s->NV = p->n_opt + p->n_fixed_imu; s->K = s->NV + p->n_fixed; s->L = p->n_points; s->E = p->n_edges; s->NL = p->n_links;
+  s->n = 15 * s->N;
+  const size_t n = s->n, K = s->K, NV = s->NV, L = s->L, E = s->E, NL = s->NL;
+  s->Rcw = zalloc(9 * K, 8); s->tcw = zalloc(3 * K, 8); s->Rwb = zalloc(9 * K, 8); s->twb = zalloc(3 * K, 8);
+  s->vel = zalloc(3 * NV, 8); s->bg = zalloc(3 * NV, 8); s->ba = zalloc(3 * NV, 8); s->X = zalloc(3 * L, 8);
+  s->bak_len = 24 * K + 9 * NV + 3 * L; s->bak = zalloc(s->bak_len, 8);
+  s->err = zalloc(3 * E, 8); s->ierr = zalloc(15 * NL, 8);
+  s->H = zalloc(n * n, 8); s->b = zalloc(n + 3 * L, 8); s->Hll = zalloc(9 * L, 8); s->Hpl = zalloc(18 * E, 8);
+  s->S = zalloc(n * n, 8); s->bs = zalloc(n, 8); s->coeff = zalloc(n, 8); s->x = zalloc(n + 3 * L, 8); s->Dinv = zalloc(9 * L, 8);
+  s->tmp = zalloc(n, 8);
+  memcpy(s->Rcw, p->pose_Rcw, 72 * K); memcpy(s->tcw, p->pose_tcw, 24 * K); memcpy(s->Rwb, p->pose_Rwb, 72 * K); memcpy(s->twb, p->pose_twb, 24 * K);
+  memcpy(s->vel, p->vel, 24 * NV); memcpy(s->bg, p->bias_g, 24 * NV); memcpy(s->ba, p->bias_a, 24 * NV); memcpy(s->X, p->points, 24 * L);
+  /* CCS of the optimisable-pose visual edges per landmark, rows ascending */
+  s->col_off = zalloc(L + 1, sizeof(int)); s->blk_edge = zalloc(E, sizeof(int));
+  for (size_t e = 0; e < E; ++e) if (p->edge_pose[e] < s->N) s->col_off[p->edge_point[e] + 1]++;
+  for (size_t j = 0; j < L; ++j) s->col_off[j + 1] += s->col_off[j];
+  int* fill = zalloc(L, sizeof(int));
+  for (size_t j = 0; j < L; ++j) fill[j] = s->col_off[j];
+  for (size_t e = 0; e < E; ++e) if (p->edge_pose[e] < s->N) s->blk_edge[fill[p->edge_point[e]]++] = (int)e;
+  for (size_t j = 0; j < L; ++j)
+    for (int a = s->col_off[j] + 1; a < s->col_off[j + 1]; ++a) {
+      int v = s->blk_edge[a], b = a - 1;
+      while (b >= s->col_off[j] && p->edge_pose[s->blk_edge[b]] > p->edge_pose[v]) { s->blk_edge[b + 1] = s->blk_edge[b]; --b; }
+      s->blk_edge[b + 1] = v;
+    }
+  free(fill);
+  return 1;
+}
+static void istate_free(istate* s) {
+  free(s->Rcw); free(s->tcw); free(s->Rwb); free(s->twb); free(s->vel); free(s->bg); free(s->ba); free(s->X); free(s->bak);
+  free(s->err); free(s->ierr); free(s->H); free(s->b); free(s->Hll); free(s->Hpl); free(s->S); free(s->bs); free(s->coeff);
+  free(s->x); free(s->Dinv); free(s->tmp); free(s->col_off); free(s->blk_edge);
+}
+
+/* Debug / parity aids */
+int oracle_liba_linearize(const osh_liba_problem* p, double* H, double* b, double* Hll, double* Hpl, double* chi2) {
+  istate s;
+  istate_init(&s, p);
+  compute_errors(&s);
+  if (chi2) *chi2 = robust_chi2(&s);
+  build_system(&s);
+  if (H) memcpy(H, s.H, sizeof(double) * (size_t)s.n * s.n);
+  if (b) memcpy(b, s.b, sizeof(double) * ((size_t)s.n + 3 * s.L));
+  if (Hll) memcpy(Hll, s.Hll, sizeof(double) * 9 * (size_t)s.L);
+  if (Hpl) memcpy(Hpl, s.Hpl, sizeof(double) * 18 * (size_t)s.E);
+  istate_free(&s);
+  return OSH_OK;
+}
+int oracle_liba_inertial_edge(const osh_liba_problem* p, int link, double* r9, double* J9x24) {
+  istate s;
+  istate_init(&s, p);
+  if (r9) inertial_error(&s, link, r9);
+  if (J9x24) inertial_jac(&s, link, J9x24);
+  istate_free(&s);
+  return OSH_OK;
+}
+
+/* optimizer.computeActiveErrors(); err = activeRobustChi2(); optimize(opt_it); err_end = activeRobustChi2() (:2843-2848) */
+int oracle_liba_solve(const osh_liba_problem* p, osh_liba_result* res) {
+  istate s;
+  if (!istate_init(&s, p)) return OSH_ERR_INVALID;
+  const int nall = s.n + 3 * s.L;
+  double lambda = -1., ni = 2.;
+  int nBad = 0, cj = 0, trials_total = 0, ok = 1;
+  res->n_trace = 0;
+  compute_errors(&s);
+  res->chi2_initial = robust_chi2(&s);
+  for (int it = 0; it < p->max_iterations && ok; ++it) {   /* no stop flag during optimize (attached after, :2849-2850) */
+    compute_errors(&s);
+    double currentChi = robust_chi2(&s), tempChi = currentChi;
+    const double iniChi = currentChi;
+    build_system(&s);
+    if (it == 0) {
+      if (p->lambda_init > 0) lambda = p->lambda_init;
+      else { double m = 0; for (int i = 0; i < s.n; ++i) m = fmax(m, fabs(s.H[(size_t)i * s.n + i])); for (int j = 0; j < s.L; ++j) for (int d = 0; d < 3; ++d) m = fmax(m, fabs(s.Hll[9 * j + 4 * d])); lambda = 1e-5 * m; }
+      ni = 2; nBad = 0;
+    }
+    double rho = 0; int qmax = 0;
+    do {
+      state_pack(&s, s.bak);
+      const int ok2 = block_solve(&s, lambda);
+      apply_update(&s);
+      compute_errors(&s);
+      tempChi = robust_chi2(&s);
+      if (!ok2) tempChi = DBL_MAX;
+      rho = currentChi - tempChi;
+      double scale = 0;
+      for (int j = 0; j < nall; ++j) scale += s.x[j] * (lambda * s.x[j] + s.b[j]);
+      scale += 1e-3;
+      rho /= scale;
+      if (rho > 0 && isfinite(tempChi)) {
+        double alpha = 1. - pow((2 * rho - 1), 3);
+        alpha = fmin(alpha, 2. / 3.);
+        lambda *= fmax(1. / 3., alpha);
+        ni = 2; currentChi = tempChi;
+      } else {
+        lambda *= ni; ni *= 2;
+        state_unpack(&s, s.bak);
+      }
+      qmax++; trials_total++;
+    } while (rho < 0 && qmax < 10);
+    ++cj;
+    if (res->n_trace < OSH_LBA_MAX_TRACE) { res->chi2_trace[res->n_trace] = currentChi; res->lambda_trace[res->n_trace] = lambda; res->trials_trace[res->n_trace] = qmax; res->n_trace++; }
+    if (qmax == 10 || rho == 0) { ok = 0; continue; }
+    if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+    if (nBad >= 3) { ok = 0; continue; }
+  }
+  res->iterations = cj; res->trials = trials_total; res->status = OSH_OK;
+  /* err_end: activeRobustChi2() on the stored (possibly stale) errors */
+  res->chi2_final = robust_chi2(&s);
+  const int N = s.N;
+  if (res->pose_Rcw) memcpy(res->pose_Rcw, s.Rcw, 72 * (size_t)N);
+  if (res->pose_tcw) memcpy(res->pose_tcw, s.tcw, 24 * (size_t)N);
+  if (res->pose_Rwb) memcpy(res->pose_Rwb, s.Rwb, 72 * (size_t)N);
+  if (res->pose_twb) memcpy(res->pose_twb, s.twb, 24 * (size_t)N);
+  if (res->vel) memcpy(res->vel, s.vel, 24 * (size_t)N);
+  if (res->bias_g) memcpy(res->bias_g, s.bg, 24 * (size_t)N);
+  if (res->bias_a) memcpy(res->bias_a, s.ba, 24 * (size_t)N);
+  if (res->points) memcpy(res->points, s.X, 24 * (size_t)s.L);
+  if (res->edge_chi2) for (int e = 0; e < s.E; ++e) res->edge_chi2[e] = vis_chi2(&s, e);
+  if (res->edge_depth_pos)
+    for (int e = 0; e < s.E; ++e) {   /* ImuCamPose::isDepthPositive (src/G2oTypes.cc:185-188) */
+      const int k = p->edge_pose[e];
+      const double* R = s.Rcw + 9 * k; const double* X = s.X + 3 * p->edge_point[e];
+      res->edge_depth_pos[e] = (R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + s.tcw[3 * k + 2]) > 0.0;
+    }
+  istate_free(&s);
+  return OSH_OK;
+}

@@ -25,6 +25,13 @@ int  oracle_edge_depth_positive(const double qt[7], const double X[3]);
 void oracle_huber(double e, double delta, double rho[3]);
 int  oracle_ldlt_solve(int n, double* A, const double* b, double* x, double* tmp);
 
+/* ---- local inertial BA (liba_oracle.c) ---- */
+int  oracle_liba_solve(const osh_liba_problem* p, osh_liba_result* res);
+int  oracle_liba_linearize(const osh_liba_problem* p, double* H, double* b, double* Hll, double* Hpl, double* chi2);
+int  oracle_liba_inertial_edge(const osh_liba_problem* p, int link, double* r9, double* J9x24);
+void oracle_exp_so3(const double* w, double* R);
+void oracle_log_so3(const double* R, double* w);
+
 /* ---- ORB matching (orb_oracle.c) ---- */
 int  oracle_descriptor_distance(const uint8_t* a, const uint8_t* b);
 void oracle_distance_matrix(int n, int m, const uint8_t* a, const uint8_t* b, int32_t* out);

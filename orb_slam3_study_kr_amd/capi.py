@@ -61,6 +61,42 @@ class LbaResult(C.Structure):
     ]
 
 
+OSH_PREINT_FLOATS = 72
+
+
+class LibaProblem(C.Structure):
+    """``osh_liba_problem`` (include/orbslam3_hip.h)."""
+
+    _fields_ = [
+        ("n_opt", C.c_int32), ("n_fixed_imu", C.c_int32), ("n_fixed", C.c_int32),
+        ("n_points", C.c_int32), ("n_edges", C.c_int32), ("n_links", C.c_int32),
+        ("pose_Rcw", c_double_p), ("pose_tcw", c_double_p), ("pose_Rwb", c_double_p), ("pose_twb", c_double_p),
+        ("Rcb", c_double_p), ("tcb", c_double_p), ("tbc", c_double_p), ("cam", c_double_p),
+        ("vel", c_double_p), ("bias_g", c_double_p), ("bias_a", c_double_p), ("points", c_double_p),
+        ("edge_pose", c_int32_p), ("edge_point", c_int32_p), ("edge_kind", c_uint8_p),
+        ("edge_obs", c_double_p), ("edge_info", c_double_p),
+        ("link_prev", c_int32_p), ("link_cur", c_int32_p), ("link_preint", c_float_p),
+        ("link_info", c_double_p), ("link_info_g", c_double_p), ("link_info_a", c_double_p), ("link_robust", c_uint8_p),
+        ("huber_mono", C.c_double), ("huber_stereo", C.c_double), ("huber_inertial", C.c_double),
+        ("lambda_init", C.c_double), ("max_iterations", C.c_int32),
+    ]
+
+
+class LibaResult(C.Structure):
+    """``osh_liba_result`` (include/orbslam3_hip.h)."""
+
+    _fields_ = [
+        ("pose_Rcw", c_double_p), ("pose_tcw", c_double_p), ("pose_Rwb", c_double_p), ("pose_twb", c_double_p),
+        ("vel", c_double_p), ("bias_g", c_double_p), ("bias_a", c_double_p), ("points", c_double_p),
+        ("edge_chi2", c_double_p), ("edge_depth_pos", c_uint8_p),
+        ("status", C.c_int32), ("iterations", C.c_int32), ("trials", C.c_int32), ("n_trace", C.c_int32),
+        ("chi2_trace", C.c_double * OSH_LBA_MAX_TRACE),
+        ("lambda_trace", C.c_double * OSH_LBA_MAX_TRACE),
+        ("trials_trace", C.c_int32 * OSH_LBA_MAX_TRACE),
+        ("chi2_initial", C.c_double), ("chi2_final", C.c_double),
+    ]
+
+
 class OrbBatch(C.Structure):
     """``osh_orb_batch`` (include/orbslam3_hip.h)."""
 

@@ -1,0 +1,347 @@
+"""Synthetic stereo-inertial local-BA windows (BASELINE.json configs[3], SURVEY.md 8d "Config 4").
+
+An EuRoC-shaped window: N temporal keyframes 0.25 s apart (+1 fixed predecessor, + fixed covisible keyframes),
+~2000 stereo landmarks, 200 Hz IMU with the EuRoC noise densities (Examples/Stereo-Inertial/EuRoC.yaml:74-78)
+scaled as src/Tracking.cc:613-614 does, T_bc from EuRoC.yaml:64-71.  The IMU stream is preintegrated with the
+reference's FLOAT32 recursion (IMU::Preintegrated::IntegrateNewMeasurement, src/ImuTypes.cc:177-237), restated
+here in numpy float32; the 9x9 information follows EdgeInertial's constructor (src/G2oTypes.cc:492-511).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import capi, synth
+
+f32 = np.float32
+GRAVITY = float(f32(9.81))
+# T_b_c1 of EuRoC cam0 (Examples/Stereo-Inertial/EuRoC.yaml:64-71)
+T_BC = np.array([[0.0148655429818, -0.999880929698, 0.00414029679422, -0.0216401454975],
+                 [0.999557249008, 0.0149672133247, 0.025715529948, -0.064676986768],
+                 [-0.0257744366974, 0.00375618835797, 0.999660727178, 0.00981073058949],
+                 [0.0, 0.0, 0.0, 1.0]])
+IMU_FREQ = 200.0
+NG, NA, NGW, NAW = 1.7e-4, 2.0e-3, 1.9393e-5, 3.0e-3
+
+
+def hat(v):
+    return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]], dtype=np.asarray(v).dtype)
+
+
+def exp_so3(w):
+    th = np.linalg.norm(w)
+    W = hat(np.asarray(w, dtype=np.float64))
+    if th < 1e-10:
+        return np.eye(3) + W
+    return np.eye(3) + np.sin(th) / th * W + (1 - np.cos(th)) / th**2 * (W @ W)
+
+
+def log_so3(R):
+    c = np.clip((np.trace(R) - 1) / 2, -1, 1)
+    th = np.arccos(c)
+    w = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) / 2
+    return w if th < 1e-10 else th * w / np.sin(th)
+
+
+def _normalize_f32(R):
+    u, _, vt = np.linalg.svd(R.astype(f32))
+    return (u @ vt).astype(f32)
+
+
+def preintegrate(acc, gyr, dt, bias, nga_diag, walk_diag):
+    """IMU::Preintegrated::IntegrateNewMeasurement over a measurement list, float32 throughout.
+    bias = (bax bay baz bwx bwy bwz).  Returns the OSH_PREINT_FLOATS record and the 15x15 covariance C."""
+    b = np.asarray(bias, dtype=f32)
+    dR, dV, dP = np.eye(3, dtype=f32), np.zeros(3, f32), np.zeros(3, f32)
+    JRg, JVg, JVa, JPg, JPa = (np.zeros((3, 3), f32) for _ in range(5))
+    Cm = np.zeros((15, 15), f32)
+    Nga, Walk = np.diag(np.asarray(nga_diag, f32)), np.diag(np.asarray(walk_diag, f32))
+    dT = f32(0)
+    dt = f32(dt)
+    I3 = np.eye(3, dtype=f32)
+    for a_m, w_m in zip(np.asarray(acc, f32), np.asarray(gyr, f32)):
+        A, B = np.eye(9, dtype=f32), np.zeros((9, 6), f32)
+        a = (a_m - b[:3]).astype(f32)
+        dP = (dP + dV * dt + f32(0.5) * (dR @ a) * dt * dt).astype(f32)
+        dV = (dV + (dR @ a) * dt).astype(f32)
+        Wacc = hat(a).astype(f32)
+        A[3:6, 0:3] = -dR * dt @ Wacc
+        A[6:9, 0:3] = f32(-0.5) * dR * dt * dt @ Wacc
+        A[6:9, 3:6] = I3 * dt
+        B[3:6, 3:6] = dR * dt
+        B[6:9, 3:6] = f32(0.5) * dR * dt * dt
+        JPa = (JPa + JVa * dt - f32(0.5) * dR * dt * dt).astype(f32)
+        JPg = (JPg + JVg * dt - f32(0.5) * dR * dt * dt @ Wacc @ JRg).astype(f32)
+        JVa = (JVa - dR * dt).astype(f32)
+        JVg = (JVg - dR * dt @ Wacc @ JRg).astype(f32)
+        # IntegratedRotation (src/ImuTypes.cc:86-108)
+        v = ((w_m - b[3:]) * dt).astype(f32)
+        d2 = f32(v @ v)
+        d = f32(np.sqrt(d2))
+        W = hat(v).astype(f32)
+        if d < f32(1e-4):
+            deltaR, rightJ = (I3 + W).astype(f32), I3.copy()
+        else:
+            deltaR = (I3 + W * f32(np.sin(d)) / d + W @ W * (f32(1.0) - f32(np.cos(d))) / d2).astype(f32)
+            rightJ = (I3 - W * (f32(1.0) - f32(np.cos(d))) / d2 + W @ W * (d - f32(np.sin(d))) / (d2 * d)).astype(f32)
+        dR = _normalize_f32(dR @ deltaR)
+        A[0:3, 0:3] = deltaR.T
+        B[0:3, 0:3] = rightJ * dt
+        Cm[0:9, 0:9] = (A @ Cm[0:9, 0:9] @ A.T + B @ Nga @ B.T).astype(f32)
+        Cm[9:15, 9:15] += Walk
+        JRg = (deltaR.T @ JRg - rightJ * dt).astype(f32)
+        dT = f32(dT + dt)
+    rec = np.zeros(capi.OSH_PREINT_FLOATS, f32)
+    rec[0] = dT
+    rec[1:10], rec[10:13], rec[13:16] = dR.ravel(), dV, dP
+    rec[16:25], rec[25:34], rec[34:43], rec[43:52], rec[52:61] = JRg.ravel(), JVg.ravel(), JVa.ravel(), JPg.ravel(), JPa.ravel()
+    rec[61:67] = b
+    return rec, Cm
+
+
+def inertial_information(Cm, downweight=False):
+    """EdgeInertial information (src/G2oTypes.cc:500-508): inverse, symmetrise, zero eigenvalues < 1e-12."""
+    info = np.linalg.inv(Cm[:9, :9].astype(np.float64))
+    info = (info + info.T) / 2
+    w, V = np.linalg.eigh(info)
+    w[w < 1e-12] = 0
+    info = V @ np.diag(w) @ V.T
+    return info * 1e-2 if downweight else info
+
+
+@dataclass
+class LibaWindow:
+    n_opt: int
+    n_fixed_imu: int
+    n_fixed: int
+    pose_Rcw: np.ndarray
+    pose_tcw: np.ndarray
+    pose_Rwb: np.ndarray
+    pose_twb: np.ndarray
+    Rcb: np.ndarray
+    tcb: np.ndarray
+    tbc: np.ndarray
+    cam: np.ndarray
+    vel: np.ndarray
+    bias_g: np.ndarray
+    bias_a: np.ndarray
+    points: np.ndarray
+    edge_pose: np.ndarray
+    edge_point: np.ndarray
+    edge_kind: np.ndarray
+    edge_obs: np.ndarray
+    edge_info: np.ndarray
+    link_prev: np.ndarray
+    link_cur: np.ndarray
+    link_preint: np.ndarray
+    link_info: np.ndarray
+    link_info_g: np.ndarray
+    link_info_a: np.ndarray
+    link_robust: np.ndarray
+    huber_mono: float = synth.HUBER_MONO
+    huber_stereo: float = synth.HUBER_STEREO
+    huber_inertial: float = float(np.sqrt(16.92))
+    lambda_init: float = 1.0
+    max_iterations: int = 10
+    gt: dict | None = None
+
+    _F64 = ("pose_Rcw", "pose_tcw", "pose_Rwb", "pose_twb", "Rcb", "tcb", "tbc", "cam", "vel", "bias_g", "bias_a", "points",
+            "edge_obs", "edge_info", "link_info", "link_info_g", "link_info_a")
+
+    def normalise(self):
+        for k in self._F64:
+            setattr(self, k, np.ascontiguousarray(getattr(self, k), dtype=np.float64))
+        for k in ("edge_pose", "edge_point", "link_prev", "link_cur"):
+            setattr(self, k, np.ascontiguousarray(getattr(self, k), dtype=np.int32))
+        for k in ("edge_kind", "link_robust"):
+            setattr(self, k, np.ascontiguousarray(getattr(self, k), dtype=np.uint8))
+        self.link_preint = np.ascontiguousarray(self.link_preint, dtype=np.float32)
+        return self
+
+    @property
+    def n_points(self):
+        return self.points.shape[0]
+
+    @property
+    def n_edges(self):
+        return self.edge_pose.shape[0]
+
+    @property
+    def n_links(self):
+        return self.link_prev.shape[0]
+
+    def as_struct(self) -> capi.LibaProblem:
+        self.normalise()
+        p = capi.LibaProblem()
+        p.n_opt, p.n_fixed_imu, p.n_fixed = self.n_opt, self.n_fixed_imu, self.n_fixed
+        p.n_points, p.n_edges, p.n_links = self.n_points, self.n_edges, self.n_links
+        for k in self._F64:
+            setattr(p, k, capi.ptr(getattr(self, k), capi.c_double_p))
+        p.edge_pose, p.edge_point = capi.ptr(self.edge_pose, capi.c_int32_p), capi.ptr(self.edge_point, capi.c_int32_p)
+        p.edge_kind = capi.ptr(self.edge_kind, capi.c_uint8_p)
+        p.link_prev, p.link_cur = capi.ptr(self.link_prev, capi.c_int32_p), capi.ptr(self.link_cur, capi.c_int32_p)
+        p.link_preint = capi.ptr(self.link_preint, capi.c_float_p)
+        p.link_robust = capi.ptr(self.link_robust, capi.c_uint8_p)
+        p.huber_mono, p.huber_stereo, p.huber_inertial = self.huber_mono, self.huber_stereo, self.huber_inertial
+        p.lambda_init, p.max_iterations = self.lambda_init, self.max_iterations
+        return p
+
+
+class LibaResultArrays:
+    def __init__(self, w: LibaWindow):
+        N, L, E = w.n_opt, w.n_points, w.n_edges
+        self.pose_Rcw, self.pose_tcw = np.zeros((N, 3, 3)), np.zeros((N, 3))
+        self.pose_Rwb, self.pose_twb = np.zeros((N, 3, 3)), np.zeros((N, 3))
+        self.vel, self.bias_g, self.bias_a = np.zeros((N, 3)), np.zeros((N, 3)), np.zeros((N, 3))
+        self.points = np.zeros((L, 3))
+        self.edge_chi2 = np.zeros(E)
+        self.edge_depth_pos = np.zeros(E, dtype=np.uint8)
+        self.struct = capi.LibaResult()
+        self.bind(self.struct)
+
+    def bind(self, r):
+        for k in ("pose_Rcw", "pose_tcw", "pose_Rwb", "pose_twb", "vel", "bias_g", "bias_a", "points", "edge_chi2"):
+            setattr(r, k, capi.ptr(getattr(self, k), capi.c_double_p))
+        r.edge_depth_pos = capi.ptr(self.edge_depth_pos, capi.c_uint8_p)
+
+    def read_scalars(self, r):
+        n = r.n_trace
+        self.status, self.iterations, self.trials = r.status, r.iterations, r.trials
+        self.chi2_initial, self.chi2_final = r.chi2_initial, r.chi2_final
+        self.chi2_trace = np.array(r.chi2_trace[:n])
+        self.lambda_trace = np.array(r.lambda_trace[:n])
+        self.trials_trace = np.array(r.trials_trace[:n])
+        return self
+
+
+def _trajectory(t):
+    """Smooth body trajectory: world z up, camera (= body z) looking along world +x."""
+    R0 = np.array([[0.0, 0.0, 1.0], [-1.0, 0.0, 0.0], [0.0, -1.0, 0.0]])
+    th = np.array([0.05 * np.sin(0.9 * t), 0.12 * np.sin(0.6 * t + 0.3), 0.04 * np.sin(1.1 * t)])
+    R = R0 @ exp_so3(th)
+    p = np.array([0.9 * t + 0.1 * np.sin(1.3 * t), 0.35 * np.sin(0.8 * t), 0.12 * np.sin(1.7 * t)])
+    v = np.array([0.9 + 0.13 * np.cos(1.3 * t), 0.28 * np.cos(0.8 * t), 0.204 * np.cos(1.7 * t)])
+    a = np.array([-0.169 * np.sin(1.3 * t), -0.224 * np.sin(0.8 * t), -0.3468 * np.sin(1.7 * t)])
+    return R, p, v, a
+
+
+def make_inertial_window(seed: int = 11, n_opt: int = 10, n_fixed: int = 20, n_points: int = 2000, kf_dt: float = 0.25,
+                         pixel_noise: bool = True, outlier_frac: float = 0.02, rec_init: bool = False, large: bool = False,
+                         imu_noise: bool = True) -> LibaWindow:
+    rng = np.random.Generator(np.random.PCG64(seed))
+    per = int(round(kf_dt * IMU_FREQ))
+    dt = 1.0 / IMU_FREQ
+    sf = np.sqrt(IMU_FREQ)
+    nga = np.array([(NG * sf) ** 2] * 3 + [(NA * sf) ** 2] * 3)
+    walk = np.array([(NGW / sf) ** 2] * 3 + [(NAW / sf) ** 2] * 3)
+    bg_true, ba_true = np.array([0.002, -0.0015, 0.003]), np.array([0.03, -0.02, 0.015])
+    Rbc, tbc = T_BC[:3, :3], T_BC[:3, 3]
+    Rcb, tcb = Rbc.T, -Rbc.T @ tbc
+    # keyframe times: fixed observers (oldest), the fixed predecessor, then the temporal window
+    K_imu = n_opt + 1
+    times = np.concatenate([-(np.arange(n_fixed, 0, -1) + 0.0) * kf_dt - kf_dt, np.arange(K_imu) * kf_dt - kf_dt])
+    # time index order: [fixed observers..., predecessor, opt_0 (oldest) ... opt_{N-1}]
+    def cam_pose(t):
+        Rwb, twb, v, _ = _trajectory(t)
+        Rwc = Rwb @ Rbc
+        twc = Rwb @ tbc + twb
+        return Rwb, twb, v, Rwc.T, -Rwc.T @ twc
+    gt = [cam_pose(t) for t in times]
+    # landmarks in front of the path (world +x), 4-12 m ahead / around
+    x0, x1 = _trajectory(times[0])[1][0], _trajectory(times[-1])[1][0]
+    Xw = np.stack([rng.uniform(x0 + 3.0, x1 + 12.0, n_points), rng.uniform(-5.0, 5.0, n_points), rng.uniform(-2.5, 2.5, n_points)], axis=1)
+    fx, fy, cx, cy, bf = (float(v) for v in (synth.FX, synth.FY, synth.CX, synth.CY, synth.BF))
+    # pose index of the problem: opt (ascending time), predecessor, fixed observers
+    T = len(times)
+    pidx = np.zeros(T, dtype=np.int32)
+    pidx[n_fixed + 1:] = np.arange(n_opt)
+    pidx[n_fixed] = n_opt
+    pidx[:n_fixed] = n_opt + 1 + np.arange(n_fixed)
+    ep, el, eobs, einfo, eout = [], [], [], [], []
+    for ti in range(T):
+        Rcw, tcw = gt[ti][3], gt[ti][4]
+        Xc = Xw @ Rcw.T + tcw
+        z = Xc[:, 2]
+        u = fx * Xc[:, 0] / z + cx
+        v = fy * Xc[:, 1] / z + cy
+        ur = u - bf / z
+        vis = (z > 1.0) & (z < 14.0) & (u >= 0) & (u < synth.IMG_W) & (v >= 0) & (v < synth.IMG_H) & (ur >= 0)
+        idx = np.nonzero(vis)[0]
+        if ti < n_fixed:   # a fixed observer keeps a random third of what it sees
+            idx = idx[rng.uniform(0, 1, idx.size) < 0.35]
+        octave = rng.integers(0, synth.N_LEVELS, idx.size)
+        sig = synth.SCALE_FACTORS[octave].astype(np.float64)
+        noise = rng.standard_normal((idx.size, 3)) * sig[:, None] if pixel_noise else np.zeros((idx.size, 3))
+        is_out = rng.uniform(0, 1, idx.size) < outlier_frac
+        noise += rng.standard_normal((idx.size, 3)) * 20.0 * is_out[:, None]
+        ep.append(np.full(idx.size, pidx[ti])); el.append(idx)
+        eobs.append(np.stack([u[idx], v[idx], ur[idx]], axis=1) + noise)
+        einfo.append(synth.INV_LEVEL_SIGMA2[octave].astype(np.float64)); eout.append(is_out)
+    ep, el, eobs, einfo, eout = (np.concatenate(a) for a in (ep, el, eobs, einfo, eout))
+    # keep landmarks seen by >= 2 keyframes of which >= 1 optimisable (local points come from the temporal window)
+    cnt = np.bincount(el, minlength=n_points)
+    cnt_opt = np.bincount(el[ep < n_opt], minlength=n_points)
+    keep_l = (cnt >= 2) & (cnt_opt >= 1)
+    sel = keep_l[el]
+    remap = -np.ones(n_points, dtype=np.int64)
+    remap[keep_l] = np.arange(keep_l.sum())
+    ep, el, eobs, einfo, eout = ep[sel], remap[el[sel]], eobs[sel], einfo[sel], eout[sel]
+    order = np.lexsort((ep, el))     # insertion order: landmark-major
+    ep, el, eobs, einfo, eout = ep[order], el[order], eobs[order], einfo[order], eout[order]
+    Xw = Xw[keep_l]
+    # IMU stream + preintegration per link (predecessor -> opt_0, opt_0 -> opt_1, ...)
+    recs, infos, infog, infoa = [], [], [], []
+    bias_lin = []
+    for l in range(n_opt):
+        t_a = times[n_fixed + l]
+        acc, gyr = [], []
+        for k in range(per):
+            t = t_a + k * dt
+            R0_, _, _, a0 = _trajectory(t)
+            R1_ = _trajectory(t + dt)[0]
+            w = log_so3(R0_.T @ R1_) / dt
+            f = R0_.T @ (a0 - np.array([0, 0, -GRAVITY]))
+            if imu_noise:
+                w = w + rng.standard_normal(3) * NG * sf
+                f = f + rng.standard_normal(3) * NA * sf
+            gyr.append(w + bg_true); acc.append(f + ba_true)
+        b_lin = np.concatenate([ba_true + rng.standard_normal(3) * 2e-3, bg_true + rng.standard_normal(3) * 2e-4])
+        rec, Cm = preintegrate(acc, gyr, dt, b_lin, nga, walk)
+        recs.append(rec); bias_lin.append(b_lin)
+        infos.append(inertial_information(Cm, downweight=(l == 0)))   # i == N-1 in the reference's newest-first order
+        infog.append(np.linalg.inv(Cm[9:12, 9:12].astype(np.float64)))
+        infoa.append(np.linalg.inv(Cm[12:15, 12:15].astype(np.float64)))
+    # initial estimates: float32 keyframe storage; optimisable keyframes perturbed in the body frame
+    K = n_opt + 1 + n_fixed
+    Rcw_a, tcw_a, Rwb_a, twb_a = np.zeros((K, 3, 3)), np.zeros((K, 3)), np.zeros((K, 3, 3)), np.zeros((K, 3))
+    vel, bg, ba = np.zeros((K_imu, 3)), np.zeros((K_imu, 3)), np.zeros((K_imu, 3))
+    gt_Rwb, gt_twb, gt_vel = np.zeros((K, 3, 3)), np.zeros((K, 3)), np.zeros((K_imu, 3))
+    for ti in range(T):
+        k = pidx[ti]
+        Rwb, twb, v = gt[ti][0], gt[ti][1], gt[ti][2]
+        gt_Rwb[k], gt_twb[k] = Rwb, twb
+        if k < n_opt:
+            Rwb = Rwb @ exp_so3(rng.standard_normal(3) * 0.01)
+            twb = twb + rng.standard_normal(3) * 0.03
+        Rwc = Rwb @ Rbc
+        twc = Rwb @ tbc + twb
+        Rcw_a[k], tcw_a[k], Rwb_a[k], twb_a[k] = Rwc.T, -Rwc.T @ twc, Rwb, twb
+        if k < K_imu:
+            gt_vel[k] = v
+            vel[k] = v + (rng.standard_normal(3) * 0.05 if k < n_opt else 0)
+            bg[k] = bg_true + rng.standard_normal(3) * 1e-4
+            ba[k] = ba_true + rng.standard_normal(3) * 1e-3
+    q = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)   # noqa: E731  float storage of the map
+    w = LibaWindow(
+        n_opt=n_opt, n_fixed_imu=1, n_fixed=n_fixed, pose_Rcw=q(Rcw_a), pose_tcw=q(tcw_a), pose_Rwb=q(Rwb_a), pose_twb=q(twb_a),
+        Rcb=q(Rcb), tcb=q(tcb), tbc=q(tbc), cam=q([fx, fy, cx, cy, bf]), vel=q(vel), bias_g=q(bg), bias_a=q(ba),
+        points=q(Xw + rng.standard_normal(Xw.shape) * 0.05), edge_pose=ep, edge_point=el,
+        edge_kind=np.full(ep.size, capi.OSH_EDGE_STEREO, dtype=np.uint8), edge_obs=q(eobs), edge_info=einfo,
+        link_prev=np.array([n_opt] + list(range(n_opt - 1)), dtype=np.int32), link_cur=np.arange(n_opt, dtype=np.int32),
+        link_preint=np.stack(recs), link_info=np.stack(infos), link_info_g=np.stack(infog), link_info_a=np.stack(infoa),
+        link_robust=np.array([1 if (l == 0 or rec_init) else 0 for l in range(n_opt)], dtype=np.uint8),
+        lambda_init=1e-2 if large else 1.0, max_iterations=4 if large else 10,
+        gt=dict(Rwb=gt_Rwb, twb=gt_twb, vel=gt_vel, points=Xw, outliers=eout, bg=bg_true, ba=ba_true))
+    return w.normalise()
