@@ -128,6 +128,7 @@ _SIGNATURES = {
     "osh_lba_solve": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(LbaProblem), C.POINTER(LbaResult)]),
     "osh_lba_linearize": (C.c_int, [C.c_void_p, C.c_int32] + [c_double_p] * 7),
     "osh_lba_debug_trial": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, c_double_p, c_double_p, c_double_p]),
+    "osh_liba_solve": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(LibaProblem), C.POINTER(LibaResult)]),
     "osh_lba_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "osh_lba_get_profile": (C.c_int, [C.c_void_p, c_int64_p, c_double_p]),
     "osh_lba_kernel_name": (C.c_char_p, [C.c_int]),

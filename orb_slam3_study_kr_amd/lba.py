@@ -59,6 +59,20 @@ class LbaSolver:
         self.optimize()
         return self.download()
 
+    # -- local inertial BA (one persistent block per window, csrc/liba_device.hip) ---------------
+    def solve_inertial(self, windows):
+        from .synth_inertial import LibaResultArrays
+        n = len(windows)
+        probs = (capi.LibaProblem * n)()
+        for i, w in enumerate(windows):
+            probs[i] = w.as_struct()
+        outs = [LibaResultArrays(w) for w in windows]
+        arr = (capi.LibaResult * n)()
+        for i, o in enumerate(outs):
+            o.bind(arr[i])
+        capi.check(self.lib.osh_liba_solve(self.ctx, n, probs, arr), "osh_liba_solve", self.lib)
+        return [o.read_scalars(arr[i]) for i, o in enumerate(outs)]
+
     # -- parity / debug aids ------------------------------------------------------------------
     def linearize(self, window: int = 0) -> dict:
         w = self._windows[window]
