@@ -4,6 +4,7 @@
 #define KEYFRAME_H
 #include <vector>
 #include "CameraModels/GeometricCamera.h"
+#include "ImuTypes.h"
 #include "Map.h"
 #include "MapPoint.h"
 #include "orbslam3_compat.h"
@@ -11,8 +12,19 @@ namespace ORB_SLAM3 {
 class KeyFrame {
  public:
   KeyFrame(long unsigned int id, Map* pMap) : mnId(id), mpMap(pMap) {}
-  void SetPose(const Sophus::SE3f& Tcw) { mTcw = Tcw; ++mnPoseSets; }
+  void SetPose(const Sophus::SE3f& Tcw);   // src/KeyFrame.cc:109-122 (also refreshes the IMU position Owb)
   Sophus::SE3f GetPose() { return mTcw; }
+  // inertial accessors (src/KeyFrame.cc:124-181,809-833)
+  void SetVelocity(const Eigen::Vector3f& Vw) { mVw = Vw; mbHasVelocity = true; }
+  Eigen::Vector3f GetImuPosition() { return mOwb; }
+  Eigen::Matrix3f GetImuRotation() { return (mTwc * mImuCalib.mTcb).rotationMatrix(); }
+  Eigen::Matrix3f GetRotation() { return mRcw; }
+  Eigen::Vector3f GetTranslation() { return mTcw.translation(); }
+  Eigen::Vector3f GetVelocity() { return mVw; }
+  void SetNewBias(const IMU::Bias& b) { mImuBias = b; if (mpImuPreintegrated) mpImuPreintegrated->SetNewBias(b); }
+  Eigen::Vector3f GetGyroBias() { return Eigen::Vector3f(mImuBias.bwx, mImuBias.bwy, mImuBias.bwz); }
+  Eigen::Vector3f GetAccBias() { return Eigen::Vector3f(mImuBias.bax, mImuBias.bay, mImuBias.baz); }
+  IMU::Bias GetImuBias() { return mImuBias; }
   std::vector<KeyFrame*> GetVectorCovisibleKeyFrames() { return mvpOrderedConnectedKeyFrames; }
   std::vector<MapPoint*> GetMapPointMatches() { return mvpMapPoints; }
   void EraseMapPointMatch(MapPoint* pMP);
@@ -29,8 +41,16 @@ class KeyFrame {
   std::vector<float> mvInvLevelSigma2;
   GeometricCamera* mpCamera = nullptr;
   GeometricCamera* mpCamera2 = nullptr;
+  KeyFrame* mPrevKF = nullptr;
+  bool bImu = false;
+  IMU::Preintegrated* mpImuPreintegrated = nullptr;
+  IMU::Calib mImuCalib;
   // test-double state
-  Sophus::SE3f mTcw, mTrl;
+  Sophus::SE3f mTcw, mTrl, mTwc;
+  Eigen::Matrix3f mRcw;
+  Eigen::Vector3f mOwb, mVw;
+  IMU::Bias mImuBias;
+  bool mbHasVelocity = false;
   std::vector<KeyFrame*> mvpOrderedConnectedKeyFrames;
   std::vector<MapPoint*> mvpMapPoints;
   bool mbBad = false;

@@ -9,6 +9,7 @@ class Map {
  public:
   long unsigned int GetInitKFid() { return mnInitKFid; }
   bool IsInertial() { return mbIsInertial; }
+  long unsigned int KeyFramesInMap() { return mnKeyFrames; }   // src/Map.cc:165
   void IncreaseChangeIndex() { ++mnMapChange; }
   int GetMapChangeIndex() { return mnMapChange; }
   std::mutex mMutexMapUpdate;
@@ -18,6 +19,7 @@ class Map {
   long unsigned int mnInitKFid = 0;
   bool mbIsInertial = false;
   int mnMapChange = 0;
+  long unsigned int mnKeyFrames = 0;
 };
 }  // namespace ORB_SLAM3
 #endif

@@ -11,7 +11,7 @@ class Optimizer {
   // src/Optimizer.cc:1116-1498.  num_MPs is never assigned by the reference either.
   void static LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF, int& num_OptKF,
                                     int& num_MPs, int& num_edges);
-  // src/Optimizer.cc:2387-2964 -- NOT built yet; declared so callers link, aborts loudly.
+  // src/Optimizer.cc:2387-2964 (csrc/host/OptimizerInertial.cc); the num_* out-parameters are never assigned, as in the reference.
   void static LocalInertialBA(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF, int& num_OptKF, int& num_MPs,
                               int& num_edges, bool bLarge = false, bool bRecInit = false);
 };

@@ -40,6 +40,8 @@ struct Matrix {
   const T& operator()(int r, int c) const { return v[r * C + c]; }
   template <class U> Matrix<U, R, C> cast() const { Matrix<U, R, C> o; for (int i = 0; i < R * C; ++i) o.v[i] = (U)v[i]; return o; }
 };
+using Matrix3f = Matrix<float, 3, 3>;
+using Matrix3d = Matrix<double, 3, 3>;
 using Vector2d = Matrix<double, 2>;
 using Vector3d = Matrix<double, 3>;
 using Vector3f = Matrix<float, 3>;
@@ -65,6 +67,52 @@ class SE3 {
  public:
   SE3() {}
   SE3(const Eigen::Quaternion<T>& q, const Eigen::Matrix<T, 3>& t) : q_(q), t_(t) { q_.normalize(); }  // SO3 ctor normalises
+  // from a rotation matrix (Eigen's matrix -> quaternion conversion)
+  SE3(const Eigen::Matrix<T, 3, 3>& R, const Eigen::Matrix<T, 3>& t) : t_(t) {
+    T tr = R(0, 0) + R(1, 1) + R(2, 2), x, y, z, w;
+    if (tr > T(0)) {
+      T s = std::sqrt(tr + T(1)); w = T(0.5) * s; s = T(0.5) / s;
+      x = (R(2, 1) - R(1, 2)) * s; y = (R(0, 2) - R(2, 0)) * s; z = (R(1, 0) - R(0, 1)) * s;
+    } else {
+      int i = 0;
+      if (R(1, 1) > R(0, 0)) i = 1;
+      if (R(2, 2) > R(i, i)) i = 2;
+      const int j = (i + 1) % 3, k = (j + 1) % 3;
+      T s = std::sqrt(R(i, i) - R(j, j) - R(k, k) + T(1));
+      T q[3];
+      q[i] = T(0.5) * s; s = T(0.5) / s;
+      w = (R(k, j) - R(j, k)) * s; q[j] = (R(j, i) + R(i, j)) * s; q[k] = (R(k, i) + R(i, k)) * s;
+      x = q[0]; y = q[1]; z = q[2];
+    }
+    q_ = Eigen::Quaternion<T>(w, x, y, z);
+    q_.normalize();
+  }
+  Eigen::Matrix<T, 3, 3> rotationMatrix() const {
+    const T x = q_.x(), y = q_.y(), z = q_.z(), w = q_.w();
+    const T tx = 2 * x, ty = 2 * y, tz = 2 * z, twx = tx * w, twy = ty * w, twz = tz * w;
+    const T txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    Eigen::Matrix<T, 3, 3> R;
+    R(0, 0) = 1 - (tyy + tzz); R(0, 1) = txy - twz; R(0, 2) = txz + twy;
+    R(1, 0) = txy + twz; R(1, 1) = 1 - (txx + tzz); R(1, 2) = tyz - twx;
+    R(2, 0) = txz - twy; R(2, 1) = tyz + twx; R(2, 2) = 1 - (txx + tyy);
+    return R;
+  }
+  SE3 inverse() const {
+    SE3 o;
+    o.q_ = Eigen::Quaternion<T>(q_.w(), -q_.x(), -q_.y(), -q_.z());
+    SE3 rot; rot.q_ = o.q_;
+    const Eigen::Matrix<T, 3> mt(-t_(0), -t_(1), -t_(2));
+    o.t_ = rot * mt;
+    return o;
+  }
+  SE3 operator*(const SE3& b) const {   // composition
+    SE3 o;
+    const T aw = q_.w(), ax = q_.x(), ay = q_.y(), az = q_.z(), bw = b.q_.w(), bx = b.q_.x(), by = b.q_.y(), bz = b.q_.z();
+    o.q_ = Eigen::Quaternion<T>(aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                                aw * by + ay * bw + az * bx - ax * bz, aw * bz + az * bw + ax * by - ay * bx);
+    o.t_ = (*this) * b.t_;
+    return o;
+  }
   const Eigen::Quaternion<T>& unit_quaternion() const { return q_; }
   const Eigen::Matrix<T, 3>& translation() const { return t_; }
   // p_out = R p + t

@@ -44,6 +44,27 @@ int  osh_host_kf_observes(osh_host_graph* g, int32_t kf_index, int32_t mp_index)
 int  osh_host_map_change_index(osh_host_graph* g);
 int  osh_host_kf_pose_sets(osh_host_graph* g, int32_t kf_index);
 
+/* ---- inertial ---- */
+/* Attach IMU state to the first n keyframes listed: previous keyframe (index or -1), velocity, bias (bax bay baz bwx bwy bwz),
+ * the preintegration from the previous keyframe (OSH_PREINT_FLOATS record, dT == 0: none) with its 15x15 covariance, and the
+ * camera-IMU calibration T_bc (qx qy qz qw tx ty tz).  Every keyframe of the map gets the calibration. */
+int osh_host_graph_set_inertial(osh_host_graph* g, int32_t n, const int32_t* kf_index, const int32_t* prev_index, const float* vel,
+                                const float* bias6, const float* preint, const float* cov225, const float* Tbc_qt);
+/* Window selection + packing of Optimizer::LocalInertialBA (no GPU): fills *out with pointers into storage owned by the
+ * graph (valid until the next call).  pose_kf_id / point_mp_id (may be NULL) receive the ids in problem order. */
+struct osh_liba_problem;
+int osh_host_pack_liba(osh_host_graph* g, int32_t kf_index, int32_t b_large, int32_t b_rec_init, struct osh_liba_problem* out,
+                       int64_t* pose_kf_id, int64_t* point_mp_id);
+/* ORB_SLAM3::Optimizer::LocalInertialBA(kf, NULL, map, ..., bLarge, bRecInit) */
+int osh_host_run_liba(osh_host_graph* g, int32_t kf_index, int32_t b_large, int32_t b_rec_init);
+void osh_host_get_kf_velocity(osh_host_graph* g, int32_t kf_index, float out[3]);
+void osh_host_get_kf_bias(osh_host_graph* g, int32_t kf_index, float out6[6]);
+/* IMU::Preintegrated: integrate n measurements (float32 recursion) -> record + covariance */
+int osh_host_preintegrate(int32_t n, const float* acc, const float* gyr, float dt, const float* bias6, const float* nga6,
+                          const float* walk6, float* rec_out, float* cov225_out);
+/* EdgeInertial information from a 15x15 preintegration covariance (inverse, symmetrise, eigenvalue clamp) */
+int osh_host_inertial_information(const float* cov225, double* info81_out);
+
 /* ---- matcher ---- */
 typedef struct osh_host_frame osh_host_frame;
 /* A frame with n keypoints (x y, octave, angle, uRight (<=0: none), 32-byte descriptor), pose Tcw. */

@@ -162,6 +162,13 @@ _HOST_SIGNATURES = {
     "osh_host_kf_observes": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "osh_host_map_change_index": (C.c_int, [C.c_void_p]),
     "osh_host_kf_pose_sets": (C.c_int, [C.c_void_p, C.c_int32]),
+    "osh_host_graph_set_inertial": (C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_int32_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p]),
+    "osh_host_pack_liba": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(LibaProblem), c_int64_p, c_int64_p]),
+    "osh_host_run_liba": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "osh_host_get_kf_velocity": (None, [C.c_void_p, C.c_int32, c_float_p]),
+    "osh_host_get_kf_bias": (None, [C.c_void_p, C.c_int32, c_float_p]),
+    "osh_host_preintegrate": (C.c_int, [C.c_int32, c_float_p, c_float_p, C.c_float, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p]),
+    "osh_host_inertial_information": (C.c_int, [c_float_p, c_double_p]),
     "osh_host_frame_create": (C.c_void_p, [C.c_int32, c_float_p, c_int32_p, c_float_p, c_float_p, c_uint8_p, c_float_p, c_float_p,
                                            C.c_float, C.c_float, C.c_int32, C.c_float]),
     "osh_host_frame_destroy": (None, [C.c_void_p]),

@@ -36,6 +36,8 @@ osh_lba_ctx* thread_ctx() {
 
 }  // namespace
 
+osh_lba_ctx* HostSolverContext() { return thread_ctx(); }
+
 // Steps 1-6 of src/Optimizer.cc:1118-1404: select the window and flatten it.
 bool PackLocalBA(KeyFrame* pKF, Map* pMap, LbaPack& pk) {
   pk = LbaPack();
@@ -223,13 +225,6 @@ void Optimizer::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap
     pMP->UpdateNormalAndDepth();
   }
   pMap->IncreaseChangeIndex();
-}
-
-void Optimizer::LocalInertialBA(KeyFrame*, bool*, Map*, int&, int&, int&, int&, bool, bool) {
-  // src/Optimizer.cc:2387-2964 -- the inertial window (EdgeInertial, 15-dof keyframe states) is the next row of
-  // SURVEY.md section 8 and has no device path yet.  Failing loudly is deliberate: there is no CPU fallback.
-  std::fprintf(stderr, "LocalInertialBA: not implemented on the MI355X path yet (DESIGN.md section 7)\n");
-  std::abort();
 }
 
 }  // namespace ORB_SLAM3

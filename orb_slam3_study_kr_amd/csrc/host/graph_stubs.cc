@@ -8,6 +8,15 @@
 
 namespace ORB_SLAM3 {
 
+// src/KeyFrame.cc:109-122: cache Rcw, Twc and the IMU position Owb = Rwc * tcb + twc
+void KeyFrame::SetPose(const Sophus::SE3f& Tcw) {
+  mTcw = Tcw;
+  mRcw = mTcw.rotationMatrix();
+  mTwc = mTcw.inverse();
+  if (mImuCalib.mbIsSet) mOwb = mTwc * mImuCalib.mTcb.translation();
+  ++mnPoseSets;
+}
+
 // src/KeyFrame.cc:309-332 (index looked up through the point's observation)
 void KeyFrame::EraseMapPointMatch(MapPoint* pMP) {
   for (size_t i = 0; i < mvpMapPoints.size(); ++i)

@@ -7,6 +7,7 @@
 #include "ORBmatcher.h"
 #include "Optimizer.h"
 #include "host_pack.h"
+#include "orbslam3_hip.h"
 #include "orbslam3_hip_host.h"
 
 using namespace ORB_SLAM3;
@@ -16,6 +17,8 @@ struct osh_host_graph {
   std::unique_ptr<Pinhole> cam;
   std::vector<std::unique_ptr<KeyFrame>> kfs;
   std::vector<std::unique_ptr<MapPoint>> mps;
+  std::vector<std::unique_ptr<IMU::Preintegrated>> preints;
+  LibaPack liba;   // storage behind osh_host_pack_liba
 };
 
 static Sophus::SE3f pose_from(const float* qt) {
@@ -118,6 +121,92 @@ extern "C" int osh_host_kf_observes(osh_host_graph* g, int32_t i, int32_t j) {
 }
 extern "C" int osh_host_map_change_index(osh_host_graph* g) { return g->map.GetMapChangeIndex(); }
 extern "C" int osh_host_kf_pose_sets(osh_host_graph* g, int32_t i) { return g->kfs[i]->mnPoseSets; }
+
+// ------------------------------------------------------------------------------------------ inertial
+extern "C" int osh_host_graph_set_inertial(osh_host_graph* g, int32_t n, const int32_t* kf_index, const int32_t* prev_index,
+                                           const float* vel, const float* bias6, const float* preint, const float* cov225,
+                                           const float* Tbc_qt) {
+  if (!g) return -1;
+  IMU::Calib calib(pose_from(Tbc_qt), 0.f, 0.f, 0.f, 0.f);
+  g->map.mnKeyFrames = g->kfs.size();
+  g->map.mbIsInertial = true;
+  for (auto& kf : g->kfs) { kf->mImuCalib = calib; kf->SetPose(kf->GetPose()); kf->mnPoseSets = 0; }
+  for (int i = 0; i < n; ++i) {
+    KeyFrame* kf = g->kfs[kf_index[i]].get();
+    kf->bImu = true;
+    kf->mPrevKF = prev_index[i] >= 0 ? g->kfs[prev_index[i]].get() : nullptr;
+    kf->SetVelocity(Eigen::Vector3f(vel[3 * i], vel[3 * i + 1], vel[3 * i + 2]));
+    kf->mImuBias = IMU::Bias(bias6[6 * i], bias6[6 * i + 1], bias6[6 * i + 2], bias6[6 * i + 3], bias6[6 * i + 4], bias6[6 * i + 5]);
+    const float* r = preint + (size_t)i * OSH_PREINT_FLOATS;
+    if (r[0] > 0.f) {
+      g->preints.emplace_back(new IMU::Preintegrated(IMU::Bias(r[61], r[62], r[63], r[64], r[65], r[66]), calib));
+      IMU::Preintegrated* P = g->preints.back().get();
+      P->dT = r[0];
+      for (int a = 0; a < 9; ++a) { P->dR.v[a] = r[1 + a]; P->JRg.v[a] = r[16 + a]; P->JVg.v[a] = r[25 + a]; P->JVa.v[a] = r[34 + a]; P->JPg.v[a] = r[43 + a]; P->JPa.v[a] = r[52 + a]; }
+      for (int a = 0; a < 3; ++a) { P->dV(a) = r[10 + a]; P->dP(a) = r[13 + a]; }
+      for (int a = 0; a < 225; ++a) P->C.v[a] = cov225[(size_t)i * 225 + a];
+      kf->mpImuPreintegrated = P;
+    }
+  }
+  return 0;
+}
+
+static void reset_marks(osh_host_graph* g) {
+  for (auto& kf : g->kfs) { kf->mnBALocalForKF = 0; kf->mnBAFixedForKF = 0; }
+  for (auto& mp : g->mps) mp->mnBALocalForKF = 0;
+}
+
+extern "C" int osh_host_pack_liba(osh_host_graph* g, int32_t kf_index, int32_t b_large, int32_t b_rec_init, osh_liba_problem* out,
+                                  int64_t* pose_kf_id, int64_t* point_mp_id) {
+  if (!g || !out || kf_index < 0 || kf_index >= (int)g->kfs.size()) return -1;
+  const bool ok = PackLocalInertialBA(g->kfs[kf_index].get(), &g->map, b_large != 0, b_rec_init != 0, g->liba);
+  reset_marks(g);
+  if (!ok) return 1;
+  if (g->liba.unsupported) return -3;
+  g->liba.fill(*out);
+  if (pose_kf_id) for (size_t i = 0; i < g->liba.vPoseKFs.size(); ++i) pose_kf_id[i] = (int64_t)g->liba.vPoseKFs[i]->mnId;
+  if (point_mp_id) for (size_t j = 0; j < g->liba.vPointMPs.size(); ++j) point_mp_id[j] = (int64_t)g->liba.vPointMPs[j]->mnId;
+  return 0;
+}
+
+extern "C" int osh_host_run_liba(osh_host_graph* g, int32_t kf_index, int32_t b_large, int32_t b_rec_init) {
+  if (!g || kf_index < 0 || kf_index >= (int)g->kfs.size()) return -1;
+  int a = -1, b = -1, c = -1, d = -1;
+  Optimizer::LocalInertialBA(g->kfs[kf_index].get(), nullptr, &g->map, a, b, c, d, b_large != 0, b_rec_init != 0);
+  return (a == -1 && b == -1 && c == -1 && d == -1) ? 0 : 2;   // the reference never assigns the num_* outputs
+}
+
+extern "C" void osh_host_get_kf_velocity(osh_host_graph* g, int32_t i, float o[3]) {
+  const Eigen::Vector3f v = g->kfs[i]->GetVelocity();
+  o[0] = v(0); o[1] = v(1); o[2] = v(2);
+}
+extern "C" void osh_host_get_kf_bias(osh_host_graph* g, int32_t i, float o[6]) {
+  const IMU::Bias b = g->kfs[i]->GetImuBias();
+  o[0] = b.bax; o[1] = b.bay; o[2] = b.baz; o[3] = b.bwx; o[4] = b.bwy; o[5] = b.bwz;
+}
+
+extern "C" int osh_host_preintegrate(int32_t n, const float* acc, const float* gyr, float dt, const float* bias6, const float* nga6,
+                                     const float* walk6, float* r, float* cov225_out) {
+  IMU::Calib calib;
+  for (int i = 0; i < 6; ++i) { calib.Cov[i] = nga6[i]; calib.CovWalk[i] = walk6[i]; }
+  IMU::Preintegrated P(IMU::Bias(bias6[0], bias6[1], bias6[2], bias6[3], bias6[4], bias6[5]), calib);
+  for (int k = 0; k < n; ++k)
+    P.IntegrateNewMeasurement(Eigen::Vector3f(acc[3 * k], acc[3 * k + 1], acc[3 * k + 2]), Eigen::Vector3f(gyr[3 * k], gyr[3 * k + 1], gyr[3 * k + 2]), dt);
+  for (int a = 0; a < OSH_PREINT_FLOATS; ++a) r[a] = 0.f;
+  r[0] = P.dT;
+  for (int a = 0; a < 9; ++a) { r[1 + a] = P.dR.v[a]; r[16 + a] = P.JRg.v[a]; r[25 + a] = P.JVg.v[a]; r[34 + a] = P.JVa.v[a]; r[43 + a] = P.JPg.v[a]; r[52 + a] = P.JPa.v[a]; }
+  for (int a = 0; a < 3; ++a) { r[10 + a] = P.dV(a); r[13 + a] = P.dP(a); }
+  r[61] = P.b.bax; r[62] = P.b.bay; r[63] = P.b.baz; r[64] = P.b.bwx; r[65] = P.b.bwy; r[66] = P.b.bwz;
+  for (int a = 0; a < 225; ++a) cov225_out[a] = P.C.v[a];
+  return 0;
+}
+
+extern "C" int osh_host_inertial_information(const float* cov225, double* info81_out) {
+  Eigen::Matrix<float, 15, 15> C;
+  for (int a = 0; a < 225; ++a) C.v[a] = cov225[a];
+  InertialInformation(C, info81_out);
+  return 0;
+}
 
 // ------------------------------------------------------------------------------------------ matcher
 struct osh_host_frame {

@@ -29,6 +29,37 @@ struct LbaPack {
     p.huber_mono = p.huber_stereo = 0; p.lambda_init = 0; p.max_iterations = 10; p.stop_flag = nullptr;
   }
 };
+struct LibaPack {
+  std::vector<KeyFrame*> vpOptimizableKFs;              // newest first, as the reference builds it (:2402-2417)
+  std::list<KeyFrame*> lFixedKeyFrames;
+  std::list<MapPoint*> lLocalMapPoints;
+  std::vector<KeyFrame*> vPoseKFs;                       // problem order: temporal (ascending id), fixed predecessor, fixed observers
+  std::vector<MapPoint*> vPointMPs;
+  std::vector<KeyFrame*> vEdgeKF;
+  std::vector<MapPoint*> vEdgeMP;
+  int n_opt = 0, n_fixed_imu = 0, n_fixed = 0, opt_it = 10;
+  const char* unsupported = nullptr;
+  std::vector<double> pose_Rcw, pose_tcw, pose_Rwb, pose_twb, vel, bias_g, bias_a, points, edge_obs, edge_info, link_info, link_info_g, link_info_a;
+  double Rcb[9], tcb[3], tbc[3], cam[5];
+  std::vector<int32_t> edge_pose, edge_point, link_prev, link_cur;
+  std::vector<uint8_t> edge_kind, link_robust;
+  std::vector<float> link_preint;
+  void fill(osh_liba_problem& p) const {
+    p.n_opt = n_opt; p.n_fixed_imu = n_fixed_imu; p.n_fixed = n_fixed;
+    p.n_points = (int32_t)vPointMPs.size(); p.n_edges = (int32_t)edge_pose.size(); p.n_links = (int32_t)link_prev.size();
+    p.pose_Rcw = pose_Rcw.data(); p.pose_tcw = pose_tcw.data(); p.pose_Rwb = pose_Rwb.data(); p.pose_twb = pose_twb.data();
+    p.Rcb = Rcb; p.tcb = tcb; p.tbc = tbc; p.cam = cam; p.vel = vel.data(); p.bias_g = bias_g.data(); p.bias_a = bias_a.data();
+    p.points = points.data(); p.edge_pose = edge_pose.data(); p.edge_point = edge_point.data(); p.edge_kind = edge_kind.data();
+    p.edge_obs = edge_obs.data(); p.edge_info = edge_info.data(); p.link_prev = link_prev.data(); p.link_cur = link_cur.data();
+    p.link_preint = link_preint.data(); p.link_info = link_info.data(); p.link_info_g = link_info_g.data(); p.link_info_a = link_info_a.data();
+    p.link_robust = link_robust.data();
+    p.huber_mono = p.huber_stereo = p.huber_inertial = 0; p.lambda_init = 1.0; p.max_iterations = opt_it;
+  }
+};
+bool PackLocalInertialBA(KeyFrame* pKF, Map* pMap, bool bLarge, bool bRecInit, LibaPack& pk);
+void InertialInformation(const Eigen::Matrix<float, 15, 15>& C, double* info81);
+osh_lba_ctx* HostSolverContext();   // one solver context per calling thread (Optimizer.cc)
+
 // Steps 1-6 of Optimizer::LocalBundleAdjustment; false when the window has no fixed keyframe.
 bool PackLocalBA(KeyFrame* pKF, Map* pMap, LbaPack& pk);
 }  // namespace ORB_SLAM3

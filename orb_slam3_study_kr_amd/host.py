@@ -152,3 +152,124 @@ class HostFrame:
                                                 capi.ptr(keep[1], capi.c_float_p), capi.ptr(keep[2], capi.c_uint8_p), th, int(mono),
                                                 int(check_ori), capi.ptr(assign, capi.c_int32_p))
         return n, assign
+
+
+def _quat_from_R(R):
+    return synth._quat_from_R(np.asarray(R, dtype=np.float64))
+
+
+class HostInertialGraph:
+    """A map with IMU state built from a synth_inertial.LibaWindow: keyframe k <-> pose index k of the window
+    (temporal keyframes ids 100+i, the fixed predecessor id 99, fixed observers ids 10+i)."""
+
+    def __init__(self, w):
+        self.lib = capi.load_library()
+        self.w = w
+        N, K = w.n_opt, w.n_opt + w.n_fixed_imu + w.n_fixed
+        self.kf_id = np.array([100 + i for i in range(N)] + [99] * w.n_fixed_imu + [10 + i for i in range(w.n_fixed)], dtype=np.int64)
+        self.mp_id = np.arange(w.n_points, dtype=np.int64) + 1000
+        pose = np.zeros((K, 7), dtype=np.float32)
+        for k in range(K):
+            pose[k, :4] = _quat_from_R(w.pose_Rcw.reshape(-1, 3, 3)[k])
+            pose[k, 4:] = w.pose_tcw.reshape(-1, 3)[k]
+        cam5, inv = _f32(w.cam), _f32(synth.INV_LEVEL_SIGMA2)
+        octave = _i32(np.round(np.log(1.0 / w.edge_info) / np.log(1.44)).astype(np.int32))
+        obs, mp_pos = _f32(w.edge_obs), _f32(w.points)
+        self.g = C.c_void_p(self.lib.osh_host_graph_create(
+            K, capi.ptr(self.kf_id, capi.c_int64_p), capi.ptr(pose, capi.c_float_p), capi.ptr(cam5, capi.c_float_p),
+            capi.ptr(inv, capi.c_float_p), len(inv), w.n_points, capi.ptr(self.mp_id, capi.c_int64_p), capi.ptr(mp_pos, capi.c_float_p),
+            w.n_edges, capi.ptr(_i32(w.edge_pose), capi.c_int32_p), capi.ptr(_i32(w.edge_point), capi.c_int32_p),
+            capi.ptr(obs, capi.c_float_p), capi.ptr(octave, capi.c_int32_p), -1 & 0x7FFFFFFF, 1))
+        n_imu = N + w.n_fixed_imu
+        kf_index = _i32(np.arange(n_imu))
+        prev = _i32([N if (i == 0 and w.n_fixed_imu) else i - 1 for i in range(N)] + [-1] * w.n_fixed_imu)
+        vel = _f32(w.vel.reshape(-1, 3)[:n_imu])
+        bias6 = _f32(np.concatenate([w.bias_a.reshape(-1, 3)[:n_imu], w.bias_g.reshape(-1, 3)[:n_imu]], axis=1))
+        pre = np.zeros((n_imu, capi.OSH_PREINT_FLOATS), dtype=np.float32)
+        cov = np.zeros((n_imu, 225), dtype=np.float32)
+        for l in range(w.n_links):
+            pre[int(w.link_cur[l])] = w.link_preint[l]
+            cov[int(w.link_cur[l])] = w.gt["link_cov"][l].ravel()
+        Tbc = w.gt["Tbc"]
+        tbc_qt = _f32(np.concatenate([_quat_from_R(Tbc[:3, :3]), Tbc[:3, 3]]))
+        self.lib.osh_host_graph_set_inertial(self.g, n_imu, capi.ptr(kf_index, capi.c_int32_p), capi.ptr(prev, capi.c_int32_p),
+                                             capi.ptr(vel, capi.c_float_p), capi.ptr(bias6, capi.c_float_p), capi.ptr(pre, capi.c_float_p),
+                                             capi.ptr(cov, capi.c_float_p), capi.ptr(tbc_qt, capi.c_float_p))
+        self.cur = N - 1
+
+    def close(self):
+        if self.g:
+            self.lib.osh_host_graph_destroy(self.g)
+            self.g = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def packed_window(self, large=False, rec_init=False):
+        """The osh_liba_problem the host layer builds, copied into a LibaWindow (for the oracle) + id maps."""
+        from .synth_inertial import LibaWindow
+        p = capi.LibaProblem()
+        K = len(self.kf_id)
+        kid, mid = np.zeros(K, dtype=np.int64), np.zeros(self.w.n_points, dtype=np.int64)
+        rc = self.lib.osh_host_pack_liba(self.g, self.cur, int(large), int(rec_init), C.byref(p), capi.ptr(kid, capi.c_int64_p),
+                                         capi.ptr(mid, capi.c_int64_p))
+        assert rc == 0, rc
+
+        def arr(ptr, n, dt=np.float64):
+            return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt).copy() if n else np.zeros(0, dtype=dt)
+        Kp, NV, L, E, NL = p.n_opt + p.n_fixed_imu + p.n_fixed, p.n_opt + p.n_fixed_imu, p.n_points, p.n_edges, p.n_links
+        w = LibaWindow(
+            n_opt=p.n_opt, n_fixed_imu=p.n_fixed_imu, n_fixed=p.n_fixed, pose_Rcw=arr(p.pose_Rcw, Kp * 9), pose_tcw=arr(p.pose_tcw, Kp * 3),
+            pose_Rwb=arr(p.pose_Rwb, Kp * 9), pose_twb=arr(p.pose_twb, Kp * 3), Rcb=arr(p.Rcb, 9), tcb=arr(p.tcb, 3), tbc=arr(p.tbc, 3),
+            cam=arr(p.cam, 5), vel=arr(p.vel, NV * 3), bias_g=arr(p.bias_g, NV * 3), bias_a=arr(p.bias_a, NV * 3),
+            points=arr(p.points, L * 3).reshape(-1, 3), edge_pose=arr(p.edge_pose, E, np.int32), edge_point=arr(p.edge_point, E, np.int32),
+            edge_kind=arr(p.edge_kind, E, np.uint8), edge_obs=arr(p.edge_obs, E * 3).reshape(-1, 3), edge_info=arr(p.edge_info, E),
+            link_prev=arr(p.link_prev, NL, np.int32), link_cur=arr(p.link_cur, NL, np.int32),
+            link_preint=arr(p.link_preint, NL * capi.OSH_PREINT_FLOATS, np.float32).reshape(NL, -1),
+            link_info=arr(p.link_info, NL * 81).reshape(NL, 81), link_info_g=arr(p.link_info_g, NL * 9).reshape(NL, 9),
+            link_info_a=arr(p.link_info_a, NL * 9).reshape(NL, 9), link_robust=arr(p.link_robust, NL, np.uint8),
+            lambda_init=1e-2 if large else 1.0, max_iterations=4 if large else 10).normalise()
+        return w, kid[:Kp], mid[:L]
+
+    def run(self, large=False, rec_init=False):
+        return self.lib.osh_host_run_liba(self.g, self.cur, int(large), int(rec_init))
+
+    def kf_pose(self, i):
+        o = np.zeros(7, dtype=np.float32)
+        self.lib.osh_host_get_kf_pose(self.g, i, capi.ptr(o, capi.c_float_p))
+        return o
+
+    def kf_velocity(self, i):
+        o = np.zeros(3, dtype=np.float32)
+        self.lib.osh_host_get_kf_velocity(self.g, i, capi.ptr(o, capi.c_float_p))
+        return o
+
+    def kf_bias(self, i):
+        o = np.zeros(6, dtype=np.float32)
+        self.lib.osh_host_get_kf_bias(self.g, i, capi.ptr(o, capi.c_float_p))
+        return o
+
+    def mp_pos(self, j):
+        o = np.zeros(3, dtype=np.float32)
+        self.lib.osh_host_get_mp_pos(self.g, j, capi.ptr(o, capi.c_float_p))
+        return o
+
+
+def host_preintegrate(acc, gyr, dt, bias6, nga6, walk6):
+    lib = capi.load_library()
+    acc, gyr = _f32(acc), _f32(gyr)
+    rec, cov = np.zeros(capi.OSH_PREINT_FLOATS, dtype=np.float32), np.zeros(225, dtype=np.float32)
+    fp = capi.c_float_p
+    lib.osh_host_preintegrate(len(acc), capi.ptr(acc, fp), capi.ptr(gyr, fp), np.float32(dt), capi.ptr(_f32(bias6), fp),
+                              capi.ptr(_f32(nga6), fp), capi.ptr(_f32(walk6), fp), capi.ptr(rec, fp), capi.ptr(cov, fp))
+    return rec, cov.reshape(15, 15)
+
+
+def host_inertial_information(cov):
+    lib = capi.load_library()
+    out = np.zeros(81)
+    lib.osh_host_inertial_information(capi.ptr(_f32(cov).ravel(), capi.c_float_p), capi.ptr(out, capi.c_double_p))
+    return out.reshape(9, 9)

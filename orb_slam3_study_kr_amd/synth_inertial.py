@@ -292,7 +292,7 @@ def make_inertial_window(seed: int = 11, n_opt: int = 10, n_fixed: int = 20, n_p
     ep, el, eobs, einfo, eout = ep[order], el[order], eobs[order], einfo[order], eout[order]
     Xw = Xw[keep_l]
     # IMU stream + preintegration per link (predecessor -> opt_0, opt_0 -> opt_1, ...)
-    recs, infos, infog, infoa = [], [], [], []
+    recs, infos, infog, infoa, covs = [], [], [], [], []
     bias_lin = []
     for l in range(n_opt):
         t_a = times[n_fixed + l]
@@ -309,7 +309,7 @@ def make_inertial_window(seed: int = 11, n_opt: int = 10, n_fixed: int = 20, n_p
             gyr.append(w + bg_true); acc.append(f + ba_true)
         b_lin = np.concatenate([ba_true + rng.standard_normal(3) * 2e-3, bg_true + rng.standard_normal(3) * 2e-4])
         rec, Cm = preintegrate(acc, gyr, dt, b_lin, nga, walk)
-        recs.append(rec); bias_lin.append(b_lin)
+        recs.append(rec); bias_lin.append(b_lin); covs.append(Cm)
         infos.append(inertial_information(Cm, downweight=(l == 0)))   # i == N-1 in the reference's newest-first order
         infog.append(np.linalg.inv(Cm[9:12, 9:12].astype(np.float64)))
         infoa.append(np.linalg.inv(Cm[12:15, 12:15].astype(np.float64)))
@@ -343,5 +343,6 @@ def make_inertial_window(seed: int = 11, n_opt: int = 10, n_fixed: int = 20, n_p
         link_preint=np.stack(recs), link_info=np.stack(infos), link_info_g=np.stack(infog), link_info_a=np.stack(infoa),
         link_robust=np.array([1 if (l == 0 or rec_init) else 0 for l in range(n_opt)], dtype=np.uint8),
         lambda_init=1e-2 if large else 1.0, max_iterations=4 if large else 10,
-        gt=dict(Rwb=gt_Rwb, twb=gt_twb, vel=gt_vel, points=Xw, outliers=eout, bg=bg_true, ba=ba_true))
+        gt=dict(Rwb=gt_Rwb, twb=gt_twb, vel=gt_vel, points=Xw, outliers=eout, bg=bg_true, ba=ba_true, link_cov=np.stack(covs),
+                Tbc=T_BC, nga=nga, walk=walk))
     return w.normalise()

@@ -136,3 +136,39 @@ def test_search_by_projection_last_frame_equals_sequential_reference(ob):
     n_ref, assign_ref, _ = ob.orb_match_last_frame(mp_desc, desc, off, idx, last_angle, angle)
     assert n == n_ref and n > 100
     np.testing.assert_array_equal(assign, assign_ref)
+
+
+def test_local_inertial_ba_through_the_reference_signature(ob):
+    """Optimizer::LocalInertialBA(KeyFrame*, bool*, Map*, int&x4, bLarge, bRecInit) on a KeyFrame/MapPoint/IMU graph vs the
+    inertial oracle on the problem the host layer packed; write-back of poses, velocities, biases and points in float."""
+    from orb_slam3_study_kr_amd import synth_inertial as si
+    w = si.make_inertial_window(51, n_opt=6, n_fixed=5, n_points=500)
+    with host.HostInertialGraph(w) as g:
+        pw, kid, mid = g.packed_window()
+        ref = ob.liba_solve(pw)
+        assert g.run() == 0                       # num_* out-parameters stay untouched, as in the reference
+        assert g.lib.osh_host_map_change_index(g.g) == 1
+        kf_index = {int(i): k for k, i in enumerate(g.kf_id)}
+        for n, kf in enumerate(kid[:pw.n_opt]):
+            k = kf_index[int(kf)]
+            qt = g.kf_pose(k).astype(np.float64)
+            np.testing.assert_allclose(qt[4:], ref.pose_tcw[n], rtol=2e-6, atol=2e-6)
+            np.testing.assert_allclose(quat_R(qt[:4]), ref.pose_Rcw[n], atol=2e-6)
+            np.testing.assert_allclose(g.kf_velocity(k), ref.vel[n], rtol=1e-5, atol=2e-6)
+            b = g.kf_bias(k)
+            np.testing.assert_allclose(b[:3], ref.bias_a[n], rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(b[3:], ref.bias_g[n], rtol=1e-4, atol=1e-7)
+            assert g.lib.osh_host_kf_pose_sets(g.g, k) == 1
+        mp_index = {int(i): k for k, i in enumerate(g.mp_id)}
+        got_pts = np.stack([g.mp_pos(mp_index[int(i)]) for i in mid]).astype(np.float64)
+        np.testing.assert_allclose(got_pts, ref.points, rtol=2e-6, atol=2e-6)
+        # stereo outliers: chi2 > 7.815 (float threshold), no depth test (:2875-2887)
+        out = ref.edge_chi2 > np.float32(7.815)
+        near = np.abs(ref.edge_chi2 - 7.815) < 1e-3
+        for e in np.nonzero(~near)[0]:
+            k, j = kf_index[int(kid[pw.edge_pose[e]])], mp_index[int(mid[pw.edge_point[e]])]
+            assert g.lib.osh_host_kf_observes(g.g, k, j) == (0 if out[e] else 1)
+
+
+def quat_R(q):
+    return synth.quat_to_R(np.asarray(q) / np.linalg.norm(q))
