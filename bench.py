@@ -159,6 +159,43 @@ def run_orb(args, info):
                 kernel_ms=ms / max(launches, 1), pairs_per_gpu=len(pairs), pair0=pairs[0], res=res)
 
 
+def make_inertial_inputs(args):
+    from orb_slam3_study_kr_amd import synth_inertial as si
+    base = [si.make_inertial_window(11 + k) for k in range(8)]       # BASELINE.json configs[3] shape
+    return [base[k % len(base)] for k in range(args.inertial_windows)]
+
+
+def run_inertial(args, info, windows):
+    """BASELINE.json configs[3]: LocalInertialBA windows through osh_liba_solve (one persistent block per window).
+    The call includes the H2D upload and the D2H download (the reference calls it one window at a time)."""
+    from orb_slam3_study_kr_amd import lba
+    solver = lba.LbaSolver(info.local_rank)
+    solver.solve_inertial(windows[:1])
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        solver.solve_inertial(windows[:1])
+    single_ms = (time.perf_counter() - t0) / reps * 1e3
+    solver.solve_inertial(windows)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = solver.solve_inertial(windows)
+    batch_s = (time.perf_counter() - t0) / reps
+    solver.close()
+    out = dict(metric="LocalInertialBA windows/sec (10 temporal KF + 21 fixed, ~1.1k landmarks, ~16.7k stereo edges, IMU preintegration edges)",
+               windows_per_s=len(windows) / batch_s, windows_per_batch=len(windows), single_window_latency_ms=single_ms,
+               lm_iterations_mean=float(np.mean([r.iterations for r in res])), includes="H2D upload + D2H download", dtype="f64 (+f32 preintegration getters)")
+    if info.rank == 0 and info.world == 1 and not args.no_cpu_baseline:
+        from oracle import binding as ob
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 4.0:
+            ob.liba_solve(windows[n % len(windows)])
+            n += 1
+        out["cpu_baseline"] = dict(value=n / (time.perf_counter() - t0), unit="windows/s", cores=1, kind="port",
+                                   sample=f"{n} solves of the same windows by oracle/liba_oracle.c, one thread")
+    return out
+
+
 def cpu_baseline(windows, budget_s=12.0):
     """The oracle (kind "port": CPU restatement of the g2o path, oracle/lba_oracle.c) timed single
     threaded on this host, rebuilt here with -O3 -march=native like the reference's own flags."""
@@ -191,12 +228,14 @@ def main():
     ap.add_argument("--prepare-only", action="store_true", help="generate (and cache) the inputs, then exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-orb", action="store_true")
+    ap.add_argument("--inertial-windows", type=int, default=128, help="config-4 windows per osh_liba_solve call (0 = skip)")
     args = ap.parse_args()
 
     env_rank, env_world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     windows = make_lba_inputs(args, env_rank, env_world)
     if args.prepare_only:
         return
+    inertial_windows = make_inertial_inputs(args) if args.inertial_windows > 0 else None
     info = osh_dist.init_from_env()
     if info.world != args.gpus and info.rank == 0 and info.world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={info.world}", file=sys.stderr)
@@ -207,6 +246,7 @@ def main():
 
     lba_out = run_lba(args, info, windows)
     orb_out = None if args.no_orb else run_orb(args, info)
+    inertial_out = run_inertial(args, info, inertial_windows) if inertial_windows else None
 
     n_gpus = info.world
     ms_per_step = lba_out["elapsed"] / args.steps * 1e3
@@ -246,6 +286,8 @@ def main():
                       "matches_per_s": orb_out["matches_per_s"], "pair_evals_per_s": orb_out["pair_evals_per_s"],
                       "frame_pairs_per_s": orb_out["frame_pairs_per_s"], "accepted_per_pair": orb_out["accepted_per_pair"],
                       "kernel_ms_per_launch": orb_out["kernel_ms"], "pairs_per_gpu": orb_out["pairs_per_gpu"], "dtype": "u32 popcount"}
+    if inertial_out is not None:
+        out["inertial"] = inertial_out
     if info.rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(lba_out["windows"])
         out["speedup_vs_cpu_1thread"] = value / out["cpu_baseline"]["value"]

@@ -10,7 +10,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $ROOT/bench.py --windows $WIN --cache-inputs /tmp/lba_inputs.pkl --prepare-only || exit 1
-BENCH="python3 $ROOT/bench.py --windows $WIN --cache-inputs /tmp/lba_inputs.pkl --workers 1 --steps 1 --warmup 1 --no-orb --no-cpu-baseline"
+BENCH="python3 $ROOT/bench.py --windows $WIN --cache-inputs /tmp/lba_inputs.pkl --workers 1 --steps 1 --warmup 1 --no-orb --no-cpu-baseline --inertial-windows 0"
 timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 echo "trace rc=$?"
 i=0
