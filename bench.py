@@ -95,30 +95,51 @@ def measured_traffic(kernel, windows_per_gpu):
 
 
 def run_lba(args, info, windows):
-    from orb_slam3_study_kr_amd import lba
-    solver = lba.LbaSolver(info.local_rank)
-    t0 = time.perf_counter()
-    solver.upload(windows)
-    upload_s = time.perf_counter() - t0
+    """Timed region: every window resident in HBM; `--streams` solver contexts (own HIP stream each, driven by a host
+    thread each) run osh_lba_optimize concurrently so the latency-bound kernels of one half overlap the other half."""
+    from concurrent.futures import ThreadPoolExecutor
+
     import torch
+    from orb_slam3_study_kr_amd import lba
+    ns = max(1, min(args.streams, len(windows)))
+    parts = [windows[k::ns] for k in range(ns)]
+    solvers = [lba.LbaSolver(info.local_rank) for _ in range(ns)]
+    t0 = time.perf_counter()
+    for sv, part in zip(solvers, parts):
+        sv.upload(part)
+    upload_s = time.perf_counter() - t0
+    pool = ThreadPoolExecutor(ns)
+
+    def step():
+        list(pool.map(lambda sv: sv.optimize(), solvers))   # each call returns after its own stream is idle
+
     for _ in range(args.warmup):
-        solver.optimize()
+        step()
     torch.cuda.synchronize()
     osh_dist.barrier(info)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        solver.optimize()                 # synchronous: returns after the context's stream is idle
+        step()
     torch.cuda.synchronize()
     osh_dist.barrier(info)
     elapsed = osh_dist.all_reduce_max(info, time.perf_counter() - t0)
-    results = solver.download()
-    # per-kernel HIP-event timing of one more (untimed) step
+    results_parts = [sv.download() for sv in solvers]
+    results = [None] * len(windows)
+    for k, rp in enumerate(results_parts):
+        results[k::ns] = rp
+    for sv in solvers:
+        sv.close()
+    pool.shutdown()
+    # per-kernel HIP-event timing: one untimed, un-overlapped step of ALL windows on a single stream
+    solver = lba.LbaSolver(info.local_rank)
+    solver.upload(windows)
+    solver.optimize()
     solver.set_profiling(True)
     solver.optimize()
     prof = solver.profile()
     solver.set_profiling(False)
-    alg = kernel_algorithmic_bytes(windows, results)
     solver.close()
+    alg = kernel_algorithmic_bytes(windows, results)
     return dict(windows=windows, results=results, elapsed=elapsed, upload_s=upload_s, prof=prof, alg=alg)
 
 
@@ -220,8 +241,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--windows", type=int, default=128, help="config-2 windows resident per GPU (one step solves them all)")
+    ap.add_argument("--windows", type=int, default=512, help="config-2 windows resident per GPU (one step solves them all)")
     ap.add_argument("--orb-pairs", type=int, default=64, help="2000x2000 frame pairs per GPU per ORB step")
+    ap.add_argument("--streams", type=int, default=2, help="solver contexts (HIP streams) sharing the GPU in the timed region")
     ap.add_argument("--workers", type=int, default=0, help="input-generation processes (0 = auto; use 1 under rocprofv3: "
                     "the profiler's signal handler hangs on the pool's worker teardown)")
     ap.add_argument("--cache-inputs", default="", help="pickle file to store / reuse the generated windows")
@@ -273,7 +295,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[1]: synthetic stereo local BA, 50 optimisable + 10 fixed KF, "
                                "10k landmarks (~75k stereo edges), optimize(10) with the reference's stop rules",
-                   "windows_per_gpu": args.windows, "global_windows": args.windows * n_gpus,
+                   "windows_per_gpu": args.windows, "global_windows": args.windows * n_gpus, "streams_per_gpu": args.streams,
                    "parallelism": f"independent windows, w mod {n_gpus}", "lm_iterations_mean": float(np.mean([r.iterations for r in res])),
                    "lm_trials_mean": float(np.mean([r.trials for r in res]))},
         "roofline": roofline,

@@ -401,16 +401,24 @@ __global__ __launch_bounds__(kBlock) void k_bdinv(BatchView bv) {
 // the same for all lanes (the record, BD_e = B_e Dinv_j, B_e db) comes in through scalar loads,
 // each lane only fetches its own 3 doubles B_q[col][0..2] of its partner block.
 // --------------------------------------------------------------------------------------------
-constexpr int kSchurPF = 4;  // records kept in flight by the vector loads (power of two)
+constexpr int kSchurPF = 4;   // records kept in flight by the vector loads (power of two)
+constexpr int kSchurRows = 4; // pose rows of S owned by one wavefront (register tiling: a partner block is loaded once for 4 rows)
 
-struct SchurSlot { double ux, uy, y0, y1, y2; };
+struct SchurSlot { double ux, uy, y0, y1, y2; unsigned rowmask; };
 
+// k_schur (row-tiled): one wavefront per (set of kSchurRows consecutive pose rows i0.., group of 10 partner poses
+// base..base+9).  Lane (t = lane/6, col = lane%6) owns column `col` of the blocks S(i0+r, base+t), r = 0..3, in registers.
+// A record = one landmark seen by >= 1 row of the set and >= 1 partner of the group:
+//   {e_first: sorted edge of the first present row (the others follow consecutively), q0: first partner edge of the group,
+//    partner mask (10 bits) | row mask << 16}.
+// Per record ONE 16-byte load per lane brings the BD|B db units of every present row (lane = 12*r + unit) and one 24-byte
+// load the lane's own partner row; the row operands are broadcast through LDS (9 x ds_read_b128 per row).
 __global__ __launch_bounds__(64) void k_schur(BatchView bv) {
-  __shared__ double2 sh_u[kSchurPF * 12];  // per in-flight record: BD_e (9 units) | B_e db (3 units)
+  __shared__ double2 sh_u[kSchurPF * kSchurRows * 12];
   const int sb = bv.srow_perm[blockIdx.x];
   if (sb < 0) return;
   const int4 row = bv.srow[sb];
-  const int w = row.x, i = row.y, base = row.z;
+  const int w = row.x, i0 = row.y, base = row.z;
   const WinDesc& wd = bv.win[w];
   const LmState& st = bv.lm[w];
   if (!st.active) return;
@@ -420,39 +428,47 @@ __global__ __launch_bounds__(64) void k_schur(BatchView bv) {
   const int t = lane / 6, col = lane - t * 6;
   const int i2 = base + t;
   const bool owner = (t < 10) && (i2 < wd.P);
+  const int nrows = min(kSchurRows, wd.P - i0);
   const double lambda = st.lambda;
   const int4* __restrict__ recs = bv.srec + row.w;
   const char* __restrict__ Hpl = reinterpret_cast<const char*>(bv.Hpl + (size_t)wd.edge_off * 18);
   const char* __restrict__ bdc = reinterpret_cast<const char*>(bv.bdc + (size_t)wd.edge_off * 24);
-  const int gp = wd.fpose_off + i;
-  // v[r] = entry (r, col) of S(i, i2); starts from Hpp + lambda on the diagonal block (setLambda)
-  double v[6];
+  // v[r][k] = entry (k, col) of S(i0 + r, i2); the diagonal block starts from Hpp + lambda (setLambda)
+  double v[kSchurRows][6];
 #pragma unroll
-  for (int r = 0; r < 6; ++r) v[r] = 0.0;
-  if (owner && i2 == i) {
+  for (int r = 0; r < kSchurRows; ++r) {
 #pragma unroll
-    for (int r = 0; r < 6; ++r) v[r] = bv.Hpp[(size_t)gp * 36 + r * 6 + col] + ((r == col) ? lambda : 0.0);
+    for (int k = 0; k < 6; ++k) v[r][k] = 0.0;
+    if (owner && r < nrows && i2 == i0 + r) {
+      const size_t gp = (size_t)wd.fpose_off + i0 + r;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) v[r][k] = bv.Hpp[gp * 36 + k * 6 + col] + ((k == col) ? lambda : 0.0);
+    }
   }
-  // lanes 9-11 sum the B_e db units of the row in landmark order (the _coefficients term)
+  // lanes 12r+9 .. 12r+11 sum the B_e db units of row r in landmark order (the _coefficients term), first group only
   double cx = 0.0, cy = 0.0;
   const unsigned below = (1u << t) - 1u;
   const unsigned mybit = (t < 10) ? (1u << t) : 0u;
-  const unsigned lane16 = (unsigned)lane * 16u, col24 = (unsigned)col * 24u;
-  const bool first_group = (base == i);
-  const int unit_lanes = first_group ? 12 : 9;
+  const unsigned col24 = (unsigned)col * 24u;
+  const bool first_group = (base == i0);
+  const int urow = lane / 12, uunit = lane - urow * 12;          // which row / 16-byte unit this lane stages
+  const bool ustage = (urow < kSchurRows) && (uunit < (first_group ? 12 : 9));
+  const unsigned ubit = 1u << urow, ubelow = ubit - 1u;
 
-  // The 64 records of a block are fetched with one coalesced vector load (a record per lane) and handed
-  // out with v_readlane, so no scalar-load latency sits in front of the dependent address arithmetic.
   int4 rr = (lane < nrec) ? recs[lane] : make_int4(0, 0, 0, 0);
   int4 rr_next = (64 + lane < nrec) ? recs[64 + lane] : make_int4(0, 0, 0, 0);
   auto fetch = [&](int k, SchurSlot& sl) {
     sl.ux = sl.uy = sl.y0 = sl.y1 = sl.y2 = 0.0;
+    sl.rowmask = 0u;
     if (k < nrec) {
       const int src = k & 63;
-      const int e = __builtin_amdgcn_readlane(rr.x, src), q0 = __builtin_amdgcn_readlane(rr.y, src);
-      const unsigned mask = (unsigned)__builtin_amdgcn_readlane(rr.z, src) & 0xffffu;
-      if (lane < unit_lanes) {
-        const double2 u = *reinterpret_cast<const double2*>(bdc + ((unsigned)e * 192u + lane16));
+      const int e_first = __builtin_amdgcn_readlane(rr.x, src), q0 = __builtin_amdgcn_readlane(rr.y, src);
+      const unsigned m = (unsigned)__builtin_amdgcn_readlane(rr.z, src);
+      const unsigned mask = m & 0xffffu, rowmask = (m >> 16) & 0xfu;
+      sl.rowmask = rowmask;
+      if (ustage && (rowmask & ubit)) {
+        const unsigned e = (unsigned)(e_first + __builtin_popcount(rowmask & ubelow));
+        const double2 u = *reinterpret_cast<const double2*>(bdc + (e * 192u + (unsigned)uunit * 16u));
         sl.ux = u.x; sl.uy = u.y;
       }
       if (mask & mybit) {
@@ -465,25 +481,26 @@ __global__ __launch_bounds__(64) void k_schur(BatchView bv) {
   SchurSlot slot[kSchurPF];
 #pragma unroll
   for (int p = 0; p < kSchurPF; ++p) fetch(p, slot[p]);
-  // stage record 0 in LDS
-  if (lane < 12) sh_u[lane] = make_double2(slot[0].ux, slot[0].uy);
+  if (lane < kSchurRows * 12) sh_u[lane] = make_double2(slot[0].ux, slot[0].uy);
   for (int k0 = 0; k0 < nrec; k0 += kSchurPF) {
 #pragma unroll
     for (int p = 0; p < kSchurPF; ++p) {
       const int k = k0 + p;
       if (k < nrec) {
         const SchurSlot sl = slot[p];
-        // stage the NEXT record's units while this one is consumed (same wave: LDS ops stay in order)
         const SchurSlot& nx = slot[(p + 1) & (kSchurPF - 1)];
-        if (lane < 12) sh_u[((p + 1) & (kSchurPF - 1)) * 12 + lane] = make_double2(nx.ux, nx.uy);
-        // broadcast BD_e: nine 16-byte LDS reads with the same address in every lane
-        double bd[18];
+        if (lane < kSchurRows * 12) sh_u[((p + 1) & (kSchurPF - 1)) * (kSchurRows * 12) + lane] = make_double2(nx.ux, nx.uy);
 #pragma unroll
-        for (int m = 0; m < 9; ++m) { const double2 u = sh_u[p * 12 + m]; bd[2 * m] = u.x; bd[2 * m + 1] = u.y; }
+        for (int r = 0; r < kSchurRows; ++r) {
+          if (sl.rowmask & (1u << r)) {     // wave-uniform
+            double bd[18];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) v[r] -= bd[r * 3] * sl.y0 + bd[r * 3 + 1] * sl.y1 + bd[r * 3 + 2] * sl.y2;
-        cx += sl.ux; cy += sl.uy;  // meaningful in lanes 9-11 of the first group only
-        // refill this slot with record k + kSchurPF; switch record blocks every 64 records
+            for (int m = 0; m < 9; ++m) { const double2 u = sh_u[p * (kSchurRows * 12) + r * 12 + m]; bd[2 * m] = u.x; bd[2 * m + 1] = u.y; }
+#pragma unroll
+            for (int kk = 0; kk < 6; ++kk) v[r][kk] -= bd[kk * 3] * sl.y0 + bd[kk * 3 + 1] * sl.y1 + bd[kk * 3 + 2] * sl.y2;
+          }
+        }
+        cx += sl.ux; cy += sl.uy;  // meaningful in lanes 12r+9..12r+11 of the first group only
         const int kn = k + kSchurPF;
         if ((kn & 63) == 0) {
           rr = rr_next;
@@ -496,12 +513,18 @@ __global__ __launch_bounds__(64) void k_schur(BatchView bv) {
   if (owner) {
     double* S = bv.S + wd.S_off;
 #pragma unroll
-    for (int r = 0; r < 6; ++r) S[(size_t)(6 * i + r) * n + 6 * i2 + col] = v[r];
+    for (int r = 0; r < kSchurRows; ++r) {
+      if (r < nrows && i2 >= i0 + r) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) S[(size_t)(6 * (i0 + r) + k) * n + 6 * i2 + col] = v[r][k];
+      }
+    }
   }
-  if (first_group && lane >= 9 && lane < 12) {
-    const int r0 = (lane - 9) * 2;
-    bv.bs[(size_t)gp * 6 + r0] = bv.bp[(size_t)gp * 6 + r0] - cx;
-    bv.bs[(size_t)gp * 6 + r0 + 1] = bv.bp[(size_t)gp * 6 + r0 + 1] - cy;
+  if (first_group && urow < nrows && uunit >= 9 && uunit < 12) {
+    const size_t gp = (size_t)wd.fpose_off + i0 + urow;
+    const int r0 = (uunit - 9) * 2;
+    bv.bs[gp * 6 + r0] = bv.bp[gp * 6 + r0] - cx;
+    bv.bs[gp * 6 + r0 + 1] = bv.bp[gp * 6 + r0 + 1] - cy;
   }
 }
 
@@ -977,32 +1000,44 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
       const int ip = h_epose[(size_t)d.edge_off + x];
       if (ip < p.n_free) h_pel[(size_t)d.pel_off + fill[ip]++] = x;
     }
-    // Schur work lists: for pose row i and every group of 10 partner poses [i+10h, i+10h+10) the records
-    // {row edge e, first partner edge q0 in the group, mask of the partner poses present | first<<16}
-    for (int i = 0; i < p.n_free; ++i) {
-      const int ngrp = (p.n_free - i + 9) / 10;
-      if ((int)grp_recs.size() < ngrp) grp_recs.resize(ngrp);
-      for (int h = 0; h < ngrp; ++h) grp_recs[h].clear();
-      for (int k = po[i]; k < po[i + 1]; ++k) {
-        const int e = h_pel[(size_t)d.pel_off + k];
-        const int j = h_epoint[(size_t)d.edge_off + e];
-        const int end = lmo[j] + h_lmnfree[(size_t)d.pt_off + j];
-        int cur_h = -1, q0 = 0;
-        unsigned mask = 0;
-        for (int q = e; q <= end; ++q) {
-          const int hq = (q < end) ? (h_epose[(size_t)d.edge_off + q] - i) / 10 : -2;
-          if (hq != cur_h) {
-            if (cur_h >= 0) grp_recs[cur_h].push_back(make_int4(e, q0, (int)(mask | (cur_h == 0 ? 0x10000u : 0u)), 0));
-            cur_h = hq; q0 = q; mask = 0;
+    // Schur work lists (row-tiled): for every set of kSchurRows consecutive pose rows i0.. and every group of 10 partner
+    // poses [i0+10h, i0+10h+10): records {first row edge, first partner edge, partner mask | row mask << 16}, landmark order
+    {
+      const int nsets = (p.n_free + kSchurRows - 1) / kSchurRows;
+      std::vector<int> grp_base(nsets + 1, 0);
+      for (int sidx = 0; sidx < nsets; ++sidx) grp_base[sidx + 1] = grp_base[sidx] + (p.n_free - sidx * kSchurRows + 9) / 10;
+      if ((int)grp_recs.size() < grp_base[nsets]) grp_recs.resize(grp_base[nsets]);
+      for (int g = 0; g < grp_base[nsets]; ++g) grp_recs[g].clear();
+      for (int j = 0; j < p.n_points; ++j) {
+        const int s0 = lmo[j], s1 = lmo[j] + h_lmnfree[(size_t)d.pt_off + j];   // optimisable-pose edges, poses ascending
+        int x = s0;
+        while (x < s1) {
+          const int pose_x = h_epose[(size_t)d.edge_off + x];
+          const int sidx = pose_x / kSchurRows, i0 = sidx * kSchurRows;
+          unsigned rowmask = 0;
+          int x_end = x;
+          while (x_end < s1 && h_epose[(size_t)d.edge_off + x_end] < i0 + kSchurRows) { rowmask |= 1u << (h_epose[(size_t)d.edge_off + x_end] - i0); ++x_end; }
+          // partners: every edge from the first present row onwards, cut into groups of 10 poses relative to i0
+          int cur_h = -1, q0 = 0;
+          unsigned mask = 0;
+          for (int q = x; q <= s1; ++q) {
+            const int hq = (q < s1) ? (h_epose[(size_t)d.edge_off + q] - i0) / 10 : -2;
+            if (hq != cur_h) {
+              if (cur_h >= 0) grp_recs[grp_base[sidx] + cur_h].push_back(make_int4(x, q0, (int)(mask | (rowmask << 16)), 0));
+              cur_h = hq; q0 = q; mask = 0;
+            }
+            if (q < s1) mask |= 1u << ((h_epose[(size_t)d.edge_off + q] - i0) % 10);
           }
-          if (q < end) mask |= 1u << ((h_epose[(size_t)d.edge_off + q] - i) % 10);
+          x = x_end;
         }
       }
-      for (int h = 0; h < ngrp; ++h) {
-        h_srow.push_back(make_int4(w, i, i + 10 * h, (int)h_rec.size()));
-        h_srow_nrec.push_back((int)grp_recs[h].size());
-        h_rec.insert(h_rec.end(), grp_recs[h].begin(), grp_recs[h].end());
-      }
+      for (int sidx = 0; sidx < nsets; ++sidx)
+        for (int h = 0; h < grp_base[sidx + 1] - grp_base[sidx]; ++h) {
+          const auto& lst = grp_recs[grp_base[sidx] + h];
+          h_srow.push_back(make_int4(w, sidx * kSchurRows, sidx * kSchurRows + 10 * h, (int)h_rec.size()));
+          h_srow_nrec.push_back((int)lst.size());
+          h_rec.insert(h_rec.end(), lst.begin(), lst.end());
+        }
     }
     // chunks: consecutive landmarks, <= kChunkEdges edges and <= kBlock landmarks (a single
     // landmark with more edges gets its own multi-pass chunk)

@@ -4,13 +4,13 @@
 # generated once without the profiler (the generator forks workers) and re-read from a cache afterwards.
 set -u
 TAG=${1:-r01}
-WIN=${2:-128}
+WIN=${2:-512}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $ROOT/bench.py --windows $WIN --cache-inputs /tmp/lba_inputs.pkl --prepare-only || exit 1
-BENCH="python3 $ROOT/bench.py --windows $WIN --cache-inputs /tmp/lba_inputs.pkl --workers 1 --steps 1 --warmup 1 --no-orb --no-cpu-baseline --inertial-windows 0"
+BENCH="python3 $ROOT/bench.py --windows $WIN --cache-inputs /tmp/lba_inputs.pkl --workers 1 --streams 1 --steps 1 --warmup 1 --no-orb --no-cpu-baseline --inertial-windows 0"
 timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 echo "trace rc=$?"
 i=0
