@@ -151,17 +151,25 @@ int osh_lba_debug_trial(osh_lba_ctx* ctx, int32_t window, double lambda, double*
 /* Kernel timing (HIP events on the context's stream).  Kernel ids: */
 #define OSH_K_LINEARIZE   0   /* residual + Jacobians + Hll/bl/Hpl                */
 #define OSH_K_POSE_HESS   1   /* Hpp / bp per optimisable pose                    */
-#define OSH_K_SCHUR       2   /* Schur complement rows + reduced rhs              */
+#define OSH_K_SCHUR       2   /* Schur products of the landmark groups (FP64 MFMA), symmetric items */
 #define OSH_K_SOLVE       3   /* dense LDL^T of the reduced camera system         */
 #define OSH_K_BACKSUB     4   /* landmark back-substitution + state update        */
 #define OSH_K_RESIDUAL    5   /* residual / robust chi2 of the trial state        */
 #define OSH_K_CONTROL     6   /* LM controller                                    */
-#define OSH_K_DINV        7   /* per-trial landmark block inverses                */
-#define OSH_K_COUNT       8
+#define OSH_K_SCHUR_REDUCE 7  /* S = Hpp + lambda I - sum of the group products, reduced rhs */
+#define OSH_K_SCHUR_CROSS 8   /* Schur products, items of landmarks with > 8 optimisable observers */
+#define OSH_K_COUNT       9
 int osh_lba_set_profiling(osh_lba_ctx* ctx, int enable);
 /* launches[k], total_ms[k] accumulated since profiling was (re)enabled */
 int osh_lba_get_profile(osh_lba_ctx* ctx, int64_t launches[OSH_K_COUNT], double total_ms[OSH_K_COUNT]);
 const char* osh_lba_kernel_name(int kernel_id);
+
+/* Host-only self check of the Schur work plan built at upload time (needs no GPU): groups the
+ * landmarks of `problem` by observer set exactly as osh_lba_upload does, verifies that the plan
+ * covers every observer pair of every landmark exactly once and returns
+ * stats = {items, symmetric items, records, contributions, rhs contributions, MFMA instructions
+ * per pass, useful 6x6 products per pass, reduce entries}. */
+int osh_lba_schur_plan_stats(const osh_lba_problem* problem, int64_t stats[8]);
 
 /* ----------------------------------------------- local inertial BA (config 4) */
 /*

@@ -24,8 +24,8 @@ OSH_ERR_NO_DEVICE = -4
 OSH_EDGE_MONO = 0
 OSH_EDGE_STEREO = 1
 OSH_LBA_MAX_TRACE = 128
-OSH_K_COUNT = 8
-KERNEL_NAMES = ["linearize", "pose_hess", "schur", "solve", "backsub", "residual", "control", "dinv"]
+OSH_K_COUNT = 9
+KERNEL_NAMES = ["linearize", "pose_hess", "schur", "solve", "backsub", "residual", "control", "schur_reduce", "schur_cross"]
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
@@ -132,6 +132,7 @@ _SIGNATURES = {
     "osh_lba_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "osh_lba_get_profile": (C.c_int, [C.c_void_p, c_int64_p, c_double_p]),
     "osh_lba_kernel_name": (C.c_char_p, [C.c_int]),
+    "osh_lba_schur_plan_stats": (C.c_int, [C.POINTER(LbaProblem), c_int64_p]),
     "osh_orb_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "osh_orb_destroy": (None, [C.c_void_p]),
     "osh_orb_upload": (C.c_int, [C.c_void_p, C.POINTER(OrbBatch)]),

@@ -10,8 +10,9 @@
 //                 g2o/core/sparse_optimizer.cpp:61-114, block_solver.hpp:502-560,
 //                 base_binary_edge.hpp:55-120  (Hll, b_l, Hpl;  also residual-only mode)
 //   k_pose_hess   the pose side of buildSystem (Hpp, b_p), one wavefront per optimisable pose
-//   k_schur       BlockSolver::solve Schur part, block_solver.hpp:367-439, one wavefront per
-//                 pose ROW of S (LDS-resident 6 x 6P row block, no atomics)
+//   k_schur_items BlockSolver::solve Schur part, block_solver.hpp:367-439: landmarks grouped by observer
+//                 set (schur_plan.h), one wavefront per group, BD * W^T on the FP64 matrix cores
+//   k_schur_reduce  S = Hpp + lambda I - sum of the group products, b_s = b_p - ..., fixed order
 //   k_solve       LinearSolverEigen::solve -> dense blocked LDL^T, g2o/solvers/linear_solver_eigen.h:94-124,
 //                 + pose update (VertexSE3Expmap::oplusImpl)
 //   k_backsub     landmark back-substitution block_solver.hpp:461-483 + VertexSBAPointXYZ::oplusImpl
@@ -22,6 +23,7 @@
 #include "common.h"
 #include "lba_math.h"
 #include "ldlt_block.h"
+#include "schur_plan.h"
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -35,7 +37,6 @@ constexpr int kChunkEdges = 256;   // edges handled per pass of a chunk (== kBlo
 constexpr double kTau = 1e-5;      // OptimizationAlgorithmLevenberg::_tau
 constexpr int kMaxTrials = 10;     // maxTrialsAfterFailure
 constexpr int kSolveThreads = 512;  // one block per window in k_solve: 2 waves per SIMD (1024 would spill: 128-VGPR cap)
-constexpr size_t kBdinvLds = (9 * 256 + 2 * 12 * 256) * sizeof(double);  // k_bdinv dynamic LDS (66 KiB)
 
 struct WinDesc {
   int P, F, L, E;
@@ -76,7 +77,7 @@ struct Chunk { int win, lm0, lm1; };
 
 // Everything the kernels need, passed by value.
 struct BatchView {
-  int n_windows, n_chunks, n_fposes, n_srows;
+  int n_windows, n_chunks, n_fposes;
   const WinDesc* win;
   LmState* lm;
   const Chunk* chunks;
@@ -96,12 +97,16 @@ struct BatchView {
   const int* lm_nfree;       // [NL] free-pose edges of each landmark
   const int* pel_off;        // per window P+1
   const int* pel_edge;       // [NEfree] window-local sorted edge index, landmark order
-  const int4* srow;          // [n_srows] {window, pose row i, first partner pose base, record offset}
-  const int* srow_nrec;      // [n_srows] records of that (row, partner group)
-  const int* srow_perm;      // [n_sblocks] blockIdx -> srow index (or -1): all rows of a window share blockIdx%8 (one XCD / one L2)
-  const int4* srec;          // {row edge e, first partner edge q0, partner mask | first<<16, 0}
+  // Schur plan (schur_plan.h)
+  const SItem* sitems;       // [n_items] symmetric items first
+  const SRec* srecs;         // landmark records of the items
+  const int* spair;          // [n_items*64] contribution index of pose pair (sa,sb) or -1
+  const int* scslot;         // [n_items*8] rhs contribution index of row pose sa or -1
+  const RBlk* rblk;          // [n_rblk] blocks of S + rhs segments with their contribution ranges
+  int n_rblk;
+  double* contrib;           // [n_contrib*36] per trial: 6x6 products of one item and pose pair
+  double* ccontrib;          // [n_ccontrib*6] per trial: rhs products of one item and pose
   double* dinv;              // [NL*9] per trial: sym (Hll+lambda I)^-1 (00 01 02 11 12 22) + Dinv*b_l (3)
-  double* bdc;               // [NE*24] per trial, per sorted edge: B_e Dinv_j (6x3 row-major) | B_e (Dinv_j b_l) (6)
   // system
   double* Hpl;               // [NE*18] 6x3 row-major per sorted edge
   double* Hll;               // [NL*6] upper: 00 01 02 11 12 22
@@ -328,204 +333,190 @@ __global__ __launch_bounds__(64) void k_pose_hess(BatchView bv) {
 }
 
 // --------------------------------------------------------------------------------------------
-// k_bdinv: per trial.  Landmark side: Dinv = (Hll + lambda I)^-1 (setLambda on Hll, then
-// Matrix3d::inverse, block_solver.hpp:389,582-587) and db = Dinv b_l.  Edge side: for every
-// optimisable-pose edge BD_e = B_e Dinv_j ("BDinv", block_solver.hpp:403) and B_e db
-// (the _coefficients term, :404-409).  Same chunking as k_linearize.
+// k_schur_items: the landmark products of the Schur complement (block_solver.hpp:381-432) on the
+// FP64 matrix cores, one wavefront per ITEM of schur_plan.h (landmarks that share their set of
+// optimisable observers).  Per chunk of 8 landmarks lane (l, s) loads the Hpl block W of landmark
+// l / row pose s, forms Dinv = (Hll + lambda I)^-1 (setLambda + Matrix3d::inverse, :389,582-587),
+// BD = W Dinv (:403) and W (Dinv b_l) (the _coefficients term, :404-409) and stores BD and W as
+// [row][k] images in LDS (row = 6 s + r, k = 3 l + m; row stride 25 doubles: conflict-free for the
+// MFMA reads).  D = BD * W^T is then 6 k-steps of v_mfma_f64_16x16x4_f64 per 16x16 tile; the
+// accumulators stay in registers across the chunks of the item.  At the end every live pose pair
+// (sa, sb) is written as one 6x6 contribution; k_schur_reduce sums them in plan order.
+//   SYM: X == Y, only the tiles on and above the diagonal; also owns the rhs term and dinv.
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_bdinv(BatchView bv) {
-  extern __shared__ __attribute__((aligned(16))) double sh_bd[];
-  double* sh_d = sh_bd;                                               // [9][256] Dinv sym + db per landmark
-  double2* sh_B = reinterpret_cast<double2*>(sh_bd + 9 * kBlock);     // [256][12] Hpl block -> BD block (9 units) | B_e db (3 units)
-  const Chunk ch = bv.chunks[blockIdx.x];
-  const WinDesc& wd = bv.win[ch.win];
-  const LmState& st = bv.lm[ch.win];
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr int kSiLm = 8;               // landmarks per chunk
+constexpr int kSiKS = 3 * kSiLm + 1;   // LDS row stride (doubles)
+constexpr int kSiRows = 6 * kItemPoses;
+
+template <bool SYM>
+__global__ __launch_bounds__(64) void k_schur_items(BatchView bv, int item_base) {
+  __shared__ double shA[kSiRows * kSiKS];
+  __shared__ double shB[kSiRows * kSiKS];
+  __shared__ int shP[64 + 8];
+  const int item_idx = item_base + blockIdx.x;
+  const SItem it = bv.sitems[item_idx];
+  const WinDesc& wd = bv.win[it.win];
+  const LmState& st = bv.lm[it.win];
   if (!st.active) return;
-  const int tid = threadIdx.x;
-  const int nl = ch.lm1 - ch.lm0;
+  const int lane = threadIdx.x;
+  const int l = lane >> 3, s = lane & 7;
+  const int nx = it.shape & 0xff, ny = (it.shape >> 8) & 0xff;
+  const int TX = (6 * nx + 15) >> 4, TY = (6 * ny + 15) >> 4;
   const double lambda = st.lambda;
-  if (tid < nl) {
-    const size_t gl = (size_t)wd.pt_off + ch.lm0 + tid;
-    const double* hl = bv.Hll + gl * 6;
-    double Dinv[9];
-    dev::inv3_sym(hl[0] + lambda, hl[1], hl[2], hl[3] + lambda, hl[4], hl[5] + lambda, Dinv);
-    const double b0 = bv.bl[gl * 3], b1 = bv.bl[gl * 3 + 1], b2 = bv.bl[gl * 3 + 2];
-    double o[9];
-    o[0] = Dinv[0]; o[1] = Dinv[1]; o[2] = Dinv[2]; o[3] = Dinv[4]; o[4] = Dinv[5]; o[5] = Dinv[8];
-    o[6] = Dinv[0] * b0 + Dinv[1] * b1 + Dinv[2] * b2;
-    o[7] = Dinv[3] * b0 + Dinv[4] * b1 + Dinv[5] * b2;
-    o[8] = Dinv[6] * b0 + Dinv[7] * b1 + Dinv[8] * b2;
+  shP[lane] = bv.spair[(size_t)item_idx * 64 + lane];
+  if (lane < 8) shP[64 + lane] = bv.scslot[(size_t)item_idx * 8 + lane];
+  const SRec* __restrict__ recs = bv.srecs + it.rec_off;
+  const double* __restrict__ Hpl = bv.Hpl + (size_t)wd.edge_off * 18;
+  f64x4 acc[3][3];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) { bv.dinv[gl * 9 + k] = o[k]; sh_d[k * kBlock + tid] = o[k]; }
-  }
-  const int* lmo = bv.lm_off + wd.lmoff_off;
-  const int e0 = lmo[ch.lm0], e1 = lmo[ch.lm1];
-  for (int base = e0; base < e1; base += kChunkEdges) {
-    const int ne = min(kChunkEdges, e1 - base);
-    const size_t gb = (size_t)wd.edge_off + base;
-    // coalesced: the chunk's Hpl blocks are one contiguous run of 16-byte units
-    const double2* src = reinterpret_cast<const double2*>(bv.Hpl + gb * 18);
-    __syncthreads();
-    for (int u = tid; u < ne * 9; u += kBlock) { const int ed = u / 9; sh_B[ed * 12 + (u - ed * 9)] = src[u]; }
-    __syncthreads();
-    if (tid < ne) {
-      const size_t ge = gb + tid;
-      const bool free_pose = bv.e_pose[ge] < wd.P;
-      const int ls = bv.e_point[ge] - ch.lm0;
-      double D[9];
+  for (int a = 0; a < 3; ++a)
 #pragma unroll
-      for (int k = 0; k < 9; ++k) D[k] = sh_d[k * kBlock + ls];
-      double* B = reinterpret_cast<double*>(sh_B + tid * 12);
-      double* C = B + 18;
+    for (int b = 0; b < 3; ++b) acc[a][b] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  double csum[6] = {0, 0, 0, 0, 0, 0};
+  const int mrow = lane & 15, mk = lane >> 4;
+
+  for (int c0 = 0; c0 < it.n_lm; c0 += kSiLm) {
+    const int ri = c0 + l;
+    const bool valid = ri < it.n_lm;
+    SRec rec;
+    rec.lm = 0; rec.e_first = 0; rec.x_lo = rec.x_hi = rec.y_lo = rec.y_hi = 0xffffffffu; rec.flags = 0; rec.pad = 0;
+    if (valid) rec = recs[ri];
+    const unsigned xo = (((s < 4) ? rec.x_lo : rec.x_hi) >> (8 * (s & 3))) & 0xffu;
+    double W[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) W[k] = 0.0;
+    if (xo != kAbsent) {
+      const double2* src = reinterpret_cast<const double2*>(Hpl + (size_t)(rec.e_first + (int)xo) * 18);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) { const double2 u = src[k]; W[2 * k] = u.x; W[2 * k + 1] = u.y; }
+    }
+    double D[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) D[k] = 0.0;
+    if (valid) {
+      const size_t gl = (size_t)wd.pt_off + rec.lm;
+      const double* hl = bv.Hll + gl * 6;
+      double Dinv[9];
+      dev::inv3_sym(hl[0] + lambda, hl[1], hl[2], hl[3] + lambda, hl[4], hl[5] + lambda, Dinv);
+      const double b0 = bv.bl[gl * 3], b1 = bv.bl[gl * 3 + 1], b2 = bv.bl[gl * 3 + 2];
+      D[0] = Dinv[0]; D[1] = Dinv[1]; D[2] = Dinv[2]; D[3] = Dinv[4]; D[4] = Dinv[5]; D[5] = Dinv[8];
+      D[6] = Dinv[0] * b0 + Dinv[1] * b1 + Dinv[2] * b2;
+      D[7] = Dinv[3] * b0 + Dinv[4] * b1 + Dinv[5] * b2;
+      D[8] = Dinv[6] * b0 + Dinv[7] * b1 + Dinv[8] * b2;
+      if (SYM && s == 0 && (rec.flags & 1)) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) bv.dinv[gl * 9 + k] = D[k];
+      }
+    }
+    __syncthreads();   // the previous chunk's MFMA reads are done
+    {
+      double* a_row = shA + (6 * s) * kSiKS + 3 * l;
+      double* b_row = shB + (6 * s) * kSiKS + 3 * l;
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
-        const double x0 = free_pose ? B[r * 3] : 0.0, x1 = free_pose ? B[r * 3 + 1] : 0.0, x2 = free_pose ? B[r * 3 + 2] : 0.0;
-        B[r * 3 + 0] = x0 * D[0] + x1 * D[1] + x2 * D[2];
-        B[r * 3 + 1] = x0 * D[1] + x1 * D[3] + x2 * D[4];
-        B[r * 3 + 2] = x0 * D[2] + x1 * D[4] + x2 * D[5];
-        C[r] = x0 * D[6] + x1 * D[7] + x2 * D[8];
+        const double x0 = W[r * 3], x1 = W[r * 3 + 1], x2 = W[r * 3 + 2];
+        a_row[r * kSiKS + 0] = x0 * D[0] + x1 * D[1] + x2 * D[2];
+        a_row[r * kSiKS + 1] = x0 * D[1] + x1 * D[3] + x2 * D[4];
+        a_row[r * kSiKS + 2] = x0 * D[2] + x1 * D[4] + x2 * D[5];
+        if (SYM) {
+          csum[r] += x0 * D[6] + x1 * D[7] + x2 * D[8];
+          b_row[r * kSiKS + 0] = x0; b_row[r * kSiKS + 1] = x1; b_row[r * kSiKS + 2] = x2;
+        }
+      }
+      if (!SYM) {
+        const unsigned yo = (((s < 4) ? rec.y_lo : rec.y_hi) >> (8 * (s & 3))) & 0xffu;
+        double Y[18];
+#pragma unroll
+        for (int k = 0; k < 18; ++k) Y[k] = 0.0;
+        if (yo != kAbsent) {
+          const double2* src = reinterpret_cast<const double2*>(Hpl + (size_t)(rec.e_first + (int)yo) * 18);
+#pragma unroll
+          for (int k = 0; k < 9; ++k) { const double2 u = src[k]; Y[2 * k] = u.x; Y[2 * k + 1] = u.y; }
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { b_row[r * kSiKS + 0] = Y[r * 3]; b_row[r * kSiKS + 1] = Y[r * 3 + 1]; b_row[r * kSiKS + 2] = Y[r * 3 + 2]; }
       }
     }
     __syncthreads();
-    double2* dB = reinterpret_cast<double2*>(bv.bdc + gb * 24);
-    for (int u = tid; u < ne * 12; u += kBlock) dB[u] = sh_B[u];
+#pragma unroll
+    for (int ks = 0; ks < (3 * kSiLm) / 4; ++ks) {
+      double a[3], b[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        a[t] = (t < TX) ? shA[(16 * t + mrow) * kSiKS + 4 * ks + mk] : 0.0;
+        b[t] = (t < TY) ? shB[(16 * t + mrow) * kSiKS + 4 * ks + mk] : 0.0;
+      }
+#pragma unroll
+      for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+        for (int tj = SYM ? ti : 0; tj < 3; ++tj)
+          if (ti < TX && tj < TY) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  // contributions: lane holds D[row = (lane >> 4) + 4 reg][col = lane & 15] of each tile
+#pragma unroll
+  for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+    for (int tj = SYM ? ti : 0; tj < 3; ++tj) {
+      if (ti < TX && tj < TY) {
+        const int C = 16 * tj + (lane & 15);
+        const int sb = C / 6, cc = C - 6 * sb;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int R = 16 * ti + (lane >> 4) + 4 * reg;
+          const int sa = R / 6, rr = R - 6 * sa;
+          const int slot = shP[sa * 8 + sb];
+          if (slot >= 0) bv.contrib[(size_t)slot * 36 + rr * 6 + cc] = acc[ti][tj][reg];
+        }
+      }
+    }
+  if (SYM) {
+    // rhs term of row pose s: sum over the 8 landmark lanes in fixed order
+#pragma unroll
+    for (int r = 0; r < 6; ++r) shA[l * kSiRows + 6 * s + r] = csum[r];
+    __syncthreads();
+    if (lane < kSiRows) {
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < kSiLm; ++k) v += shA[k * kSiRows + lane];
+      const int sa = lane / 6;
+      const int slot = shP[64 + sa];
+      if (slot >= 0) bv.ccontrib[(size_t)slot * 6 + (lane - 6 * sa)] = v;
+    }
   }
 }
 
 // --------------------------------------------------------------------------------------------
-// k_schur: one wavefront per (pose row i, group of 10 partner poses base..base+9) of S
-// (block_solver.hpp:381-432).  Lane (t = lane/6, col = lane%6) OWNS column `col` of the 6x6
-// block S(i, base+t) and keeps its 6 entries in registers, so the row is accumulated in
-// landmark order with no atomics and no LDS.  The work list is a stream of records
-// {row edge e, first partner edge q0, mask of the partner poses present}; everything that is
-// the same for all lanes (the record, BD_e = B_e Dinv_j, B_e db) comes in through scalar loads,
-// each lane only fetches its own 3 doubles B_q[col][0..2] of its partner block.
+// k_schur_reduce: S(i,j) = [i == j] (Hpp_i + lambda I) - sum of the block's contributions,
+// b_s(i) = b_p(i) - sum of the pose's rhs contributions; 7 blocks of S per 256-thread group,
+// one thread per entry, contributions in plan order.
 // --------------------------------------------------------------------------------------------
-constexpr int kSchurPF = 4;   // records kept in flight by the vector loads (power of two)
-constexpr int kSchurRows = 4; // pose rows of S owned by one wavefront (register tiling: a partner block is loaded once for 4 rows)
-
-struct SchurSlot { double ux, uy, y0, y1, y2; unsigned rowmask; };
-
-// k_schur (row-tiled): one wavefront per (set of kSchurRows consecutive pose rows i0.., group of 10 partner poses
-// base..base+9).  Lane (t = lane/6, col = lane%6) owns column `col` of the blocks S(i0+r, base+t), r = 0..3, in registers.
-// A record = one landmark seen by >= 1 row of the set and >= 1 partner of the group:
-//   {e_first: sorted edge of the first present row (the others follow consecutively), q0: first partner edge of the group,
-//    partner mask (10 bits) | row mask << 16}.
-// Per record ONE 16-byte load per lane brings the BD|B db units of every present row (lane = 12*r + unit) and one 24-byte
-// load the lane's own partner row; the row operands are broadcast through LDS (9 x ds_read_b128 per row).
-__global__ __launch_bounds__(64) void k_schur(BatchView bv) {
-  __shared__ double2 sh_u[kSchurPF * kSchurRows * 12];
-  const int sb = bv.srow_perm[blockIdx.x];
-  if (sb < 0) return;
-  const int4 row = bv.srow[sb];
-  const int w = row.x, i0 = row.y, base = row.z;
-  const WinDesc& wd = bv.win[w];
-  const LmState& st = bv.lm[w];
+__global__ __launch_bounds__(256) void k_schur_reduce(BatchView bv) {
+  const int t = threadIdx.x / 36, el = threadIdx.x - 36 * t;
+  const int idx = blockIdx.x * 7 + t;
+  if (t >= 7 || idx >= bv.n_rblk) return;
+  const RBlk rb = bv.rblk[idx];
+  const WinDesc& wd = bv.win[rb.win];
+  const LmState& st = bv.lm[rb.win];
   if (!st.active) return;
-  const int nrec = bv.srow_nrec[sb];
-  const int n = wd.n;
-  const int lane = threadIdx.x;
-  const int t = lane / 6, col = lane - t * 6;
-  const int i2 = base + t;
-  const bool owner = (t < 10) && (i2 < wd.P);
-  const int nrows = min(kSchurRows, wd.P - i0);
-  const double lambda = st.lambda;
-  const int4* __restrict__ recs = bv.srec + row.w;
-  const char* __restrict__ Hpl = reinterpret_cast<const char*>(bv.Hpl + (size_t)wd.edge_off * 18);
-  const char* __restrict__ bdc = reinterpret_cast<const char*>(bv.bdc + (size_t)wd.edge_off * 24);
-  // v[r][k] = entry (k, col) of S(i0 + r, i2); the diagonal block starts from Hpp + lambda (setLambda)
-  double v[kSchurRows][6];
-#pragma unroll
-  for (int r = 0; r < kSchurRows; ++r) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) v[r][k] = 0.0;
-    if (owner && r < nrows && i2 == i0 + r) {
-      const size_t gp = (size_t)wd.fpose_off + i0 + r;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) v[r][k] = bv.Hpp[gp * 36 + k * 6 + col] + ((k == col) ? lambda : 0.0);
-    }
+  const int i = rb.ij & 0xffff, j = (rb.ij >> 16) & 0xffff;
+  if (j == 0xffff) {
+    if (el >= 6) return;
+    const size_t gp = (size_t)wd.fpose_off + i;
+    double v = bv.bp[gp * 6 + el];
+    const double* c = bv.ccontrib + (size_t)rb.start * 6 + el;
+    for (int k = 0; k < rb.count; ++k) v -= c[(size_t)k * 6];
+    bv.bs[gp * 6 + el] = v;
+    return;
   }
-  // lanes 12r+9 .. 12r+11 sum the B_e db units of row r in landmark order (the _coefficients term), first group only
-  double cx = 0.0, cy = 0.0;
-  const unsigned below = (1u << t) - 1u;
-  const unsigned mybit = (t < 10) ? (1u << t) : 0u;
-  const unsigned col24 = (unsigned)col * 24u;
-  const bool first_group = (base == i0);
-  const int urow = lane / 12, uunit = lane - urow * 12;          // which row / 16-byte unit this lane stages
-  const bool ustage = (urow < kSchurRows) && (uunit < (first_group ? 12 : 9));
-  const unsigned ubit = 1u << urow, ubelow = ubit - 1u;
-
-  int4 rr = (lane < nrec) ? recs[lane] : make_int4(0, 0, 0, 0);
-  int4 rr_next = (64 + lane < nrec) ? recs[64 + lane] : make_int4(0, 0, 0, 0);
-  auto fetch = [&](int k, SchurSlot& sl) {
-    sl.ux = sl.uy = sl.y0 = sl.y1 = sl.y2 = 0.0;
-    sl.rowmask = 0u;
-    if (k < nrec) {
-      const int src = k & 63;
-      const int e_first = __builtin_amdgcn_readlane(rr.x, src), q0 = __builtin_amdgcn_readlane(rr.y, src);
-      const unsigned m = (unsigned)__builtin_amdgcn_readlane(rr.z, src);
-      const unsigned mask = m & 0xffffu, rowmask = (m >> 16) & 0xfu;
-      sl.rowmask = rowmask;
-      if (ustage && (rowmask & ubit)) {
-        const unsigned e = (unsigned)(e_first + __builtin_popcount(rowmask & ubelow));
-        const double2 u = *reinterpret_cast<const double2*>(bdc + (e * 192u + (unsigned)uunit * 16u));
-        sl.ux = u.x; sl.uy = u.y;
-      }
-      if (mask & mybit) {
-        const unsigned off = (unsigned)(q0 + __builtin_popcount(mask & below)) * 144u + col24;
-        const double* q = reinterpret_cast<const double*>(Hpl + off);
-        sl.y0 = q[0]; sl.y1 = q[1]; sl.y2 = q[2];
-      }
-    }
-  };
-  SchurSlot slot[kSchurPF];
-#pragma unroll
-  for (int p = 0; p < kSchurPF; ++p) fetch(p, slot[p]);
-  if (lane < kSchurRows * 12) sh_u[lane] = make_double2(slot[0].ux, slot[0].uy);
-  for (int k0 = 0; k0 < nrec; k0 += kSchurPF) {
-#pragma unroll
-    for (int p = 0; p < kSchurPF; ++p) {
-      const int k = k0 + p;
-      if (k < nrec) {
-        const SchurSlot sl = slot[p];
-        const SchurSlot& nx = slot[(p + 1) & (kSchurPF - 1)];
-        if (lane < kSchurRows * 12) sh_u[((p + 1) & (kSchurPF - 1)) * (kSchurRows * 12) + lane] = make_double2(nx.ux, nx.uy);
-#pragma unroll
-        for (int r = 0; r < kSchurRows; ++r) {
-          if (sl.rowmask & (1u << r)) {     // wave-uniform
-            double bd[18];
-#pragma unroll
-            for (int m = 0; m < 9; ++m) { const double2 u = sh_u[p * (kSchurRows * 12) + r * 12 + m]; bd[2 * m] = u.x; bd[2 * m + 1] = u.y; }
-#pragma unroll
-            for (int kk = 0; kk < 6; ++kk) v[r][kk] -= bd[kk * 3] * sl.y0 + bd[kk * 3 + 1] * sl.y1 + bd[kk * 3 + 2] * sl.y2;
-          }
-        }
-        cx += sl.ux; cy += sl.uy;  // meaningful in lanes 12r+9..12r+11 of the first group only
-        const int kn = k + kSchurPF;
-        if ((kn & 63) == 0) {
-          rr = rr_next;
-          rr_next = (kn + 64 + lane < nrec) ? recs[kn + 64 + lane] : make_int4(0, 0, 0, 0);
-        }
-        fetch(kn, slot[p]);
-      }
-    }
-  }
-  if (owner) {
-    double* S = bv.S + wd.S_off;
-#pragma unroll
-    for (int r = 0; r < kSchurRows; ++r) {
-      if (r < nrows && i2 >= i0 + r) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) S[(size_t)(6 * (i0 + r) + k) * n + 6 * i2 + col] = v[r][k];
-      }
-    }
-  }
-  if (first_group && urow < nrows && uunit >= 9 && uunit < 12) {
-    const size_t gp = (size_t)wd.fpose_off + i0 + urow;
-    const int r0 = (uunit - 9) * 2;
-    bv.bs[gp * 6 + r0] = bv.bp[gp * 6 + r0] - cx;
-    bv.bs[gp * 6 + r0 + 1] = bv.bp[gp * 6 + r0 + 1] - cy;
-  }
+  const int r = el / 6, cc = el - 6 * r;
+  double v = 0.0;
+  if (i == j) v = bv.Hpp[((size_t)wd.fpose_off + i) * 36 + el] + ((r == cc) ? st.lambda : 0.0);
+  const double* c = bv.contrib + (size_t)rb.start * 36 + el;
+  for (int k = 0; k < rb.count; ++k) v -= c[(size_t)k * 36];
+  bv.S[wd.S_off + (size_t)(6 * i + r) * wd.n + 6 * j + cc] = v;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -818,13 +809,15 @@ struct osh_lba_ctx {
   std::vector<WinDesc> h_win;
   std::vector<const volatile unsigned char*> stop_ptr;
   bool any_stop = false;
-  size_t NP = 0, NFP = 0, NL = 0, NE = 0, NEf = 0, NR = 0, n_srows = 0, n_sblocks = 0, n_chunks = 0;
+  size_t NP = 0, NFP = 0, NL = 0, NE = 0, NEf = 0, n_chunks = 0;
+  size_t n_items = 0, n_sym = 0, n_rblk = 0, n_contrib = 0, n_ccontrib = 0;
+  long long plan_tile_steps = 0, plan_pair_blocks = 0;
   size_t S_total = 0;
   int n_max = 0, solve_nb = 24, solve_W = 0;
-  size_t solve_lds = 0, schur_lds = 0, backsub_lds = 0;
+  size_t solve_lds = 0, backsub_lds = 0;
   // device buffers
   DevBuf d_win, d_lm, d_chunks, d_fpose_win, d_pose_init, d_pose[2], d_pt_init, d_pt[2], d_cam;
-  DevBuf d_e_pose, d_e_point, d_e_kind, d_e_obs, d_e_info, d_e_orig, d_lm_off, d_lm_nfree, d_pel_off, d_pel_edge, d_srow, d_srow_nrec, d_srow_perm, d_srec, d_dinv, d_bdc;
+  DevBuf d_e_pose, d_e_point, d_e_kind, d_e_obs, d_e_info, d_e_orig, d_lm_off, d_lm_nfree, d_pel_off, d_pel_edge, d_sitems, d_srecs, d_spair, d_scslot, d_rblk, d_contrib, d_ccontrib, d_dinv;
   DevBuf d_Hpl, d_Hll, d_bl, d_Hpp, d_bp, d_S, d_bs, d_xp, d_chi, d_scale, d_dmaxc, d_dmaxp, d_nactive, d_out_chi2, d_out_depth, d_stop;
   int* h_nactive = nullptr;          // pinned
   unsigned char* h_stop = nullptr;   // pinned [n_windows]
@@ -869,7 +862,7 @@ extern "C" void osh_lba_destroy(osh_lba_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DevBuf* bufs[] = {&c->d_win, &c->d_lm, &c->d_chunks, &c->d_fpose_win, &c->d_pose_init, &c->d_pose[0], &c->d_pose[1],
                     &c->d_pt_init, &c->d_pt[0], &c->d_pt[1], &c->d_cam, &c->d_e_pose, &c->d_e_point, &c->d_e_kind,
-                    &c->d_e_obs, &c->d_e_info, &c->d_e_orig, &c->d_lm_off, &c->d_lm_nfree, &c->d_pel_off, &c->d_pel_edge, &c->d_srow, &c->d_srow_nrec, &c->d_srow_perm, &c->d_srec, &c->d_dinv, &c->d_bdc,
+                    &c->d_e_obs, &c->d_e_info, &c->d_e_orig, &c->d_lm_off, &c->d_lm_nfree, &c->d_pel_off, &c->d_pel_edge, &c->d_sitems, &c->d_srecs, &c->d_spair, &c->d_scslot, &c->d_rblk, &c->d_contrib, &c->d_ccontrib, &c->d_dinv,
                     &c->d_Hpl, &c->d_Hll, &c->d_bl, &c->d_Hpp, &c->d_bp, &c->d_S, &c->d_bs, &c->d_xp, &c->d_chi,
                     &c->d_scale, &c->d_dmaxc, &c->d_dmaxp, &c->d_nactive, &c->d_out_chi2, &c->d_out_depth, &c->d_stop};
   for (DevBuf* b : bufs) b->release();
@@ -939,10 +932,9 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   std::vector<int> h_epose(NE), h_epoint(NE), h_eorig(NE), h_lmoff(NLO), h_lmnfree(NL), h_peloff(NPO), h_pel(NEf), h_fpw(NFP);
   std::vector<unsigned char> h_kind(NE);
   std::vector<Chunk> h_chunks;
-  std::vector<int4> h_srow, h_rec;
-  std::vector<int> h_srow_nrec;
-  h_rec.reserve(NEf + NEf / 4 + 16);
-  std::vector<std::vector<int4>> grp_recs;
+  SchurPlan plan;
+  std::vector<plan_detail::Build> builds;
+  std::vector<int> build_win;
   std::vector<int> cnt, fill, order;
   for (int w = 0; w < nw; ++w) {
     const osh_lba_problem& p = pr[w];
@@ -1000,44 +992,15 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
       const int ip = h_epose[(size_t)d.edge_off + x];
       if (ip < p.n_free) h_pel[(size_t)d.pel_off + fill[ip]++] = x;
     }
-    // Schur work lists (row-tiled): for every set of kSchurRows consecutive pose rows i0.. and every group of 10 partner
-    // poses [i0+10h, i0+10h+10): records {first row edge, first partner edge, partner mask | row mask << 16}, landmark order
+    // Schur work plan: landmarks grouped by observer set (schur_plan.h)
     {
-      const int nsets = (p.n_free + kSchurRows - 1) / kSchurRows;
-      std::vector<int> grp_base(nsets + 1, 0);
-      for (int sidx = 0; sidx < nsets; ++sidx) grp_base[sidx + 1] = grp_base[sidx] + (p.n_free - sidx * kSchurRows + 9) / 10;
-      if ((int)grp_recs.size() < grp_base[nsets]) grp_recs.resize(grp_base[nsets]);
-      for (int g = 0; g < grp_base[nsets]; ++g) grp_recs[g].clear();
-      for (int j = 0; j < p.n_points; ++j) {
-        const int s0 = lmo[j], s1 = lmo[j] + h_lmnfree[(size_t)d.pt_off + j];   // optimisable-pose edges, poses ascending
-        int x = s0;
-        while (x < s1) {
-          const int pose_x = h_epose[(size_t)d.edge_off + x];
-          const int sidx = pose_x / kSchurRows, i0 = sidx * kSchurRows;
-          unsigned rowmask = 0;
-          int x_end = x;
-          while (x_end < s1 && h_epose[(size_t)d.edge_off + x_end] < i0 + kSchurRows) { rowmask |= 1u << (h_epose[(size_t)d.edge_off + x_end] - i0); ++x_end; }
-          // partners: every edge from the first present row onwards, cut into groups of 10 poses relative to i0
-          int cur_h = -1, q0 = 0;
-          unsigned mask = 0;
-          for (int q = x; q <= s1; ++q) {
-            const int hq = (q < s1) ? (h_epose[(size_t)d.edge_off + q] - i0) / 10 : -2;
-            if (hq != cur_h) {
-              if (cur_h >= 0) grp_recs[grp_base[sidx] + cur_h].push_back(make_int4(x, q0, (int)(mask | (rowmask << 16)), 0));
-              cur_h = hq; q0 = q; mask = 0;
-            }
-            if (q < s1) mask |= 1u << ((h_epose[(size_t)d.edge_off + q] - i0) % 10);
-          }
-          x = x_end;
-        }
+      const size_t b0 = builds.size();
+      if (!plan_window(w, p.n_free, p.n_points, lmo, &h_lmnfree[(size_t)d.pt_off], &h_epose[(size_t)d.edge_off], builds, plan)) {
+        set_error("window %d: a landmark has more than 254 optimisable observers", w);
+        return OSH_ERR_UNSUPPORTED;
       }
-      for (int sidx = 0; sidx < nsets; ++sidx)
-        for (int h = 0; h < grp_base[sidx + 1] - grp_base[sidx]; ++h) {
-          const auto& lst = grp_recs[grp_base[sidx] + h];
-          h_srow.push_back(make_int4(w, sidx * kSchurRows, sidx * kSchurRows + 10 * h, (int)h_rec.size()));
-          h_srow_nrec.push_back((int)lst.size());
-          h_rec.insert(h_rec.end(), lst.begin(), lst.end());
-        }
+      build_win.resize(builds.size(), w);
+      (void)b0;
     }
     // chunks: consecutive landmarks, <= kChunkEdges edges and <= kBlock landmarks (a single
     // landmark with more edges gets its own multi-pass chunk)
@@ -1052,34 +1015,21 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
     d.n_chunks = (int)h_chunks.size() - d.chunk_off;
   }
   c->n_chunks = h_chunks.size();
-  c->NR = h_rec.size();
-  c->n_srows = h_srow.size();
-  // XCD-aware launch order (MI355X: 8 XCDs, blocks dealt round-robin, one private L2 each): every row of
-  // window w is given a blockIdx with blockIdx % 8 == w % 8, so the rows that re-read the same Hpl / BD
-  // blocks share one L2.  Speed only, never correctness.
-  std::vector<int> h_perm;
-  {
-    std::vector<std::vector<int>> per_xcd(8);
-    for (size_t r = 0; r < h_srow.size(); ++r) per_xcd[h_srow[r].x & 7].push_back((int)r);
-    size_t longest = 0;
-    for (auto& v : per_xcd) longest = std::max(longest, v.size());
-    h_perm.assign(longest * 8, -1);
-    for (int x = 0; x < 8; ++x)
-      for (size_t k = 0; k < per_xcd[x].size(); ++k) h_perm[k * 8 + x] = per_xcd[x][k];
-  }
-  c->n_sblocks = h_perm.size();
-  if (h_rec.size() > 0x7fffff00u) { set_error("batch too large for 32-bit record offsets"); return OSH_ERR_UNSUPPORTED; }
+  finish_plan(build_win, builds, plan);
+  if (plan.n_contrib > 0x7fffff00u / 36 * 16 || plan.recs.size() > 0x7fffff00u) { set_error("batch too large for 32-bit contribution offsets"); return OSH_ERR_UNSUPPORTED; }
+  c->n_items = plan.items.size(); c->n_sym = (size_t)plan.n_sym; c->n_rblk = plan.rblk.size();
+  c->n_contrib = plan.n_contrib; c->n_ccontrib = plan.n_ccontrib;
+  c->plan_tile_steps = plan.tile_steps; c->plan_pair_blocks = plan.pair_blocks;
   c->h_e_orig = h_eorig;
 
   // ---- LDS budgets
-  c->schur_lds = 0;
   c->backsub_lds = (size_t)(3 * kChunkEdges + 4 + std::max(n_max, 1)) * sizeof(double);
   {
     const size_t budget = 150 * 1024;
     int nb = 24;
     auto need = [&](int b) { return ((size_t)2 * b * (n_max + 8) + (n_max + 8) + 2 * b + kSolveThreads / 64 + 8) * sizeof(double); };
     while (nb > 6 && need(nb) > budget) nb /= 2;  // 24 -> 12 -> 6 (template instantiations of k_solve)
-    if (need(nb) > budget || c->schur_lds > budget) {
+    if (need(nb) > budget) {
       set_error("window with %d optimisable poses exceeds the LDS budget of the reduced-system kernels", n_max / 6);
       return OSH_ERR_UNSUPPORTED;
     }
@@ -1106,14 +1056,15 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   OSH_TRY(upload_vec(c->d_lm_nfree, h_lmnfree, s));
   OSH_TRY(upload_vec(c->d_pel_off, h_peloff, s));
   OSH_TRY(upload_vec(c->d_pel_edge, h_pel, s));
-  OSH_TRY(upload_vec(c->d_srow, h_srow, s));
-  OSH_TRY(upload_vec(c->d_srow_nrec, h_srow_nrec, s));
-  OSH_TRY(upload_vec(c->d_srow_perm, h_perm, s));
-  OSH_TRY(upload_vec(c->d_srec, h_rec, s));
+  OSH_TRY(upload_vec(c->d_sitems, plan.items, s));
+  OSH_TRY(upload_vec(c->d_srecs, plan.recs, s));
+  OSH_TRY(upload_vec(c->d_spair, plan.pair_slot, s));
+  OSH_TRY(upload_vec(c->d_scslot, plan.c_slot, s));
+  OSH_TRY(upload_vec(c->d_rblk, plan.rblk, s));
   auto R = [&](DevBuf& b, size_t bytes) { return b.reserve(std::max<size_t>(bytes, 8)); };
   OSH_TRY(R(c->d_lm, nw * sizeof(LmState)));
   for (int k = 0; k < 2; ++k) { OSH_TRY(R(c->d_pose[k], NP * 7 * 8)); OSH_TRY(R(c->d_pt[k], NL * 3 * 8)); }
-  OSH_TRY(R(c->d_dinv, NL * 9 * 8)); OSH_TRY(R(c->d_bdc, NE * 24 * 8));
+  OSH_TRY(R(c->d_dinv, NL * 9 * 8)); OSH_TRY(R(c->d_contrib, plan.n_contrib * 36 * 8)); OSH_TRY(R(c->d_ccontrib, plan.n_ccontrib * 6 * 8));
   OSH_TRY(R(c->d_Hpl, NE * 18 * 8)); OSH_TRY(R(c->d_Hll, NL * 6 * 8)); OSH_TRY(R(c->d_bl, NL * 3 * 8));
   OSH_TRY(R(c->d_Hpp, NFP * 36 * 8)); OSH_TRY(R(c->d_bp, NFP * 6 * 8)); OSH_TRY(R(c->d_S, S_total * 8));
   OSH_TRY(R(c->d_bs, NFP * 6 * 8)); OSH_TRY(R(c->d_xp, NFP * 6 * 8));
@@ -1138,9 +1089,10 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   bv.e_obs = c->d_e_obs.as<double>(); bv.e_info = c->d_e_info.as<double>(); bv.e_orig = c->d_e_orig.as<int>();
   bv.lm_off = c->d_lm_off.as<int>(); bv.lm_nfree = c->d_lm_nfree.as<int>();
   bv.pel_off = c->d_pel_off.as<int>(); bv.pel_edge = c->d_pel_edge.as<int>();
-  bv.srow = c->d_srow.as<int4>(); bv.srow_nrec = c->d_srow_nrec.as<int>(); bv.srow_perm = c->d_srow_perm.as<int>(); bv.srec = c->d_srec.as<int4>();
-  bv.dinv = c->d_dinv.as<double>(); bv.bdc = c->d_bdc.as<double>();
-  bv.n_srows = (int)c->n_srows;
+  bv.sitems = c->d_sitems.as<SItem>(); bv.srecs = c->d_srecs.as<SRec>(); bv.spair = c->d_spair.as<int>(); bv.scslot = c->d_scslot.as<int>();
+  bv.rblk = c->d_rblk.as<RBlk>(); bv.n_rblk = (int)c->n_rblk;
+  bv.contrib = c->d_contrib.as<double>(); bv.ccontrib = c->d_ccontrib.as<double>();
+  bv.dinv = c->d_dinv.as<double>();
   bv.Hpl = c->d_Hpl.as<double>(); bv.Hll = c->d_Hll.as<double>(); bv.bl = c->d_bl.as<double>();
   bv.Hpp = c->d_Hpp.as<double>(); bv.bp = c->d_bp.as<double>(); bv.S = c->d_S.as<double>();
   bv.bs = c->d_bs.as<double>(); bv.xp = c->d_xp.as<double>();
@@ -1157,7 +1109,6 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
     OSH_HIP(hipFuncSetAttribute((const void*)k_solve<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     OSH_HIP(hipFuncSetAttribute((const void*)k_solve<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     OSH_HIP(hipFuncSetAttribute((const void*)k_backsub, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-    OSH_HIP(hipFuncSetAttribute((const void*)k_bdinv, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     attr_done = true;
   }
   return OSH_OK;
@@ -1223,8 +1174,9 @@ extern "C" int osh_lba_optimize(osh_lba_ctx* c) {
     LAUNCH(OSH_K_LINEARIZE, k_linearize, c->n_chunks, kBlock, 0, c->bv, 0);
     LAUNCH(OSH_K_POSE_HESS, k_pose_hess, c->NFP, 64, 0, c->bv);
     LAUNCH(OSH_K_CONTROL, k_control, c->n_windows, 64, 0, c->bv, 0);
-    LAUNCH(OSH_K_DINV, k_bdinv, c->n_chunks, kBlock, kBdinvLds, c->bv);
-    LAUNCH(OSH_K_SCHUR, k_schur, c->n_sblocks, 64, 0, c->bv);
+    LAUNCH(OSH_K_SCHUR, k_schur_items<true>, c->n_sym, 64, 0, c->bv, 0);
+    LAUNCH(OSH_K_SCHUR_CROSS, k_schur_items<false>, c->n_items - c->n_sym, 64, 0, c->bv, (int)c->n_sym);
+    LAUNCH(OSH_K_SCHUR_REDUCE, k_schur_reduce, (c->n_rblk + 6) / 7, 256, 0, c->bv);
     if (c->solve_nb == 24) LAUNCH(OSH_K_SOLVE, k_solve<24>, c->n_windows, kSolveThreads, c->solve_lds, c->bv, c->solve_W);
     else if (c->solve_nb == 12) LAUNCH(OSH_K_SOLVE, k_solve<12>, c->n_windows, kSolveThreads, c->solve_lds, c->bv, c->solve_W);
     else LAUNCH(OSH_K_SOLVE, k_solve<6>, c->n_windows, kSolveThreads, c->solve_lds, c->bv, c->solve_W);
@@ -1349,8 +1301,9 @@ extern "C" int osh_lba_debug_trial(osh_lba_ctx* c, int32_t window, double lambda
   for (auto& st : h_lm) st.lambda = lambda;
   OSH_HIP(hipMemcpy(c->d_lm.p, h_lm.data(), c->n_windows * sizeof(LmState), hipMemcpyHostToDevice));
   const WinDesc& d = c->h_win[window];
-  if (c->n_chunks) { hipLaunchKernelGGL(k_bdinv, dim3((unsigned)c->n_chunks), dim3(kBlock), kBdinvLds, s, c->bv); OSH_TRY(launch_check("k_bdinv")); }
-  if (c->n_sblocks) { hipLaunchKernelGGL(k_schur, dim3((unsigned)c->n_sblocks), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_schur")); }
+  if (c->n_sym) { hipLaunchKernelGGL(k_schur_items<true>, dim3((unsigned)c->n_sym), dim3(64), 0, s, c->bv, 0); OSH_TRY(launch_check("k_schur_items")); }
+  if (c->n_items > c->n_sym) { hipLaunchKernelGGL(k_schur_items<false>, dim3((unsigned)(c->n_items - c->n_sym)), dim3(64), 0, s, c->bv, (int)c->n_sym); OSH_TRY(launch_check("k_schur_items")); }
+  if (c->n_rblk) { hipLaunchKernelGGL(k_schur_reduce, dim3((unsigned)((c->n_rblk + 6) / 7)), dim3(256), 0, s, c->bv); OSH_TRY(launch_check("k_schur_reduce")); }
   OSH_HIP(hipStreamSynchronize(s));
   if (S && d.n) OSH_HIP(hipMemcpy(S, c->d_S.as<double>() + d.S_off, (size_t)d.n * d.n * 8, hipMemcpyDeviceToHost));
   if (bs && d.n) OSH_HIP(hipMemcpy(bs, c->d_bs.as<double>() + (size_t)d.fpose_off * 6, (size_t)d.n * 8, hipMemcpyDeviceToHost));
@@ -1391,6 +1344,6 @@ extern "C" int osh_lba_get_profile(osh_lba_ctx* c, int64_t launches[OSH_K_COUNT]
 }
 
 extern "C" const char* osh_lba_kernel_name(int k) {
-  static const char* names[OSH_K_COUNT] = {"k_linearize", "k_pose_hess", "k_schur", "k_solve", "k_backsub", "k_linearize(residual)", "k_control", "k_bdinv"};
+  static const char* names[OSH_K_COUNT] = {"k_linearize", "k_pose_hess", "k_schur", "k_solve", "k_backsub", "k_linearize(residual)", "k_control", "k_schur_reduce", "k_schur_items(cross)"};
   return (k >= 0 && k < OSH_K_COUNT) ? names[k] : "?";
 }
