@@ -189,13 +189,15 @@ def make_window(seed: int, n_free: int = 50, n_fixed: int = 10, n_points: int = 
                 track_len=(4, 12), pose_noise=(0.01, 0.05), point_noise: float = 0.1,
                 outlier_frac: float = 0.03, pixel_noise: bool = True, kf_spacing: float = 0.25,
                 yaw_drift: float = 0.02, lambda_init: float = 0.0, max_iterations: int = 10,
-                mixed_mono_frac: float = 0.0) -> LbaWindow:
+                mixed_mono_frac: float = 0.0, obs_dropout: float = 0.0) -> LbaWindow:
     """A synthetic local-BA window.
 
     Keyframes move along +x looking down +z with a slow yaw drift; the oldest
     ``n_fixed`` keyframes are the fixed observers, the rest are optimisable.
     Landmarks fill a 4-12 m deep slab; each is observed by a contiguous run of
-    ``track_len`` keyframes that see it.  Order of poses: optimisable first.
+    ``track_len`` keyframes that see it; ``obs_dropout`` removes that fraction of the
+    observations at random (missed detections: the observer sets stop being contiguous runs).
+    Order of poses: optimisable first.
     """
     rng = np.random.Generator(np.random.PCG64(seed))
     K = n_free + n_fixed
@@ -236,6 +238,8 @@ def make_window(seed: int, n_free: int = 50, n_fixed: int = 10, n_points: int = 
     start = first + np.floor(rng.uniform(0, 1, n_points) * (count - tlen + 1)).astype(np.int64)
     tt = np.arange(K)[:, None]
     obs_mask = vis & (tt >= start[None, :]) & (tt < (start + tlen)[None, :])
+    if obs_dropout > 0:
+        obs_mask &= np.random.Generator(np.random.PCG64(seed + 7919)).uniform(0, 1, obs_mask.shape) >= obs_dropout
     # every landmark needs >= 2 observations and >= 1 optimisable keyframe
     ok = (obs_mask.sum(axis=0) >= 2) & (obs_mask[n_fixed:].sum(axis=0) >= 1)
     obs_mask[:, ~ok] = False

@@ -170,3 +170,23 @@ def test_zero_noise_window_converges_to_ground_truth(solver):
     g = solver.solve([w])[0]
     assert rel_translation_error(g.pose_qt, w.gt_pose_qt[:w.n_free]) < 1e-5
     assert np.abs(g.points - w.gt_points).max() < 1e-3
+
+
+@pytest.mark.parametrize("kwargs", [
+    dict(seed=31, n_free=12, n_fixed=3, n_points=800, track_len=(2, 9), obs_dropout=0.2),     # ragged observer sets
+    dict(seed=32, n_free=30, n_fixed=4, n_points=1500, track_len=(10, 28)),                   # > 8 and > 16 observers: cross items
+    dict(seed=33, n_free=30, n_fixed=4, n_points=1500, track_len=(10, 28), obs_dropout=0.3, stereo=False),
+])
+def test_observer_set_grouping_ragged_and_long_tracks(solver, ob, kwargs):
+    """The Schur work plan (csrc/schur_plan.h) on graphs whose landmarks do not share observer sets:
+    one trial (S, b_s, x) and the full optimisation against the oracle."""
+    kw = dict(kwargs)
+    w = synth.make_window(kw.pop("seed"), **kw)
+    solver.upload([w])
+    S, bs, x = solver.debug_trial(0, 1e-3)
+    So, bso, xo = ob.lba_schur_step(w, 1e-3)
+    iu = np.triu_indices(S.shape[0])
+    np.testing.assert_allclose(S[iu], So[iu], rtol=1e-10, atol=1e-11 * np.abs(So).max())
+    np.testing.assert_allclose(bs, bso, rtol=1e-10, atol=1e-11 * np.abs(bso).max())
+    np.testing.assert_allclose(x, xo, rtol=1e-7, atol=1e-9 * np.abs(xo).max())
+    _check_result(solver.solve([w])[0], ob.lba_solve(w), w)
