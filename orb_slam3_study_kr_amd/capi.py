@@ -24,8 +24,8 @@ OSH_ERR_NO_DEVICE = -4
 OSH_EDGE_MONO = 0
 OSH_EDGE_STEREO = 1
 OSH_LBA_MAX_TRACE = 128
-OSH_K_COUNT = 9
-KERNEL_NAMES = ["linearize", "pose_hess", "schur", "solve", "backsub", "residual", "control", "schur_reduce", "schur_cross"]
+OSH_K_COUNT = 10
+KERNEL_NAMES = ["linearize", "pose_hess", "schur", "solve", "backsub", "residual", "control", "schur_reduce", "schur_cross", "lin_aux"]
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)

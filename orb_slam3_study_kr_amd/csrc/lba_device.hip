@@ -6,10 +6,11 @@
 // DESIGN.md for the data layout and the roofline of each kernel.
 //
 // Kernel map (reference loop -> kernel), "g2o/" = Thirdparty/g2o/g2o/:
-//   k_linearize   computeActiveErrors + activeRobustChi2 + buildSystem for the landmark side
+//   k_lin_items   computeActiveErrors + activeRobustChi2 + buildSystem
 //                 g2o/core/sparse_optimizer.cpp:61-114, block_solver.hpp:502-560,
-//                 base_binary_edge.hpp:55-120  (Hll, b_l, Hpl;  also residual-only mode)
-//   k_pose_hess   the pose side of buildSystem (Hpp, b_p), one wavefront per optimisable pose
+//                 base_binary_edge.hpp:55-120  (Hll, b_l, Hpl, per-group Hpp / b_p partials)
+//   k_pose_reduce the pose side of buildSystem (Hpp, b_p) from the group partials, fixed order
+//   k_residual    computeActiveErrors + activeRobustChi2 at the trial estimates
 //   k_schur_items BlockSolver::solve Schur part, block_solver.hpp:367-439: landmarks grouped by observer
 //                 set (schur_plan.h), one wavefront per group, BD * W^T on the FP64 matrix cores
 //   k_schur_reduce  S = Hpp + lambda I - sum of the group products, b_s = b_p - ..., fixed order
@@ -48,6 +49,8 @@ struct WinDesc {
   int peloff_off;  // start of this window's P+1 pose->edge-list offsets
   int pel_off;     // start of this window's pose edge list
   int chunk_off, n_chunks;
+  int sitem_off, n_sitems;  // this window's symmetric items of the Schur plan (they also carry the linearisation)
+  int aux_off, n_aux;       // this window's chunks of k_lin_aux
   int n;           // 6P
   int max_iter;
   long long S_off; // doubles
@@ -102,6 +105,15 @@ struct BatchView {
   const SRec* srecs;         // landmark records of the items
   const int* spair;          // [n_items*64] contribution index of pose pair (sa,sb) or -1
   const int* scslot;         // [n_items*8] rhs contribution index of row pose sa or -1
+  const int* sposex;         // [n_items*8] window-local row pose of slot sa or -1
+  const int2* pose_crange;   // [NFP] {first, count} of the pose's (item, pose) contributions
+  double* hcontrib;          // [n_ccontrib*27] per linearisation: upper(Hpp) (21) + b_p (6) of one item and pose
+  double* chi_item;          // [n_sym] robust chi2 partial of each symmetric item
+  double* dmax_item;         // [n_sym] largest Hll diagonal entry seen by the item
+  const int4* aux_chunks;    // [n_aux_chunks] {window, first entry, entries, 0} of k_lin_aux
+  const int2* aux_entries;   // {landmark, sorted edge}, window-local
+  double* chi_aux;           // [n_aux_chunks]
+  double* dmax_aux;          // [n_aux_chunks]
   const RBlk* rblk;          // [n_rblk] blocks of S + rhs segments with their contribution ranges
   int n_rblk;
   double* contrib;           // [n_contrib*36] per trial: 6x6 products of one item and pose pair
@@ -118,13 +130,20 @@ struct BatchView {
   double* xp;                // [NFP*6]
   double* chi_part;          // [n_chunks]
   double* scale_part;        // [n_chunks]
-  double* dmax_part;         // [n_chunks]
   double* dmax_pose;         // [NFP]
   int* n_active;             // [1]
   // outputs
   double* out_chi2;          // [NE] caller order
   unsigned char* out_depth;  // [NE]
 };
+
+// Read-only snapshot of the controller fields a kernel needs, taken once at kernel entry (a reference into
+// global memory would be re-read after every store: the compiler cannot prove the stores do not alias it).
+struct LmView { double lambda; int active, need_lin, sel, solve_ok, last_eval_sel, iterations; };
+__device__ __forceinline__ LmView lm_view(const LmState* lm, int w) {
+  const LmState& s = lm[w];
+  return LmView{s.lambda, s.active, s.need_lin, s.sel, s.solve_ok, s.last_eval_sel, s.iterations};
+}
 
 // --------------------------------------------------------------------------------------------
 // block-wide deterministic reductions (4 wavefronts of 64)
@@ -149,187 +168,40 @@ __device__ __forceinline__ double block_max(double v, double* sh4) {
 }
 
 // --------------------------------------------------------------------------------------------
-// k_linearize: one block per chunk of consecutive landmarks (<= 256 edges per pass).
-//   mode 0: linearise at the current estimates (windows opening an iteration)
-//   mode 1: residual + robust chi2 only, at the trial estimates (every active window)
+// k_residual: computeActiveErrors + activeRobustChi2 at the TRIAL estimates (every active window),
+// one block per chunk of consecutive landmarks, lane per edge; chunk partial sums in fixed order.
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_linearize(BatchView bv, int mode) {
-  __shared__ double sh_c[9 * kChunkEdges];
+__global__ __launch_bounds__(kBlock) void k_residual(BatchView bv) {
   __shared__ double sh4[4];
   const Chunk ch = bv.chunks[blockIdx.x];
-  const WinDesc& wd = bv.win[ch.win];
-  const LmState& st = bv.lm[ch.win];
+  const WinDesc wd = bv.win[ch.win];   // by value: the fields stay in SGPRs across the kernel's stores
+  const LmView st = lm_view(bv.lm, ch.win);
   if (!st.active) return;
-  if (mode == 0 && !st.need_lin) return;
-  const int sel = (mode == 0) ? st.sel : (st.sel ^ 1);
+  const int sel = st.sel ^ 1;
   const double* poses = bv.pose_state[sel] + (size_t)wd.pose_off * 7;
   const double* pts = bv.pt_state[sel] + (size_t)wd.pt_off * 3;
   const double* cams = bv.pose_cam + (size_t)wd.pose_off * 5;
   const int* lmo = bv.lm_off + wd.lmoff_off;
-  const int tid = threadIdx.x;
   const int e0 = lmo[ch.lm0], e1 = lmo[ch.lm1];
-  const int nl = ch.lm1 - ch.lm0;
   double chi_acc = 0.0;
-  double acc[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) acc[k] = 0.0;
-  int my_lo = 0, my_hi = 0;
-  if (tid < nl) { my_lo = lmo[ch.lm0 + tid]; my_hi = lmo[ch.lm0 + tid + 1]; }
-
-  for (int base = e0; base < e1; base += kChunkEdges) {
-    const int e = base + tid;
-    double contrib[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) contrib[k] = 0.0;
-    if (e < e1) {
-      const size_t ge = (size_t)wd.edge_off + e;
-      const int ip = bv.e_pose[ge], il = bv.e_point[ge];
-      const int kind = bv.e_kind[ge];
-      const double info = bv.e_info[ge];
-      double qt[7], cam[5], X[3], obs[3], r[3], Xc[3];
-#pragma unroll
-      for (int k = 0; k < 7; ++k) qt[k] = poses[(size_t)ip * 7 + k];
-#pragma unroll
-      for (int k = 0; k < 5; ++k) cam[k] = cams[(size_t)ip * 5 + k];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) { X[k] = pts[(size_t)il * 3 + k]; obs[k] = bv.e_obs[ge * 3 + k]; }
-      const double chi2 = dev::edge_residual(kind, qt, cam, X, obs, info, r, Xc);
-      double rho0, rho1;
-      dev::huber(chi2, kind == OSH_EDGE_MONO ? wd.huber_mono : wd.huber_stereo, rho0, rho1);
-      chi_acc += rho0;
-      if (mode == 0) {
-        double JX[9], Jp[18];
-        dev::edge_jacobians(kind, qt, cam, Xc, JX, Jp);
-        const double ww = rho1 * info;                       // robustInformation (first order only)
-        const double wr[3] = {-(info * r[0]) * rho1, -(info * r[1]) * rho1, -(info * r[2]) * rho1};
-        // landmark side: upper(JX^T W JX) and JX^T (-rho' Omega r)
-        double AtW[9];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-          for (int k = 0; k < 3; ++k) AtW[i * 3 + k] = JX[k * 3 + i] * ww;
-        contrib[0] = AtW[0] * JX[0] + AtW[1] * JX[3] + AtW[2] * JX[6];
-        contrib[1] = AtW[0] * JX[1] + AtW[1] * JX[4] + AtW[2] * JX[7];
-        contrib[2] = AtW[0] * JX[2] + AtW[1] * JX[5] + AtW[2] * JX[8];
-        contrib[3] = AtW[3] * JX[1] + AtW[4] * JX[4] + AtW[5] * JX[7];
-        contrib[4] = AtW[3] * JX[2] + AtW[4] * JX[5] + AtW[5] * JX[8];
-        contrib[5] = AtW[6] * JX[2] + AtW[7] * JX[5] + AtW[8] * JX[8];
-        contrib[6] = JX[0] * wr[0] + JX[3] * wr[1] + JX[6] * wr[2];
-        contrib[7] = JX[1] * wr[0] + JX[4] * wr[1] + JX[7] * wr[2];
-        contrib[8] = JX[2] * wr[0] + JX[5] * wr[1] + JX[8] * wr[2];
-        if (ip < wd.P) {
-          // Hpl block = Jp^T W JX  (6x3, pose row x landmark col)
-          double* H = bv.Hpl + ge * 18;
-#pragma unroll
-          for (int i = 0; i < 6; ++i) {
-            const double b0 = Jp[i] * ww, b1 = Jp[6 + i] * ww, b2 = Jp[12 + i] * ww;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) H[i * 3 + j] = b0 * JX[j] + b1 * JX[3 + j] + b2 * JX[6 + j];
-          }
-        }
-      }
-    }
-    if (mode == 0) {
-#pragma unroll
-      for (int k = 0; k < 9; ++k) sh_c[k * kChunkEdges + tid] = contrib[k];
-      __syncthreads();
-      if (tid < nl) {
-        const int lo = max(my_lo, base), hi = min(my_hi, base + kChunkEdges);
-        for (int x = lo; x < hi; ++x) {
-#pragma unroll
-          for (int k = 0; k < 9; ++k) acc[k] += sh_c[k * kChunkEdges + (x - base)];
-        }
-      }
-      __syncthreads();
-    }
-  }
-  double dmax = 0.0;
-  if (mode == 0 && tid < nl) {
-    const size_t gl = (size_t)wd.pt_off + ch.lm0 + tid;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) bv.Hll[gl * 6 + k] = acc[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) bv.bl[gl * 3 + k] = acc[6 + k];
-    dmax = fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5])));
-  }
-  const double chi = block_sum(chi_acc, sh4);
-  if (mode == 0) {
-    const double dm = block_max(dmax, sh4);
-    if (tid == 0) bv.dmax_part[blockIdx.x] = dm;
-  }
-  if (tid == 0) bv.chi_part[blockIdx.x] = chi;
-}
-
-// --------------------------------------------------------------------------------------------
-// k_pose_hess: one wavefront per optimisable pose, lanes stride the pose's edge list.
-// --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_pose_hess(BatchView bv) {
-  const int gp = blockIdx.x;
-  const int w = bv.fpose_win[gp];
-  const WinDesc& wd = bv.win[w];
-  const LmState& st = bv.lm[w];
-  if (!st.active || !st.need_lin) return;
-  const int i = gp - wd.fpose_off;
-  const int lane = threadIdx.x;
-  const double* pts = bv.pt_state[st.sel] + (size_t)wd.pt_off * 3;
-  double qt[7], cam[5];
-#pragma unroll
-  for (int k = 0; k < 7; ++k) qt[k] = bv.pose_state[st.sel][((size_t)wd.pose_off + i) * 7 + k];
-#pragma unroll
-  for (int k = 0; k < 5; ++k) cam[k] = bv.pose_cam[((size_t)wd.pose_off + i) * 5 + k];
-  const int* po = bv.pel_off + wd.peloff_off;
-  const int lo = po[i], hi = po[i + 1];
-  double H[21], b[6];
-#pragma unroll
-  for (int k = 0; k < 21; ++k) H[k] = 0.0;
-#pragma unroll
-  for (int k = 0; k < 6; ++k) b[k] = 0.0;
-  for (int idx = lo + lane; idx < hi; idx += 64) {
-    const int e = bv.pel_edge[(size_t)wd.pel_off + idx];
+  for (int e = e0 + threadIdx.x; e < e1; e += kBlock) {
     const size_t ge = (size_t)wd.edge_off + e;
-    const int il = bv.e_point[ge];
+    const int ip = bv.e_pose[ge], il = bv.e_point[ge];
     const int kind = bv.e_kind[ge];
-    const double info = bv.e_info[ge];
-    double X[3], obs[3], r[3], Xc[3];
+    double qt[7], cam[5], X[3], obs[3], r[3], Xc[3];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) qt[k] = poses[(size_t)ip * 7 + k];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) cam[k] = cams[(size_t)ip * 5 + k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) { X[k] = pts[(size_t)il * 3 + k]; obs[k] = bv.e_obs[ge * 3 + k]; }
-    const double chi2 = dev::edge_residual(kind, qt, cam, X, obs, info, r, Xc);
+    const double chi2 = dev::edge_residual(kind, qt, cam, X, obs, bv.e_info[ge], r, Xc);
     double rho0, rho1;
     dev::huber(chi2, kind == OSH_EDGE_MONO ? wd.huber_mono : wd.huber_stereo, rho0, rho1);
-    double JX[9], Jp[18];
-    dev::edge_jacobians(kind, qt, cam, Xc, JX, Jp);
-    const double ww = rho1 * info;
-    const double wr[3] = {-(info * r[0]) * rho1, -(info * r[1]) * rho1, -(info * r[2]) * rho1};
-    int m = 0;
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {
-      const double a0 = Jp[a] * ww, a1 = Jp[6 + a] * ww, a2 = Jp[12 + a] * ww;
-#pragma unroll
-      for (int c = a; c < 6; ++c) { H[m] += a0 * Jp[c] + a1 * Jp[6 + c] + a2 * Jp[12 + c]; ++m; }
-      b[a] += Jp[a] * wr[0] + Jp[6 + a] * wr[1] + Jp[12 + a] * wr[2];
-    }
+    chi_acc += rho0;
   }
-#pragma unroll
-  for (int k = 0; k < 21; ++k) H[k] = dev::wave_sum(H[k]);
-#pragma unroll
-  for (int k = 0; k < 6; ++k) b[k] = dev::wave_sum(b[k]);
-  if (lane == 0) {
-    double* Ho = bv.Hpp + (size_t)gp * 36;
-    int m = 0;
-    double dm = 0.0;
-#pragma unroll
-    for (int a = 0; a < 6; ++a)
-#pragma unroll
-      for (int c = a; c < 6; ++c) {
-        Ho[a * 6 + c] = H[m];
-        Ho[c * 6 + a] = H[m];
-        if (a == c) dm = fmax(dm, fabs(H[m]));
-        ++m;
-      }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) bv.bp[(size_t)gp * 6 + k] = b[k];
-    bv.dmax_pose[gp] = dm;
-  }
+  const double chi = block_sum(chi_acc, sh4);
+  if (threadIdx.x == 0) bv.chi_part[blockIdx.x] = chi;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -356,8 +228,8 @@ __global__ __launch_bounds__(64) void k_schur_items(BatchView bv, int item_base)
   __shared__ int shP[64 + 8];
   const int item_idx = item_base + blockIdx.x;
   const SItem it = bv.sitems[item_idx];
-  const WinDesc& wd = bv.win[it.win];
-  const LmState& st = bv.lm[it.win];
+  const WinDesc wd = bv.win[it.win];   // by value: the fields stay in SGPRs across the kernel's stores
+  const LmView st = lm_view(bv.lm, it.win);
   if (!st.active) return;
   const int lane = threadIdx.x;
   const int l = lane >> 3, s = lane & 7;
@@ -498,8 +370,8 @@ __global__ __launch_bounds__(256) void k_schur_reduce(BatchView bv) {
   const int idx = blockIdx.x * 7 + t;
   if (t >= 7 || idx >= bv.n_rblk) return;
   const RBlk rb = bv.rblk[idx];
-  const WinDesc& wd = bv.win[rb.win];
-  const LmState& st = bv.lm[rb.win];
+  const WinDesc wd = bv.win[rb.win];   // by value: the fields stay in SGPRs across the kernel's stores
+  const LmView st = lm_view(bv.lm, rb.win);
   if (!st.active) return;
   const int i = rb.ij & 0xffff, j = (rb.ij >> 16) & 0xffff;
   if (j == 0xffff) {
@@ -517,6 +389,309 @@ __global__ __launch_bounds__(256) void k_schur_reduce(BatchView bv) {
   const double* c = bv.contrib + (size_t)rb.start * 36 + el;
   for (int k = 0; k < rb.count; ++k) v -= c[(size_t)k * 36];
   bv.S[wd.S_off + (size_t)(6 * i + r) * wd.n + 6 * j + cc] = v;
+}
+
+// --------------------------------------------------------------------------------------------
+// k_lin_items: linearisation at the current estimates (computeActiveErrors + activeRobustChi2 +
+// buildSystem, g2o/core/sparse_optimizer.cpp:61-114, block_solver.hpp:502-560,
+// base_binary_edge.hpp:55-120), one wavefront per SYMMETRIC item of the Schur plan.  Lane (l, s)
+// owns the edge of landmark l (8 per chunk) and row pose X[s]: residual, Huber weight, both
+// Jacobians, then
+//   Hpl block  -> global (used by every trial of the iteration and by the back-substitution)
+//   Hpp / b_p  -> summed over the item's landmarks in registers, one 27-double contribution per
+//                 (item, pose), reduced in plan order by k_pose_reduce
+//   Hll / b_l  -> summed over the 8 pose lanes of the landmark by a fixed butterfly and written by
+//                 the record that owns the landmark (part 0).  The landmark's remaining edges
+//                 (observers beyond the first 8, fixed keyframes) are added by k_lin_aux.
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ double group8_sum(double v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(64, 2) void k_lin_items(BatchView bv) {
+  __shared__ double shH[64 * 27];
+  const int item_idx = blockIdx.x;
+  const SItem it = bv.sitems[item_idx];
+  const WinDesc wd = bv.win[it.win];   // by value: the fields stay in SGPRs across the kernel's stores
+  const LmView st = lm_view(bv.lm, it.win);
+  if (!st.active || !st.need_lin) return;
+  const int lane = threadIdx.x;
+  const int l = lane >> 3, s = lane & 7;
+  const int nx = it.shape & 0xff;
+  const double* poses = bv.pose_state[st.sel] + (size_t)wd.pose_off * 7;
+  const double* pts = bv.pt_state[st.sel] + (size_t)wd.pt_off * 3;
+  const double* cams = bv.pose_cam + (size_t)wd.pose_off * 5;
+  const SRec* __restrict__ recs = bv.srecs + it.rec_off;
+  double qt[7], cam[5];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) qt[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) cam[k] = 0.0;
+  if (s < nx) {
+    const int ip = bv.sposex[(size_t)item_idx * 8 + s];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) qt[k] = poses[(size_t)ip * 7 + k];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) cam[k] = cams[(size_t)ip * 5 + k];
+  }
+  double Rm[9];
+  dev::quat_to_R(qt, Rm);
+  double H[21], b[6];
+#pragma unroll
+  for (int k = 0; k < 21; ++k) H[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) b[k] = 0.0;
+  double chi_acc = 0.0, dmax = 0.0;
+
+  // Two-stage software pipeline, unrolled by two so that no register is copied between iterations (a copy
+  // would force the wait for the prefetch at the end of every iteration): while chunk c is computed the
+  // record of chunk c+2 and the edge data of chunk c+1 are in flight.  All loads are unconditional on
+  // clamped indices (a load inside a divergent branch is waited for at the end of the branch); validity is
+  // applied when the values are used.
+  struct Cur { int lm, e_first, flags, ne; unsigned xo; };
+  struct In { int kind; double info, X[3], obs[3]; };
+  const int last_rec = it.n_lm - 1;
+  const size_t last_edge = (size_t)wd.edge_off + (size_t)(wd.E - 1);
+  auto load_rec = [&](int c0, int4& ra, int4& rb) {
+    const int4* src = reinterpret_cast<const int4*>(recs + min(c0 + l, last_rec));
+    ra = src[0]; rb = src[1];          // {lm, e_first, x_lo, x_hi} {y_lo, y_hi, flags, pad}
+  };
+  auto decode = [&](int c0, const int4& ra, const int4& rb) {
+    Cur cu;
+    const bool valid = (c0 + l) < it.n_lm;
+    cu.lm = ra.x; cu.e_first = ra.y; cu.flags = valid ? rb.z : 0; cu.ne = rb.w;
+    cu.xo = valid ? ((((s < 4) ? (unsigned)ra.z : (unsigned)ra.w) >> (8 * (s & 3))) & 0xffu) : kAbsent;
+    return cu;
+  };
+  auto load_in = [&](const Cur& cu, In& in) {
+    const size_t ge = min((size_t)wd.edge_off + cu.e_first + (cu.xo != kAbsent ? (int)cu.xo : 0), last_edge);
+    in.kind = bv.e_kind[ge];
+    in.info = bv.e_info[ge];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { in.X[k] = pts[(size_t)cu.lm * 3 + k]; in.obs[k] = bv.e_obs[ge * 3 + k]; }
+  };
+  auto process = [&](const Cur& cur, const In& inp) {
+    const bool owner = (cur.flags & 1) != 0;
+    const unsigned xo = cur.xo;
+    double hl[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) hl[k] = 0.0;
+    const double X[3] = {inp.X[0], inp.X[1], inp.X[2]};
+    if (xo != kAbsent) {
+      const size_t ge = (size_t)wd.edge_off + cur.e_first + (int)xo;
+      const int kind = inp.kind;
+      const double info = inp.info;
+      double r[3], Xc[3];
+      const double obs[3] = {inp.obs[0], inp.obs[1], inp.obs[2]};
+      const double chi2 = dev::edge_residual(kind, qt, cam, X, obs, info, r, Xc);
+      double rho0, rho1;
+      dev::huber(chi2, kind == OSH_EDGE_MONO ? wd.huber_mono : wd.huber_stereo, rho0, rho1);
+      double JX[9], Jp[18];
+      dev::edge_jacobians(kind, Rm, cam, Xc, JX, Jp);
+      const double ww = rho1 * info;                       // robustInformation (first order only)
+      const double wr[3] = {-(info * r[0]) * rho1, -(info * r[1]) * rho1, -(info * r[2]) * rho1};
+      if (owner) {
+        chi_acc += rho0;
+        double AtW[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) AtW[i * 3 + k] = JX[k * 3 + i] * ww;
+        hl[0] = AtW[0] * JX[0] + AtW[1] * JX[3] + AtW[2] * JX[6];
+        hl[1] = AtW[0] * JX[1] + AtW[1] * JX[4] + AtW[2] * JX[7];
+        hl[2] = AtW[0] * JX[2] + AtW[1] * JX[5] + AtW[2] * JX[8];
+        hl[3] = AtW[3] * JX[1] + AtW[4] * JX[4] + AtW[5] * JX[7];
+        hl[4] = AtW[3] * JX[2] + AtW[4] * JX[5] + AtW[5] * JX[8];
+        hl[5] = AtW[6] * JX[2] + AtW[7] * JX[5] + AtW[8] * JX[8];
+        hl[6] = JX[0] * wr[0] + JX[3] * wr[1] + JX[6] * wr[2];
+        hl[7] = JX[1] * wr[0] + JX[4] * wr[1] + JX[7] * wr[2];
+        hl[8] = JX[2] * wr[0] + JX[5] * wr[1] + JX[8] * wr[2];
+      }
+      // Hpl block = Jp^T W JX (6x3), Hpp += Jp^T W Jp (upper), b_p += Jp^T (-rho' Omega r)
+      double2* Hout = reinterpret_cast<double2*>(bv.Hpl + ge * 18);
+      double hp[18];
+      int m = 0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const double b0 = Jp[i] * ww, b1 = Jp[6 + i] * ww, b2 = Jp[12 + i] * ww;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) hp[i * 3 + j] = b0 * JX[j] + b1 * JX[3 + j] + b2 * JX[6 + j];
+#pragma unroll
+        for (int c = i; c < 6; ++c) { H[m] += b0 * Jp[c] + b1 * Jp[6 + c] + b2 * Jp[12 + c]; ++m; }
+        b[i] += Jp[i] * wr[0] + Jp[6 + i] * wr[1] + Jp[12 + i] * wr[2];
+      }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Hout[k] = make_double2(hp[2 * k], hp[2 * k + 1]);
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) hl[k] = group8_sum(hl[k]);
+    if (owner && s == 0) {
+      const size_t gl = (size_t)wd.pt_off + cur.lm;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) bv.Hll[gl * 6 + k] = hl[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) bv.bl[gl * 3 + k] = hl[6 + k];
+      // a landmark with further edges (k_lin_aux adds them) reports its diagonal there
+      if (cur.ne == ((cur.flags >> 8) & 0xff)) dmax = fmax(dmax, fmax(fabs(hl[0]), fmax(fabs(hl[3]), fabs(hl[5]))));
+    }
+  };
+  int4 rA0, rA1, rB0, rB1;
+  In inA, inB;
+  load_rec(0, rA0, rA1);
+  load_rec(kSiLm, rB0, rB1);
+  load_in(decode(0, rA0, rA1), inA);
+  for (int c0 = 0; c0 < it.n_lm; c0 += 2 * kSiLm) {
+    {
+      const Cur cur = decode(c0, rA0, rA1);
+      load_rec(c0 + 2 * kSiLm, rA0, rA1);
+      load_in(decode(c0 + kSiLm, rB0, rB1), inB);
+      process(cur, inA);
+    }
+    if (c0 + kSiLm < it.n_lm) {
+      const Cur cur = decode(c0 + kSiLm, rB0, rB1);
+      load_rec(c0 + 3 * kSiLm, rB0, rB1);
+      load_in(decode(c0 + 2 * kSiLm, rA0, rA1), inA);
+      process(cur, inB);
+    }
+  }
+  chi_acc = dev::wave_sum(chi_acc);
+  dmax = dev::wave_max(dmax);
+  if (lane == 0) { bv.chi_item[item_idx] = chi_acc; bv.dmax_item[item_idx] = dmax; }
+  // Hpp / b_p of row pose s: sum over the 8 landmark lanes in fixed order
+#pragma unroll
+  for (int k = 0; k < 21; ++k) shH[k * 64 + lane] = H[k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) shH[(21 + k) * 64 + lane] = b[k];
+  __syncthreads();
+  for (int o = lane; o < 8 * 27; o += 64) {
+    const int k = o >> 3, sa = o & 7;
+    const int slot = bv.scslot[(size_t)item_idx * 8 + sa];
+    if (slot >= 0) {
+      double v = 0.0;
+#pragma unroll
+      for (int ll = 0; ll < 8; ++ll) v += shH[k * 64 + ll * 8 + sa];
+      bv.hcontrib[(size_t)slot * 27 + k] = v;
+    }
+  }
+}
+
+// k_lin_aux: the edges k_lin_items does not cover for the landmark side -- fixed-keyframe edges and the
+// optimisable observers beyond a landmark's first 8 (their Hpl / Hpp part is done by the item of
+// their own part): residual, Huber weight, d err / d point; Hll += J^T W J, b_l += ..., chi2.
+// One lane per edge, edges sorted by landmark, a landmark never straddles two wavefronts (a chunk
+// longer than 64 edges holds a single landmark); the first lane of each landmark sums its run in
+// lane order and is the only writer of that landmark.  Runs after k_lin_items.
+__global__ __launch_bounds__(64) void k_lin_aux(BatchView bv) {
+  __shared__ double shv[9 * 64];
+  __shared__ int shl[64];
+  const int4 ch = bv.aux_chunks[blockIdx.x];   // {window, first entry, entries, 0}
+  const WinDesc wd = bv.win[ch.x];   // by value: the fields stay in SGPRs across the kernel's stores
+  const LmView st = lm_view(bv.lm, ch.x);
+  if (!st.active || !st.need_lin) return;
+  const int lane = threadIdx.x;
+  const double* poses = bv.pose_state[st.sel] + (size_t)wd.pose_off * 7;
+  const double* pts = bv.pt_state[st.sel] + (size_t)wd.pt_off * 3;
+  const double* cams = bv.pose_cam + (size_t)wd.pose_off * 5;
+  double hl[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) hl[k] = 0.0;
+  double chi_acc = 0.0;
+  int my_lm = -1;
+  for (int x = lane; x < ch.z; x += 64) {
+    const int2 en = bv.aux_entries[(size_t)ch.y + x];   // {landmark, sorted edge}
+    my_lm = en.x;
+    const size_t ge = (size_t)wd.edge_off + en.y;
+    const int ip = bv.e_pose[ge];
+    const int kind = bv.e_kind[ge];
+    const double info = bv.e_info[ge];
+    double qt[7], cam[5], X[3], obs[3], r[3], Xc[3];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) qt[k] = poses[(size_t)ip * 7 + k];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) cam[k] = cams[(size_t)ip * 5 + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { X[k] = pts[(size_t)en.x * 3 + k]; obs[k] = bv.e_obs[ge * 3 + k]; }
+    const double chi2 = dev::edge_residual(kind, qt, cam, X, obs, info, r, Xc);
+    double rho0, rho1;
+    dev::huber(chi2, kind == OSH_EDGE_MONO ? wd.huber_mono : wd.huber_stereo, rho0, rho1);
+    chi_acc += rho0;
+    double JX[9], Jp[18], R[9];
+    dev::quat_to_R(qt, R);
+    dev::edge_jacobians(kind, R, cam, Xc, JX, Jp);
+    const double ww = rho1 * info;
+    const double wr[3] = {-(info * r[0]) * rho1, -(info * r[1]) * rho1, -(info * r[2]) * rho1};
+    double AtW[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) AtW[i * 3 + k] = JX[k * 3 + i] * ww;
+    hl[0] += AtW[0] * JX[0] + AtW[1] * JX[3] + AtW[2] * JX[6];
+    hl[1] += AtW[0] * JX[1] + AtW[1] * JX[4] + AtW[2] * JX[7];
+    hl[2] += AtW[0] * JX[2] + AtW[1] * JX[5] + AtW[2] * JX[8];
+    hl[3] += AtW[3] * JX[1] + AtW[4] * JX[4] + AtW[5] * JX[7];
+    hl[4] += AtW[3] * JX[2] + AtW[4] * JX[5] + AtW[5] * JX[8];
+    hl[5] += AtW[6] * JX[2] + AtW[7] * JX[5] + AtW[8] * JX[8];
+    hl[6] += JX[0] * wr[0] + JX[3] * wr[1] + JX[6] * wr[2];
+    hl[7] += JX[1] * wr[0] + JX[4] * wr[1] + JX[7] * wr[2];
+    hl[8] += JX[2] * wr[0] + JX[5] * wr[1] + JX[8] * wr[2];
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) shv[k * 64 + lane] = hl[k];
+  shl[lane] = my_lm;
+  __syncthreads();
+  double dmax = 0.0;
+  if (my_lm >= 0 && (lane == 0 || shl[lane - 1] != my_lm)) {
+    for (int y = lane + 1; y < 64 && shl[y] == my_lm; ++y) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) hl[k] += shv[k * 64 + y];
+    }
+    const size_t gl = (size_t)wd.pt_off + my_lm;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { hl[k] += bv.Hll[gl * 6 + k]; bv.Hll[gl * 6 + k] = hl[k]; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) bv.bl[gl * 3 + k] += hl[6 + k];
+    dmax = fmax(fabs(hl[0]), fmax(fabs(hl[3]), fabs(hl[5])));
+  }
+  chi_acc = dev::wave_sum(chi_acc);
+  dmax = dev::wave_max(dmax);
+  if (lane == 0) { bv.chi_aux[blockIdx.x] = chi_acc; bv.dmax_aux[blockIdx.x] = dmax; }
+}
+
+// k_pose_reduce: Hpp_i (full symmetric 6x6), b_p(i) and the largest diagonal entry of pose i from
+// the item contributions, in plan order.  One thread per optimisable pose.
+__global__ __launch_bounds__(64) void k_pose_reduce(BatchView bv) {
+  const int gp = blockIdx.x * 64 + threadIdx.x;
+  if (gp >= bv.n_fposes) return;
+  const int w = bv.fpose_win[gp];
+  const LmView st = lm_view(bv.lm, w);
+  if (!st.active || !st.need_lin) return;
+  const int2 rg = bv.pose_crange[gp];
+  double a[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) a[k] = 0.0;
+  for (int c = 0; c < rg.y; ++c) {
+    const double* src = bv.hcontrib + (size_t)(rg.x + c) * 27;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) a[k] += src[k];
+  }
+  double* Ho = bv.Hpp + (size_t)gp * 36;
+  int m = 0;
+  double dm = 0.0;
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = r; c < 6; ++c) {
+      Ho[r * 6 + c] = a[m];
+      Ho[c * 6 + r] = a[m];
+      if (r == c) dm = fmax(dm, fabs(a[m]));
+      ++m;
+    }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) bv.bp[(size_t)gp * 6 + k] = a[21 + k];
+  bv.dmax_pose[gp] = dm;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -570,7 +745,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(BatchView bv, int W) {
 
 // --------------------------------------------------------------------------------------------
 // k_backsub: x_l = Dinv (b_l - Hpl^T x_p), X_trial = X + x_l, landmark part of computeScale.
-// Same chunking as k_linearize: lane per edge for the Hpl^T x_p products, lane per landmark
+// Same chunking as k_residual: lane per edge for the Hpl^T x_p products, lane per landmark
 // for the ordered sum.
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_backsub(BatchView bv) {
@@ -579,8 +754,8 @@ __global__ __launch_bounds__(kBlock) void k_backsub(BatchView bv) {
   double* sh4 = sh_bs + 3 * kChunkEdges;
   double* sh_dyn = sh4 + 4;
   const Chunk ch = bv.chunks[blockIdx.x];
-  const WinDesc& wd = bv.win[ch.win];
-  const LmState& st = bv.lm[ch.win];
+  const WinDesc wd = bv.win[ch.win];   // by value: the fields stay in SGPRs across the kernel's stores
+  const LmView st = lm_view(bv.lm, ch.win);
   if (!st.active) return;
   const int tid = threadIdx.x;
   const int n = wd.n;
@@ -654,15 +829,21 @@ __global__ __launch_bounds__(64) void k_control(BatchView bv, int phase) {
   LmState& st = bv.lm[w];
   const int lane = threadIdx.x;
   if (!st.active) return;
-  // robust chi2 of the state evaluated last = sum of the chunk partials (fixed order)
+  // robust chi2 of the state evaluated last = sum of the partials (fixed order): item partials after a
+  // linearisation, chunk partials after a trial residual
   double chi = 0.0;
-  for (int c = lane; c < wd.n_chunks; c += 64) chi += bv.chi_part[wd.chunk_off + c];
+  if (phase == 0) {
+    for (int c = lane; c < wd.n_sitems; c += 64) chi += bv.chi_item[wd.sitem_off + c];
+    for (int c = lane; c < wd.n_aux; c += 64) chi += bv.chi_aux[wd.aux_off + c];
+  }
+  else { for (int c = lane; c < wd.n_chunks; c += 64) chi += bv.chi_part[wd.chunk_off + c]; }
   chi = dev::wave_sum(chi);
   if (phase == 0) {
     if (!st.need_lin) return;
     double dm = 0.0;
     if (st.iter == 0) {
-      for (int c = lane; c < wd.n_chunks; c += 64) dm = fmax(dm, bv.dmax_part[wd.chunk_off + c]);
+      for (int c = lane; c < wd.n_sitems; c += 64) dm = fmax(dm, bv.dmax_item[wd.sitem_off + c]);
+      for (int c = lane; c < wd.n_aux; c += 64) dm = fmax(dm, bv.dmax_aux[wd.aux_off + c]);
       for (int p = lane; p < wd.P; p += 64) dm = fmax(dm, bv.dmax_pose[wd.fpose_off + p]);
       dm = dev::wave_max(dm);
     }
@@ -757,8 +938,8 @@ __global__ void k_set_stop(BatchView bv, const unsigned char* stop) {
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_finalize(BatchView bv) {
   const Chunk ch = bv.chunks[blockIdx.x];
-  const WinDesc& wd = bv.win[ch.win];
-  const LmState& st = bv.lm[ch.win];
+  const WinDesc wd = bv.win[ch.win];   // by value: the fields stay in SGPRs across the kernel's stores
+  const LmView st = lm_view(bv.lm, ch.win);
   const int* lmo = bv.lm_off + wd.lmoff_off;
   const int e0 = lmo[ch.lm0], e1 = lmo[ch.lm1];
   const bool evaluated = st.iterations > 0;
@@ -810,15 +991,15 @@ struct osh_lba_ctx {
   std::vector<const volatile unsigned char*> stop_ptr;
   bool any_stop = false;
   size_t NP = 0, NFP = 0, NL = 0, NE = 0, NEf = 0, n_chunks = 0;
-  size_t n_items = 0, n_sym = 0, n_rblk = 0, n_contrib = 0, n_ccontrib = 0;
+  size_t n_items = 0, n_sym = 0, n_rblk = 0, n_contrib = 0, n_ccontrib = 0, n_aux_chunks = 0;
   long long plan_tile_steps = 0, plan_pair_blocks = 0;
   size_t S_total = 0;
   int n_max = 0, solve_nb = 24, solve_W = 0;
   size_t solve_lds = 0, backsub_lds = 0;
   // device buffers
   DevBuf d_win, d_lm, d_chunks, d_fpose_win, d_pose_init, d_pose[2], d_pt_init, d_pt[2], d_cam;
-  DevBuf d_e_pose, d_e_point, d_e_kind, d_e_obs, d_e_info, d_e_orig, d_lm_off, d_lm_nfree, d_pel_off, d_pel_edge, d_sitems, d_srecs, d_spair, d_scslot, d_rblk, d_contrib, d_ccontrib, d_dinv;
-  DevBuf d_Hpl, d_Hll, d_bl, d_Hpp, d_bp, d_S, d_bs, d_xp, d_chi, d_scale, d_dmaxc, d_dmaxp, d_nactive, d_out_chi2, d_out_depth, d_stop;
+  DevBuf d_e_pose, d_e_point, d_e_kind, d_e_obs, d_e_info, d_e_orig, d_lm_off, d_lm_nfree, d_pel_off, d_pel_edge, d_sitems, d_srecs, d_spair, d_scslot, d_sposex, d_pose_crange, d_hcontrib, d_chi_item, d_dmax_item, d_aux_chunks, d_aux_entries, d_chi_aux, d_dmax_aux, d_rblk, d_contrib, d_ccontrib, d_dinv;
+  DevBuf d_Hpl, d_Hll, d_bl, d_Hpp, d_bp, d_S, d_bs, d_xp, d_chi, d_scale, d_dmaxp, d_nactive, d_out_chi2, d_out_depth, d_stop;
   int* h_nactive = nullptr;          // pinned
   unsigned char* h_stop = nullptr;   // pinned [n_windows]
   size_t h_stop_cap = 0;
@@ -862,9 +1043,9 @@ extern "C" void osh_lba_destroy(osh_lba_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DevBuf* bufs[] = {&c->d_win, &c->d_lm, &c->d_chunks, &c->d_fpose_win, &c->d_pose_init, &c->d_pose[0], &c->d_pose[1],
                     &c->d_pt_init, &c->d_pt[0], &c->d_pt[1], &c->d_cam, &c->d_e_pose, &c->d_e_point, &c->d_e_kind,
-                    &c->d_e_obs, &c->d_e_info, &c->d_e_orig, &c->d_lm_off, &c->d_lm_nfree, &c->d_pel_off, &c->d_pel_edge, &c->d_sitems, &c->d_srecs, &c->d_spair, &c->d_scslot, &c->d_rblk, &c->d_contrib, &c->d_ccontrib, &c->d_dinv,
+                    &c->d_e_obs, &c->d_e_info, &c->d_e_orig, &c->d_lm_off, &c->d_lm_nfree, &c->d_pel_off, &c->d_pel_edge, &c->d_sitems, &c->d_srecs, &c->d_spair, &c->d_scslot, &c->d_sposex, &c->d_pose_crange, &c->d_hcontrib, &c->d_chi_item, &c->d_dmax_item, &c->d_aux_chunks, &c->d_aux_entries, &c->d_chi_aux, &c->d_dmax_aux, &c->d_rblk, &c->d_contrib, &c->d_ccontrib, &c->d_dinv,
                     &c->d_Hpl, &c->d_Hll, &c->d_bl, &c->d_Hpp, &c->d_bp, &c->d_S, &c->d_bs, &c->d_xp, &c->d_chi,
-                    &c->d_scale, &c->d_dmaxc, &c->d_dmaxp, &c->d_nactive, &c->d_out_chi2, &c->d_out_depth, &c->d_stop};
+                    &c->d_scale, &c->d_dmaxp, &c->d_nactive, &c->d_out_chi2, &c->d_out_depth, &c->d_stop};
   for (DevBuf* b : bufs) b->release();
   c->timer.destroy();
   if (c->h_nactive) (void)hipHostFree(c->h_nactive);
@@ -933,6 +1114,8 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   std::vector<unsigned char> h_kind(NE);
   std::vector<Chunk> h_chunks;
   SchurPlan plan;
+  std::vector<int4> h_aux_chunks;
+  std::vector<int2> h_aux_entries;
   std::vector<plan_detail::Build> builds;
   std::vector<int> build_win;
   std::vector<int> cnt, fill, order;
@@ -1002,6 +1185,23 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
       build_win.resize(builds.size(), w);
       (void)b0;
     }
+    // k_lin_aux work list: per landmark the edges beyond its first 8 optimisable observers (fixed keyframes included)
+    {
+      d.aux_off = (int)h_aux_chunks.size();
+      int first = (int)h_aux_entries.size(), n = 0;
+      auto close = [&]() { if (n > 0) h_aux_chunks.push_back(make_int4(w, first, n, 0)); first = (int)h_aux_entries.size(); n = 0; };
+      for (int j = 0; j < p.n_points; ++j) {
+        const int n0 = std::min(h_lmnfree[(size_t)d.pt_off + j], kItemPoses);
+        const int cnt_j = (lmo[j + 1] - lmo[j]) - n0;
+        if (cnt_j <= 0) continue;
+        if (n + cnt_j > 64) close();
+        for (int x = lmo[j] + n0; x < lmo[j + 1]; ++x) h_aux_entries.push_back(make_int2(j, x));
+        n += cnt_j;
+        if (n >= 64) close();
+      }
+      close();
+      d.n_aux = (int)h_aux_chunks.size() - d.aux_off;
+    }
     // chunks: consecutive landmarks, <= kChunkEdges edges and <= kBlock landmarks (a single
     // landmark with more edges gets its own multi-pass chunk)
     d.chunk_off = (int)h_chunks.size();
@@ -1017,6 +1217,15 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   c->n_chunks = h_chunks.size();
   finish_plan(build_win, builds, plan);
   if (plan.n_contrib > 0x7fffff00u / 36 * 16 || plan.recs.size() > 0x7fffff00u) { set_error("batch too large for 32-bit contribution offsets"); return OSH_ERR_UNSUPPORTED; }
+  for (WinDesc& d : c->h_win) { d.sitem_off = 0; d.n_sitems = 0; }
+  for (int x = 0; x < plan.n_sym; ++x) {
+    WinDesc& d = c->h_win[plan.items[x].win];
+    if (d.n_sitems == 0) d.sitem_off = x;
+    d.n_sitems++;
+  }
+  std::vector<int2> h_crange;
+  h_crange.reserve(NFP);
+  for (const RBlk& rb : plan.rblk) if (((rb.ij >> 16) & 0xffff) == 0xffff) h_crange.push_back(make_int2(rb.start, rb.count));
   c->n_items = plan.items.size(); c->n_sym = (size_t)plan.n_sym; c->n_rblk = plan.rblk.size();
   c->n_contrib = plan.n_contrib; c->n_ccontrib = plan.n_ccontrib;
   c->plan_tile_steps = plan.tile_steps; c->plan_pair_blocks = plan.pair_blocks;
@@ -1061,14 +1270,21 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   OSH_TRY(upload_vec(c->d_spair, plan.pair_slot, s));
   OSH_TRY(upload_vec(c->d_scslot, plan.c_slot, s));
   OSH_TRY(upload_vec(c->d_rblk, plan.rblk, s));
+  OSH_TRY(upload_vec(c->d_sposex, plan.pose_x, s));
+  OSH_TRY(upload_vec(c->d_aux_chunks, h_aux_chunks, s));
+  OSH_TRY(upload_vec(c->d_aux_entries, h_aux_entries, s));
+  c->n_aux_chunks = h_aux_chunks.size();
+  OSH_TRY(upload_vec(c->d_pose_crange, h_crange, s));
   auto R = [&](DevBuf& b, size_t bytes) { return b.reserve(std::max<size_t>(bytes, 8)); };
   OSH_TRY(R(c->d_lm, nw * sizeof(LmState)));
   for (int k = 0; k < 2; ++k) { OSH_TRY(R(c->d_pose[k], NP * 7 * 8)); OSH_TRY(R(c->d_pt[k], NL * 3 * 8)); }
   OSH_TRY(R(c->d_dinv, NL * 9 * 8)); OSH_TRY(R(c->d_contrib, plan.n_contrib * 36 * 8)); OSH_TRY(R(c->d_ccontrib, plan.n_ccontrib * 6 * 8));
+  OSH_TRY(R(c->d_hcontrib, plan.n_ccontrib * 27 * 8)); OSH_TRY(R(c->d_chi_item, (size_t)plan.n_sym * 8)); OSH_TRY(R(c->d_dmax_item, (size_t)plan.n_sym * 8));
+  OSH_TRY(R(c->d_chi_aux, h_aux_chunks.size() * 8)); OSH_TRY(R(c->d_dmax_aux, h_aux_chunks.size() * 8));
   OSH_TRY(R(c->d_Hpl, NE * 18 * 8)); OSH_TRY(R(c->d_Hll, NL * 6 * 8)); OSH_TRY(R(c->d_bl, NL * 3 * 8));
   OSH_TRY(R(c->d_Hpp, NFP * 36 * 8)); OSH_TRY(R(c->d_bp, NFP * 6 * 8)); OSH_TRY(R(c->d_S, S_total * 8));
   OSH_TRY(R(c->d_bs, NFP * 6 * 8)); OSH_TRY(R(c->d_xp, NFP * 6 * 8));
-  OSH_TRY(R(c->d_chi, c->n_chunks * 8)); OSH_TRY(R(c->d_scale, c->n_chunks * 8)); OSH_TRY(R(c->d_dmaxc, c->n_chunks * 8));
+  OSH_TRY(R(c->d_chi, c->n_chunks * 8)); OSH_TRY(R(c->d_scale, c->n_chunks * 8));
   OSH_TRY(R(c->d_dmaxp, NFP * 8)); OSH_TRY(R(c->d_nactive, sizeof(int)));
   OSH_TRY(R(c->d_out_chi2, NE * 8)); OSH_TRY(R(c->d_out_depth, NE)); OSH_TRY(R(c->d_stop, nw));
   if (c->h_stop_cap < (size_t)nw) {
@@ -1092,12 +1308,16 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   bv.sitems = c->d_sitems.as<SItem>(); bv.srecs = c->d_srecs.as<SRec>(); bv.spair = c->d_spair.as<int>(); bv.scslot = c->d_scslot.as<int>();
   bv.rblk = c->d_rblk.as<RBlk>(); bv.n_rblk = (int)c->n_rblk;
   bv.contrib = c->d_contrib.as<double>(); bv.ccontrib = c->d_ccontrib.as<double>();
+  bv.sposex = c->d_sposex.as<int>(); bv.pose_crange = c->d_pose_crange.as<int2>(); bv.hcontrib = c->d_hcontrib.as<double>();
+  bv.chi_item = c->d_chi_item.as<double>(); bv.dmax_item = c->d_dmax_item.as<double>();
+  bv.aux_chunks = c->d_aux_chunks.as<int4>(); bv.aux_entries = c->d_aux_entries.as<int2>();
+  bv.chi_aux = c->d_chi_aux.as<double>(); bv.dmax_aux = c->d_dmax_aux.as<double>();
   bv.dinv = c->d_dinv.as<double>();
   bv.Hpl = c->d_Hpl.as<double>(); bv.Hll = c->d_Hll.as<double>(); bv.bl = c->d_bl.as<double>();
   bv.Hpp = c->d_Hpp.as<double>(); bv.bp = c->d_bp.as<double>(); bv.S = c->d_S.as<double>();
   bv.bs = c->d_bs.as<double>(); bv.xp = c->d_xp.as<double>();
   bv.chi_part = c->d_chi.as<double>(); bv.scale_part = c->d_scale.as<double>();
-  bv.dmax_part = c->d_dmaxc.as<double>(); bv.dmax_pose = c->d_dmaxp.as<double>();
+  bv.dmax_pose = c->d_dmaxp.as<double>();
   bv.n_active = c->d_nactive.as<int>();
   bv.out_chi2 = c->d_out_chi2.as<double>(); bv.out_depth = c->d_out_depth.as<unsigned char>();
   OSH_HIP(hipStreamSynchronize(s));
@@ -1171,8 +1391,9 @@ extern "C" int osh_lba_optimize(osh_lba_ctx* c) {
   for (const WinDesc& d : c->h_win) max_iter = std::max(max_iter, d.max_iter);
   const long max_rounds = (long)max_iter * kMaxTrials + 1;
   for (long round = 0; round < max_rounds && n_active > 0; ++round) {
-    LAUNCH(OSH_K_LINEARIZE, k_linearize, c->n_chunks, kBlock, 0, c->bv, 0);
-    LAUNCH(OSH_K_POSE_HESS, k_pose_hess, c->NFP, 64, 0, c->bv);
+    LAUNCH(OSH_K_LINEARIZE, k_lin_items, c->n_sym, 64, 0, c->bv);
+    LAUNCH(OSH_K_LIN_AUX, k_lin_aux, c->n_aux_chunks, 64, 0, c->bv);
+    LAUNCH(OSH_K_POSE_HESS, k_pose_reduce, (c->NFP + 63) / 64, 64, 0, c->bv);
     LAUNCH(OSH_K_CONTROL, k_control, c->n_windows, 64, 0, c->bv, 0);
     LAUNCH(OSH_K_SCHUR, k_schur_items<true>, c->n_sym, 64, 0, c->bv, 0);
     LAUNCH(OSH_K_SCHUR_CROSS, k_schur_items<false>, c->n_items - c->n_sym, 64, 0, c->bv, (int)c->n_sym);
@@ -1181,7 +1402,7 @@ extern "C" int osh_lba_optimize(osh_lba_ctx* c) {
     else if (c->solve_nb == 12) LAUNCH(OSH_K_SOLVE, k_solve<12>, c->n_windows, kSolveThreads, c->solve_lds, c->bv, c->solve_W);
     else LAUNCH(OSH_K_SOLVE, k_solve<6>, c->n_windows, kSolveThreads, c->solve_lds, c->bv, c->solve_W);
     LAUNCH(OSH_K_BACKSUB, k_backsub, c->n_chunks, kBlock, c->backsub_lds, c->bv);
-    LAUNCH(OSH_K_RESIDUAL, k_linearize, c->n_chunks, kBlock, 0, c->bv, 1);
+    LAUNCH(OSH_K_RESIDUAL, k_residual, c->n_chunks, kBlock, 0, c->bv);
     if (c->any_stop) {
       // terminate() is polled after every trial (levenberg.cpp:149) and before every iteration
       snapshot_stop(c);
@@ -1242,9 +1463,9 @@ extern "C" int osh_lba_linearize(osh_lba_ctx* c, int32_t window, double* Hpp, do
   OSH_HIP(hipSetDevice(c->device));
   hipStream_t s = c->stream;
   OSH_TRY(reset_state(c));
-  hipLaunchKernelGGL(k_linearize, dim3((unsigned)c->n_chunks), dim3(kBlock), 0, s, c->bv, 0);
-  OSH_TRY(launch_check("k_linearize"));
-  if (c->NFP) { hipLaunchKernelGGL(k_pose_hess, dim3((unsigned)c->NFP), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_pose_hess")); }
+  if (c->n_sym) { hipLaunchKernelGGL(k_lin_items, dim3((unsigned)c->n_sym), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_lin_items")); }
+  if (c->n_aux_chunks) { hipLaunchKernelGGL(k_lin_aux, dim3((unsigned)c->n_aux_chunks), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_lin_aux")); }
+  if (c->NFP) { hipLaunchKernelGGL(k_pose_reduce, dim3((unsigned)((c->NFP + 63) / 64)), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_pose_reduce")); }
   hipLaunchKernelGGL(k_control, dim3((unsigned)c->n_windows), dim3(64), 0, s, c->bv, 0);
   OSH_TRY(launch_check("k_control"));
   // per-edge chi2 through k_finalize needs "evaluated" semantics: emulate by a residual pass bookkeeping
@@ -1290,9 +1511,9 @@ extern "C" int osh_lba_debug_trial(osh_lba_ctx* c, int32_t window, double lambda
   OSH_HIP(hipSetDevice(c->device));
   hipStream_t s = c->stream;
   OSH_TRY(reset_state(c));
-  hipLaunchKernelGGL(k_linearize, dim3((unsigned)c->n_chunks), dim3(kBlock), 0, s, c->bv, 0);
-  OSH_TRY(launch_check("k_linearize"));
-  if (c->NFP) { hipLaunchKernelGGL(k_pose_hess, dim3((unsigned)c->NFP), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_pose_hess")); }
+  if (c->n_sym) { hipLaunchKernelGGL(k_lin_items, dim3((unsigned)c->n_sym), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_lin_items")); }
+  if (c->n_aux_chunks) { hipLaunchKernelGGL(k_lin_aux, dim3((unsigned)c->n_aux_chunks), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_lin_aux")); }
+  if (c->NFP) { hipLaunchKernelGGL(k_pose_reduce, dim3((unsigned)((c->NFP + 63) / 64)), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_pose_reduce")); }
   hipLaunchKernelGGL(k_control, dim3((unsigned)c->n_windows), dim3(64), 0, s, c->bv, 0);
   OSH_TRY(launch_check("k_control"));
   OSH_HIP(hipStreamSynchronize(s));
@@ -1344,6 +1565,6 @@ extern "C" int osh_lba_get_profile(osh_lba_ctx* c, int64_t launches[OSH_K_COUNT]
 }
 
 extern "C" const char* osh_lba_kernel_name(int k) {
-  static const char* names[OSH_K_COUNT] = {"k_linearize", "k_pose_hess", "k_schur", "k_solve", "k_backsub", "k_linearize(residual)", "k_control", "k_schur_reduce", "k_schur_items(cross)"};
+  static const char* names[OSH_K_COUNT] = {"k_lin_items", "k_pose_reduce", "k_schur_items", "k_solve", "k_backsub", "k_residual", "k_control", "k_schur_reduce", "k_schur_items(cross)", "k_lin_aux"};
   return (k >= 0 && k < OSH_K_COUNT) ? names[k] : "?";
 }

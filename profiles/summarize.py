@@ -26,15 +26,14 @@ if rows:
     d["Kernel_Name"] = d["Kernel_Name"].str.replace(r"\(.*", "", regex=True).str.replace("osh::", "")
     piv = d.pivot_table(index="Counter_Name", columns="Kernel_Name", values="Counter_Value")
     piv.to_csv(dst / f"{tag}_pmc_summary.csv", float_format="%.6g")
-    names = {"k_schur": "schur", "k_solve": "solve", "k_bdinv": "dinv", "k_pose_hess": "pose_hess", "k_backsub": "backsub"}
+    names = {"k_lin_items": "linearize", "k_pose_reduce": "pose_hess", "void k_schur_items<true>": "schur",
+             "void k_schur_items<false>": "schur_cross", "k_schur_reduce": "schur_reduce", "void k_solve<24>": "solve",
+             "k_backsub": "backsub", "k_residual": "residual"}
     traffic = {}
     for k, short in names.items():
         if k in piv.columns and "FETCH_SIZE" in piv.index and "WRITE_SIZE" in piv.index:
             # rocprofv3 reports KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B -> double it
             traffic[short] = float((2.0 * piv.loc["FETCH_SIZE", k] + piv.loc["WRITE_SIZE", k]) * 1024.0)
-    # k_linearize runs in two modes (linearise / residual) under one name: keep the mean of both as 'linearize_mean'
-    if "k_linearize" in piv.columns and "FETCH_SIZE" in piv.index:
-        traffic["linearize_mean"] = float((2.0 * piv.loc["FETCH_SIZE", "k_linearize"] + piv.loc["WRITE_SIZE", "k_linearize"]) * 1024.0)
     (dst / "traffic.json").write_text(json.dumps({"tag": tag, "windows_per_gpu": win, "bytes_per_launch": traffic,
                                                   "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; "
                                                             "bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB (gfx950 FETCH_SIZE halving, MI355X_MICROARCH.md HBM section)"},
