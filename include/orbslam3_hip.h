@@ -159,7 +159,8 @@ int osh_lba_debug_trial(osh_lba_ctx* ctx, int32_t window, double lambda, double*
 #define OSH_K_SCHUR_REDUCE 7  /* S = Hpp + lambda I - sum of the group products, reduced rhs */
 #define OSH_K_SCHUR_CROSS 8   /* Schur products, items of landmarks with > 8 optimisable observers */
 #define OSH_K_LIN_AUX     9   /* landmark side of the edges beyond a landmark's first 8 optimisable observers */
-#define OSH_K_COUNT       10
+#define OSH_K_LIN_POSE    10  /* pose side of the linearisation: Hpp / b_p partials per landmark group */
+#define OSH_K_COUNT       11
 int osh_lba_set_profiling(osh_lba_ctx* ctx, int enable);
 /* launches[k], total_ms[k] accumulated since profiling was (re)enabled */
 int osh_lba_get_profile(osh_lba_ctx* ctx, int64_t launches[OSH_K_COUNT], double total_ms[OSH_K_COUNT]);

@@ -24,8 +24,8 @@ OSH_ERR_NO_DEVICE = -4
 OSH_EDGE_MONO = 0
 OSH_EDGE_STEREO = 1
 OSH_LBA_MAX_TRACE = 128
-OSH_K_COUNT = 10
-KERNEL_NAMES = ["linearize", "pose_hess", "schur", "solve", "backsub", "residual", "control", "schur_reduce", "schur_cross", "lin_aux"]
+OSH_K_COUNT = 11
+KERNEL_NAMES = ["linearize", "pose_hess", "schur", "solve", "backsub", "residual", "control", "schur_reduce", "schur_cross", "lin_aux", "lin_pose"]
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
@@ -188,7 +188,8 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = Path(path) if path else LIB_PATH
+    # ORBSLAM3_HIP_LIB: developer aid for A/B runs of an alternative build of the same library
+    p = Path(path) if path else Path(os.environ.get("ORBSLAM3_HIP_LIB", LIB_PATH))
     if not p.exists():
         raise RuntimeError(
             f"{p} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "

