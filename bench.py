@@ -43,18 +43,24 @@ def generate_windows(seeds, workers=8):
         return pool.map(_make_cfg2, seeds)
 
 
+# Steps of the reference loop -> the device kernels that implement them (names of capi.KERNEL_NAMES).
+STEP_KERNELS = {
+    "linearize": ["linearize", "lin_pose", "lin_aux", "pose_hess"],   # k_lin_items<0>, <1>, k_lin_aux, k_pose_reduce
+    "schur": ["schur", "schur_cross", "schur_reduce"],                # k_schur_items<true>, <false>, k_schur_reduce
+    "solve": ["solve"], "backsub": ["backsub"], "residual": ["residual"],
+}
+
+
 def kernel_algorithmic_bytes(windows, results):
-    """Algorithmic bytes each kernel moved over one optimize(), per SURVEY.md 8(d):
-    per-window byte formulas x the number of times the reference loop runs for that window
-    (linearise: once per iteration; Schur / back-substitution / trial residual: once per LM trial)."""
-    tot = dict(linearize=0, pose_hess=0, schur=0, solve=0, backsub=0, residual=0)
+    """Algorithmic bytes each step of the loop moved over one optimize(), per SURVEY.md 8(d):
+    per-window byte formulas x the number of times the reference loop runs that step for the window
+    (linearise: once per iteration; Schur / solve / back-substitution / trial residual: once per LM trial)."""
+    tot = dict(linearize=0, schur=0, solve=0, backsub=0, residual=0)
     for w, r in zip(windows, results):
         b = w.algorithmic_bytes()
-        P, Ef = w.n_free, w.n_free_edges
+        P = w.n_free
         it, tr = int(r.iterations), int(r.trials)
-        d_free = int(np.where(w.edge_kind[w.edge_pose < P] == 0, 2, 3).sum())
-        tot["linearize"] += it * (b["lin"] - P * 216)                     # edges+points+poses in, Hpl/Hll/b_l out
-        tot["pose_hess"] += it * (8 * d_free + 16 * Ef + Ef * 24 + P * (56 + 216))
+        tot["linearize"] += it * b["lin"]                                  # edges+points+poses in, Hpl/Hll/b_l/Hpp/b_p out
         tot["schur"] += tr * b["schur"]
         tot["solve"] += tr * ((6 * P) * (6 * P + 1) * 8 + 2 * 6 * P * 8 + 2 * P * 56)
         tot["backsub"] += tr * (b["back"] + 2 * w.n_points * 24)
@@ -82,8 +88,8 @@ def make_lba_inputs(args, rank, world):
     return windows
 
 
-def measured_traffic(kernel, windows_per_gpu):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/traffic.json:
+def measured_traffic(step, windows_per_gpu):
+    """HBM bytes per round of the kernels of `step` from the committed rocprofv3 PMC summary (profiles/traffic.json:
     FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, separate --pmc passes), or None."""
     f = ROOT / "profiles" / "traffic.json"
     if not f.exists():
@@ -91,7 +97,10 @@ def measured_traffic(kernel, windows_per_gpu):
     t = json.loads(f.read_text())
     if t.get("windows_per_gpu") != windows_per_gpu:
         return None
-    return t.get("bytes_per_launch", {}).get(kernel)
+    per = t.get("bytes_per_launch", {})
+    if any(k not in per for k in STEP_KERNELS[step]):
+        return None
+    return float(sum(per[k] for k in STEP_KERNELS[step]))
 
 
 def run_lba(args, info, windows):
@@ -274,18 +283,24 @@ def main():
     ms_per_step = lba_out["elapsed"] / args.steps * 1e3
     value = args.windows * n_gpus / (ms_per_step * 1e-3)
 
-    # roofline of the dominant kernel (largest total HIP-event time in one optimize())
+    # roofline of the dominant step of the loop (largest total HIP-event time in one optimize()); a step is one or
+    # more kernels (STEP_KERNELS), its launch time the sum of theirs, its algorithmic bytes SURVEY.md 8(d)'s figure
+    from orb_slam3_study_kr_amd import lba
     prof, alg = lba_out["prof"], lba_out["alg"]
-    dom = max((k for k in alg), key=lambda k: prof[k][1])
-    launches, total_ms = prof[dom]
+    step_ms = {st: sum(prof[k][1] for k in ks) for st, ks in STEP_KERNELS.items()}
+    dom = max(step_ms, key=step_ms.get)
+    launches = prof[STEP_KERNELS[dom][0]][0]
+    total_ms = step_ms[dom]
     avg_ms = total_ms / max(launches, 1)
     achieved = (alg[dom] / max(launches, 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+    roofline = dict(bound="hbm", kernel=dom + " = " + " + ".join(lba.kernel_symbol(k) for k in STEP_KERNELS[dom]),
+                    achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=achieved / HBM_PEAK_GBS, traffic=measured_traffic(dom, args.windows),
-                    avg_launch_ms=avg_ms, launches=launches, algorithmic_bytes_per_launch=alg[dom] / max(launches, 1))
-    kernels = {k: dict(launches=prof[k][0], total_ms=round(prof[k][1], 4),
-                       alg_GBps=(alg[k] / (prof[k][1] * 1e-3) / 1e9) if (k in alg and prof[k][1] > 0) else None)
-               for k in prof}
+                    avg_launch_ms=avg_ms, launches=launches, algorithmic_bytes_per_launch=alg[dom] / max(launches, 1),
+                    avg_ms_by_kernel={lba.kernel_symbol(k): prof[k][1] / max(prof[k][0], 1) for k in STEP_KERNELS[dom]})
+    kernels = {k: dict(launches=prof[k][0], total_ms=round(prof[k][1], 4)) for k in prof}
+    steps = {st: dict(total_ms=round(step_ms[st], 4), alg_GBps=(alg[st] / (step_ms[st] * 1e-3) / 1e9) if step_ms[st] > 0 else None)
+             for st in STEP_KERNELS}
     whole_bytes = sum(alg.values())
     res = lba_out["results"]
     out = {
@@ -299,7 +314,7 @@ def main():
                    "parallelism": f"independent windows, w mod {n_gpus}", "lm_iterations_mean": float(np.mean([r.iterations for r in res])),
                    "lm_trials_mean": float(np.mean([r.trials for r in res]))},
         "roofline": roofline,
-        "kernels": kernels,
+        "kernels": kernels, "steps": steps,
         "whole_job_alg_GBps_per_gpu": whole_bytes / (ms_per_step * 1e-3) / 1e9,
         "upload_s_per_batch": lba_out["upload_s"],
     }

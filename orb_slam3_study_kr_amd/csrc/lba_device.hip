@@ -1649,6 +1649,6 @@ extern "C" int osh_lba_get_profile(osh_lba_ctx* c, int64_t launches[OSH_K_COUNT]
 }
 
 extern "C" const char* osh_lba_kernel_name(int k) {
-  static const char* names[OSH_K_COUNT] = {"k_lin_items", "k_pose_reduce", "k_schur_items", "k_solve", "k_backsub", "k_residual", "k_control", "k_schur_reduce", "k_schur_items(cross)", "k_lin_aux", "k_lin_items(pose side)"};
+  static const char* names[OSH_K_COUNT] = {"k_lin_items<0>", "k_pose_reduce", "k_schur_items<true>", "k_solve", "k_backsub", "k_residual", "k_control", "k_schur_reduce", "k_schur_items<false>", "k_lin_aux", "k_lin_items<1>"};
   return (k >= 0 && k < OSH_K_COUNT) ? names[k] : "?";
 }

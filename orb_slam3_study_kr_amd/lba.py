@@ -102,8 +102,15 @@ class LbaSolver:
         capi.check(self.lib.osh_lba_set_profiling(self.ctx, int(enable)), "osh_lba_set_profiling", self.lib)
 
     def profile(self) -> dict:
+        """{short kernel name: (launches, total ms)} measured with HIP events on the solver's stream."""
         launches = np.zeros(capi.OSH_K_COUNT, dtype=np.int64)
         ms = np.zeros(capi.OSH_K_COUNT, dtype=np.float64)
         capi.check(self.lib.osh_lba_get_profile(self.ctx, capi.ptr(launches, capi.c_int64_p), capi.ptr(ms, capi.c_double_p)),
                    "osh_lba_get_profile", self.lib)
         return {capi.KERNEL_NAMES[k]: (int(launches[k]), float(ms[k])) for k in range(capi.OSH_K_COUNT)}
+
+
+def kernel_symbol(short_name: str) -> str:
+    """Device kernel name (as rocprofv3 prints it) behind a short name of ``capi.KERNEL_NAMES``."""
+    lib = capi.load_library()
+    return lib.osh_lba_kernel_name(capi.KERNEL_NAMES.index(short_name)).decode()

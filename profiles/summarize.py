@@ -26,9 +26,10 @@ if rows:
     d["Kernel_Name"] = d["Kernel_Name"].str.replace(r"\(.*", "", regex=True).str.replace("osh::", "")
     piv = d.pivot_table(index="Counter_Name", columns="Kernel_Name", values="Counter_Value")
     piv.to_csv(dst / f"{tag}_pmc_summary.csv", float_format="%.6g")
-    names = {"k_lin_items": "linearize", "k_pose_reduce": "pose_hess", "void k_schur_items<true>": "schur",
-             "void k_schur_items<false>": "schur_cross", "k_schur_reduce": "schur_reduce", "void k_solve<24>": "solve",
-             "k_backsub": "backsub", "k_residual": "residual"}
+    # rocprofv3 kernel name -> short name of capi.KERNEL_NAMES
+    names = {"void k_lin_items<0>": "linearize", "void k_lin_items<1>": "lin_pose", "k_lin_aux": "lin_aux", "k_pose_reduce": "pose_hess",
+             "void k_schur_items<true>": "schur", "void k_schur_items<false>": "schur_cross", "k_schur_reduce": "schur_reduce",
+             "void k_solve<24>": "solve", "void k_solve<12>": "solve", "void k_solve<6>": "solve", "k_backsub": "backsub", "k_residual": "residual"}
     traffic = {}
     for k, short in names.items():
         if k in piv.columns and "FETCH_SIZE" in piv.index and "WRITE_SIZE" in piv.index:
