@@ -28,6 +28,8 @@ class Frame {
   std::vector<bool> mvbOutlier;
   cv::Mat mDescriptors;
   std::vector<float> mvScaleFactors;
+  int mnScaleLevels = 0;
+  float mfLogScaleFactor = 0;   // log(mfScaleFactor), src/Frame.cc:75
   GeometricCamera* mpCamera = nullptr;
   std::vector<std::size_t> mGrid[FRAME_GRID_COLS][FRAME_GRID_ROWS];
   float mnMinX = 0, mnMaxX = 752, mnMinY = 0, mnMaxY = 480;   // static in the reference

@@ -8,6 +8,7 @@
 #include "orbslam3_compat.h"
 namespace ORB_SLAM3 {
 class KeyFrame;
+class Frame;
 class Map;
 class MapPoint {
  public:
@@ -22,6 +23,10 @@ class MapPoint {
   Map* GetMap() { return mpMap; }
   void UpdateNormalAndDepth() { ++mnNormalUpdates; }
   cv::Mat GetDescriptor() { return mDescriptor.clone(); }
+  // scale-invariance distances (src/MapPoint.cc:502-512) and predicted pyramid level (:531-546)
+  float GetMinDistanceInvariance() { return 0.8f * mfMinDistance; }
+  float GetMaxDistanceInvariance() { return 1.2f * mfMaxDistance; }
+  int PredictScale(const float& currentDist, Frame* pF);
 
   long unsigned int mnId;
   long unsigned int mnBALocalForKF = 0;
@@ -30,6 +35,7 @@ class MapPoint {
   bool mbTrackInView = false, mbTrackInViewR = false;
   int mnTrackScaleLevel = 0;
   float mTrackViewCos = 1.f;
+  float mfMinDistance = 0, mfMaxDistance = 0;
   // test-double state
   Eigen::Vector3f mWorldPos;
   std::map<KeyFrame*, std::tuple<int, int>> mObservations;

@@ -2,8 +2,10 @@
  * reference's signatures (include/ORBmatcher.h:36-102). */
 #ifndef ORBMATCHER_H
 #define ORBMATCHER_H
+#include <set>
 #include <vector>
 #include "Frame.h"
+#include "KeyFrame.h"
 #include "MapPoint.h"
 #include "orbslam3_compat.h"
 namespace ORB_SLAM3 {
@@ -18,6 +20,9 @@ class ORBmatcher {
                          const float thFarPoints = 50.0f);
   // src/ORBmatcher.cc:1676-1887 (TrackWithMotionModel)
   int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono);
+  // src/ORBmatcher.cc:1889-2010 (Relocalization): best candidate only, any occupied slot is skipped, accept <= ORBdist
+  int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, const float th,
+                         const int ORBdist);
   static const int TH_LOW;
   static const int TH_HIGH;
   static const int HISTO_LENGTH;

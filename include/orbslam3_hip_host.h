@@ -83,6 +83,14 @@ int osh_host_search_local_points(osh_host_frame* f, int32_t n_mp, const uint8_t*
 int osh_host_search_last_frame(osh_host_frame* cur, osh_host_frame* last, const int32_t* last_mp, int32_t n_mp,
                                const float* mp_pos, const uint8_t* mp_desc, float th, int32_t b_mono, int32_t check_ori,
                                int32_t* assignment);
+/* ORBmatcher(0.9, check_ori).SearchByProjection(Current, pKF, sAlreadyFound, th, ORBdist) (relocalisation,
+ * src/ORBmatcher.cc:1889-2010): the keyframe is given by its keypoint angles and kf_mp[k] = map point held by keypoint k
+ * (-1 none); map points by world position, descriptor, {mfMinDistance, mfMaxDistance}, membership of sAlreadyFound, isBad();
+ * cur_mp[k] = map point already held by keypoint k of the current frame (-1 none). */
+int osh_host_search_keyframe(osh_host_frame* cur, int32_t n_kf, const float* kf_angle, const int32_t* kf_mp, int32_t n_mp,
+                             const float* mp_pos, const uint8_t* mp_desc, const float* mp_min_max_dist,
+                             const uint8_t* mp_found, const uint8_t* mp_bad, const int32_t* cur_mp, float th,
+                             int32_t orb_dist, int32_t check_ori, int32_t* assignment);
 #ifdef __cplusplus
 }
 #endif

@@ -261,4 +261,86 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
   return nmatches;
 }
 
+// src/ORBmatcher.cc:1889-2010 (Tracking::Relocalization): the keyframe's map points are projected with the current
+// pose estimate; best candidate only; a slot holding ANY map point is skipped (:1952) -- also one filled earlier in this
+// call; accept bestDist <= ORBdist; rotation histogram with the keyframe keypoint's angle.
+int ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, const float th,
+                                   const int ORBdist) {
+  if (CurrentFrame.Nleft != -1) {
+    std::fprintf(stderr, "ORBmatcher::SearchByProjection: fisheye-stereo frames are not supported by the MI355X path yet\n");
+    std::abort();
+  }
+  const Sophus::SE3f Tcw = CurrentFrame.GetPose();
+  const Eigen::Vector3f Ow = Tcw.inverse().translation();
+  std::vector<int> rotHist[30];
+  for (int i = 0; i < HISTO_LENGTH; i++) rotHist[i].reserve(500);
+  const float factor = 1.0f / HISTO_LENGTH;
+  const std::vector<MapPoint*> vpMPs = pKF->GetMapPointMatches();
+
+  std::vector<int32_t> level(CurrentFrame.N);
+  std::vector<uint8_t> occupied(CurrentFrame.N, 0);
+  for (int i = 0; i < CurrentFrame.N; ++i) {
+    level[i] = CurrentFrame.mvKeysUn[i].octave;
+    occupied[i] = CurrentFrame.mvpMapPoints[i] ? 1 : 0;
+  }
+  Search s;
+  std::vector<int> qKF;  // keypoint index in pKF of every query
+  for (size_t i = 0, iend = vpMPs.size(); i < iend; i++) {
+    MapPoint* pMP = vpMPs[i];
+    if (!pMP || pMP->isBad() || sAlreadyFound.count(pMP)) continue;
+    const Eigen::Vector3f x3Dw = pMP->GetWorldPos();
+    const Eigen::Vector3f x3Dc = Tcw * x3Dw;
+    const Eigen::Vector2f uv = CurrentFrame.mpCamera->project(x3Dc);
+    if (uv(0) < CurrentFrame.mnMinX || uv(0) > CurrentFrame.mnMaxX) continue;
+    if (uv(1) < CurrentFrame.mnMinY || uv(1) > CurrentFrame.mnMaxY) continue;
+    // predicted scale level from the distance to the camera centre (:1922-1933)
+    const float px = x3Dw(0) - Ow(0), py = x3Dw(1) - Ow(1), pz = x3Dw(2) - Ow(2);
+    const float dist3D = std::sqrt(px * px + py * py + pz * pz);
+    const float maxDistance = pMP->GetMaxDistanceInvariance();
+    const float minDistance = pMP->GetMinDistanceInvariance();
+    if (dist3D < minDistance || dist3D > maxDistance) continue;
+    const int nPredictedLevel = pMP->PredictScale(dist3D, &CurrentFrame);
+    const float radius = th * CurrentFrame.mvScaleFactors[nPredictedLevel];
+    const std::vector<size_t> vIndices2 = CurrentFrame.GetFeaturesInArea(uv(0), uv(1), radius, nPredictedLevel - 1, nPredictedLevel + 1);
+    if (vIndices2.empty()) continue;
+    for (const size_t i2 : vIndices2) {
+      if (occupied[i2]) continue;
+      s.idx.push_back((int32_t)i2);
+    }
+    s.off.push_back((int32_t)s.idx.size());
+    const cv::Mat d = pMP->GetDescriptor();
+    const uint8_t* dp = d.ptr<uint8_t>(0);
+    s.qdesc.insert(s.qdesc.end(), dp, dp + 32);
+    qKF.push_back((int)i);
+  }
+  if (!device_search(s, CurrentFrame.mDescriptors, level)) return 0;
+
+  int nmatches = 0;
+  std::vector<uint8_t> taken(CurrentFrame.N, 0);
+  for (int q = 0; q < s.nq(); ++q) {
+    int bestIdx2 = s.best_idx[q], bestDist = s.best_dist[q], d2, l1, l2;
+    if (bestIdx2 >= 0 && taken[bestIdx2]) rescan(s, q, CurrentFrame.mDescriptors, level, taken, bestIdx2, bestDist, d2, l1, l2);
+    if (bestDist > ORBdist) continue;
+    CurrentFrame.mvpMapPoints[bestIdx2] = vpMPs[qKF[q]];
+    taken[bestIdx2] = 1;
+    nmatches++;
+    if (mbCheckOrientation) {
+      float rot = pKF->mvKeysUn[qKF[q]].angle - CurrentFrame.mvKeysUn[bestIdx2].angle;
+      if (rot < 0.0) rot += 360.0f;
+      int bin = (int)std::round(rot * factor);
+      if (bin == HISTO_LENGTH) bin = 0;
+      rotHist[bin].push_back(bestIdx2);
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (const int slot : rotHist[i]) { CurrentFrame.mvpMapPoints[slot] = nullptr; nmatches--; }
+    }
+  }
+  return nmatches;
+}
+
 }  // namespace ORB_SLAM3

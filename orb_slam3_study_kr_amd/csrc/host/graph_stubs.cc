@@ -30,6 +30,15 @@ void MapPoint::AddObservation(KeyFrame* pKF, int idx) {
 }
 
 // src/MapPoint.cc:168-201: drop the observation; a point left with <= 2 observations goes bad
+// src/MapPoint.cc:531-546 (float ratio, float log: `log(ratio)` resolves to the float overload there)
+int MapPoint::PredictScale(const float& currentDist, Frame* pF) {
+  const float ratio = mfMaxDistance / currentDist;
+  int nScale = (int)std::ceil(std::log(ratio) / pF->mfLogScaleFactor);
+  if (nScale < 0) nScale = 0;
+  else if (nScale >= pF->mnScaleLevels) nScale = pF->mnScaleLevels - 1;
+  return nScale;
+}
+
 void MapPoint::EraseObservation(KeyFrame* pKF) {
   auto it = mObservations.find(pKF);
   if (it == mObservations.end()) return;

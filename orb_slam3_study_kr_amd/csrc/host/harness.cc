@@ -1,6 +1,7 @@
 // harness.cc -- extern "C" wrappers around the C++ host layer (include/orbslam3_hip_host.h).
 #include <cmath>
 #include <memory>
+#include <set>
 #include <vector>
 
 #include "Frame.h"
@@ -226,6 +227,8 @@ extern "C" osh_host_frame* osh_host_frame_create(int32_t n, const float* kp_xy, 
   F.mTcw = pose_from(pose_qt);
   F.mvScaleFactors.assign(n_levels, 1.0f);
   for (int l = 1; l < n_levels; ++l) F.mvScaleFactors[l] = F.mvScaleFactors[l - 1] * scale_factor;  // src/ORBextractor.cc:414-422
+  F.mnScaleLevels = n_levels;
+  F.mfLogScaleFactor = std::log(scale_factor);   // src/Frame.cc:75 (float log of the float factor)
   F.mDescriptors = cv::Mat(n, 32);
   for (int i = 0; i < n; ++i) {
     cv::KeyPoint kp;
@@ -291,5 +294,35 @@ extern "C" int osh_host_search_last_frame(osh_host_frame* cur, osh_host_frame* l
   for (int k = 0; k < cur->F.N; ++k) assignment[k] = cur->F.mvpMapPoints[k] ? (int32_t)cur->F.mvpMapPoints[k]->mnId : -1;
   cur->F.mvpMapPoints.assign(cur->F.N, nullptr);
   last->F.mvpMapPoints.assign(last->F.N, nullptr);
+  return n;
+}
+
+// ORBmatcher(0.9, check_ori).SearchByProjection(Current, pKF, sAlreadyFound, th, ORBdist)
+extern "C" int osh_host_search_keyframe(osh_host_frame* cur, int32_t n_kf, const float* kf_angle, const int32_t* kf_mp, int32_t n_mp,
+                                        const float* mp_pos, const uint8_t* mp_desc, const float* mp_min_max_dist,
+                                        const uint8_t* mp_found, const uint8_t* mp_bad, const int32_t* cur_mp, float th,
+                                        int32_t orb_dist, int32_t check_ori, int32_t* assignment) {
+  if (!cur) return -1;
+  auto pts = make_points(&cur->map, n_mp, mp_desc, mp_pos, nullptr);
+  std::set<MapPoint*> found;
+  for (int j = 0; j < n_mp; ++j) {
+    pts[j]->mfMinDistance = mp_min_max_dist[2 * j]; pts[j]->mfMaxDistance = mp_min_max_dist[2 * j + 1];
+    if (mp_found && mp_found[j]) found.insert(pts[j].get());
+    if (mp_bad && mp_bad[j]) pts[j]->mbBad = true;
+  }
+  KeyFrame kf(1, &cur->map);
+  kf.N = n_kf;
+  kf.mvKeysUn.resize(n_kf);
+  kf.mvpMapPoints.assign(n_kf, nullptr);
+  for (int k = 0; k < n_kf; ++k) {
+    kf.mvKeysUn[k].angle = kf_angle ? kf_angle[k] : 0.f;
+    if (kf_mp[k] >= 0) kf.mvpMapPoints[k] = pts[kf_mp[k]].get();
+  }
+  Frame& F = cur->F;
+  for (int k = 0; k < F.N; ++k) F.mvpMapPoints[k] = (cur_mp && cur_mp[k] >= 0) ? pts[cur_mp[k]].get() : nullptr;
+  ORBmatcher matcher(0.9f, check_ori != 0);
+  const int n = matcher.SearchByProjection(F, &kf, found, th, orb_dist);
+  for (int k = 0; k < F.N; ++k) assignment[k] = F.mvpMapPoints[k] ? (int32_t)F.mvpMapPoints[k]->mnId : -1;
+  F.mvpMapPoints.assign(F.N, nullptr);
   return n;
 }

@@ -154,6 +154,22 @@ class HostFrame:
         return n, assign
 
 
+    def search_keyframe(self, kf_angle, kf_mp, mp_pos, mp_desc, mp_min_max_dist, mp_found=None, mp_bad=None, cur_mp=None,
+                        th=10.0, orb_dist=100, check_ori=True):
+        """ORBmatcher(0.9, check_ori).SearchByProjection(self, pKF, sAlreadyFound, th, ORBdist) (src/ORBmatcher.cc:1889-2010)."""
+        assign = -np.ones(self.n, dtype=np.int32)
+        u8 = lambda a: np.ascontiguousarray(a, dtype=np.uint8)
+        keep = [_f32(kf_angle), _i32(kf_mp), _f32(mp_pos), u8(mp_desc), _f32(mp_min_max_dist),
+                u8(mp_found if mp_found is not None else np.zeros(len(mp_pos))), u8(mp_bad if mp_bad is not None else np.zeros(len(mp_pos))),
+                _i32(cur_mp if cur_mp is not None else -np.ones(self.n))]
+        n = self.lib.osh_host_search_keyframe(self.f, len(kf_mp), capi.ptr(keep[0], capi.c_float_p), capi.ptr(keep[1], capi.c_int32_p),
+                                              len(mp_pos), capi.ptr(keep[2], capi.c_float_p), capi.ptr(keep[3], capi.c_uint8_p),
+                                              capi.ptr(keep[4], capi.c_float_p), capi.ptr(keep[5], capi.c_uint8_p),
+                                              capi.ptr(keep[6], capi.c_uint8_p), capi.ptr(keep[7], capi.c_int32_p), th, int(orb_dist),
+                                              int(check_ori), capi.ptr(assign, capi.c_int32_p))
+        return n, assign
+
+
 def _quat_from_R(R):
     return synth._quat_from_R(np.asarray(R, dtype=np.float64))
 

@@ -138,6 +138,74 @@ def test_search_by_projection_last_frame_equals_sequential_reference(ob):
     np.testing.assert_array_equal(assign, assign_ref)
 
 
+def test_search_by_projection_keyframe_relocalisation_equals_sequential_reference(ob):
+    """M4, src/ORBmatcher.cc:1889-2010: projection with the current pose, predicted level from the distance, any occupied slot
+    skipped, accept <= ORBdist, rotation histogram; bad / already-found map points and out-of-range distances are dropped."""
+    rng = np.random.Generator(np.random.PCG64(9))
+    n_kp = 700
+    xy, octave, desc, _, _, _, _ = _frame_and_points(12, n_kp=n_kp, n_mp=10)
+    angle = rng.uniform(0, 360, n_kp).astype(np.float32)
+    # current pose: small rotation about y + translation; map points on the viewing rays of the current keypoints
+    yaw = 0.05
+    Rcw = np.array([[np.cos(yaw), 0, np.sin(yaw)], [0, 1, 0], [-np.sin(yaw), 0, np.cos(yaw)]])
+    tcw = np.array([0.1, -0.05, 0.2])
+    pose_qt = np.concatenate([synth._quat_from_R(Rcw), tcw]).astype(np.float32)
+    depth = rng.uniform(4, 10, n_kp)
+    noisy = xy + rng.normal(0, 1.5, xy.shape)
+    Xc = np.stack([(noisy[:, 0] - float(synth.CX)) / float(synth.FX) * depth, (noisy[:, 1] - float(synth.CY)) / float(synth.FY) * depth, depth], axis=1)
+    pos = ((Xc - tcw) @ Rcw).astype(np.float32)          # Xw = Rcw^T (Xc - tcw)
+    mp_desc = desc ^ np.packbits(rng.uniform(0, 1, (n_kp, 256)) < 0.05, axis=1)
+    kf_angle = ((angle + rng.choice([0.0, 1.0, 95.0], n_kp, p=[0.6, 0.3, 0.1])) % 360).astype(np.float32)
+    # scale-invariance distances chosen so that the predicted level is the keypoint's octave (+-1), a few out of range
+    maxd = (depth * synth.SCALE_FACTORS[octave].astype(np.float64) * rng.uniform(0.9, 1.05, n_kp)).astype(np.float32)
+    mind = (maxd / np.float32(synth.SCALE_FACTORS[-1]) * np.float32(0.5)).astype(np.float32)
+    far = rng.uniform(0, 1, n_kp) < 0.03
+    maxd[far] = (depth[far] * 0.5).astype(np.float32)       # 1.2 * max < dist -> dropped
+    found = rng.uniform(0, 1, n_kp) < 0.05
+    bad = rng.uniform(0, 1, n_kp) < 0.03
+    kf_mp = np.arange(n_kp, dtype=np.int32)
+    kf_mp[rng.uniform(0, 1, n_kp) < 0.1] = -1
+    cur_mp = -np.ones(n_kp, dtype=np.int32)
+    held = rng.permutation(n_kp)[:60]
+    cur_mp[held] = held                                     # slots that already hold a map point
+    th, orb_dist = 10.0, 100
+    cur = host.HostFrame(xy, octave, desc, angle=angle, pose_qt=pose_qt)
+    try:
+        n, assign = cur.search_keyframe(kf_angle, kf_mp, pos, mp_desc, np.stack([mind, maxd], axis=1), found, bad, cur_mp,
+                                        th=th, orb_dist=orb_dist, check_ori=True)
+    finally:
+        cur.close()
+    # ---- reference pipeline in float32 (Sophus::SE3f * Vector3f, Pinhole::project)
+    from tests.helpers import quat_to_R
+    f32 = np.float32
+    q = pose_qt[:4] / np.linalg.norm(pose_qt[:4].astype(np.float64))
+    R32 = quat_to_R(q.astype(np.float64)).astype(f32)
+    t32 = pose_qt[4:].astype(f32)
+    x3Dc = (pos @ R32.T + t32).astype(f32)
+    u = (f32(synth.FX) * x3Dc[:, 0] / x3Dc[:, 2] + f32(synth.CX)).astype(f32)
+    v = (f32(synth.FY) * x3Dc[:, 1] / x3Dc[:, 2] + f32(synth.CY)).astype(f32)
+    Ow = (-(R32.T @ t32)).astype(f32)
+    dist3d = np.sqrt(((pos - Ow).astype(f32) ** 2).sum(axis=1, dtype=f32)).astype(f32)
+    ok = (kf_mp >= 0) & ~bad & ~found & (u >= 0) & (u <= synth.IMG_W) & (v >= 0) & (v <= synth.IMG_H)
+    ok &= ~((dist3d < f32(0.8) * mind) | (dist3d > f32(1.2) * maxd))
+    lvl = np.ceil(np.log((maxd / dist3d).astype(f32)) / np.log(f32(synth.SCALE_FACTOR))).astype(np.int64)
+    lvl = np.clip(lvl, 0, synth.N_LEVELS - 1).astype(np.int32)
+    radius = (f32(th) * synth.SCALE_FACTORS[lvl]).astype(f32)
+    qsel = np.nonzero(ok)[0]
+    off, idx = synth.features_in_area_lists(xy[:, 0], xy[:, 1], octave, u[qsel], v[qsel], radius[qsel], lvl[qsel] - 1, lvl[qsel] + 1)
+    # queries whose window is empty are skipped before the candidate loop: the oracle does the same for empty lists
+    occ0 = (cur_mp >= 0).astype(np.uint8)
+    n_ref, assign_q, _ = ob.orb_match_last_frame(mp_desc[qsel], desc, off, idx, kf_angle[qsel], angle, th_high=orb_dist,
+                                                 check_orientation=True, occupied=occ0)
+    assign_ref = np.where(assign_q >= 0, qsel[np.maximum(assign_q, 0)], -1).astype(np.int32)
+    # slots that held a point before the call keep it unless... they are never candidates, so they are untouched
+    assign_ref = np.where(cur_mp >= 0, cur_mp, assign_ref)
+    assert n == n_ref and n > 100
+    np.testing.assert_array_equal(assign, assign_ref)
+    # the edge cases did occur
+    assert (assign[held] == held).all() and bad.any() and found.any() and far.any()
+
+
 def test_local_inertial_ba_through_the_reference_signature(ob):
     """Optimizer::LocalInertialBA(KeyFrame*, bool*, Map*, int&x4, bLarge, bRecInit) on a KeyFrame/MapPoint/IMU graph vs the
     inertial oracle on the problem the host layer packed; write-back of poses, velocities, biases and points in float."""
