@@ -34,6 +34,9 @@ class KeyFrame {
 
   long unsigned int mnId;
   long unsigned int mnBALocalForKF = 0, mnBAFixedForKF = 0;
+  // global BA results kept beside the live pose until the loop-closing thread applies them (include/KeyFrame.h:369-372)
+  Sophus::SE3f mTcwGBA;
+  long unsigned int mnBAGlobalForKF = 0;
   float fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0;
   int N = 0, NLeft = -1;
   std::vector<cv::KeyPoint> mvKeysUn, mvKeysRight;

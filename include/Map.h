@@ -1,15 +1,21 @@
 /* Map.h -- members of ORB_SLAM3::Map used by Optimizer::LocalBundleAdjustment
- * (reference include/Map.h:141,155-156; src/Map.cc:181,291,341). */
+ * (reference include/Map.h:84-85,97,141,155-156; src/Map.cc:153-189,291,341). */
 #ifndef MAP_H
 #define MAP_H
 #include <mutex>
 #include <set>
+#include <vector>
 namespace ORB_SLAM3 {
+class KeyFrame;
+class MapPoint;
 class Map {
  public:
   long unsigned int GetInitKFid() { return mnInitKFid; }
   bool IsInertial() { return mbIsInertial; }
   long unsigned int KeyFramesInMap() { return mnKeyFrames; }   // src/Map.cc:165
+  std::vector<KeyFrame*> GetAllKeyFrames() { return mvpKeyFrames; }   // src/Map.cc:153-163 (copies of the sets)
+  std::vector<MapPoint*> GetAllMapPoints() { return mvpMapPoints; }
+  KeyFrame* GetOriginKF() { return mpKFinitial; }                     // src/Map.cc:186-189
   void IncreaseChangeIndex() { ++mnMapChange; }
   int GetMapChangeIndex() { return mnMapChange; }
   std::mutex mMutexMapUpdate;
@@ -20,6 +26,9 @@ class Map {
   bool mbIsInertial = false;
   int mnMapChange = 0;
   long unsigned int mnKeyFrames = 0;
+  std::vector<KeyFrame*> mvpKeyFrames;
+  std::vector<MapPoint*> mvpMapPoints;
+  KeyFrame* mpKFinitial = nullptr;
 };
 }  // namespace ORB_SLAM3
 #endif

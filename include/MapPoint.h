@@ -30,6 +30,8 @@ class MapPoint {
 
   long unsigned int mnId;
   long unsigned int mnBALocalForKF = 0;
+  Eigen::Vector3f mPosGBA;                    // include/MapPoint.h:147-148
+  long unsigned int mnBAGlobalForKF = 0;
   // tracking scratch written by Frame::isInFrustum (src/Frame.cc:513-587), read by SearchByProjection
   float mTrackProjX = 0, mTrackProjY = 0, mTrackDepth = 0, mTrackProjXR = 0;
   bool mbTrackInView = false, mbTrackInViewR = false;

@@ -1,13 +1,19 @@
-/* Optimizer.h -- the two entry points of ORB_SLAM3::Optimizer that form the local-BA hot path, with the
- * reference's signatures (include/Optimizer.h:57,86).  Drop-in: same mangled symbols, same side effects. */
+/* Optimizer.h -- the entry points of ORB_SLAM3::Optimizer on the bundle-adjustment hot path, with the
+ * reference's signatures (include/Optimizer.h:50-57,86).  Drop-in: same mangled symbols, same side effects. */
 #ifndef OPTIMIZER_H
 #define OPTIMIZER_H
 #include "KeyFrame.h"
 #include "Map.h"
+#include <vector>
 #include "MapPoint.h"
 namespace ORB_SLAM3 {
 class Optimizer {
  public:
+  // src/Optimizer.cc:61-392 / 53-58 (csrc/host/OptimizerGlobal.cc): every keyframe and point of the map, one optimize(nIterations)
+  void static BundleAdjustment(const std::vector<KeyFrame*>& vpKF, const std::vector<MapPoint*>& vpMP, int nIterations = 5,
+                               bool* pbStopFlag = NULL, const unsigned long nLoopKF = 0, const bool bRobust = true);
+  void static GlobalBundleAdjustemnt(Map* pMap, int nIterations = 5, bool* pbStopFlag = NULL, const unsigned long nLoopKF = 0,
+                                     const bool bRobust = true);
   // src/Optimizer.cc:1116-1498.  num_MPs is never assigned by the reference either.
   void static LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF, int& num_OptKF,
                                     int& num_MPs, int& num_edges);

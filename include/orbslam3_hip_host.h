@@ -66,6 +66,18 @@ int osh_host_preintegrate(int32_t n, const float* acc, const float* gyr, float d
 int osh_host_inertial_information(const float* cov225, double* info81_out);
 
 /* ---- matcher ---- */
+/* Optimizer::GlobalBundleAdjustemnt(&map, n_iterations, stop_flag, n_loop_kf, robust) on every keyframe and point of the graph
+ * (src/Optimizer.cc:53-392).  pack: the osh_lba_problem the host layer builds (sizes = {n_free, n_fixed, n_points, n_edges,
+ * points without any edge}); the GBA getters return mnBAGlobalForKF and fill mTcwGBA / mPosGBA. */
+int osh_host_pack_gba(osh_host_graph* g, int32_t sizes[5], double* pose_qt, double* pose_cam, double* points,
+                      int32_t* edge_pose, int32_t* edge_point, uint8_t* edge_kind, double* edge_obs, double* edge_info,
+                      int64_t* pose_kf_id, int64_t* point_mp_id);
+int osh_host_run_gba(osh_host_graph* g, int32_t n_iterations, unsigned char* stop_flag, int64_t n_loop_kf, int32_t robust);
+int64_t osh_host_get_kf_pose_gba(osh_host_graph* g, int32_t kf_index, float pose_qt[7]);
+int64_t osh_host_get_mp_pos_gba(osh_host_graph* g, int32_t mp_index, float pos[3]);
+int osh_host_mp_normal_updates(osh_host_graph* g, int32_t mp_index);
+void osh_host_set_bad(osh_host_graph* g, int32_t kf_index, int32_t mp_index);   /* marks a keyframe and/or a point bad (-1: none) */
+
 typedef struct osh_host_frame osh_host_frame;
 /* A frame with n keypoints (x y, octave, angle, uRight (<=0: none), 32-byte descriptor), pose Tcw. */
 osh_host_frame* osh_host_frame_create(int32_t n, const float* kp_xy, const int32_t* octave, const float* angle,

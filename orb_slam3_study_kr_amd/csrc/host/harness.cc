@@ -1,4 +1,5 @@
 // harness.cc -- extern "C" wrappers around the C++ host layer (include/orbslam3_hip_host.h).
+#include <algorithm>
 #include <cmath>
 #include <memory>
 #include <set>
@@ -58,6 +59,13 @@ extern "C" osh_host_graph* osh_host_graph_create(int32_t n_kf, const int64_t* kf
     kf->N = idx + 1;
     mp->AddObservation(kf, idx);
   }
+  // Map::GetAllKeyFrames / GetOriginKF: the origin keyframe is the one with the map's initial id (else the first one)
+  for (auto& kf : g->kfs) {
+    g->map.mvpKeyFrames.push_back(kf.get());
+    if (kf->mnId == g->map.mnInitKFid) g->map.mpKFinitial = kf.get();
+  }
+  if (!g->map.mpKFinitial && !g->kfs.empty()) g->map.mpKFinitial = g->kfs[0].get();
+  for (auto& mp : g->mps) g->map.mvpMapPoints.push_back(mp.get());
   return g;
 }
 
@@ -99,6 +107,48 @@ extern "C" int osh_host_run_lba(osh_host_graph* g, int32_t kf_index, unsigned ch
   Optimizer::LocalBundleAdjustment(g->kfs[kf_index].get(), reinterpret_cast<bool*>(stop_flag), &g->map, a, b, c, d);
   counts[0] = a; counts[1] = b; counts[2] = c; counts[3] = d;
   return 0;
+}
+
+// ---- Optimizer::GlobalBundleAdjustemnt (csrc/host/OptimizerGlobal.cc)
+extern "C" int osh_host_pack_gba(osh_host_graph* g, int32_t sizes[5], double* pose_qt, double* pose_cam, double* points,
+                                 int32_t* edge_pose, int32_t* edge_point, uint8_t* edge_kind, double* edge_obs, double* edge_info,
+                                 int64_t* pose_kf_id, int64_t* point_mp_id) {
+  if (!g) return -1;
+  LbaPack pk;
+  std::vector<bool> notIncluded;
+  PackBundleAdjustment(g->map.GetAllKeyFrames(), g->map.GetAllMapPoints(), pk, notIncluded);
+  sizes[0] = pk.n_free; sizes[1] = pk.n_fixed; sizes[2] = (int32_t)pk.vPointMPs.size(); sizes[3] = (int32_t)pk.edge_pose.size();
+  sizes[4] = (int32_t)std::count(notIncluded.begin(), notIncluded.end(), true);
+  if (pk.unsupported) return -3;
+  auto cp = [](auto* dst, const auto& src) { if (dst) std::copy(src.begin(), src.end(), dst); };
+  cp(pose_qt, pk.pose_qt); cp(pose_cam, pk.pose_cam); cp(points, pk.points); cp(edge_pose, pk.edge_pose);
+  cp(edge_point, pk.edge_point); cp(edge_kind, pk.edge_kind); cp(edge_obs, pk.edge_obs); cp(edge_info, pk.edge_info);
+  if (pose_kf_id) for (size_t i = 0; i < pk.vPoseKFs.size(); ++i) pose_kf_id[i] = (int64_t)pk.vPoseKFs[i]->mnId;
+  if (point_mp_id) for (size_t j = 0; j < pk.vPointMPs.size(); ++j) point_mp_id[j] = (int64_t)pk.vPointMPs[j]->mnId;
+  return 0;
+}
+
+extern "C" int osh_host_run_gba(osh_host_graph* g, int32_t n_iterations, unsigned char* stop_flag, int64_t n_loop_kf, int32_t robust) {
+  if (!g) return -1;
+  Optimizer::GlobalBundleAdjustemnt(&g->map, n_iterations, reinterpret_cast<bool*>(stop_flag), (unsigned long)n_loop_kf, robust != 0);
+  return 0;
+}
+
+extern "C" int64_t osh_host_get_kf_pose_gba(osh_host_graph* g, int32_t i, float o[7]) {
+  const Sophus::SE3f T = g->kfs[i]->mTcwGBA;
+  o[0] = T.unit_quaternion().x(); o[1] = T.unit_quaternion().y(); o[2] = T.unit_quaternion().z(); o[3] = T.unit_quaternion().w();
+  o[4] = T.translation()(0); o[5] = T.translation()(1); o[6] = T.translation()(2);
+  return (int64_t)g->kfs[i]->mnBAGlobalForKF;
+}
+extern "C" int64_t osh_host_get_mp_pos_gba(osh_host_graph* g, int32_t j, float o[3]) {
+  const Eigen::Vector3f p = g->mps[j]->mPosGBA;
+  o[0] = p(0); o[1] = p(1); o[2] = p(2);
+  return (int64_t)g->mps[j]->mnBAGlobalForKF;
+}
+extern "C" int osh_host_mp_normal_updates(osh_host_graph* g, int32_t j) { return g->mps[j]->mnNormalUpdates; }
+extern "C" void osh_host_set_bad(osh_host_graph* g, int32_t kf_index, int32_t mp_index) {
+  if (kf_index >= 0) g->kfs[kf_index]->mbBad = true;
+  if (mp_index >= 0) g->mps[mp_index]->mbBad = true;
 }
 
 extern "C" void osh_host_get_kf_pose(osh_host_graph* g, int32_t i, float o[7]) {

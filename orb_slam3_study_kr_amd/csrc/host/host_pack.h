@@ -62,4 +62,7 @@ osh_lba_ctx* HostSolverContext();   // one solver context per calling thread (Op
 
 // Steps 1-6 of Optimizer::LocalBundleAdjustment; false when the window has no fixed keyframe.
 bool PackLocalBA(KeyFrame* pKF, Map* pMap, LbaPack& pk);
+// Vertex / edge construction of Optimizer::BundleAdjustment (src/Optimizer.cc:112-300); vbNotIncludedMP as there.
+void PackBundleAdjustment(const std::vector<KeyFrame*>& vpKFs, const std::vector<MapPoint*>& vpMP, LbaPack& pk,
+                          std::vector<bool>& vbNotIncludedMP);
 }  // namespace ORB_SLAM3

@@ -26,7 +26,7 @@ class HostGraph:
     reference equals the window's order), fixed poses get ids 10+i (older keyframes).  The current keyframe is
     the newest optimisable one; every other optimisable keyframe is covisible with it."""
 
-    def __init__(self, w: LbaWindow, init_kf_fixed: bool = False, inertial: bool = False):
+    def __init__(self, w: LbaWindow, init_kf_fixed: bool = False, inertial: bool = False, init_kf_id_index: int | None = None):
         self.lib = capi.load_library()
         self.w = w
         P, F = w.n_free, w.n_fixed
@@ -39,6 +39,8 @@ class HostGraph:
         obs = _f32(w.edge_obs)
         obs[w.edge_kind == capi.OSH_EDGE_MONO, 2] = -1.0
         init_id = int(self.kf_id[0]) if init_kf_fixed else -1 & 0x7FFFFFFF
+        if init_kf_id_index is not None:      # the map's initial keyframe (Map::GetInitKFid / GetOriginKF) is keyframe number ...
+            init_id = int(self.kf_id[init_kf_id_index])
         self.init_kf_fixed = init_kf_fixed
         mp_pos = _f32(w.points)
         self._keep = [pose, cam5, inv, octave, obs, mp_pos]
@@ -98,6 +100,46 @@ class HostGraph:
                                        C.cast(None, capi.c_uint8_p), capi.ptr(counts, capi.c_int32_p))
         assert rc == 0
         return counts
+
+    # ---- Optimizer::GlobalBundleAdjustemnt
+    def packed_global_window(self, max_iterations=5, robust=True):
+        """The osh_lba_problem the host layer builds for BundleAdjustment over the whole graph, as an LbaWindow."""
+        sizes = np.zeros(5, dtype=np.int32)
+        d, i32, u8, i64 = capi.c_double_p, capi.c_int32_p, capi.c_uint8_p, capi.c_int64_p
+        rc = self.lib.osh_host_pack_gba(self.g, capi.ptr(sizes, i32), *[C.cast(None, t) for t in (d, d, d, i32, i32, u8, d, d, i64, i64)])
+        assert rc == 0, rc
+        P, F, L, E = (int(x) for x in sizes[:4])
+        o = dict(pose_qt=np.zeros((P + F, 7)), pose_cam=np.zeros((P + F, 5)), points=np.zeros((L, 3)),
+                 edge_pose=np.zeros(E, dtype=np.int32), edge_point=np.zeros(E, dtype=np.int32), edge_kind=np.zeros(E, dtype=np.uint8),
+                 edge_obs=np.zeros((E, 3)), edge_info=np.zeros(E), pose_kf_id=np.zeros(P + F, dtype=np.int64),
+                 point_mp_id=np.zeros(L, dtype=np.int64), n_not_included=int(sizes[4]))
+        rc = self.lib.osh_host_pack_gba(self.g, capi.ptr(sizes, i32), capi.ptr(o["pose_qt"], d), capi.ptr(o["pose_cam"], d),
+                                        capi.ptr(o["points"], d), capi.ptr(o["edge_pose"], i32), capi.ptr(o["edge_point"], i32),
+                                        capi.ptr(o["edge_kind"], u8), capi.ptr(o["edge_obs"], d), capi.ptr(o["edge_info"], d),
+                                        capi.ptr(o["pose_kf_id"], i64), capi.ptr(o["point_mp_id"], i64))
+        assert rc == 0, rc
+        w = LbaWindow(n_free=P, n_fixed=F, pose_qt=o["pose_qt"], pose_cam=o["pose_cam"], points=o["points"],
+                      edge_pose=o["edge_pose"], edge_point=o["edge_point"], edge_kind=o["edge_kind"], edge_obs=o["edge_obs"],
+                      edge_info=o["edge_info"], lambda_init=0.0, max_iterations=max_iterations).normalise()
+        # const float thHuber2D = sqrt(5.99), thHuber3D = sqrt(7.815) (src/Optimizer.cc:130-131); none unless bRobust
+        w.huber_mono = float(np.float32(np.sqrt(5.99))) if robust else float("inf")
+        w.huber_stereo = float(np.float32(np.sqrt(7.815))) if robust else float("inf")
+        return w, o
+
+    def run_gba(self, n_iterations=5, n_loop_kf=0, robust=True, stop_flag=None):
+        rc = self.lib.osh_host_run_gba(self.g, n_iterations, capi.ptr(stop_flag, capi.c_uint8_p) if stop_flag is not None else
+                                       C.cast(None, capi.c_uint8_p), int(n_loop_kf), int(robust))
+        assert rc == 0
+
+    def kf_pose_gba(self, i):
+        o = np.zeros(7, dtype=np.float32)
+        mark = self.lib.osh_host_get_kf_pose_gba(self.g, i, capi.ptr(o, capi.c_float_p))
+        return int(mark), o
+
+    def mp_pos_gba(self, j):
+        o = np.zeros(3, dtype=np.float32)
+        mark = self.lib.osh_host_get_mp_pos_gba(self.g, j, capi.ptr(o, capi.c_float_p))
+        return int(mark), o
 
     def kf_pose(self, i):
         o = np.zeros(7, dtype=np.float32)

@@ -75,6 +75,69 @@ def test_stop_flag_leaves_the_map_untouched(ob):
         assert all(g.lib.osh_host_kf_pose_sets(g.g, i) == 0 for i in range(w.n_free + w.n_fixed))
 
 
+def _gba_reference(g, ob, n_iterations, robust):
+    pw, o = g.packed_global_window(max_iterations=n_iterations, robust=robust)
+    return pw, o, ob.lba_solve(pw)
+
+
+@pytest.mark.parametrize("robust", [True, False])
+def test_global_bundle_adjustment_writes_poses_when_called_for_the_origin_keyframe(ob, robust):
+    """Optimizer::GlobalBundleAdjustemnt (src/Optimizer.cc:53-392) with nLoopKF == origin keyframe id: SetPose / SetWorldPos +
+    UpdateNormalAndDepth; the map's initial keyframe is the only fixed vertex, every other keyframe is optimised."""
+    w = synth.make_window(44, n_free=9, n_fixed=1, n_points=700, stereo=True)
+    with host.HostGraph(w, init_kf_id_index=w.n_free) as g:        # the (single) fixed pose of the window is the init keyframe
+        g.lib.osh_host_set_bad(g.g, -1, 5)                          # a bad point is not a vertex
+        pw, o, ref = _gba_reference(g, ob, 5, robust)
+        assert pw.n_free == w.n_free and pw.n_fixed == 1 and pw.n_points == w.n_points - 1
+        origin = int(g.kf_id[w.n_free])
+        g.run_gba(5, n_loop_kf=origin, robust=robust)
+        kf_index = {int(i): k for k, i in enumerate(g.kf_id)}
+        got_qt = np.stack([g.kf_pose(kf_index[int(i)]) for i in o["pose_kf_id"][:pw.n_free]]).astype(np.float64)
+        assert rel_translation_error(got_qt, ref.pose_qt) < 2e-6
+        assert rotation_error(got_qt, ref.pose_qt) < 2e-6
+        mp_index = {int(i): k for k, i in enumerate(g.mp_id)}
+        got_pts = np.stack([g.mp_pos(mp_index[int(i)]) for i in o["point_mp_id"]]).astype(np.float64)
+        np.testing.assert_allclose(got_pts, ref.points, rtol=2e-6, atol=2e-6)
+        assert ref.iterations == 5
+        for i in range(w.n_free + 1):
+            assert g.lib.osh_host_kf_pose_sets(g.g, i) == 1          # every keyframe incl. the fixed one gets SetPose (:311-314)
+        assert g.lib.osh_host_mp_normal_updates(g.g, 5) == 0 and g.lib.osh_host_mp_normal_updates(g.g, 6) == 1
+        np.testing.assert_array_equal(g.mp_pos(5), np.float32(w.points[5]))   # the bad point is untouched
+
+
+def test_global_bundle_adjustment_for_a_loop_keeps_results_beside_the_live_map(ob):
+    """nLoopKF != origin id: results go to mTcwGBA / mPosGBA with mnBAGlobalForKF = nLoopKF; live poses / points untouched."""
+    w = synth.make_window(45, n_free=6, n_fixed=1, n_points=400, stereo=False, track_len=(2, 6))
+    with host.HostGraph(w, init_kf_id_index=w.n_free) as g:
+        pw, o, ref = _gba_reference(g, ob, 10, True)
+        live_before = np.stack([g.kf_pose(i) for i in range(w.n_free + 1)])
+        g.run_gba(10, n_loop_kf=77, robust=True)
+        kf_index = {int(i): k for k, i in enumerate(g.kf_id)}
+        marks, poses = zip(*[g.kf_pose_gba(kf_index[int(i)]) for i in o["pose_kf_id"][:pw.n_free]])
+        assert set(marks) == {77}
+        assert rel_translation_error(np.stack(poses).astype(np.float64), ref.pose_qt) < 2e-6
+        mp_index = {int(i): k for k, i in enumerate(g.mp_id)}
+        marks, pts = zip(*[g.mp_pos_gba(mp_index[int(i)]) for i in o["point_mp_id"]])
+        assert set(marks) == {77}
+        np.testing.assert_allclose(np.stack(pts).astype(np.float64), ref.points, rtol=2e-6, atol=2e-6)
+        np.testing.assert_array_equal(np.stack([g.kf_pose(i) for i in range(w.n_free + 1)]), live_before)
+        assert all(g.lib.osh_host_kf_pose_sets(g.g, i) == 0 for i in range(w.n_free + 1))
+        assert g.lib.osh_host_map_change_index(g.g) == 0
+
+
+def test_global_bundle_adjustment_of_a_map_with_80_keyframes(ob):
+    """A reduced camera system of 480 unknowns: the LDS-resident factorisation falls back to one block per CU."""
+    w = synth.make_window(46, n_free=80, n_fixed=1, n_points=4000, stereo=True, track_len=(3, 10))
+    with host.HostGraph(w, init_kf_id_index=w.n_free) as g:
+        pw, o, ref = _gba_reference(g, ob, 5, True)
+        assert pw.n_free == 80
+        g.run_gba(5, n_loop_kf=int(g.kf_id[w.n_free]), robust=True)
+        kf_index = {int(i): k for k, i in enumerate(g.kf_id)}
+        got_qt = np.stack([g.kf_pose(kf_index[int(i)]) for i in o["pose_kf_id"][:pw.n_free]]).astype(np.float64)
+        assert rel_translation_error(got_qt, ref.pose_qt) < 2e-6
+        assert rotation_error(got_qt, ref.pose_qt) < 2e-6
+
+
 def _frame_and_points(seed, n_kp=800, n_mp=500):
     rng = np.random.Generator(np.random.PCG64(seed))
     xy = np.stack([rng.uniform(5, synth.IMG_W - 5, n_kp), rng.uniform(5, synth.IMG_H - 5, n_kp)], axis=1).astype(np.float32)

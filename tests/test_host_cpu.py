@@ -78,3 +78,26 @@ def test_window_without_fixed_keyframe_aborts():
     with host.HostGraph(w) as g:
         rc, sizes, _ = g.pack()
         assert rc == 1 and sizes[4] == 0      # "LM-LBA: There are 0 fixed KF" path (:1182-1186)
+
+
+def test_global_ba_pack_selects_every_keyframe_and_skips_bad_and_unobserved_points():
+    """PackBundleAdjustment (src/Optimizer.cc:112-300): every non-bad keyframe is a vertex, the map's initial keyframe the only
+    fixed one; bad points are no vertices; a point whose observers are all bad is removed again (vbNotIncludedMP)."""
+    w = synth.make_window(51, n_free=5, n_fixed=2, n_points=120, stereo=True, track_len=(2, 4))
+    with host.HostGraph(w, init_kf_id_index=w.n_free) as g:
+        pw, o = g.packed_global_window()
+        # both fixed poses of the window are keyframes of the map: one is the init keyframe (fixed), the other is optimised
+        assert (pw.n_free, pw.n_fixed) == (w.n_free + 1, 1)
+        assert list(o["pose_kf_id"][:pw.n_free]) == sorted(o["pose_kf_id"][:pw.n_free])
+        assert o["pose_kf_id"][pw.n_free] == g.kf_id[w.n_free]
+        assert pw.n_points == w.n_points and pw.n_edges == w.n_edges and o["n_not_included"] == 0
+        g.lib.osh_host_set_bad(g.g, -1, 3)
+        pw2, o2 = g.packed_global_window()
+        assert pw2.n_points == w.n_points - 1 and int(g.mp_id[3]) not in set(o2["point_mp_id"].tolist())
+        # make every observer of point 7 bad -> the point has no edge and is dropped from the problem
+        obs7 = set(int(p) for p, l in zip(w.edge_pose, w.edge_point) if l == 7)
+        for k in obs7:
+            g.lib.osh_host_set_bad(g.g, k, -1)
+        pw3, o3 = g.packed_global_window()
+        assert o3["n_not_included"] >= 1 and int(g.mp_id[7]) not in set(o3["point_mp_id"].tolist())
+        assert pw3.n_free + pw3.n_fixed == w.n_free + w.n_fixed - len(obs7)
