@@ -31,6 +31,9 @@ class KeyFrame {
   Sophus::SE3f GetRelativePoseTrl() { return mTrl; }
   bool isBad() { return mbBad; }
   Map* GetMap() { return mpMap; }
+  // candidate generator of the Sim3 searches (src/KeyFrame.cc:704-750): the grid is the one of the Frame the keyframe was made from
+  std::vector<size_t> GetFeaturesInArea(const float& x, const float& y, const float& r, const bool bRight = false) const;
+  bool IsInImage(const float& x, const float& y) const { return (x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY); }
 
   long unsigned int mnId;
   long unsigned int mnBALocalForKF = 0, mnBAFixedForKF = 0;
@@ -42,6 +45,14 @@ class KeyFrame {
   std::vector<cv::KeyPoint> mvKeysUn, mvKeysRight;
   std::vector<float> mvuRight;
   std::vector<float> mvInvLevelSigma2;
+  std::vector<float> mvScaleFactors;
+  int mnScaleLevels = 0;
+  float mfLogScaleFactor = 0;
+  cv::Mat mDescriptors;
+  int mnGridCols = 0, mnGridRows = 0;
+  float mfGridElementWidthInv = 0, mfGridElementHeightInv = 0;
+  int mnMinX = 0, mnMinY = 0, mnMaxX = 0, mnMaxY = 0;   // const int in the reference (include/KeyFrame.h:357-360)
+  std::vector<std::vector<std::vector<size_t>>> mGrid;
   GeometricCamera* mpCamera = nullptr;
   GeometricCamera* mpCamera2 = nullptr;
   KeyFrame* mPrevKF = nullptr;

@@ -27,6 +27,8 @@ class MapPoint {
   float GetMinDistanceInvariance() { return 0.8f * mfMinDistance; }
   float GetMaxDistanceInvariance() { return 1.2f * mfMaxDistance; }
   int PredictScale(const float& currentDist, Frame* pF);
+  int PredictScale(const float& currentDist, KeyFrame* pKF);   // src/MapPoint.cc:514-529
+  Eigen::Vector3f GetNormal() { return mNormalVector; }
 
   long unsigned int mnId;
   long unsigned int mnBALocalForKF = 0;
@@ -38,6 +40,7 @@ class MapPoint {
   int mnTrackScaleLevel = 0;
   float mTrackViewCos = 1.f;
   float mfMinDistance = 0, mfMaxDistance = 0;
+  Eigen::Vector3f mNormalVector;
   // test-double state
   Eigen::Vector3f mWorldPos;
   std::map<KeyFrame*, std::tuple<int, int>> mObservations;

@@ -23,6 +23,13 @@ class ORBmatcher {
   // src/ORBmatcher.cc:1889-2010 (Relocalization): best candidate only, any occupied slot is skipped, accept <= ORBdist
   int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, const float th,
                          const int ORBdist);
+  // src/ORBmatcher.cc:427-532 and :534-646 (loop closing / map merging): map points projected with a Sim3 into a keyframe,
+  // level filter inside the candidate loop, any matched slot is skipped, accept bestDist <= TH_LOW * ratioHamming (float)
+  int SearchByProjection(KeyFrame* pKF, Sophus::Sim3f& Scw, const std::vector<MapPoint*>& vpPoints, std::vector<MapPoint*>& vpMatched,
+                         int th, float ratioHamming = 1.0);
+  int SearchByProjection(KeyFrame* pKF, Sophus::Sim3<float>& Scw, const std::vector<MapPoint*>& vpPoints,
+                         const std::vector<KeyFrame*>& vpPointsKFs, std::vector<MapPoint*>& vpMatched,
+                         std::vector<KeyFrame*>& vpMatchedKF, int th, float ratioHamming = 1.0);
   static const int TH_LOW;
   static const int TH_HIGH;
   static const int HISTO_LENGTH;

@@ -127,6 +127,21 @@ class SE3 {
   Eigen::Matrix<T, 3> t_;
 };
 using SE3f = SE3<float>;
+// Sim3 as rotation + translation + scale; only the accessors ORBmatcher::SearchByProjection(KeyFrame*, Sim3f&, ...) uses.
+template <class T>
+class Sim3 {
+ public:
+  Sim3() : s_(1) {}
+  Sim3(const Eigen::Quaternion<T>& unit_q, const Eigen::Matrix<T, 3>& t, T scale) : rot_(unit_q, Eigen::Matrix<T, 3>(0, 0, 0)), t_(t), s_(scale) {}
+  Eigen::Matrix<T, 3, 3> rotationMatrix() const { return rot_.rotationMatrix(); }
+  const Eigen::Matrix<T, 3>& translation() const { return t_; }
+  T scale() const { return s_; }
+ private:
+  SE3<T> rot_;
+  Eigen::Matrix<T, 3> t_;
+  T s_;
+};
+using Sim3f = Sim3<float>;
 }  // namespace Sophus
 
 namespace cv {

@@ -103,6 +103,14 @@ int osh_host_search_keyframe(osh_host_frame* cur, int32_t n_kf, const float* kf_
                              const float* mp_pos, const uint8_t* mp_desc, const float* mp_min_max_dist,
                              const uint8_t* mp_found, const uint8_t* mp_bad, const int32_t* cur_mp, float th,
                              int32_t orb_dist, int32_t check_ori, int32_t* assignment);
+/* ORBmatcher::SearchByProjection(KeyFrame*, Sim3f&, vpPoints[, vpPointsKFs], vpMatched[, vpMatchedKF], th, ratioHamming)
+ * (src/ORBmatcher.cc:427-646): the keyframe is made from `f`; scw = unit quaternion (x y z w), translation, scale;
+ * map points by world position, descriptor, {mfMinDistance, mfMaxDistance}, normal, isBad(); matched_in[k] = map point
+ * already matched to keypoint k (-1 none).  with_keyframes selects the second overload (point j comes from keyframe j). */
+int osh_host_search_sim3(osh_host_frame* f, const float scw[8], int32_t n_mp, const float* mp_pos, const uint8_t* mp_desc,
+                         const float* mp_min_max_dist, const float* mp_normal, const uint8_t* mp_bad,
+                         const int32_t* matched_in, int32_t th, float ratio_hamming, int32_t with_keyframes,
+                         int32_t* matched_out, int32_t* matched_kf_out);
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <set>
 
 #include "orbslam3_hip.h"
 
@@ -341,6 +342,96 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std
     }
   }
   return nmatches;
+}
+
+namespace {
+
+// Common body of the two Sim3 overloads (src/ORBmatcher.cc:427-532, 534-646).  They differ in how the point is projected
+// (camera model object vs. the keyframe's pinhole intrinsics with a float 1/z) and in the extra vpMatchedKF output.
+int search_by_sim3(KeyFrame* pKF, Sophus::Sim3f& Scw, const std::vector<MapPoint*>& vpPoints, const std::vector<KeyFrame*>* vpPointsKFs,
+                   std::vector<MapPoint*>& vpMatched, std::vector<KeyFrame*>* vpMatchedKF, int th, float ratioHamming, int th_low) {
+  const float &fx = pKF->fx, &fy = pKF->fy, &cx = pKF->cx, &cy = pKF->cy;
+  const Eigen::Vector3f ts = Scw.translation();
+  const float sc = Scw.scale();
+  const Sophus::SE3f Tcw(Scw.rotationMatrix(), Eigen::Vector3f(ts(0) / sc, ts(1) / sc, ts(2) / sc));
+  const Eigen::Vector3f Ow = Tcw.inverse().translation();
+  std::set<MapPoint*> spAlreadyFound(vpMatched.begin(), vpMatched.end());
+  spAlreadyFound.erase(static_cast<MapPoint*>(NULL));
+
+  const int N = (int)vpMatched.size();
+  std::vector<int32_t> level(N);
+  std::vector<uint8_t> occupied(N, 0);
+  for (int i = 0; i < N; ++i) { level[i] = pKF->mvKeysUn[i].octave; occupied[i] = vpMatched[i] ? 1 : 0; }
+  Search s;
+  std::vector<int> qMP;
+  for (int iMP = 0, iendMP = (int)vpPoints.size(); iMP < iendMP; iMP++) {
+    MapPoint* pMP = vpPoints[iMP];
+    if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+    const Eigen::Vector3f p3Dw = pMP->GetWorldPos();
+    const Eigen::Vector3f p3Dc = Tcw * p3Dw;
+    if (p3Dc(2) < 0.0) continue;
+    float u, v;
+    if (!vpPointsKFs) {
+      const Eigen::Vector2f uv = pKF->mpCamera->project(p3Dc);   // :467
+      u = uv(0); v = uv(1);
+    } else {
+      const float invz = 1 / p3Dc(2);                            // :573-578
+      const float x = p3Dc(0) * invz, y = p3Dc(1) * invz;
+      u = fx * x + cx; v = fy * y + cy;
+    }
+    if (!pKF->IsInImage(u, v)) continue;
+    const float maxDistance = pMP->GetMaxDistanceInvariance();
+    const float minDistance = pMP->GetMinDistanceInvariance();
+    const float px = p3Dw(0) - Ow(0), py = p3Dw(1) - Ow(1), pz = p3Dw(2) - Ow(2);
+    const float dist = std::sqrt(px * px + py * py + pz * pz);
+    if (dist < minDistance || dist > maxDistance) continue;
+    const Eigen::Vector3f Pn = pMP->GetNormal();                 // viewing angle below 60 degrees (:485-489)
+    const float dotp = px * Pn(0) + py * Pn(1) + pz * Pn(2);
+    if (dotp < 0.5 * dist) continue;
+    const int nPredictedLevel = pMP->PredictScale(dist, pKF);
+    const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
+    const std::vector<size_t> vIndices = pKF->GetFeaturesInArea(u, v, radius);
+    if (vIndices.empty()) continue;
+    for (const size_t idx : vIndices) {
+      if (occupied[idx]) continue;
+      const int& kpLevel = pKF->mvKeysUn[idx].octave;
+      if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+      s.idx.push_back((int32_t)idx);
+    }
+    s.off.push_back((int32_t)s.idx.size());
+    const cv::Mat d = pMP->GetDescriptor();
+    const uint8_t* dp = d.ptr<uint8_t>(0);
+    s.qdesc.insert(s.qdesc.end(), dp, dp + 32);
+    qMP.push_back(iMP);
+  }
+  if (!device_search(s, pKF->mDescriptors, level)) return 0;
+
+  int nmatches = 0;
+  std::vector<uint8_t> taken(N, 0);
+  for (int q = 0; q < s.nq(); ++q) {
+    int bestIdx = s.best_idx[q], bestDist = s.best_dist[q], d2, l1, l2;
+    if (bestIdx >= 0 && taken[bestIdx]) rescan(s, q, pKF->mDescriptors, level, taken, bestIdx, bestDist, d2, l1, l2);
+    if (bestIdx >= 0 && bestDist <= th_low * ratioHamming) {      // int <= float (:523,636)
+      vpMatched[bestIdx] = vpPoints[qMP[q]];
+      if (vpMatchedKF) (*vpMatchedKF)[bestIdx] = (*vpPointsKFs)[qMP[q]];
+      taken[bestIdx] = 1;
+      nmatches++;
+    }
+  }
+  return nmatches;
+}
+
+}  // namespace
+
+int ORBmatcher::SearchByProjection(KeyFrame* pKF, Sophus::Sim3f& Scw, const std::vector<MapPoint*>& vpPoints,
+                                   std::vector<MapPoint*>& vpMatched, int th, float ratioHamming) {
+  return search_by_sim3(pKF, Scw, vpPoints, nullptr, vpMatched, nullptr, th, ratioHamming, TH_LOW);
+}
+
+int ORBmatcher::SearchByProjection(KeyFrame* pKF, Sophus::Sim3<float>& Scw, const std::vector<MapPoint*>& vpPoints,
+                                   const std::vector<KeyFrame*>& vpPointsKFs, std::vector<MapPoint*>& vpMatched,
+                                   std::vector<KeyFrame*>& vpMatchedKF, int th, float ratioHamming) {
+  return search_by_sim3(pKF, Scw, vpPoints, &vpPointsKFs, vpMatched, &vpMatchedKF, th, ratioHamming, TH_LOW);
 }
 
 }  // namespace ORB_SLAM3

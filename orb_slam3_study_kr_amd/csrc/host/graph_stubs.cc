@@ -39,6 +39,41 @@ int MapPoint::PredictScale(const float& currentDist, Frame* pF) {
   return nScale;
 }
 
+int MapPoint::PredictScale(const float& currentDist, KeyFrame* pKF) {
+  const float ratio = mfMaxDistance / currentDist;
+  int nScale = (int)std::ceil(std::log(ratio) / pKF->mfLogScaleFactor);
+  if (nScale < 0) nScale = 0;
+  else if (nScale >= pKF->mnScaleLevels) nScale = pKF->mnScaleLevels - 1;
+  return nScale;
+}
+
+// src/KeyFrame.cc:704-745, NLeft == -1 layout
+std::vector<size_t> KeyFrame::GetFeaturesInArea(const float& x, const float& y, const float& r, const bool bRight) const {
+  (void)bRight;
+  std::vector<size_t> vIndices;
+  vIndices.reserve(N);
+  const float factorX = r, factorY = r;
+  const int nMinCellX = std::max(0, (int)std::floor((x - mnMinX - factorX) * mfGridElementWidthInv));
+  if (nMinCellX >= mnGridCols) return vIndices;
+  const int nMaxCellX = std::min((int)mnGridCols - 1, (int)std::ceil((x - mnMinX + factorX) * mfGridElementWidthInv));
+  if (nMaxCellX < 0) return vIndices;
+  const int nMinCellY = std::max(0, (int)std::floor((y - mnMinY - factorY) * mfGridElementHeightInv));
+  if (nMinCellY >= mnGridRows) return vIndices;
+  const int nMaxCellY = std::min((int)mnGridRows - 1, (int)std::ceil((y - mnMinY + factorY) * mfGridElementHeightInv));
+  if (nMaxCellY < 0) return vIndices;
+  for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+    for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+      const std::vector<size_t>& vCell = mGrid[ix][iy];
+      for (size_t j = 0, jend = vCell.size(); j < jend; j++) {
+        const cv::KeyPoint& kpUn = mvKeysUn[vCell[j]];
+        const float distx = kpUn.pt.x - x;
+        const float disty = kpUn.pt.y - y;
+        if (std::fabs(distx) < r && std::fabs(disty) < r) vIndices.push_back(vCell[j]);
+      }
+    }
+  return vIndices;
+}
+
 void MapPoint::EraseObservation(KeyFrame* pKF) {
   auto it = mObservations.find(pKF);
   if (it == mObservations.end()) return;

@@ -376,3 +376,55 @@ extern "C" int osh_host_search_keyframe(osh_host_frame* cur, int32_t n_kf, const
   F.mvpMapPoints.assign(F.N, nullptr);
   return n;
 }
+
+// ORBmatcher(0.75, true).SearchByProjection(pKF, Scw, vpPoints[, vpPointsKFs], vpMatched[, vpMatchedKF], th, ratioHamming):
+// the keyframe is made from the frame's keypoints, descriptors and grid (as the KeyFrame constructor copies them).
+extern "C" int osh_host_search_sim3(osh_host_frame* f, const float scw[8], int32_t n_mp, const float* mp_pos, const uint8_t* mp_desc,
+                                    const float* mp_min_max_dist, const float* mp_normal, const uint8_t* mp_bad,
+                                    const int32_t* matched_in, int32_t th, float ratio_hamming, int32_t with_keyframes,
+                                    int32_t* matched_out, int32_t* matched_kf_out) {
+  if (!f) return -1;
+  Frame& F = f->F;
+  auto pts = make_points(&f->map, n_mp, mp_desc, mp_pos, nullptr);
+  for (int j = 0; j < n_mp; ++j) {
+    pts[j]->mfMinDistance = mp_min_max_dist[2 * j]; pts[j]->mfMaxDistance = mp_min_max_dist[2 * j + 1];
+    pts[j]->mNormalVector = Eigen::Vector3f(mp_normal[3 * j], mp_normal[3 * j + 1], mp_normal[3 * j + 2]);
+    if (mp_bad && mp_bad[j]) pts[j]->mbBad = true;
+  }
+  KeyFrame kf(1, &f->map);
+  kf.N = F.N;
+  kf.mvKeysUn = F.mvKeysUn;
+  kf.mDescriptors = F.mDescriptors;
+  kf.mvScaleFactors = F.mvScaleFactors;
+  kf.mnScaleLevels = F.mnScaleLevels;
+  kf.mfLogScaleFactor = F.mfLogScaleFactor;
+  kf.mpCamera = F.mpCamera;
+  kf.fx = f->cam->getParameter(0); kf.fy = f->cam->getParameter(1); kf.cx = f->cam->getParameter(2); kf.cy = f->cam->getParameter(3);
+  kf.mnGridCols = FRAME_GRID_COLS; kf.mnGridRows = FRAME_GRID_ROWS;
+  kf.mfGridElementWidthInv = F.mfGridElementWidthInv; kf.mfGridElementHeightInv = F.mfGridElementHeightInv;
+  kf.mnMinX = (int)F.mnMinX; kf.mnMinY = (int)F.mnMinY; kf.mnMaxX = (int)F.mnMaxX; kf.mnMaxY = (int)F.mnMaxY;
+  kf.mGrid.assign(FRAME_GRID_COLS, std::vector<std::vector<size_t>>(FRAME_GRID_ROWS));
+  for (int i = 0; i < FRAME_GRID_COLS; ++i)
+    for (int j = 0; j < FRAME_GRID_ROWS; ++j) kf.mGrid[i][j] = F.mGrid[i][j];
+  // one distinct (dummy) source keyframe per point for the second overload
+  std::vector<std::unique_ptr<KeyFrame>> srcs;
+  std::vector<KeyFrame*> vpPointsKFs;
+  std::vector<MapPoint*> vpPoints;
+  for (int j = 0; j < n_mp; ++j) {
+    vpPoints.push_back(pts[j].get());
+    srcs.emplace_back(new KeyFrame((unsigned long)(1000 + j), &f->map));
+    vpPointsKFs.push_back(srcs.back().get());
+  }
+  std::vector<MapPoint*> vpMatched(F.N, nullptr);
+  std::vector<KeyFrame*> vpMatchedKF(F.N, nullptr);
+  for (int k = 0; k < F.N; ++k) if (matched_in && matched_in[k] >= 0) vpMatched[k] = pts[matched_in[k]].get();
+  Sophus::Sim3f Scw(Eigen::Quaternionf(scw[3], scw[0], scw[1], scw[2]), Eigen::Vector3f(scw[4], scw[5], scw[6]), scw[7]);
+  ORBmatcher matcher(0.75f, true);
+  const int n = with_keyframes ? matcher.SearchByProjection(&kf, Scw, vpPoints, vpPointsKFs, vpMatched, vpMatchedKF, th, ratio_hamming)
+                               : matcher.SearchByProjection(&kf, Scw, vpPoints, vpMatched, th, ratio_hamming);
+  for (int k = 0; k < F.N; ++k) {
+    matched_out[k] = vpMatched[k] ? (int32_t)vpMatched[k]->mnId : -1;
+    if (matched_kf_out) matched_kf_out[k] = vpMatchedKF[k] ? (int32_t)(vpMatchedKF[k]->mnId - 1000) : -1;
+  }
+  return n;
+}

@@ -212,6 +212,22 @@ class HostFrame:
         return n, assign
 
 
+    def search_sim3(self, scw, mp_pos, mp_desc, mp_min_max_dist, mp_normal, mp_bad=None, matched_in=None, th=3, ratio_hamming=1.0,
+                    with_keyframes=False):
+        """ORBmatcher::SearchByProjection(pKF, Scw, vpPoints[, vpPointsKFs], vpMatched[, vpMatchedKF], th, ratioHamming)
+        (src/ORBmatcher.cc:427-646) with this frame turned into the keyframe."""
+        u8 = lambda a: np.ascontiguousarray(a, dtype=np.uint8)
+        out, out_kf = -np.ones(self.n, dtype=np.int32), -np.ones(self.n, dtype=np.int32)
+        keep = [_f32(scw), _f32(mp_pos), u8(mp_desc), _f32(mp_min_max_dist), _f32(mp_normal),
+                u8(mp_bad if mp_bad is not None else np.zeros(len(mp_pos))), _i32(matched_in if matched_in is not None else -np.ones(self.n))]
+        fp = capi.c_float_p
+        n = self.lib.osh_host_search_sim3(self.f, capi.ptr(keep[0], fp), len(mp_pos), capi.ptr(keep[1], fp), capi.ptr(keep[2], capi.c_uint8_p),
+                                          capi.ptr(keep[3], fp), capi.ptr(keep[4], fp), capi.ptr(keep[5], capi.c_uint8_p),
+                                          capi.ptr(keep[6], capi.c_int32_p), int(th), float(ratio_hamming), int(with_keyframes),
+                                          capi.ptr(out, capi.c_int32_p), capi.ptr(out_kf, capi.c_int32_p))
+        return n, out, out_kf
+
+
 def _quat_from_R(R):
     return synth._quat_from_R(np.asarray(R, dtype=np.float64))
 

@@ -269,6 +269,79 @@ def test_search_by_projection_keyframe_relocalisation_equals_sequential_referenc
     assert (assign[held] == held).all() and bad.any() and found.any() and far.any()
 
 
+@pytest.mark.parametrize("with_keyframes", [False, True])
+def test_search_by_projection_sim3_equals_sequential_reference(ob, with_keyframes):
+    """M5, src/ORBmatcher.cc:427-532 / 534-646: Sim3 projection into a keyframe, distance + viewing-angle gates, level filter
+    inside the candidate loop, matched slots skipped, accept bestDist <= TH_LOW * ratioHamming; second overload also returns
+    the source keyframe of every match."""
+    rng = np.random.Generator(np.random.PCG64(21 + int(with_keyframes)))
+    n_kp = 700
+    f32 = np.float32
+    xy, octave, desc, _, _, _, _ = _frame_and_points(13, n_kp=n_kp, n_mp=10)
+    scale = f32(1.25)
+    ts = np.array([0.25, -0.1, 0.5], dtype=f32)                  # Scw = (I, ts, s)  ->  Tcw = (I, ts / s)
+    t = (ts / scale).astype(f32)
+    depth = rng.uniform(4, 10, n_kp)
+    noisy = xy + rng.normal(0, 1.0, xy.shape)
+    Xc = np.stack([(noisy[:, 0] - float(synth.CX)) / float(synth.FX) * depth, (noisy[:, 1] - float(synth.CY)) / float(synth.FY) * depth, depth], axis=1)
+    pos = (Xc - t.astype(np.float64)).astype(f32)
+    mp_desc = desc ^ np.packbits(rng.uniform(0, 1, (n_kp, 256)) < 0.04, axis=1)
+    maxd = (depth * synth.SCALE_FACTORS[octave].astype(np.float64) * rng.uniform(0.9, 1.05, n_kp)).astype(f32)
+    mind = (maxd / f32(synth.SCALE_FACTORS[-1]) * f32(0.5)).astype(f32)
+    # normals: most look back at the camera, a few sideways (rejected by the 60 degree gate)
+    Ow = (-t).astype(f32)
+    PO = (pos - Ow).astype(f32)
+    normal = (PO / np.linalg.norm(PO, axis=1, keepdims=True)).astype(f32)
+    side = rng.uniform(0, 1, n_kp) < 0.05
+    normal[side] = np.array([1.0, 0.0, 0.0], dtype=f32)
+    bad = rng.uniform(0, 1, n_kp) < 0.03
+    matched_in = -np.ones(n_kp, dtype=np.int32)
+    held = rng.permutation(n_kp)[:50]
+    matched_in[held] = held                                      # slots already matched; those points count as "already found"
+    th, ratio = 4, 1.3
+    kf = host.HostFrame(xy, octave, desc)
+    try:
+        n, matched, matched_kf = kf.search_sim3(np.concatenate([[0, 0, 0, 1], ts, [scale]]), pos, mp_desc, np.stack([mind, maxd], axis=1),
+                                                normal, bad, matched_in, th=th, ratio_hamming=ratio, with_keyframes=with_keyframes)
+    finally:
+        kf.close()
+    # ---- reference pipeline in float32
+    pc = (pos + t).astype(f32)
+    fx, fy, cx, cy = (f32(v) for v in (synth.FX, synth.FY, synth.CX, synth.CY))
+    if with_keyframes:
+        invz = (f32(1) / pc[:, 2]).astype(f32)
+        u = (fx * (pc[:, 0] * invz).astype(f32) + cx).astype(f32)
+        v = (fy * (pc[:, 1] * invz).astype(f32) + cy).astype(f32)
+    else:
+        u = (fx * pc[:, 0] / pc[:, 2] + cx).astype(f32)
+        v = (fy * pc[:, 1] / pc[:, 2] + cy).astype(f32)
+    dist = np.sqrt((PO[:, 0] * PO[:, 0] + PO[:, 1] * PO[:, 1]).astype(f32) + (PO[:, 2] * PO[:, 2]).astype(f32)).astype(f32)
+    dot = ((PO[:, 0] * normal[:, 0] + PO[:, 1] * normal[:, 1]).astype(f32) + (PO[:, 2] * normal[:, 2]).astype(f32)).astype(f32)
+    found = np.zeros(n_kp, dtype=bool)
+    found[held] = True
+    ok = ~bad & ~found & (pc[:, 2] >= 0) & (u >= 0) & (u < synth.IMG_W) & (v >= 0) & (v < synth.IMG_H)
+    ok &= ~((dist < f32(0.8) * mind) | (dist > f32(1.2) * maxd))
+    ok &= ~(dot.astype(np.float64) < 0.5 * dist.astype(np.float64))
+    lvl = np.clip(np.ceil(np.log((maxd / dist).astype(f32)) / np.log(f32(synth.SCALE_FACTOR))).astype(np.int64), 0, synth.N_LEVELS - 1).astype(np.int32)
+    radius = (f32(th) * synth.SCALE_FACTORS[lvl]).astype(f32)
+    qsel = np.nonzero(ok)[0]
+    # KeyFrame::GetFeaturesInArea has no level filter; the loop keeps levels L-1..L: same order as a filtered list
+    off, idx = synth.features_in_area_lists(xy[:, 0], xy[:, 1], octave, u[qsel], v[qsel], radius[qsel], lvl[qsel] - 1, lvl[qsel])
+    # a query whose (unfiltered) window is empty is skipped; one whose filtered list is empty never beats 256: same outcome
+    n_ref, assign_q, _ = ob.orb_match_last_frame(mp_desc[qsel], desc, off, idx, np.zeros(len(qsel), f32), np.zeros(n_kp, f32),
+                                                 th_high=int(np.floor(50 * f32(ratio))), check_orientation=False,
+                                                 occupied=(matched_in >= 0).astype(np.uint8))
+    ref = np.where(assign_q >= 0, qsel[np.maximum(assign_q, 0)], -1).astype(np.int32)
+    ref = np.where(matched_in >= 0, matched_in, ref)
+    assert n == n_ref and n > 100
+    np.testing.assert_array_equal(matched, ref)
+    if with_keyframes:
+        new = (matched_in < 0) & (matched >= 0)
+        np.testing.assert_array_equal(matched_kf[new], matched[new])      # point j was handed in with source keyframe j
+        assert (matched_kf[~new] == -1).all()
+    assert side.any() and bad.any()
+
+
 def test_local_inertial_ba_through_the_reference_signature(ob):
     """Optimizer::LocalInertialBA(KeyFrame*, bool*, Map*, int&x4, bLarge, bRecInit) on a KeyFrame/MapPoint/IMU graph vs the
     inertial oracle on the problem the host layer packed; write-back of poses, velocities, biases and points in float."""
