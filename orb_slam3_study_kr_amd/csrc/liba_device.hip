@@ -23,6 +23,12 @@ namespace osh {
 
 constexpr int kLT = 512;      // threads of the persistent block
 constexpr int kLNB = 24;      // LDL^T panel width
+constexpr int kStageEdges = 32;                                   // edges of a pose row staged in LDS per pass of the Schur loop
+constexpr int kStageMaxN = 32;                                    // partner-edge list entries per staged edge (N <= 25 optimisable keyframes)
+constexpr size_t kStageDoublesPerWave = kStageEdges * 18 + (kStageEdges * kStageMaxN + 1) / 2;
+__host__ __device__ constexpr size_t liba_scratch_doubles(int W) {
+  return ldlt_lds_doubles(kLNB, W, kLT) > (kLT / 64) * kStageDoublesPerWave ? ldlt_lds_doubles(kLNB, W, kLT) : (kLT / 64) * kStageDoublesPerWave;
+}
 constexpr double kGrav = (double)9.81f;   // g << 0, 0, -IMU::GRAVITY_VALUE (a float constant)
 
 struct LibaDesc {
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(kLT) void k_liba(LibaView v, int W) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int N = d.N, n = d.n, L = d.L;
   // LDS carve: [0, ldlt) the LDL^T scratch (reused as general scratch between solves), then control words
-  double* shw = sh + ldlt_lds_doubles(kLNB, W, kLT);      // [kLT/64] reductions
+  double* shw = sh + liba_scratch_doubles(W);             // [kLT/64] reductions
   double* H = v.H + d.H_off; double* S = v.S + d.H_off;
   double* b = v.b + d.b_off; double* bs = v.bs + d.b_off; double* xg = v.x + d.b_off;
   double* Hpl = v.Hpl + (size_t)d.edge_off * 18;
@@ -442,43 +448,73 @@ __global__ __launch_bounds__(kLT) void k_liba(LibaView v, int W) {
       for (int k = tid; k < n * n; k += kLT) { const int r = k / n, c = k - r * n; S[k] = H[k] + ((r == c) ? lambda : 0.0); }
       for (int k = tid; k < n; k += kLT) bs[k] = b[k];
       __syncthreads();
-      // Schur rows (block_solver.hpp:381-432): wavefront per pose row i, lane (t, col) owns column col of S(i, base+t)
+      // Schur rows (block_solver.hpp:381-432): one wavefront per pose row i; lane (t, col) owns column col of the blocks
+      // S(i, i + 10 g + t), g = 0..2.  The row's edges are taken 32 at a time: lane k of the pass loads edge k (its landmark's
+      // Dinv, its Hpl block, the landmark's partner-edge list), forms BD = B Dinv once and parks it in the wave's LDS slice;
+      // all lanes then walk the 32 staged edges out of LDS, so the only global load left in the inner loop is the partner
+      // block (independent across edges -> several in flight).  Before: every edge cost three dependent global loads, ~1 us.
       for (int i = wave; i < N; i += kLT / 64) {
         const int t = lane / 6, col = lane - t * 6;
+        double* stBD = sh + (size_t)wave * kStageDoublesPerWave;
+        int* stq = reinterpret_cast<int*>(stBD + kStageEdges * 18);
         double ci[6] = {0, 0, 0, 0, 0, 0};
-        for (int base = i; base < N; base += 10) {
-          const int i2 = base + t;
-          const bool owner = (t < 10) && (i2 < N);
-          double acc[6] = {0, 0, 0, 0, 0, 0};
-          for (int idx = po[i]; idx < po[i + 1]; ++idx) {
-            const int e = v.pel_edge[(size_t)d.pel_off + idx];
+        double acc[3][6];
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+          for (int r = 0; r < 6; ++r) acc[g][r] = 0.0;
+        const int ngroups = (N - i + 9) / 10;   // <= 3 for N <= 25 + the guard below
+        for (int c0 = po[i]; c0 < po[i + 1]; c0 += kStageEdges) {
+          const int cnt = min(kStageEdges, po[i + 1] - c0);
+          if (lane < cnt) {
+            const int e = v.pel_edge[(size_t)d.pel_off + c0 + lane];
             const int j = v.e_point[(size_t)d.edge_off + e];
             const double* Dj = dinv + (size_t)j * 9;
             const double* Be = Hpl + (size_t)e * 18;
-            double BD[18];
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
               const double x0 = Be[r * 3], x1 = Be[r * 3 + 1], x2 = Be[r * 3 + 2];
-              BD[r * 3 + 0] = x0 * Dj[0] + x1 * Dj[1] + x2 * Dj[2];
-              BD[r * 3 + 1] = x0 * Dj[1] + x1 * Dj[3] + x2 * Dj[4];
-              BD[r * 3 + 2] = x0 * Dj[2] + x1 * Dj[4] + x2 * Dj[5];
-              if (base == i) ci[r] += x0 * Dj[6] + x1 * Dj[7] + x2 * Dj[8];
+              stBD[lane * 18 + r * 3 + 0] = x0 * Dj[0] + x1 * Dj[1] + x2 * Dj[2];
+              stBD[lane * 18 + r * 3 + 1] = x0 * Dj[1] + x1 * Dj[3] + x2 * Dj[4];
+              stBD[lane * 18 + r * 3 + 2] = x0 * Dj[2] + x1 * Dj[4] + x2 * Dj[5];
+              ci[r] += x0 * Dj[6] + x1 * Dj[7] + x2 * Dj[8];
             }
-            if (owner) {
-              const int q = lmpe[(size_t)j * N + i2];
-              if (q >= 0) {
-                const double* Bq = Hpl + (size_t)q * 18 + col * 3;
-                const double y0 = Bq[0], y1 = Bq[1], y2 = Bq[2];
+            for (int p2 = 0; p2 < N; ++p2) stq[lane * kStageMaxN + p2] = lmpe[(size_t)j * N + p2];
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 4
+          for (int k = 0; k < cnt; ++k) {
+            double BD[18];
 #pragma unroll
-                for (int r = 0; r < 6; ++r) acc[r] += BD[r * 3] * y0 + BD[r * 3 + 1] * y1 + BD[r * 3 + 2] * y2;
+            for (int m = 0; m < 18; ++m) BD[m] = stBD[k * 18 + m];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+              const int i2 = i + 10 * g + t;
+              if (g < ngroups && t < 10 && i2 < N) {
+                const int q = stq[k * kStageMaxN + i2];
+                if (q >= 0) {
+                  const double* Bq = Hpl + (size_t)q * 18 + col * 3;
+                  const double y0 = Bq[0], y1 = Bq[1], y2 = Bq[2];
+#pragma unroll
+                  for (int r = 0; r < 6; ++r) acc[g][r] += BD[r * 3] * y0 + BD[r * 3 + 1] * y1 + BD[r * 3 + 2] * y2;
+                }
               }
             }
           }
-          if (owner) {
+          __builtin_amdgcn_wave_barrier();
+        }
 #pragma unroll
-            for (int r = 0; r < 6; ++r) S[(size_t)(6 * i + r) * n + 6 * i2 + col] -= acc[r];
+        for (int g = 0; g < 3; ++g) {
+          const int i2 = i + 10 * g + t;
+          if (g < ngroups && t < 10 && i2 < N) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) S[(size_t)(6 * i + r) * n + 6 * i2 + col] -= acc[g][r];
           }
         }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) ci[r] = dev::wave_sum(ci[r]);
         if (lane < 6) {
           double c = ci[0];
           if (lane == 1) c = ci[1]; else if (lane == 2) c = ci[2]; else if (lane == 3) c = ci[3];
@@ -651,8 +687,9 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
     EF += ef; LP += (size_t)d.L * d.N;
     n_max = std::max(n_max, d.n);
   }
+  if (n_max / 15 > 30) { set_error("inertial window with %d optimisable keyframes: the device path handles up to 30 (the reference uses 10 or 25)", n_max / 15); return OSH_ERR_UNSUPPORTED; }
   const int W = n_max + 8;
-  const size_t lds = (ldlt_lds_doubles(kLNB, W, kLT) + kLT / 64 + 8) * sizeof(double);
+  const size_t lds = (liba_scratch_doubles(W) + kLT / 64 + 8) * sizeof(double);
   if (lds > 160 * 1024 - 64) { set_error("inertial window with %d keyframes exceeds the LDS budget", n_max / 15); return OSH_ERR_UNSUPPORTED; }
   // ---- pack
   std::vector<double> h_pose(K * 24), h_vba(NV * 9), h_pts(L * 3), h_obs(E * 3), h_info(E);
