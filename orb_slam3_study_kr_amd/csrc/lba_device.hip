@@ -37,9 +37,11 @@ constexpr int kBlock = 256;        // threads per block of the edge/landmark ker
 constexpr int kChunkEdges = 256;   // edges handled per pass of a chunk (== kBlock)
 constexpr double kTau = 1e-5;      // OptimizationAlgorithmLevenberg::_tau
 constexpr int kMaxTrials = 10;     // maxTrialsAfterFailure
-constexpr int kSolveThreads = 256;  // one block per window in k_solve.  The factorisation is a chain of dependent pivots: two
-                                    // 256-thread blocks per CU (LDS <= 75 KB each) overlap their latencies, measured 1.21 ms per
-                                    // 512 windows against 1.70 ms for one 512-thread block per CU (128 / 192 / 384 threads: 1.79 / 1.39 / 1.65)
+// k_solve runs one block per window.  The factorisation is a chain of dependent pivots: with many windows two 256-thread
+// blocks per CU (LDS <= 75 KB each, 12-wide panels) overlap their latencies (measured 1.21 ms per 512 windows against 1.70 ms
+// for one 512-thread block per CU; 128 / 192 / 384 threads: 1.79 / 1.39 / 1.65); with fewer windows than CUs one 512-thread
+// block with 24-wide panels finishes a single system sooner.
+constexpr int kSolveThreadsBatch = 256, kSolveThreadsLatency = 512;
 
 struct WinDesc {
   int P, F, L, E;
@@ -732,38 +734,48 @@ __global__ __launch_bounds__(64) void k_lin_aux(BatchView bv) {
   if (lane == 0) { bv.chi_aux[blockIdx.x] = chi_acc; bv.dmax_aux[blockIdx.x] = dmax; }
 }
 
-// k_pose_reduce: Hpp_i (full symmetric 6x6), b_p(i) and the largest diagonal entry of pose i from
-// the item contributions, in plan order.  One thread per optimisable pose.
+// k_pose_reduce: Hpp_i (full symmetric 6x6), b_p(i) and the largest diagonal entry of pose i from the item
+// contributions, in plan order.  32 lanes per optimisable pose: lane k < 27 sums entry k of the contributions
+// (one contribution = 27 contiguous doubles -> coalesced, the loads of successive contributions are independent).
 __global__ __launch_bounds__(64) void k_pose_reduce(BatchView bv) {
-  const int gp = blockIdx.x * 64 + threadIdx.x;
+  const int gp = blockIdx.x * 2 + (threadIdx.x >> 5);
+  const int k = threadIdx.x & 31;
   if (gp >= bv.n_fposes) return;
   const int w = bv.fpose_win[gp];
   const LmView st = lm_view(bv.lm, w);
   if (!st.active || !st.need_lin) return;
   const int2 rg = bv.pose_crange[gp];
-  double a[27];
-#pragma unroll
-  for (int k = 0; k < 27; ++k) a[k] = 0.0;
-  for (int c = 0; c < rg.y; ++c) {
-    const double* src = bv.hcontrib + (size_t)(rg.x + c) * 27;
-#pragma unroll
-    for (int k = 0; k < 27; ++k) a[k] += src[k];
-  }
-  double* Ho = bv.Hpp + (size_t)gp * 36;
-  int m = 0;
-  double dm = 0.0;
-#pragma unroll
-  for (int r = 0; r < 6; ++r)
-#pragma unroll
-    for (int c = r; c < 6; ++c) {
-      Ho[r * 6 + c] = a[m];
-      Ho[c * 6 + r] = a[m];
-      if (r == c) dm = fmax(dm, fabs(a[m]));
-      ++m;
+  double a = 0.0;
+  if (k < 27) {
+    const double* src = bv.hcontrib + (size_t)rg.x * 27 + k;
+    int c = 0;
+    for (; c + 4 <= rg.y; c += 4) {
+      const double v0 = src[(size_t)c * 27], v1 = src[(size_t)(c + 1) * 27], v2 = src[(size_t)(c + 2) * 27], v3 = src[(size_t)(c + 3) * 27];
+      a += v0; a += v1; a += v2; a += v3;
     }
-#pragma unroll
-  for (int k = 0; k < 6; ++k) bv.bp[(size_t)gp * 6 + k] = a[21 + k];
-  bv.dmax_pose[gp] = dm;
+    for (; c < rg.y; ++c) a += src[(size_t)c * 27];
+    if (k < 21) {
+      // entry k of the upper triangle -> (r, cc)
+      int r = 0, rem = k;
+      while (rem >= 6 - r) { rem -= 6 - r; ++r; }
+      const int cc = r + rem;
+      double* Ho = bv.Hpp + (size_t)gp * 36;
+      Ho[r * 6 + cc] = a;
+      Ho[cc * 6 + r] = a;
+    } else {
+      bv.bp[(size_t)gp * 6 + (k - 21)] = a;
+    }
+  }
+  // largest diagonal entry: upper-triangle entries 0, 6, 11, 15, 18, 20 are the diagonal
+  __shared__ double shd[64];
+  shd[threadIdx.x] = fabs(a);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (k == 0) {
+    const double* d = shd + (threadIdx.x & 32);
+    bv.dmax_pose[gp] = fmax(fmax(fmax(d[0], d[6]), fmax(d[11], d[15])), fmax(d[18], d[20]));
+  }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -772,8 +784,9 @@ __global__ __launch_bounds__(64) void k_pose_reduce(BatchView bv) {
 // back-substitution, then the pose update T <- exp(x) T and the pose part of computeScale.
 // LDS: U panel [nb][W] (unscaled rows), L panel [nb][W] (rows / pivot), x [n], d [nb].
 // --------------------------------------------------------------------------------------------
-template <int NB>
-__global__ __launch_bounds__(kSolveThreads) void k_solve(BatchView bv, int W) {
+template <int NB, int NT>
+__global__ __launch_bounds__(NT) void k_solve(BatchView bv, int W) {
+  constexpr int kSolveThreads = NT;
   extern __shared__ __attribute__((aligned(16))) double sh[];   // all LDS scratch is dynamic (16-B aligned base)
   const int w = blockIdx.x;
   const WinDesc& wd = bv.win[w];
@@ -1066,7 +1079,7 @@ struct osh_lba_ctx {
   size_t n_items = 0, n_sym = 0, n_rblk = 0, n_contrib = 0, n_ccontrib = 0, n_aux_chunks = 0;
   long long plan_tile_steps = 0, plan_pair_blocks = 0;
   size_t S_total = 0;
-  int n_max = 0, solve_nb = 24, solve_W = 0;
+  int n_max = 0, solve_nb = 24, solve_W = 0, solve_threads = kSolveThreadsBatch;
   size_t solve_lds = 0, backsub_lds = 0;
   // device buffers
   DevBuf d_win, d_lm, d_chunks, d_fpose_win, d_pose_init, d_pose[2], d_pt_init, d_pt[2], d_cam;
@@ -1306,10 +1319,14 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   // ---- LDS budgets
   c->backsub_lds = (size_t)(3 * kChunkEdges + 4 + std::max(n_max, 1)) * sizeof(double);
   {
-    // Prefer two blocks per CU (75 KB each) as long as that leaves a panel width of at least 12 columns.
-    auto need = [&](int b) { return ((size_t)2 * b * (n_max + 8) + (n_max + 8) + 2 * b + kSolveThreads / 64 + 8) * sizeof(double); };
+    // Many windows: two 256-thread blocks per CU (75 KB each) as long as that leaves a panel width of at least 12 columns.
+    // Fewer windows than half the CUs: one 512-thread block per window with the widest panel that fits.
+    const bool latency = nw <= 128;
+    c->solve_threads = latency ? kSolveThreadsLatency : kSolveThreadsBatch;
+    auto need = [&](int b) { return ((size_t)2 * b * (n_max + 8) + (n_max + 8) + 2 * b + c->solve_threads / 64 + 8) * sizeof(double); };
     int nb = 0;
     for (size_t budget : {(size_t)75 * 1024, (size_t)150 * 1024}) {
+      if (latency && budget < 150 * 1024) continue;
       nb = 24;
       while (nb > 6 && need(nb) > budget) nb /= 2;  // 24 -> 12 -> 6 (template instantiations of k_solve)
       if (need(nb) <= budget && (nb >= 12 || budget > 75 * 1024)) break;
@@ -1402,9 +1419,10 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   // opt in to large dynamic LDS once per process
   static bool attr_done = false;
   if (!attr_done) {
-    OSH_HIP(hipFuncSetAttribute((const void*)k_solve<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-    OSH_HIP(hipFuncSetAttribute((const void*)k_solve<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-    OSH_HIP(hipFuncSetAttribute((const void*)k_solve<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+#define OSH_SOLVE_ATTR(NB, NT) OSH_HIP(hipFuncSetAttribute((const void*)k_solve<NB, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64))
+    OSH_SOLVE_ATTR(24, kSolveThreadsBatch); OSH_SOLVE_ATTR(12, kSolveThreadsBatch); OSH_SOLVE_ATTR(6, kSolveThreadsBatch);
+    OSH_SOLVE_ATTR(24, kSolveThreadsLatency); OSH_SOLVE_ATTR(12, kSolveThreadsLatency); OSH_SOLVE_ATTR(6, kSolveThreadsLatency);
+#undef OSH_SOLVE_ATTR
     OSH_HIP(hipFuncSetAttribute((const void*)k_backsub, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     attr_done = true;
   }
@@ -1430,6 +1448,17 @@ static bool snapshot_stop(osh_lba_ctx* c) {
       OSH_TRY(launch_check(#name));                                                           \
     }                                                                                         \
   } while (0)
+
+// the instantiation of k_solve chosen at upload time (panel width x threads per block)
+static int launch_solve(osh_lba_ctx* c, hipStream_t s) {
+  const dim3 grid((unsigned)c->n_windows);
+#define OSH_SOLVE_CASE(NB, NT) \
+  if (c->solve_nb == NB && c->solve_threads == NT) hipLaunchKernelGGL((k_solve<NB, NT>), grid, dim3(NT), c->solve_lds, s, c->bv, c->solve_W);
+  OSH_SOLVE_CASE(24, kSolveThreadsBatch) OSH_SOLVE_CASE(12, kSolveThreadsBatch) OSH_SOLVE_CASE(6, kSolveThreadsBatch)
+  OSH_SOLVE_CASE(24, kSolveThreadsLatency) OSH_SOLVE_CASE(12, kSolveThreadsLatency) OSH_SOLVE_CASE(6, kSolveThreadsLatency)
+#undef OSH_SOLVE_CASE
+  return launch_check("k_solve");
+}
 
 static int reset_state(osh_lba_ctx* c) {
   hipStream_t s = c->stream;
@@ -1471,14 +1500,16 @@ extern "C" int osh_lba_optimize(osh_lba_ctx* c) {
     LAUNCH(OSH_K_LINEARIZE, k_lin_items<0>, c->n_sym, 64, 0, c->bv);
     LAUNCH(OSH_K_LIN_POSE, k_lin_items<1>, c->n_sym, 64, 0, c->bv);
     LAUNCH(OSH_K_LIN_AUX, k_lin_aux, c->n_aux_chunks, 64, 0, c->bv);
-    LAUNCH(OSH_K_POSE_HESS, k_pose_reduce, (c->NFP + 63) / 64, 64, 0, c->bv);
+    LAUNCH(OSH_K_POSE_HESS, k_pose_reduce, (c->NFP + 1) / 2, 64, 0, c->bv);
     LAUNCH(OSH_K_CONTROL, k_control, c->n_windows, 64, 0, c->bv, 0);
     LAUNCH(OSH_K_SCHUR, k_schur_items<true>, c->n_sym, 64, 0, c->bv, 0);
     LAUNCH(OSH_K_SCHUR_CROSS, k_schur_items<false>, c->n_items - c->n_sym, 64, 0, c->bv, (int)c->n_sym);
     LAUNCH(OSH_K_SCHUR_REDUCE, k_schur_reduce, (c->n_rblk + 6) / 7, 256, 0, c->bv);
-    if (c->solve_nb == 24) LAUNCH(OSH_K_SOLVE, k_solve<24>, c->n_windows, kSolveThreads, c->solve_lds, c->bv, c->solve_W);
-    else if (c->solve_nb == 12) LAUNCH(OSH_K_SOLVE, k_solve<12>, c->n_windows, kSolveThreads, c->solve_lds, c->bv, c->solve_W);
-    else LAUNCH(OSH_K_SOLVE, k_solve<6>, c->n_windows, kSolveThreads, c->solve_lds, c->bv, c->solve_W);
+    {
+      const bool _t = c->timer.begin(OSH_K_SOLVE, s);
+      OSH_TRY(launch_solve(c, s));
+      if (_t) c->timer.end(s);
+    }
     LAUNCH(OSH_K_BACKSUB, k_backsub, c->n_chunks, kBlock, c->backsub_lds, c->bv);
     LAUNCH(OSH_K_RESIDUAL, k_residual, c->n_chunks, kBlock, 0, c->bv);
     if (c->any_stop) {
@@ -1546,7 +1577,7 @@ extern "C" int osh_lba_linearize(osh_lba_ctx* c, int32_t window, double* Hpp, do
     hipLaunchKernelGGL(k_lin_items<1>, dim3((unsigned)c->n_sym), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_lin_items<1>"));
   }
   if (c->n_aux_chunks) { hipLaunchKernelGGL(k_lin_aux, dim3((unsigned)c->n_aux_chunks), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_lin_aux")); }
-  if (c->NFP) { hipLaunchKernelGGL(k_pose_reduce, dim3((unsigned)((c->NFP + 63) / 64)), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_pose_reduce")); }
+  if (c->NFP) { hipLaunchKernelGGL(k_pose_reduce, dim3((unsigned)((c->NFP + 1) / 2)), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_pose_reduce")); }
   hipLaunchKernelGGL(k_control, dim3((unsigned)c->n_windows), dim3(64), 0, s, c->bv, 0);
   OSH_TRY(launch_check("k_control"));
   // per-edge chi2 through k_finalize needs "evaluated" semantics: emulate by a residual pass bookkeeping
@@ -1597,7 +1628,7 @@ extern "C" int osh_lba_debug_trial(osh_lba_ctx* c, int32_t window, double lambda
     hipLaunchKernelGGL(k_lin_items<1>, dim3((unsigned)c->n_sym), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_lin_items<1>"));
   }
   if (c->n_aux_chunks) { hipLaunchKernelGGL(k_lin_aux, dim3((unsigned)c->n_aux_chunks), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_lin_aux")); }
-  if (c->NFP) { hipLaunchKernelGGL(k_pose_reduce, dim3((unsigned)((c->NFP + 63) / 64)), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_pose_reduce")); }
+  if (c->NFP) { hipLaunchKernelGGL(k_pose_reduce, dim3((unsigned)((c->NFP + 1) / 2)), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_pose_reduce")); }
   hipLaunchKernelGGL(k_control, dim3((unsigned)c->n_windows), dim3(64), 0, s, c->bv, 0);
   OSH_TRY(launch_check("k_control"));
   OSH_HIP(hipStreamSynchronize(s));
@@ -1612,10 +1643,7 @@ extern "C" int osh_lba_debug_trial(osh_lba_ctx* c, int32_t window, double lambda
   OSH_HIP(hipStreamSynchronize(s));
   if (S && d.n) OSH_HIP(hipMemcpy(S, c->d_S.as<double>() + d.S_off, (size_t)d.n * d.n * 8, hipMemcpyDeviceToHost));
   if (bs && d.n) OSH_HIP(hipMemcpy(bs, c->d_bs.as<double>() + (size_t)d.fpose_off * 6, (size_t)d.n * 8, hipMemcpyDeviceToHost));
-  if (c->solve_nb == 24) hipLaunchKernelGGL(k_solve<24>, dim3((unsigned)c->n_windows), dim3(kSolveThreads), c->solve_lds, s, c->bv, c->solve_W);
-  else if (c->solve_nb == 12) hipLaunchKernelGGL(k_solve<12>, dim3((unsigned)c->n_windows), dim3(kSolveThreads), c->solve_lds, s, c->bv, c->solve_W);
-  else hipLaunchKernelGGL(k_solve<6>, dim3((unsigned)c->n_windows), dim3(kSolveThreads), c->solve_lds, s, c->bv, c->solve_W);
-  OSH_TRY(launch_check("k_solve"));
+  OSH_TRY(launch_solve(c, s));
   hipLaunchKernelGGL(k_backsub, dim3((unsigned)c->n_chunks), dim3(kBlock), c->backsub_lds, s, c->bv);
   OSH_TRY(launch_check("k_backsub"));
   OSH_HIP(hipStreamSynchronize(s));
