@@ -18,10 +18,15 @@ class Frame {
                                         const int maxLevel = -1, const bool bRight = false) const;
   void AssignFeaturesToGrid();   // src/Frame.cc:397-417 with PosInGrid :726-736
   Sophus::SE3f GetPose() const { return mTcw; }
+  void SetPose(const Sophus::SE3f& Tcw) { mTcw = Tcw; ++mnPoseSets; }   // src/Frame.cc:291-296 (UpdatePoseMatrices omitted)
 
   int N = 0;
   int Nleft = -1, Nright = -1;
   float mbf = 0, mb = 0;
+  float fx = 0, fy = 0, cx = 0, cy = 0;          // static members in the reference (include/Frame.h:208-213)
+  std::vector<float> mvInvLevelSigma2;
+  GeometricCamera* mpCamera2 = nullptr;
+  int mnPoseSets = 0;                            // test-double bookkeeping
   std::vector<cv::KeyPoint> mvKeys, mvKeysUn, mvKeysRight;
   std::vector<float> mvuRight;
   std::vector<MapPoint*> mvpMapPoints;

@@ -4,6 +4,7 @@
 #ifndef MAPPOINT_H
 #define MAPPOINT_H
 #include <map>
+#include <mutex>
 #include <tuple>
 #include "orbslam3_compat.h"
 namespace ORB_SLAM3 {
@@ -30,6 +31,7 @@ class MapPoint {
   int PredictScale(const float& currentDist, KeyFrame* pKF);   // src/MapPoint.cc:514-529
   Eigen::Vector3f GetNormal() { return mNormalVector; }
 
+  static std::mutex mGlobalMutex;             // include/MapPoint.h:151 (held while PoseOptimization reads the positions)
   long unsigned int mnId;
   long unsigned int mnBALocalForKF = 0;
   Eigen::Vector3f mPosGBA;                    // include/MapPoint.h:147-148

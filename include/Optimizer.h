@@ -2,6 +2,7 @@
  * reference's signatures (include/Optimizer.h:50-57,86).  Drop-in: same mangled symbols, same side effects. */
 #ifndef OPTIMIZER_H
 #define OPTIMIZER_H
+#include "Frame.h"
 #include "KeyFrame.h"
 #include "Map.h"
 #include <vector>
@@ -14,6 +15,9 @@ class Optimizer {
                                bool* pbStopFlag = NULL, const unsigned long nLoopKF = 0, const bool bRobust = true);
   void static GlobalBundleAdjustemnt(Map* pMap, int nIterations = 5, bool* pbStopFlag = NULL, const unsigned long nLoopKF = 0,
                                      const bool bRobust = true);
+  // src/Optimizer.cc:815-1114 (csrc/host/OptimizerPose.cc): pose of a tracked frame from its map-point matches, four rounds of
+  // optimize(10) with outlier re-classification; returns the number of inlier correspondences and sets mvbOutlier / the pose.
+  int static PoseOptimization(Frame* pFrame);
   // src/Optimizer.cc:1116-1498.  num_MPs is never assigned by the reference either.
   void static LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF, int& num_OptKF,
                                     int& num_MPs, int& num_edges);

@@ -166,6 +166,39 @@ int osh_lba_set_profiling(osh_lba_ctx* ctx, int enable);
 int osh_lba_get_profile(osh_lba_ctx* ctx, int64_t launches[OSH_K_COUNT], double total_ms[OSH_K_COUNT]);
 const char* osh_lba_kernel_name(int kernel_id);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Pose-only optimisation of a tracked frame: replaces what `Optimizer::PoseOptimization(Frame*)` does between building its
+ * unary edges and `pFrame->SetPose` (reference src/Optimizer.cc:815-1114; edges EdgeSE3ProjectXYZOnlyPose
+ * src/OptimizableTypes.cpp:49-61 and g2o::EdgeStereoSE3ProjectXYZOnlyPose types_six_dof_expmap.cpp:306-405; one 6-dof
+ * vertex, Levenberg-Marquardt with a dense 6x6 solve, four rounds of optimize(iterations[r]) that each restart from the
+ * initial pose, re-classify every edge with chi2 > chi2_mono/stereo[r] (float compare, :1035-1105) and drop the Huber kernel
+ * after the third round).  One frame per block on the device; `n` frames per call. */
+typedef struct osh_pose_problem {
+  int32_t n_edges;
+  const double* pose_qt;      /* [7] initial Tcw: unit quaternion x y z w, translation */
+  const double* cam;          /* [5] fx fy cx cy bf */
+  const double* points;       /* [n_edges*3] world position of the map point of every edge (e->Xw) */
+  const uint8_t* edge_kind;   /* [n_edges] OSH_EDGE_MONO / OSH_EDGE_STEREO */
+  const double* edge_obs;     /* [n_edges*3] u v u_right (third unused for mono) */
+  const double* edge_info;    /* [n_edges] invSigma2 */
+  double huber_mono, huber_stereo;   /* deltaMono, deltaStereo of rounds 0..2 */
+  float chi2_mono[4], chi2_stereo[4];
+  int32_t iterations[4];
+} osh_pose_problem;
+
+typedef struct osh_pose_result {
+  double pose_qt[7];          /* estimate after the last round */
+  uint8_t* outlier;           /* [n_edges] mvbOutlier after the last round (may be NULL) */
+  double* edge_chi2;          /* [n_edges] the chi2 each edge was classified with in the last round (may be NULL) */
+  int32_t n_bad;              /* outliers of the last round */
+  int32_t rounds;             /* rounds executed (the loop stops after one round when there are fewer than 10 edges) */
+  int32_t iterations[4];      /* LM iterations of every round */
+  double chi2_final[4];       /* activeRobustChi2 at the end of every round */
+  int32_t status;
+} osh_pose_result;
+
+int osh_pose_optimize(osh_lba_ctx* ctx, int32_t n, const osh_pose_problem* problems, osh_pose_result* results);
+
 /* Host-only self check of the Schur work plan built at upload time (needs no GPU): groups the
  * landmarks of `problem` by observer set exactly as osh_lba_upload does, verifies that the plan
  * covers every observer pair of every landmark exactly once and returns

@@ -111,6 +111,10 @@ int osh_host_search_sim3(osh_host_frame* f, const float scw[8], int32_t n_mp, co
                          const float* mp_min_max_dist, const float* mp_normal, const uint8_t* mp_bad,
                          const int32_t* matched_in, int32_t th, float ratio_hamming, int32_t with_keyframes,
                          int32_t* matched_out, int32_t* matched_kf_out);
+/* Optimizer::PoseOptimization(&frame) (src/Optimizer.cc:815-1114): kp_mp[k] = map point matched to keypoint k (-1 none);
+ * returns the inlier count, the optimised pose and mvbOutlier (keypoints without a match keep the value 1 they are preset to). */
+int osh_host_frame_pose_optimization(osh_host_frame* f, int32_t n_mp, const float* mp_pos, const int32_t* kp_mp,
+                                     const float* inv_level_sigma2, int32_t n_levels, float pose_out[7], uint8_t* outlier_out);
 #ifdef __cplusplus
 }
 #endif

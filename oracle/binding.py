@@ -39,6 +39,8 @@ def load(native: bool = False) -> C.CDLL:
     d, i32, u8 = capi.c_double_p, capi.c_int32_p, capi.c_uint8_p
     lib.oracle_lba_solve.restype = C.c_int
     lib.oracle_lba_solve.argtypes = [C.POINTER(capi.LbaProblem), C.POINTER(capi.LbaResult)]
+    lib.oracle_pose_optimize.restype = C.c_int
+    lib.oracle_pose_optimize.argtypes = [C.POINTER(capi.PoseProblem), C.POINTER(capi.PoseResult)]
     lib.oracle_lba_linearize.restype = C.c_int
     lib.oracle_lba_linearize.argtypes = [C.POINTER(capi.LbaProblem)] + [d] * 7
     lib.oracle_lba_schur_step.restype = C.c_int
@@ -221,6 +223,18 @@ def orb_match_last_frame(query, train, cand_off, cand_idx, query_angle, train_an
                                         capi.ptr(qa, capi.c_float_p), capi.ptr(ta, capi.c_float_p), th_high,
                                         int(check_orientation), _u8(occ), _i32(assign))
     return int(n), assign, occ
+
+
+# ------------------------------------------------------------------ pose-only optimisation
+def pose_optimize(f, native: bool = False):
+    from orb_slam3_study_kr_amd.synth import PoseResultArrays
+    lib = load(native)
+    res = PoseResultArrays(f)
+    prob = f.as_struct()
+    rc = lib.oracle_pose_optimize(C.byref(prob), C.byref(res.struct))
+    if rc != 0:
+        raise RuntimeError(f"oracle_pose_optimize failed: {rc}")
+    return res.read_scalars(res.struct)
 
 
 # ------------------------------------------------------------------ local inertial BA

@@ -25,6 +25,9 @@ int  oracle_edge_depth_positive(const double qt[7], const double X[3]);
 void oracle_huber(double e, double delta, double rho[3]);
 int  oracle_ldlt_solve(int n, double* A, const double* b, double* x, double* tmp);
 
+/* ---- pose-only optimisation of a frame (pose_oracle.c) ---- */
+int  oracle_pose_optimize(const osh_pose_problem* p, osh_pose_result* res);
+
 /* ---- local inertial BA (liba_oracle.c) ---- */
 int  oracle_liba_solve(const osh_liba_problem* p, osh_liba_result* res);
 int  oracle_liba_linearize(const osh_liba_problem* p, double* H, double* b, double* Hll, double* Hpl, double* chi2);

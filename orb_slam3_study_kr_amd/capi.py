@@ -61,6 +61,27 @@ class LbaResult(C.Structure):
     ]
 
 
+class PoseProblem(C.Structure):
+    """``osh_pose_problem`` (include/orbslam3_hip.h)."""
+
+    _fields_ = [
+        ("n_edges", C.c_int32), ("pose_qt", c_double_p), ("cam", c_double_p), ("points", c_double_p),
+        ("edge_kind", c_uint8_p), ("edge_obs", c_double_p), ("edge_info", c_double_p),
+        ("huber_mono", C.c_double), ("huber_stereo", C.c_double),
+        ("chi2_mono", C.c_float * 4), ("chi2_stereo", C.c_float * 4), ("iterations", C.c_int32 * 4),
+    ]
+
+
+class PoseResult(C.Structure):
+    """``osh_pose_result`` (include/orbslam3_hip.h)."""
+
+    _fields_ = [
+        ("pose_qt", C.c_double * 7), ("outlier", c_uint8_p), ("edge_chi2", c_double_p),
+        ("n_bad", C.c_int32), ("rounds", C.c_int32), ("iterations", C.c_int32 * 4), ("chi2_final", C.c_double * 4),
+        ("status", C.c_int32),
+    ]
+
+
 OSH_PREINT_FLOATS = 72
 
 
@@ -132,6 +153,7 @@ _SIGNATURES = {
     "osh_lba_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "osh_lba_get_profile": (C.c_int, [C.c_void_p, c_int64_p, c_double_p]),
     "osh_lba_kernel_name": (C.c_char_p, [C.c_int]),
+    "osh_pose_optimize": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(PoseProblem), C.POINTER(PoseResult)]),
     "osh_lba_schur_plan_stats": (C.c_int, [C.POINTER(LbaProblem), c_int64_p]),
     "osh_orb_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "osh_orb_destroy": (None, [C.c_void_p]),
@@ -177,6 +199,7 @@ _HOST_SIGNATURES = {
                                                c_int32_p, C.c_float, C.c_float, c_int32_p]),
     "osh_host_search_last_frame": (C.c_int, [C.c_void_p, C.c_void_p, c_int32_p, C.c_int32, c_float_p, c_uint8_p, C.c_float, C.c_int32,
                                              C.c_int32, c_int32_p]),
+    "osh_host_frame_pose_optimization": (C.c_int, [C.c_void_p, C.c_int32, c_float_p, c_int32_p, c_float_p, C.c_int32, c_float_p, c_uint8_p]),
     "osh_host_search_sim3": (C.c_int, [C.c_void_p, c_float_p, C.c_int32, c_float_p, c_uint8_p, c_float_p, c_float_p, c_uint8_p, c_int32_p,
                                        C.c_int32, C.c_float, C.c_int32, c_int32_p, c_int32_p]),
     "osh_host_pack_gba": (C.c_int, [C.c_void_p, c_int32_p, c_double_p, c_double_p, c_double_p, c_int32_p, c_int32_p, c_uint8_p, c_double_p,

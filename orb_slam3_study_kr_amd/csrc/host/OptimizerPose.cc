@@ -1,0 +1,85 @@
+// OptimizerPose.cc -- ORB_SLAM3::Optimizer::PoseOptimization on MI355X.
+//
+// Host side: the edge construction of src/Optimizer.cc:815-1017 flattened into an osh_pose_problem, the device runs the
+// four optimise / classify rounds (:1019-1108, csrc/pose_device.hip), the host writes mvbOutlier and the pose back
+// (:1110-1114).  Monocular and rectified-stereo / RGB-D frames (pFrame->mpCamera2 == NULL).
+#include <cmath>
+#include <cstdio>
+#include <mutex>
+#include <vector>
+
+#include "Optimizer.h"
+#include "host_pack.h"
+#include "orbslam3_hip.h"
+
+namespace ORB_SLAM3 {
+
+int Optimizer::PoseOptimization(Frame* pFrame) {
+  if (pFrame->mpCamera2) {
+    std::fprintf(stderr, "PoseOptimization: fisheye-stereo frames (mpCamera2) are not supported by the MI355X path yet\n");
+    return 0;
+  }
+  int nInitialCorrespondences = 0;
+  const Sophus::SE3f Tcw = pFrame->GetPose();
+  const Eigen::Quaterniond q = Tcw.unit_quaternion().cast<double>();   // :833-834 float -> double
+  const Eigen::Vector3d t = Tcw.translation().cast<double>();
+  const double pose_qt[7] = {q.x(), q.y(), q.z(), q.w(), t[0], t[1], t[2]};
+  const double cam[5] = {pFrame->fx, pFrame->fy, pFrame->cx, pFrame->cy, pFrame->mbf};   // :928-932
+  const int N = pFrame->N;
+  std::vector<double> points, obs, info;
+  std::vector<uint8_t> kind;
+  std::vector<int> index;   // keypoint of every edge (vnIndexEdgeMono / vnIndexEdgeStereo merged, edge order = keypoint order)
+  points.reserve((size_t)N * 3); obs.reserve((size_t)N * 3); info.reserve(N); kind.reserve(N); index.reserve(N);
+  {
+    std::unique_lock<std::mutex> lock(MapPoint::mGlobalMutex);
+    for (int i = 0; i < N; i++) {
+      MapPoint* pMP = pFrame->mvpMapPoints[i];
+      if (!pMP) continue;
+      nInitialCorrespondences++;
+      pFrame->mvbOutlier[i] = false;
+      const cv::KeyPoint& kpUn = pFrame->mvKeysUn[i];
+      const float kp_ur = pFrame->mvuRight[i];
+      const bool stereo = !(kp_ur < 0);   // mono if mvuRight < 0 (:871), stereo otherwise
+      if (!stereo) {
+        // the mono edge projects through pFrame->mpCamera (:897); the device keeps one intrinsics row per frame
+        GeometricCamera* c = pFrame->mpCamera;
+        if (!c || c->GetType() != GeometricCamera::CAM_PINHOLE || c->getParameter(0) != pFrame->fx || c->getParameter(1) != pFrame->fy ||
+            c->getParameter(2) != pFrame->cx || c->getParameter(3) != pFrame->cy) {
+          std::fprintf(stderr, "PoseOptimization: monocular observation through a camera that is not the frame's pinhole model; not supported yet\n");
+          return 0;
+        }
+      }
+      const Eigen::Vector3d Xw = pMP->GetWorldPos().cast<double>();
+      points.push_back(Xw[0]); points.push_back(Xw[1]); points.push_back(Xw[2]);
+      obs.push_back(kpUn.pt.x); obs.push_back(kpUn.pt.y); obs.push_back(stereo ? kp_ur : -1.0);
+      info.push_back(pFrame->mvInvLevelSigma2[kpUn.octave]);
+      kind.push_back(stereo ? OSH_EDGE_STEREO : OSH_EDGE_MONO);
+      index.push_back(i);
+    }
+  }
+  if (nInitialCorrespondences < 3) return 0;   // :1012-1013
+
+  osh_lba_ctx* ctx = HostSolverContext();
+  if (!ctx) return 0;
+  osh_pose_problem prob;
+  prob.n_edges = (int32_t)index.size();
+  prob.pose_qt = pose_qt; prob.cam = cam; prob.points = points.data(); prob.edge_kind = kind.data();
+  prob.edge_obs = obs.data(); prob.edge_info = info.data();
+  prob.huber_mono = (double)(float)std::sqrt(5.991);     // const float deltaMono = sqrt(5.991) (:858)
+  prob.huber_stereo = (double)(float)std::sqrt(7.815);   // (:859)
+  for (int k = 0; k < 4; ++k) { prob.chi2_mono[k] = 5.991f; prob.chi2_stereo[k] = 7.815f; prob.iterations[k] = 10; }   // :1016-1018
+  std::vector<uint8_t> outlier(index.size());
+  osh_pose_result res;
+  res.outlier = outlier.data(); res.edge_chi2 = nullptr;
+  if (osh_pose_optimize(ctx, 1, &prob, &res) != OSH_OK) {
+    std::fprintf(stderr, "PoseOptimization: device solve failed (%s); frame left untouched\n", osh_last_error());
+    return 0;
+  }
+  for (size_t e = 0; e < index.size(); ++e) pFrame->mvbOutlier[index[e]] = outlier[e] != 0;
+  const double* qt = res.pose_qt;
+  const Sophus::SE3f pose(Eigen::Quaterniond(qt[3], qt[0], qt[1], qt[2]).cast<float>(), Eigen::Vector3d(qt[4], qt[5], qt[6]).cast<float>());
+  pFrame->SetPose(pose);   // :1111-1112
+  return nInitialCorrespondences - res.n_bad;
+}
+
+}  // namespace ORB_SLAM3

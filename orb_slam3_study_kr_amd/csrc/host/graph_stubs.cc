@@ -8,6 +8,8 @@
 
 namespace ORB_SLAM3 {
 
+std::mutex MapPoint::mGlobalMutex;
+
 // src/KeyFrame.cc:109-122: cache Rcw, Twc and the IMU position Owb = Rwc * tcb + twc
 void KeyFrame::SetPose(const Sophus::SE3f& Tcw) {
   mTcw = Tcw;

@@ -428,3 +428,22 @@ extern "C" int osh_host_search_sim3(osh_host_frame* f, const float scw[8], int32
   }
   return n;
 }
+
+// Optimizer::PoseOptimization(&frame): kp_mp[k] = map point matched to keypoint k (-1 none), map points by position.
+extern "C" int osh_host_frame_pose_optimization(osh_host_frame* f, int32_t n_mp, const float* mp_pos, const int32_t* kp_mp,
+                                                const float* inv_level_sigma2, int32_t n_levels, float pose_out[7], uint8_t* outlier_out) {
+  if (!f) return -1;
+  Frame& F = f->F;
+  std::vector<uint8_t> nodesc((size_t)n_mp * 32, 0);
+  auto pts = make_points(&f->map, n_mp, nodesc.data(), mp_pos, nullptr);
+  F.fx = f->cam->getParameter(0); F.fy = f->cam->getParameter(1); F.cx = f->cam->getParameter(2); F.cy = f->cam->getParameter(3);
+  F.mvInvLevelSigma2.assign(inv_level_sigma2, inv_level_sigma2 + n_levels);
+  for (int k = 0; k < F.N; ++k) { F.mvpMapPoints[k] = kp_mp[k] >= 0 ? pts[kp_mp[k]].get() : nullptr; F.mvbOutlier[k] = true; }
+  const int n = Optimizer::PoseOptimization(&F);
+  const Sophus::SE3f T = F.GetPose();
+  pose_out[0] = T.unit_quaternion().x(); pose_out[1] = T.unit_quaternion().y(); pose_out[2] = T.unit_quaternion().z(); pose_out[3] = T.unit_quaternion().w();
+  pose_out[4] = T.translation()(0); pose_out[5] = T.translation()(1); pose_out[6] = T.translation()(2);
+  for (int k = 0; k < F.N; ++k) outlier_out[k] = F.mvbOutlier[k] ? 1 : 0;
+  F.mvpMapPoints.assign(F.N, nullptr);
+  return n;
+}

@@ -1,0 +1,330 @@
+// pose_device.hip -- pose-only optimisation of tracked frames on MI355X (gfx950): HIP kernel + C-ABI driver.
+//
+// Replaces, for a batch of frames, the solver part of ORB_SLAM3::Optimizer::PoseOptimization
+// (src/Optimizer.cc:815-1114): one VertexSE3Expmap, unary edges EdgeSE3ProjectXYZOnlyPose
+// (src/OptimizableTypes.cpp:49-61) / g2o::EdgeStereoSE3ProjectXYZOnlyPose
+// (Thirdparty/g2o/g2o/types/types_six_dof_expmap.cpp:306-405), four rounds of
+// optimizer.optimize(10) that restart from the frame's pose, re-classify every edge (chi2 as float against
+// 5.991 / 7.815, :1035-1105) and drop the Huber kernel after the third round (:1054).
+//
+// The problem is tiny (6 unknowns, O(10^3) edges) and latency-critical, so the whole of it -- all four rounds with
+// their Levenberg-Marquardt loops (g2o/core/sparse_optimizer.cpp:354-419, optimization_algorithm_levenberg.cpp:61-169)
+// and the dense 6x6 solve (g2o/solvers/linear_solver_dense.h:97-105) -- runs inside ONE block per frame: no host round
+// trip, thread per edge, fixed-order block reductions (bitwise reproducible).
+#include "common.h"
+#include "lba_math.h"
+#include <cfloat>
+#include <vector>
+
+namespace osh {
+
+constexpr int kPT = 256;   // threads per frame block
+
+struct PoseDesc {
+  int E, edge_off;
+  double qt[7], cam[5], huber_mono, huber_stereo;
+  float chi2_mono[4], chi2_stereo[4];
+  int iters[4];
+};
+struct PoseOut { double qt[7]; double chi2_final[4]; int iterations[4]; int n_bad, rounds; };
+struct PoseView {
+  const PoseDesc* desc;
+  PoseOut* out;
+  const double* X;            // [NE*3]
+  const unsigned char* kind;  // [NE]
+  const double* obs;          // [NE*3]
+  const double* info;         // [NE]
+  double* chi2;               // [NE] chi2 of the edge's _error as last computed
+  unsigned char* level;       // [NE] 1: classified outlier, outside the active set
+};
+
+// deterministic block sum: butterfly inside each wavefront, wavefronts added in order
+__device__ __forceinline__ double pose_block_sum(double v, double* sh) {
+  v = dev::wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int k = 0; k < kPT / 64; ++k) t += sh[k];
+  return t;
+}
+
+// computeActiveErrors + activeRobustChi2 at pose `qt` over the active edges; stores every edge's chi2
+__device__ double pose_eval(const PoseView& v, const PoseDesc& d, const double* qt, bool robust, double* sh) {
+  double acc = 0.0;
+  for (int e = threadIdx.x; e < d.E; e += kPT) {
+    const size_t ge = (size_t)d.edge_off + e;
+    if (v.level[ge]) continue;
+    const int kind = v.kind[ge];
+    double X[3], obs[3], r[3], Xc[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { X[k] = v.X[ge * 3 + k]; obs[k] = v.obs[ge * 3 + k]; }
+    const double c = dev::edge_residual(kind, qt, d.cam, X, obs, v.info[ge], r, Xc);
+    v.chi2[ge] = c;
+    if (robust) {
+      double r0, r1;
+      dev::huber(c, kind == OSH_EDGE_MONO ? d.huber_mono : d.huber_stereo, r0, r1);
+      acc += r0;
+    } else acc += c;
+  }
+  return pose_block_sum(acc, sh);
+}
+
+__global__ __launch_bounds__(kPT) void k_pose_opt(PoseView v) {
+  __shared__ double sh[kPT / 64];
+  __shared__ double shH[28];          // upper(Hpp) (21), b (6), spare
+  __shared__ double sh_qt[2][7];      // current / trial estimate
+  __shared__ double sh_x[6];
+  __shared__ int sh_ok;
+  const PoseDesc& d = v.desc[blockIdx.x];
+  PoseOut& out = v.out[blockIdx.x];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < d.E; e += kPT) { v.level[(size_t)d.edge_off + e] = 0; v.chi2[(size_t)d.edge_off + e] = 0.0; }
+  bool robust = true;
+  int n_bad = 0, rounds = 0;
+  __syncthreads();
+  for (int round = 0; round < 4; ++round) {
+    // vSE3->setEstimate(g2o::SE3Quat(q, t)): the rotation is normalised (se3quat.h:61-63)
+    if (tid == 0) {
+      double q[7];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) q[k] = d.qt[k];
+      dev::quat_normalize_rotation(q);
+#pragma unroll
+      for (int k = 0; k < 7; ++k) sh_qt[0][k] = q[k];
+    }
+    __syncthreads();
+    int sel = 0, cj = 0;
+    bool ok = true;
+    double lambda = -1.0, ni = 2.0, last_chi = 0.0;
+    int nBad = 0;
+    // initializeOptimization(0): nothing to do without active edges
+    int active = 0;
+    for (int e = tid; e < d.E; e += kPT) active += v.level[(size_t)d.edge_off + e] ? 0 : 1;
+    const bool any = pose_block_sum((double)active, sh) > 0.0;
+    for (int it = 0; it < d.iters[round] && ok && any; ++it) {
+      double qt[7];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) qt[k] = sh_qt[sel][k];
+      double currentChi = pose_eval(v, d, qt, robust, sh);
+      const double iniChi = currentChi;
+      // ---- buildSystem: Hpp += Jp^T W Jp, b += Jp^T (-rho' Omega r) over the active edges
+      double H[21], b[6];
+#pragma unroll
+      for (int k = 0; k < 21; ++k) H[k] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) b[k] = 0.0;
+      double R[9];
+      dev::quat_to_R(qt, R);
+      for (int e = tid; e < d.E; e += kPT) {
+        const size_t ge = (size_t)d.edge_off + e;
+        if (v.level[ge]) continue;
+        const int kind = v.kind[ge];
+        const double info = v.info[ge];
+        double X[3], obs[3], r[3], Xc[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { X[k] = v.X[ge * 3 + k]; obs[k] = v.obs[ge * 3 + k]; }
+        const double c = dev::edge_residual(kind, qt, d.cam, X, obs, info, r, Xc);
+        double r0 = c, r1 = 1.0;
+        if (robust) dev::huber(c, kind == OSH_EDGE_MONO ? d.huber_mono : d.huber_stereo, r0, r1);
+        double JX[9], Jp[18];
+        dev::edge_jacobians(kind, R, d.cam, Xc, JX, Jp);
+        const double ww = r1 * info;
+        const double wr[3] = {-(info * r[0]) * r1, -(info * r[1]) * r1, -(info * r[2]) * r1};
+        int m = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          const double b0 = Jp[a] * ww, b1 = Jp[6 + a] * ww, b2 = Jp[12 + a] * ww;
+#pragma unroll
+          for (int c2 = a; c2 < 6; ++c2) { H[m] += b0 * Jp[c2] + b1 * Jp[6 + c2] + b2 * Jp[12 + c2]; ++m; }
+          b[a] += Jp[a] * wr[0] + Jp[6 + a] * wr[1] + Jp[12 + a] * wr[2];
+        }
+      }
+      for (int k = 0; k < 27; ++k) {
+        const double t = pose_block_sum(k < 21 ? H[k < 21 ? k : 0] : b[(k - 21) < 0 ? 0 : (k - 21)], sh);
+        if (tid == 0) shH[k] = t;
+      }
+      __syncthreads();
+      if (it == 0) {
+        // computeLambdaInit: tau * max |H_dd| (optimization_algorithm_levenberg.cpp:171-185); diagonal = entries 0, 6, 11, 15, 18, 20
+        lambda = 1e-5 * fmax(fmax(fmax(fabs(shH[0]), fabs(shH[6])), fmax(fabs(shH[11]), fabs(shH[15]))), fmax(fabs(shH[18]), fabs(shH[20])));
+        ni = 2.0; nBad = 0;
+      }
+      double rho = 0.0;
+      int qmax = 0;
+      do {
+        const int trs = sel ^ 1;
+        if (tid == 0) {
+          // (Hpp + lambda I) x = b by LDL^T; the solver reports failure unless every pivot is positive
+          double A[36], x[6];
+          int m = 0;
+          for (int a = 0; a < 6; ++a)
+            for (int c2 = a; c2 < 6; ++c2) { A[a * 6 + c2] = shH[m] + ((a == c2) ? lambda : 0.0); A[c2 * 6 + a] = A[a * 6 + c2]; ++m; }
+          int good = 1;
+          for (int k = 0; k < 6; ++k) {
+            const double dk = A[k * 6 + k];
+            if (!(dk > 0.0)) { good = 0; break; }
+            double l[6];
+            for (int i = k + 1; i < 6; ++i) l[i] = A[k * 6 + i] / dk;
+            for (int i = k + 1; i < 6; ++i)
+              for (int j = i; j < 6; ++j) A[i * 6 + j] -= l[i] * A[k * 6 + j];
+            for (int i = k + 1; i < 6; ++i) A[k * 6 + i] = l[i];
+          }
+          for (int k = 0; k < 6; ++k) x[k] = good ? shH[21 + k] : 0.0;
+          if (good) {
+            for (int k = 0; k < 6; ++k) for (int i = k + 1; i < 6; ++i) x[i] -= A[k * 6 + i] * x[k];
+            for (int k = 0; k < 6; ++k) x[k] /= A[k * 6 + k];
+            for (int k = 5; k >= 0; --k) { double s2 = x[k]; for (int i = k + 1; i < 6; ++i) s2 -= A[k * 6 + i] * x[i]; x[k] = s2; }
+          }
+          double qin[7], qout[7];
+          for (int k = 0; k < 7; ++k) qin[k] = sh_qt[sel][k];
+          dev::pose_oplus(x, qin, qout);
+          for (int k = 0; k < 7; ++k) sh_qt[trs][k] = qout[k];
+          for (int k = 0; k < 6; ++k) sh_x[k] = x[k];
+          sh_ok = good;
+        }
+        __syncthreads();
+        double qtr[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) qtr[k] = sh_qt[trs][k];
+        double tempChi = pose_eval(v, d, qtr, robust, sh);
+        if (!sh_ok) tempChi = DBL_MAX;
+        rho = currentChi - tempChi;
+        double scale = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) scale += sh_x[k] * (lambda * sh_x[k] + shH[21 + k]);
+        scale += 1e-3;
+        rho /= scale;
+        if (rho > 0 && isfinite(tempChi)) {
+          double alpha = 1. - pow((2 * rho - 1), 3);
+          alpha = fmin(alpha, 2. / 3.);
+          lambda *= fmax(1. / 3., alpha);
+          ni = 2; currentChi = tempChi;
+          sel = trs;
+        } else {
+          lambda *= ni; ni *= 2;
+        }
+        qmax++;
+        __syncthreads();
+      } while (rho < 0 && qmax < 10);
+      ++cj;
+      last_chi = currentChi;
+      if (qmax == 10 || rho == 0) { ok = false; continue; }
+      if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+      if (nBad >= 3) { ok = false; continue; }
+    }
+    // ---- classification (:1030-1105).  chi2 of an inlier = its _error as last computed by the optimiser (after a rejected
+    // final trial that is the trial's error, as in the reference); an outlier is re-evaluated at the final estimate.
+    double qf[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) qf[k] = sh_qt[sel][k];
+    int bad = 0;
+    for (int e = tid; e < d.E; e += kPT) {
+      const size_t ge = (size_t)d.edge_off + e;
+      const int kind = v.kind[ge];
+      if (v.level[ge]) {
+        double X[3], obs[3], r[3], Xc[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { X[k] = v.X[ge * 3 + k]; obs[k] = v.obs[ge * 3 + k]; }
+        v.chi2[ge] = dev::edge_residual(kind, qf, d.cam, X, obs, v.info[ge], r, Xc);
+      }
+      const float chi2 = (float)v.chi2[ge];
+      const float th = kind == OSH_EDGE_MONO ? d.chi2_mono[round] : d.chi2_stereo[round];
+      if (chi2 > th) { v.level[ge] = 1; ++bad; } else v.level[ge] = 0;
+    }
+    n_bad = (int)pose_block_sum((double)bad, sh);
+    rounds = round + 1;
+    if (tid == 0) { out.iterations[round] = cj; out.chi2_final[round] = last_chi; }
+    if (round == 2) robust = false;
+    if (tid == 0 && (round == 3 || d.E < 10)) {
+#pragma unroll
+      for (int k = 0; k < 7; ++k) out.qt[k] = sh_qt[sel][k];
+    }
+    __syncthreads();
+    if (d.E < 10) break;
+  }
+  if (tid == 0) { out.n_bad = n_bad; out.rounds = rounds; }
+}
+
+struct PoseBuffers { DevBuf desc, out, X, kind, obs, info, chi2, level; };
+PoseBuffers& pose_buffers() { static thread_local PoseBuffers b; return b; }
+
+}  // namespace osh
+
+using namespace osh;
+
+#define OSH_TRY(expr) do { int _rc = (expr); if (_rc != OSH_OK) return _rc; } while (0)
+
+extern "C" int osh_lba_stream(osh_lba_ctx* ctx, int* device, hipStream_t* stream);   // lba_device.hip
+
+extern "C" int osh_pose_optimize(osh_lba_ctx* ctx, int32_t n, const osh_pose_problem* pr, osh_pose_result* res) {
+  if (!ctx || n <= 0 || !pr || !res) { set_error("osh_pose_optimize: bad arguments"); return OSH_ERR_INVALID; }
+  int device = 0;
+  hipStream_t s = nullptr;
+  OSH_TRY(osh_lba_stream(ctx, &device, &s));
+  OSH_HIP(hipSetDevice(device));
+  std::vector<PoseDesc> h_desc(n);
+  size_t NE = 0;
+  for (int f = 0; f < n; ++f) {
+    const osh_pose_problem& p = pr[f];
+    if (p.n_edges < 0 || !p.pose_qt || !p.cam || (p.n_edges > 0 && (!p.points || !p.edge_kind || !p.edge_obs || !p.edge_info))) {
+      set_error("frame %d: negative size or NULL array", f); return OSH_ERR_INVALID;
+    }
+    PoseDesc& d = h_desc[f];
+    d.E = p.n_edges; d.edge_off = (int)NE;
+    for (int k = 0; k < 7; ++k) d.qt[k] = p.pose_qt[k];
+    for (int k = 0; k < 5; ++k) d.cam[k] = p.cam[k];
+    d.huber_mono = p.huber_mono; d.huber_stereo = p.huber_stereo;
+    for (int k = 0; k < 4; ++k) { d.chi2_mono[k] = p.chi2_mono[k]; d.chi2_stereo[k] = p.chi2_stereo[k]; d.iters[k] = p.iterations[k]; }
+    for (int e = 0; e < p.n_edges; ++e) if (p.edge_kind[e] > OSH_EDGE_STEREO) { set_error("frame %d edge %d: kind out of range", f, e); return OSH_ERR_INVALID; }
+    NE += (size_t)p.n_edges;
+  }
+  if (NE > 0x7fffff00u) { set_error("batch too large for 32-bit offsets"); return OSH_ERR_UNSUPPORTED; }
+  std::vector<double> h_X(NE * 3 + 1), h_obs(NE * 3 + 1), h_info(NE + 1);
+  std::vector<unsigned char> h_kind(NE + 1);
+  for (int f = 0; f < n; ++f) {
+    const osh_pose_problem& p = pr[f];
+    const size_t o = (size_t)h_desc[f].edge_off;
+    for (int e = 0; e < p.n_edges; ++e) {
+      for (int k = 0; k < 3; ++k) { h_X[(o + e) * 3 + k] = p.points[3 * (size_t)e + k]; h_obs[(o + e) * 3 + k] = p.edge_obs[3 * (size_t)e + k]; }
+      h_info[o + e] = p.edge_info[e];
+      h_kind[o + e] = p.edge_kind[e];
+    }
+  }
+  PoseBuffers& B = pose_buffers();
+  auto up = [&](DevBuf& b, const void* src, size_t bytes) -> int {
+    OSH_TRY(b.reserve(std::max<size_t>(bytes, 8)));
+    if (bytes) OSH_HIP(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, s));
+    return OSH_OK;
+  };
+  OSH_TRY(up(B.desc, h_desc.data(), n * sizeof(PoseDesc)));
+  OSH_TRY(up(B.X, h_X.data(), NE * 24)); OSH_TRY(up(B.obs, h_obs.data(), NE * 24)); OSH_TRY(up(B.info, h_info.data(), NE * 8));
+  OSH_TRY(up(B.kind, h_kind.data(), NE));
+  OSH_TRY(B.out.reserve(n * sizeof(PoseOut))); OSH_TRY(B.chi2.reserve(std::max<size_t>(NE * 8, 8))); OSH_TRY(B.level.reserve(std::max<size_t>(NE, 8)));
+  PoseView v;
+  v.desc = B.desc.as<PoseDesc>(); v.out = B.out.as<PoseOut>(); v.X = B.X.as<double>(); v.kind = B.kind.as<unsigned char>();
+  v.obs = B.obs.as<double>(); v.info = B.info.as<double>(); v.chi2 = B.chi2.as<double>(); v.level = B.level.as<unsigned char>();
+  hipLaunchKernelGGL(k_pose_opt, dim3((unsigned)n), dim3(kPT), 0, s, v);
+  { hipError_t e = hipGetLastError(); if (e != hipSuccess) { set_error("kernel launch k_pose_opt failed: %s", hipGetErrorString(e)); return OSH_ERR_DEVICE; } }
+  std::vector<PoseOut> h_out(n);
+  std::vector<unsigned char> h_level(NE + 1);
+  std::vector<double> h_chi2(NE + 1);
+  OSH_HIP(hipMemcpyAsync(h_out.data(), B.out.p, n * sizeof(PoseOut), hipMemcpyDeviceToHost, s));
+  if (NE) {
+    OSH_HIP(hipMemcpyAsync(h_level.data(), B.level.p, NE, hipMemcpyDeviceToHost, s));
+    OSH_HIP(hipMemcpyAsync(h_chi2.data(), B.chi2.p, NE * 8, hipMemcpyDeviceToHost, s));
+  }
+  OSH_HIP(hipStreamSynchronize(s));
+  for (int f = 0; f < n; ++f) {
+    osh_pose_result& r = res[f];
+    const PoseOut& o = h_out[f];
+    for (int k = 0; k < 7; ++k) r.pose_qt[k] = o.qt[k];
+    for (int k = 0; k < 4; ++k) { r.iterations[k] = k < o.rounds ? o.iterations[k] : 0; r.chi2_final[k] = k < o.rounds ? o.chi2_final[k] : 0.0; }
+    r.n_bad = o.n_bad; r.rounds = o.rounds; r.status = OSH_OK;
+    const size_t off = (size_t)h_desc[f].edge_off;
+    if (r.outlier) for (int e = 0; e < h_desc[f].E; ++e) r.outlier[e] = h_level[off + e];
+    if (r.edge_chi2) for (int e = 0; e < h_desc[f].E; ++e) r.edge_chi2[e] = h_chi2[off + e];
+  }
+  return OSH_OK;
+}

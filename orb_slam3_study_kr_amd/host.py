@@ -212,6 +212,16 @@ class HostFrame:
         return n, assign
 
 
+    def pose_optimization(self, kp_mp, mp_pos):
+        """Optimizer::PoseOptimization(&frame) (src/Optimizer.cc:815-1114); returns (n_inliers, pose_qt, mvbOutlier)."""
+        pose = np.zeros(7, dtype=np.float32)
+        outlier = np.zeros(self.n, dtype=np.uint8)
+        keep = [_f32(mp_pos), _i32(kp_mp), _f32(synth.INV_LEVEL_SIGMA2)]
+        n = self.lib.osh_host_frame_pose_optimization(self.f, len(mp_pos), capi.ptr(keep[0], capi.c_float_p), capi.ptr(keep[1], capi.c_int32_p),
+                                                      capi.ptr(keep[2], capi.c_float_p), len(keep[2]), capi.ptr(pose, capi.c_float_p),
+                                                      capi.ptr(outlier, capi.c_uint8_p))
+        return n, pose, outlier
+
     def search_sim3(self, scw, mp_pos, mp_desc, mp_min_max_dist, mp_normal, mp_bad=None, matched_in=None, th=3, ratio_hamming=1.0,
                     with_keyframes=False):
         """ORBmatcher::SearchByProjection(pKF, Scw, vpPoints[, vpPointsKFs], vpMatched[, vpMatchedKF], th, ratioHamming)

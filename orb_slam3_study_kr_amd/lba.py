@@ -98,6 +98,18 @@ class LbaSolver:
         return S, bs, x
 
     # -- profiling ------------------------------------------------------------------------------
+    def optimize_poses(self, frames):
+        """``osh_pose_optimize``: Optimizer::PoseOptimization's four rounds for every frame of the batch, one block per frame."""
+        from .synth import PoseResultArrays
+        n = len(frames)
+        probs = (capi.PoseProblem * n)(*[f.as_struct() for f in frames])
+        res = [PoseResultArrays(f) for f in frames]
+        rs = (capi.PoseResult * n)()
+        for r, a in zip(rs, res):
+            a.bind(r)
+        capi.check(self.lib.osh_pose_optimize(self.ctx, n, probs, rs), "osh_pose_optimize", self.lib)
+        return [a.read_scalars(r) for r, a in zip(rs, res)]
+
     def set_profiling(self, enable: bool):
         capi.check(self.lib.osh_lba_set_profiling(self.ctx, int(enable)), "osh_lba_set_profiling", self.lib)
 

@@ -373,3 +373,102 @@ def features_in_area_lists(tx, ty, tlevel, qx, qy, r, min_level, max_level):
                             idx.append(j)
         off.append(len(idx))
     return np.asarray(off, dtype=np.int32), np.asarray(idx, dtype=np.int32)
+
+
+# --------------------------------------------------------------------------- pose-only optimisation of a frame
+@dataclass
+class PoseFrame:
+    """Flat problem of Optimizer::PoseOptimization (src/Optimizer.cc:815-1114): one pose, unary edges."""
+    pose_qt: np.ndarray       # [7] initial Tcw
+    cam: np.ndarray           # [5]
+    points: np.ndarray        # [E,3]
+    edge_kind: np.ndarray     # [E] u8
+    edge_obs: np.ndarray      # [E,3]
+    edge_info: np.ndarray     # [E]
+    gt_pose_qt: np.ndarray | None = None
+    outlier_mask: np.ndarray | None = None
+    huber_mono: float = HUBER_MONO
+    huber_stereo: float = HUBER_STEREO
+    chi2_mono: tuple = (5.991, 5.991, 5.991, 5.991)
+    chi2_stereo: tuple = (7.815, 7.815, 7.815, 7.815)
+    iterations: tuple = (10, 10, 10, 10)
+
+    @property
+    def n_edges(self) -> int:
+        return int(self.edge_kind.shape[0])
+
+    def normalise(self):
+        self.pose_qt = np.ascontiguousarray(self.pose_qt, dtype=np.float64)
+        self.cam = np.ascontiguousarray(self.cam, dtype=np.float64)
+        self.points = np.ascontiguousarray(self.points, dtype=np.float64).reshape(-1, 3)
+        self.edge_kind = np.ascontiguousarray(self.edge_kind, dtype=np.uint8)
+        self.edge_obs = np.ascontiguousarray(self.edge_obs, dtype=np.float64).reshape(-1, 3)
+        self.edge_info = np.ascontiguousarray(self.edge_info, dtype=np.float64)
+        return self
+
+    def as_struct(self) -> "capi.PoseProblem":
+        p = capi.PoseProblem()
+        p.n_edges = self.n_edges
+        p.pose_qt = capi.ptr(self.pose_qt, capi.c_double_p)
+        p.cam = capi.ptr(self.cam, capi.c_double_p)
+        p.points = capi.ptr(self.points, capi.c_double_p)
+        p.edge_kind = capi.ptr(self.edge_kind, capi.c_uint8_p)
+        p.edge_obs = capi.ptr(self.edge_obs, capi.c_double_p)
+        p.edge_info = capi.ptr(self.edge_info, capi.c_double_p)
+        p.huber_mono, p.huber_stereo = self.huber_mono, self.huber_stereo
+        for k in range(4):
+            p.chi2_mono[k] = self.chi2_mono[k]
+            p.chi2_stereo[k] = self.chi2_stereo[k]
+            p.iterations[k] = self.iterations[k]
+        return p
+
+
+class PoseResultArrays:
+    def __init__(self, f: PoseFrame):
+        self.outlier = np.zeros(f.n_edges, dtype=np.uint8)
+        self.edge_chi2 = np.zeros(f.n_edges, dtype=np.float64)
+        self.struct = capi.PoseResult()
+        self.bind(self.struct)
+
+    def bind(self, r):
+        r.outlier = capi.ptr(self.outlier, capi.c_uint8_p)
+        r.edge_chi2 = capi.ptr(self.edge_chi2, capi.c_double_p)
+
+    def read_scalars(self, r):
+        self.pose_qt = np.array(r.pose_qt[:7])
+        self.n_bad, self.rounds, self.status = int(r.n_bad), int(r.rounds), int(r.status)
+        self.iterations = np.array(r.iterations[:4])
+        self.chi2_final = np.array(r.chi2_final[:4])
+        return self
+
+
+def make_pose_frame(seed: int = 21, n_points: int = 800, stereo: bool = True, mixed_mono_frac: float = 0.3, outlier_frac: float = 0.1,
+                    pose_noise=(0.01, 0.05)) -> PoseFrame:
+    """A tracked frame: map points in front of the camera, pixel noise by pyramid level, gross outliers (wrong matches),
+    the initial pose = ground truth + perturbation, everything the reference stores as float rounded to float32."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    yaw = 0.1
+    Rcw = _rodrigues(np.array([0.02, yaw, -0.01]))
+    tcw = np.array([0.3, -0.1, 0.2])
+    Xc = np.stack([rng.uniform(-4, 4, n_points), rng.uniform(-2.5, 2.5, n_points), rng.uniform(3, 14, n_points)], axis=1)
+    u = float(FX) * Xc[:, 0] / Xc[:, 2] + float(CX)
+    v = float(FY) * Xc[:, 1] / Xc[:, 2] + float(CY)
+    vis = (u >= 0) & (u < IMG_W) & (v >= 0) & (v < IMG_H) & ((u - float(BF) / Xc[:, 2]) >= 0)
+    Xc, u, v = Xc[vis], u[vis], v[vis]
+    E = Xc.shape[0]
+    Xw = (Xc - tcw) @ Rcw                              # Rcw^T (Xc - tcw)
+    octave = rng.integers(0, N_LEVELS, E)
+    sig = SCALE_FACTORS[octave].astype(np.float64)
+    is_out = rng.uniform(0, 1, E) < outlier_frac
+    noise = rng.standard_normal((E, 3)) * sig[:, None] + rng.standard_normal((E, 3)) * 25.0 * is_out[:, None]
+    obs = np.stack([u, v, u - float(BF) / Xc[:, 2]], axis=1) + noise
+    kind = np.full(E, capi.OSH_EDGE_STEREO if stereo else capi.OSH_EDGE_MONO, dtype=np.uint8)
+    if stereo and mixed_mono_frac > 0:
+        kind[rng.uniform(0, 1, E) < mixed_mono_frac] = capi.OSH_EDGE_MONO
+    obs[kind == capi.OSH_EDGE_MONO, 2] = -1.0
+    gt = np.concatenate([_quat_from_R(Rcw), tcw])
+    dR = _rodrigues(rng.standard_normal(3) * pose_noise[0])
+    init = np.concatenate([_quat_from_R(dR @ Rcw), tcw + rng.standard_normal(3) * pose_noise[1]])
+    cam = np.array([FX, FY, CX, CY, BF], dtype=np.float32).astype(np.float64)
+    return PoseFrame(pose_qt=_f32(init), cam=cam, points=_f32(Xw), edge_kind=kind, edge_obs=_f32(obs),
+                     edge_info=INV_LEVEL_SIGMA2[octave].astype(np.float64), gt_pose_qt=gt, outlier_mask=is_out).normalise()

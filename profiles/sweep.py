@@ -107,6 +107,27 @@ def main():
         print(rows[-1], flush=True)
     out["inertial_batch_sweep"] = rows
     solver.close()
+    # ---- Optimizer::PoseOptimization: one frame (the live call pattern) and a batch, next to the single-thread oracle
+    frames = [synth.make_pose_frame(60 + k, n_points=1200) for k in range(256)]
+    t0 = time.perf_counter(); n_cpu = 0
+    while time.perf_counter() - t0 < 3.0:
+        ob.pose_optimize(frames[n_cpu % 256], native=True); n_cpu += 1
+    cpu_fps = n_cpu / (time.perf_counter() - t0)
+    solver = lba.LbaSolver(0)
+    rows = []
+    for B in (1, 16, 256):
+        fs = frames[:B]
+        solver.optimize_poses(fs)
+        reps = 20 if B == 1 else 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            solver.optimize_poses(fs)
+        dt = (time.perf_counter() - t0) / reps
+        rows.append({"frames": B, "ms_per_call": dt * 1e3, "frames_per_s": B / dt})
+        print(rows[-1], flush=True)
+    out["pose_optimization"] = {"edges_per_frame": int(np.mean([f.n_edges for f in frames])), "sweep": rows,
+                                "cpu_one_thread_frames_per_s": cpu_fps, "includes": "H2D upload + D2H download"}
+    solver.close()
     dst = ROOT / "gpurun_out"
     dst.mkdir(exist_ok=True)
     (dst / f"sweep_{tag}.json").write_text(json.dumps(out, indent=1))

@@ -342,6 +342,40 @@ def test_search_by_projection_sim3_equals_sequential_reference(ob, with_keyframe
     assert side.any() and bad.any()
 
 
+def test_pose_optimization_through_the_reference_signature(ob):
+    """Optimizer::PoseOptimization(Frame*) (src/Optimizer.cc:815-1114) on a Frame whose keypoints hold map points: the returned
+    inlier count, mvbOutlier and the float32 pose against the oracle run on the same flat problem."""
+    f = synth.make_pose_frame(51, n_points=900, mixed_mono_frac=0.4, outlier_frac=0.15)
+    E = f.n_edges
+    rng = np.random.Generator(np.random.PCG64(51))
+    n_kp = E + 40                                            # a few keypoints without a map point
+    kp_of_edge = np.sort(rng.permutation(n_kp)[:E])          # edge order of the problem = keypoint order
+    xy = np.zeros((n_kp, 2), dtype=np.float32)
+    uright = -np.ones(n_kp, dtype=np.float32)
+    octave = np.zeros(n_kp, dtype=np.int32)
+    xy[kp_of_edge] = f.edge_obs[:, :2]
+    uright[kp_of_edge] = np.where(f.edge_kind == 1, f.edge_obs[:, 2], -1.0)
+    octave[kp_of_edge] = np.round(np.log(1.0 / f.edge_info) / np.log(1.44)).astype(np.int32)
+    kp_mp = -np.ones(n_kp, dtype=np.int32)
+    kp_mp[kp_of_edge] = np.arange(E)
+    desc = np.zeros((n_kp, 32), dtype=np.uint8)
+    frame = host.HostFrame(xy, octave, desc, uright=uright, pose_qt=f.pose_qt)
+    try:
+        n_in, pose, outlier = frame.pose_optimization(kp_mp, f.points)
+    finally:
+        frame.close()
+    ref = ob.pose_optimize(f)
+    th = np.where(f.edge_kind == 0, np.float32(5.991), np.float32(7.815)).astype(np.float64)
+    near = np.abs(ref.edge_chi2 - th) < 1e-5 * th
+    np.testing.assert_array_equal(outlier[kp_of_edge][~near], ref.outlier[~near])
+    assert abs(n_in - (E - ref.n_bad)) <= int(near.sum())
+    assert (outlier[kp_mp < 0] == 1).all()                   # untouched preset of the keypoints without a map point
+    got = pose.astype(np.float64)[None]
+    assert rel_translation_error(got, ref.pose_qt[None]) < 2e-6      # float32 write-back
+    assert rotation_error(got, ref.pose_qt[None]) < 2e-6
+    assert n_in > 0.7 * E
+
+
 def test_local_inertial_ba_through_the_reference_signature(ob):
     """Optimizer::LocalInertialBA(KeyFrame*, bool*, Map*, int&x4, bLarge, bRecInit) on a KeyFrame/MapPoint/IMU graph vs the
     inertial oracle on the problem the host layer packed; write-back of poses, velocities, biases and points in float."""

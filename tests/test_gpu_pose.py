@@ -1,0 +1,62 @@
+"""GPU parity of the pose-only optimisation (osh_pose_optimize <-> oracle/pose_oracle.c <-> Optimizer::PoseOptimization,
+src/Optimizer.cc:815-1114): poses to 1e-6 relative on the translation, iteration counts per round within one, identical
+inlier / outlier classification except within rounding of the chi2 threshold."""
+import numpy as np
+import pytest
+
+from helpers import rel_translation_error, rotation_error
+from orb_slam3_study_kr_amd import lba, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def solver(hip_lib):
+    s = lba.LbaSolver(0)
+    yield s
+    s.close()
+
+
+@pytest.fixture(scope="module")
+def ob():
+    from oracle import binding
+    return binding
+
+
+def _check(got, ref, f):
+    assert got.rounds == ref.rounds
+    # a 6-dof problem converges in ~5 iterations; its last iterations change chi2 at rounding level, so the stop rules
+    # (rho == 0, three iterations below 0.1 % gain) may fire one iteration apart when sums are associated differently
+    assert np.abs(got.iterations - ref.iterations).max() <= 1
+    np.testing.assert_allclose(got.chi2_final, ref.chi2_final, rtol=1e-7)
+    assert rel_translation_error(got.pose_qt[None], ref.pose_qt[None]) < 1e-6
+    assert rotation_error(got.pose_qt[None], ref.pose_qt[None]) < 1e-6
+    np.testing.assert_allclose(got.edge_chi2, ref.edge_chi2, rtol=1e-5, atol=1e-6)
+    th = np.where(f.edge_kind == 0, np.float32(5.991), np.float32(7.815)).astype(np.float64)
+    near = np.abs(ref.edge_chi2 - th) < 1e-5 * th
+    np.testing.assert_array_equal(got.outlier[~near], ref.outlier[~near])
+    assert abs(got.n_bad - ref.n_bad) <= int(near.sum())
+
+
+@pytest.mark.parametrize("kw", [
+    dict(seed=21), dict(seed=24, stereo=False, mixed_mono_frac=0.0), dict(seed=25, mixed_mono_frac=0.5, outlier_frac=0.3),
+    dict(seed=26, n_points=60, outlier_frac=0.0), dict(seed=27, n_points=3000),
+])
+def test_pose_optimisation_matches_oracle(solver, ob, kw):
+    f = synth.make_pose_frame(**kw)
+    _check(solver.optimize_poses([f])[0], ob.pose_optimize(f), f)
+
+
+def test_batch_of_frames_equals_single_calls_and_small_frames(solver, ob):
+    frames = [synth.make_pose_frame(30 + k, n_points=200 + 150 * k) for k in range(6)]
+    tiny = synth.make_pose_frame(40, n_points=14)
+    keep = np.arange(min(8, tiny.n_edges))
+    tiny.points, tiny.edge_kind, tiny.edge_obs, tiny.edge_info = tiny.points[keep], tiny.edge_kind[keep], tiny.edge_obs[keep], tiny.edge_info[keep]
+    frames.append(tiny.normalise())
+    got = solver.optimize_poses(frames)
+    for f, g in zip(frames, got):
+        _check(g, ob.pose_optimize(f), f)
+    assert got[-1].rounds == 1
+    again = solver.optimize_poses(frames)
+    for g, a in zip(got, again):
+        np.testing.assert_array_equal(g.pose_qt, a.pose_qt)          # fixed-order reductions: bitwise reproducible

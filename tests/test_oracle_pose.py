@@ -1,0 +1,53 @@
+"""CPU oracle of the pose-only optimisation (oracle/pose_oracle.c <-> src/Optimizer.cc:815-1114): property tests.
+PARITY UNPINNED against a reference binary; the edge functions it uses are the ones
+tests/test_oracle_lba.py pins against numpy and central differences."""
+import numpy as np
+
+from helpers import quat_to_R
+from orb_slam3_study_kr_amd import synth
+from oracle import binding as ob
+
+
+def _pose_err(a, b):
+    Ra, Rb = quat_to_R(a[:4]), quat_to_R(b[:4])
+    return np.abs(a[4:] - b[4:]).max(), np.arccos(np.clip((np.trace(Ra.T @ Rb) - 1) / 2, -1, 1))
+
+
+def test_four_rounds_reject_wrong_matches_and_recover_the_pose():
+    f = synth.make_pose_frame(21, outlier_frac=0.1)
+    r = ob.pose_optimize(f)
+    assert r.rounds == 4 and (r.iterations > 0).all()
+    dt, dr = _pose_err(r.pose_qt, f.gt_pose_qt)
+    dt0, dr0 = _pose_err(f.pose_qt, f.gt_pose_qt)
+    assert dt < 0.1 * dt0 and dr < 0.2 * dr0
+    flagged = r.outlier.astype(bool)
+    assert flagged[f.outlier_mask].mean() > 0.9          # gross outliers are found
+    assert flagged[~f.outlier_mask].mean() < 0.12        # the chi2 test rejects ~5 % of the true matches
+    assert r.n_bad == int(flagged.sum())
+    # the last round runs without the Huber kernel on the inliers only: its cost is the plain chi2 sum
+    assert abs(r.chi2_final[3] - r.edge_chi2[~flagged].sum()) < 1e-6 * r.chi2_final[3]
+
+
+def test_noise_free_frame_converges_to_ground_truth():
+    f = synth.make_pose_frame(22, outlier_frac=0.0)
+    f.edge_obs = synth._f32(np.where(f.edge_kind[:, None] == 0, [1, 1, 0], [1, 1, 1]) * 0 + _project(f))
+    f.edge_obs[f.edge_kind == 0, 2] = -1.0
+    r = ob.pose_optimize(f.normalise())
+    dt, dr = _pose_err(r.pose_qt, f.gt_pose_qt)
+    assert dt < 2e-5 and dr < 2e-5 and r.n_bad == 0
+
+
+def _project(f):
+    R, t = quat_to_R(f.gt_pose_qt[:4]), f.gt_pose_qt[4:]
+    Xc = f.points @ R.T + t
+    u = f.cam[0] * Xc[:, 0] / Xc[:, 2] + f.cam[2]
+    v = f.cam[1] * Xc[:, 1] / Xc[:, 2] + f.cam[3]
+    return np.stack([u, v, u - f.cam[4] / Xc[:, 2]], axis=1)
+
+
+def test_fewer_than_ten_edges_stop_after_the_first_round():
+    f = synth.make_pose_frame(23, n_points=14)
+    keep = np.arange(min(8, f.n_edges))
+    f.points, f.edge_kind, f.edge_obs, f.edge_info = f.points[keep], f.edge_kind[keep], f.edge_obs[keep], f.edge_info[keep]
+    r = ob.pose_optimize(f.normalise())
+    assert r.rounds == 1 and r.iterations[1:].sum() == 0
