@@ -2,6 +2,7 @@
  * (reference include/KeyFrame.h; src/KeyFrame.cc:109-131,237,309,367,681,1108).  Minimal test double. */
 #ifndef KEYFRAME_H
 #define KEYFRAME_H
+#include <set>
 #include <vector>
 #include "CameraModels/GeometricCamera.h"
 #include "ImuTypes.h"
@@ -27,6 +28,8 @@ class KeyFrame {
   IMU::Bias GetImuBias() { return mImuBias; }
   std::vector<KeyFrame*> GetVectorCovisibleKeyFrames() { return mvpOrderedConnectedKeyFrames; }
   std::vector<MapPoint*> GetMapPointMatches() { return mvpMapPoints; }
+  std::set<MapPoint*> GetMapPoints();                        // src/KeyFrame.cc:336-349: the non-bad matches
+  MapPoint* GetMapPoint(const size_t& idx) { return mvpMapPoints[idx]; }   // src/KeyFrame.cc:373-377
   void EraseMapPointMatch(MapPoint* pMP);
   Sophus::SE3f GetRelativePoseTrl() { return mTrl; }
   bool isBad() { return mbBad; }
@@ -37,6 +40,7 @@ class KeyFrame {
 
   long unsigned int mnId;
   long unsigned int mnBALocalForKF = 0, mnBAFixedForKF = 0;
+  long unsigned int mnBALocalForMerge = 0;   // include/KeyFrame.h:318
   // global BA results kept beside the live pose until the loop-closing thread applies them (include/KeyFrame.h:369-372)
   Sophus::SE3f mTcwGBA;
   long unsigned int mnBAGlobalForKF = 0;

@@ -34,6 +34,7 @@ class MapPoint {
   static std::mutex mGlobalMutex;             // include/MapPoint.h:151 (held while PoseOptimization reads the positions)
   long unsigned int mnId;
   long unsigned int mnBALocalForKF = 0;
+  long unsigned int mnBALocalForMerge = 0;    // include/MapPoint.h:139
   Eigen::Vector3f mPosGBA;                    // include/MapPoint.h:147-148
   long unsigned int mnBAGlobalForKF = 0;
   // tracking scratch written by Frame::isInFrustum (src/Frame.cc:513-587), read by SearchByProjection

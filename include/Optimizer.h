@@ -21,6 +21,9 @@ class Optimizer {
   // src/Optimizer.cc:1116-1498.  num_MPs is never assigned by the reference either.
   void static LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF, int& num_OptKF,
                                     int& num_MPs, int& num_edges);
+  // src/Optimizer.cc:3506-3955 (csrc/host/OptimizerGlobal.cc): the welding bundle adjustment of a map merge -- vpAdjustKF
+  // optimised, vpFixedKF fixed, optimize(5) with Huber, outliers demoted and the kernel dropped, optimize(10)
+  void static LocalBundleAdjustment(KeyFrame* pMainKF, std::vector<KeyFrame*> vpAdjustKF, std::vector<KeyFrame*> vpFixedKF, bool* pbStopFlag);
   // src/Optimizer.cc:2387-2964 (csrc/host/OptimizerInertial.cc); the num_* out-parameters are never assigned, as in the reference.
   void static LocalInertialBA(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF, int& num_OptKF, int& num_MPs,
                               int& num_edges, bool bLarge = false, bool bRecInit = false);

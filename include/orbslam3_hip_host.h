@@ -72,6 +72,14 @@ int osh_host_inertial_information(const float* cov225, double* info81_out);
 int osh_host_pack_gba(osh_host_graph* g, int32_t sizes[5], double* pose_qt, double* pose_cam, double* points,
                       int32_t* edge_pose, int32_t* edge_point, uint8_t* edge_kind, double* edge_obs, double* edge_info,
                       int64_t* pose_kf_id, int64_t* point_mp_id);
+/* The welding Optimizer::LocalBundleAdjustment(pMainKF, vpAdjustKF, vpFixedKF, pbStopFlag) (src/Optimizer.cc:3506-3955); pack =
+ * the problem of its first optimisation. */
+int osh_host_pack_welding(osh_host_graph* g, int32_t main_index, int32_t n_adj, const int32_t* adj, int32_t n_fix,
+                          const int32_t* fix, int32_t sizes[5], double* pose_qt, double* pose_cam, double* points,
+                          int32_t* edge_pose, int32_t* edge_point, uint8_t* edge_kind, double* edge_obs, double* edge_info,
+                          int64_t* pose_kf_id, int64_t* point_mp_id);
+int osh_host_run_welding(osh_host_graph* g, int32_t main_index, int32_t n_adj, const int32_t* adj, int32_t n_fix,
+                         const int32_t* fix, unsigned char* stop_flag);
 int osh_host_run_gba(osh_host_graph* g, int32_t n_iterations, unsigned char* stop_flag, int64_t n_loop_kf, int32_t robust);
 int64_t osh_host_get_kf_pose_gba(osh_host_graph* g, int32_t kf_index, float pose_qt[7]);
 int64_t osh_host_get_mp_pos_gba(osh_host_graph* g, int32_t mp_index, float pos[3]);

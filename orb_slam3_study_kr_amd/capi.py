@@ -204,6 +204,9 @@ _HOST_SIGNATURES = {
                                        C.c_int32, C.c_float, C.c_int32, c_int32_p, c_int32_p]),
     "osh_host_pack_gba": (C.c_int, [C.c_void_p, c_int32_p, c_double_p, c_double_p, c_double_p, c_int32_p, c_int32_p, c_uint8_p, c_double_p,
                                     c_double_p, c_int64_p, c_int64_p]),
+    "osh_host_pack_welding": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_int32_p, C.c_int32, c_int32_p, c_int32_p, c_double_p, c_double_p,
+                                        c_double_p, c_int32_p, c_int32_p, c_uint8_p, c_double_p, c_double_p, c_int64_p, c_int64_p]),
+    "osh_host_run_welding": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_int32_p, C.c_int32, c_int32_p, c_uint8_p]),
     "osh_host_run_gba": (C.c_int, [C.c_void_p, C.c_int32, c_uint8_p, C.c_int64, C.c_int32]),
     "osh_host_get_kf_pose_gba": (C.c_int64, [C.c_void_p, C.c_int32, c_float_p]),
     "osh_host_get_mp_pos_gba": (C.c_int64, [C.c_void_p, C.c_int32, c_float_p]),

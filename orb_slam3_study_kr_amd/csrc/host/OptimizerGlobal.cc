@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <limits>
 #include <map>
+#include <mutex>
+#include <set>
 
 #include "Optimizer.h"
 #include "host_pack.h"
@@ -165,6 +167,214 @@ void Optimizer::BundleAdjustment(const std::vector<KeyFrame*>& vpKFs, const std:
       pMP->mPosGBA = X;
       pMP->mnBAGlobalForKF = nLoopKF;
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Welding bundle adjustment of a map merge (src/Optimizer.cc:3506-3955, called from LoopClosing::MergeLocal).
+void PackWeldingBA(KeyFrame* pMainKF, const std::vector<KeyFrame*>& vpAdjustKF, const std::vector<KeyFrame*>& vpFixedKF, LbaPack& pk,
+                   std::vector<MapPoint*>& vpMPs) {
+  pk = LbaPack();
+  vpMPs.clear();
+  Map* pCurrentMap = pMainKF->GetMap();
+  long unsigned int maxKFid = 0;
+  std::vector<KeyFrame*> vFree, vFixed;
+  auto collect = [&](KeyFrame* pKFi) {   // the keyframe's map points, each once (:3551-3563, 3589-3606)
+    const std::set<MapPoint*> spViewMPs = pKFi->GetMapPoints();
+    for (MapPoint* pMPi : spViewMPs) {
+      if (!pMPi) continue;
+      if (!pMPi->isBad() && pMPi->GetMap() == pCurrentMap && pMPi->mnBALocalForMerge != pMainKF->mnId) {
+        vpMPs.push_back(pMPi);
+        pMPi->mnBALocalForMerge = pMainKF->mnId;
+      }
+    }
+  };
+  for (KeyFrame* pKFi : vpFixedKF) {
+    if (pKFi->isBad() || pKFi->GetMap() != pCurrentMap) continue;   // "ERROR LBA: KF is bad or is not in the current map"
+    pKFi->mnBALocalForMerge = pMainKF->mnId;
+    vFixed.push_back(pKFi);
+    if (pKFi->mnId > maxKFid) maxKFid = pKFi->mnId;
+    collect(pKFi);
+  }
+  for (KeyFrame* pKFi : vpAdjustKF) {
+    if (pKFi->isBad() || pKFi->GetMap() != pCurrentMap) continue;
+    pKFi->mnBALocalForMerge = pMainKF->mnId;
+    vFree.push_back(pKFi);
+    if (pKFi->mnId > maxKFid) maxKFid = pKFi->mnId;
+    collect(pKFi);
+  }
+  std::sort(vFree.begin(), vFree.end(), [](KeyFrame* a, KeyFrame* b) { return a->mnId < b->mnId; });
+  pk.vPoseKFs = vFree;
+  pk.vPoseKFs.insert(pk.vPoseKFs.end(), vFixed.begin(), vFixed.end());
+  pk.n_free = (int)vFree.size();
+  pk.n_fixed = (int)vFixed.size();
+  pk.num_fixedKF = pk.n_fixed;
+  std::map<KeyFrame*, int> poseIndex;
+  for (size_t i = 0; i < pk.vPoseKFs.size(); ++i) poseIndex[pk.vPoseKFs[i]] = (int)i;
+  for (KeyFrame* pKF : pk.vPoseKFs) {
+    const Sophus::SE3f Tcw = pKF->GetPose();
+    const Eigen::Quaterniond q = Tcw.unit_quaternion().cast<double>();
+    const Eigen::Vector3d t = Tcw.translation().cast<double>();
+    const double qt[7] = {q.x(), q.y(), q.z(), q.w(), t[0], t[1], t[2]};
+    pk.pose_qt.insert(pk.pose_qt.end(), qt, qt + 7);
+    const double cam[5] = {pKF->fx, pKF->fy, pKF->cx, pKF->cy, pKF->mbf};
+    pk.pose_cam.insert(pk.pose_cam.end(), cam, cam + 5);
+  }
+  for (MapPoint* pMPi : vpMPs) if (!pMPi->isBad()) pk.vPointMPs.push_back(pMPi);
+  std::sort(pk.vPointMPs.begin(), pk.vPointMPs.end(), [](MapPoint* a, MapPoint* b) { return a->mnId < b->mnId; });
+  std::map<MapPoint*, int> pointIndex;
+  for (size_t j = 0; j < pk.vPointMPs.size(); ++j) {
+    pointIndex[pk.vPointMPs[j]] = (int)j;
+    const Eigen::Vector3d X = pk.vPointMPs[j]->GetWorldPos().cast<double>();
+    pk.points.push_back(X[0]); pk.points.push_back(X[1]); pk.points.push_back(X[2]);
+  }
+  // edges (:3631-3705): left observation only, mono if mvuRight < 0, stereo otherwise; always a Huber kernel
+  for (MapPoint* pMPi : vpMPs) {
+    if (pMPi->isBad()) continue;
+    const std::map<KeyFrame*, std::tuple<int, int>> observations = pMPi->GetObservations();
+    for (const auto& ob : observations) {
+      KeyFrame* pKF = ob.first;
+      const int leftIndex = std::get<0>(ob.second);
+      if (pKF->isBad() || pKF->mnId > maxKFid || pKF->mnBALocalForMerge != pMainKF->mnId || !pKF->GetMapPoint(leftIndex)) continue;
+      const cv::KeyPoint& kpUn = pKF->mvKeysUn[leftIndex];
+      const float kp_ur = pKF->mvuRight[leftIndex];
+      const bool stereo = !(kp_ur < 0);
+      if (!stereo) {
+        GeometricCamera* cam = pKF->mpCamera;
+        if (!cam || cam->GetType() != GeometricCamera::CAM_PINHOLE || cam->getParameter(0) != pKF->fx ||
+            cam->getParameter(1) != pKF->fy || cam->getParameter(2) != pKF->cx || cam->getParameter(3) != pKF->cy) {
+          pk.unsupported = "monocular observation through a camera that is not the keyframe's pinhole model";
+          return;
+        }
+      }
+      pk.edge_pose.push_back(poseIndex.at(pKF));
+      pk.edge_point.push_back(pointIndex.at(pMPi));
+      pk.edge_kind.push_back(stereo ? OSH_EDGE_STEREO : OSH_EDGE_MONO);
+      pk.edge_obs.push_back(kpUn.pt.x); pk.edge_obs.push_back(kpUn.pt.y); pk.edge_obs.push_back(stereo ? kp_ur : -1.0);
+      pk.edge_info.push_back(pKF->mvInvLevelSigma2[kpUn.octave]);
+      pk.vEdgeKF.push_back(pKF);
+      pk.vEdgeMP.push_back(pMPi);
+    }
+  }
+}
+
+void Optimizer::LocalBundleAdjustment(KeyFrame* pMainKF, std::vector<KeyFrame*> vpAdjustKF, std::vector<KeyFrame*> vpFixedKF, bool* pbStopFlag) {
+  LbaPack pk;
+  std::vector<MapPoint*> vpMPs;
+  PackWeldingBA(pMainKF, vpAdjustKF, vpFixedKF, pk, vpMPs);
+  if (pk.unsupported) {
+    std::fprintf(stderr, "[BA]: %s is not supported by the MI355X path yet; map left untouched\n", pk.unsupported);
+    return;
+  }
+  if (pbStopFlag && *pbStopFlag) return;   // :3707-3709
+  osh_lba_ctx* ctx = HostSolverContext();
+  if (!ctx) return;
+  const size_t E = pk.edge_pose.size();
+  const double thMono = 5.991, thStereo = 7.815;
+  // ---- first optimisation: Huber kernels, 5 iterations (:3711-3712)
+  osh_lba_problem prob;
+  pk.fill(prob);
+  prob.huber_mono = (double)(float)std::sqrt(5.99);     // const float thHuber2D = sqrt(5.99) (:3625)
+  prob.huber_stereo = (double)(float)std::sqrt(7.815);
+  prob.lambda_init = 0.0;
+  prob.max_iterations = 5;
+  prob.stop_flag = reinterpret_cast<const volatile unsigned char*>(pbStopFlag);
+  std::vector<double> pose1((size_t)pk.n_free * 7), pts1(pk.points.size()), chi1(E);
+  std::vector<uint8_t> depth1(E);
+  osh_lba_result res;
+  res.pose_qt = pose1.data(); res.points = pts1.data(); res.edge_chi2 = chi1.data(); res.edge_depth_pos = depth1.data();
+  if (osh_lba_solve(ctx, 1, &prob, &res) != OSH_OK) {
+    std::fprintf(stderr, "[BA]: device solve failed (%s); map left untouched\n", osh_last_error());
+    return;
+  }
+  std::vector<double> chiF = chi1, poseF = pose1, ptsF = pts1;
+  std::vector<uint8_t> depthF = depth1;
+  const bool bDoMore = !(pbStopFlag && *pbStopFlag);   // :3714-3718
+  if (bDoMore) {
+    // outliers of the first optimisation leave the active set (setLevel(1)), every kernel is dropped (:3724-3753),
+    // then optimize(10) from the current estimates (:3757-3758)
+    std::vector<uint8_t> level1(E, 0);
+    LbaPack p2;
+    p2.n_free = pk.n_free; p2.n_fixed = pk.n_fixed;
+    p2.vPointMPs = pk.vPointMPs;
+    p2.pose_qt = pk.pose_qt;
+    std::copy(pose1.begin(), pose1.end(), p2.pose_qt.begin());
+    p2.pose_cam = pk.pose_cam;
+    p2.points = pts1;
+    std::vector<size_t> keep;
+    for (size_t e = 0; e < E; ++e) {
+      const double th = pk.edge_kind[e] == OSH_EDGE_MONO ? thMono : thStereo;
+      if (!pk.vEdgeMP[e]->isBad() && (chi1[e] > th || !depth1[e])) { level1[e] = 1; continue; }
+      keep.push_back(e);
+      p2.edge_pose.push_back(pk.edge_pose[e]); p2.edge_point.push_back(pk.edge_point[e]); p2.edge_kind.push_back(pk.edge_kind[e]);
+      for (int k = 0; k < 3; ++k) p2.edge_obs.push_back(pk.edge_obs[3 * e + k]);
+      p2.edge_info.push_back(pk.edge_info[e]);
+    }
+    osh_lba_problem prob2;
+    p2.fill(prob2);
+    prob2.huber_mono = prob2.huber_stereo = std::numeric_limits<double>::infinity();   // e->setRobustKernel(0)
+    prob2.lambda_init = 0.0;
+    prob2.max_iterations = 10;
+    prob2.stop_flag = reinterpret_cast<const volatile unsigned char*>(pbStopFlag);
+    std::vector<double> pose2((size_t)pk.n_free * 7), pts2(pk.points.size()), chi2(keep.size());
+    std::vector<uint8_t> depth2(keep.size());
+    osh_lba_result res2;
+    res2.pose_qt = pose2.data(); res2.points = pts2.data(); res2.edge_chi2 = chi2.data(); res2.edge_depth_pos = depth2.data();
+    if (osh_lba_solve(ctx, 1, &prob2, &res2) != OSH_OK) {
+      std::fprintf(stderr, "[BA]: device solve failed (%s); map left untouched\n", osh_last_error());
+      return;
+    }
+    poseF = pose2; ptsF = pts2;
+    for (size_t x = 0; x < keep.size(); ++x) { chiF[keep[x]] = chi2[x]; depthF[keep[x]] = depth2[x]; }
+    // a demoted edge keeps the error of the first optimisation (it is never evaluated again), but isDepthPositive()
+    // reads the final estimates (EdgeSE3ProjectXYZ::isDepthPositive, include/OptimizableTypes.h:99-103)
+    for (size_t e = 0; e < E; ++e) {
+      if (!level1[e]) continue;
+      const int ip = pk.edge_pose[e], il = pk.edge_point[e];
+      const double* qt = (ip < pk.n_free) ? &poseF[(size_t)ip * 7] : &pk.pose_qt[(size_t)ip * 7];
+      const double* X = &ptsF[3 * (size_t)il];
+      // third row of q * X + t with Eigen's two-cross-product form (se3quat.h:217-221)
+      const double uv0 = 2 * (qt[1] * X[2] - qt[2] * X[1]), uv1 = 2 * (qt[2] * X[0] - qt[0] * X[2]), uv2 = 2 * (qt[0] * X[1] - qt[1] * X[0]);
+      const double z = X[2] + qt[3] * uv2 + (qt[0] * uv1 - qt[1] * uv0) + qt[6];
+      depthF[e] = z > 0.0 ? 1 : 0;
+    }
+  }
+  // ---- outlier observations (:3761-3804): mono edges first, then stereo
+  std::vector<std::pair<KeyFrame*, MapPoint*>> vToErase;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int kind = pass == 0 ? OSH_EDGE_MONO : OSH_EDGE_STEREO;
+    const double th = pass == 0 ? thMono : thStereo;
+    for (size_t e = 0; e < E; ++e) {
+      if (pk.edge_kind[e] != kind) continue;
+      MapPoint* pMP = pk.vEdgeMP[e];
+      if (pMP->isBad()) continue;
+      if (chiF[e] > th || !depthF[e]) vToErase.push_back(std::make_pair(pk.vEdgeKF[e], pMP));
+    }
+  }
+  std::unique_lock<std::mutex> lock(pMainKF->GetMap()->mMutexMapUpdate);   // :3809
+  for (auto& er : vToErase) {
+    er.first->EraseMapPointMatch(er.second);
+    er.second->EraseObservation(er.first);
+  }
+  // ---- recover optimised data (:3843-3943)
+  std::map<KeyFrame*, int> poseIndex;
+  for (size_t i = 0; i < pk.vPoseKFs.size(); ++i) poseIndex[pk.vPoseKFs[i]] = (int)i;
+  for (KeyFrame* pKFi : vpAdjustKF) {
+    if (pKFi->isBad()) continue;
+    const auto it = poseIndex.find(pKFi);
+    if (it == poseIndex.end()) continue;   // not in the current map: never a vertex
+    const double* qt = &poseF[(size_t)it->second * 7];
+    pKFi->SetPose(Sophus::SE3f(Eigen::Quaterniond(qt[3], qt[0], qt[1], qt[2]).cast<float>(), Eigen::Vector3d(qt[4], qt[5], qt[6]).cast<float>()));
+  }
+  std::map<MapPoint*, int> pointIndex;
+  for (size_t j = 0; j < pk.vPointMPs.size(); ++j) pointIndex[pk.vPointMPs[j]] = (int)j;
+  for (MapPoint* pMPi : vpMPs) {
+    if (pMPi->isBad()) continue;
+    const auto it = pointIndex.find(pMPi);
+    if (it == pointIndex.end()) continue;
+    const size_t j = (size_t)it->second;
+    pMPi->SetWorldPos(Eigen::Vector3d(ptsF[3 * j], ptsF[3 * j + 1], ptsF[3 * j + 2]).cast<float>());
+    pMPi->UpdateNormalAndDepth();
   }
 }
 

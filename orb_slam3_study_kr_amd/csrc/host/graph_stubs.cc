@@ -19,6 +19,16 @@ void KeyFrame::SetPose(const Sophus::SE3f& Tcw) {
   ++mnPoseSets;
 }
 
+// src/KeyFrame.cc:336-349
+std::set<MapPoint*> KeyFrame::GetMapPoints() {
+  std::set<MapPoint*> s;
+  for (MapPoint* pMP : mvpMapPoints) {
+    if (!pMP) continue;
+    if (!pMP->isBad()) s.insert(pMP);
+  }
+  return s;
+}
+
 // src/KeyFrame.cc:309-332 (index looked up through the point's observation)
 void KeyFrame::EraseMapPointMatch(MapPoint* pMP) {
   for (size_t i = 0; i < mvpMapPoints.size(); ++i)

@@ -128,6 +128,44 @@ extern "C" int osh_host_pack_gba(osh_host_graph* g, int32_t sizes[5], double* po
   return 0;
 }
 
+// ---- welding Optimizer::LocalBundleAdjustment(pMainKF, vpAdjustKF, vpFixedKF, pbStopFlag)
+static void kf_lists(osh_host_graph* g, int32_t n_adj, const int32_t* adj, int32_t n_fix, const int32_t* fix,
+                     std::vector<KeyFrame*>& A, std::vector<KeyFrame*>& F) {
+  for (int i = 0; i < n_adj; ++i) A.push_back(g->kfs[adj[i]].get());
+  for (int i = 0; i < n_fix; ++i) F.push_back(g->kfs[fix[i]].get());
+}
+extern "C" int osh_host_pack_welding(osh_host_graph* g, int32_t main_index, int32_t n_adj, const int32_t* adj, int32_t n_fix,
+                                     const int32_t* fix, int32_t sizes[5], double* pose_qt, double* pose_cam, double* points,
+                                     int32_t* edge_pose, int32_t* edge_point, uint8_t* edge_kind, double* edge_obs, double* edge_info,
+                                     int64_t* pose_kf_id, int64_t* point_mp_id) {
+  if (!g) return -1;
+  std::vector<KeyFrame*> A, F;
+  kf_lists(g, n_adj, adj, n_fix, fix, A, F);
+  LbaPack pk;
+  std::vector<MapPoint*> vpMPs;
+  PackWeldingBA(g->kfs[main_index].get(), A, F, pk, vpMPs);
+  for (auto& kf : g->kfs) kf->mnBALocalForMerge = 0;   // undo the marks so the call can be repeated
+  for (auto& mp : g->mps) mp->mnBALocalForMerge = 0;
+  sizes[0] = pk.n_free; sizes[1] = pk.n_fixed; sizes[2] = (int32_t)pk.vPointMPs.size(); sizes[3] = (int32_t)pk.edge_pose.size(); sizes[4] = 0;
+  if (pk.unsupported) return -3;
+  auto cp = [](auto* dst, const auto& src) { if (dst) std::copy(src.begin(), src.end(), dst); };
+  cp(pose_qt, pk.pose_qt); cp(pose_cam, pk.pose_cam); cp(points, pk.points); cp(edge_pose, pk.edge_pose);
+  cp(edge_point, pk.edge_point); cp(edge_kind, pk.edge_kind); cp(edge_obs, pk.edge_obs); cp(edge_info, pk.edge_info);
+  if (pose_kf_id) for (size_t i = 0; i < pk.vPoseKFs.size(); ++i) pose_kf_id[i] = (int64_t)pk.vPoseKFs[i]->mnId;
+  if (point_mp_id) for (size_t j = 0; j < pk.vPointMPs.size(); ++j) point_mp_id[j] = (int64_t)pk.vPointMPs[j]->mnId;
+  return 0;
+}
+extern "C" int osh_host_run_welding(osh_host_graph* g, int32_t main_index, int32_t n_adj, const int32_t* adj, int32_t n_fix,
+                                    const int32_t* fix, unsigned char* stop_flag) {
+  if (!g) return -1;
+  std::vector<KeyFrame*> A, F;
+  kf_lists(g, n_adj, adj, n_fix, fix, A, F);
+  for (auto& kf : g->kfs) kf->mnBALocalForMerge = 0;
+  for (auto& mp : g->mps) mp->mnBALocalForMerge = 0;
+  Optimizer::LocalBundleAdjustment(g->kfs[main_index].get(), A, F, reinterpret_cast<bool*>(stop_flag));
+  return 0;
+}
+
 extern "C" int osh_host_run_gba(osh_host_graph* g, int32_t n_iterations, unsigned char* stop_flag, int64_t n_loop_kf, int32_t robust) {
   if (!g) return -1;
   Optimizer::GlobalBundleAdjustemnt(&g->map, n_iterations, reinterpret_cast<bool*>(stop_flag), (unsigned long)n_loop_kf, robust != 0);

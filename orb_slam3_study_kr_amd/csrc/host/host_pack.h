@@ -62,6 +62,10 @@ osh_lba_ctx* HostSolverContext();   // one solver context per calling thread (Op
 
 // Steps 1-6 of Optimizer::LocalBundleAdjustment; false when the window has no fixed keyframe.
 bool PackLocalBA(KeyFrame* pKF, Map* pMap, LbaPack& pk);
+// Vertex / edge construction of the welding Optimizer::LocalBundleAdjustment(pMainKF, vpAdjustKF, vpFixedKF, ...) (src/Optimizer.cc:3524-3705);
+// vpMPs = the map points of the problem in the reference's insertion order.
+void PackWeldingBA(KeyFrame* pMainKF, const std::vector<KeyFrame*>& vpAdjustKF, const std::vector<KeyFrame*>& vpFixedKF, LbaPack& pk,
+                   std::vector<MapPoint*>& vpMPs);
 // Vertex / edge construction of Optimizer::BundleAdjustment (src/Optimizer.cc:112-300); vbNotIncludedMP as there.
 void PackBundleAdjustment(const std::vector<KeyFrame*>& vpKFs, const std::vector<MapPoint*>& vpMP, LbaPack& pk,
                           std::vector<bool>& vbNotIncludedMP);

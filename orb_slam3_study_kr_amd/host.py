@@ -131,6 +131,37 @@ class HostGraph:
                                        C.cast(None, capi.c_uint8_p), int(n_loop_kf), int(robust))
         assert rc == 0
 
+    # ---- welding Optimizer::LocalBundleAdjustment(pMainKF, vpAdjustKF, vpFixedKF, pbStopFlag)
+    def packed_welding_window(self, main, adjust, fixed):
+        sizes = np.zeros(5, dtype=np.int32)
+        d, i32, u8, i64 = capi.c_double_p, capi.c_int32_p, capi.c_uint8_p, capi.c_int64_p
+        adj, fix = _i32(adjust), _i32(fixed)
+        head = (self.g, int(main), len(adj), capi.ptr(adj, i32), len(fix), capi.ptr(fix, i32), capi.ptr(sizes, i32))
+        rc = self.lib.osh_host_pack_welding(*head, *[C.cast(None, t) for t in (d, d, d, i32, i32, u8, d, d, i64, i64)])
+        assert rc == 0, rc
+        P, F, L, E = (int(x) for x in sizes[:4])
+        o = dict(pose_qt=np.zeros((P + F, 7)), pose_cam=np.zeros((P + F, 5)), points=np.zeros((L, 3)),
+                 edge_pose=np.zeros(E, dtype=np.int32), edge_point=np.zeros(E, dtype=np.int32), edge_kind=np.zeros(E, dtype=np.uint8),
+                 edge_obs=np.zeros((E, 3)), edge_info=np.zeros(E), pose_kf_id=np.zeros(P + F, dtype=np.int64),
+                 point_mp_id=np.zeros(L, dtype=np.int64))
+        rc = self.lib.osh_host_pack_welding(*head, capi.ptr(o["pose_qt"], d), capi.ptr(o["pose_cam"], d), capi.ptr(o["points"], d),
+                                            capi.ptr(o["edge_pose"], i32), capi.ptr(o["edge_point"], i32), capi.ptr(o["edge_kind"], u8),
+                                            capi.ptr(o["edge_obs"], d), capi.ptr(o["edge_info"], d), capi.ptr(o["pose_kf_id"], i64),
+                                            capi.ptr(o["point_mp_id"], i64))
+        assert rc == 0, rc
+        w = LbaWindow(n_free=P, n_fixed=F, pose_qt=o["pose_qt"], pose_cam=o["pose_cam"], points=o["points"],
+                      edge_pose=o["edge_pose"], edge_point=o["edge_point"], edge_kind=o["edge_kind"], edge_obs=o["edge_obs"],
+                      edge_info=o["edge_info"], lambda_init=0.0, max_iterations=5).normalise()
+        w.huber_mono = float(np.float32(np.sqrt(5.99)))      # const float thHuber2D = sqrt(5.99) (src/Optimizer.cc:3625)
+        w.huber_stereo = float(np.float32(np.sqrt(7.815)))
+        return w, o
+
+    def run_welding(self, main, adjust, fixed, stop_flag=None):
+        adj, fix = _i32(adjust), _i32(fixed)
+        rc = self.lib.osh_host_run_welding(self.g, int(main), len(adj), capi.ptr(adj, capi.c_int32_p), len(fix), capi.ptr(fix, capi.c_int32_p),
+                                           capi.ptr(stop_flag, capi.c_uint8_p) if stop_flag is not None else C.cast(None, capi.c_uint8_p))
+        assert rc == 0
+
     def kf_pose_gba(self, i):
         o = np.zeros(7, dtype=np.float32)
         mark = self.lib.osh_host_get_kf_pose_gba(self.g, i, capi.ptr(o, capi.c_float_p))

@@ -125,6 +125,54 @@ def test_global_bundle_adjustment_for_a_loop_keeps_results_beside_the_live_map(o
         assert g.lib.osh_host_map_change_index(g.g) == 0
 
 
+def test_welding_local_bundle_adjustment_two_stages(ob):
+    """Optimizer::LocalBundleAdjustment(pMainKF, vpAdjustKF, vpFixedKF, pbStopFlag) (src/Optimizer.cc:3506-3955): optimize(5) with
+    Huber kernels, outliers demoted to level 1 and every kernel dropped, optimize(10); erased observations, poses and points
+    against the same two stages run with the oracle."""
+    import copy
+    w = synth.make_window(47, n_free=8, n_fixed=3, n_points=700, stereo=True, outlier_frac=0.05)
+    P, F = w.n_free, w.n_fixed
+    with host.HostGraph(w) as g:
+        adjust, fixed = list(range(P)), list(range(P, P + F))
+        pw1, o = g.packed_welding_window(P - 1, adjust, fixed)
+        assert (pw1.n_free, pw1.n_fixed, pw1.n_points, pw1.n_edges) == (P, F, w.n_points, w.n_edges)
+        r1 = ob.lba_solve(pw1)
+        thr = np.where(pw1.edge_kind == 0, synth.CHI2_MONO, synth.CHI2_STEREO)
+        flagged = (r1.edge_chi2 > thr) | (r1.edge_depth_pos == 0)
+        assert 0 < flagged.sum() < 0.2 * pw1.n_edges
+        keep = ~flagged
+        pw2 = copy.copy(pw1)
+        pw2.pose_qt = pw1.pose_qt.copy(); pw2.pose_qt[:P] = r1.pose_qt
+        pw2.points = r1.points.copy()
+        for name in ("edge_pose", "edge_point", "edge_kind", "edge_obs", "edge_info"):
+            setattr(pw2, name, getattr(pw1, name)[keep])
+        pw2.huber_mono = pw2.huber_stereo = float("inf")
+        pw2.max_iterations = 10
+        r2 = ob.lba_solve(pw2.normalise())
+        g.run_welding(P - 1, adjust, fixed)
+        kf_index = {int(i): k for k, i in enumerate(g.kf_id)}
+        got_qt = np.stack([g.kf_pose(kf_index[int(i)]) for i in o["pose_kf_id"][:P]]).astype(np.float64)
+        assert rel_translation_error(got_qt, r2.pose_qt) < 2e-6
+        assert rotation_error(got_qt, r2.pose_qt) < 2e-6
+        mp_index = {int(i): k for k, i in enumerate(g.mp_id)}
+        got_pts = np.stack([g.mp_pos(mp_index[int(i)]) for i in o["point_mp_id"]]).astype(np.float64)
+        bad = np.array([g.lib.osh_host_mp_is_bad(g.g, mp_index[int(i)]) for i in o["point_mp_id"]], dtype=bool)
+        np.testing.assert_allclose(got_pts[~bad], r2.points[~bad], rtol=2e-6, atol=2e-6)
+        # erased observations: demoted edges keep their first-stage chi2, the others are judged after the second stage
+        chi_f = r1.edge_chi2.copy(); chi_f[keep] = r2.edge_chi2
+        out = chi_f > thr
+        out[keep] |= r2.edge_depth_pos == 0
+        near = np.abs(chi_f - thr) < 1e-4 * thr
+        for e in np.nonzero(~near)[0]:
+            k, j = kf_index[int(o["pose_kf_id"][pw1.edge_pose[e]])], mp_index[int(o["point_mp_id"][pw1.edge_point[e]])]
+            if out[e]:
+                assert g.lib.osh_host_kf_observes(g.g, k, j) == 0
+        for i in range(P):
+            assert g.lib.osh_host_kf_pose_sets(g.g, i) == 1
+        for i in range(P, P + F):
+            assert g.lib.osh_host_kf_pose_sets(g.g, i) == 0
+
+
 def test_global_bundle_adjustment_of_a_map_with_80_keyframes(ob):
     """A reduced camera system of 480 unknowns: the LDS-resident factorisation falls back to one block per CU."""
     w = synth.make_window(46, n_free=80, n_fixed=1, n_points=4000, stereo=True, track_len=(3, 10))
