@@ -305,6 +305,27 @@ typedef struct osh_orb_batch {
   const int64_t* pair_cand_base; /* [n_pairs] start of each pair's slice in cand_idx (NULL if brute) */
 } osh_orb_batch;
 
+/* Candidate generation on the device (replaces the host-built lists of Frame::GetFeaturesInArea src/Frame.cc:658-722 /
+ * KeyFrame::GetFeaturesInArea src/KeyFrame.cc:704-745 and the per-candidate filters of the SearchByProjection loops): the train
+ * keypoints are binned into the frame grid exactly as Frame::AssignFeaturesToGrid does (src/Frame.cc:397-417, PosInGrid :726-736:
+ * cell = round((pt - min) * inv), insertion order inside a cell), every query carries its search window.  A candidate is a train
+ * keypoint of a cell overlapping the window, in cell order ix-major / iy / insertion order, with
+ *   train_skip == 0,  octave >= min_level,  max_level < 0 || octave <= max_level,  |x - qx| < r && |y - qy| < r   (float32)
+ *   and, when query_uright is given and train_uright > 0:  |u_right(query) - train_uright| <= tolerance. */
+typedef struct osh_orb_grid {
+  const float* train_xy;        /* [n_pairs*n_train*2] keypoint positions (mvKeysUn[i].pt) */
+  const float* train_uright;    /* [n_pairs*n_train] mvuRight, or NULL */
+  const uint8_t* train_skip;    /* [n_pairs*n_train] 1: never a candidate (slot already holds a map point), or NULL */
+  float min_x, min_y, cell_w_inv, cell_h_inv;   /* mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv */
+  int32_t cols, rows;           /* FRAME_GRID_COLS, FRAME_GRID_ROWS */
+  const float* query_window;    /* [n_pairs*n_query*3] x, y, r of GetFeaturesInArea; r <= 0: the query has no candidates */
+  const int32_t* query_levels;  /* [n_pairs*n_query*2] minLevel, maxLevel */
+  const float* query_uright;    /* [n_pairs*n_query*2] predicted u_right and its tolerance, or NULL */
+} osh_orb_grid;
+
+/* Like osh_orb_upload with batch->cand_* == NULL, but the candidates of every query come from `grid`. */
+int osh_orb_upload_grid(osh_orb_ctx* ctx, const osh_orb_batch* batch, const osh_orb_grid* grid);
+
 /* Upload a batch (descriptors become HBM resident). */
 int osh_orb_upload(osh_orb_ctx* ctx, const osh_orb_batch* batch);
 /* Run the search on the resident batch; synchronous. */

@@ -128,6 +128,17 @@ class OrbBatch(C.Structure):
     ]
 
 
+class OrbGrid(C.Structure):
+    """``osh_orb_grid`` (include/orbslam3_hip.h)."""
+
+    _fields_ = [
+        ("train_xy", c_float_p), ("train_uright", c_float_p), ("train_skip", c_uint8_p),
+        ("min_x", C.c_float), ("min_y", C.c_float), ("cell_w_inv", C.c_float), ("cell_h_inv", C.c_float),
+        ("cols", C.c_int32), ("rows", C.c_int32),
+        ("query_window", c_float_p), ("query_levels", c_int32_p), ("query_uright", c_float_p),
+    ]
+
+
 def ptr(a, typ):
     """Pointer of ctypes type `typ` to the data of numpy array `a` (None -> NULL)."""
     if a is None:
@@ -158,6 +169,7 @@ _SIGNATURES = {
     "osh_orb_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "osh_orb_destroy": (None, [C.c_void_p]),
     "osh_orb_upload": (C.c_int, [C.c_void_p, C.POINTER(OrbBatch)]),
+    "osh_orb_upload_grid": (C.c_int, [C.c_void_p, C.POINTER(OrbBatch), C.POINTER(OrbGrid)]),
     "osh_orb_match": (C.c_int, [C.c_void_p]),
     "osh_orb_download": (C.c_int, [C.c_void_p] + [c_int32_p] * 6),
     "osh_orb_get_profile": (C.c_int, [C.c_void_p, c_int64_p, c_double_p]),

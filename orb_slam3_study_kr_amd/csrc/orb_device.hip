@@ -12,6 +12,7 @@
 // 4 select ops; the 32-byte train rows are staged in LDS and read as wave-wide broadcasts.
 #include "common.h"
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -32,6 +33,12 @@ struct OrbView {
   const int* cand_idx;
   const long long* pair_cand_base;
   unsigned* part_keys;       // [n_split][n_pairs*n_query][2] (brute force partials)
+  // grid mode (osh_orb_upload_grid)
+  const float2* train_xy; const float* train_uright; const unsigned char* train_skip;
+  const int* cell_off;       // [n_pairs*(cols*rows+1)]
+  const int* cell_idx;       // [n_pairs*n_train] train indices by cell, insertion order inside a cell
+  const float* qwin; const int2* qlev; const float2* qur;
+  float min_x, min_y, winv, hinv; int cols, rows;
   int* best_idx; int* best_dist; int* second_dist; int* best_level; int* second_level; int* second_idx;
 };
 
@@ -161,6 +168,84 @@ __global__ __launch_bounds__(kQBlock) void k_orb_windowed(OrbView v) {
   if (lane == 0) emit(v, gq, (size_t)pair * v.n_train, best, second, cand);
 }
 
+// Grid search: one wavefront per query, lane c walks cell c of the query's window (ix-major, then iy: the order of
+// Frame::GetFeaturesInArea) and its entries in insertion order; position key = (cell number << 8) | entry, so equal
+// distances resolve to the earliest candidate of the reference's scan.
+__global__ __launch_bounds__(kQBlock) void k_orb_grid(OrbView v) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t gq = (size_t)blockIdx.x * (kQBlock / 64) + wave;
+  const size_t nq_total = (size_t)v.n_pairs * v.n_query;
+  if (gq >= nq_total) return;
+  const int pair = (int)(gq / v.n_query);
+  const size_t tb = (size_t)pair * v.n_train;
+  const int* coff = v.cell_off + (size_t)pair * (v.cols * v.rows + 1);
+  const int* cidx = v.cell_idx + tb;
+  const float x = v.qwin[gq * 3], y = v.qwin[gq * 3 + 1], r = v.qwin[gq * 3 + 2];
+  const int2 lev = v.qlev[gq];
+  unsigned best = kKeyNone, second = kKeyNone;
+  int c0x = 0, c0y = 0, ncx = 0, ncy = 0;
+  if (r > 0.0f) {
+    // src/Frame.cc:666-684: float arithmetic, left to right
+    const int nMinCellX = max(0, (int)floorf((x - v.min_x - r) * v.winv));
+    const int nMaxCellX = min(v.cols - 1, (int)ceilf((x - v.min_x + r) * v.winv));
+    const int nMinCellY = max(0, (int)floorf((y - v.min_y - r) * v.hinv));
+    const int nMaxCellY = min(v.rows - 1, (int)ceilf((y - v.min_y + r) * v.hinv));
+    if (nMinCellX < v.cols && nMaxCellX >= 0 && nMinCellY < v.rows && nMaxCellY >= 0 && nMaxCellX >= nMinCellX && nMaxCellY >= nMinCellY) {
+      c0x = nMinCellX; c0y = nMinCellY; ncx = nMaxCellX - nMinCellX + 1; ncy = nMaxCellY - nMinCellY + 1;
+    }
+  }
+  const int ncell = ncx * ncy;
+  const uint4 a0 = v.query[gq * 2], a1 = v.query[gq * 2 + 1];
+  const uint4* tr = v.train + tb * 2;
+  const bool check_ur = v.qur != nullptr && v.train_uright != nullptr;
+  float q_ur = 0.f, q_tol = 0.f;
+  if (check_ur) { const float2 u = v.qur[gq]; q_ur = u.x; q_tol = u.y; }
+  for (int c = lane; c < ncell; c += 64) {
+    const int cx = c / ncy, cy = c - cx * ncy;
+    const int cell = (c0x + cx) * v.rows + (c0y + cy);
+    const int k0 = coff[cell], k1 = coff[cell + 1];
+    for (int k = k0; k < k1; ++k) {
+      const int idx = cidx[k];
+      if (v.train_skip && v.train_skip[tb + idx]) continue;
+      const int oct = v.train_level ? v.train_level[tb + idx] : 0;
+      if (oct < lev.x) continue;
+      if (lev.y >= 0 && oct > lev.y) continue;
+      const float2 p = v.train_xy[tb + idx];
+      const float distx = p.x - x, disty = p.y - y;
+      if (!(fabsf(distx) < r && fabsf(disty) < r)) continue;
+      if (check_ur) {
+        const float tur = v.train_uright[tb + idx];
+        if (tur > 0.f) { const float er = fabsf(q_ur - tur); if (er > q_tol) continue; }
+      }
+      const uint4 b0 = tr[(size_t)idx * 2], b1 = tr[(size_t)idx * 2 + 1];
+      const unsigned d = hamming256(a0, a1, b0, b1);
+      top2_insert((d << kPosBits) | ((unsigned)c << 8) | (unsigned)(k - k0), best, second);
+    }
+  }
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) {
+    const unsigned ob = __shfl_xor(best, m, 64), os = __shfl_xor(second, m, 64);
+    top2_merge(ob, os, best, second);
+  }
+  if (lane == 0) {
+    auto decode = [&](unsigned key) {
+      const unsigned pos = key & kPosMask;
+      const int c = (int)(pos >> 8), k = (int)(pos & 0xff);
+      const int cx = c / ncy, cy = c - cx * ncy;
+      return cidx[coff[(c0x + cx) * v.rows + (c0y + cy)] + k];
+    };
+    const unsigned bd = best >> kPosBits, sd = second >> kPosBits;
+    int bi = -1, bl = -1, sl = -1, si = -1, bdist = 256, sdist = 256;
+    if (best != kKeyNone && bd < 256) {
+      bi = decode(best); bdist = (int)bd;
+      bl = v.train_level ? v.train_level[tb + bi] : 0;
+      if (second != kKeyNone && sd < 256) { si = decode(second); sdist = (int)sd; sl = v.train_level ? v.train_level[tb + si] : 0; }
+    }
+    v.best_idx[gq] = bi; v.best_dist[gq] = bdist; v.second_dist[gq] = sdist;
+    v.best_level[gq] = bl; v.second_level[gq] = sl; v.second_idx[gq] = si;
+  }
+}
+
 __global__ void k_orb_distance_matrix(int n, int m, const uint4* a, const uint4* b, int* out) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)n * m) return;
@@ -177,8 +262,9 @@ struct osh_orb_ctx {
   hipStream_t stream = nullptr;
   KernelTimer timer;
   DevBuf d_query, d_train, d_level, d_off, d_idx, d_base, d_part, d_out[6], d_a, d_b, d_dm;
+  DevBuf d_txy, d_tur, d_tskip, d_coff, d_cidx, d_qwin, d_qlev, d_qur;
   OrbView v{};
-  bool uploaded = false, matched = false, windowed = false;
+  bool uploaded = false, matched = false, windowed = false, grid = false;
 };
 
 #define OSH_TRY(expr) do { int _rc = (expr); if (_rc != OSH_OK) return _rc; } while (0)
@@ -201,7 +287,8 @@ extern "C" void osh_orb_destroy(osh_orb_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DevBuf* bufs[] = {&c->d_query, &c->d_train, &c->d_level, &c->d_off, &c->d_idx, &c->d_base, &c->d_part,
-                    &c->d_out[0], &c->d_out[1], &c->d_out[2], &c->d_out[3], &c->d_out[4], &c->d_out[5], &c->d_a, &c->d_b, &c->d_dm};
+                    &c->d_out[0], &c->d_out[1], &c->d_out[2], &c->d_out[3], &c->d_out[4], &c->d_out[5], &c->d_a, &c->d_b, &c->d_dm,
+                    &c->d_txy, &c->d_tur, &c->d_tskip, &c->d_coff, &c->d_cidx, &c->d_qwin, &c->d_qlev, &c->d_qur};
   for (DevBuf* b : bufs) b->release();
   c->timer.destroy();
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -233,6 +320,7 @@ extern "C" int osh_orb_upload(osh_orb_ctx* c, const osh_orb_batch* b) {
     v.train_level = c->d_level.as<int>();
   }
   c->windowed = b->cand_off != nullptr;
+  c->grid = false;
   if (c->windowed) {
     const size_t noff = (size_t)b->n_pairs * (b->n_query + 1);
     // validate candidate lists on the host: an out-of-range index would fault the GPU
@@ -278,6 +366,55 @@ extern "C" int osh_orb_upload(osh_orb_ctx* c, const osh_orb_batch* b) {
   return OSH_OK;
 }
 
+extern "C" int osh_orb_upload_grid(osh_orb_ctx* c, const osh_orb_batch* b, const osh_orb_grid* g) {
+  if (!g || !b || b->cand_off) { set_error("osh_orb_upload_grid: needs a grid and a batch without candidate lists"); return OSH_ERR_INVALID; }
+  if (!g->train_xy || !g->query_window || !g->query_levels || g->cols <= 0 || g->rows <= 0 || (long)g->cols * g->rows > (1 << 14)) {
+    set_error("osh_orb_upload_grid: bad grid description"); return OSH_ERR_INVALID;
+  }
+  OSH_TRY(osh_orb_upload(c, b));
+  hipStream_t s = c->stream;
+  const size_t nq = (size_t)b->n_pairs * b->n_query, nt = (size_t)b->n_pairs * b->n_train;
+  const int ncell = g->cols * g->rows;
+  // Frame::AssignFeaturesToGrid (src/Frame.cc:397-417): counting sort by cell, keypoint order inside a cell
+  std::vector<int> coff((size_t)b->n_pairs * (ncell + 1), 0), cidx(std::max<size_t>(nt, 1), 0), cell_of(std::max<size_t>(b->n_train, 1));
+  for (int p = 0; p < b->n_pairs; ++p) {
+    int* off = &coff[(size_t)p * (ncell + 1)];
+    const float* xy = g->train_xy + (size_t)p * b->n_train * 2;
+    for (int i = 0; i < b->n_train; ++i) {
+      const int posX = (int)std::round((xy[2 * i] - g->min_x) * g->cell_w_inv);       // PosInGrid, src/Frame.cc:726-736
+      const int posY = (int)std::round((xy[2 * i + 1] - g->min_y) * g->cell_h_inv);
+      cell_of[i] = (posX < 0 || posX >= g->cols || posY < 0 || posY >= g->rows) ? -1 : posX * g->rows + posY;
+      if (cell_of[i] >= 0) off[cell_of[i] + 1]++;
+    }
+    for (int k = 0; k < ncell; ++k) {
+      if (off[k + 1] > 255) { set_error("pair %d: more than 255 keypoints in one grid cell", p); return OSH_ERR_UNSUPPORTED; }
+      off[k + 1] += off[k];
+    }
+    std::vector<int> fill(off, off + ncell);
+    int* ci = &cidx[(size_t)p * b->n_train];
+    for (int i = 0; i < b->n_train; ++i) if (cell_of[i] >= 0) ci[fill[cell_of[i]]++] = i;
+  }
+  auto up = [&](DevBuf& d, const void* src, size_t bytes) -> int {
+    OSH_TRY(d.reserve(std::max<size_t>(bytes, 8)));
+    if (bytes) OSH_HIP(hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, s));
+    return OSH_OK;
+  };
+  OSH_TRY(up(c->d_coff, coff.data(), coff.size() * 4)); OSH_TRY(up(c->d_cidx, cidx.data(), nt * 4));
+  OSH_TRY(up(c->d_txy, g->train_xy, nt * 8));
+  OSH_TRY(up(c->d_qwin, g->query_window, nq * 12)); OSH_TRY(up(c->d_qlev, g->query_levels, nq * 8));
+  OrbView& v = c->v;
+  v.train_xy = c->d_txy.as<float2>(); v.cell_off = c->d_coff.as<int>(); v.cell_idx = c->d_cidx.as<int>();
+  v.qwin = c->d_qwin.as<float>(); v.qlev = c->d_qlev.as<int2>();
+  v.train_uright = nullptr; v.train_skip = nullptr; v.qur = nullptr;
+  if (g->train_uright) { OSH_TRY(up(c->d_tur, g->train_uright, nt * 4)); v.train_uright = c->d_tur.as<float>(); }
+  if (g->train_skip) { OSH_TRY(up(c->d_tskip, g->train_skip, nt)); v.train_skip = c->d_tskip.as<unsigned char>(); }
+  if (g->query_uright) { OSH_TRY(up(c->d_qur, g->query_uright, nq * 8)); v.qur = c->d_qur.as<float2>(); }
+  v.min_x = g->min_x; v.min_y = g->min_y; v.winv = g->cell_w_inv; v.hinv = g->cell_h_inv; v.cols = g->cols; v.rows = g->rows;
+  OSH_HIP(hipStreamSynchronize(s));
+  c->grid = true;
+  return OSH_OK;
+}
+
 extern "C" int osh_orb_match(osh_orb_ctx* c) {
   if (!c || !c->uploaded) { set_error("osh_orb_match: nothing uploaded"); return OSH_ERR_INVALID; }
   OSH_HIP(hipSetDevice(c->device));
@@ -287,7 +424,10 @@ extern "C" int osh_orb_match(osh_orb_ctx* c) {
   if (nq == 0) { c->matched = true; return OSH_OK; }
   if (c->timer.enabled) OSH_TRY(c->timer.init());
   const bool t = c->timer.begin(0, s);
-  if (c->windowed) {
+  if (c->grid) {
+    const unsigned grid = (unsigned)((nq + (kQBlock / 64) - 1) / (kQBlock / 64));
+    hipLaunchKernelGGL(k_orb_grid, dim3(grid), dim3(kQBlock), 0, s, v);
+  } else if (c->windowed) {
     const unsigned grid = (unsigned)((nq + (kQBlock / 64) - 1) / (kQBlock / 64));
     hipLaunchKernelGGL(k_orb_windowed, dim3(grid), dim3(kQBlock), 0, s, v);
   } else {

@@ -53,6 +53,35 @@ class OrbMatcher:
         self._shape = (n_pairs, nq)
         capi.check(self.lib.osh_orb_upload(self.ctx, C.byref(b)), "osh_orb_upload", self.lib)
 
+    def upload_grid(self, query_desc, train_desc, train_level, train_xy, query_window, query_levels, train_uright=None,
+                    train_skip=None, query_uright=None):
+        """One frame pair whose candidates are generated on the device from the train frame's grid
+        (Frame::GetFeaturesInArea, src/Frame.cc:658-722): query_window [nq,3] = x, y, r; query_levels [nq,2] = min, max."""
+        from . import synth
+        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+        q = np.ascontiguousarray(query_desc, dtype=np.uint8)
+        t = np.ascontiguousarray(train_desc, dtype=np.uint8)
+        lev = np.ascontiguousarray(train_level, dtype=np.int32)
+        b = capi.OrbBatch()
+        b.n_pairs, b.n_query, b.n_train = 1, q.shape[0], t.shape[0]
+        b.query_desc, b.train_desc, b.train_level = capi.ptr(q, capi.c_uint8_p), capi.ptr(t, capi.c_uint8_p), capi.ptr(lev, capi.c_int32_p)
+        g = capi.OrbGrid()
+        keep = [q, t, lev, f32(train_xy), f32(query_window), np.ascontiguousarray(query_levels, dtype=np.int32)]
+        g.train_xy, g.query_window, g.query_levels = capi.ptr(keep[3], capi.c_float_p), capi.ptr(keep[4], capi.c_float_p), capi.ptr(keep[5], capi.c_int32_p)
+        if train_uright is not None:
+            keep.append(f32(train_uright)); g.train_uright = capi.ptr(keep[-1], capi.c_float_p)
+        if train_skip is not None:
+            keep.append(np.ascontiguousarray(train_skip, dtype=np.uint8)); g.train_skip = capi.ptr(keep[-1], capi.c_uint8_p)
+        if query_uright is not None:
+            keep.append(f32(query_uright)); g.query_uright = capi.ptr(keep[-1], capi.c_float_p)
+        g.min_x, g.min_y = 0.0, 0.0
+        g.cell_w_inv = np.float32(synth.FRAME_GRID_COLS) / np.float32(synth.IMG_W)
+        g.cell_h_inv = np.float32(synth.FRAME_GRID_ROWS) / np.float32(synth.IMG_H)
+        g.cols, g.rows = synth.FRAME_GRID_COLS, synth.FRAME_GRID_ROWS
+        self._keep = keep
+        self._shape = (1, q.shape[0])
+        capi.check(self.lib.osh_orb_upload_grid(self.ctx, C.byref(b), C.byref(g)), "osh_orb_upload_grid", self.lib)
+
     def match(self):
         capi.check(self.lib.osh_orb_match(self.ctx), "osh_orb_match", self.lib)
 

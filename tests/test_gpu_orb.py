@@ -100,3 +100,47 @@ def test_tie_break_and_none_cases(matcher, ob):
         np.testing.assert_array_equal(got[k][0], exp[k], err_msg=k)
     assert got["best_idx"][0][0] == 2 and got["best_idx"][0][1] == -1
     assert got["best_idx"][0][2] == -1 and got["best_dist"][0][2] == 256  # only candidate is at distance 256
+
+
+def test_device_candidate_generation_equals_host_built_lists(hip_lib):
+    """osh_orb_upload_grid: the grid binning, window / level / occupancy / u_right filters and the candidate ORDER of
+    Frame::GetFeaturesInArea (src/Frame.cc:658-722) on the device give the same best / second as the search over lists built
+    on the host in the reference's order -- including ties, which resolve to the earliest candidate."""
+    from oracle import binding as ob
+    rng = np.random.Generator(np.random.PCG64(77))
+    nt, nq = 1500, 900
+    xy = np.stack([rng.uniform(0, synth.IMG_W, nt), rng.uniform(0, synth.IMG_H, nt)], axis=1).astype(np.float32)
+    xy[:40] = xy[40:80]                                          # keypoints at identical positions (same cell, same distance)
+    level = rng.integers(0, synth.N_LEVELS, nt).astype(np.int32)
+    # few distinct descriptors -> many exact ties between candidates
+    base = rng.integers(0, 256, (12, 32), dtype=np.uint8)
+    tdesc = base[rng.integers(0, 12, nt)]
+    qdesc = base[rng.integers(0, 12, nq)] ^ np.packbits(rng.uniform(0, 1, (nq, 256)) < 0.01, axis=1)
+    qx = rng.uniform(-20, synth.IMG_W + 20, nq).astype(np.float32)
+    qy = rng.uniform(-20, synth.IMG_H + 20, nq).astype(np.float32)
+    r = rng.choice([0.0, 8.0, 15.0, 40.0, 90.0], nq).astype(np.float32)
+    lo = rng.integers(-1, 5, nq).astype(np.int32)
+    hi = np.where(rng.uniform(0, 1, nq) < 0.3, -1, lo + rng.integers(0, 4, nq)).astype(np.int32)
+    skip = (rng.uniform(0, 1, nt) < 0.1).astype(np.uint8)
+    tur = np.where(rng.uniform(0, 1, nt) < 0.6, xy[:, 0] - rng.uniform(1, 30, nt), -1.0).astype(np.float32)
+    qur = np.stack([qx - rng.uniform(1, 30, nq), rng.uniform(2, 25, nq)], axis=1).astype(np.float32)
+    with orb.OrbMatcher(0) as m:
+        m.upload_grid(qdesc, tdesc, level, xy, np.stack([qx, qy, r], axis=1), np.stack([lo, hi], axis=1), train_uright=tur,
+                      train_skip=skip, query_uright=qur)
+        m.match()
+        got = m.download()
+    # host-built lists in the reference's order with the same static filters
+    off, idx = synth.features_in_area_lists(xy[:, 0], xy[:, 1], level, qx, qy, r, lo, hi)
+    keep_off, keep_idx = [0], []
+    for q in range(nq):
+        for j in idx[off[q]:off[q + 1]]:
+            if skip[j]:
+                continue
+            if tur[j] > 0 and np.abs(np.float32(qur[q, 0]) - tur[j]) > qur[q, 1]:
+                continue
+            keep_idx.append(j)
+        keep_off.append(len(keep_idx))
+    ref = ob.orb_search(qdesc, tdesc, level, np.asarray(keep_off, dtype=np.int32), np.asarray(keep_idx, dtype=np.int32))
+    for name in ("best_idx", "best_dist", "second_dist", "best_level", "second_level"):
+        np.testing.assert_array_equal(got[name][0], ref[name], err_msg=name)
+    assert (got["best_idx"][0] >= 0).sum() > 300 and (r == 0).any()
