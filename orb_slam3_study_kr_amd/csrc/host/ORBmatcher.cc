@@ -1,11 +1,13 @@
 // ORBmatcher.cc -- ORB_SLAM3::ORBmatcher::SearchByProjection on MI355X (host side).
 //
-// The candidate loops of the reference (src/ORBmatcher.cc:84-120, 1743-1768) run on the GPU as one batched
-// nearest / second-nearest Hamming search (osh_orb_*); what stays on the host is the geometry that builds the
-// candidate lists (the reference's own Frame::GetFeaturesInArea, a "next" row of SURVEY.md 8f) and the
-// sequential "this slot was just taken" rule, replayed exactly as SURVEY.md 8a prescribes: occupancy only ever
-// removes candidates, so only a query whose best or second-best slot was claimed earlier in the same call is
-// re-scanned with the reference's left-to-right loop.
+// The candidate loops of the reference (src/ORBmatcher.cc:84-120, 1743-1768, 1949-1964, 499-520) run on the GPU as one
+// batched nearest / second-nearest Hamming search (osh_orb_*).  The candidates themselves are generated on the device
+// too: the host hands over the keypoint positions and every query's window (centre, radius, level range, u_right test)
+// and osh_orb_upload_grid reproduces Frame::GetFeaturesInArea / KeyFrame::GetFeaturesInArea including their candidate
+// order.  What stays on the host is the projection geometry of each entry point and the sequential "this slot was just
+// taken" rule, replayed exactly as SURVEY.md 8a prescribes: occupancy only ever removes candidates, so only a query whose
+// best or second-best slot was claimed earlier in the same call is re-scanned with the reference's left-to-right loop
+// (its candidate list is then rebuilt by the frame's own GetFeaturesInArea).
 #include "ORBmatcher.h"
 
 #include <cmath>
@@ -51,25 +53,56 @@ osh_orb_ctx* thread_ctx() {
 
 struct Search {
   std::vector<uint8_t> qdesc;            // [nq*32]
-  std::vector<int32_t> off{0}, idx;      // candidate lists (static filters already applied)
+  std::vector<float> win;                // [nq*3] x, y, r of the query's GetFeaturesInArea call
+  std::vector<int32_t> lev;              // [nq*2] minLevel, maxLevel
+  std::vector<float> ur;                 // [nq*2] predicted u_right and tolerance (empty: no u_right test in this entry point)
   std::vector<int32_t> best_idx, best_dist, second_dist, best_level, second_level, second_idx;
-  int nq() const { return (int)off.size() - 1; }
+  int nq() const { return (int)(win.size() / 3); }
+  void add(const cv::Mat& d, float x, float y, float r, int minLevel, int maxLevel) {
+    const uint8_t* dp = d.ptr<uint8_t>(0);
+    qdesc.insert(qdesc.end(), dp, dp + 32);
+    win.push_back(x); win.push_back(y); win.push_back(r);
+    lev.push_back(minLevel); lev.push_back(maxLevel);
+  }
 };
 
-// one batched device search of all queries against the frame's descriptors
-bool device_search(Search& s, const cv::Mat& train, const std::vector<int32_t>& level) {
+// the frame / keyframe whose keypoints are searched
+struct Train {
+  const cv::Mat* desc = nullptr;
+  std::vector<int32_t> level;
+  std::vector<float> xy, uright;         // uright empty: no stereo test
+  std::vector<uint8_t> skip;             // slots that are no candidates when the call starts
+  float min_x = 0, min_y = 0, winv = 0, hinv = 0;
+  int cols = 0, rows = 0;
+  int n() const { return (int)level.size(); }
+};
+
+Train train_of(const Frame& F) {
+  Train t;
+  t.desc = &F.mDescriptors;
+  t.level.resize(F.N); t.xy.resize((size_t)F.N * 2); t.skip.assign(F.N, 0);
+  for (int i = 0; i < F.N; ++i) { t.level[i] = F.mvKeysUn[i].octave; t.xy[2 * i] = F.mvKeysUn[i].pt.x; t.xy[2 * i + 1] = F.mvKeysUn[i].pt.y; }
+  t.min_x = F.mnMinX; t.min_y = F.mnMinY; t.winv = F.mfGridElementWidthInv; t.hinv = F.mfGridElementHeightInv;
+  t.cols = FRAME_GRID_COLS; t.rows = FRAME_GRID_ROWS;
+  return t;
+}
+
+// one batched device search of all queries; the candidates come from the train side's grid
+bool device_search(Search& s, const Train& t) {
   const int nq = s.nq();
   for (auto* v : {&s.best_idx, &s.best_dist, &s.second_dist, &s.best_level, &s.second_level, &s.second_idx}) v->assign(nq, -1);
   if (nq == 0) return true;
   osh_orb_ctx* ctx = thread_ctx();
   if (!ctx) return false;
-  if (s.idx.empty()) s.idx.push_back(0);
-  const int64_t base = 0;
   osh_orb_batch b;
-  b.n_pairs = 1; b.n_query = nq; b.n_train = train.rows;
-  b.query_desc = s.qdesc.data(); b.train_desc = train.ptr<uint8_t>(0); b.train_level = level.data();
-  b.cand_off = s.off.data(); b.cand_idx = s.idx.data(); b.pair_cand_base = &base;
-  if (osh_orb_upload(ctx, &b) != OSH_OK || osh_orb_match(ctx) != OSH_OK ||
+  b.n_pairs = 1; b.n_query = nq; b.n_train = t.n();
+  b.query_desc = s.qdesc.data(); b.train_desc = t.desc->ptr<uint8_t>(0); b.train_level = t.level.data();
+  b.cand_off = nullptr; b.cand_idx = nullptr; b.pair_cand_base = nullptr;
+  osh_orb_grid g;
+  g.train_xy = t.xy.data(); g.train_uright = t.uright.empty() ? nullptr : t.uright.data(); g.train_skip = t.skip.data();
+  g.min_x = t.min_x; g.min_y = t.min_y; g.cell_w_inv = t.winv; g.cell_h_inv = t.hinv; g.cols = t.cols; g.rows = t.rows;
+  g.query_window = s.win.data(); g.query_levels = s.lev.data(); g.query_uright = s.ur.empty() ? nullptr : s.ur.data();
+  if (osh_orb_upload_grid(ctx, &b, &g) != OSH_OK || osh_orb_match(ctx) != OSH_OK ||
       osh_orb_download(ctx, s.best_idx.data(), s.best_dist.data(), s.second_dist.data(), s.best_level.data(),
                        s.second_level.data(), s.second_idx.data()) != OSH_OK) {
     std::fprintf(stderr, "ORBmatcher: device search failed: %s\n", osh_last_error());
@@ -78,19 +111,30 @@ bool device_search(Search& s, const cv::Mat& train, const std::vector<int32_t>& 
   return true;
 }
 
-// the reference's scan of one candidate list with the current occupancy (only for contested queries)
-void rescan(const Search& s, int q, const cv::Mat& train, const std::vector<int32_t>& level, const std::vector<uint8_t>& occupied,
+// the reference's scan of one query's candidates with the current occupancy (only for contested queries): `area` is the
+// entry point's own GetFeaturesInArea call, the static filters are the ones the device applied
+template <class Area>
+void rescan(const Search& s, int q, const Train& t, const std::vector<uint8_t>& occupied, Area area,
             int& bestIdx, int& bestDist, int& bestDist2, int& bestLevel, int& bestLevel2) {
   bestDist = 256; bestLevel = -1; bestDist2 = 256; bestLevel2 = -1; bestIdx = -1;
   const uint32_t* qd = reinterpret_cast<const uint32_t*>(&s.qdesc[(size_t)q * 32]);
-  for (int c = s.off[q]; c < s.off[q + 1]; ++c) {
-    const int idx = s.idx[c];
-    if (occupied[idx]) continue;
-    const uint32_t* td = train.ptr<uint32_t>(idx);
+  const float r = s.win[3 * q + 2];
+  if (!(r > 0.f)) return;
+  const int minLevel = s.lev[2 * q], maxLevel = s.lev[2 * q + 1];
+  const std::vector<size_t> cand = area(s.win[3 * q], s.win[3 * q + 1], r, minLevel, maxLevel);
+  for (const size_t i : cand) {
+    const int idx = (int)i;
+    if (t.skip[idx] || occupied[idx]) continue;
+    if (t.level[idx] < minLevel || (maxLevel >= 0 && t.level[idx] > maxLevel)) continue;
+    if (!s.ur.empty() && !t.uright.empty() && t.uright[idx] > 0) {
+      const float er = std::fabs(s.ur[2 * q] - t.uright[idx]);
+      if (er > s.ur[2 * q + 1]) continue;
+    }
+    const uint32_t* td = t.desc->ptr<uint32_t>(idx);
     int dist = 0;
     for (int k = 0; k < 8; ++k) dist += __builtin_popcount(qd[k] ^ td[k]);
-    if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = level[idx]; bestIdx = idx; }
-    else if (dist < bestDist2) { bestLevel2 = level[idx]; bestDist2 = dist; }
+    if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = t.level[idx]; bestIdx = idx; }
+    else if (dist < bestDist2) { bestLevel2 = t.level[idx]; bestDist2 = dist; }
   }
 }
 
@@ -104,12 +148,10 @@ int ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMap
     std::abort();  // no silent CPU fallback
   }
   const bool bFactor = th != 1.0;
-  std::vector<int32_t> level(F.N);
-  std::vector<uint8_t> occupied(F.N, 0);
-  for (int i = 0; i < F.N; ++i) {
-    level[i] = F.mvKeysUn[i].octave;
-    occupied[i] = (F.mvpMapPoints[i] && F.mvpMapPoints[i]->Observations() > 0) ? 1 : 0;   // :88-90 at call entry
-  }
+  Train t = train_of(F);
+  t.uright = F.mvuRight;                                            // stereo consistency window (:92-97)
+  for (int i = 0; i < F.N; ++i) t.skip[i] = (F.mvpMapPoints[i] && F.mvpMapPoints[i]->Observations() > 0) ? 1 : 0;   // :88-90 at call entry
+  auto area = [&F](float x, float y, float r, int lo, int hi) { return F.GetFeaturesInArea(x, y, r, lo, hi); };
   Search s;
   std::vector<MapPoint*> qMP;
   for (size_t iMP = 0; iMP < vpMapPoints.size(); iMP++) {
@@ -122,23 +164,12 @@ int ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMap
     float r = RadiusByViewingCos(pMP->mTrackViewCos);   // window size depends on the viewing direction (:66-72)
     if (bFactor) r *= th;
     const float win = r * F.mvScaleFactors[nPredictedLevel];
-    const std::vector<size_t> vIndices = F.GetFeaturesInArea(pMP->mTrackProjX, pMP->mTrackProjY, win, nPredictedLevel - 1, nPredictedLevel);
-    if (vIndices.empty()) continue;
-    for (const size_t idx : vIndices) {
-      if (occupied[idx]) continue;                                  // slots taken before this call
-      if (F.mvuRight[idx] > 0) {                                    // stereo consistency window (:92-97)
-        const float er = std::fabs(pMP->mTrackProjXR - F.mvuRight[idx]);
-        if (er > win) continue;
-      }
-      s.idx.push_back((int32_t)idx);
-    }
-    s.off.push_back((int32_t)s.idx.size());
-    const cv::Mat d = pMP->GetDescriptor();
-    const uint8_t* dp = d.ptr<uint8_t>(0);
-    s.qdesc.insert(s.qdesc.end(), dp, dp + 32);
+    // candidates: GetFeaturesInArea(mTrackProjX, mTrackProjY, win, level-1, level) minus occupied slots, |ur - uR| <= win
+    s.add(pMP->GetDescriptor(), pMP->mTrackProjX, pMP->mTrackProjY, win, nPredictedLevel - 1, nPredictedLevel);
+    s.ur.push_back(pMP->mTrackProjXR); s.ur.push_back(win);
     qMP.push_back(pMP);
   }
-  if (!device_search(s, F.mDescriptors, level)) return 0;
+  if (!device_search(s, t)) return 0;
 
   int nmatches = 0;
   std::vector<uint8_t> taken(F.N, 0);  // slots claimed during this call
@@ -146,7 +177,7 @@ int ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMap
     int bestIdx = s.best_idx[q], bestDist = s.best_dist[q], bestDist2 = s.second_dist[q];
     int bestLevel = s.best_level[q], bestLevel2 = s.second_level[q];
     if ((bestIdx >= 0 && taken[bestIdx]) || (s.second_idx[q] >= 0 && taken[s.second_idx[q]]))
-      rescan(s, q, F.mDescriptors, level, taken, bestIdx, bestDist, bestDist2, bestLevel, bestLevel2);
+      rescan(s, q, t, taken, area, bestIdx, bestDist, bestDist2, bestLevel, bestLevel2);
     // ratio to the second match only if both are in the same scale level; the product is a float (:123-139)
     if (bestDist <= TH_HIGH) {
       if (bestLevel == bestLevel2 && bestDist > mfNNratio * bestDist2) continue;
@@ -192,12 +223,11 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
   const bool bForward = tlc(2) > CurrentFrame.mb && !bMono;
   const bool bBackward = -tlc(2) > CurrentFrame.mb && !bMono;
 
-  std::vector<int32_t> level(CurrentFrame.N);
-  std::vector<uint8_t> occupied(CurrentFrame.N, 0);
-  for (int i = 0; i < CurrentFrame.N; ++i) {
-    level[i] = CurrentFrame.mvKeysUn[i].octave;
-    occupied[i] = (CurrentFrame.mvpMapPoints[i] && CurrentFrame.mvpMapPoints[i]->Observations() > 0) ? 1 : 0;
-  }
+  Train t = train_of(CurrentFrame);
+  t.uright = CurrentFrame.mvuRight;
+  for (int i = 0; i < CurrentFrame.N; ++i)
+    t.skip[i] = (CurrentFrame.mvpMapPoints[i] && CurrentFrame.mvpMapPoints[i]->Observations() > 0) ? 1 : 0;
+  auto area = [&CurrentFrame](float x, float y, float r, int lo, int hi) { return CurrentFrame.GetFeaturesInArea(x, y, r, lo, hi); };
   Search s;
   std::vector<int> qLast;  // index in LastFrame of every query
   for (int i = 0; i < LastFrame.N; i++) {
@@ -211,33 +241,22 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
     if (uv(1) < CurrentFrame.mnMinY || uv(1) > CurrentFrame.mnMaxY) continue;
     const int nLastOctave = LastFrame.mvKeys[i].octave;
     const float radius = th * CurrentFrame.mvScaleFactors[nLastOctave];   // window scales with the octave
-    std::vector<size_t> vIndices2;
-    if (bForward) vIndices2 = CurrentFrame.GetFeaturesInArea(uv(0), uv(1), radius, nLastOctave);
-    else if (bBackward) vIndices2 = CurrentFrame.GetFeaturesInArea(uv(0), uv(1), radius, 0, nLastOctave);
-    else vIndices2 = CurrentFrame.GetFeaturesInArea(uv(0), uv(1), radius, nLastOctave - 1, nLastOctave + 1);
-    if (vIndices2.empty()) continue;
-    for (const size_t i2 : vIndices2) {
-      if (occupied[i2]) continue;
-      if (CurrentFrame.mvuRight[i2] > 0) {
-        const float ur = uv(0) - CurrentFrame.mbf * invzc;
-        const float er = std::fabs(ur - CurrentFrame.mvuRight[i2]);
-        if (er > radius) continue;
-      }
-      s.idx.push_back((int32_t)i2);
-    }
-    s.off.push_back((int32_t)s.idx.size());
-    const cv::Mat d = pMP->GetDescriptor();
-    const uint8_t* dp = d.ptr<uint8_t>(0);
-    s.qdesc.insert(s.qdesc.end(), dp, dp + 32);
+    // level range by the motion direction (:1744-1750): forward -> [octave, inf), backward -> [0, octave], else octave +- 1
+    int lo, hi;
+    if (bForward) { lo = nLastOctave; hi = -1; }
+    else if (bBackward) { lo = 0; hi = nLastOctave; }
+    else { lo = nLastOctave - 1; hi = nLastOctave + 1; }
+    s.add(pMP->GetDescriptor(), uv(0), uv(1), radius, lo, hi);
+    s.ur.push_back(uv(0) - CurrentFrame.mbf * invzc); s.ur.push_back(radius);   // |ur - mvuRight| <= radius (:1762-1767)
     qLast.push_back(i);
   }
-  if (!device_search(s, CurrentFrame.mDescriptors, level)) return 0;
+  if (!device_search(s, t)) return 0;
 
   int nmatches = 0;
   std::vector<uint8_t> taken(CurrentFrame.N, 0);
   for (int q = 0; q < s.nq(); ++q) {
     int bestIdx2 = s.best_idx[q], bestDist = s.best_dist[q], d2, l1, l2;
-    if (bestIdx2 >= 0 && taken[bestIdx2]) rescan(s, q, CurrentFrame.mDescriptors, level, taken, bestIdx2, bestDist, d2, l1, l2);
+    if (bestIdx2 >= 0 && taken[bestIdx2]) rescan(s, q, t, taken, area, bestIdx2, bestDist, d2, l1, l2);
     if (bestDist > TH_HIGH) continue;
     MapPoint* pMP = LastFrame.mvpMapPoints[qLast[q]];
     CurrentFrame.mvpMapPoints[bestIdx2] = pMP;
@@ -278,12 +297,9 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std
   const float factor = 1.0f / HISTO_LENGTH;
   const std::vector<MapPoint*> vpMPs = pKF->GetMapPointMatches();
 
-  std::vector<int32_t> level(CurrentFrame.N);
-  std::vector<uint8_t> occupied(CurrentFrame.N, 0);
-  for (int i = 0; i < CurrentFrame.N; ++i) {
-    level[i] = CurrentFrame.mvKeysUn[i].octave;
-    occupied[i] = CurrentFrame.mvpMapPoints[i] ? 1 : 0;
-  }
+  Train t = train_of(CurrentFrame);
+  for (int i = 0; i < CurrentFrame.N; ++i) t.skip[i] = CurrentFrame.mvpMapPoints[i] ? 1 : 0;   // any matched slot (:1952)
+  auto area = [&CurrentFrame](float x, float y, float r, int lo, int hi) { return CurrentFrame.GetFeaturesInArea(x, y, r, lo, hi); };
   Search s;
   std::vector<int> qKF;  // keypoint index in pKF of every query
   for (size_t i = 0, iend = vpMPs.size(); i < iend; i++) {
@@ -302,25 +318,16 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std
     if (dist3D < minDistance || dist3D > maxDistance) continue;
     const int nPredictedLevel = pMP->PredictScale(dist3D, &CurrentFrame);
     const float radius = th * CurrentFrame.mvScaleFactors[nPredictedLevel];
-    const std::vector<size_t> vIndices2 = CurrentFrame.GetFeaturesInArea(uv(0), uv(1), radius, nPredictedLevel - 1, nPredictedLevel + 1);
-    if (vIndices2.empty()) continue;
-    for (const size_t i2 : vIndices2) {
-      if (occupied[i2]) continue;
-      s.idx.push_back((int32_t)i2);
-    }
-    s.off.push_back((int32_t)s.idx.size());
-    const cv::Mat d = pMP->GetDescriptor();
-    const uint8_t* dp = d.ptr<uint8_t>(0);
-    s.qdesc.insert(s.qdesc.end(), dp, dp + 32);
+    s.add(pMP->GetDescriptor(), uv(0), uv(1), radius, nPredictedLevel - 1, nPredictedLevel + 1);
     qKF.push_back((int)i);
   }
-  if (!device_search(s, CurrentFrame.mDescriptors, level)) return 0;
+  if (!device_search(s, t)) return 0;
 
   int nmatches = 0;
   std::vector<uint8_t> taken(CurrentFrame.N, 0);
   for (int q = 0; q < s.nq(); ++q) {
     int bestIdx2 = s.best_idx[q], bestDist = s.best_dist[q], d2, l1, l2;
-    if (bestIdx2 >= 0 && taken[bestIdx2]) rescan(s, q, CurrentFrame.mDescriptors, level, taken, bestIdx2, bestDist, d2, l1, l2);
+    if (bestIdx2 >= 0 && taken[bestIdx2]) rescan(s, q, t, taken, area, bestIdx2, bestDist, d2, l1, l2);
     if (bestDist > ORBdist) continue;
     CurrentFrame.mvpMapPoints[bestIdx2] = vpMPs[qKF[q]];
     taken[bestIdx2] = 1;
@@ -359,9 +366,16 @@ int search_by_sim3(KeyFrame* pKF, Sophus::Sim3f& Scw, const std::vector<MapPoint
   spAlreadyFound.erase(static_cast<MapPoint*>(NULL));
 
   const int N = (int)vpMatched.size();
-  std::vector<int32_t> level(N);
-  std::vector<uint8_t> occupied(N, 0);
-  for (int i = 0; i < N; ++i) { level[i] = pKF->mvKeysUn[i].octave; occupied[i] = vpMatched[i] ? 1 : 0; }
+  Train t;
+  t.desc = &pKF->mDescriptors;
+  t.level.resize(N); t.xy.resize((size_t)N * 2); t.skip.assign(N, 0);
+  for (int i = 0; i < N; ++i) {
+    t.level[i] = pKF->mvKeysUn[i].octave; t.xy[2 * i] = pKF->mvKeysUn[i].pt.x; t.xy[2 * i + 1] = pKF->mvKeysUn[i].pt.y;
+    t.skip[i] = vpMatched[i] ? 1 : 0;                                  // matched slots are skipped (:501-502)
+  }
+  t.min_x = (float)pKF->mnMinX; t.min_y = (float)pKF->mnMinY; t.winv = pKF->mfGridElementWidthInv; t.hinv = pKF->mfGridElementHeightInv;
+  t.cols = pKF->mnGridCols; t.rows = pKF->mnGridRows;
+  auto area = [pKF](float x, float y, float r, int, int) { return pKF->GetFeaturesInArea(x, y, r); };
   Search s;
   std::vector<int> qMP;
   for (int iMP = 0, iendMP = (int)vpPoints.size(); iMP < iendMP; iMP++) {
@@ -390,27 +404,17 @@ int search_by_sim3(KeyFrame* pKF, Sophus::Sim3f& Scw, const std::vector<MapPoint
     if (dotp < 0.5 * dist) continue;
     const int nPredictedLevel = pMP->PredictScale(dist, pKF);
     const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
-    const std::vector<size_t> vIndices = pKF->GetFeaturesInArea(u, v, radius);
-    if (vIndices.empty()) continue;
-    for (const size_t idx : vIndices) {
-      if (occupied[idx]) continue;
-      const int& kpLevel = pKF->mvKeysUn[idx].octave;
-      if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
-      s.idx.push_back((int32_t)idx);
-    }
-    s.off.push_back((int32_t)s.idx.size());
-    const cv::Mat d = pMP->GetDescriptor();
-    const uint8_t* dp = d.ptr<uint8_t>(0);
-    s.qdesc.insert(s.qdesc.end(), dp, dp + 32);
+    // KeyFrame::GetFeaturesInArea(u, v, radius) has no level arguments; the loop keeps levels L-1 .. L (:504-507)
+    s.add(pMP->GetDescriptor(), u, v, radius, std::max(nPredictedLevel - 1, 0), nPredictedLevel);
     qMP.push_back(iMP);
   }
-  if (!device_search(s, pKF->mDescriptors, level)) return 0;
+  if (!device_search(s, t)) return 0;
 
   int nmatches = 0;
   std::vector<uint8_t> taken(N, 0);
   for (int q = 0; q < s.nq(); ++q) {
     int bestIdx = s.best_idx[q], bestDist = s.best_dist[q], d2, l1, l2;
-    if (bestIdx >= 0 && taken[bestIdx]) rescan(s, q, pKF->mDescriptors, level, taken, bestIdx, bestDist, d2, l1, l2);
+    if (bestIdx >= 0 && taken[bestIdx]) rescan(s, q, t, taken, area, bestIdx, bestDist, d2, l1, l2);
     if (bestIdx >= 0 && bestDist <= th_low * ratioHamming) {      // int <= float (:523,636)
       vpMatched[bestIdx] = vpPoints[qMP[q]];
       if (vpMatchedKF) (*vpMatchedKF)[bestIdx] = (*vpPointsKFs)[qMP[q]];
