@@ -28,6 +28,7 @@ if str(ROOT) not in sys.path:
 from orb_slam3_study_kr_amd import dist as osh_dist  # noqa: E402
 from orb_slam3_study_kr_amd import synth  # noqa: E402
 
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (= vector) peak, AMD product figure; v_mfma_f64_16x16x4 measured at 64 cycles
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -146,10 +147,11 @@ def run_lba(args, info, windows):
     solver.set_profiling(True)
     solver.optimize()
     prof = solver.profile()
+    plan = solver.plan_stats()
     solver.set_profiling(False)
     solver.close()
     alg = kernel_algorithmic_bytes(windows, results)
-    return dict(windows=windows, results=results, elapsed=elapsed, upload_s=upload_s, prof=prof, alg=alg)
+    return dict(windows=windows, results=results, elapsed=elapsed, upload_s=upload_s, prof=prof, alg=alg, plan=plan)
 
 
 def run_orb(args, info):
@@ -299,6 +301,15 @@ def main():
                     avg_launch_ms=avg_ms, launches=launches, algorithmic_bytes_per_launch=alg[dom] / max(launches, 1),
                     avg_ms_by_kernel={lba.kernel_symbol(k): prof[k][1] / max(prof[k][0], 1) for k in STEP_KERNELS[dom]})
     kernels = {k: dict(launches=prof[k][0], total_ms=round(prof[k][1], 4)) for k in prof}
+    # FP64 matrix-core view of the Schur products: every launch of k_schur_items<true>/<false> issues the plan's MFMA count for
+    # each still-active window (v_mfma_f64_16x16x4_f64 = 2048 flop); peak = AMD's 78.6 TFLOP/s FP64 matrix figure for MI355X
+    res_all = lba_out["results"]
+    mfma_total = lba_out["plan"]["mfma_per_pass"] / max(len(res_all), 1) * float(sum(int(r.trials) for r in res_all))
+    mfma_ms = prof["schur"][1] + prof["schur_cross"][1]
+    mfma = dict(kernel="k_schur_items<true> + k_schur_items<false>", issued_TFLOPs=(mfma_total * 2048 / (mfma_ms * 1e-3) / 1e12) if mfma_ms > 0 else 0.0,
+                peak_TFLOPs=FP64_MFMA_PEAK_TFLOPS, useful_fraction_of_issued=lba_out["plan"]["useful_blocks"] * 108 * 2 / max(lba_out["plan"]["mfma_per_pass"] * 2048, 1))
+    mfma["frac"] = mfma["issued_TFLOPs"] / FP64_MFMA_PEAK_TFLOPS
+    roofline["mfma"] = mfma
     steps = {st: dict(total_ms=round(step_ms[st], 4), alg_GBps=(alg[st] / (step_ms[st] * 1e-3) / 1e9) if step_ms[st] > 0 else None)
              for st in STEP_KERNELS}
     whole_bytes = sum(alg.values())

@@ -199,6 +199,10 @@ typedef struct osh_pose_result {
 
 int osh_pose_optimize(osh_lba_ctx* ctx, int32_t n, const osh_pose_problem* problems, osh_pose_result* results);
 
+/* Statistics of the Schur work plan of the resident batch: {items, symmetric items, v_mfma_f64_16x16x4 instructions of one
+ * pass over every window, useful 6x6x3 products of one pass (upper triangle), contribution slots, reduce entries}. */
+int osh_lba_get_plan_stats(osh_lba_ctx* ctx, int64_t stats[6]);
+
 /* Host-only self check of the Schur work plan built at upload time (needs no GPU): groups the
  * landmarks of `problem` by observer set exactly as osh_lba_upload does, verifies that the plan
  * covers every observer pair of every landmark exactly once and returns

@@ -165,6 +165,7 @@ _SIGNATURES = {
     "osh_lba_get_profile": (C.c_int, [C.c_void_p, c_int64_p, c_double_p]),
     "osh_lba_kernel_name": (C.c_char_p, [C.c_int]),
     "osh_pose_optimize": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(PoseProblem), C.POINTER(PoseResult)]),
+    "osh_lba_get_plan_stats": (C.c_int, [C.c_void_p, c_int64_p]),
     "osh_lba_schur_plan_stats": (C.c_int, [C.POINTER(LbaProblem), c_int64_p]),
     "osh_orb_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "osh_orb_destroy": (None, [C.c_void_p]),

@@ -1676,6 +1676,13 @@ extern "C" int osh_lba_get_profile(osh_lba_ctx* c, int64_t launches[OSH_K_COUNT]
   return OSH_OK;
 }
 
+extern "C" int osh_lba_get_plan_stats(osh_lba_ctx* c, int64_t stats[6]) {
+  if (!c || !stats || c->n_windows <= 0) { set_error("osh_lba_get_plan_stats: nothing uploaded"); return OSH_ERR_INVALID; }
+  stats[0] = (int64_t)c->n_items; stats[1] = (int64_t)c->n_sym; stats[2] = c->plan_tile_steps; stats[3] = c->plan_pair_blocks;
+  stats[4] = (int64_t)c->n_contrib; stats[5] = (int64_t)c->n_rblk;
+  return OSH_OK;
+}
+
 extern "C" const char* osh_lba_kernel_name(int k) {
   static const char* names[OSH_K_COUNT] = {"k_lin_items<0>", "k_pose_reduce", "k_schur_items<true>", "k_solve", "k_backsub", "k_residual", "k_control", "k_schur_reduce", "k_schur_items<false>", "k_lin_aux", "k_lin_items<1>"};
   return (k >= 0 && k < OSH_K_COUNT) ? names[k] : "?";

@@ -110,6 +110,12 @@ class LbaSolver:
         capi.check(self.lib.osh_pose_optimize(self.ctx, n, probs, rs), "osh_pose_optimize", self.lib)
         return [a.read_scalars(r) for r, a in zip(rs, res)]
 
+    def plan_stats(self) -> dict:
+        st = np.zeros(6, dtype=np.int64)
+        capi.check(self.lib.osh_lba_get_plan_stats(self.ctx, capi.ptr(st, capi.c_int64_p)), "osh_lba_get_plan_stats", self.lib)
+        return dict(items=int(st[0]), sym_items=int(st[1]), mfma_per_pass=int(st[2]), useful_blocks=int(st[3]), contributions=int(st[4]),
+                    reduce_entries=int(st[5]))
+
     def set_profiling(self, enable: bool):
         capi.check(self.lib.osh_lba_set_profiling(self.ctx, int(enable)), "osh_lba_set_profiling", self.lib)
 

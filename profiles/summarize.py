@@ -29,7 +29,8 @@ if rows:
     # rocprofv3 kernel name -> short name of capi.KERNEL_NAMES
     names = {"void k_lin_items<0>": "linearize", "void k_lin_items<1>": "lin_pose", "k_lin_aux": "lin_aux", "k_pose_reduce": "pose_hess",
              "void k_schur_items<true>": "schur", "void k_schur_items<false>": "schur_cross", "k_schur_reduce": "schur_reduce",
-             "void k_solve<24>": "solve", "void k_solve<12>": "solve", "void k_solve<6>": "solve", "k_backsub": "backsub", "k_residual": "residual"}
+             "void k_solve<24, 256>": "solve", "void k_solve<12, 256>": "solve", "void k_solve<6, 256>": "solve", "void k_solve<24, 512>": "solve",
+             "void k_solve<12, 512>": "solve", "void k_solve<6, 512>": "solve", "k_backsub": "backsub", "k_residual": "residual"}
     traffic = {}
     for k, short in names.items():
         if k in piv.columns and "FETCH_SIZE" in piv.index and "WRITE_SIZE" in piv.index:
