@@ -226,7 +226,7 @@ constexpr int kSiKS = 3 * kSiLm + 1;   // LDS row stride (doubles)
 constexpr int kSiRows = 6 * kItemPoses;
 
 template <bool SYM>
-__global__ __launch_bounds__(64) void k_schur_items(BatchView bv, int item_base) {
+__global__ __launch_bounds__(64, 2) void k_schur_items(BatchView bv, int item_base) {
   __shared__ double shA[kSiRows * kSiKS];
   __shared__ double shB[kSiRows * kSiKS];
   __shared__ int shP[64 + 8];
@@ -252,35 +252,54 @@ __global__ __launch_bounds__(64) void k_schur_items(BatchView bv, int item_base)
   double csum[6] = {0, 0, 0, 0, 0, 0};
   const int mrow = lane & 15, mk = lane >> 4;
 
-  for (int c0 = 0; c0 < it.n_lm; c0 += kSiLm) {
-    const int ri = c0 + l;
-    const bool valid = ri < it.n_lm;
-    SRec rec;
-    rec.lm = 0; rec.e_first = 0; rec.x_lo = rec.x_hi = rec.y_lo = rec.y_hi = 0xffffffffu; rec.flags = 0; rec.pad = 0;
-    if (valid) rec = recs[ri];
-    const unsigned xo = (((s < 4) ? rec.x_lo : rec.x_hi) >> (8 * (s & 3))) & 0xffu;
+  // Software pipeline over the chunks: the blocks of chunk c+1 are requested right after chunk c's operands are parked in LDS,
+  // so they are in flight during chunk c's MFMA phase (which needs few registers), and the record of chunk c+2 with them.
+  // Every load is unconditional on a clamped index (a load inside a divergent branch is waited for at the end of the branch,
+  // which used to expose three dependent global round trips per chunk); validity is applied when the values are used.
+  struct Dat { double2 w[9]; double2 y[9]; double hl[6], bl[3]; };
+  const int last_rec = it.n_lm - 1;
+  const int last_edge = wd.E - 1;
+  auto load_rec = [&](int c0, int4& ra, int4& rb) {
+    const int4* src = reinterpret_cast<const int4*>(recs + min(c0 + l, last_rec));
+    ra = src[0]; rb = src[1];          // {lm, e_first, x_lo, x_hi} {y_lo, y_hi, flags, pad}
+  };
+  auto slot_of = [&](unsigned lo, unsigned hi) { return (((s < 4) ? lo : hi) >> (8 * (s & 3))) & 0xffu; };
+  auto load_dat = [&](const int4& ra, const int4& rb, Dat& d) {
+    const unsigned xo = slot_of((unsigned)ra.z, (unsigned)ra.w);
+    const double2* src = reinterpret_cast<const double2*>(Hpl + (size_t)min(ra.y + (xo != kAbsent ? (int)xo : 0), last_edge) * 18);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) d.w[k] = src[k];
+    if (!SYM) {
+      const unsigned yo = slot_of((unsigned)rb.x, (unsigned)rb.y);
+      const double2* sy = reinterpret_cast<const double2*>(Hpl + (size_t)min(ra.y + (yo != kAbsent ? (int)yo : 0), last_edge) * 18);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) d.y[k] = sy[k];
+    }
+    const size_t gl = (size_t)wd.pt_off + ra.x;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) d.hl[k] = bv.Hll[gl * 6 + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d.bl[k] = bv.bl[gl * 3 + k];
+  };
+  auto park = [&](int c0, const int4& ra, const int4& rb, const Dat& d) {
+    const bool valid = (c0 + l) < it.n_lm;
+    const unsigned xo = valid ? slot_of((unsigned)ra.z, (unsigned)ra.w) : kAbsent;
     double W[18];
 #pragma unroll
-    for (int k = 0; k < 18; ++k) W[k] = 0.0;
-    if (xo != kAbsent) {
-      const double2* src = reinterpret_cast<const double2*>(Hpl + (size_t)(rec.e_first + (int)xo) * 18);
-#pragma unroll
-      for (int k = 0; k < 9; ++k) { const double2 u = src[k]; W[2 * k] = u.x; W[2 * k + 1] = u.y; }
-    }
+    for (int k = 0; k < 9; ++k) { W[2 * k] = (xo != kAbsent) ? d.w[k].x : 0.0; W[2 * k + 1] = (xo != kAbsent) ? d.w[k].y : 0.0; }
     double D[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) D[k] = 0.0;
     if (valid) {
-      const size_t gl = (size_t)wd.pt_off + rec.lm;
-      const double* hl = bv.Hll + gl * 6;
+      const size_t gl = (size_t)wd.pt_off + ra.x;
       double Dinv[9];
-      dev::inv3_sym(hl[0] + lambda, hl[1], hl[2], hl[3] + lambda, hl[4], hl[5] + lambda, Dinv);
-      const double b0 = bv.bl[gl * 3], b1 = bv.bl[gl * 3 + 1], b2 = bv.bl[gl * 3 + 2];
+      dev::inv3_sym(d.hl[0] + lambda, d.hl[1], d.hl[2], d.hl[3] + lambda, d.hl[4], d.hl[5] + lambda, Dinv);
+      const double b0 = d.bl[0], b1 = d.bl[1], b2 = d.bl[2];
       D[0] = Dinv[0]; D[1] = Dinv[1]; D[2] = Dinv[2]; D[3] = Dinv[4]; D[4] = Dinv[5]; D[5] = Dinv[8];
       D[6] = Dinv[0] * b0 + Dinv[1] * b1 + Dinv[2] * b2;
       D[7] = Dinv[3] * b0 + Dinv[4] * b1 + Dinv[5] * b2;
       D[8] = Dinv[6] * b0 + Dinv[7] * b1 + Dinv[8] * b2;
-      if (SYM && s == 0 && (rec.flags & 1)) {
+      if (SYM && s == 0 && (rb.z & 1)) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) bv.dinv[gl * 9 + k] = D[k];
       }
@@ -301,20 +320,16 @@ __global__ __launch_bounds__(64) void k_schur_items(BatchView bv, int item_base)
         }
       }
       if (!SYM) {
-        const unsigned yo = (((s < 4) ? rec.y_lo : rec.y_hi) >> (8 * (s & 3))) & 0xffu;
+        const unsigned yo = valid ? slot_of((unsigned)rb.x, (unsigned)rb.y) : kAbsent;
         double Y[18];
 #pragma unroll
-        for (int k = 0; k < 18; ++k) Y[k] = 0.0;
-        if (yo != kAbsent) {
-          const double2* src = reinterpret_cast<const double2*>(Hpl + (size_t)(rec.e_first + (int)yo) * 18);
-#pragma unroll
-          for (int k = 0; k < 9; ++k) { const double2 u = src[k]; Y[2 * k] = u.x; Y[2 * k + 1] = u.y; }
-        }
+        for (int k = 0; k < 9; ++k) { Y[2 * k] = (yo != kAbsent) ? d.y[k].x : 0.0; Y[2 * k + 1] = (yo != kAbsent) ? d.y[k].y : 0.0; }
 #pragma unroll
         for (int r = 0; r < 6; ++r) { b_row[r * kSiKS + 0] = Y[r * 3]; b_row[r * kSiKS + 1] = Y[r * 3 + 1]; b_row[r * kSiKS + 2] = Y[r * 3 + 2]; }
       }
     }
-    __syncthreads();
+  };
+  auto multiply = [&]() {
 #pragma unroll
     for (int ks = 0; ks < (3 * kSiLm) / 4; ++ks) {
       double a[3], b[3];
@@ -329,6 +344,19 @@ __global__ __launch_bounds__(64) void k_schur_items(BatchView bv, int item_base)
         for (int tj = SYM ? ti : 0; tj < 3; ++tj)
           if (ti < TX && tj < TY) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
     }
+  };
+  int4 rc0, rc1, rn0, rn1;
+  Dat d;
+  load_rec(0, rc0, rc1);
+  load_rec(kSiLm, rn0, rn1);
+  load_dat(rc0, rc1, d);
+  for (int c0 = 0; c0 < it.n_lm; c0 += kSiLm) {
+    park(c0, rc0, rc1, d);                 // Dinv, BD, W of chunk c0 -> LDS (consumes d)
+    __syncthreads();
+    rc0 = rn0; rc1 = rn1;                  // loaded one iteration ago
+    load_dat(rc0, rc1, d);                 // chunk c0 + 1: in flight during the MFMAs below
+    load_rec(c0 + 2 * kSiLm, rn0, rn1);
+    multiply();
   }
   __syncthreads();
   // contributions: lane holds D[row = (lane >> 4) + 4 reg][col = lane & 15] of each tile
