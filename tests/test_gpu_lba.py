@@ -191,3 +191,36 @@ def test_observer_set_grouping_ragged_and_long_tracks(solver, ob, kwargs):
     np.testing.assert_allclose(bs, bso, rtol=1e-10, atol=1e-11 * np.abs(bso).max())
     np.testing.assert_allclose(x, xo, rtol=1e-7, atol=1e-9 * np.abs(xo).max())
     _check_result(solver.solve([w])[0], ob.lba_solve(w), w)
+
+
+def test_randomised_small_windows_in_one_batch(solver, ob):
+    """Forty random windows of assorted shapes in one batch (1-9 optimisable poses, 0-4 fixed, 5-400 landmarks, mono / stereo /
+    mixed, ragged observer sets, short iteration limits): every one against the oracle.  Exercises items without row poses,
+    landmarks seen by fixed keyframes only, single-pose windows and windows without any fixed keyframe."""
+    rng = np.random.Generator(np.random.PCG64(2024))
+    ws = []
+    for k in range(40):
+        n_free = int(rng.integers(1, 10))
+        n_fixed = int(rng.integers(0, 5)) if n_free > 1 else int(rng.integers(1, 4))
+        w = synth.make_window(900 + k, n_free=n_free, n_fixed=n_fixed, n_points=int(rng.integers(5, 400)), stereo=bool(rng.integers(0, 2)),
+                              mixed_mono_frac=float(rng.choice([0.0, 0.3])), track_len=(2, int(rng.integers(3, 14))),
+                              obs_dropout=float(rng.choice([0.0, 0.15, 0.35])), max_iterations=int(rng.integers(1, 11)),
+                              lambda_init=float(rng.choice([0.0, 1e-3, 10.0])))
+        if w.n_edges == 0 or w.n_points == 0:
+            continue
+        ws.append(w)
+    assert len(ws) > 30
+    got = solver.solve(ws)
+    worst = 0.0
+    for w, g in zip(ws, got):
+        r = ob.lba_solve(w)
+        assert g.iterations == r.iterations
+        np.testing.assert_array_equal(g.trials_trace, r.trials_trace)
+        np.testing.assert_allclose(g.chi2_trace, r.chi2_trace, rtol=1e-6)
+        # the estimates are only comparable where the gauge is fixed: a stereo window needs one fixed keyframe, a window
+        # with monocular edges only needs two (scale); otherwise the cost agrees but the state may drift along the gauge
+        all_mono = bool((w.edge_kind == 0).all())
+        if w.n_fixed >= (2 if all_mono else 1):
+            worst = max(worst, rel_translation_error(g.pose_qt, r.pose_qt))
+            np.testing.assert_allclose(g.points, r.points, rtol=1e-5, atol=1e-5, err_msg=f"window {w.n_free}+{w.n_fixed} KF, {w.n_points} points")
+    assert worst < 1e-6
