@@ -1351,7 +1351,7 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
     // Fewer windows than half the CUs: one 512-thread block per window with the widest panel that fits.
     const bool latency = nw <= 128;
     c->solve_threads = latency ? kSolveThreadsLatency : kSolveThreadsBatch;
-    auto need = [&](int b) { return ((size_t)2 * b * ldlt_row_stride(n_max) + ldlt_row_stride(n_max) + 2 * b + c->solve_threads / 64 + 8) * sizeof(double); };
+    auto need = [&](int b) { return ldlt_lds_doubles(b, ldlt_row_stride(n_max), c->solve_threads) * sizeof(double); };
     int nb = 0;
     for (size_t budget : {(size_t)75 * 1024, (size_t)150 * 1024}) {
       if (latency && budget < 150 * 1024) continue;

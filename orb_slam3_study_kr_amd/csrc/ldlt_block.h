@@ -1,8 +1,9 @@
 // ldlt_block.h -- dense blocked LDL^T (no pivoting, upper storage, fails only on an exactly-zero pivot) + solve,
 // executed cooperatively by one thread block.  Stand-in for Eigen::SimplicialLDLT behind LinearSolverEigen::solve
 // (Thirdparty/g2o/g2o/solvers/linear_solver_eigen.h:94-124).
-//   A   : n x n row-major in global memory, upper triangle valid; overwritten by the factor
-//   rhs : n, overwritten by the forward-substituted right-hand side
+//   A   : n x n row-major in global memory, upper triangle valid; overwritten by the factor (the strict lower triangle is
+//         scratch: never read, partly overwritten)
+//   rhs : n, read once (the forward substitution runs on a copy in LDS)
 //   sh  : dynamic LDS scratch, ldlt_lds_doubles(NB, W, NT) doubles, W = ldlt_row_stride(n_max)
 //   xs  : returns a pointer into `sh` holding the solution (n doubles) when the result is true
 #pragma once
@@ -15,11 +16,18 @@ namespace osh {
 __host__ __device__ constexpr int ldlt_row_stride(int n) { return (n + 24 + 1) & ~1; }
 
 __host__ __device__ constexpr size_t ldlt_lds_doubles(int nb, int W, int nthreads) {
-  return (size_t)2 * nb * W + W + 2 * nb + nthreads / 64 + 8;
+  return (size_t)2 * nb * W + W + 2 * nb + (size_t)nb * nb + nthreads / 64 + 8;
+}
+
+// value of `v` in lane `lane` (compile-time constant after unrolling) as a wave-uniform scalar
+__device__ __forceinline__ double ldlt_readlane(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
 }
 
 template <int NB, int NT>
-__device__ bool ldlt_solve_block(double* __restrict__ A, double* __restrict__ rhs, const int n, const int W, double* sh,
+__device__ bool ldlt_solve_block(double* __restrict__ A, const double* __restrict__ rhs, const int n, const int W, double* sh,
                                  double*& xs_out, double*& shw_out) {
   constexpr int nb = NB;
   constexpr int kSolveThreads = NT;
@@ -29,11 +37,14 @@ __device__ bool ldlt_solve_block(double* __restrict__ A, double* __restrict__ rh
   double* xs = Lp + (size_t)nb * W;  // [W]
   double* dd = xs + W;               // [nb]
   double* part = dd + nb;            // [nb]
-  double* shw = part + nb;           // [NT/64] cross-wave scratch for the caller
+  double* Ld = part + nb;            // [nb][nb] diagonal block: padded input, then its scaled factor rows
+  double* shw = Ld + nb * nb;        // [NT/64] cross-wave scratch for the caller
   int& sh_ok = *reinterpret_cast<int*>(shw + kSolveThreads / 64);
   xs_out = xs;
   shw_out = shw;
   if (tid == 0) sh_ok = 1;
+  // the right-hand side lives in LDS (in `xs`) from here on: forward-substituted in place, then overwritten by the solution
+  for (int k = tid; k < n; k += kSolveThreads) xs[k] = rhs[k];
   __syncthreads();
 
 #ifdef OSH_LDLT_TRACE
@@ -46,76 +57,118 @@ __device__ bool ldlt_solve_block(double* __restrict__ A, double* __restrict__ rh
   for (int k0 = 0; k0 < n; k0 += nb) {
     const int kb = min(nb, n - k0);
     const int m = n - k0;  // local columns 0..m-1, rhs at local column m
-    // ---- 1. diagonal block: load, then factor it with ONE wavefront (LDS ops of a wave stay in order)
-    for (int idx = tid; idx < kb * kb; idx += kSolveThreads) {
-      const int r = idx / kb, c2 = idx - r * kb;
-      U[r * W + c2] = (c2 >= r) ? A[(size_t)(k0 + r) * n + k0 + c2] : 0.0;
+    // ---- 1. diagonal block, padded with the identity to a full NB x NB block so the factor below is branch-free
+    for (int idx = tid; idx < NB * NB; idx += kSolveThreads) {
+      const int r = idx / NB, c2 = idx - r * NB;
+      const bool in = r < kb && c2 < kb;
+      const double a = A[in && c2 >= r ? (size_t)(k0 + r) * n + k0 + c2 : 0];
+      Ld[idx] = in ? (c2 >= r ? a : 0.0) : (r == c2 ? 1.0 : 0.0);
     }
     __syncthreads();
     OSH_TR(0);
     if (tid < 64) {
-      for (int k = 0; k < kb; ++k) {
-        const double d = U[k * W + k];
-        if (d == 0.0 && tid == 0) sh_ok = 0;
-        const int rows = kb - k - 1;
-        // multipliers l_ii = u_k,ii / d once per row (the products are the same numbers as with a division per element), then
-        // two rows x 32 columns per pass: no FP64 division and no integer division inside the element loop
-        if (tid < rows) part[tid] = U[k * W + k + 1 + tid] / d;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (kb <= 32) {
-          const int jj = tid & 31, rsub = tid >> 5;
-          const double ukj = (jj < kb) ? U[k * W + jj] : 0.0;
-          for (int ri = rsub; ri < rows; ri += 2) {
-            const int ii = k + 1 + ri;
-            if (jj < kb && jj >= ii) U[ii * W + jj] -= part[ri] * ukj;
-          }
-        } else {
-          for (int idx = tid; idx < rows * kb; idx += 64) {
-            const int ri = idx / kb, jj = idx - ri * kb;
-            const int ii = k + 1 + ri;
-            if (jj >= ii) U[ii * W + jj] -= part[ri] * U[k * W + jj];
-          }
+      // ONE wavefront factors the block.  Lane j keeps column j in registers and the pivot row is broadcast with v_readlane
+      // (an LDS round trip per pivot bounded this phase before): l_k,j = u_k,j / d_k is formed by lane j itself, then
+      // u_i,j -= l_k,i * u_k,j for every row i > k.  Lanes j < i compute values of the unused lower triangle; nothing valid
+      // reads them.  Same operations in the same order as the textbook loop; a padded pivot is 1 with zero multipliers.
+      double col[NB];
+      const int cj = tid < NB ? tid : 0;
+#pragma unroll
+      for (int r = 0; r < NB; ++r) col[r] = Ld[r * NB + cj];
+      double* lout = tid < NB ? Ld + tid : part;  // lanes beyond the block write to a slot nobody reads in this phase
+      bool zero_pivot = false;
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const double d = ldlt_readlane(col[k], k);
+        zero_pivot |= d == 0.0;
+        const double lk = col[k] / d;
+#pragma unroll
+        for (int ii = k + 1; ii < NB; ++ii) {
+          col[ii] -= ldlt_readlane(lk, ii) * col[k];
+          asm volatile("" : "+v"(col[ii]));  // keeps the update here: sunk to its use, all 276 multipliers stay live in SGPRs
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        lout[k * NB] = tid > k ? lk : 0.0;  // scaled row k of the block (l_kj)
+        if (tid == 0) dd[k] = d;
+        __builtin_amdgcn_sched_barrier(0);
       }
-      for (int idx = tid; idx < kb * kb; idx += 64) {
-        const int r = idx / kb, c2 = idx - r * kb;
-        const double d = U[r * W + r];
-        Lp[r * W + c2] = (c2 > r) ? U[r * W + c2] / d : 0.0;
-        if (c2 == r) dd[r] = d;
-      }
+      if (zero_pivot && tid == 0) sh_ok = 0;
     }
     __syncthreads();
     OSH_TR(1);
     if (!sh_ok) break;
-    // ---- 2. row panel: every thread forward-substitutes whole columns (incl. the rhs column m) in registers
+    // ---- 2. row panel: every thread forward-substitutes whole columns (incl. the rhs column m) in registers.  Column
+    // sweep: once w_k is final it is removed from every later row, so the 23 + 22 + ... FMAs of a sweep are independent (the
+    // row-by-row order had one 276-long dependent chain); each w_r still receives its terms in the order k = 0, 1, ...
+    // Uniform (broadcast) LDS operands are read as 16-byte pairs through ONE base register with immediate offsets, and every
+    // store is unconditional: padded rows r >= kb carry zeros into panel rows nobody reads, and their global store goes to an
+    // entry of the block's unused lower triangle.  (With per-row branches and 8-byte reads this phase issued ~2.4 k
+    // instructions per column, a third of them address bookkeeping, and was bound by instruction issue.)
+    static_assert(NB % 2 == 0, "panel width must be even");
+    typedef double ldlt_f64x2 __attribute__((ext_vector_type(2)));
+    const ldlt_f64x2* const Ld2 = reinterpret_cast<const ldlt_f64x2*>(Ld);        // [NB][NB / 2]
+    const ldlt_f64x2* const ys2 = reinterpret_cast<const ldlt_f64x2*>(xs + k0);   // rhs entries of this panel
+    const ldlt_f64x2* const dd2 = reinterpret_cast<const ldlt_f64x2*>(dd);
+    char* const Apanel = reinterpret_cast<char*>(A + (size_t)k0 * n + k0);
+    const unsigned n8p = (unsigned)n * 8u;
     for (int jj = kb + tid; jj <= m; jj += kSolveThreads) {
       double wv[NB];
+      const bool is_rhs = jj == m;
+      const unsigned j8 = is_rhs ? 0u : (unsigned)jj * 8u;
 #pragma unroll
-      for (int r = 0; r < NB; ++r) {
-        wv[r] = 0.0;
-        if (r < kb) wv[r] = (jj == m) ? rhs[k0 + r] : A[(size_t)(k0 + r) * n + k0 + jj];
-      }
-      // the multipliers of row r are fetched from LDS as one batch BEFORE the dependent chain of FMAs (one wait per row
-      // instead of one per multiplier: the chain itself cannot hide an LDS round trip)
+      for (int r2 = 0; r2 < NB / 2; ++r2) {
+        const ldlt_f64x2 y = ys2[r2];
 #pragma unroll
-      for (int r = 1; r < NB; ++r) {
-        if (r < kb) {
-          double lrow[NB];
-#pragma unroll
-          for (int k = 0; k < r; ++k) lrow[k] = Lp[k * W + r];
-          double acc = wv[r];
-#pragma unroll
-          for (int k = 0; k < r; ++k) acc -= lrow[k] * wv[k];
-          wv[r] = acc;
+        for (int h = 0; h < 2; ++h) {
+          const int r = 2 * r2 + h;
+          const unsigned roff = (unsigned)(r < kb ? r : kb - 1) * n8p;
+          const double v = *reinterpret_cast<const double*>(Apanel + (roff + j8));
+          wv[r] = r < kb ? (is_rhs ? y[h] : v) : 0.0;
         }
       }
+      // multipliers of sweep k + 1 are fetched while sweep k runs; the scheduling fence keeps the compiler from hoisting all
+      // the LDS reads to the top (that needs 552 registers)
+      ldlt_f64x2 lnext[NB / 2];
 #pragma unroll
-      for (int r = 0; r < NB; ++r) {
-        if (r < kb) { U[r * W + jj] = wv[r]; Lp[r * W + jj] = (jj < m) ? wv[r] / dd[r] : 0.0; }
+      for (int p2 = 0; p2 < NB / 2; ++p2) lnext[p2] = Ld2[p2];
+#pragma unroll
+      for (int k = 0; k < NB - 1; ++k) {
+        ldlt_f64x2 lcur[NB / 2];
+#pragma unroll
+        for (int p2 = (k + 1) / 2; p2 < NB / 2; ++p2) lcur[p2] = lnext[p2];
+#pragma unroll
+        for (int p2 = (k + 2) / 2; p2 < NB / 2; ++p2) lnext[p2] = Ld2[(k + 1) * (NB / 2) + p2];
+#pragma unroll
+        for (int r = k + 1; r < NB; ++r) {
+          wv[r] -= lcur[r / 2][r & 1] * wv[k];
+          asm volatile("" : "+v"(wv[r]));  // pins the FMA to this sweep (the optimiser otherwise sinks it into a row-order chain)
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
       }
+      // panels for the trailing update, and the final values of each row straight to the factor (no separate write-back pass)
+#pragma unroll
+      for (int r2 = 0; r2 < NB / 2; ++r2) {
+        const ldlt_f64x2 d2 = dd2[r2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int r = 2 * r2 + h;
+          const double q = wv[r] / d2[h];
+          const double l = is_rhs ? 0.0 : q;
+          U[r * W + jj] = wv[r]; Lp[r * W + jj] = l;
+          unsigned o = (r < kb && !is_rhs) ? (unsigned)r * n8p + j8 : n8p;  // n8p: entry (1, 0) of the block
+          asm volatile("" : "+v"(o));
+          *reinterpret_cast<double*>(Apanel + o) = l;
+        }
+      }
+      if (is_rhs) {
+#pragma unroll
+        for (int r = 0; r < NB; ++r) if (r < kb) xs[k0 + r] = wv[r];
+      }
+    }
+    // the factored diagonal block: pivots on the diagonal, l_rj to their right
+    for (int idx = tid; idx < NB * NB; idx += kSolveThreads) {
+      const int r = idx / NB, c2 = idx - r * NB;
+      if (r < kb && c2 < kb && c2 >= r) A[(size_t)(k0 + r) * n + k0 + c2] = c2 == r ? dd[r] : Ld[idx];
     }
     // zero padding so the 16-wide tiles below may over-read (W >= n + 17, see ldlt_row_stride)
     for (int idx = tid; idx < kb * 16; idx += kSolveThreads) {
@@ -124,135 +177,181 @@ __device__ bool ldlt_solve_block(double* __restrict__ A, double* __restrict__ rh
     }
     __syncthreads();
     OSH_TR(2);
-    // ---- 3. trailing update of rows k0+kb .. n-1 (upper part) and of the rhs column on the FP64 matrix cores: one
-    // wavefront per 16x16 tile of the trailing block, C -= L[16 x kb] U[kb x 16] as kb/4 v_mfma_f64_16x16x4_f64.
-    // Operand lanes read straight from the panels in LDS: A[i = lane & 15][k = lane >> 4] = Lp[k][i0 + i], B[k][j] = U[k][j0 + j];
-    // lane holds D[row = (lane >> 4) + 4 reg][col = lane & 15].  (A 4x4 register-tiled VALU version spent 3 of 4 issue
-    // slots on operand traffic: 44 k cycles per panel on one CU against ~10 k here.)
+    // ---- 3. trailing update of rows k0+kb .. n-1 (upper part) on the FP64 matrix cores: one wavefront per 16x16 tile of
+    // the trailing block, C -= L[16 x NB] U[NB x 16] as NB/4 v_mfma_f64_16x16x4_f64 (a partial panel is the last one and has
+    // no trailing block).  Operand lanes read straight from the panels in LDS: A[i = lane & 15][k = lane >> 4] = Lp[k][i0 + i],
+    // B[k][j] = U[k][j0 + j]; lane holds D[row = (lane >> 4) + 4 reg][col = lane & 15].  (A 4x4 register-tiled VALU version
+    // spent 3 of 4 issue slots on operand traffic: 44 k cycles per panel on one CU against ~10 k for the first MFMA version.)
     const int tr = m - kb;  // trailing rows
     if (tr > 0) {
+      // right-hand side: y_i -= sum_k l_ki y_k, one thread per row, panels read conflict-free
+      for (int ii = kb + tid; ii < m; ii += kSolveThreads) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) acc += Lp[k * W + ii] * U[k * W + m];
+        xs[k0 + ii] -= acc;
+      }
       typedef double ldlt_f64x4 __attribute__((ext_vector_type(4)));
-      const int Tr = (tr + 15) >> 4, Tc = (tr + 1 + 15) >> 4;  // column tiles include the rhs column (local column m)
-      const int ntile = Tr * Tc - Tr * (Tr - 1) / 2;
-      const int wave = tid >> 6, lane = tid & 63;
+      const int Tr = (tr + 15) >> 4;
+      const int ntile = Tr * (Tr + 1) / 2;  // upper triangle of 16x16 tiles, diagonal tiles included
+      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // wave index as a scalar: tile decode on the SALU
       const int lrow = lane >> 4, lcol = lane & 15;
-      // tile t -> (ti, tj), its 4 old values per lane (unconditional loads: an out-of-range entry reads A[0] and is discarded);
-      // the loads of the wave's NEXT tile are issued before the current tile is multiplied (an L2 round trip is longer than
-      // the six MFMAs of a tile)
-      struct Tile { int i0, jj; double old[4]; };
+      // All addressing is 32-bit byte offsets from the panel origin (uniform base in SGPRs), every load and store is
+      // unconditional: an out-of-range row or column is clamped for the load and its store goes to `sink_off`, an entry of the
+      // never-read lower triangle; lanes below the diagonal of a diagonal tile update their own (unused) lower-triangle entry.
+      // The per-element cost is what bounded this phase before: ~600 VALU/SALU instructions per pair of tiles against 12 MFMAs.
+      char* const Ab = reinterpret_cast<char*>(A + (size_t)k0 * n + k0);
+      const unsigned n8 = (unsigned)n * 8u;
+      const unsigned sink_off = (unsigned)kb * n8;
+      const int cA = lrow * W + lcol;
+      struct Tile { int i0, j0; unsigned off[4]; double old[4]; };
       auto prep = [&](int t, Tile& T) {
         int ti = 0, rem = t;
-        while (rem >= Tc - ti) { rem -= Tc - ti; ++ti; }
+        while (rem >= Tr - ti) { rem -= Tr - ti; ++ti; }
         T.i0 = kb + 16 * ti;
-        T.jj = kb + 16 * (ti + rem) + lcol;
+        T.j0 = kb + 16 * (ti + rem);
+        const unsigned j8 = (unsigned)min(T.j0 + lcol, m - 1) * 8u;
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-          const int ii = T.i0 + lrow + 4 * reg;
-          const bool in = ii < m && T.jj >= ii && T.jj <= m;
-          const double* src = !in ? A : ((T.jj == m) ? rhs + k0 + ii : A + (size_t)(k0 + ii) * n + k0 + T.jj);
-          T.old[reg] = *src;
+          const int ii = min(T.i0 + lrow + 4 * reg, m - 1);
+          T.off[reg] = __umul24((unsigned)ii, n8) + j8;
+          T.old[reg] = *reinterpret_cast<const double*>(Ab + T.off[reg]);
+        }
+      };
+      auto finish = [&](const Tile& T, const ldlt_f64x4& acc) {
+        const bool jin = T.j0 + lcol < m;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const bool in = jin && T.i0 + lrow + 4 * reg < m;
+          unsigned o = in ? T.off[reg] : sink_off;
+          asm volatile("" : "+v"(o));  // one store through a selected offset, not two stores behind a branch
+          *reinterpret_cast<double*>(Ab + o) = T.old[reg] - acc[reg];
         }
       };
       // two tiles per step: their MFMA chains are independent, so the matrix core issues back to back instead of waiting
       // for each accumulator; all operand reads of a step are issued before its first MFMA
-      auto finish = [&](const Tile& T, const ldlt_f64x4& acc) {
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int ii = T.i0 + lrow + 4 * reg;
-          if (!(ii < m && T.jj >= ii && T.jj <= m)) continue;
-          if (T.jj == m) rhs[k0 + ii] = T.old[reg] - acc[reg];
-          else A[(size_t)(k0 + ii) * n + k0 + T.jj] = T.old[reg] - acc[reg];
-        }
-      };
-      auto run2 = [&](const Tile& T0, const Tile& T1, bool two) {
+      auto run2 = [&](const Tile& T0, const Tile& T1) {
         constexpr int KS = (NB + 3) / 4;
         double a0[KS], b0[KS], a1[KS], b1[KS];
+        const double* pa0 = Lp + cA + T0.i0; const double* pb0 = U + cA + T0.j0;
+        const double* pa1 = Lp + cA + T1.i0; const double* pb1 = U + cA + T1.j0;
 #pragma unroll
         for (int q = 0; q < KS; ++q) {
-          const int k = 4 * q + lrow;
-          const bool kin = k < kb;
-          const int kc = kin ? k : 0;
-          a0[q] = Lp[kc * W + T0.i0 + lcol]; b0[q] = U[kc * W + T0.jj];
-          a1[q] = Lp[kc * W + T1.i0 + lcol]; b1[q] = U[kc * W + T1.jj];
-          if (!kin) { a0[q] = 0.0; b0[q] = 0.0; a1[q] = 0.0; b1[q] = 0.0; }
+          if (4 * q + 3 < NB) {
+            a0[q] = pa0[4 * q * W]; b0[q] = pb0[4 * q * W];
+            a1[q] = pa1[4 * q * W]; b1[q] = pb1[4 * q * W];
+          } else {
+            // last k step of a panel whose width is not a multiple of 4: rows >= NB do not exist, their lanes multiply zeros
+            const bool kin = 4 * q + lrow < NB;
+            const int back = kin ? 0 : lrow * W;
+            a0[q] = pa0[4 * q * W - back]; b0[q] = pb0[4 * q * W - back];
+            a1[q] = pa1[4 * q * W - back]; b1[q] = pb1[4 * q * W - back];
+            if (!kin) { a0[q] = 0.0; b0[q] = 0.0; a1[q] = 0.0; b1[q] = 0.0; }
+          }
         }
         ldlt_f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int q = 0; q < KS; ++q) {
-          if (4 * q < kb) {
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0[q], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b1[q], acc1, 0, 0, 0);
-          }
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0[q], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b1[q], acc1, 0, 0, 0);
         }
         finish(T0, acc0);
-        if (two) finish(T1, acc1);
+        finish(T1, acc1);
       };
       constexpr int nwaves = kSolveThreads / 64;
-      // wave w takes tiles w, w + nwaves, ... two at a time; the loads of the next pair are in flight during the current one
+      // wave w takes tiles w, w + nwaves, ... two at a time; the loads of the next pair are in flight during the current one.
+      // An odd tile out is paired with a copy of itself (both copies were loaded before either is stored, so the second
+      // store repeats the first), and past the last pair the prefetch re-reads the current one and is dropped.
       Tile TA0, TA1, TB0, TB1;
       auto prep_pair = [&](int t, Tile& X, Tile& Y) {
         prep(t, X);
-        if (t + nwaves < ntile) prep(t + nwaves, Y); else Y = X;
+        prep(t + nwaves < ntile ? t + nwaves : t, Y);
       };
-      if (wave < ntile) prep_pair(wave, TA0, TA1);
-      for (int t = wave; t < ntile; t += 4 * nwaves) {
-        const bool moreB = t + 2 * nwaves < ntile;
-        if (moreB) prep_pair(t + 2 * nwaves, TB0, TB1);
-        run2(TA0, TA1, t + nwaves < ntile);
-        if (moreB) {
-          if (t + 4 * nwaves < ntile) prep_pair(t + 4 * nwaves, TA0, TA1);
-          run2(TB0, TB1, t + 3 * nwaves < ntile);
+      if (wave < ntile) {
+        int t = wave;
+        prep_pair(t, TA0, TA1);
+        while (true) {
+          const int tb = t + 2 * nwaves;
+          const bool hasB = tb < ntile;
+          prep_pair(hasB ? tb : t, TB0, TB1);
+          run2(TA0, TA1);
+          if (!hasB) break;
+          const int ta = tb + 2 * nwaves;
+          const bool hasA = ta < ntile;
+          prep_pair(hasA ? ta : tb, TA0, TA1);
+          run2(TB0, TB1);
+          if (!hasA) break;
+          t = ta;
         }
       }
     }
-    OSH_TR(3);
-    // ---- 4. write the factor back: L rows, pivots on the diagonal, forward-substituted rhs
-    for (int idx = tid; idx < kb * (m + 1); idx += kSolveThreads) {
-      const int r = idx / (m + 1), jj = idx - r * (m + 1);
-      if (jj == m) rhs[k0 + r] = U[r * W + m];
-      else if (jj == r) A[(size_t)(k0 + r) * n + k0 + r] = dd[r];
-      else if (jj > r) A[(size_t)(k0 + r) * n + k0 + jj] = Lp[r * W + jj];
-    }
     __syncthreads();
-    OSH_TR(4);
+    OSH_TR(3);
   }
   const int ok = sh_ok;
   if (ok) {
-    // back substitution  L^T x = D^-1 y, panels in reverse
+    // back substitution  L^T x = D^-1 y, panels in reverse.  Per panel: the global loads of the diagonal block and of every
+    // row's tail are issued together (one L2 round trip, not one per row), then one wavefront eliminates the block's columns
+    // right to left with the row of each lane in registers and the solved entry broadcast by v_readlane.
     const int npanel = (n + nb - 1) / nb;
     const int wv = tid >> 6, lane = tid & 63;
+    constexpr int nwaves = kSolveThreads / 64;
+    constexpr int kRowsPerWave = (NB + nwaves - 1) / nwaves;
+    constexpr int kDiagPerThread = (NB * NB + kSolveThreads - 1) / kSolveThreads;
     for (int pi = npanel - 1; pi >= 0; --pi) {
       const int k0 = pi * nb;
       const int kb = min(nb, n - k0);
       const int tail0 = k0 + kb;  // x known for indices >= tail0
-      // part[r] = sum_{j>=tail0} L[k0+r][j] x[j] : one wavefront per group of rows
-      for (int r = wv; r < kb; r += kSolveThreads / 64) {
-        double sacc = 0.0;
-        const double* row = A + (size_t)(k0 + r) * n;
-        for (int j = tail0 + lane; j < n; j += 64) sacc += row[j] * xs[j];
-        sacc = dev::wave_sum(sacc);
-        if (lane == 0) part[r] = sacc;
+      // diagonal block of the factor, padded: row r right of the diagonal, zero elsewhere
+      double dg[kDiagPerThread];
+#pragma unroll
+      for (int q = 0; q < kDiagPerThread; ++q) {
+        const int idx = tid + q * kSolveThreads;
+        const int r = idx / NB, c2 = idx - r * NB;
+        const bool in = idx < NB * NB && r < kb && c2 < kb && c2 >= r;
+        dg[q] = A[in ? (size_t)(k0 + r) * n + k0 + c2 : 0];
+        if (!in) dg[q] = 0.0;
       }
-      // diagonal block of the factor (L above the diagonal, pivots on it) and the rhs into LDS
-      for (int idx = tid; idx < kb * kb; idx += kSolveThreads) {
-        const int r = idx / kb, c2 = idx - r * kb;
-        U[r * W + c2] = (c2 >= r) ? A[(size_t)(k0 + r) * n + k0 + c2] : 0.0;
+      // part[r] = sum_{j>=tail0} L[k0+r][j] x[j] : one wavefront per group of rows, lanes stride the columns
+      double sacc[kRowsPerWave];
+#pragma unroll
+      for (int q = 0; q < kRowsPerWave; ++q) {
+        const int r = wv + q * nwaves;
+        const double* row = A + (size_t)(k0 + (r < kb ? r : 0)) * n;
+        sacc[q] = 0.0;
+        for (int j = tail0 + lane; j < n; j += 64) sacc[q] += row[j] * xs[j];
       }
-      if (tid < kb) dd[tid] = rhs[k0 + tid];
+#pragma unroll
+      for (int q = 0; q < kRowsPerWave; ++q) {
+        const int r = wv + q * nwaves;
+        const double sred = dev::wave_sum(sacc[q]);
+        if (lane == 0 && r < NB) part[r] = r < kb ? sred : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < kDiagPerThread; ++q) {
+        const int idx = tid + q * kSolveThreads;
+        if (idx < NB * NB) Ld[idx] = dg[q];
+      }
+      if (tid < NB) dd[tid] = tid < kb ? xs[k0 + tid] : 0.0;
       __syncthreads();
       if (wv == 0) {
-        // lane r holds s_r; columns are eliminated right to left
-        double sv = 0.0;
-        if (lane < kb) sv = dd[lane] / U[lane * W + lane] - part[lane];
-        for (int c2 = kb - 1; c2 >= 0; --c2) {
-          const double xc = __shfl(sv, c2, 64);
-          if (lane < c2) sv -= U[lane * W + c2] * xc;
+        // lane r holds s_r = y_r / d_r - part_r and row r of the block; lanes beyond the block hold zeros
+        const int lr = lane < NB ? lane : 0;
+        double urow[NB];
+#pragma unroll
+        for (int c2 = 0; c2 < NB; ++c2) urow[c2] = Ld[lr * NB + c2];
+        const double piv = Ld[lr * NB + lr];
+        double sv = (lane < kb) ? dd[lr] / piv - part[lr] : 0.0;
+#pragma unroll
+        for (int c2 = NB - 1; c2 >= 1; --c2) {
+          const double xc = ldlt_readlane(sv, c2);
+          const double nv = sv - urow[c2] * xc;
+          sv = lane < c2 ? nv : sv;
         }
         if (lane < kb) xs[k0 + lane] = sv;
       }
       __syncthreads();
     }
-    
   } else {
     // zero pivot: LinearSolverEigen::solve returns false; the step is rejected by the controller
     for (int k = tid; k < n; k += kSolveThreads) xs[k] = 0.0;
