@@ -18,7 +18,12 @@ class Frame {
                                         const int maxLevel = -1, const bool bRight = false) const;
   void AssignFeaturesToGrid();   // src/Frame.cc:397-417 with PosInGrid :726-736
   Sophus::SE3f GetPose() const { return mTcw; }
-  void SetPose(const Sophus::SE3f& Tcw) { mTcw = Tcw; ++mnPoseSets; }   // src/Frame.cc:291-296 (UpdatePoseMatrices omitted)
+  void SetPose(const Sophus::SE3f& Tcw) { mTcw = Tcw; ++mnPoseSets; UpdatePoseMatrices(); }   // src/Frame.cc:291-296
+  void UpdatePoseMatrices();     // src/Frame.cc:473-480
+  // src/Frame.cc:513-587 (Nleft == -1).  The batch form is the loop of Tracking::SearchLocalPoints (src/Tracking.cc:3411-3432)
+  // as one device launch: it fills the same MapPoint fields and returns how many points are in view (-1 on a device error).
+  bool isInFrustum(MapPoint* pMP, float viewingCosLimit);
+  int isInFrustum(const std::vector<MapPoint*>& vpMPs, float viewingCosLimit, std::vector<bool>& vbInView);
 
   int N = 0;
   int Nleft = -1, Nright = -1;
@@ -40,6 +45,8 @@ class Frame {
   float mnMinX = 0, mnMaxX = 752, mnMinY = 0, mnMaxY = 480;   // static in the reference
   float mfGridElementWidthInv = 64.f / 752.f, mfGridElementHeightInv = 48.f / 480.f;
   Sophus::SE3f mTcw;
+  Eigen::Matrix3f mRcw, mRwc;      // include/Frame.h:337-340 (private in the reference)
+  Eigen::Vector3f mtcw, mOw;
 };
 }  // namespace ORB_SLAM3
 #endif

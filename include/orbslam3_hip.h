@@ -342,6 +342,36 @@ int osh_orb_download(osh_orb_ctx* ctx, int32_t* best_idx, int32_t* best_dist,
 int osh_orb_get_profile(osh_orb_ctx* ctx, int64_t* launches, double* total_ms);
 int osh_orb_set_profiling(osh_orb_ctx* ctx, int enable);
 
+/* ------------------------------------------------- frustum projection (candidate generation) */
+/*
+ * Frame::isInFrustum (src/Frame.cc:513-587, Nleft == -1 branch) for every local map point of a frame: the loop of
+ * Tracking::SearchLocalPoints (src/Tracking.cc:3411-3432) as one launch.  Float32 arithmetic like the reference.
+ *   stage[i]  0: rejected before the projection was stored (behind the camera or outside the image: mTrackProjX/Y stay -1)
+ *             1: mTrackProjX/Y stored, then rejected by the distance range or the viewing angle
+ *             2: in view (mbTrackInView): proj_x/proj_y/proj_xr = mTrackProjX/Y/XR, depth = mTrackDepth (|Pc|),
+ *                view_cos = mTrackViewCos, level = mnTrackScaleLevel (MapPoint::PredictScale, src/MapPoint.cc:531-546)
+ * The outputs feed osh_orb_grid.query_window / query_levels (ORBmatcher::SearchByProjection, src/ORBmatcher.cc:44-141).
+ */
+typedef struct osh_frustum_frame {
+  float Rcw[9], tcw[3], Ow[3];              /* Frame::mRcw (row-major), mtcw, mOw                                  */
+  float fx, fy, cx, cy, bf;                 /* Pinhole parameters, Frame::mbf                                      */
+  float min_x, max_x, min_y, max_y;         /* Frame::mnMinX, mnMaxX, mnMinY, mnMaxY                               */
+  float log_scale_factor;                   /* Frame::mfLogScaleFactor                                             */
+  int32_t n_scale_levels;                   /* Frame::mnScaleLevels                                                */
+  float viewing_cos_limit;                  /* 0.5 in SearchLocalPoints                                            */
+} osh_frustum_frame;
+typedef struct osh_frustum_points {
+  int32_t n;
+  const float* pos;        /* [n*3] MapPoint::GetWorldPos()                 */
+  const float* normal;     /* [n*3] MapPoint::GetNormal()                   */
+  const float* min_dist;   /* [n]   MapPoint::mfMinDistance (the 0.8 / 1.2 invariance factors are applied on the device) */
+  const float* max_dist;   /* [n]   MapPoint::mfMaxDistance                 */
+} osh_frustum_points;
+typedef struct osh_frustum_result {
+  uint8_t* stage; float* proj_x; float* proj_y; float* proj_xr; float* depth; float* view_cos; int32_t* level;   /* [n] each */
+} osh_frustum_result;
+int osh_orb_frustum(osh_orb_ctx* ctx, const osh_frustum_frame* frame, const osh_frustum_points* points, osh_frustum_result* result);
+
 /* Full n x m distance matrix (ORBmatcher::DescriptorDistance for every pair),
  * out[n*m] int32.  Used by parity tests. */
 int osh_orb_distance_matrix(osh_orb_ctx* ctx, int32_t n, int32_t m,

@@ -98,6 +98,15 @@ void osh_host_frame_destroy(osh_host_frame* f);
 int osh_host_search_local_points(osh_host_frame* f, int32_t n_mp, const uint8_t* mp_desc, const float* proj_xy,
                                  const float* proj_xr, const int32_t* level, const float* viewcos, const float* depth,
                                  const int32_t* n_observations, float nnratio, float th, int32_t* assignment);
+/* Frame::isInFrustum(pMP, viewing_cos_limit) for every map point (the loop of Tracking::SearchLocalPoints,
+ * src/Tracking.cc:3411-3432) as one device launch; outputs are the MapPoint tracking fields afterwards.  With
+ * assignment != NULL it continues with ORBmatcher(nnratio).SearchByProjection(F, vpMapPoints, th) (:3460) like
+ * osh_host_search_local_points.  Returns the number of points in view (<0: error). */
+int osh_host_frame_search_local_points_projected(osh_host_frame* f, int32_t n_mp, const float* mp_pos, const float* mp_normal,
+                                                 const float* mp_min_dist, const float* mp_max_dist, float viewing_cos_limit,
+                                                 uint8_t* in_view, float* proj_xy, float* proj_xr, float* depth, float* view_cos,
+                                                 int32_t* level, const uint8_t* mp_desc, const int32_t* n_observations,
+                                                 float nnratio, float th, int32_t* assignment, int32_t* n_matches);
 /* ORBmatcher(nnratio, check_ori).SearchByProjection(Current, Last, th, bMono): last_mp[k] = map point index held by
  * keypoint k of the last frame (-1 none); map points given by world position + descriptor. */
 int osh_host_search_last_frame(osh_host_frame* cur, osh_host_frame* last, const int32_t* last_mp, int32_t n_mp,

@@ -41,6 +41,8 @@ def load(native: bool = False) -> C.CDLL:
     lib.oracle_lba_solve.argtypes = [C.POINTER(capi.LbaProblem), C.POINTER(capi.LbaResult)]
     lib.oracle_pose_optimize.restype = C.c_int
     lib.oracle_pose_optimize.argtypes = [C.POINTER(capi.PoseProblem), C.POINTER(capi.PoseResult)]
+    lib.oracle_frustum.restype = None
+    lib.oracle_frustum.argtypes = [C.POINTER(capi.FrustumFrame), C.POINTER(capi.FrustumPoints), C.POINTER(capi.FrustumResult)]
     lib.oracle_lba_linearize.restype = C.c_int
     lib.oracle_lba_linearize.argtypes = [C.POINTER(capi.LbaProblem)] + [d] * 7
     lib.oracle_lba_schur_step.restype = C.c_int
@@ -223,6 +225,15 @@ def orb_match_last_frame(query, train, cand_off, cand_idx, query_angle, train_an
                                         capi.ptr(qa, capi.c_float_p), capi.ptr(ta, capi.c_float_p), th_high,
                                         int(check_orientation), _u8(occ), _i32(assign))
     return int(n), assign, occ
+
+
+# ------------------------------------------------------------------ frustum projection
+def frustum(frame, pos, normal, min_dist, max_dist, native: bool = False) -> dict:
+    from orb_slam3_study_kr_amd.orb import frustum_args
+    lib = load(native)
+    args, res, outs = frustum_args(pos, normal, min_dist, max_dist)
+    lib.oracle_frustum(C.byref(frame), C.byref(args[0]), C.byref(res))
+    return outs
 
 
 # ------------------------------------------------------------------ pose-only optimisation

@@ -25,6 +25,9 @@ int  oracle_edge_depth_positive(const double qt[7], const double X[3]);
 void oracle_huber(double e, double delta, double rho[3]);
 int  oracle_ldlt_solve(int n, double* A, const double* b, double* x, double* tmp);
 
+/* ---- frustum projection of map points into a frame (frustum_oracle.c) ---- */
+void oracle_frustum(const osh_frustum_frame* f, const osh_frustum_points* p, osh_frustum_result* out);
+
 /* ---- pose-only optimisation of a frame (pose_oracle.c) ---- */
 int  oracle_pose_optimize(const osh_pose_problem* p, osh_pose_result* res);
 

@@ -139,6 +139,30 @@ class OrbGrid(C.Structure):
     ]
 
 
+class FrustumFrame(C.Structure):
+    """``osh_frustum_frame`` (include/orbslam3_hip.h)."""
+
+    _fields_ = [
+        ("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("Ow", C.c_float * 3),
+        ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float),
+        ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float),
+        ("log_scale_factor", C.c_float), ("n_scale_levels", C.c_int32), ("viewing_cos_limit", C.c_float),
+    ]
+
+
+class FrustumPoints(C.Structure):
+    """``osh_frustum_points`` (include/orbslam3_hip.h)."""
+
+    _fields_ = [("n", C.c_int32), ("pos", c_float_p), ("normal", c_float_p), ("min_dist", c_float_p), ("max_dist", c_float_p)]
+
+
+class FrustumResult(C.Structure):
+    """``osh_frustum_result`` (include/orbslam3_hip.h)."""
+
+    _fields_ = [("stage", c_uint8_p), ("proj_x", c_float_p), ("proj_y", c_float_p), ("proj_xr", c_float_p),
+                ("depth", c_float_p), ("view_cos", c_float_p), ("level", c_int32_p)]
+
+
 def ptr(a, typ):
     """Pointer of ctypes type `typ` to the data of numpy array `a` (None -> NULL)."""
     if a is None:
@@ -171,6 +195,7 @@ _SIGNATURES = {
     "osh_orb_destroy": (None, [C.c_void_p]),
     "osh_orb_upload": (C.c_int, [C.c_void_p, C.POINTER(OrbBatch)]),
     "osh_orb_upload_grid": (C.c_int, [C.c_void_p, C.POINTER(OrbBatch), C.POINTER(OrbGrid)]),
+    "osh_orb_frustum": (C.c_int, [C.c_void_p, C.POINTER(FrustumFrame), C.POINTER(FrustumPoints), C.POINTER(FrustumResult)]),
     "osh_orb_match": (C.c_int, [C.c_void_p]),
     "osh_orb_download": (C.c_int, [C.c_void_p] + [c_int32_p] * 6),
     "osh_orb_get_profile": (C.c_int, [C.c_void_p, c_int64_p, c_double_p]),
@@ -208,6 +233,9 @@ _HOST_SIGNATURES = {
     "osh_host_frame_create": (C.c_void_p, [C.c_int32, c_float_p, c_int32_p, c_float_p, c_float_p, c_uint8_p, c_float_p, c_float_p,
                                            C.c_float, C.c_float, C.c_int32, C.c_float]),
     "osh_host_frame_destroy": (None, [C.c_void_p]),
+    "osh_host_frame_search_local_points_projected": (C.c_int, [C.c_void_p, C.c_int32, c_float_p, c_float_p, c_float_p, c_float_p, C.c_float,
+                                                              c_uint8_p, c_float_p, c_float_p, c_float_p, c_float_p, c_int32_p, c_uint8_p,
+                                                              c_int32_p, C.c_float, C.c_float, c_int32_p, c_int32_p]),
     "osh_host_search_local_points": (C.c_int, [C.c_void_p, C.c_int32, c_uint8_p, c_float_p, c_float_p, c_int32_p, c_float_p, c_float_p,
                                                c_int32_p, C.c_float, C.c_float, c_int32_p]),
     "osh_host_search_last_frame": (C.c_int, [C.c_void_p, C.c_void_p, c_int32_p, C.c_int32, c_float_p, c_uint8_p, C.c_float, C.c_int32,

@@ -51,6 +51,12 @@ osh_orb_ctx* thread_ctx() {
   return ctx;
 }
 
+}  // namespace
+
+osh_orb_ctx* HostMatcherContext() { return thread_ctx(); }
+
+namespace {
+
 struct Search {
   std::vector<uint8_t> qdesc;            // [nq*32]
   std::vector<float> win;                // [nq*3] x, y, r of the query's GetFeaturesInArea call

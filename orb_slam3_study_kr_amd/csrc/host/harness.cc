@@ -313,6 +313,8 @@ extern "C" osh_host_frame* osh_host_frame_create(int32_t n, const float* kp_xy, 
   F.mpCamera = f->cam.get();
   F.N = n; F.mbf = mbf; F.mb = mb;
   F.mTcw = pose_from(pose_qt);
+  F.UpdatePoseMatrices();
+  F.fx = cam4[0]; F.fy = cam4[1]; F.cx = cam4[2]; F.cy = cam4[3];
   F.mvScaleFactors.assign(n_levels, 1.0f);
   for (int l = 1; l < n_levels; ++l) F.mvScaleFactors[l] = F.mvScaleFactors[l - 1] * scale_factor;  // src/ORBextractor.cc:414-422
   F.mnScaleLevels = n_levels;
@@ -368,6 +370,46 @@ extern "C" int osh_host_search_local_points(osh_host_frame* f, int32_t n_mp, con
   for (int k = 0; k < f->F.N; ++k) assignment[k] = f->F.mvpMapPoints[k] ? (int32_t)f->F.mvpMapPoints[k]->mnId : -1;
   f->F.mvpMapPoints.assign(f->F.N, nullptr);
   return n;
+}
+
+// Frame::isInFrustum over a list of map points (the loop of Tracking::SearchLocalPoints, src/Tracking.cc:3411-3432),
+// optionally followed by ORBmatcher(nnratio).SearchByProjection(F, vpMapPoints, th) on the points it put in view (:3460).
+extern "C" int osh_host_frame_search_local_points_projected(osh_host_frame* f, int32_t n_mp, const float* mp_pos, const float* mp_normal,
+                                                            const float* mp_min_dist, const float* mp_max_dist, float viewing_cos_limit,
+                                                            uint8_t* in_view, float* proj_xy, float* proj_xr, float* depth,
+                                                            float* view_cos, int32_t* level, const uint8_t* mp_desc,
+                                                            const int32_t* n_observations, float nnratio, float th,
+                                                            int32_t* assignment, int32_t* n_matches) {
+  if (!f) return -1;
+  std::vector<uint8_t> zero_desc;
+  if (!mp_desc) { zero_desc.assign((size_t)n_mp * 32, 0); }
+  auto pts = make_points(&f->map, n_mp, mp_desc ? mp_desc : zero_desc.data(), mp_pos, n_observations);
+  std::vector<MapPoint*> vp;
+  for (int j = 0; j < n_mp; ++j) {
+    MapPoint* p = pts[j].get();
+    p->mNormalVector = Eigen::Vector3f(mp_normal[3 * j], mp_normal[3 * j + 1], mp_normal[3 * j + 2]);
+    p->mfMinDistance = mp_min_dist[j]; p->mfMaxDistance = mp_max_dist[j];
+    p->mnTrackScaleLevel = -1; p->mTrackViewCos = 0.f; p->mTrackProjXR = 0.f; p->mTrackDepth = 0.f;
+    vp.push_back(p);
+  }
+  std::vector<bool> in;
+  const int n_in = f->F.isInFrustum(vp, viewing_cos_limit, in);
+  if (n_in < 0) return -1;
+  for (int j = 0; j < n_mp; ++j) {
+    const MapPoint* p = vp[j];
+    in_view[j] = p->mbTrackInView ? 1 : 0;
+    proj_xy[2 * j] = p->mTrackProjX; proj_xy[2 * j + 1] = p->mTrackProjY;
+    proj_xr[j] = p->mTrackProjXR; depth[j] = p->mTrackDepth; view_cos[j] = p->mTrackViewCos; level[j] = p->mnTrackScaleLevel;
+  }
+  if (assignment) {
+    f->F.mvpMapPoints.assign(f->F.N, nullptr);
+    ORBmatcher matcher(nnratio);
+    const int n = matcher.SearchByProjection(f->F, vp, th);
+    for (int k = 0; k < f->F.N; ++k) assignment[k] = f->F.mvpMapPoints[k] ? (int32_t)f->F.mvpMapPoints[k]->mnId : -1;
+    f->F.mvpMapPoints.assign(f->F.N, nullptr);
+    if (n_matches) *n_matches = n;
+  }
+  return n_in;
 }
 
 extern "C" int osh_host_search_last_frame(osh_host_frame* cur, osh_host_frame* last, const int32_t* last_mp, int32_t n_mp,

@@ -257,12 +257,80 @@ __global__ void k_orb_distance_matrix(int n, int m, const uint4* a, const uint4*
 
 using namespace osh;
 
+// --------------------------------------------------------------------------------------------
+// k_frustum: Frame::isInFrustum (src/Frame.cc:513-587, Nleft == -1 branch) for a batch of map
+// points, one point per thread.  Float32 throughout like the reference (mRcw, mtcw, mOw and the
+// MapPoint getters are float), no fused multiply-add, and the three-term sums in the order of
+// Eigen's fixed-size reduction, a0 + (a1 + a2) (recalled, not readable here).
+// in : 8 floats per point  (world position, normal, mfMinDistance, mfMaxDistance)
+// out: 8 words per point   (stage, u, v, u - bf/z, |Pc|, viewCos, level, 0); stage 0: rejected before
+//      the projection was stored, 1: mTrackProjX/Y stored then rejected, 2: in view.
+// --------------------------------------------------------------------------------------------
+struct FrustumFrame { float R[9], t[3], O[3], fx, fy, cx, cy, bf, min_x, max_x, min_y, max_y, log_sf, cos_limit; int levels; };
+
+// plain operators with contraction switched off per function (HIP's __fmul_rn / __fadd_rn are inline functions compiled with
+// the default contract flag: after inlining their results still fuse into FMAs)
+__device__ __forceinline__ float sum3(float a0, float a1, float a2) {
+#pragma clang fp contract(off)
+  return a0 + (a1 + a2);
+}
+// correctly rounded float32 square root (v_sqrt_f32 alone is good to 1 ulp): the FP64 root rounds to the same float as the
+// exact one because 53 >= 2 * 24 + 2
+__device__ __forceinline__ float sqrt_rn(float x) { return (float)sqrt((double)x); }
+
+__global__ __launch_bounds__(256) void k_frustum(FrustumFrame f, int n, const float4* __restrict__ in, float4* __restrict__ out) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float4 a = in[2 * i], b = in[2 * i + 1];
+  const float P[3] = {a.x, a.y, a.z}, Pn[3] = {a.w, b.x, b.y};
+  // MapPoint::GetMinDistanceInvariance / GetMaxDistanceInvariance (src/MapPoint.cc:502-512)
+  const float min_d = (0.8f * b.z), max_d = (1.2f * b.w);
+  float Pc[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    Pc[r] = sum3(f.R[3 * r] * P[0], f.R[3 * r + 1] * P[1], f.R[3 * r + 2] * P[2]) + f.t[r];
+  const float pc_dist = sqrt_rn(sum3((Pc[0] * Pc[0]), (Pc[1] * Pc[1]), (Pc[2] * Pc[2])));
+  int stage = 0, level = -1;
+  float u = -1.f, v = -1.f, ur = 0.f, vcos = 0.f, vcos_out = 0.f;
+  if (!(Pc[2] < 0.0f)) {
+    const float invz = (1.0f / Pc[2]);
+    // Pinhole::project(Vector3f): fx * x / z + cx  (src/CameraModels/Pinhole.cpp:43-49)
+    const float pu = f.fx * Pc[0] / Pc[2] + f.cx;
+    const float pv = f.fy * Pc[1] / Pc[2] + f.cy;
+    if (!(pu < f.min_x || pu > f.max_x) && !(pv < f.min_y || pv > f.max_y)) {
+      stage = 1; u = pu; v = pv;
+      const float PO[3] = {(P[0] - f.O[0]), (P[1] - f.O[1]), (P[2] - f.O[2])};
+      const float dist = sqrt_rn(sum3((PO[0] * PO[0]), (PO[1] * PO[1]), (PO[2] * PO[2])));
+      if (!(dist < min_d || dist > max_d)) {
+        vcos = sum3(PO[0] * Pn[0], PO[1] * Pn[1], PO[2] * Pn[2]) / dist;
+        if (!(vcos < f.cos_limit)) {
+          // MapPoint::PredictScale (src/MapPoint.cc:531-546)
+          const float ratio = (b.w / dist);
+          // logf as the correctly rounded value (FP64 log rounded once): libm-independent, so the level of a point that sits
+          // exactly on a boundary (ratio == scaleFactor^k) is reproducible; glibc's logf agrees except for rare 1-ulp cases
+          const float lg = (float)log((double)ratio);
+          int ns = (int)ceilf(lg / f.log_sf);
+          if (ns < 0) ns = 0; else if (ns >= f.levels) ns = f.levels - 1;
+          level = ns; stage = 2;
+          ur = pu - f.bf * invz;
+          vcos_out = vcos;
+        }
+      }
+    }
+  }
+  out[2 * i] = make_float4(__int_as_float(stage), u, v, ur);
+  out[2 * i + 1] = make_float4(pc_dist, vcos_out, __int_as_float(level), 0.f);
+}
+
 struct osh_orb_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   KernelTimer timer;
   DevBuf d_query, d_train, d_level, d_off, d_idx, d_base, d_part, d_out[6], d_a, d_b, d_dm;
   DevBuf d_txy, d_tur, d_tskip, d_coff, d_cidx, d_qwin, d_qlev, d_qur;
+  DevBuf d_fin, d_fout;
+  std::vector<float> h_fin, h_fout;
   OrbView v{};
   bool uploaded = false, matched = false, windowed = false, grid = false;
 };
@@ -469,6 +537,46 @@ extern "C" int osh_orb_get_profile(osh_orb_ctx* c, int64_t* launches, double* to
   if (!c || !launches || !total_ms) return OSH_ERR_INVALID;
   *launches = c->timer.launches[0];
   *total_ms = c->timer.total_ms[0];
+  return OSH_OK;
+}
+
+extern "C" int osh_orb_frustum(osh_orb_ctx* c, const osh_frustum_frame* fr, const osh_frustum_points* pts, osh_frustum_result* res) {
+  if (!c || !fr || !pts || !res || pts->n < 0) { set_error("osh_orb_frustum: bad arguments"); return OSH_ERR_INVALID; }
+  const int n = pts->n;
+  if (n == 0) return OSH_OK;
+  if (!pts->pos || !pts->normal || !pts->min_dist || !pts->max_dist || !res->stage || !res->proj_x || !res->proj_y || !res->proj_xr ||
+      !res->depth || !res->view_cos || !res->level) { set_error("osh_orb_frustum: NULL array"); return OSH_ERR_INVALID; }
+  if (fr->n_scale_levels <= 0 || !(fr->log_scale_factor > 0.f)) { set_error("osh_orb_frustum: bad scale pyramid"); return OSH_ERR_INVALID; }
+  OSH_HIP(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  c->h_fin.resize((size_t)n * 8); c->h_fout.resize((size_t)n * 8);
+  for (int i = 0; i < n; ++i) {
+    float* d = &c->h_fin[(size_t)i * 8];
+    d[0] = pts->pos[3 * i]; d[1] = pts->pos[3 * i + 1]; d[2] = pts->pos[3 * i + 2];
+    d[3] = pts->normal[3 * i]; d[4] = pts->normal[3 * i + 1]; d[5] = pts->normal[3 * i + 2];
+    d[6] = pts->min_dist[i]; d[7] = pts->max_dist[i];
+  }
+  OSH_TRY(c->d_fin.reserve((size_t)n * 32));
+  OSH_TRY(c->d_fout.reserve((size_t)n * 32));
+  OSH_HIP(hipMemcpyAsync(c->d_fin.p, c->h_fin.data(), (size_t)n * 32, hipMemcpyHostToDevice, s));
+  FrustumFrame f;
+  for (int k = 0; k < 9; ++k) f.R[k] = fr->Rcw[k];
+  for (int k = 0; k < 3; ++k) { f.t[k] = fr->tcw[k]; f.O[k] = fr->Ow[k]; }
+  f.fx = fr->fx; f.fy = fr->fy; f.cx = fr->cx; f.cy = fr->cy; f.bf = fr->bf;
+  f.min_x = fr->min_x; f.max_x = fr->max_x; f.min_y = fr->min_y; f.max_y = fr->max_y;
+  f.log_sf = fr->log_scale_factor; f.cos_limit = fr->viewing_cos_limit; f.levels = fr->n_scale_levels;
+  hipLaunchKernelGGL(k_frustum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, f, n, c->d_fin.as<float4>(), c->d_fout.as<float4>());
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("k_frustum launch failed: %s", hipGetErrorString(e)); return OSH_ERR_DEVICE; }
+  OSH_HIP(hipMemcpyAsync(c->h_fout.data(), c->d_fout.p, (size_t)n * 32, hipMemcpyDeviceToHost, s));
+  OSH_HIP(hipStreamSynchronize(s));
+  for (int i = 0; i < n; ++i) {
+    const float* o = &c->h_fout[(size_t)i * 8];
+    int32_t st, lv;
+    std::memcpy(&st, &o[0], 4); std::memcpy(&lv, &o[6], 4);
+    res->stage[i] = (uint8_t)st; res->proj_x[i] = o[1]; res->proj_y[i] = o[2]; res->proj_xr[i] = o[3];
+    res->depth[i] = o[4]; res->view_cos[i] = o[5]; res->level[i] = lv;
+  }
   return OSH_OK;
 }
 

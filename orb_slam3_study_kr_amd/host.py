@@ -218,6 +218,29 @@ class HostFrame:
                                                   capi.ptr(assign, capi.c_int32_p))
         return n, assign
 
+    def search_local_points_projected(self, mp_pos, mp_normal, mp_min_dist, mp_max_dist, viewing_cos_limit=0.5, mp_desc=None,
+                                      n_obs=None, nnratio=0.8, th=1.0):
+        """Frame::isInFrustum for every map point on the device (src/Frame.cc:513-587), then, when descriptors are given,
+        SearchByProjection(F, vpMapPoints, th) as in Tracking::SearchLocalPoints (src/Tracking.cc:3411-3460)."""
+        n_mp = len(mp_min_dist)
+        fp, ip = capi.c_float_p, capi.c_int32_p
+        keep = [_f32(mp_pos), _f32(mp_normal), _f32(mp_min_dist), _f32(mp_max_dist)]
+        out = dict(in_view=np.zeros(n_mp, np.uint8), proj_xy=np.zeros((n_mp, 2), np.float32), proj_xr=np.zeros(n_mp, np.float32),
+                   depth=np.zeros(n_mp, np.float32), view_cos=np.zeros(n_mp, np.float32), level=np.zeros(n_mp, np.int32))
+        assign = -np.ones(self.n, dtype=np.int32) if mp_desc is not None else None
+        nm = C.c_int32(0)
+        desc = np.ascontiguousarray(mp_desc, dtype=np.uint8) if mp_desc is not None else None
+        nobs = _i32(n_obs) if n_obs is not None else None
+        n_in = self.lib.osh_host_frame_search_local_points_projected(
+            self.f, n_mp, capi.ptr(keep[0], fp), capi.ptr(keep[1], fp), capi.ptr(keep[2], fp), capi.ptr(keep[3], fp), viewing_cos_limit,
+            capi.ptr(out["in_view"], capi.c_uint8_p), capi.ptr(out["proj_xy"], fp), capi.ptr(out["proj_xr"], fp), capi.ptr(out["depth"], fp),
+            capi.ptr(out["view_cos"], fp), capi.ptr(out["level"], ip), capi.ptr(desc, capi.c_uint8_p), capi.ptr(nobs, ip), nnratio, th,
+            capi.ptr(assign, ip), C.cast(C.byref(nm), ip) if assign is not None else C.cast(None, ip))
+        if n_in < 0:
+            raise RuntimeError("osh_host_frame_search_local_points_projected failed: " + self.lib.osh_last_error().decode())
+        out.update(n_in_view=n_in, assignment=assign, n_matches=nm.value)
+        return out
+
     def search_last_frame(self, last: "HostFrame", last_mp, mp_pos, mp_desc, th=15.0, mono=True, check_ori=True):
         assign = -np.ones(self.n, dtype=np.int32)
         keep = [_i32(last_mp), _f32(mp_pos), np.ascontiguousarray(mp_desc, dtype=np.uint8)]

@@ -82,6 +82,12 @@ class OrbMatcher:
         self._shape = (1, q.shape[0])
         capi.check(self.lib.osh_orb_upload_grid(self.ctx, C.byref(b), C.byref(g)), "osh_orb_upload_grid", self.lib)
 
+    def frustum(self, frame: "capi.FrustumFrame", pos, normal, min_dist, max_dist) -> dict:
+        """Frame::isInFrustum (src/Frame.cc:513-587) for every map point of `pos` [n,3]; see osh_orb_frustum."""
+        args, res, outs = frustum_args(pos, normal, min_dist, max_dist)
+        capi.check(self.lib.osh_orb_frustum(self.ctx, C.byref(frame), C.byref(args[0]), C.byref(res)), "osh_orb_frustum", self.lib)
+        return outs
+
     def match(self):
         capi.check(self.lib.osh_orb_match(self.ctx), "osh_orb_match", self.lib)
 
@@ -152,3 +158,39 @@ def replay_local_points(res: dict, pair_index: int, rescan, nn_ratio: float = 0.
         occ[b] = 1
         nmatches += 1
     return nmatches, assign, rescans
+
+
+def frustum_frame(Rcw, tcw, fx, fy, cx, cy, bf, bounds, log_scale_factor, n_scale_levels, viewing_cos_limit=0.5):
+    """osh_frustum_frame from a float32 camera pose; Ow = -Rcw^T tcw formed in float32 like Frame::UpdatePoseMatrices
+    (src/Frame.cc:298-307)."""
+    R = np.asarray(Rcw, dtype=np.float32).reshape(3, 3)
+    t = np.asarray(tcw, dtype=np.float32).reshape(3)
+    Ow = (-(R.T.astype(np.float32) @ t)).astype(np.float32)
+    f = capi.FrustumFrame()
+    f.Rcw[:] = [float(x) for x in R.reshape(9)]
+    f.tcw[:] = [float(x) for x in t]
+    f.Ow[:] = [float(x) for x in Ow]
+    f.fx, f.fy, f.cx, f.cy, f.bf = fx, fy, cx, cy, bf
+    f.min_x, f.max_x, f.min_y, f.max_y = bounds
+    f.log_scale_factor, f.n_scale_levels, f.viewing_cos_limit = log_scale_factor, n_scale_levels, viewing_cos_limit
+    return f
+
+
+def frustum_args(pos, normal, min_dist, max_dist):
+    """ctypes argument / result structs of osh_orb_frustum (also taken by the oracle) and the dict of output arrays."""
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    pos, normal, min_dist, max_dist = f32(pos), f32(normal), f32(min_dist), f32(max_dist)
+    n = pos.shape[0]
+    pts = capi.FrustumPoints()
+    pts.n = n
+    pts.pos, pts.normal = capi.ptr(pos, capi.c_float_p), capi.ptr(normal, capi.c_float_p)
+    pts.min_dist, pts.max_dist = capi.ptr(min_dist, capi.c_float_p), capi.ptr(max_dist, capi.c_float_p)
+    outs = dict(stage=np.zeros(n, np.uint8), proj_x=np.zeros(n, np.float32), proj_y=np.zeros(n, np.float32),
+                proj_xr=np.zeros(n, np.float32), depth=np.zeros(n, np.float32), view_cos=np.zeros(n, np.float32),
+                level=np.zeros(n, np.int32))
+    res = capi.FrustumResult()
+    res.stage = capi.ptr(outs["stage"], capi.c_uint8_p)
+    for k in ("proj_x", "proj_y", "proj_xr", "depth", "view_cos"):
+        setattr(res, k, capi.ptr(outs[k], capi.c_float_p))
+    res.level = capi.ptr(outs["level"], capi.c_int32_p)
+    return (pts, pos, normal, min_dist, max_dist), res, outs

@@ -458,3 +458,51 @@ def test_local_inertial_ba_through_the_reference_signature(ob):
 
 def quat_R(q):
     return synth.quat_to_R(np.asarray(q) / np.linalg.norm(q))
+
+
+def test_search_local_points_projected_on_device(ob):
+    """Tracking::SearchLocalPoints core (src/Tracking.cc:3411-3460): Frame::isInFrustum for the whole list on the device, then
+    SearchByProjection(F, vpMapPoints, th).  The MapPoint fields equal the oracle's, and the matches equal the existing
+    entry point fed with those fields for the points put in view."""
+    from orb_slam3_study_kr_amd import orb
+    xy, octave, desc, mp_desc, proj, level, _ = _frame_and_points(11, n_kp=900, n_mp=600)
+    rng = np.random.Generator(np.random.PCG64(12))
+    n_mp = len(level)
+    # camera at C = (0.3, -0.2, 0.1), axes aligned with the world: tcw = -C; each map point sits on the ray of its projection
+    C3 = np.array([0.3, -0.2, 0.1], dtype=np.float32)
+    pose_qt = np.array([0, 0, 0, 1, -C3[0], -C3[1], -C3[2]], dtype=np.float32)
+    depth = rng.uniform(3, 12, n_mp)
+    depth[:40] = -depth[:40]                                       # behind the camera
+    Pc = np.stack([(proj[:, 0] - float(synth.CX)) / float(synth.FX) * depth, (proj[:, 1] - float(synth.CY)) / float(synth.FY) * depth, depth], axis=1)
+    Pc[40:80, 0] += 40.0                                           # far outside the image
+    pos = (Pc + C3.astype(np.float64)).astype(np.float32)
+    normal = np.tile(np.array([[0, 0, 1.0]], dtype=np.float32), (n_mp, 1))
+    normal[80:120] = np.array([1.0, 0, 0], dtype=np.float32)       # seen edge-on
+    dist = np.linalg.norm(Pc, axis=1)
+    max_d = (dist * float(synth.SCALE_FACTOR) ** (level - 0.5)).astype(np.float32)     # predicted level == level, off the boundary
+    max_d[120:160] = (dist[120:160] * 0.5).astype(np.float32)     # too far for its scale range
+    min_d = (max_d / np.float32(synth.SCALE_FACTOR) ** (synth.N_LEVELS - 1)).astype(np.float32)
+    th = 3.0
+    f = host.HostFrame(xy, octave, desc, pose_qt=pose_qt)
+    try:
+        out = f.search_local_points_projected(pos, normal, min_d, max_d, 0.5, mp_desc=mp_desc, nnratio=0.8, th=th)
+        frame = orb.frustum_frame(np.eye(3), -C3, float(synth.FX), float(synth.FY), float(synth.CX), float(synth.CY), float(synth.BF),
+                                  (0.0, float(synth.IMG_W), 0.0, float(synth.IMG_H)), float(np.log(np.float32(synth.SCALE_FACTOR))),
+                                  synth.N_LEVELS)
+        ref = ob.frustum(frame, pos, normal, min_d, max_d)
+        inv = ref["stage"] == 2
+        assert out["n_in_view"] == int(inv.sum()) and 300 < inv.sum() < n_mp - 100
+        np.testing.assert_array_equal(out["in_view"].astype(bool), inv)
+        np.testing.assert_array_equal(out["proj_xy"][:, 0].view(np.uint32), ref["proj_x"].view(np.uint32))
+        np.testing.assert_array_equal(out["proj_xy"][:, 1].view(np.uint32), ref["proj_y"].view(np.uint32))
+        for k in ("proj_xr", "depth", "view_cos"):
+            np.testing.assert_array_equal(out[k][inv].view(np.uint32), ref[k][inv].view(np.uint32), err_msg=k)
+        np.testing.assert_array_equal(out["level"][inv], ref["level"][inv])
+        # the matcher stage on the in-view subset, through the entry point that takes the tracking fields directly
+        sub = np.flatnonzero(inv)
+        n2, assign2 = f.search_local_points(mp_desc[sub], out["proj_xy"][sub], out["level"][sub], out["view_cos"][sub],
+                                            proj_xr=out["proj_xr"][sub], depth=out["depth"][sub], nnratio=0.8, th=th)
+    finally:
+        f.close()
+    assert out["n_matches"] == n2 and n2 > 100
+    np.testing.assert_array_equal(out["assignment"], np.where(assign2 >= 0, sub[np.maximum(assign2, 0)], -1))

@@ -144,3 +144,56 @@ def test_device_candidate_generation_equals_host_built_lists(hip_lib):
     for name in ("best_idx", "best_dist", "second_dist", "best_level", "second_level"):
         np.testing.assert_array_equal(got[name][0], ref[name], err_msg=name)
     assert (got["best_idx"][0] >= 0).sum() > 300 and (r == 0).any()
+
+
+def _frustum_scene(seed, n):
+    """A camera with a random float32 pose and map points scattered so that every rejection branch is taken."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    a = rng.normal(size=4)
+    a /= np.linalg.norm(a)
+    w, x, y, z = a
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]]).astype(np.float32)
+    t = rng.normal(0, 1.0, 3).astype(np.float32)
+    frame = orb.frustum_frame(R, t, float(synth.FX), float(synth.FY), float(synth.CX), float(synth.CY), float(synth.BF),
+                              (0.0, float(synth.IMG_W), 0.0, float(synth.IMG_H)), float(np.log(np.float32(synth.SCALE_FACTOR))),
+                              synth.N_LEVELS)
+    # points in camera coordinates: mostly in front and inside the image, some behind / outside
+    zc = rng.uniform(-2.0, 30.0, n)
+    xc = rng.normal(0, 0.6, n) * np.abs(zc)
+    yc = rng.normal(0, 0.4, n) * np.abs(zc)
+    Pc = np.stack([xc, yc, zc], axis=1)
+    Rd, td = R.astype(np.float64), t.astype(np.float64)
+    P = ((Pc - td) @ Rd).astype(np.float32)            # Rcw^T (Pc - tcw)
+    Ow = -(Rd.T @ td)
+    to_cam = Ow - P.astype(np.float64)
+    to_cam /= np.linalg.norm(to_cam, axis=1, keepdims=True)
+    normal = -(to_cam + rng.normal(0, 0.8, (n, 3)))    # roughly facing the camera (PO . Pn > 0), some oblique
+    normal /= np.linalg.norm(normal, axis=1, keepdims=True)
+    dist = np.linalg.norm(P.astype(np.float64) - Ow, axis=1)
+    max_d = (dist * rng.uniform(0.5, 6.0, n)).astype(np.float32)
+    min_d = (max_d / np.float32(synth.SCALE_FACTOR) ** (synth.N_LEVELS - 1)).astype(np.float32)
+    return frame, P, normal.astype(np.float32), min_d, max_d
+
+
+@pytest.mark.parametrize("seed,n", [(1, 20000), (2, 1), (3, 257)])
+def test_frustum_projection_bit_exact(matcher, ob, seed, n):
+    """k_frustum (Frame::isInFrustum, src/Frame.cc:513-587) against the oracle: float32 fields compared as bit patterns."""
+    frame, P, normal, min_d, max_d = _frustum_scene(seed, n)
+    got = matcher.frustum(frame, P, normal, min_d, max_d)
+    ref = ob.frustum(frame, P, normal, min_d, max_d)
+    np.testing.assert_array_equal(got["stage"], ref["stage"])
+    np.testing.assert_array_equal(got["level"], ref["level"])
+    for k in ("proj_x", "proj_y", "proj_xr", "depth", "view_cos"):
+        np.testing.assert_array_equal(got[k].view(np.uint32), ref[k].view(np.uint32), err_msg=k)
+    if n > 1000:
+        counts = np.bincount(ref["stage"], minlength=3)
+        assert counts.min() > n // 20, counts          # every branch exercised
+        assert len(np.unique(ref["level"][ref["stage"] == 2])) == synth.N_LEVELS
+
+
+def test_frustum_empty_batch(matcher):
+    frame, P, normal, min_d, max_d = _frustum_scene(4, 1)
+    out = matcher.frustum(frame, P[:0], normal[:0], min_d[:0], max_d[:0])
+    assert out["stage"].shape == (0,)
