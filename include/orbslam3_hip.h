@@ -80,6 +80,9 @@ typedef struct osh_lba_problem {
   double lambda_init;        /* >0: setUserLambdaInit (Optimizer.cc:1197-1198); else tau*max diag */
   int32_t max_iterations;    /* optimizer.optimize(N), 10 at Optimizer.cc:1411     */
   const volatile unsigned char* stop_flag; /* pbStopFlag (may be NULL); polled once per LM trial */
+  const double* kb8;         /* NULL: pinhole.  [4] k1..k4 (KannalaBrandt8 mvParameters[4..7]): the window's camera is a      */
+                             /* fisheye, every edge must be OSH_EDGE_MONO and projects through KannalaBrandt8::project /     */
+                             /* projectJac (src/CameraModels/KannalaBrandt8.cpp:45-63,147-175) with pose_cam's fx fy cx cy   */
 } osh_lba_problem;
 
 /* -------------------------------------------------------- local BA: output */

@@ -53,6 +53,10 @@ def load(native: bool = False) -> C.CDLL:
     lib.oracle_edge_error.argtypes = [C.c_int, d, d, d, d, d]
     lib.oracle_edge_jacobians.restype = None
     lib.oracle_edge_jacobians.argtypes = [C.c_int, d, d, d, d, d]
+    lib.oracle_edge_error_kb8.restype = None
+    lib.oracle_edge_error_kb8.argtypes = [d] * 6
+    lib.oracle_edge_jacobians_kb8.restype = None
+    lib.oracle_edge_jacobians_kb8.argtypes = [d] * 6
     lib.oracle_edge_depth_positive.restype = C.c_int
     lib.oracle_edge_depth_positive.argtypes = [d, d]
     lib.oracle_huber.restype = None
@@ -148,6 +152,22 @@ def edge_jacobians(kind, qt, cam, X):
     a = [np.ascontiguousarray(v, dtype=np.float64) for v in (qt, cam, X)]
     Jxi, Jxj = np.zeros((3, 3)), np.zeros((3, 6))
     lib.oracle_edge_jacobians(int(kind), _d(a[0]), _d(a[1]), _d(a[2]), _d(Jxi), _d(Jxj))
+    return Jxi, Jxj
+
+
+def edge_error_kb8(qt, cam, kb, X, obs):
+    lib = load()
+    a = [np.ascontiguousarray(v, dtype=np.float64) for v in (qt, cam, kb, X, obs)]
+    err = np.zeros(3)
+    lib.oracle_edge_error_kb8(_d(a[0]), _d(a[1]), _d(a[2]), _d(a[3]), _d(a[4]), _d(err))
+    return err
+
+
+def edge_jacobians_kb8(qt, cam, kb, X):
+    lib = load()
+    a = [np.ascontiguousarray(v, dtype=np.float64) for v in (qt, cam, kb, X)]
+    Jxi, Jxj = np.zeros((3, 3)), np.zeros((3, 6))
+    lib.oracle_edge_jacobians_kb8(_d(a[0]), _d(a[1]), _d(a[2]), _d(a[3]), _d(Jxi), _d(Jxj))
     return Jxi, Jxj
 
 

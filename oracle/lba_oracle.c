@@ -320,6 +320,75 @@ static double edge_chi2(const ostate* s, int e) {
   return r[0] * (w * r[0]) + r[1] * (w * r[1]) + r[2] * (w * r[2]);
 }
 
+/* ---- KannalaBrandt8 monocular edge: ORB_SLAM3::EdgeSE3ProjectXYZ (src/OptimizableTypes.cpp:139-160) with
+ * KannalaBrandt8::project(Vector3d) (src/CameraModels/KannalaBrandt8.cpp:45-63) and ::projectJac (:147-175).
+ * cam = fx fy cx cy (mvParameters[0..3]), kb = k1..k4 (mvParameters[4..7]).
+ * The reference calls atan2f / sqrtf on double arguments (theta and psi are float32 values).  float32 atan2 is taken as
+ * its correctly rounded value (double atan2 rounded once): libm independent, so the device reproduces it; glibc's atan2f
+ * differs from it only in rare 1-ulp cases. */
+static float atan2f_rn(float y, float x) { return (float)atan2((double)y, (double)x); }
+
+void oracle_edge_error_kb8(const double qt[7], const double cam[5], const double kb[4],
+                           const double X[3], const double obs[3], double err[3]) {
+  double Xc[3];
+  se3_map(qt, X, Xc);
+  const double x2_plus_y2 = Xc[0] * Xc[0] + Xc[1] * Xc[1];
+  const double theta = atan2f_rn(sqrtf((float)x2_plus_y2), (float)Xc[2]);
+  const double psi = atan2f_rn((float)Xc[1], (float)Xc[0]);
+  const double theta2 = theta * theta;
+  const double theta3 = theta * theta2;
+  const double theta5 = theta3 * theta2;
+  const double theta7 = theta5 * theta2;
+  const double theta9 = theta7 * theta2;
+  const double r = theta + kb[0] * theta3 + kb[1] * theta5 + kb[2] * theta7 + kb[3] * theta9;
+  err[0] = obs[0] - (cam[0] * r * cos(psi) + cam[2]);
+  err[1] = obs[1] - (cam[1] * r * sin(psi) + cam[3]);
+  err[2] = 0.0;
+}
+
+void oracle_edge_jacobians_kb8(const double qt[7], const double cam[5], const double kb[4],
+                               const double X[3], double Jxi[9], double Jxj[18]) {
+  double Xc[3], R[9];
+  se3_map(qt, X, Xc);
+  quat_to_R(qt, R);
+  const double x = Xc[0], y = Xc[1], z = Xc[2];
+  memset(Jxi, 0, 9 * sizeof(double));
+  memset(Jxj, 0, 18 * sizeof(double));
+  const double x2 = x * x, y2 = y * y, z2 = z * z;
+  const double r2 = x2 + y2;
+  const double r = sqrt(r2);
+  const double r3 = r2 * r;
+  const double theta = atan2(r, z);
+  const double theta2 = theta * theta, theta3 = theta2 * theta;
+  const double theta4 = theta2 * theta2, theta5 = theta4 * theta;
+  const double theta6 = theta2 * theta4, theta7 = theta6 * theta;
+  const double theta8 = theta4 * theta4, theta9 = theta8 * theta;
+  const double f = theta + theta3 * kb[0] + theta5 * kb[1] + theta7 * kb[2] + theta9 * kb[3];
+  const double fd = 1 + 3 * kb[0] * theta2 + 5 * kb[1] * theta4 + 7 * kb[2] * theta6 + 9 * kb[3] * theta8;
+  double J[6];
+  J[0] = cam[0] * (fd * z * x2 / (r2 * (r2 + z2)) + f * y2 / r3);
+  J[3] = cam[1] * (fd * z * y * x / (r2 * (r2 + z2)) - f * y * x / r3);
+  J[1] = cam[0] * (fd * z * y * x / (r2 * (r2 + z2)) - f * y * x / r3);
+  J[4] = cam[1] * (fd * z * y2 / (r2 * (r2 + z2)) + f * x2 / r3);
+  J[2] = -cam[0] * fd * x / (r2 + z2);
+  J[5] = -cam[1] * fd * y / (r2 + z2);
+  double pj[6];
+  for (int k = 0; k < 6; ++k) pj[k] = -J[k];
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double s = 0;
+      for (int k = 0; k < 3; ++k) s += pj[i * 3 + k] * R[k * 3 + j];
+      Jxi[i * 3 + j] = s;
+    }
+  const double D[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 6; ++j) {
+      double s = 0;
+      for (int k = 0; k < 3; ++k) s += pj[i * 3 + k] * D[k * 6 + j];
+      Jxj[i * 6 + j] = s;
+    }
+}
+
 static double edge_delta(const ostate* s, int e) {
   return s->pr->edge_kind[e] == OSH_EDGE_MONO ? s->pr->huber_mono : s->pr->huber_stereo;
 }
@@ -329,8 +398,11 @@ static void compute_active_errors(ostate* s) {
   const osh_lba_problem* p = s->pr;
   for (int e = 0; e < s->E; ++e) {
     const int ip = p->edge_pose[e], il = p->edge_point[e];
-    oracle_edge_error(p->edge_kind[e], s->qt + 7 * ip, p->pose_cam + 5 * ip, s->X + 3 * il,
-                      p->edge_obs + 3 * e, s->err + 3 * e);
+    if (p->kb8 && p->edge_kind[e] == OSH_EDGE_MONO)
+      oracle_edge_error_kb8(s->qt + 7 * ip, p->pose_cam + 5 * ip, p->kb8, s->X + 3 * il, p->edge_obs + 3 * e, s->err + 3 * e);
+    else
+      oracle_edge_error(p->edge_kind[e], s->qt + 7 * ip, p->pose_cam + 5 * ip, s->X + 3 * il,
+                        p->edge_obs + 3 * e, s->err + 3 * e);
   }
 }
 
@@ -360,7 +432,8 @@ static void build_system(ostate* s) {
     const int kind = p->edge_kind[e];
     const int D = (kind == OSH_EDGE_MONO) ? 2 : 3;
     double A[9], B[18];
-    oracle_edge_jacobians(kind, s->qt + 7 * ip, p->pose_cam + 5 * ip, s->X + 3 * il, A, B);
+    if (p->kb8 && kind == OSH_EDGE_MONO) oracle_edge_jacobians_kb8(s->qt + 7 * ip, p->pose_cam + 5 * ip, p->kb8, s->X + 3 * il, A, B);
+    else oracle_edge_jacobians(kind, s->qt + 7 * ip, p->pose_cam + 5 * ip, s->X + 3 * il, A, B);
     const double w = p->edge_info[e];
     const double* r = s->err + 3 * e;
     double omega_r[3] = {-(w * r[0]), -(w * r[1]), -(w * r[2])};
@@ -596,6 +669,7 @@ static int validate(const osh_lba_problem* p) {
     if (p->edge_pose[e] < 0 || p->edge_pose[e] >= p->n_free + p->n_fixed) return 0;
     if (p->edge_point[e] < 0 || p->edge_point[e] >= p->n_points) return 0;
     if (p->edge_kind[e] > OSH_EDGE_STEREO) return 0;
+    if (p->kb8 && p->edge_kind[e] != OSH_EDGE_MONO) return 0;   /* a fisheye window is monocular */
   }
   return 1;
 }

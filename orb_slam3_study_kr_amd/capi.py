@@ -44,7 +44,7 @@ class LbaProblem(C.Structure):
         ("edge_obs", c_double_p), ("edge_info", c_double_p),
         ("huber_mono", C.c_double), ("huber_stereo", C.c_double),
         ("lambda_init", C.c_double), ("max_iterations", C.c_int32),
-        ("stop_flag", c_uint8_p),
+        ("stop_flag", c_uint8_p), ("kb8", c_double_p),
     ]
 
 

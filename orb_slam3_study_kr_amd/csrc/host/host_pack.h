@@ -21,12 +21,15 @@ struct LbaPack {
   std::vector<double> pose_qt, pose_cam, points, edge_obs, edge_info;
   std::vector<int32_t> edge_pose, edge_point;
   std::vector<uint8_t> edge_kind;
+  bool has_kb8 = false;       // the keyframes' camera is a KannalaBrandt8 (monocular fisheye)
+  double kb8[4] = {0, 0, 0, 0};
   void fill(osh_lba_problem& p) const {
     p.n_free = n_free; p.n_fixed = n_fixed; p.n_points = (int32_t)vPointMPs.size(); p.n_edges = (int32_t)edge_pose.size();
     p.pose_qt = pose_qt.data(); p.pose_cam = pose_cam.data(); p.points = points.data();
     p.edge_pose = edge_pose.data(); p.edge_point = edge_point.data(); p.edge_kind = edge_kind.data();
     p.edge_obs = edge_obs.data(); p.edge_info = edge_info.data();
     p.huber_mono = p.huber_stereo = 0; p.lambda_init = 0; p.max_iterations = 10; p.stop_flag = nullptr;
+    p.kb8 = has_kb8 ? kb8 : nullptr;
   }
 };
 struct LibaPack {

@@ -59,6 +59,8 @@ struct WinDesc {
   int max_iter;
   long long S_off; // doubles
   double huber_mono, huber_stereo, lambda_init;
+  double kb8[4];   // KannalaBrandt8 k1..k4 of the window's camera (osh_lba_problem.kb8)
+  int kb8_on;      // 1: the window's mono edges project through KannalaBrandt8
 };
 
 struct LmState {
@@ -171,10 +173,26 @@ __device__ __forceinline__ double block_max(double v, double* sh4) {
   return r;
 }
 
+// Residual / Jacobians of one visual edge through the window's camera model.  KB8 is a compile-time switch: the pinhole
+// instantiations of the kernels (every batch without a fisheye window) carry no KannalaBrandt8 code or registers.
+template <bool KB8>
+__device__ __forceinline__ double win_edge_residual(const WinDesc& wd, int kind, const double* qt, const double* cam, const double* X,
+                                                    const double* obs, double info, double* r, double* Xc) {
+  if (KB8 && wd.kb8_on && kind == OSH_EDGE_MONO) return dev::edge_residual_kb8(qt, cam, wd.kb8, X, obs, info, r, Xc);
+  return dev::edge_residual(kind, qt, cam, X, obs, info, r, Xc);
+}
+template <bool KB8>
+__device__ __forceinline__ void win_edge_jacobians(const WinDesc& wd, int kind, const double* R, const double* cam, const double* Xc,
+                                                   double* JX, double* Jp) {
+  if (KB8 && wd.kb8_on && kind == OSH_EDGE_MONO) { dev::edge_jacobians_kb8(R, cam, wd.kb8, Xc, JX, Jp); return; }
+  dev::edge_jacobians(kind, R, cam, Xc, JX, Jp);
+}
+
 // --------------------------------------------------------------------------------------------
 // k_residual: computeActiveErrors + activeRobustChi2 at the TRIAL estimates (every active window),
 // one block per chunk of consecutive landmarks, lane per edge; chunk partial sums in fixed order.
 // --------------------------------------------------------------------------------------------
+template <bool KB8>
 __global__ __launch_bounds__(kBlock) void k_residual(BatchView bv) {
   __shared__ double sh4[4];
   const Chunk ch = bv.chunks[blockIdx.x];
@@ -199,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void k_residual(BatchView bv) {
     for (int k = 0; k < 5; ++k) cam[k] = cams[(size_t)ip * 5 + k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) { X[k] = pts[(size_t)il * 3 + k]; obs[k] = bv.e_obs[ge * 3 + k]; }
-    const double chi2 = dev::edge_residual(kind, qt, cam, X, obs, bv.e_info[ge], r, Xc);
+    const double chi2 = win_edge_residual<KB8>(wd, kind, qt, cam, X, obs, bv.e_info[ge], r, Xc);
     double rho0, rho1;
     dev::huber(chi2, kind == OSH_EDGE_MONO ? wd.huber_mono : wd.huber_stereo, rho0, rho1);
     chi_acc += rho0;
@@ -443,7 +461,7 @@ __device__ __forceinline__ double group8_sum(double v) {
   return v;
 }
 
-template <int SIDE>   // 0: landmark side (Hpl, Hll, b_l, chi2)   1: pose side (Hpp, b_p partials)
+template <int SIDE, bool KB8>   // SIDE 0: landmark side (Hpl, Hll, b_l, chi2)   1: pose side (Hpp, b_p partials)
 __global__ __launch_bounds__(64, 2) void k_lin_items(BatchView bv) {
   __shared__ double shStage[64 * 18];   // Hpl blocks of one chunk; also the scratch of the final Hpp reduction
   __shared__ double shPose[SIDE == 0 ? 21 * 64 : 1];   // landmark side, per lane: quaternion + translation (7), camera (5), rotation matrix (9)
@@ -545,10 +563,10 @@ __global__ __launch_bounds__(64, 2) void k_lin_items(BatchView bv) {
       const double info = inp.info;
       double r[3], Xc[3];
       const double obs[3] = {inp.obs[0], inp.obs[1], inp.obs[2]};
-      const double chi2 = dev::edge_residual(kind, qt, cam, X, obs, info, r, Xc);
+      const double chi2 = win_edge_residual<KB8>(wd, kind, qt, cam, X, obs, info, r, Xc);
       double rho0, rho1;
       dev::huber(chi2, kind == OSH_EDGE_MONO ? wd.huber_mono : wd.huber_stereo, rho0, rho1);
-      dev::edge_jacobians(kind, Rm, cam, Xc, JX, Jp);
+      win_edge_jacobians<KB8>(wd, kind, Rm, cam, Xc, JX, Jp);
       ww = rho1 * info;                       // robustInformation (first order only)
       wr[0] = -(info * r[0]) * rho1; wr[1] = -(info * r[1]) * rho1; wr[2] = -(info * r[2]) * rho1;
       if (SIDE == 0 && owner) {
@@ -686,6 +704,7 @@ __global__ __launch_bounds__(64, 2) void k_lin_items(BatchView bv) {
 // One lane per edge, edges sorted by landmark, a landmark never straddles two wavefronts (a chunk
 // longer than 64 edges holds a single landmark); the first lane of each landmark sums its run in
 // lane order and is the only writer of that landmark.  Runs after k_lin_items.
+template <bool KB8>
 __global__ __launch_bounds__(64) void k_lin_aux(BatchView bv) {
   __shared__ double shv[9 * 64];
   __shared__ int shl[64];
@@ -716,13 +735,13 @@ __global__ __launch_bounds__(64) void k_lin_aux(BatchView bv) {
     for (int k = 0; k < 5; ++k) cam[k] = cams[(size_t)ip * 5 + k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) { X[k] = pts[(size_t)en.x * 3 + k]; obs[k] = bv.e_obs[ge * 3 + k]; }
-    const double chi2 = dev::edge_residual(kind, qt, cam, X, obs, info, r, Xc);
+    const double chi2 = win_edge_residual<KB8>(wd, kind, qt, cam, X, obs, info, r, Xc);
     double rho0, rho1;
     dev::huber(chi2, kind == OSH_EDGE_MONO ? wd.huber_mono : wd.huber_stereo, rho0, rho1);
     chi_acc += rho0;
     double JX[9], Jp[18], R[9];
     dev::quat_to_R(qt, R);
-    dev::edge_jacobians(kind, R, cam, Xc, JX, Jp);
+    win_edge_jacobians<KB8>(wd, kind, R, cam, Xc, JX, Jp);
     const double ww = rho1 * info;
     const double wr[3] = {-(info * r[0]) * rho1, -(info * r[1]) * rho1, -(info * r[2]) * rho1};
     double AtW[9];
@@ -1049,6 +1068,7 @@ __global__ void k_set_stop(BatchView bv, const unsigned char* stop) {
 // k_finalize: per-edge chi2 of the LAST evaluated errors (stale after a rejected final trial,
 // levenberg.cpp:123-147) and isDepthPositive from the FINAL estimates (Optimizer.cc:1425).
 // --------------------------------------------------------------------------------------------
+template <bool KB8>
 __global__ __launch_bounds__(kBlock) void k_finalize(BatchView bv) {
   const Chunk ch = bv.chunks[blockIdx.x];
   const WinDesc wd = bv.win[ch.win];   // by value: the fields stay in SGPRs across the kernel's stores
@@ -1072,7 +1092,7 @@ __global__ __launch_bounds__(kBlock) void k_finalize(BatchView bv) {
       for (int k = 0; k < 7; ++k) qt[k] = bv.pose_state[s][((size_t)wd.pose_off + ip) * 7 + k];
 #pragma unroll
       for (int k = 0; k < 3; ++k) X[k] = bv.pt_state[s][((size_t)wd.pt_off + il) * 3 + k];
-      chi2 = dev::edge_residual(kind, qt, cam, X, obs, bv.e_info[ge], r, Xc);
+      chi2 = win_edge_residual<KB8>(wd, kind, qt, cam, X, obs, bv.e_info[ge], r, Xc);
     }
     const int f = st.sel;
 #pragma unroll
@@ -1109,6 +1129,13 @@ struct osh_lba_ctx {
   size_t S_total = 0;
   int n_max = 0, solve_nb = 24, solve_W = 0, solve_threads = kSolveThreadsBatch;
   size_t solve_lds = 0, backsub_lds = 0;
+  // edge kernels of the batch's camera models: the KannalaBrandt8 instantiations only when a window asks for them
+  bool has_kb8 = false;
+  void (*kp_lin_lm)(BatchView) = nullptr;
+  void (*kp_lin_pose)(BatchView) = nullptr;
+  void (*kp_lin_aux)(BatchView) = nullptr;
+  void (*kp_residual)(BatchView) = nullptr;
+  void (*kp_finalize)(BatchView) = nullptr;
   // device buffers
   DevBuf d_win, d_lm, d_chunks, d_fpose_win, d_pose_init, d_pose[2], d_pt_init, d_pt[2], d_cam;
   DevBuf d_e_pose, d_e_point, d_e_kind, d_e_obs, d_e_info, d_e_orig, d_lm_off, d_lm_nfree, d_pel_off, d_pel_edge, d_sitems, d_srecs, d_spair, d_scslot, d_sposex, d_pose_crange, d_hcontrib, d_chi_item, d_dmax_item, d_aux_chunks, d_aux_entries, d_chi_aux, d_dmax_aux, d_rblk, d_contrib, d_ccontrib, d_dinv;
@@ -1183,6 +1210,7 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   c->h_win.assign(nw, WinDesc{});
   c->stop_ptr.assign(nw, nullptr);
   c->any_stop = false;
+  c->has_kb8 = false;
   size_t NP = 0, NFP = 0, NL = 0, NE = 0, NEf = 0, NLO = 0, NPO = 0, S_total = 0;
   int n_max = 0;
   // ---- pass 1: validate + offsets
@@ -1201,6 +1229,17 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
     d.lmoff_off = (int)NLO; d.peloff_off = (int)NPO; d.pel_off = (int)NEf;
     d.n = 6 * p.n_free; d.max_iter = p.max_iterations; d.S_off = (long long)S_total;
     d.huber_mono = p.huber_mono; d.huber_stereo = p.huber_stereo; d.lambda_init = p.lambda_init;
+    d.kb8_on = p.kb8 ? 1 : 0;
+    for (int k = 0; k < 4; ++k) d.kb8[k] = p.kb8 ? p.kb8[k] : 0.0;
+    if (p.kb8) {
+      c->has_kb8 = true;
+      for (int e = 0; e < p.n_edges; ++e)
+        if (p.edge_kind[e] != OSH_EDGE_MONO) {
+          set_error("window %d: a KannalaBrandt8 window takes monocular edges only (edge %d); the right-camera edges of a fisheye "
+                    "stereo rig (EdgeSE3ProjectXYZToBody) are not supported by the device path yet", w, e);
+          return OSH_ERR_UNSUPPORTED;
+        }
+    }
     c->stop_ptr[w] = p.stop_flag;
     if (p.stop_flag) c->any_stop = true;
     NP += (size_t)p.n_free + p.n_fixed; NFP += p.n_free; NL += p.n_points; NE += p.n_edges;
@@ -1259,7 +1298,13 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
     for (int j = 0; j <= p.n_points; ++j) lmo[j] = cnt[j];
     for (int j = 0; j < p.n_points; ++j) {
       int lo = cnt[j], hi = cnt[j + 1];
-      std::stable_sort(order.begin() + lo, order.begin() + hi, [&](int a, int b) { return p.edge_pose[a] < p.edge_pose[b]; });
+      // stable insertion sort by pose: tracks are short (~8 edges) and std::stable_sort allocates a buffer per call
+      for (int x = lo + 1; x < hi; ++x) {
+        const int e = order[x], pe = p.edge_pose[e];
+        int y = x;
+        for (; y > lo && p.edge_pose[order[y - 1]] > pe; --y) order[y] = order[y - 1];
+        order[y] = e;
+      }
       int nf = 0;
       for (int x = lo; x < hi; ++x) {
         if (p.edge_pose[order[x]] < p.n_free) ++nf;
@@ -1444,6 +1489,14 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   bv.out_chi2 = c->d_out_chi2.as<double>(); bv.out_depth = c->d_out_depth.as<unsigned char>();
   OSH_HIP(hipStreamSynchronize(s));
 
+  if (c->has_kb8) {
+    c->kp_lin_lm = k_lin_items<0, true>; c->kp_lin_pose = k_lin_items<1, true>; c->kp_lin_aux = k_lin_aux<true>;
+    c->kp_residual = k_residual<true>; c->kp_finalize = k_finalize<true>;
+  } else {
+    c->kp_lin_lm = k_lin_items<0, false>; c->kp_lin_pose = k_lin_items<1, false>; c->kp_lin_aux = k_lin_aux<false>;
+    c->kp_residual = k_residual<false>; c->kp_finalize = k_finalize<false>;
+  }
+
   // opt in to large dynamic LDS once per process
   static bool attr_done = false;
   if (!attr_done) {
@@ -1525,9 +1578,9 @@ extern "C" int osh_lba_optimize(osh_lba_ctx* c) {
   for (const WinDesc& d : c->h_win) max_iter = std::max(max_iter, d.max_iter);
   const long max_rounds = (long)max_iter * kMaxTrials + 1;
   for (long round = 0; round < max_rounds && n_active > 0; ++round) {
-    LAUNCH(OSH_K_LINEARIZE, k_lin_items<0>, c->n_sym, 64, 0, c->bv);
-    LAUNCH(OSH_K_LIN_POSE, k_lin_items<1>, c->n_sym, 64, 0, c->bv);
-    LAUNCH(OSH_K_LIN_AUX, k_lin_aux, c->n_aux_chunks, 64, 0, c->bv);
+    LAUNCH(OSH_K_LINEARIZE, c->kp_lin_lm, c->n_sym, 64, 0, c->bv);
+    LAUNCH(OSH_K_LIN_POSE, c->kp_lin_pose, c->n_sym, 64, 0, c->bv);
+    LAUNCH(OSH_K_LIN_AUX, c->kp_lin_aux, c->n_aux_chunks, 64, 0, c->bv);
     LAUNCH(OSH_K_POSE_HESS, k_pose_reduce, (c->NFP + 1) / 2, 64, 0, c->bv);
     LAUNCH(OSH_K_CONTROL, k_control, c->n_windows, 64, 0, c->bv, 0);
     LAUNCH(OSH_K_SCHUR, k_schur_items<true>, c->n_sym, 64, 0, c->bv, 0);
@@ -1539,7 +1592,7 @@ extern "C" int osh_lba_optimize(osh_lba_ctx* c) {
       if (_t) c->timer.end(s);
     }
     LAUNCH(OSH_K_BACKSUB, k_backsub, c->n_chunks, kBlock, c->backsub_lds, c->bv);
-    LAUNCH(OSH_K_RESIDUAL, k_residual, c->n_chunks, kBlock, 0, c->bv);
+    LAUNCH(OSH_K_RESIDUAL, c->kp_residual, c->n_chunks, kBlock, 0, c->bv);
     if (c->any_stop) {
       // terminate() is polled after every trial (levenberg.cpp:149) and before every iteration
       snapshot_stop(c);
@@ -1553,7 +1606,7 @@ extern "C" int osh_lba_optimize(osh_lba_ctx* c) {
     if (c->timer.enabled) c->timer.collect();
   }
   if (c->n_chunks) {
-    hipLaunchKernelGGL(k_finalize, dim3((unsigned)c->n_chunks), dim3(kBlock), 0, s, c->bv);
+    hipLaunchKernelGGL(c->kp_finalize, dim3((unsigned)c->n_chunks), dim3(kBlock), 0, s, c->bv);
     OSH_TRY(launch_check("k_finalize"));
   }
   OSH_HIP(hipStreamSynchronize(s));
@@ -1601,10 +1654,10 @@ extern "C" int osh_lba_linearize(osh_lba_ctx* c, int32_t window, double* Hpp, do
   hipStream_t s = c->stream;
   OSH_TRY(reset_state(c));
   if (c->n_sym) {
-    hipLaunchKernelGGL(k_lin_items<0>, dim3((unsigned)c->n_sym), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_lin_items<0>"));
-    hipLaunchKernelGGL(k_lin_items<1>, dim3((unsigned)c->n_sym), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_lin_items<1>"));
+    hipLaunchKernelGGL(c->kp_lin_lm, dim3((unsigned)c->n_sym), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_lin_items<0>"));
+    hipLaunchKernelGGL(c->kp_lin_pose, dim3((unsigned)c->n_sym), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_lin_items<1>"));
   }
-  if (c->n_aux_chunks) { hipLaunchKernelGGL(k_lin_aux, dim3((unsigned)c->n_aux_chunks), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_lin_aux")); }
+  if (c->n_aux_chunks) { hipLaunchKernelGGL(c->kp_lin_aux, dim3((unsigned)c->n_aux_chunks), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_lin_aux")); }
   if (c->NFP) { hipLaunchKernelGGL(k_pose_reduce, dim3((unsigned)((c->NFP + 1) / 2)), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_pose_reduce")); }
   hipLaunchKernelGGL(k_control, dim3((unsigned)c->n_windows), dim3(64), 0, s, c->bv, 0);
   OSH_TRY(launch_check("k_control"));
@@ -1635,7 +1688,7 @@ extern "C" int osh_lba_linearize(osh_lba_ctx* c, int32_t window, double* Hpp, do
     // mark every window evaluated so k_finalize emits chi2 of the current state
     for (auto& st : h_lm) { st.iterations = 1; st.last_eval_sel = st.sel; }
     OSH_HIP(hipMemcpy(c->d_lm.p, h_lm.data(), c->n_windows * sizeof(LmState), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_finalize, dim3((unsigned)c->n_chunks), dim3(kBlock), 0, s, c->bv);
+    hipLaunchKernelGGL(c->kp_finalize, dim3((unsigned)c->n_chunks), dim3(kBlock), 0, s, c->bv);
     OSH_TRY(launch_check("k_finalize"));
     OSH_HIP(hipStreamSynchronize(s));
     OSH_HIP(hipMemcpy(chi2, c->d_out_chi2.as<double>() + d.edge_off, (size_t)d.E * 8, hipMemcpyDeviceToHost));
@@ -1652,10 +1705,10 @@ extern "C" int osh_lba_debug_trial(osh_lba_ctx* c, int32_t window, double lambda
   hipStream_t s = c->stream;
   OSH_TRY(reset_state(c));
   if (c->n_sym) {
-    hipLaunchKernelGGL(k_lin_items<0>, dim3((unsigned)c->n_sym), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_lin_items<0>"));
-    hipLaunchKernelGGL(k_lin_items<1>, dim3((unsigned)c->n_sym), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_lin_items<1>"));
+    hipLaunchKernelGGL(c->kp_lin_lm, dim3((unsigned)c->n_sym), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_lin_items<0>"));
+    hipLaunchKernelGGL(c->kp_lin_pose, dim3((unsigned)c->n_sym), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_lin_items<1>"));
   }
-  if (c->n_aux_chunks) { hipLaunchKernelGGL(k_lin_aux, dim3((unsigned)c->n_aux_chunks), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_lin_aux")); }
+  if (c->n_aux_chunks) { hipLaunchKernelGGL(c->kp_lin_aux, dim3((unsigned)c->n_aux_chunks), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_lin_aux")); }
   if (c->NFP) { hipLaunchKernelGGL(k_pose_reduce, dim3((unsigned)((c->NFP + 1) / 2)), dim3(64), 0, s, c->bv); OSH_TRY(launch_check("k_pose_reduce")); }
   hipLaunchKernelGGL(k_control, dim3((unsigned)c->n_windows), dim3(64), 0, s, c->bv, 0);
   OSH_TRY(launch_check("k_control"));

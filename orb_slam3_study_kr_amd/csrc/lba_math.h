@@ -219,6 +219,66 @@ __device__ __forceinline__ void edge_jacobians(int kind, const double* R, const 
   }
 }
 
+// ---- KannalaBrandt8 (fisheye) monocular edge: ORB_SLAM3::EdgeSE3ProjectXYZ through KannalaBrandt8::project(Vector3d)
+// (src/CameraModels/KannalaBrandt8.cpp:45-63) and ::projectJac (:147-175).  cam = fx fy cx cy (pose_cam), kb = k1..k4
+// (mvParameters[4..7]).  The reference rounds theta and psi to float32 (atan2f / sqrtf on double arguments); float32
+// atan2 is taken as its correctly rounded value (FP64 atan2 rounded once), which is libm independent and differs from
+// glibc's atan2f only in rare 1-ulp cases (same convention as oracle/lba_oracle.c).
+__device__ __forceinline__ float atan2f_rn(float y, float x) { return (float)atan2((double)y, (double)x); }
+__device__ __forceinline__ float sqrtf_rn(float x) { return (float)sqrt((double)x); }
+
+__device__ __forceinline__ double edge_residual_kb8(const double* qt, const double* cam, const double* kb, const double* X,
+                                                    const double* obs, double info, double* r, double* Xc) {
+  double rot[3];
+  quat_rotate(qt, X, rot);
+  Xc[0] = rot[0] + qt[4]; Xc[1] = rot[1] + qt[5]; Xc[2] = rot[2] + qt[6];
+  const double x2_plus_y2 = Xc[0] * Xc[0] + Xc[1] * Xc[1];
+  const double theta = (double)atan2f_rn(sqrtf_rn((float)x2_plus_y2), (float)Xc[2]);
+  const double psi = (double)atan2f_rn((float)Xc[1], (float)Xc[0]);
+  const double theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2,
+               theta9 = theta7 * theta2;
+  const double rr = theta + kb[0] * theta3 + kb[1] * theta5 + kb[2] * theta7 + kb[3] * theta9;
+  r[0] = obs[0] - (cam[0] * rr * cos(psi) + cam[2]);
+  r[1] = obs[1] - (cam[1] * rr * sin(psi) + cam[3]);
+  r[2] = 0.0;
+  return r[0] * (info * r[0]) + r[1] * (info * r[1]);
+}
+
+__device__ __forceinline__ void edge_jacobians_kb8(const double* R, const double* cam, const double* kb, const double* Xc,
+                                                   double* JX, double* Jp) {
+  const double x = Xc[0], y = Xc[1], z = Xc[2];
+  const double x2 = x * x, y2 = y * y, z2 = z * z;
+  const double r2 = x2 + y2, rr = sqrt(r2), r3 = r2 * rr;
+  const double theta = atan2(rr, z);
+  const double theta2 = theta * theta, theta3 = theta2 * theta, theta4 = theta2 * theta2, theta5 = theta4 * theta,
+               theta6 = theta2 * theta4, theta7 = theta6 * theta, theta8 = theta4 * theta4, theta9 = theta8 * theta;
+  const double f = theta + theta3 * kb[0] + theta5 * kb[1] + theta7 * kb[2] + theta9 * kb[3];
+  const double fd = 1 + 3 * kb[0] * theta2 + 5 * kb[1] * theta4 + 7 * kb[2] * theta6 + 9 * kb[3] * theta8;
+  const double den = r2 * (r2 + z2);
+  // Pm = -projectJac(Xc)  (src/OptimizableTypes.cpp:146)
+  double Pm[6];
+  Pm[0] = -(cam[0] * (fd * z * x2 / den + f * y2 / r3));
+  Pm[3] = -(cam[1] * (fd * z * y * x / den - f * y * x / r3));
+  Pm[1] = -(cam[0] * (fd * z * y * x / den - f * y * x / r3));
+  Pm[4] = -(cam[1] * (fd * z * y2 / den + f * x2 / r3));
+  Pm[2] = -(-cam[0] * fd * x / (r2 + z2));
+  Pm[5] = -(-cam[1] * fd * y / (r2 + z2));
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) JX[3 * i + j] = Pm[3 * i] * R[j] + Pm[3 * i + 1] * R[3 + j] + Pm[3 * i + 2] * R[6 + j];
+    // SE3deriv = [0 z -y 1 0 0; -z 0 x 0 1 0; y -x 0 0 0 1]
+    Jp[6 * i + 0] = Pm[3 * i + 2] * y - Pm[3 * i + 1] * z;
+    Jp[6 * i + 1] = Pm[3 * i] * z - Pm[3 * i + 2] * x;
+    Jp[6 * i + 2] = Pm[3 * i + 1] * x - Pm[3 * i] * y;
+    Jp[6 * i + 3] = Pm[3 * i]; Jp[6 * i + 4] = Pm[3 * i + 1]; Jp[6 * i + 5] = Pm[3 * i + 2];
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) JX[6 + j] = 0.0;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) Jp[12 + j] = 0.0;
+}
+
 // 64-lane butterfly sum: every lane ends with the same total (deterministic order).
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -20,6 +20,7 @@
 #include <climits>
 #include <cstdint>
 #include <iterator>
+#include <utility>
 #include <vector>
 
 namespace osh {
@@ -57,10 +58,33 @@ namespace plan_detail {
 
 inline int tiles_of(int n_poses) { return (6 * n_poses + 15) / 16; }
 
+// Sort key of one (landmark, part pair): sym flag, X poses, Y poses, compared lexicographically with absent slots last.
+// Poses are packed 16 bits each, most significant first, so four 64-bit compares order a key (pose indices < 65535).
 struct Unit {
-  std::array<int, 2 * kItemPoses + 1> key;  // sym flag, X poses, Y poses (INT_MAX padded)
+  uint64_t k[5];   // k[0]: 0 symmetric / 1 cross; k[1..2]: X poses; k[3..4]: Y poses (0xffff padded)
   int lm, a, b;
+  bool same_key(const Unit& o) const { return k[0] == o.k[0] && k[1] == o.k[1] && k[2] == o.k[2] && k[3] == o.k[3] && k[4] == o.k[4]; }
 };
+inline bool unit_less(const Unit& p, const Unit& q) {
+  for (int i = 0; i < 5; ++i) if (p.k[i] != q.k[i]) return p.k[i] < q.k[i];
+  if (p.lm != q.lm) return p.lm < q.lm;      // creation order (what a stable sort on the key alone would keep)
+  if (p.a != q.a) return p.a < q.a;
+  return p.b < q.b;
+}
+inline void pack_poses(const int* obs, int r0, int r1, uint64_t out[2]) {
+  out[0] = out[1] = ~0ull;
+  for (int r = r0; r < r1; ++r) {
+    const int s = r - r0, w = s >> 2, sh = 48 - 16 * (s & 3);
+    out[w] = (out[w] & ~(0xffffull << sh)) | ((uint64_t)(unsigned)obs[r] << sh);
+  }
+}
+inline void unpack_poses(const uint64_t in[2], std::vector<int>& out) {
+  out.clear();
+  for (int s = 0; s < kItemPoses; ++s) {
+    const unsigned v = (unsigned)((in[s >> 2] >> (48 - 16 * (s & 3))) & 0xffff);
+    if (v != 0xffff) out.push_back((int)v);
+  }
+}
 
 struct Build {
   bool sym = true;
@@ -99,33 +123,58 @@ inline bool plan_window(int w, int P, int L, const int* lmo, const int* nfree, c
   units.reserve((size_t)L + L / 2);
   for (int j = 0; j < L; ++j) {
     const int k = nfree[j];
-    if (k > 254) return false;
+    if (k > 254 || P >= 0xffff) return false;
     const int* obs = epose + lmo[j];
     const int nparts = std::max(1, (k + kItemPoses - 1) / kItemPoses);
     for (int a = 0; a < nparts; ++a)
       for (int b = a; b < nparts; ++b) {
         Unit u;
-        u.key.fill(INT_MAX);
-        u.key[0] = (a == b) ? 0 : 1;
+        u.k[0] = (a == b) ? 0 : 1;
         const int a0 = a * kItemPoses, a1 = std::min(k, a0 + kItemPoses);
         const int b0 = b * kItemPoses, b1 = std::min(k, b0 + kItemPoses);
-        for (int r = a0; r < a1; ++r) u.key[1 + r - a0] = obs[r];
-        for (int r = b0; r < b1; ++r) u.key[1 + kItemPoses + r - b0] = obs[r];
+        pack_poses(obs, a0, a1, &u.k[1]);
+        pack_poses(obs, b0, b1, &u.k[3]);
         u.lm = j; u.a = a; u.b = b;
         units.push_back(u);
       }
     plan.pair_blocks += (long long)k * (k + 1) / 2;
   }
-  std::stable_sort(units.begin(), units.end(), [](const Unit& p, const Unit& q) { return p.key < q.key; });
+  // Order by unit_less.  A window has few distinct keys (hundreds, against tens of thousands of units), so the units are
+  // bucketed by key with a small open-addressing table, only the distinct keys are sorted, and the units of a key keep their
+  // creation order (lm, a, b ascending), which is unit_less's tie-break.
+  {
+    size_t cap = 64;
+    while (cap < 2 * units.size()) cap <<= 1;
+    std::vector<int> table(cap, -1);          // slot -> group
+    std::vector<int> rep, count, gid(units.size());   // group -> first unit with that key, number of units
+    for (size_t i = 0; i < units.size(); ++i) {
+      const Unit& u = units[i];
+      uint64_t h = u.k[0] * 0x9e3779b97f4a7c15ull;
+      for (int q = 1; q < 5; ++q) { h ^= u.k[q]; h *= 0xff51afd7ed558ccdull; h ^= h >> 32; }
+      size_t slot = (size_t)h & (cap - 1);
+      while (table[slot] >= 0 && !units[rep[table[slot]]].same_key(u)) slot = (slot + 1) & (cap - 1);
+      if (table[slot] < 0) { table[slot] = (int)rep.size(); rep.push_back((int)i); count.push_back(0); }
+      gid[i] = table[slot];
+      count[gid[i]]++;
+    }
+    std::vector<int> gorder(rep.size());
+    for (size_t g = 0; g < rep.size(); ++g) gorder[g] = (int)g;
+    std::sort(gorder.begin(), gorder.end(), [&](int p, int q) { return unit_less(units[rep[p]], units[rep[q]]); });
+    std::vector<size_t> start(rep.size());
+    size_t acc = 0;
+    for (int g : gorder) { start[g] = acc; acc += (size_t)count[g]; }
+    std::vector<Unit> sorted(units.size());
+    for (size_t i = 0; i < units.size(); ++i) sorted[start[gid[i]]++] = units[i];
+    units.swap(sorted);
+  }
 
   const size_t first_build = out_builds.size();
   std::vector<int> curX, curY;
   std::vector<const Unit*> cur;
   bool cur_sym = true;
   auto key_sets = [](const Unit& u, std::vector<int>& X, std::vector<int>& Y) {
-    X.clear(); Y.clear();
-    for (int s = 0; s < kItemPoses; ++s) if (u.key[1 + s] != INT_MAX) X.push_back(u.key[1 + s]);
-    for (int s = 0; s < kItemPoses; ++s) if (u.key[1 + kItemPoses + s] != INT_MAX) Y.push_back(u.key[1 + kItemPoses + s]);
+    unpack_poses(&u.k[1], X);
+    unpack_poses(&u.k[3], Y);
   };
   auto flush = [&]() {
     for (size_t base = 0; base < cur.size(); base += kItemMaxLm) {
@@ -134,13 +183,19 @@ inline bool plan_window(int w, int P, int L, const int* lmo, const int* nfree, c
       std::fill(bd.pair_slot, bd.pair_slot + 64, -1);
       std::fill(bd.c_slot, bd.c_slot + 8, -1);
       const size_t end = std::min(cur.size(), base + kItemMaxLm);
+      bd.recs.reserve(end - base);
+      const Unit* prev = nullptr;
+      unsigned long long xs = 0, ys = 0;
       for (size_t x = base; x < end; ++x) {
         const Unit& u = *cur[x];
         const int k = nfree[u.lm];
         const int* obs = epose + lmo[u.lm];
         const int a0 = u.a * kItemPoses, a1 = std::min(k, a0 + kItemPoses);
         const int b0 = u.b * kItemPoses, b1 = std::min(k, b0 + kItemPoses);
-        const unsigned long long xs = pack_slots(curX, obs, a0, a1), ys = pack_slots(curY, obs, b0, b1);
+        // units with the same key and part pair have the same slot assignment and mark the same live pairs
+        const bool same = prev && prev->same_key(u) && prev->a == u.a && prev->b == u.b;
+        if (!same) { xs = pack_slots(curX, obs, a0, a1); ys = pack_slots(curY, obs, b0, b1); }
+        prev = &u;
         SRec r;
         r.lm = u.lm; r.e_first = lmo[u.lm];
         r.x_lo = (unsigned)xs; r.x_hi = (unsigned)(xs >> 32); r.y_lo = (unsigned)ys; r.y_hi = (unsigned)(ys >> 32);
@@ -148,6 +203,7 @@ inline bool plan_window(int w, int P, int L, const int* lmo, const int* nfree, c
         r.pad = lmo[u.lm + 1] - lmo[u.lm];
         bd.recs.push_back(r);
         // live pairs (marked with -2, numbered later)
+        if (same) continue;
         for (int sa = 0; sa < kItemPoses; ++sa) {
           if (((xs >> (8 * sa)) & 0xff) == kAbsent) continue;
           if (cur_sym) bd.c_slot[sa] = -2;
@@ -166,9 +222,9 @@ inline bool plan_window(int w, int P, int L, const int* lmo, const int* nfree, c
   size_t x = 0;
   while (x < units.size()) {
     size_t x1 = x + 1;
-    while (x1 < units.size() && units[x1].key == units[x].key) ++x1;
+    while (x1 < units.size() && units[x1].same_key(units[x])) ++x1;
     key_sets(units[x], gX, gY);
-    const bool g_sym = units[x].key[0] == 0;
+    const bool g_sym = units[x].k[0] == 0;
     bool merged = false;
     if (!cur.empty() && cur_sym == g_sym && cur.size() < (size_t)kItemMaxLm) {
       std::vector<int> ux = set_union(curX, gX), uy = set_union(curY, gY);

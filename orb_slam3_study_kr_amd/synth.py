@@ -23,6 +23,9 @@ from . import capi
 FX, FY, CX, CY = np.float32(458.654), np.float32(457.296), np.float32(367.215), np.float32(248.375)
 IMG_W, IMG_H = 752, 480
 BF = np.float32(np.float32(458.654) * np.float32(0.110078))
+# KannalaBrandt8 k1..k4 (the float32 values an ORB-SLAM3 TUM-VI settings file stores as Camera1.k1..k4)
+KB8_K = np.array([0.0034823894022493434, 0.0007150348452162257, -0.0020532361418706202, 0.00020293673591811182],
+                 dtype=np.float32).astype(np.float64)
 N_LEVELS, SCALE_FACTOR = 8, 1.2
 # mvInvLevelSigma2[l] = 1/(1.2^l)^2 as float (src/ORBextractor.cc:414-429)
 _sf = np.ones(N_LEVELS, dtype=np.float32)
@@ -57,6 +60,7 @@ class LbaWindow:
     lambda_init: float = 0.0
     max_iterations: int = 10
     stop_flag: np.ndarray | None = None   # u8[1] or None
+    kb8: np.ndarray | None = None         # [4] f64 KannalaBrandt8 k1..k4: mono edges project through the fisheye model
     gt_pose_qt: np.ndarray | None = None  # ground truth (not part of the problem)
     gt_points: np.ndarray | None = None
     outlier_mask: np.ndarray | None = None
@@ -101,6 +105,9 @@ class LbaWindow:
         p.huber_mono, p.huber_stereo = self.huber_mono, self.huber_stereo
         p.lambda_init, p.max_iterations = self.lambda_init, self.max_iterations
         p.stop_flag = capi.ptr(self.stop_flag, capi.c_uint8_p) if self.stop_flag is not None else C.cast(None, capi.c_uint8_p)
+        if self.kb8 is not None:
+            self.kb8 = np.ascontiguousarray(self.kb8, dtype=np.float64)
+        p.kb8 = capi.ptr(self.kb8, capi.c_double_p)
         return p
 
     def algorithmic_bytes(self) -> dict:
@@ -189,7 +196,7 @@ def make_window(seed: int, n_free: int = 50, n_fixed: int = 10, n_points: int = 
                 track_len=(4, 12), pose_noise=(0.01, 0.05), point_noise: float = 0.1,
                 outlier_frac: float = 0.03, pixel_noise: bool = True, kf_spacing: float = 0.25,
                 yaw_drift: float = 0.02, lambda_init: float = 0.0, max_iterations: int = 10,
-                mixed_mono_frac: float = 0.0, obs_dropout: float = 0.0) -> LbaWindow:
+                mixed_mono_frac: float = 0.0, obs_dropout: float = 0.0, fisheye: bool = False) -> LbaWindow:
     """A synthetic local-BA window.
 
     Keyframes move along +x looking down +z with a slow yaw drift; the oldest
@@ -197,8 +204,10 @@ def make_window(seed: int, n_free: int = 50, n_fixed: int = 10, n_points: int = 
     Landmarks fill a 4-12 m deep slab; each is observed by a contiguous run of
     ``track_len`` keyframes that see it; ``obs_dropout`` removes that fraction of the
     observations at random (missed detections: the observer sets stop being contiguous runs).
-    Order of poses: optimisable first.
+    Order of poses: optimisable first.  ``fisheye``: a monocular KannalaBrandt8 camera (KB8_K, same fx fy cx cy):
+    the observations are the fisheye projections and the window carries ``kb8``.
     """
+    assert not (fisheye and stereo), "the fisheye window is monocular"
     rng = np.random.Generator(np.random.PCG64(seed))
     K = n_free + n_fixed
     # ---- ground-truth keyframe poses, Twc then Tcw
@@ -224,8 +233,15 @@ def make_window(seed: int, n_free: int = 50, n_fixed: int = 10, n_points: int = 
     # project into all keyframes
     Xc = np.einsum("kij,lj->kli", Rcw, Xw) + tcw[:, None, :]          # [K,L,3]
     z = Xc[..., 2]
-    u = float(FX) * Xc[..., 0] / z + float(CX)
-    v = float(FY) * Xc[..., 1] / z + float(CY)
+    if fisheye:
+        theta = np.arctan2(np.hypot(Xc[..., 0], Xc[..., 1]), z)
+        psi = np.arctan2(Xc[..., 1], Xc[..., 0])
+        rr = theta + KB8_K[0] * theta**3 + KB8_K[1] * theta**5 + KB8_K[2] * theta**7 + KB8_K[3] * theta**9
+        u = float(FX) * rr * np.cos(psi) + float(CX)
+        v = float(FY) * rr * np.sin(psi) + float(CY)
+    else:
+        u = float(FX) * Xc[..., 0] / z + float(CX)
+        v = float(FY) * Xc[..., 1] / z + float(CY)
     vis = (z > 0.5) & (u >= 0) & (u < IMG_W) & (v >= 0) & (v < IMG_H)
     if stereo:
         vis &= (u - float(BF) / z) >= 0
@@ -284,7 +300,7 @@ def make_window(seed: int, n_free: int = 50, n_fixed: int = 10, n_points: int = 
         edge_pose=pose_index[kk].astype(np.int32), edge_point=remap[ll].astype(np.int32), edge_kind=kind,
         edge_obs=_f32(obs), edge_info=INV_LEVEL_SIGMA2[octave].astype(np.float64),
         lambda_init=lambda_init, max_iterations=max_iterations,
-        gt_pose_qt=gt_qt, gt_points=pts_gt, outlier_mask=is_out,
+        gt_pose_qt=gt_qt, gt_points=pts_gt, outlier_mask=is_out, kb8=KB8_K.copy() if fisheye else None,
     )
     return w.normalise()
 

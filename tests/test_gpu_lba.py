@@ -224,3 +224,25 @@ def test_randomised_small_windows_in_one_batch(solver, ob):
             worst = max(worst, rel_translation_error(g.pose_qt, r.pose_qt))
             np.testing.assert_allclose(g.points, r.points, rtol=1e-5, atol=1e-5, err_msg=f"window {w.n_free}+{w.n_fixed} KF, {w.n_points} points")
     assert worst < 1e-6
+
+
+def test_fisheye_monocular_window_kannala_brandt8(solver, ob):
+    """Monocular KannalaBrandt8 windows (osh_lba_problem.kb8; EdgeSE3ProjectXYZ through KannalaBrandt8::project / projectJac,
+    src/CameraModels/KannalaBrandt8.cpp:45-63,147-175): assembled blocks, the full LM run, and a batch that mixes a fisheye
+    window with pinhole ones (the KB8 kernel instantiations take the pinhole path per window)."""
+    w = synth.make_window(31, n_free=12, n_fixed=4, n_points=1500, stereo=False, track_len=(3, 10), fisheye=True)
+    solver.upload([w])
+    _assert_blocks(solver.linearize(0), ob.lba_linearize(w), tol=1e-10)
+    got = solver.solve([w])[0]
+    ref = ob.lba_solve(w)
+    assert ref.iterations >= 5 and ref.chi2_trace[ref.iterations - 1] < 0.3 * ref.chi2_initial
+    _check_result(got, ref, w)
+    ws = [w, synth.make_config1(3), synth.make_window(32, n_free=5, n_fixed=2, n_points=300, stereo=True, track_len=(2, 6)),
+          synth.make_window(33, n_free=7, n_fixed=3, n_points=600, stereo=False, track_len=(3, 8), fisheye=True, obs_dropout=0.2)]
+    for g, wi in zip(solver.solve(ws), ws):
+        _check_result(g, ob.lba_solve(wi), wi)
+    # stereo edges cannot live in a fisheye window
+    bad = synth.make_window(34, n_free=4, n_fixed=2, n_points=100, stereo=False, track_len=(2, 5), fisheye=True)
+    bad.edge_kind[3] = 1
+    with pytest.raises(RuntimeError, match="KannalaBrandt8"):
+        solver.upload([bad])
