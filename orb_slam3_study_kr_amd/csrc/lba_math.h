@@ -223,7 +223,7 @@ __device__ __forceinline__ void edge_jacobians(int kind, const double* R, const 
 // (src/CameraModels/KannalaBrandt8.cpp:45-63) and ::projectJac (:147-175).  cam = fx fy cx cy (pose_cam), kb = k1..k4
 // (mvParameters[4..7]).  The reference rounds theta and psi to float32 (atan2f / sqrtf on double arguments); float32
 // atan2 is taken as its correctly rounded value (FP64 atan2 rounded once), which is libm independent and differs from
-// glibc's atan2f only in rare 1-ulp cases (same convention as oracle/lba_oracle.c).
+// glibc's atan2f only in rare 1-ulp cases (the parity tests' CPU restatement uses the same convention).
 __device__ __forceinline__ float atan2f_rn(float y, float x) { return (float)atan2((double)y, (double)x); }
 __device__ __forceinline__ float sqrtf_rn(float x) { return (float)sqrt((double)x); }
 
