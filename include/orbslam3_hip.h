@@ -187,6 +187,7 @@ typedef struct osh_pose_problem {
   double huber_mono, huber_stereo;   /* deltaMono, deltaStereo of rounds 0..2 */
   float chi2_mono[4], chi2_stereo[4];
   int32_t iterations[4];
+  const double* kb8;          /* NULL: pinhole.  [4] k1..k4: the frame's camera is a KannalaBrandt8 (as osh_lba_problem.kb8), mono edges only */
 } osh_pose_problem;
 
 typedef struct osh_pose_result {

@@ -24,6 +24,10 @@ osh_host_graph* osh_host_graph_create(int32_t n_kf, const int64_t* kf_id, const 
                                       int32_t n_obs, const int32_t* obs_kf, const int32_t* obs_mp, const float* obs_uvr,
                                       const int32_t* obs_octave, int64_t init_kf_id, int32_t inertial);
 void osh_host_graph_destroy(osh_host_graph* g);
+/* Camera model of the window the last osh_host_pack_lba / _gba / _welding call built: 1 + k1..k4 for KannalaBrandt8, else 0. */
+int osh_host_last_pack_kb8(osh_host_graph* g, double k[4]);
+/* Switch the map's camera to a KannalaBrandt8 (same fx fy cx cy, coefficients k1..k4): a monocular fisheye map. */
+void osh_host_graph_set_fisheye(osh_host_graph* g, const float k[4]);
 /* covisibility list returned by KeyFrame::GetVectorCovisibleKeyFrames() of keyframe kf_index */
 int osh_host_graph_set_covisible(osh_host_graph* g, int32_t kf_index, int32_t n, const int32_t* kf_indices);
 
@@ -92,6 +96,8 @@ osh_host_frame* osh_host_frame_create(int32_t n, const float* kp_xy, const int32
                                       const float* uright, const uint8_t* desc, const float pose_qt[7],
                                       const float cam4[4], float mbf, float mb, int32_t n_levels, float scale_factor);
 void osh_host_frame_destroy(osh_host_frame* f);
+/* Switch the frame's camera to a KannalaBrandt8 (same fx fy cx cy, coefficients k1..k4). */
+void osh_host_frame_set_fisheye(osh_host_frame* f, const float k[4]);
 /* ORBmatcher(nnratio).SearchByProjection(F, vpMapPoints, th): map points given by their tracking scratch
  * (mTrackProjX/Y/XR, mnTrackScaleLevel, mTrackViewCos, mTrackDepth), descriptor and Observations().
  * assignment[k] = index of the map point stored in F.mvpMapPoints[k] or -1.  Returns nmatches (<0: error). */

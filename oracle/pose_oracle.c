@@ -35,7 +35,10 @@ static double edge_chi2(const pstate* s, int e) {
 
 static void compute_error(pstate* s, int e) {
   const osh_pose_problem* p = s->p;
-  oracle_edge_error(p->edge_kind[e], s->qt, p->cam, p->points + 3 * (size_t)e, p->edge_obs + 3 * (size_t)e, s->err + 3 * (size_t)e);
+  if (p->kb8 && p->edge_kind[e] == OSH_EDGE_MONO)
+    oracle_edge_error_kb8(s->qt, p->cam, p->kb8, p->points + 3 * (size_t)e, p->edge_obs + 3 * (size_t)e, s->err + 3 * (size_t)e);
+  else
+    oracle_edge_error(p->edge_kind[e], s->qt, p->cam, p->points + 3 * (size_t)e, p->edge_obs + 3 * (size_t)e, s->err + 3 * (size_t)e);
 }
 
 static void compute_active_errors(pstate* s) {
@@ -63,7 +66,8 @@ static void build_system(pstate* s, double H[36], double b[6]) {
   for (int e = 0; e < p->n_edges; ++e) {
     if (s->level[e]) continue;
     double JX[9], Jp[18];
-    oracle_edge_jacobians(p->edge_kind[e], s->qt, p->cam, p->points + 3 * (size_t)e, JX, Jp);
+    if (p->kb8 && p->edge_kind[e] == OSH_EDGE_MONO) oracle_edge_jacobians_kb8(s->qt, p->cam, p->kb8, p->points + 3 * (size_t)e, JX, Jp);
+    else oracle_edge_jacobians(p->edge_kind[e], s->qt, p->cam, p->points + 3 * (size_t)e, JX, Jp);
     const double* r = s->err + 3 * (size_t)e;
     const double info = p->edge_info[e];
     double rho1 = 1.0;

@@ -69,6 +69,7 @@ class PoseProblem(C.Structure):
         ("edge_kind", c_uint8_p), ("edge_obs", c_double_p), ("edge_info", c_double_p),
         ("huber_mono", C.c_double), ("huber_stereo", C.c_double),
         ("chi2_mono", C.c_float * 4), ("chi2_stereo", C.c_float * 4), ("iterations", C.c_int32 * 4),
+        ("kb8", c_double_p),
     ]
 
 
@@ -211,6 +212,8 @@ _HOST_SIGNATURES = {
     "osh_host_graph_create": (C.c_void_p, [C.c_int32, c_int64_p, c_float_p, c_float_p, c_float_p, C.c_int32, C.c_int32, c_int64_p,
                                            c_float_p, C.c_int32, c_int32_p, c_int32_p, c_float_p, c_int32_p, C.c_int64, C.c_int32]),
     "osh_host_graph_destroy": (None, [C.c_void_p]),
+    "osh_host_graph_set_fisheye": (None, [C.c_void_p, c_float_p]),
+    "osh_host_last_pack_kb8": (C.c_int, [C.c_void_p, c_double_p]),
     "osh_host_graph_set_covisible": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_int32_p]),
     "osh_host_pack_lba": (C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_double_p, c_double_p, c_double_p, c_int32_p, c_int32_p,
                                     c_uint8_p, c_double_p, c_double_p, c_int64_p, c_int64_p]),
@@ -232,6 +235,7 @@ _HOST_SIGNATURES = {
     "osh_host_inertial_information": (C.c_int, [c_float_p, c_double_p]),
     "osh_host_frame_create": (C.c_void_p, [C.c_int32, c_float_p, c_int32_p, c_float_p, c_float_p, c_uint8_p, c_float_p, c_float_p,
                                            C.c_float, C.c_float, C.c_int32, C.c_float]),
+    "osh_host_frame_set_fisheye": (None, [C.c_void_p, c_float_p]),
     "osh_host_frame_destroy": (None, [C.c_void_p]),
     "osh_host_frame_search_local_points_projected": (C.c_int, [C.c_void_p, C.c_int32, c_float_p, c_float_p, c_float_p, c_float_p, C.c_float,
                                                               c_uint8_p, c_float_p, c_float_p, c_float_p, c_float_p, c_int32_p, c_uint8_p,

@@ -120,12 +120,7 @@ bool PackLocalBA(KeyFrame* pKF, Map* pMap, LbaPack& pk) {
         const bool stereo = kp_ur >= 0;   // mono if mvuRight < 0 (:1305), stereo otherwise (:1332)
         if (!stereo) {
           // the mono edge projects through pKFi->mpCamera (:1323); the device keeps ONE intrinsics row per keyframe
-          GeometricCamera* cam = pKFi->mpCamera;
-          if (!cam || cam->GetType() != GeometricCamera::CAM_PINHOLE || cam->getParameter(0) != pKFi->fx ||
-              cam->getParameter(1) != pKFi->fy || cam->getParameter(2) != pKFi->cx || cam->getParameter(3) != pKFi->cy) {
-            pk.unsupported = "monocular observation through a camera that is not the keyframe's pinhole model";
-            return true;
-          }
+          if (!pk.mono_camera(pKFi->mpCamera, pKFi->fx, pKFi->fy, pKFi->cx, pKFi->cy)) return true;
         }
         pk.edge_pose.push_back(poseIndex.at(pKFi));
         pk.edge_point.push_back(pointIndex.at(pMP));
@@ -143,6 +138,7 @@ bool PackLocalBA(KeyFrame* pKF, Map* pMap, LbaPack& pk) {
       }
     }
   }
+  pk.camera_models_ok();
   return true;
 }
 

@@ -70,14 +70,7 @@ void PackBundleAdjustment(const std::vector<KeyFrame*>& vpKFs, const std::vector
         const cv::KeyPoint& kpUn = pKF->mvKeysUn[leftIndex];
         const float kp_ur = pKF->mvuRight[leftIndex];
         const bool stereo = kp_ur >= 0;   // mono if mvuRight < 0 (:167), stereo otherwise (:194)
-        if (!stereo) {
-          GeometricCamera* cam = pKF->mpCamera;
-          if (!cam || cam->GetType() != GeometricCamera::CAM_PINHOLE || cam->getParameter(0) != pKF->fx ||
-              cam->getParameter(1) != pKF->fy || cam->getParameter(2) != pKF->cx || cam->getParameter(3) != pKF->cy) {
-            pk.unsupported = "monocular observation through a camera that is not the keyframe's pinhole model";
-            return;
-          }
-        }
+        if (!stereo && !pk.mono_camera(pKF->mpCamera, pKF->fx, pKF->fy, pKF->cx, pKF->cy)) return;
         Ed e;
         e.kf = pKF; e.mp = pMP; e.pose = pit->second; e.kind = stereo ? OSH_EDGE_STEREO : OSH_EDGE_MONO;
         e.obs[0] = kpUn.pt.x; e.obs[1] = kpUn.pt.y; e.obs[2] = stereo ? kp_ur : -1.0;
@@ -109,6 +102,7 @@ void PackBundleAdjustment(const std::vector<KeyFrame*>& vpKFs, const std::vector
     pk.vEdgeKF.push_back(e.kf);
     pk.vEdgeMP.push_back(e.mp);
   }
+  pk.camera_models_ok();
 }
 
 void Optimizer::GlobalBundleAdjustemnt(Map* pMap, int nIterations, bool* pbStopFlag, const unsigned long nLoopKF, const bool bRobust) {
@@ -239,14 +233,7 @@ void PackWeldingBA(KeyFrame* pMainKF, const std::vector<KeyFrame*>& vpAdjustKF, 
       const cv::KeyPoint& kpUn = pKF->mvKeysUn[leftIndex];
       const float kp_ur = pKF->mvuRight[leftIndex];
       const bool stereo = !(kp_ur < 0);
-      if (!stereo) {
-        GeometricCamera* cam = pKF->mpCamera;
-        if (!cam || cam->GetType() != GeometricCamera::CAM_PINHOLE || cam->getParameter(0) != pKF->fx ||
-            cam->getParameter(1) != pKF->fy || cam->getParameter(2) != pKF->cx || cam->getParameter(3) != pKF->cy) {
-          pk.unsupported = "monocular observation through a camera that is not the keyframe's pinhole model";
-          return;
-        }
-      }
+      if (!stereo && !pk.mono_camera(pKF->mpCamera, pKF->fx, pKF->fy, pKF->cx, pKF->cy)) return;
       pk.edge_pose.push_back(poseIndex.at(pKF));
       pk.edge_point.push_back(pointIndex.at(pMPi));
       pk.edge_kind.push_back(stereo ? OSH_EDGE_STEREO : OSH_EDGE_MONO);
@@ -256,6 +243,7 @@ void PackWeldingBA(KeyFrame* pMainKF, const std::vector<KeyFrame*>& vpAdjustKF, 
       pk.vEdgeMP.push_back(pMPi);
     }
   }
+  pk.camera_models_ok();
 }
 
 void Optimizer::LocalBundleAdjustment(KeyFrame* pMainKF, std::vector<KeyFrame*> vpAdjustKF, std::vector<KeyFrame*> vpFixedKF, bool* pbStopFlag) {

@@ -2,7 +2,7 @@
 //
 // Host side: the edge construction of src/Optimizer.cc:815-1017 flattened into an osh_pose_problem, the device runs the
 // four optimise / classify rounds (:1019-1108, csrc/pose_device.hip), the host writes mvbOutlier and the pose back
-// (:1110-1114).  Monocular and rectified-stereo / RGB-D frames (pFrame->mpCamera2 == NULL).
+// (:1110-1114).  Monocular (pinhole or KannalaBrandt8) and rectified-stereo / RGB-D frames (pFrame->mpCamera2 == NULL).
 #include <cmath>
 #include <cstdio>
 #include <mutex>
@@ -28,6 +28,9 @@ int Optimizer::PoseOptimization(Frame* pFrame) {
   const int N = pFrame->N;
   std::vector<double> points, obs, info;
   std::vector<uint8_t> kind;
+  bool has_kb8 = false;
+  double kb8[4] = {0, 0, 0, 0};
+  int n_stereo = 0;
   std::vector<int> index;   // keypoint of every edge (vnIndexEdgeMono / vnIndexEdgeStereo merged, edge order = keypoint order)
   points.reserve((size_t)N * 3); obs.reserve((size_t)N * 3); info.reserve(N); kind.reserve(N); index.reserve(N);
   {
@@ -41,14 +44,16 @@ int Optimizer::PoseOptimization(Frame* pFrame) {
       const float kp_ur = pFrame->mvuRight[i];
       const bool stereo = !(kp_ur < 0);   // mono if mvuRight < 0 (:871), stereo otherwise
       if (!stereo) {
-        // the mono edge projects through pFrame->mpCamera (:897); the device keeps one intrinsics row per frame
+        // the mono edge projects through pFrame->mpCamera (:897): the frame's pinhole model or its KannalaBrandt8 (fisheye) model
         GeometricCamera* c = pFrame->mpCamera;
-        if (!c || c->GetType() != GeometricCamera::CAM_PINHOLE || c->getParameter(0) != pFrame->fx || c->getParameter(1) != pFrame->fy ||
-            c->getParameter(2) != pFrame->cx || c->getParameter(3) != pFrame->cy) {
-          std::fprintf(stderr, "PoseOptimization: monocular observation through a camera that is not the frame's pinhole model; not supported yet\n");
+        const bool fisheye = c && c->GetType() == GeometricCamera::CAM_FISHEYE;
+        if (!c || (!fisheye && c->GetType() != GeometricCamera::CAM_PINHOLE) || c->getParameter(0) != pFrame->fx ||
+            c->getParameter(1) != pFrame->fy || c->getParameter(2) != pFrame->cx || c->getParameter(3) != pFrame->cy) {
+          std::fprintf(stderr, "PoseOptimization: monocular observation through a camera that is not the frame's own model; not supported yet\n");
           return 0;
         }
-      }
+        if (fisheye) { has_kb8 = true; for (int k = 0; k < 4; ++k) kb8[k] = c->getParameter(4 + k); }
+      } else n_stereo++;
       const Eigen::Vector3d Xw = pMP->GetWorldPos().cast<double>();
       points.push_back(Xw[0]); points.push_back(Xw[1]); points.push_back(Xw[2]);
       obs.push_back(kpUn.pt.x); obs.push_back(kpUn.pt.y); obs.push_back(stereo ? kp_ur : -1.0);
@@ -58,6 +63,10 @@ int Optimizer::PoseOptimization(Frame* pFrame) {
     }
   }
   if (nInitialCorrespondences < 3) return 0;   // :1012-1013
+  if (has_kb8 && n_stereo > 0) {
+    std::fprintf(stderr, "PoseOptimization: rectified-stereo observations in a KannalaBrandt8 frame are not supported by the MI355X path yet\n");
+    return 0;
+  }
 
   osh_lba_ctx* ctx = HostSolverContext();
   if (!ctx) return 0;
@@ -65,6 +74,7 @@ int Optimizer::PoseOptimization(Frame* pFrame) {
   prob.n_edges = (int32_t)index.size();
   prob.pose_qt = pose_qt; prob.cam = cam; prob.points = points.data(); prob.edge_kind = kind.data();
   prob.edge_obs = obs.data(); prob.edge_info = info.data();
+  prob.kb8 = has_kb8 ? kb8 : nullptr;
   prob.huber_mono = (double)(float)std::sqrt(5.991);     // const float deltaMono = sqrt(5.991) (:858)
   prob.huber_stereo = (double)(float)std::sqrt(7.815);   // (:859)
   for (int k = 0; k < 4; ++k) { prob.chi2_mono[k] = 5.991f; prob.chi2_stereo[k] = 7.815f; prob.iterations[k] = 10; }   // :1016-1018

@@ -16,11 +16,13 @@ using namespace ORB_SLAM3;
 
 struct osh_host_graph {
   Map map;
-  std::unique_ptr<Pinhole> cam;
+  std::unique_ptr<GeometricCamera> cam;
   std::vector<std::unique_ptr<KeyFrame>> kfs;
   std::vector<std::unique_ptr<MapPoint>> mps;
   std::vector<std::unique_ptr<IMU::Preintegrated>> preints;
   LibaPack liba;   // storage behind osh_host_pack_liba
+  bool last_has_kb8 = false;   // camera model of the last osh_host_pack_lba / _gba / _welding
+  double last_kb8[4] = {0, 0, 0, 0};
 };
 
 static Sophus::SE3f pose_from(const float* qt) {
@@ -69,6 +71,14 @@ extern "C" osh_host_graph* osh_host_graph_create(int32_t n_kf, const int64_t* kf
   return g;
 }
 
+// Replace the map's camera by a KannalaBrandt8 with the same fx fy cx cy and coefficients k[4] (a monocular fisheye map).
+extern "C" void osh_host_graph_set_fisheye(osh_host_graph* g, const float k[4]) {
+  if (!g || g->kfs.empty()) return;
+  KeyFrame* k0 = g->kfs[0].get();
+  g->cam.reset(new KannalaBrandt8(std::vector<float>{k0->fx, k0->fy, k0->cx, k0->cy, k[0], k[1], k[2], k[3]}));
+  for (auto& kf : g->kfs) kf->mpCamera = g->cam.get();
+}
+
 extern "C" void osh_host_graph_destroy(osh_host_graph* g) { delete g; }
 
 extern "C" int osh_host_graph_set_covisible(osh_host_graph* g, int32_t kf_index, int32_t n, const int32_t* kf_indices) {
@@ -92,6 +102,7 @@ extern "C" int osh_host_pack_lba(osh_host_graph* g, int32_t kf_index, int32_t si
   sizes[4] = pk.num_fixedKF;
   if (!ok) return 1;
   if (pk.unsupported) return -3;
+  g->last_has_kb8 = pk.has_kb8; for (int k = 0; k < 4; ++k) g->last_kb8[k] = pk.kb8[k];
   auto cp = [](auto* dst, const auto& src) { if (dst) std::copy(src.begin(), src.end(), dst); };
   cp(pose_qt, pk.pose_qt); cp(pose_cam, pk.pose_cam); cp(points, pk.points); cp(edge_pose, pk.edge_pose);
   cp(edge_point, pk.edge_point); cp(edge_kind, pk.edge_kind); cp(edge_obs, pk.edge_obs); cp(edge_info, pk.edge_info);
@@ -109,6 +120,13 @@ extern "C" int osh_host_run_lba(osh_host_graph* g, int32_t kf_index, unsigned ch
   return 0;
 }
 
+// Camera model of the window the last pack call produced: returns 1 and fills k[4] for a KannalaBrandt8 window, else 0.
+extern "C" int osh_host_last_pack_kb8(osh_host_graph* g, double k[4]) {
+  if (!g || !g->last_has_kb8) return 0;
+  for (int i = 0; i < 4; ++i) k[i] = g->last_kb8[i];
+  return 1;
+}
+
 // ---- Optimizer::GlobalBundleAdjustemnt (csrc/host/OptimizerGlobal.cc)
 extern "C" int osh_host_pack_gba(osh_host_graph* g, int32_t sizes[5], double* pose_qt, double* pose_cam, double* points,
                                  int32_t* edge_pose, int32_t* edge_point, uint8_t* edge_kind, double* edge_obs, double* edge_info,
@@ -120,6 +138,7 @@ extern "C" int osh_host_pack_gba(osh_host_graph* g, int32_t sizes[5], double* po
   sizes[0] = pk.n_free; sizes[1] = pk.n_fixed; sizes[2] = (int32_t)pk.vPointMPs.size(); sizes[3] = (int32_t)pk.edge_pose.size();
   sizes[4] = (int32_t)std::count(notIncluded.begin(), notIncluded.end(), true);
   if (pk.unsupported) return -3;
+  g->last_has_kb8 = pk.has_kb8; for (int k = 0; k < 4; ++k) g->last_kb8[k] = pk.kb8[k];
   auto cp = [](auto* dst, const auto& src) { if (dst) std::copy(src.begin(), src.end(), dst); };
   cp(pose_qt, pk.pose_qt); cp(pose_cam, pk.pose_cam); cp(points, pk.points); cp(edge_pose, pk.edge_pose);
   cp(edge_point, pk.edge_point); cp(edge_kind, pk.edge_kind); cp(edge_obs, pk.edge_obs); cp(edge_info, pk.edge_info);
@@ -148,6 +167,7 @@ extern "C" int osh_host_pack_welding(osh_host_graph* g, int32_t main_index, int3
   for (auto& mp : g->mps) mp->mnBALocalForMerge = 0;
   sizes[0] = pk.n_free; sizes[1] = pk.n_fixed; sizes[2] = (int32_t)pk.vPointMPs.size(); sizes[3] = (int32_t)pk.edge_pose.size(); sizes[4] = 0;
   if (pk.unsupported) return -3;
+  g->last_has_kb8 = pk.has_kb8; for (int k = 0; k < 4; ++k) g->last_kb8[k] = pk.kb8[k];
   auto cp = [](auto* dst, const auto& src) { if (dst) std::copy(src.begin(), src.end(), dst); };
   cp(pose_qt, pk.pose_qt); cp(pose_cam, pk.pose_cam); cp(points, pk.points); cp(edge_pose, pk.edge_pose);
   cp(edge_point, pk.edge_point); cp(edge_kind, pk.edge_kind); cp(edge_obs, pk.edge_obs); cp(edge_info, pk.edge_info);
@@ -300,7 +320,7 @@ extern "C" int osh_host_inertial_information(const float* cov225, double* info81
 // ------------------------------------------------------------------------------------------ matcher
 struct osh_host_frame {
   Frame F;
-  std::unique_ptr<Pinhole> cam;
+  std::unique_ptr<GeometricCamera> cam;
   Map map;
 };
 
@@ -331,6 +351,13 @@ extern "C" osh_host_frame* osh_host_frame_create(int32_t n, const float* kp_xy, 
   F.mvbOutlier.assign(n, false);
   F.AssignFeaturesToGrid();
   return f;
+}
+// Replace the frame's camera by a KannalaBrandt8 with the same fx fy cx cy and coefficients k[4] (monocular fisheye frame).
+extern "C" void osh_host_frame_set_fisheye(osh_host_frame* f, const float k[4]) {
+  if (!f) return;
+  f->cam.reset(new KannalaBrandt8(std::vector<float>{f->cam->getParameter(0), f->cam->getParameter(1), f->cam->getParameter(2),
+                                                     f->cam->getParameter(3), k[0], k[1], k[2], k[3]}));
+  f->F.mpCamera = f->cam.get();
 }
 extern "C" void osh_host_frame_destroy(osh_host_frame* f) { delete f; }
 

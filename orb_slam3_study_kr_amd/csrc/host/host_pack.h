@@ -3,6 +3,7 @@
 #include <cstdint>
 #include <list>
 #include <vector>
+#include "CameraModels/GeometricCamera.h"
 #include "KeyFrame.h"
 #include "Map.h"
 #include "MapPoint.h"
@@ -23,6 +24,34 @@ struct LbaPack {
   std::vector<uint8_t> edge_kind;
   bool has_kb8 = false;       // the keyframes' camera is a KannalaBrandt8 (monocular fisheye)
   double kb8[4] = {0, 0, 0, 0};
+  int n_pinhole_mono = 0;
+  // Camera of a monocular observation (the edge projects through pKF->mpCamera, src/Optimizer.cc:1323): the keyframe's own
+  // pinhole model, or one KannalaBrandt8 model shared by the whole window.  Anything else sets `unsupported`.
+  bool mono_camera(GeometricCamera* cam, float fx, float fy, float cx, float cy) {
+    if (!cam || cam->getParameter(0) != fx || cam->getParameter(1) != fy || cam->getParameter(2) != cx || cam->getParameter(3) != cy) {
+      unsupported = "monocular observation through a camera that is not the keyframe's own model";
+      return false;
+    }
+    if (cam->GetType() == GeometricCamera::CAM_PINHOLE) { ++n_pinhole_mono; }
+    else if (cam->GetType() == GeometricCamera::CAM_FISHEYE) {
+      double k[4];
+      for (int i = 0; i < 4; ++i) k[i] = cam->getParameter(4 + i);
+      if (has_kb8 && (k[0] != kb8[0] || k[1] != kb8[1] || k[2] != kb8[2] || k[3] != kb8[3])) {
+        unsupported = "keyframes with different KannalaBrandt8 coefficients in one window";
+        return false;
+      }
+      has_kb8 = true;
+      for (int i = 0; i < 4; ++i) kb8[i] = k[i];
+    } else { unsupported = "unknown camera model"; return false; }
+    if (has_kb8 && n_pinhole_mono > 0) { unsupported = "pinhole and KannalaBrandt8 monocular observations in one window"; return false; }
+    return true;
+  }
+  // a fisheye window is monocular on the device (no rectified-stereo edges next to KannalaBrandt8 ones)
+  bool camera_models_ok() {
+    if (has_kb8)
+      for (uint8_t k : edge_kind) if (k != OSH_EDGE_MONO) { unsupported = "rectified-stereo observation in a KannalaBrandt8 window"; return false; }
+    return true;
+  }
   void fill(osh_lba_problem& p) const {
     p.n_free = n_free; p.n_fixed = n_fixed; p.n_points = (int32_t)vPointMPs.size(); p.n_edges = (int32_t)edge_pose.size();
     p.pose_qt = pose_qt.data(); p.pose_cam = pose_cam.data(); p.points = points.data();

@@ -23,6 +23,8 @@ constexpr int kPT = 256;   // threads per frame block
 struct PoseDesc {
   int E, edge_off;
   double qt[7], cam[5], huber_mono, huber_stereo;
+  double kb8[4];   // KannalaBrandt8 k1..k4 (osh_pose_problem.kb8)
+  int kb8_on;      // 1: the frame's mono edges project through KannalaBrandt8
   float chi2_mono[4], chi2_stereo[4];
   int iters[4];
 };
@@ -50,7 +52,21 @@ __device__ __forceinline__ double pose_block_sum(double v, double* sh) {
   return t;
 }
 
+// edge residual / Jacobians through the frame's camera model; the pinhole instantiation carries no KannalaBrandt8 code
+template <bool KB8>
+__device__ __forceinline__ double pose_edge_residual(const PoseDesc& d, int kind, const double* qt, const double* X, const double* obs,
+                                                     double info, double* r, double* Xc) {
+  if (KB8 && d.kb8_on && kind == OSH_EDGE_MONO) return dev::edge_residual_kb8(qt, d.cam, d.kb8, X, obs, info, r, Xc);
+  return dev::edge_residual(kind, qt, d.cam, X, obs, info, r, Xc);
+}
+template <bool KB8>
+__device__ __forceinline__ void pose_edge_jacobians(const PoseDesc& d, int kind, const double* R, const double* Xc, double* JX, double* Jp) {
+  if (KB8 && d.kb8_on && kind == OSH_EDGE_MONO) { dev::edge_jacobians_kb8(R, d.cam, d.kb8, Xc, JX, Jp); return; }
+  dev::edge_jacobians(kind, R, d.cam, Xc, JX, Jp);
+}
+
 // computeActiveErrors + activeRobustChi2 at pose `qt` over the active edges; stores every edge's chi2
+template <bool KB8>
 __device__ double pose_eval(const PoseView& v, const PoseDesc& d, const double* qt, bool robust, double* sh) {
   double acc = 0.0;
   for (int e = threadIdx.x; e < d.E; e += kPT) {
@@ -60,7 +76,7 @@ __device__ double pose_eval(const PoseView& v, const PoseDesc& d, const double* 
     double X[3], obs[3], r[3], Xc[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) { X[k] = v.X[ge * 3 + k]; obs[k] = v.obs[ge * 3 + k]; }
-    const double c = dev::edge_residual(kind, qt, d.cam, X, obs, v.info[ge], r, Xc);
+    const double c = pose_edge_residual<KB8>(d, kind, qt, X, obs, v.info[ge], r, Xc);
     v.chi2[ge] = c;
     if (robust) {
       double r0, r1;
@@ -71,6 +87,7 @@ __device__ double pose_eval(const PoseView& v, const PoseDesc& d, const double* 
   return pose_block_sum(acc, sh);
 }
 
+template <bool KB8>
 __global__ __launch_bounds__(kPT) void k_pose_opt(PoseView v) {
   __shared__ double sh[kPT / 64];
   __shared__ double shH[28];          // upper(Hpp) (21), b (6), spare
@@ -107,7 +124,7 @@ __global__ __launch_bounds__(kPT) void k_pose_opt(PoseView v) {
       double qt[7];
 #pragma unroll
       for (int k = 0; k < 7; ++k) qt[k] = sh_qt[sel][k];
-      double currentChi = pose_eval(v, d, qt, robust, sh);
+      double currentChi = pose_eval<KB8>(v, d, qt, robust, sh);
       const double iniChi = currentChi;
       // ---- buildSystem: Hpp += Jp^T W Jp, b += Jp^T (-rho' Omega r) over the active edges
       double H[21], b[6];
@@ -125,11 +142,11 @@ __global__ __launch_bounds__(kPT) void k_pose_opt(PoseView v) {
         double X[3], obs[3], r[3], Xc[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) { X[k] = v.X[ge * 3 + k]; obs[k] = v.obs[ge * 3 + k]; }
-        const double c = dev::edge_residual(kind, qt, d.cam, X, obs, info, r, Xc);
+        const double c = pose_edge_residual<KB8>(d, kind, qt, X, obs, info, r, Xc);
         double r0 = c, r1 = 1.0;
         if (robust) dev::huber(c, kind == OSH_EDGE_MONO ? d.huber_mono : d.huber_stereo, r0, r1);
         double JX[9], Jp[18];
-        dev::edge_jacobians(kind, R, d.cam, Xc, JX, Jp);
+        pose_edge_jacobians<KB8>(d, kind, R, Xc, JX, Jp);
         const double ww = r1 * info;
         const double wr[3] = {-(info * r[0]) * r1, -(info * r[1]) * r1, -(info * r[2]) * r1};
         int m = 0;
@@ -188,7 +205,7 @@ __global__ __launch_bounds__(kPT) void k_pose_opt(PoseView v) {
         double qtr[7];
 #pragma unroll
         for (int k = 0; k < 7; ++k) qtr[k] = sh_qt[trs][k];
-        double tempChi = pose_eval(v, d, qtr, robust, sh);
+        double tempChi = pose_eval<KB8>(v, d, qtr, robust, sh);
         if (!sh_ok) tempChi = DBL_MAX;
         rho = currentChi - tempChi;
         double scale = 0.0;
@@ -227,7 +244,7 @@ __global__ __launch_bounds__(kPT) void k_pose_opt(PoseView v) {
         double X[3], obs[3], r[3], Xc[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) { X[k] = v.X[ge * 3 + k]; obs[k] = v.obs[ge * 3 + k]; }
-        v.chi2[ge] = dev::edge_residual(kind, qf, d.cam, X, obs, v.info[ge], r, Xc);
+        v.chi2[ge] = pose_edge_residual<KB8>(d, kind, qf, X, obs, v.info[ge], r, Xc);
       }
       const float chi2 = (float)v.chi2[ge];
       const float th = kind == OSH_EDGE_MONO ? d.chi2_mono[round] : d.chi2_stereo[round];
@@ -266,6 +283,7 @@ extern "C" int osh_pose_optimize(osh_lba_ctx* ctx, int32_t n, const osh_pose_pro
   OSH_HIP(hipSetDevice(device));
   std::vector<PoseDesc> h_desc(n);
   size_t NE = 0;
+  bool any_kb8 = false;
   for (int f = 0; f < n; ++f) {
     const osh_pose_problem& p = pr[f];
     if (p.n_edges < 0 || !p.pose_qt || !p.cam || (p.n_edges > 0 && (!p.points || !p.edge_kind || !p.edge_obs || !p.edge_info))) {
@@ -276,6 +294,13 @@ extern "C" int osh_pose_optimize(osh_lba_ctx* ctx, int32_t n, const osh_pose_pro
     for (int k = 0; k < 7; ++k) d.qt[k] = p.pose_qt[k];
     for (int k = 0; k < 5; ++k) d.cam[k] = p.cam[k];
     d.huber_mono = p.huber_mono; d.huber_stereo = p.huber_stereo;
+    d.kb8_on = p.kb8 ? 1 : 0;
+    for (int k = 0; k < 4; ++k) d.kb8[k] = p.kb8 ? p.kb8[k] : 0.0;
+    if (p.kb8) {
+      any_kb8 = true;
+      for (int e = 0; e < p.n_edges; ++e)
+        if (p.edge_kind[e] != OSH_EDGE_MONO) { set_error("frame %d: a KannalaBrandt8 frame takes monocular edges only (edge %d)", f, e); return OSH_ERR_UNSUPPORTED; }
+    }
     for (int k = 0; k < 4; ++k) { d.chi2_mono[k] = p.chi2_mono[k]; d.chi2_stereo[k] = p.chi2_stereo[k]; d.iters[k] = p.iterations[k]; }
     for (int e = 0; e < p.n_edges; ++e) if (p.edge_kind[e] > OSH_EDGE_STEREO) { set_error("frame %d edge %d: kind out of range", f, e); return OSH_ERR_INVALID; }
     NE += (size_t)p.n_edges;
@@ -305,7 +330,8 @@ extern "C" int osh_pose_optimize(osh_lba_ctx* ctx, int32_t n, const osh_pose_pro
   PoseView v;
   v.desc = B.desc.as<PoseDesc>(); v.out = B.out.as<PoseOut>(); v.X = B.X.as<double>(); v.kind = B.kind.as<unsigned char>();
   v.obs = B.obs.as<double>(); v.info = B.info.as<double>(); v.chi2 = B.chi2.as<double>(); v.level = B.level.as<unsigned char>();
-  hipLaunchKernelGGL(k_pose_opt, dim3((unsigned)n), dim3(kPT), 0, s, v);
+  if (any_kb8) hipLaunchKernelGGL(k_pose_opt<true>, dim3((unsigned)n), dim3(kPT), 0, s, v);
+  else hipLaunchKernelGGL(k_pose_opt<false>, dim3((unsigned)n), dim3(kPT), 0, s, v);
   { hipError_t e = hipGetLastError(); if (e != hipSuccess) { set_error("kernel launch k_pose_opt failed: %s", hipGetErrorString(e)); return OSH_ERR_DEVICE; } }
   std::vector<PoseOut> h_out(n);
   std::vector<unsigned char> h_level(NE + 1);

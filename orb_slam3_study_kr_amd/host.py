@@ -50,6 +50,8 @@ class HostGraph:
             capi.ptr(mp_pos, capi.c_float_p), w.n_edges, capi.ptr(_i32(w.edge_pose), capi.c_int32_p),
             capi.ptr(_i32(w.edge_point), capi.c_int32_p), capi.ptr(obs, capi.c_float_p), capi.ptr(octave, capi.c_int32_p),
             init_id, int(inertial)))
+        if w.kb8 is not None:     # monocular fisheye map: every keyframe's mpCamera is one KannalaBrandt8
+            self.lib.osh_host_graph_set_fisheye(self.g, capi.ptr(_f32(w.kb8), capi.c_float_p))
         self.cur = P - 1
         cov = _i32([i for i in range(P) if i != self.cur])
         self.lib.osh_host_graph_set_covisible(self.g, self.cur, len(cov), capi.ptr(cov, capi.c_int32_p))
@@ -92,7 +94,11 @@ class HostGraph:
         assert rc == 0, rc
         return LbaWindow(n_free=int(sizes[0]), n_fixed=int(sizes[1]), pose_qt=o["pose_qt"], pose_cam=o["pose_cam"], points=o["points"],
                          edge_pose=o["edge_pose"], edge_point=o["edge_point"], edge_kind=o["edge_kind"], edge_obs=o["edge_obs"],
-                         edge_info=o["edge_info"], lambda_init=0.0, max_iterations=10).normalise(), o
+                         edge_info=o["edge_info"], lambda_init=0.0, max_iterations=10, kb8=self._last_kb8()).normalise(), o
+
+    def _last_kb8(self):
+        k = np.zeros(4)
+        return k if self.lib.osh_host_last_pack_kb8(self.g, capi.ptr(k, capi.c_double_p)) else None
 
     def run_lba(self, stop_flag: np.ndarray | None = None):
         counts = np.zeros(4, dtype=np.int32)
@@ -120,7 +126,7 @@ class HostGraph:
         assert rc == 0, rc
         w = LbaWindow(n_free=P, n_fixed=F, pose_qt=o["pose_qt"], pose_cam=o["pose_cam"], points=o["points"],
                       edge_pose=o["edge_pose"], edge_point=o["edge_point"], edge_kind=o["edge_kind"], edge_obs=o["edge_obs"],
-                      edge_info=o["edge_info"], lambda_init=0.0, max_iterations=max_iterations).normalise()
+                      edge_info=o["edge_info"], lambda_init=0.0, max_iterations=max_iterations, kb8=self._last_kb8()).normalise()
         # const float thHuber2D = sqrt(5.99), thHuber3D = sqrt(7.815) (src/Optimizer.cc:130-131); none unless bRobust
         w.huber_mono = float(np.float32(np.sqrt(5.99))) if robust else float("inf")
         w.huber_stereo = float(np.float32(np.sqrt(7.815))) if robust else float("inf")
@@ -151,7 +157,7 @@ class HostGraph:
         assert rc == 0, rc
         w = LbaWindow(n_free=P, n_fixed=F, pose_qt=o["pose_qt"], pose_cam=o["pose_cam"], points=o["points"],
                       edge_pose=o["edge_pose"], edge_point=o["edge_point"], edge_kind=o["edge_kind"], edge_obs=o["edge_obs"],
-                      edge_info=o["edge_info"], lambda_init=0.0, max_iterations=5).normalise()
+                      edge_info=o["edge_info"], lambda_init=0.0, max_iterations=5, kb8=self._last_kb8()).normalise()
         w.huber_mono = float(np.float32(np.sqrt(5.99)))      # const float thHuber2D = sqrt(5.99) (src/Optimizer.cc:3625)
         w.huber_stereo = float(np.float32(np.sqrt(7.815)))
         return w, o
@@ -184,7 +190,7 @@ class HostGraph:
 
 
 class HostFrame:
-    def __init__(self, xy, octave, desc, angle=None, uright=None, pose_qt=None, mbf=float(synth.BF), mb=0.110078):
+    def __init__(self, xy, octave, desc, angle=None, uright=None, pose_qt=None, mbf=float(synth.BF), mb=0.110078, kb8=None):
         self.lib = capi.load_library()
         n = len(octave)
         self.n = n
@@ -198,6 +204,8 @@ class HostFrame:
             capi.ptr(u, capi.c_float_p) if u is not None else C.cast(None, capi.c_float_p),
             capi.ptr(np.ascontiguousarray(desc, dtype=np.uint8), capi.c_uint8_p), capi.ptr(pose, capi.c_float_p),
             capi.ptr(cam4, capi.c_float_p), mbf, mb, synth.N_LEVELS, np.float32(synth.SCALE_FACTOR)))
+        if kb8 is not None:      # monocular fisheye frame: mpCamera is a KannalaBrandt8
+            self.lib.osh_host_frame_set_fisheye(self.f, capi.ptr(_f32(kb8), capi.c_float_p))
 
     def close(self):
         if self.f:

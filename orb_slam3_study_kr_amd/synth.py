@@ -408,6 +408,7 @@ class PoseFrame:
     chi2_mono: tuple = (5.991, 5.991, 5.991, 5.991)
     chi2_stereo: tuple = (7.815, 7.815, 7.815, 7.815)
     iterations: tuple = (10, 10, 10, 10)
+    kb8: np.ndarray | None = None   # [4] KannalaBrandt8 k1..k4: mono edges project through the fisheye model
 
     @property
     def n_edges(self) -> int:
@@ -436,6 +437,9 @@ class PoseFrame:
             p.chi2_mono[k] = self.chi2_mono[k]
             p.chi2_stereo[k] = self.chi2_stereo[k]
             p.iterations[k] = self.iterations[k]
+        if self.kb8 is not None:
+            self.kb8 = np.ascontiguousarray(self.kb8, dtype=np.float64)
+        p.kb8 = capi.ptr(self.kb8, capi.c_double_p)
         return p
 
 
@@ -459,7 +463,7 @@ class PoseResultArrays:
 
 
 def make_pose_frame(seed: int = 21, n_points: int = 800, stereo: bool = True, mixed_mono_frac: float = 0.3, outlier_frac: float = 0.1,
-                    pose_noise=(0.01, 0.05)) -> PoseFrame:
+                    pose_noise=(0.01, 0.05), fisheye: bool = False) -> PoseFrame:
     """A tracked frame: map points in front of the camera, pixel noise by pyramid level, gross outliers (wrong matches),
     the initial pose = ground truth + perturbation, everything the reference stores as float rounded to float32."""
     rng = np.random.Generator(np.random.PCG64(seed))
@@ -467,9 +471,17 @@ def make_pose_frame(seed: int = 21, n_points: int = 800, stereo: bool = True, mi
     Rcw = _rodrigues(np.array([0.02, yaw, -0.01]))
     tcw = np.array([0.3, -0.1, 0.2])
     Xc = np.stack([rng.uniform(-4, 4, n_points), rng.uniform(-2.5, 2.5, n_points), rng.uniform(3, 14, n_points)], axis=1)
-    u = float(FX) * Xc[:, 0] / Xc[:, 2] + float(CX)
-    v = float(FY) * Xc[:, 1] / Xc[:, 2] + float(CY)
-    vis = (u >= 0) & (u < IMG_W) & (v >= 0) & (v < IMG_H) & ((u - float(BF) / Xc[:, 2]) >= 0)
+    if fisheye:      # monocular KannalaBrandt8 camera (KB8_K), same fx fy cx cy
+        assert not stereo, "the fisheye frame is monocular"
+        theta = np.arctan2(np.hypot(Xc[:, 0], Xc[:, 1]), Xc[:, 2])
+        psi = np.arctan2(Xc[:, 1], Xc[:, 0])
+        rr = theta + KB8_K[0] * theta**3 + KB8_K[1] * theta**5 + KB8_K[2] * theta**7 + KB8_K[3] * theta**9
+        u = float(FX) * rr * np.cos(psi) + float(CX)
+        v = float(FY) * rr * np.sin(psi) + float(CY)
+    else:
+        u = float(FX) * Xc[:, 0] / Xc[:, 2] + float(CX)
+        v = float(FY) * Xc[:, 1] / Xc[:, 2] + float(CY)
+    vis = (u >= 0) & (u < IMG_W) & (v >= 0) & (v < IMG_H) & (fisheye | ((u - float(BF) / Xc[:, 2]) >= 0))
     Xc, u, v = Xc[vis], u[vis], v[vis]
     E = Xc.shape[0]
     Xw = (Xc - tcw) @ Rcw                              # Rcw^T (Xc - tcw)
@@ -487,4 +499,5 @@ def make_pose_frame(seed: int = 21, n_points: int = 800, stereo: bool = True, mi
     init = np.concatenate([_quat_from_R(dR @ Rcw), tcw + rng.standard_normal(3) * pose_noise[1]])
     cam = np.array([FX, FY, CX, CY, BF], dtype=np.float32).astype(np.float64)
     return PoseFrame(pose_qt=_f32(init), cam=cam, points=_f32(Xw), edge_kind=kind, edge_obs=_f32(obs),
-                     edge_info=INV_LEVEL_SIGMA2[octave].astype(np.float64), gt_pose_qt=gt, outlier_mask=is_out).normalise()
+                     edge_info=INV_LEVEL_SIGMA2[octave].astype(np.float64), gt_pose_qt=gt, outlier_mask=is_out,
+                     kb8=KB8_K.copy() if fisheye else None).normalise()

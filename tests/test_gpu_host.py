@@ -390,10 +390,13 @@ def test_search_by_projection_sim3_equals_sequential_reference(ob, with_keyframe
     assert side.any() and bad.any()
 
 
-def test_pose_optimization_through_the_reference_signature(ob):
+@pytest.mark.parametrize("fisheye", [False, True])
+def test_pose_optimization_through_the_reference_signature(ob, fisheye):
     """Optimizer::PoseOptimization(Frame*) (src/Optimizer.cc:815-1114) on a Frame whose keypoints hold map points: the returned
-    inlier count, mvbOutlier and the float32 pose against the oracle run on the same flat problem."""
-    f = synth.make_pose_frame(51, n_points=900, mixed_mono_frac=0.4, outlier_frac=0.15)
+    inlier count, mvbOutlier and the float32 pose against the oracle run on the same flat problem.  fisheye: the frame's
+    mpCamera is a KannalaBrandt8 (monocular)."""
+    f = (synth.make_pose_frame(52, n_points=900, stereo=False, outlier_frac=0.15, fisheye=True) if fisheye else
+         synth.make_pose_frame(51, n_points=900, mixed_mono_frac=0.4, outlier_frac=0.15))
     E = f.n_edges
     rng = np.random.Generator(np.random.PCG64(51))
     n_kp = E + 40                                            # a few keypoints without a map point
@@ -407,7 +410,7 @@ def test_pose_optimization_through_the_reference_signature(ob):
     kp_mp = -np.ones(n_kp, dtype=np.int32)
     kp_mp[kp_of_edge] = np.arange(E)
     desc = np.zeros((n_kp, 32), dtype=np.uint8)
-    frame = host.HostFrame(xy, octave, desc, uright=uright, pose_qt=f.pose_qt)
+    frame = host.HostFrame(xy, octave, desc, uright=uright, pose_qt=f.pose_qt, kb8=f.kb8)
     try:
         n_in, pose, outlier = frame.pose_optimization(kp_mp, f.points)
     finally:
@@ -506,3 +509,23 @@ def test_search_local_points_projected_on_device(ob):
         f.close()
     assert out["n_matches"] == n2 and n2 > 100
     np.testing.assert_array_equal(out["assignment"], np.where(assign2 >= 0, sub[np.maximum(assign2, 0)], -1))
+
+
+def test_local_and_global_bundle_adjustment_fisheye_map(ob):
+    """A monocular map whose keyframes share one KannalaBrandt8 camera (TUM-VI style): the packers recognise the model
+    (GeometricCamera::GetType() == CAM_FISHEYE), hand k1..k4 to the device and the results equal the oracle's."""
+    w = synth.make_window(51, n_free=8, n_fixed=3, n_points=700, stereo=False, track_len=(3, 8), fisheye=True)
+    with host.HostGraph(w) as g:
+        pw, _ = g.packed_window()
+        assert pw.kb8 is not None and np.array_equal(pw.kb8, np.float32(w.kb8).astype(np.float64))
+    _run_and_check(w, ob)
+    with host.HostGraph(w, init_kf_id_index=w.n_free) as g:      # the origin keyframe is one of the old observers
+        pw, o, ref = _gba_reference(g, ob, 5, True)
+        assert pw.kb8 is not None
+        g.run_gba(5, n_loop_kf=7, robust=True)
+        kf_index = {int(i): k for k, i in enumerate(g.kf_id)}
+        marks, poses = zip(*[g.kf_pose_gba(kf_index[int(i)]) for i in o["pose_kf_id"][:pw.n_free]])
+        assert set(marks) == {7}
+        got_qt = np.stack(poses).astype(np.float64)
+        assert rel_translation_error(got_qt, ref.pose_qt) < 2e-6
+        assert rotation_error(got_qt, ref.pose_qt) < 2e-6

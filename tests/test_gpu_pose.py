@@ -41,6 +41,7 @@ def _check(got, ref, f):
 @pytest.mark.parametrize("kw", [
     dict(seed=21), dict(seed=24, stereo=False, mixed_mono_frac=0.0), dict(seed=25, mixed_mono_frac=0.5, outlier_frac=0.3),
     dict(seed=26, n_points=60, outlier_frac=0.0), dict(seed=27, n_points=3000),
+    dict(seed=28, stereo=False, fisheye=True), dict(seed=29, stereo=False, fisheye=True, n_points=150, outlier_frac=0.3),
 ])
 def test_pose_optimisation_matches_oracle(solver, ob, kw):
     f = synth.make_pose_frame(**kw)
@@ -60,3 +61,15 @@ def test_batch_of_frames_equals_single_calls_and_small_frames(solver, ob):
     again = solver.optimize_poses(frames)
     for g, a in zip(got, again):
         np.testing.assert_array_equal(g.pose_qt, a.pose_qt)          # fixed-order reductions: bitwise reproducible
+
+
+def test_fisheye_and_pinhole_frames_in_one_batch(solver, ob):
+    """A batch mixing KannalaBrandt8 and pinhole frames runs the fisheye instantiation; every frame equals its single solve."""
+    frames = [synth.make_pose_frame(60, n_points=300), synth.make_pose_frame(61, n_points=400, stereo=False, fisheye=True),
+              synth.make_pose_frame(62, n_points=250, stereo=False, mixed_mono_frac=0.0)]
+    for f, g in zip(frames, solver.optimize_poses(frames)):
+        _check(g, ob.pose_optimize(f), f)
+    bad = synth.make_pose_frame(63, n_points=100, stereo=False, fisheye=True)
+    bad.edge_kind[0] = 1
+    with pytest.raises(RuntimeError, match="KannalaBrandt8"):
+        solver.optimize_poses([bad])
