@@ -258,6 +258,7 @@ typedef struct osh_liba_problem {
   double huber_mono, huber_stereo, huber_inertial;
   double lambda_init;       /* 1e0, or 1e-2 when bLarge (:2517-2528)                                          */
   int32_t max_iterations;   /* opt_it: 10, or 4 when bLarge                                                   */
+  const double* kb8;        /* NULL: pinhole.  [4] k1..k4: the window's camera is a KannalaBrandt8, mono edges only (as osh_lba_problem.kb8) */
 } osh_liba_problem;
 
 typedef struct osh_liba_result {

@@ -328,10 +328,8 @@ static double edge_chi2(const ostate* s, int e) {
  * differs from it only in rare 1-ulp cases. */
 static float atan2f_rn(float y, float x) { return (float)atan2((double)y, (double)x); }
 
-void oracle_edge_error_kb8(const double qt[7], const double cam[5], const double kb[4],
-                           const double X[3], const double obs[3], double err[3]) {
-  double Xc[3];
-  se3_map(qt, X, Xc);
+/* KannalaBrandt8::project(Vector3d), src/CameraModels/KannalaBrandt8.cpp:45-63 */
+void oracle_kb8_project(const double cam[5], const double kb[4], const double Xc[3], double uv[2]) {
   const double x2_plus_y2 = Xc[0] * Xc[0] + Xc[1] * Xc[1];
   const double theta = atan2f_rn(sqrtf((float)x2_plus_y2), (float)Xc[2]);
   const double psi = atan2f_rn((float)Xc[1], (float)Xc[0]);
@@ -341,19 +339,13 @@ void oracle_edge_error_kb8(const double qt[7], const double cam[5], const double
   const double theta7 = theta5 * theta2;
   const double theta9 = theta7 * theta2;
   const double r = theta + kb[0] * theta3 + kb[1] * theta5 + kb[2] * theta7 + kb[3] * theta9;
-  err[0] = obs[0] - (cam[0] * r * cos(psi) + cam[2]);
-  err[1] = obs[1] - (cam[1] * r * sin(psi) + cam[3]);
-  err[2] = 0.0;
+  uv[0] = cam[0] * r * cos(psi) + cam[2];
+  uv[1] = cam[1] * r * sin(psi) + cam[3];
 }
 
-void oracle_edge_jacobians_kb8(const double qt[7], const double cam[5], const double kb[4],
-                               const double X[3], double Jxi[9], double Jxj[18]) {
-  double Xc[3], R[9];
-  se3_map(qt, X, Xc);
-  quat_to_R(qt, R);
+/* KannalaBrandt8::projectJac, src/CameraModels/KannalaBrandt8.cpp:147-175; J row-major 2x3 */
+void oracle_kb8_project_jac(const double cam[5], const double kb[4], const double Xc[3], double J[6]) {
   const double x = Xc[0], y = Xc[1], z = Xc[2];
-  memset(Jxi, 0, 9 * sizeof(double));
-  memset(Jxj, 0, 18 * sizeof(double));
   const double x2 = x * x, y2 = y * y, z2 = z * z;
   const double r2 = x2 + y2;
   const double r = sqrt(r2);
@@ -365,13 +357,33 @@ void oracle_edge_jacobians_kb8(const double qt[7], const double cam[5], const do
   const double theta8 = theta4 * theta4, theta9 = theta8 * theta;
   const double f = theta + theta3 * kb[0] + theta5 * kb[1] + theta7 * kb[2] + theta9 * kb[3];
   const double fd = 1 + 3 * kb[0] * theta2 + 5 * kb[1] * theta4 + 7 * kb[2] * theta6 + 9 * kb[3] * theta8;
-  double J[6];
   J[0] = cam[0] * (fd * z * x2 / (r2 * (r2 + z2)) + f * y2 / r3);
   J[3] = cam[1] * (fd * z * y * x / (r2 * (r2 + z2)) - f * y * x / r3);
   J[1] = cam[0] * (fd * z * y * x / (r2 * (r2 + z2)) - f * y * x / r3);
   J[4] = cam[1] * (fd * z * y2 / (r2 * (r2 + z2)) + f * x2 / r3);
   J[2] = -cam[0] * fd * x / (r2 + z2);
   J[5] = -cam[1] * fd * y / (r2 + z2);
+}
+
+void oracle_edge_error_kb8(const double qt[7], const double cam[5], const double kb[4],
+                           const double X[3], const double obs[3], double err[3]) {
+  double Xc[3], uv[2];
+  se3_map(qt, X, Xc);
+  oracle_kb8_project(cam, kb, Xc, uv);
+  err[0] = obs[0] - uv[0];
+  err[1] = obs[1] - uv[1];
+  err[2] = 0.0;
+}
+
+void oracle_edge_jacobians_kb8(const double qt[7], const double cam[5], const double kb[4],
+                               const double X[3], double Jxi[9], double Jxj[18]) {
+  double Xc[3], R[9], J[6];
+  se3_map(qt, X, Xc);
+  quat_to_R(qt, R);
+  const double x = Xc[0], y = Xc[1], z = Xc[2];
+  memset(Jxi, 0, 9 * sizeof(double));
+  memset(Jxj, 0, 18 * sizeof(double));
+  oracle_kb8_project_jac(cam, kb, Xc, J);
   double pj[6];
   for (int k = 0; k < 6; ++k) pj[k] = -J[k];
   for (int i = 0; i < 2; ++i)

@@ -214,7 +214,12 @@ static void vis_error(const istate* s, int e, double* r) {
   double Xc[3];
   m3_vec(s->Rcw + 9 * k, s->X + 3 * l, Xc);
   for (int i = 0; i < 3; ++i) Xc[i] += s->tcw[3 * k + i];
-  const double u = p->cam[0] * Xc[0] / Xc[2] + p->cam[2], v = p->cam[1] * Xc[1] / Xc[2] + p->cam[3];
+  double u = p->cam[0] * Xc[0] / Xc[2] + p->cam[2], v = p->cam[1] * Xc[1] / Xc[2] + p->cam[3];
+  if (p->kb8) {   /* ImuCamPose::Project -> pCamera->project (src/G2oTypes.cc:166-171) through KannalaBrandt8 */
+    double uv[2];
+    oracle_kb8_project(p->cam, p->kb8, Xc, uv);
+    u = uv[0]; v = uv[1];
+  }
   r[0] = p->edge_obs[3 * e] - u;
   r[1] = p->edge_obs[3 * e + 1] - v;
   r[2] = 0;
@@ -245,6 +250,7 @@ static void vis_jac(const istate* s, int e, double* JX, double* Jp) {
   if (p->edge_kind[e] == OSH_EDGE_STEREO) {
     pj[6] = pj[0]; pj[7] = pj[1]; pj[8] = pj[2] + p->cam[4] * (1.0 / (Xc[2] * Xc[2]));
   }
+  if (p->kb8) oracle_kb8_project_jac(p->cam, p->kb8, Xc, pj);   /* pCamera->projectJac (src/G2oTypes.cc:359); monocular window */
   double M[9];
   m3_mul(pj, s->Rcw + 9 * k, M);
   for (int i = 0; i < 9; ++i) JX[i] = -M[i];

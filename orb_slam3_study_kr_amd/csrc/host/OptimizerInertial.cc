@@ -224,6 +224,18 @@ bool PackLocalInertialBA(KeyFrame* pKF, Map* pMap, bool bLarge, bool bRecInit, L
         const cv::KeyPoint& kpUn = pKFi->mvKeysUn[leftIndex];
         const float kp_ur = pKFi->mvuRight[leftIndex];
         const bool stereo = !(kp_ur < 0);
+        if (!stereo && pKFi->mpCamera && pKFi->mpCamera->GetType() == GeometricCamera::CAM_FISHEYE) {
+          // EdgeMono projects through pKFi->mpCamera (ImuCamPose::Project, src/G2oTypes.cc:166-171): one KannalaBrandt8 per window
+          GeometricCamera* c = pKFi->mpCamera;
+          if (c->getParameter(0) != pKF->fx || c->getParameter(1) != pKF->fy || c->getParameter(2) != pKF->cx || c->getParameter(3) != pKF->cy) {
+            pk.unsupported = "monocular observation through a camera that is not the window's own model"; return true;
+          }
+          for (int k = 0; k < 4; ++k) {
+            if (pk.has_kb8 && pk.kb8[k] != (double)c->getParameter(4 + k)) { pk.unsupported = "keyframes with different KannalaBrandt8 coefficients"; return true; }
+            pk.kb8[k] = c->getParameter(4 + k);
+          }
+          pk.has_kb8 = true;
+        }
         Eigen::Matrix<double, 2, 1> obs2(kpUn.pt.x, kpUn.pt.y);
         const float unc2 = pKFi->mpCamera->uncertainty2(obs2);
         const float invSigma2 = pKFi->mvInvLevelSigma2[kpUn.octave] / unc2;   // :2741, float division
@@ -238,6 +250,8 @@ bool PackLocalInertialBA(KeyFrame* pKF, Map* pMap, bool bLarge, bool bRecInit, L
       if (pKFi->mpCamera2 && std::get<1>(ob.second) != -1) { pk.unsupported = "right-camera (fisheye stereo) observation"; return true; }
     }
   }
+  if (pk.has_kb8)
+    for (uint8_t k : pk.edge_kind) if (k != OSH_EDGE_MONO) { pk.unsupported = "rectified-stereo observation in a KannalaBrandt8 window"; return true; }
   return true;
 }
 

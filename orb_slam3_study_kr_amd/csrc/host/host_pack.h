@@ -73,6 +73,8 @@ struct LibaPack {
   const char* unsupported = nullptr;
   std::vector<double> pose_Rcw, pose_tcw, pose_Rwb, pose_twb, vel, bias_g, bias_a, points, edge_obs, edge_info, link_info, link_info_g, link_info_a;
   double Rcb[9], tcb[3], tbc[3], cam[5];
+  bool has_kb8 = false;       // the window's camera is a KannalaBrandt8 (monocular fisheye)
+  double kb8[4] = {0, 0, 0, 0};
   std::vector<int32_t> edge_pose, edge_point, link_prev, link_cur;
   std::vector<uint8_t> edge_kind, link_robust;
   std::vector<float> link_preint;
@@ -86,6 +88,7 @@ struct LibaPack {
     p.link_preint = link_preint.data(); p.link_info = link_info.data(); p.link_info_g = link_info_g.data(); p.link_info_a = link_info_a.data();
     p.link_robust = link_robust.data();
     p.huber_mono = p.huber_stereo = p.huber_inertial = 0; p.lambda_init = 1.0; p.max_iterations = opt_it;
+    p.kb8 = has_kb8 ? kb8 : nullptr;
   }
 };
 bool PackLocalInertialBA(KeyFrame* pKF, Map* pMap, bool bLarge, bool bRecInit, LibaPack& pk);

@@ -227,25 +227,19 @@ __device__ __forceinline__ void edge_jacobians(int kind, const double* R, const 
 __device__ __forceinline__ float atan2f_rn(float y, float x) { return (float)atan2((double)y, (double)x); }
 __device__ __forceinline__ float sqrtf_rn(float x) { return (float)sqrt((double)x); }
 
-__device__ __forceinline__ double edge_residual_kb8(const double* qt, const double* cam, const double* kb, const double* X,
-                                                    const double* obs, double info, double* r, double* Xc) {
-  double rot[3];
-  quat_rotate(qt, X, rot);
-  Xc[0] = rot[0] + qt[4]; Xc[1] = rot[1] + qt[5]; Xc[2] = rot[2] + qt[6];
+// KannalaBrandt8::project(Vector3d) (src/CameraModels/KannalaBrandt8.cpp:45-63)
+__device__ __forceinline__ void kb8_project(const double* cam, const double* kb, const double* Xc, double& u, double& v) {
   const double x2_plus_y2 = Xc[0] * Xc[0] + Xc[1] * Xc[1];
   const double theta = (double)atan2f_rn(sqrtf_rn((float)x2_plus_y2), (float)Xc[2]);
   const double psi = (double)atan2f_rn((float)Xc[1], (float)Xc[0]);
   const double theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2,
                theta9 = theta7 * theta2;
   const double rr = theta + kb[0] * theta3 + kb[1] * theta5 + kb[2] * theta7 + kb[3] * theta9;
-  r[0] = obs[0] - (cam[0] * rr * cos(psi) + cam[2]);
-  r[1] = obs[1] - (cam[1] * rr * sin(psi) + cam[3]);
-  r[2] = 0.0;
-  return r[0] * (info * r[0]) + r[1] * (info * r[1]);
+  u = cam[0] * rr * cos(psi) + cam[2];
+  v = cam[1] * rr * sin(psi) + cam[3];
 }
-
-__device__ __forceinline__ void edge_jacobians_kb8(const double* R, const double* cam, const double* kb, const double* Xc,
-                                                   double* JX, double* Jp) {
+// KannalaBrandt8::projectJac (src/CameraModels/KannalaBrandt8.cpp:147-175): J row-major 2x3
+__device__ __forceinline__ void kb8_project_jac(const double* cam, const double* kb, const double* Xc, double* J) {
   const double x = Xc[0], y = Xc[1], z = Xc[2];
   const double x2 = x * x, y2 = y * y, z2 = z * z;
   const double r2 = x2 + y2, rr = sqrt(r2), r3 = r2 * rr;
@@ -255,14 +249,35 @@ __device__ __forceinline__ void edge_jacobians_kb8(const double* R, const double
   const double f = theta + theta3 * kb[0] + theta5 * kb[1] + theta7 * kb[2] + theta9 * kb[3];
   const double fd = 1 + 3 * kb[0] * theta2 + 5 * kb[1] * theta4 + 7 * kb[2] * theta6 + 9 * kb[3] * theta8;
   const double den = r2 * (r2 + z2);
+  J[0] = cam[0] * (fd * z * x2 / den + f * y2 / r3);
+  J[3] = cam[1] * (fd * z * y * x / den - f * y * x / r3);
+  J[1] = cam[0] * (fd * z * y * x / den - f * y * x / r3);
+  J[4] = cam[1] * (fd * z * y2 / den + f * x2 / r3);
+  J[2] = -cam[0] * fd * x / (r2 + z2);
+  J[5] = -cam[1] * fd * y / (r2 + z2);
+}
+
+__device__ __forceinline__ double edge_residual_kb8(const double* qt, const double* cam, const double* kb, const double* X,
+                                                    const double* obs, double info, double* r, double* Xc) {
+  double rot[3];
+  quat_rotate(qt, X, rot);
+  Xc[0] = rot[0] + qt[4]; Xc[1] = rot[1] + qt[5]; Xc[2] = rot[2] + qt[6];
+  double u, v;
+  kb8_project(cam, kb, Xc, u, v);
+  r[0] = obs[0] - u;
+  r[1] = obs[1] - v;
+  r[2] = 0.0;
+  return r[0] * (info * r[0]) + r[1] * (info * r[1]);
+}
+
+__device__ __forceinline__ void edge_jacobians_kb8(const double* R, const double* cam, const double* kb, const double* Xc,
+                                                   double* JX, double* Jp) {
+  const double x = Xc[0], y = Xc[1], z = Xc[2];
   // Pm = -projectJac(Xc)  (src/OptimizableTypes.cpp:146)
   double Pm[6];
-  Pm[0] = -(cam[0] * (fd * z * x2 / den + f * y2 / r3));
-  Pm[3] = -(cam[1] * (fd * z * y * x / den - f * y * x / r3));
-  Pm[1] = -(cam[0] * (fd * z * y * x / den - f * y * x / r3));
-  Pm[4] = -(cam[1] * (fd * z * y2 / den + f * x2 / r3));
-  Pm[2] = -(-cam[0] * fd * x / (r2 + z2));
-  Pm[5] = -(-cam[1] * fd * y / (r2 + z2));
+  kb8_project_jac(cam, kb, Xc, Pm);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) Pm[k] = -Pm[k];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll

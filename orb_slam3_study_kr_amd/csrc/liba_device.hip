@@ -37,6 +37,8 @@ struct LibaDesc {
   long long H_off;       // n*n doubles (H and S use the same offset in their own arrays)
   int b_off;             // n doubles
   double Rcb[9], tcb[3], tbc[3], cam[5];
+  double kb8[4];   // KannalaBrandt8 k1..k4 (osh_liba_problem.kb8)
+  int kb8_on;      // 1: mono edges project through KannalaBrandt8
   double huber_mono, huber_stereo, huber_inertial, lambda_init;
 };
 
@@ -94,7 +96,9 @@ __device__ __forceinline__ void vis_residual(const LibaDesc& d, int kind, const 
                                              double info, VisEval& o) {
   imu::m3_vec(pose, X, o.Xc);
   o.Xc[0] += pose[9]; o.Xc[1] += pose[10]; o.Xc[2] += pose[11];
-  const double u = d.cam[0] * o.Xc[0] / o.Xc[2] + d.cam[2], v = d.cam[1] * o.Xc[1] / o.Xc[2] + d.cam[3];
+  double u, v;
+  if (d.kb8_on) dev::kb8_project(d.cam, d.kb8, o.Xc, u, v);   // ImuCamPose::Project -> pCamera->project (src/G2oTypes.cc:166-171)
+  else { u = d.cam[0] * o.Xc[0] / o.Xc[2] + d.cam[2]; v = d.cam[1] * o.Xc[1] / o.Xc[2] + d.cam[3]; }
   o.r[0] = obs[0] - u; o.r[1] = obs[1] - v; o.r[2] = 0.0;
   if (kind == OSH_EDGE_STEREO) {
     const double invZ = 1 / o.Xc[2];   // ProjectStereo keeps 1/z in double (src/G2oTypes.cc:181)
@@ -111,6 +115,7 @@ __device__ __forceinline__ void vis_jacobians(const LibaDesc& d, int kind, const
   Xb[0] += d.tbc[0]; Xb[1] += d.tbc[1]; Xb[2] += d.tbc[2];
   double pj[9] = {d.cam[0] / Xc[2], 0, -d.cam[0] * Xc[0] / (Xc[2] * Xc[2]), 0, d.cam[1] / Xc[2], -d.cam[1] * Xc[1] / (Xc[2] * Xc[2]), 0, 0, 0};
   if (kind == OSH_EDGE_STEREO) { pj[6] = pj[0]; pj[7] = pj[1]; pj[8] = pj[2] + d.cam[4] * (1.0 / (Xc[2] * Xc[2])); }
+  if (d.kb8_on) dev::kb8_project_jac(d.cam, d.kb8, Xc, pj);   // pCamera->projectJac (src/G2oTypes.cc:359); a fisheye window is monocular
   double M[9];
   imu::m3_mul(pj, pose, M);
 #pragma unroll
@@ -672,6 +677,11 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
     d.peloff_off = (int)PO; d.pel_off = (int)EF; d.lmpose_off = (int)LP; d.H_off = (long long)Htot; d.b_off = (int)btot;
     std::memcpy(d.Rcb, p.Rcb, 72); std::memcpy(d.tcb, p.tcb, 24); std::memcpy(d.tbc, p.tbc, 24); std::memcpy(d.cam, p.cam, 40);
     d.huber_mono = p.huber_mono; d.huber_stereo = p.huber_stereo; d.huber_inertial = p.huber_inertial; d.lambda_init = p.lambda_init;
+    d.kb8_on = p.kb8 ? 1 : 0;
+    for (int k = 0; k < 4; ++k) d.kb8[k] = p.kb8 ? p.kb8[k] : 0.0;
+    if (p.kb8)
+      for (int e = 0; e < p.n_edges; ++e)
+        if (p.edge_kind[e] != OSH_EDGE_MONO) { set_error("window %d: a KannalaBrandt8 window takes monocular edges only (edge %d)", w, e); return OSH_ERR_UNSUPPORTED; }
     size_t ef = 0;
     for (int e = 0; e < p.n_edges; ++e) {
       if (p.edge_pose[e] < 0 || p.edge_pose[e] >= d.K || p.edge_point[e] < 0 || p.edge_point[e] >= d.L || p.edge_kind[e] > OSH_EDGE_STEREO) {

@@ -341,6 +341,8 @@ class HostInertialGraph:
         self.lib.osh_host_graph_set_inertial(self.g, n_imu, capi.ptr(kf_index, capi.c_int32_p), capi.ptr(prev, capi.c_int32_p),
                                              capi.ptr(vel, capi.c_float_p), capi.ptr(bias6, capi.c_float_p), capi.ptr(pre, capi.c_float_p),
                                              capi.ptr(cov, capi.c_float_p), capi.ptr(tbc_qt, capi.c_float_p))
+        if w.kb8 is not None:     # monocular fisheye map: every keyframe's mpCamera is one KannalaBrandt8
+            self.lib.osh_host_graph_set_fisheye(self.g, capi.ptr(_f32(w.kb8), capi.c_float_p))
         self.cur = N - 1
 
     def close(self):
@@ -377,7 +379,8 @@ class HostInertialGraph:
             link_preint=arr(p.link_preint, NL * capi.OSH_PREINT_FLOATS, np.float32).reshape(NL, -1),
             link_info=arr(p.link_info, NL * 81).reshape(NL, 81), link_info_g=arr(p.link_info_g, NL * 9).reshape(NL, 9),
             link_info_a=arr(p.link_info_a, NL * 9).reshape(NL, 9), link_robust=arr(p.link_robust, NL, np.uint8),
-            lambda_init=1e-2 if large else 1.0, max_iterations=4 if large else 10).normalise()
+            lambda_init=1e-2 if large else 1.0, max_iterations=4 if large else 10,
+            kb8=arr(p.kb8, 4) if p.kb8 else None).normalise()
         return w, kid[:Kp], mid[:L]
 
     def run(self, large=False, rec_init=False):

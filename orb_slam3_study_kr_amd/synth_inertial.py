@@ -145,6 +145,7 @@ class LibaWindow:
     huber_inertial: float = float(np.sqrt(16.92))
     lambda_init: float = 1.0
     max_iterations: int = 10
+    kb8: np.ndarray | None = None   # [4] KannalaBrandt8 k1..k4 (monocular fisheye window)
     gt: dict | None = None
 
     _F64 = ("pose_Rcw", "pose_tcw", "pose_Rwb", "pose_twb", "Rcb", "tcb", "tbc", "cam", "vel", "bias_g", "bias_a", "points",
@@ -186,6 +187,9 @@ class LibaWindow:
         p.link_robust = capi.ptr(self.link_robust, capi.c_uint8_p)
         p.huber_mono, p.huber_stereo, p.huber_inertial = self.huber_mono, self.huber_stereo, self.huber_inertial
         p.lambda_init, p.max_iterations = self.lambda_init, self.max_iterations
+        if self.kb8 is not None:
+            self.kb8 = np.ascontiguousarray(self.kb8, dtype=np.float64)
+        p.kb8 = capi.ptr(self.kb8, capi.c_double_p)
         return p
 
 
@@ -229,7 +233,8 @@ def _trajectory(t):
 
 def make_inertial_window(seed: int = 11, n_opt: int = 10, n_fixed: int = 20, n_points: int = 2000, kf_dt: float = 0.25,
                          pixel_noise: bool = True, outlier_frac: float = 0.02, rec_init: bool = False, large: bool = False,
-                         imu_noise: bool = True) -> LibaWindow:
+                         imu_noise: bool = True, fisheye: bool = False) -> LibaWindow:
+    """``fisheye``: a monocular KannalaBrandt8 camera (synth.KB8_K): mono edges only, the window carries ``kb8``."""
     rng = np.random.Generator(np.random.PCG64(seed))
     per = int(round(kf_dt * IMU_FREQ))
     dt = 1.0 / IMU_FREQ
@@ -264,10 +269,19 @@ def make_inertial_window(seed: int = 11, n_opt: int = 10, n_fixed: int = 20, n_p
         Rcw, tcw = gt[ti][3], gt[ti][4]
         Xc = Xw @ Rcw.T + tcw
         z = Xc[:, 2]
-        u = fx * Xc[:, 0] / z + cx
-        v = fy * Xc[:, 1] / z + cy
-        ur = u - bf / z
-        vis = (z > 1.0) & (z < 14.0) & (u >= 0) & (u < synth.IMG_W) & (v >= 0) & (v < synth.IMG_H) & (ur >= 0)
+        if fisheye:
+            theta = np.arctan2(np.hypot(Xc[:, 0], Xc[:, 1]), z)
+            psi = np.arctan2(Xc[:, 1], Xc[:, 0])
+            kb = synth.KB8_K
+            rr = theta + kb[0] * theta**3 + kb[1] * theta**5 + kb[2] * theta**7 + kb[3] * theta**9
+            u = fx * rr * np.cos(psi) + cx
+            v = fy * rr * np.sin(psi) + cy
+            ur = np.full_like(u, -1.0)
+        else:
+            u = fx * Xc[:, 0] / z + cx
+            v = fy * Xc[:, 1] / z + cy
+            ur = u - bf / z
+        vis = (z > 1.0) & (z < 14.0) & (u >= 0) & (u < synth.IMG_W) & (v >= 0) & (v < synth.IMG_H) & (fisheye | (ur >= 0))
         idx = np.nonzero(vis)[0]
         if ti < n_fixed:   # a fixed observer keeps a random third of what it sees
             idx = idx[rng.uniform(0, 1, idx.size) < 0.35]
@@ -280,6 +294,8 @@ def make_inertial_window(seed: int = 11, n_opt: int = 10, n_fixed: int = 20, n_p
         eobs.append(np.stack([u[idx], v[idx], ur[idx]], axis=1) + noise)
         einfo.append(synth.INV_LEVEL_SIGMA2[octave].astype(np.float64)); eout.append(is_out)
     ep, el, eobs, einfo, eout = (np.concatenate(a) for a in (ep, el, eobs, einfo, eout))
+    if fisheye:
+        eobs[:, 2] = -1.0        # monocular keypoints: mvuRight < 0
     # keep landmarks seen by >= 2 keyframes of which >= 1 optimisable (local points come from the temporal window)
     cnt = np.bincount(el, minlength=n_points)
     cnt_opt = np.bincount(el[ep < n_opt], minlength=n_points)
@@ -338,7 +354,8 @@ def make_inertial_window(seed: int = 11, n_opt: int = 10, n_fixed: int = 20, n_p
         n_opt=n_opt, n_fixed_imu=1, n_fixed=n_fixed, pose_Rcw=q(Rcw_a), pose_tcw=q(tcw_a), pose_Rwb=q(Rwb_a), pose_twb=q(twb_a),
         Rcb=q(Rcb), tcb=q(tcb), tbc=q(tbc), cam=q([fx, fy, cx, cy, bf]), vel=q(vel), bias_g=q(bg), bias_a=q(ba),
         points=q(Xw + rng.standard_normal(Xw.shape) * 0.05), edge_pose=ep, edge_point=el,
-        edge_kind=np.full(ep.size, capi.OSH_EDGE_STEREO, dtype=np.uint8), edge_obs=q(eobs), edge_info=einfo,
+        edge_kind=np.full(ep.size, capi.OSH_EDGE_MONO if fisheye else capi.OSH_EDGE_STEREO, dtype=np.uint8), edge_obs=q(eobs), edge_info=einfo,
+        kb8=synth.KB8_K.copy() if fisheye else None,
         link_prev=np.array([n_opt] + list(range(n_opt - 1)), dtype=np.int32), link_cur=np.arange(n_opt, dtype=np.int32),
         link_preint=np.stack(recs), link_info=np.stack(infos), link_info_g=np.stack(infog), link_info_a=np.stack(infoa),
         link_robust=np.array([1 if (l == 0 or rec_init) else 0 for l in range(n_opt)], dtype=np.uint8),

@@ -427,11 +427,13 @@ def test_pose_optimization_through_the_reference_signature(ob, fisheye):
     assert n_in > 0.7 * E
 
 
-def test_local_inertial_ba_through_the_reference_signature(ob):
+@pytest.mark.parametrize("fisheye", [False, True])
+def test_local_inertial_ba_through_the_reference_signature(ob, fisheye):
     """Optimizer::LocalInertialBA(KeyFrame*, bool*, Map*, int&x4, bLarge, bRecInit) on a KeyFrame/MapPoint/IMU graph vs the
-    inertial oracle on the problem the host layer packed; write-back of poses, velocities, biases and points in float."""
+    inertial oracle on the problem the host layer packed; write-back of poses, velocities, biases and points in float.
+    fisheye: a mono-inertial map whose keyframes share a KannalaBrandt8 camera."""
     from orb_slam3_study_kr_amd import synth_inertial as si
-    w = si.make_inertial_window(51, n_opt=6, n_fixed=5, n_points=500)
+    w = si.make_inertial_window(51, n_opt=6, n_fixed=5, n_points=500, fisheye=fisheye)
     with host.HostInertialGraph(w) as g:
         pw, kid, mid = g.packed_window()
         ref = ob.liba_solve(pw)
@@ -450,10 +452,17 @@ def test_local_inertial_ba_through_the_reference_signature(ob):
             assert g.lib.osh_host_kf_pose_sets(g.g, k) == 1
         mp_index = {int(i): k for k, i in enumerate(g.mp_id)}
         got_pts = np.stack([g.mp_pos(mp_index[int(i)]) for i in mid]).astype(np.float64)
-        np.testing.assert_allclose(got_pts, ref.points, rtol=2e-6, atol=2e-6)
-        # stereo outliers: chi2 > 7.815 (float threshold), no depth test (:2875-2887)
-        out = ref.edge_chi2 > np.float32(7.815)
-        near = np.abs(ref.edge_chi2 - 7.815) < 1e-3
+        # monocular: the depth of low-parallax landmarks is weakly constrained (see tests/test_gpu_liba.py), poses / velocities /
+        # biases above hold the tight bound
+        pt = 2e-3 if fisheye else 2e-6
+        np.testing.assert_allclose(got_pts, ref.points, rtol=pt, atol=pt)
+        if fisheye:   # mono outliers: map points of the test double have mTrackDepth 0 (< 10: "close") -> 1.5 x 5.991, or negative depth (:2861-2873)
+            thr = float(np.float32(1.5) * np.float32(5.991))
+            out = (ref.edge_chi2 > thr) | (ref.edge_depth_pos == 0)
+        else:         # stereo outliers: chi2 > 7.815 (float threshold), no depth test (:2875-2887)
+            thr = 7.815
+            out = ref.edge_chi2 > np.float32(7.815)
+        near = np.abs(ref.edge_chi2 - thr) < 1e-3
         for e in np.nonzero(~near)[0]:
             k, j = kf_index[int(kid[pw.edge_pose[e]])], mp_index[int(mid[pw.edge_point[e]])]
             assert g.lib.osh_host_kf_observes(g.g, k, j) == (0 if out[e] else 1)

@@ -21,7 +21,7 @@ def ob():
     return binding
 
 
-def _check(got, ref, w, tol=1e-6):
+def _check(got, ref, w, tol=1e-6, pts_tol=1e-6, edge_tol=1e-4):
     assert got.iterations == ref.iterations
     np.testing.assert_array_equal(got.trials_trace, ref.trials_trace)
     # float32 sinf/cosf of the preintegration getters differ by an ulp between device and host libm; the
@@ -37,8 +37,8 @@ def _check(got, ref, w, tol=1e-6):
     np.testing.assert_allclose(got.vel, ref.vel, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(got.bias_g, ref.bias_g, rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(got.bias_a, ref.bias_a, rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(got.points, ref.points, rtol=1e-6, atol=1e-6)
-    np.testing.assert_allclose(got.edge_chi2, ref.edge_chi2, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(got.points, ref.points, rtol=pts_tol, atol=pts_tol)
+    np.testing.assert_allclose(got.edge_chi2, ref.edge_chi2, rtol=edge_tol, atol=edge_tol / 10)
     np.testing.assert_array_equal(got.edge_depth_pos, ref.edge_depth_pos)
 
 
@@ -68,3 +68,23 @@ def test_result_is_physically_sensible(solver):
     assert np.abs(g.pose_twb - w.gt["twb"][:N]).max() < 0.01
     assert np.abs(g.vel - w.gt["vel"][:N]).max() < 0.02
     assert g.chi2_final < 0.02 * g.chi2_initial
+
+
+def test_monocular_fisheye_inertial_window(solver, ob):
+    """Mono-inertial window whose camera is a KannalaBrandt8 (TUM-VI style): EdgeMono projects through
+    KannalaBrandt8::project / projectJac (osh_liba_problem.kb8); a stereo edge in such a window is refused."""
+    w = si.make_inertial_window(13, n_opt=6, n_fixed=6, n_points=700, fisheye=True)
+    assert w.kb8 is not None and (w.edge_kind == 0).all()
+    ref = ob.liba_solve(w)
+    assert ref.iterations >= 3 and ref.chi2_final < 0.1 * ref.chi2_initial
+    # monocular: the depth of a low-parallax landmark is weakly constrained, so the 1e-8 noise of the float32 preintegration
+    # getters (see _check) shows up at the 1e-5 level in a few landmark coordinates; poses, velocities and biases stay at 1e-6
+    # per-edge chi2: the reference rounds theta and psi to float32, so the fisheye residual is a staircase with ~3e-5 px steps;
+    # a state difference of 1e-9 can move an edge to the next step (1e-4 .. 1e-3 of a chi2 near 1)
+    _check(solver.solve_inertial([w])[0], ref, w, pts_tol=2e-4, edge_tol=2e-3)
+    ws = [w, si.make_inertial_window(14, n_opt=4, n_fixed=4, n_points=400)]        # fisheye + pinhole stereo in one batch
+    for g, wi in zip(solver.solve_inertial(ws), ws):
+        _check(g, ob.liba_solve(wi), wi, pts_tol=2e-4 if wi.kb8 is not None else 1e-6, edge_tol=2e-3 if wi.kb8 is not None else 1e-4)
+    w.edge_kind[5] = 1
+    with pytest.raises(RuntimeError, match="KannalaBrandt8"):
+        solver.solve_inertial([w])
