@@ -124,7 +124,7 @@ struct BatchView {
   int n_rblk;
   double* contrib;           // [n_contrib*36] per trial: 6x6 products of one item and pose pair
   double* ccontrib;          // [n_ccontrib*6] per trial: rhs products of one item and pose
-  double* dinv;              // [NL*9] per trial: sym (Hll+lambda I)^-1 (00 01 02 11 12 22) + Dinv*b_l (3)
+  double* dinv;              // [NL*9] unused since the landmark inverse is re-formed in k_backsub (kept for the debug exports)
   // system
   double* Hpl;               // [NE*18] 6x3 row-major per sorted edge
   double* Hll;               // [NL*6] upper: 00 01 02 11 12 22
@@ -171,6 +171,16 @@ __device__ __forceinline__ double block_max(double v, double* sh4) {
   const double r = fmax(fmax(sh4[0], sh4[1]), fmax(sh4[2], sh4[3]));
   __syncthreads();
   return r;
+}
+
+// Ordering point for the single-wavefront kernels (64-thread blocks): LDS operations of one wavefront execute in order, so
+// only the compiler has to be told not to move LDS accesses across this point.  __syncthreads() would additionally wait for
+// every outstanding GLOBAL access of the wavefront (it is also a workgroup-scope memory fence): a full store round trip per
+// chunk in k_lin_items (the Hpl stores); k_schur_items has no global store in its chunk loop at all (exact s_waitcnt counts).
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // Residual / Jacobians of one visual edge through the window's camera model.  KB8 is a compile-time switch: the pinhole
@@ -236,7 +246,7 @@ __global__ __launch_bounds__(kBlock) void k_residual(BatchView bv) {
 // MFMA reads).  D = BD * W^T is then 6 k-steps of v_mfma_f64_16x16x4_f64 per 16x16 tile; the
 // accumulators stay in registers across the chunks of the item.  At the end every live pose pair
 // (sa, sb) is written as one 6x6 contribution; k_schur_reduce sums them in plan order.
-//   SYM: X == Y, only the tiles on and above the diagonal; also owns the rhs term and dinv.
+//   SYM: X == Y, only the tiles on and above the diagonal; also owns the rhs term.
 // --------------------------------------------------------------------------------------------
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int kSiLm = 8;               // landmarks per chunk
@@ -309,7 +319,6 @@ __global__ __launch_bounds__(64, 2) void k_schur_items(BatchView bv, int item_ba
 #pragma unroll
     for (int k = 0; k < 9; ++k) D[k] = 0.0;
     if (valid) {
-      const size_t gl = (size_t)wd.pt_off + ra.x;
       double Dinv[9];
       dev::inv3_sym(d.hl[0] + lambda, d.hl[1], d.hl[2], d.hl[3] + lambda, d.hl[4], d.hl[5] + lambda, Dinv);
       const double b0 = d.bl[0], b1 = d.bl[1], b2 = d.bl[2];
@@ -317,12 +326,8 @@ __global__ __launch_bounds__(64, 2) void k_schur_items(BatchView bv, int item_ba
       D[6] = Dinv[0] * b0 + Dinv[1] * b1 + Dinv[2] * b2;
       D[7] = Dinv[3] * b0 + Dinv[4] * b1 + Dinv[5] * b2;
       D[8] = Dinv[6] * b0 + Dinv[7] * b1 + Dinv[8] * b2;
-      if (SYM && s == 0 && (rb.z & 1)) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) bv.dinv[gl * 9 + k] = D[k];
-      }
     }
-    __syncthreads();   // the previous chunk's MFMA reads are done
+    wave_sync();   // the previous chunk's MFMA reads are done
     {
       double* a_row = shA + (6 * s) * kSiKS + 3 * l;
       double* b_row = shB + (6 * s) * kSiKS + 3 * l;
@@ -370,13 +375,13 @@ __global__ __launch_bounds__(64, 2) void k_schur_items(BatchView bv, int item_ba
   load_dat(rc0, rc1, d);
   for (int c0 = 0; c0 < it.n_lm; c0 += kSiLm) {
     park(c0, rc0, rc1, d);                 // Dinv, BD, W of chunk c0 -> LDS (consumes d)
-    __syncthreads();
+    wave_sync();
     rc0 = rn0; rc1 = rn1;                  // loaded one iteration ago
     load_dat(rc0, rc1, d);                 // chunk c0 + 1: in flight during the MFMAs below
     load_rec(c0 + 2 * kSiLm, rn0, rn1);
     multiply();
   }
-  __syncthreads();
+  wave_sync();
   // contributions: lane holds D[row = (lane >> 4) + 4 reg][col = lane & 15] of each tile
 #pragma unroll
   for (int ti = 0; ti < 3; ++ti)
@@ -398,7 +403,7 @@ __global__ __launch_bounds__(64, 2) void k_schur_items(BatchView bv, int item_ba
     // rhs term of row pose s: sum over the 8 landmark lanes in fixed order
 #pragma unroll
     for (int r = 0; r < 6; ++r) shA[l * kSiRows + 6 * s + r] = csum[r];
-    __syncthreads();
+    wave_sync();
     if (lane < kSiRows) {
       double v = 0.0;
 #pragma unroll
@@ -631,7 +636,7 @@ __global__ __launch_bounds__(64, 2) void k_lin_items(BatchView bv) {
       }
     }
     // coalesced copy of the staged blocks (a strided 16-byte store per lane costs a partial-line write each)
-    __syncthreads();
+    wave_sync();
     {
       const double2* stg = reinterpret_cast<const double2*>(shStage);
 #pragma unroll
@@ -647,7 +652,7 @@ __global__ __launch_bounds__(64, 2) void k_lin_items(BatchView bv) {
         }
       }
     }
-    __syncthreads();
+    wave_sync();
   };
   int4 rA0, rA1, rB0, rB1;
   In inA, inB;
@@ -678,13 +683,13 @@ __global__ __launch_bounds__(64, 2) void k_lin_items(BatchView bv) {
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     const int k0 = half * 14, nk = half ? 13 : 14;
-    __syncthreads();
+    wave_sync();
 #pragma unroll
     for (int k = 0; k < 14; ++k) {
       const int kk = k0 + k;
       if (k < nk) shStage[k * 64 + lane] = (kk < 21) ? H[kk < 21 ? kk : 0] : b[(kk - 21) < 0 ? 0 : ((kk - 21) > 5 ? 5 : (kk - 21))];
     }
-    __syncthreads();
+    wave_sync();
     for (int o = lane; o < 8 * nk; o += 64) {
       const int k = o >> 3, sa = o & 7;
       const int slot = bv.scslot[(size_t)item_idx * 8 + sa];
@@ -762,7 +767,7 @@ __global__ __launch_bounds__(64) void k_lin_aux(BatchView bv) {
 #pragma unroll
   for (int k = 0; k < 9; ++k) shv[k * 64 + lane] = hl[k];
   shl[lane] = my_lm;
-  __syncthreads();
+  wave_sync();
   double dmax = 0.0;
   if (my_lm >= 0 && (lane == 0 || shl[lane - 1] != my_lm)) {
     for (int y = lane + 1; y < 64 && shl[y] == my_lm; ++y) {
@@ -930,7 +935,12 @@ __global__ __launch_bounds__(kBlock) void k_backsub(BatchView bv) {
   double sc = 0.0;
   if (tid < nl) {
     const size_t gl = (size_t)wd.pt_off + ch.lm0 + tid;
-    const double* D = bv.dinv + gl * 9;  // sym 00 01 02 11 12 22
+    // (Hll + lambda I)^-1 is formed again here (the same inv3_sym on the same inputs as in k_schur_items: identical bits) rather
+    // than stored there and re-read: a global store inside the Schur kernel's chunk loop makes its s_waitcnt counts inexact
+    double Dinv[9];
+    dev::inv3_sym(bv.Hll[gl * 6] + lambda, bv.Hll[gl * 6 + 1], bv.Hll[gl * 6 + 2], bv.Hll[gl * 6 + 3] + lambda, bv.Hll[gl * 6 + 4],
+                  bv.Hll[gl * 6 + 5] + lambda, Dinv);
+    const double D[6] = {Dinv[0], Dinv[1], Dinv[2], Dinv[4], Dinv[5], Dinv[8]};   // sym 00 01 02 11 12 22
     const double b0 = bv.bl[gl * 3], b1 = bv.bl[gl * 3 + 1], b2 = bv.bl[gl * 3 + 2];
     const double c0 = b0 + acc[0], c1 = b1 + acc[1], c2 = b2 + acc[2];
     double xl[3];
