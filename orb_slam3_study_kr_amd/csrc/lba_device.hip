@@ -22,6 +22,7 @@
 //                 and the optimize() loop conditions, sparse_optimizer.cpp:354-419
 //   k_finalize    per-edge chi2 / isDepthPositive for the outlier test, src/Optimizer.cc:1413-1460
 #include "common.h"
+#include <type_traits>
 #include "lba_math.h"
 #include "ldlt_block.h"
 #include "schur_plan.h"
@@ -352,20 +353,48 @@ __global__ __launch_bounds__(64, 2) void k_schur_items(BatchView bv, int item_ba
       }
     }
   };
-  auto multiply = [&]() {
+  // The tile counts are compile-time constants inside each instantiation (dispatched once per chunk): with run-time tile tests
+  // every MFMA and every operand read sat behind its own scalar branch (127 branches per chunk against 36 MFMAs).
+  auto multiply_t = [&](auto txc, auto tyc) {
+    constexpr int TXc = decltype(txc)::value, TYc = decltype(tyc)::value;
 #pragma unroll
     for (int ks = 0; ks < (3 * kSiLm) / 4; ++ks) {
       double a[3], b[3];
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
-        a[t] = (t < TX) ? shA[(16 * t + mrow) * kSiKS + 4 * ks + mk] : 0.0;
-        b[t] = (t < TY) ? shB[(16 * t + mrow) * kSiKS + 4 * ks + mk] : 0.0;
+        a[t] = (t < TXc) ? shA[(16 * t + mrow) * kSiKS + 4 * ks + mk] : 0.0;
+        b[t] = (t < TYc) ? shB[(16 * t + mrow) * kSiKS + 4 * ks + mk] : 0.0;
       }
 #pragma unroll
       for (int ti = 0; ti < 3; ++ti)
 #pragma unroll
         for (int tj = SYM ? ti : 0; tj < 3; ++tj)
-          if (ti < TX && tj < TY) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+          if (ti < TXc && tj < TYc) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+      if (ks & 1) __builtin_amdgcn_sched_barrier(0);   // operands of two k-steps in flight at most (the prefetched chunk needs the registers)
+    }
+  };
+  using std::integral_constant;
+  auto multiply = [&]() {
+    if (SYM) {   // TX == TY
+      if (TX == 3) multiply_t(integral_constant<int, 3>{}, integral_constant<int, 3>{});
+      else if (TX == 2) multiply_t(integral_constant<int, 2>{}, integral_constant<int, 2>{});
+      else multiply_t(integral_constant<int, 1>{}, integral_constant<int, 1>{});
+    } else {
+      // cross items keep run-time tile tests: nine instantiations cost them 50 more registers (spills) for no gain
+#pragma unroll
+      for (int ks = 0; ks < (3 * kSiLm) / 4; ++ks) {
+        double a[3], b[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          a[t] = (t < TX) ? shA[(16 * t + mrow) * kSiKS + 4 * ks + mk] : 0.0;
+          b[t] = (t < TY) ? shB[(16 * t + mrow) * kSiKS + 4 * ks + mk] : 0.0;
+        }
+#pragma unroll
+        for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < 3; ++tj)
+            if (ti < TX && tj < TY) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+      }
     }
   };
   int4 rc0, rc1, rn0, rn1;
