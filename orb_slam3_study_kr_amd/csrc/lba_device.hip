@@ -1804,6 +1804,6 @@ extern "C" int osh_lba_get_plan_stats(osh_lba_ctx* c, int64_t stats[6]) {
 }
 
 extern "C" const char* osh_lba_kernel_name(int k) {
-  static const char* names[OSH_K_COUNT] = {"k_lin_items<0>", "k_pose_reduce", "k_schur_items<true>", "k_solve", "k_backsub", "k_residual", "k_control", "k_schur_reduce", "k_schur_items<false>", "k_lin_aux", "k_lin_items<1>"};
+  static const char* names[OSH_K_COUNT] = {"k_lin_items<0, false>", "k_pose_reduce", "k_schur_items<true>", "k_solve", "k_backsub", "k_residual<false>", "k_control", "k_schur_reduce", "k_schur_items<false>", "k_lin_aux<false>", "k_lin_items<1, false>"};   // pinhole instantiations (<.., true> for a fisheye batch)
   return (k >= 0 && k < OSH_K_COUNT) ? names[k] : "?";
 }
