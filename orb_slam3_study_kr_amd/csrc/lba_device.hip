@@ -36,6 +36,8 @@ namespace osh {
 
 constexpr int kBlock = 256;        // threads per block of the edge/landmark kernels
 constexpr int kChunkEdges = 256;   // edges handled per pass of a chunk (== kBlock)
+constexpr int kChunkMaxEdges = 1024;   // edges of one chunk (= one block of k_residual / k_backsub / k_finalize): four passes amortise
+                                       // the per-block staging of the window's poses and x_p in k_backsub
 constexpr double kTau = 1e-5;      // OptimizationAlgorithmLevenberg::_tau
 constexpr int kMaxTrials = 10;     // maxTrialsAfterFailure
 // k_solve runs one block per window.  The factorisation is a chain of dependent pivots: with many windows two 256-thread
@@ -912,10 +914,14 @@ __global__ __launch_bounds__(NT) void k_solve(BatchView bv, int W) {
 // --------------------------------------------------------------------------------------------
 // k_backsub: x_l = Dinv (b_l - Hpl^T x_p), X_trial = X + x_l, landmark part of computeScale.
 // Same chunking as k_residual: lane per edge for the Hpl^T x_p products, lane per landmark
-// for the ordered sum.
+// for the ordered sum.  The product of an edge is formed from its Jacobians, Hpl^T x = JX^T (rho' Omega) (Jp x), re-evaluated at
+// the linearisation point from ~45 bytes of edge data instead of reading the 144-byte block the linearisation stored (the
+// kernel is HBM-bound: 5.9 GB -> see DESIGN.md); the optimisable poses of the window sit in LDS with their rotation matrices.
 // --------------------------------------------------------------------------------------------
+constexpr int kBsPoseStride = 17;   // qt(7) + R(9), odd stride against LDS bank conflicts
+template <bool KB8>
 __global__ __launch_bounds__(kBlock) void k_backsub(BatchView bv) {
-  extern __shared__ __attribute__((aligned(16))) double sh_bs[];  // [3*256] partials, [4] reduce, [n] x_p
+  extern __shared__ __attribute__((aligned(16))) double sh_bs[];  // [3*256] partials, [4] reduce, [n] x_p, [P*17] poses
   double* sh_c = sh_bs;
   double* sh4 = sh_bs + 3 * kChunkEdges;
   double* sh_dyn = sh4 + 4;
@@ -927,11 +933,27 @@ __global__ __launch_bounds__(kBlock) void k_backsub(BatchView bv) {
   const int n = wd.n;
   const double* xp = bv.xp + (size_t)wd.fpose_off * 6;
   for (int k = tid; k < n; k += kBlock) sh_dyn[k] = xp[k];
+  double* sh_pose = sh_dyn + n;
+  {
+    const double* poses = bv.pose_state[st.sel] + (size_t)wd.pose_off * 7;
+    for (int i = tid; i < wd.P; i += kBlock) {
+      double qt[7], R[9];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) qt[k] = poses[(size_t)i * 7 + k];
+      dev::quat_to_R(qt, R);
+#pragma unroll
+      for (int k = 0; k < 7; ++k) sh_pose[i * kBsPoseStride + k] = qt[k];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) sh_pose[i * kBsPoseStride + 7 + k] = R[k];
+    }
+  }
   __syncthreads();
   const int* lmo = bv.lm_off + wd.lmoff_off;
   const int e0 = lmo[ch.lm0], e1 = lmo[ch.lm1];
   const int nl = ch.lm1 - ch.lm0;
   const double lambda = st.lambda;
+  const double* pts = bv.pt_state[st.sel] + (size_t)wd.pt_off * 3;
+  const double* cams = bv.pose_cam + (size_t)wd.pose_off * 5;
   double acc[3] = {0, 0, 0};
   int my_lo = 0, my_hi = 0;
   if (tid < nl) { my_lo = lmo[ch.lm0 + tid]; my_hi = lmo[ch.lm0 + tid + 1]; }
@@ -942,13 +964,35 @@ __global__ __launch_bounds__(kBlock) void k_backsub(BatchView bv) {
       const size_t ge = (size_t)wd.edge_off + e;
       const int ip = bv.e_pose[ge];
       if (ip < wd.P) {
-        const double* B = bv.Hpl + ge * 18;
-        const double* x = sh_dyn + 6 * ip;
+        const int il = bv.e_point[ge];
+        const int kind = bv.e_kind[ge];
+        const double info = bv.e_info[ge];
+        double qt[7], R[9], cam[5], X[3], obs[3], r[3], Xc[3], JX[9], Jp[18];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) {
-          const double mx = -x[r];  // rightMultiply with cp = -xp
-          c0 += B[r * 3] * mx; c1 += B[r * 3 + 1] * mx; c2 += B[r * 3 + 2] * mx;
+        for (int k = 0; k < 7; ++k) qt[k] = sh_pose[ip * kBsPoseStride + k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[k] = sh_pose[ip * kBsPoseStride + 7 + k];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) cam[k] = cams[(size_t)ip * 5 + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { X[k] = pts[(size_t)il * 3 + k]; obs[k] = bv.e_obs[ge * 3 + k]; }
+        const double chi2 = win_edge_residual<KB8>(wd, kind, qt, cam, X, obs, info, r, Xc);
+        double rho0, rho1;
+        dev::huber(chi2, kind == OSH_EDGE_MONO ? wd.huber_mono : wd.huber_stereo, rho0, rho1);
+        win_edge_jacobians<KB8>(wd, kind, R, cam, Xc, JX, Jp);
+        const double ww = rho1 * info;
+        const double* x = sh_dyn + 6 * ip;
+        double t[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          double a = 0.0;
+#pragma unroll
+          for (int rr = 0; rr < 6; ++rr) a += Jp[k * 6 + rr] * (-x[rr]);   // rightMultiply with cp = -xp
+          t[k] = ww * a;
         }
+        c0 = JX[0] * t[0] + JX[3] * t[1] + JX[6] * t[2];
+        c1 = JX[1] * t[0] + JX[4] * t[1] + JX[7] * t[2];
+        c2 = JX[2] * t[0] + JX[5] * t[1] + JX[8] * t[2];
       }
     }
     sh_c[tid] = c0; sh_c[kChunkEdges + tid] = c1; sh_c[2 * kChunkEdges + tid] = c2;
@@ -1175,6 +1219,7 @@ struct osh_lba_ctx {
   void (*kp_lin_aux)(BatchView) = nullptr;
   void (*kp_residual)(BatchView) = nullptr;
   void (*kp_finalize)(BatchView) = nullptr;
+  void (*kp_backsub)(BatchView) = nullptr;
   // device buffers
   DevBuf d_win, d_lm, d_chunks, d_fpose_win, d_pose_init, d_pose[2], d_pt_init, d_pt[2], d_cam;
   DevBuf d_e_pose, d_e_point, d_e_kind, d_e_obs, d_e_info, d_e_orig, d_lm_off, d_lm_nfree, d_pel_off, d_pel_edge, d_sitems, d_srecs, d_spair, d_scslot, d_sposex, d_pose_crange, d_hcontrib, d_chi_item, d_dmax_item, d_aux_chunks, d_aux_entries, d_chi_aux, d_dmax_aux, d_rblk, d_contrib, d_ccontrib, d_dinv;
@@ -1399,13 +1444,13 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
       close();
       d.n_aux = (int)h_aux_chunks.size() - d.aux_off;
     }
-    // chunks: consecutive landmarks, <= kChunkEdges edges and <= kBlock landmarks (a single
+    // chunks: consecutive landmarks, <= kChunkMaxEdges edges and <= kBlock landmarks (a single
     // landmark with more edges gets its own multi-pass chunk)
     d.chunk_off = (int)h_chunks.size();
     int j = 0;
     while (j < p.n_points) {
       int j1 = j + 1;
-      while (j1 < p.n_points && (j1 - j) < kBlock && (lmo[j1 + 1] - lmo[j]) <= kChunkEdges) ++j1;
+      while (j1 < p.n_points && (j1 - j) < kBlock && (lmo[j1 + 1] - lmo[j]) <= kChunkMaxEdges) ++j1;
       h_chunks.push_back(Chunk{w, j, j1});
       j = j1;
     }
@@ -1429,7 +1474,7 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   c->h_e_orig = h_eorig;
 
   // ---- LDS budgets
-  c->backsub_lds = (size_t)(3 * kChunkEdges + 4 + std::max(n_max, 1)) * sizeof(double);
+  c->backsub_lds = (size_t)(3 * kChunkEdges + 4 + std::max(n_max, 1) + (std::max(n_max, 6) / 6) * kBsPoseStride) * sizeof(double);
   {
     // Many windows: two 256-thread blocks per CU (75 KB each) as long as that leaves a panel width of at least 12 columns.
     // Fewer windows than half the CUs: one 512-thread block per window with the widest panel that fits.
@@ -1530,10 +1575,10 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
 
   if (c->has_kb8) {
     c->kp_lin_lm = k_lin_items<0, true>; c->kp_lin_pose = k_lin_items<1, true>; c->kp_lin_aux = k_lin_aux<true>;
-    c->kp_residual = k_residual<true>; c->kp_finalize = k_finalize<true>;
+    c->kp_residual = k_residual<true>; c->kp_finalize = k_finalize<true>; c->kp_backsub = k_backsub<true>;
   } else {
     c->kp_lin_lm = k_lin_items<0, false>; c->kp_lin_pose = k_lin_items<1, false>; c->kp_lin_aux = k_lin_aux<false>;
-    c->kp_residual = k_residual<false>; c->kp_finalize = k_finalize<false>;
+    c->kp_residual = k_residual<false>; c->kp_finalize = k_finalize<false>; c->kp_backsub = k_backsub<false>;
   }
 
   // opt in to large dynamic LDS once per process
@@ -1543,7 +1588,8 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
     OSH_SOLVE_ATTR(24, kSolveThreadsBatch); OSH_SOLVE_ATTR(12, kSolveThreadsBatch); OSH_SOLVE_ATTR(6, kSolveThreadsBatch);
     OSH_SOLVE_ATTR(24, kSolveThreadsLatency); OSH_SOLVE_ATTR(12, kSolveThreadsLatency); OSH_SOLVE_ATTR(6, kSolveThreadsLatency);
 #undef OSH_SOLVE_ATTR
-    OSH_HIP(hipFuncSetAttribute((const void*)k_backsub, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    OSH_HIP(hipFuncSetAttribute((const void*)k_backsub<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    OSH_HIP(hipFuncSetAttribute((const void*)k_backsub<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     attr_done = true;
   }
   return OSH_OK;
@@ -1630,7 +1676,7 @@ extern "C" int osh_lba_optimize(osh_lba_ctx* c) {
       OSH_TRY(launch_solve(c, s));
       if (_t) c->timer.end(s);
     }
-    LAUNCH(OSH_K_BACKSUB, k_backsub, c->n_chunks, kBlock, c->backsub_lds, c->bv);
+    LAUNCH(OSH_K_BACKSUB, c->kp_backsub, c->n_chunks, kBlock, c->backsub_lds, c->bv);
     LAUNCH(OSH_K_RESIDUAL, c->kp_residual, c->n_chunks, kBlock, 0, c->bv);
     if (c->any_stop) {
       // terminate() is polled after every trial (levenberg.cpp:149) and before every iteration
@@ -1764,7 +1810,7 @@ extern "C" int osh_lba_debug_trial(osh_lba_ctx* c, int32_t window, double lambda
   if (S && d.n) OSH_HIP(hipMemcpy(S, c->d_S.as<double>() + d.S_off, (size_t)d.n * d.n * 8, hipMemcpyDeviceToHost));
   if (bs && d.n) OSH_HIP(hipMemcpy(bs, c->d_bs.as<double>() + (size_t)d.fpose_off * 6, (size_t)d.n * 8, hipMemcpyDeviceToHost));
   OSH_TRY(launch_solve(c, s));
-  hipLaunchKernelGGL(k_backsub, dim3((unsigned)c->n_chunks), dim3(kBlock), c->backsub_lds, s, c->bv);
+  hipLaunchKernelGGL(c->kp_backsub, dim3((unsigned)c->n_chunks), dim3(kBlock), c->backsub_lds, s, c->bv);
   OSH_TRY(launch_check("k_backsub"));
   OSH_HIP(hipStreamSynchronize(s));
   if (x) {
@@ -1804,6 +1850,6 @@ extern "C" int osh_lba_get_plan_stats(osh_lba_ctx* c, int64_t stats[6]) {
 }
 
 extern "C" const char* osh_lba_kernel_name(int k) {
-  static const char* names[OSH_K_COUNT] = {"k_lin_items<0, false>", "k_pose_reduce", "k_schur_items<true>", "k_solve", "k_backsub", "k_residual<false>", "k_control", "k_schur_reduce", "k_schur_items<false>", "k_lin_aux<false>", "k_lin_items<1, false>"};   // pinhole instantiations (<.., true> for a fisheye batch)
+  static const char* names[OSH_K_COUNT] = {"k_lin_items<0, false>", "k_pose_reduce", "k_schur_items<true>", "k_solve", "k_backsub<false>", "k_residual<false>", "k_control", "k_schur_reduce", "k_schur_items<false>", "k_lin_aux<false>", "k_lin_items<1, false>"};   // pinhole instantiations (<.., true> for a fisheye batch)
   return (k >= 0 && k < OSH_K_COUNT) ? names[k] : "?";
 }

@@ -30,6 +30,7 @@ if rows:
     names = {"void k_lin_items<0, false>": "linearize", "void k_lin_items<1, false>": "lin_pose", "void k_lin_aux<false>": "lin_aux",
              "void k_lin_items<0, true>": "linearize", "void k_lin_items<1, true>": "lin_pose", "void k_lin_aux<true>": "lin_aux",
              "void k_residual<false>": "residual", "void k_residual<true>": "residual", "k_pose_reduce": "pose_hess",
+             "void k_backsub<false>": "backsub", "void k_backsub<true>": "backsub",
              "void k_schur_items<true>": "schur", "void k_schur_items<false>": "schur_cross", "k_schur_reduce": "schur_reduce",
              "void k_solve<24, 256>": "solve", "void k_solve<12, 256>": "solve", "void k_solve<6, 256>": "solve", "void k_solve<24, 512>": "solve",
              "void k_solve<12, 512>": "solve", "void k_solve<6, 512>": "solve", "k_backsub": "backsub", "k_residual": "residual"}
