@@ -364,6 +364,8 @@ typedef struct osh_frustum_frame {
   float log_scale_factor;                   /* Frame::mfLogScaleFactor                                             */
   int32_t n_scale_levels;                   /* Frame::mnScaleLevels                                                */
   float viewing_cos_limit;                  /* 0.5 in SearchLocalPoints                                            */
+  int32_t fisheye;                          /* 0: Pinhole::project.  1: KannalaBrandt8::project(Vector3f) with kb8 below */
+  float kb8[4];                             /* k1..k4 (mvParameters[4..7]) when fisheye                            */
 } osh_frustum_frame;
 typedef struct osh_frustum_points {
   int32_t n;

@@ -34,8 +34,19 @@ void oracle_frustum(const osh_frustum_frame* f, const osh_frustum_points* p, osh
     const float invz = 1.0f / Pc[2];
     if (Pc[2] < 0.0f) continue;
     /* :532-537 */
-    const float u = f->fx * Pc[0] / Pc[2] + f->cx;
-    const float v = f->fy * Pc[1] / Pc[2] + f->cy;
+    float u = f->fx * Pc[0] / Pc[2] + f->cx;
+    float v = f->fy * Pc[1] / Pc[2] + f->cy;
+    if (f->fisheye) {
+      /* KannalaBrandt8::project(Vector3f), src/CameraModels/KannalaBrandt8.cpp:66-84; atan2f / cosf / sinf as their correctly
+       * rounded values (double function rounded once), the libm-independent convention the device reproduces */
+      const float x2y2 = Pc[0] * Pc[0] + Pc[1] * Pc[1];
+      const float theta = (float)atan2((double)sqrtf(x2y2), (double)Pc[2]);
+      const float psi = (float)atan2((double)Pc[1], (double)Pc[0]);
+      const float t2 = theta * theta, t3 = theta * t2, t5 = t3 * t2, t7 = t5 * t2, t9 = t7 * t2;
+      const float rr = theta + f->kb8[0] * t3 + f->kb8[1] * t5 + f->kb8[2] * t7 + f->kb8[3] * t9;
+      u = f->fx * rr * (float)cos((double)psi) + f->cx;
+      v = f->fy * rr * (float)sin((double)psi) + f->cy;
+    }
     if (u < f->min_x || u > f->max_x) continue;
     if (v < f->min_y || v > f->max_y) continue;
     /* :539-540 */

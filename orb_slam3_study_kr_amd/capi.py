@@ -148,6 +148,7 @@ class FrustumFrame(C.Structure):
         ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float),
         ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float),
         ("log_scale_factor", C.c_float), ("n_scale_levels", C.c_int32), ("viewing_cos_limit", C.c_float),
+        ("fisheye", C.c_int32), ("kb8", C.c_float * 4),
     ]
 
 

@@ -41,6 +41,8 @@ int Frame::isInFrustum(const std::vector<MapPoint*>& vpMPs, float viewingCosLimi
   f.fx = fx; f.fy = fy; f.cx = cx; f.cy = cy; f.bf = mbf;
   f.min_x = mnMinX; f.max_x = mnMaxX; f.min_y = mnMinY; f.max_y = mnMaxY;
   f.log_scale_factor = mfLogScaleFactor; f.n_scale_levels = mnScaleLevels; f.viewing_cos_limit = viewingCosLimit;
+  f.fisheye = (mpCamera && mpCamera->GetType() == GeometricCamera::CAM_FISHEYE) ? 1 : 0;   // mpCamera->project(Pc) (:532)
+  for (int k = 0; k < 4; ++k) f.kb8[k] = f.fisheye ? mpCamera->getParameter(4 + k) : 0.f;
   std::vector<float> pos((size_t)n * 3), nrm((size_t)n * 3), dmin(n), dmax(n);
   for (int i = 0; i < n; ++i) {
     const Eigen::Vector3f P = vpMPs[i]->GetWorldPos(), Pn = vpMPs[i]->GetNormal();

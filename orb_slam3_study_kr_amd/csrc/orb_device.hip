@@ -266,7 +266,7 @@ using namespace osh;
 // out: 8 words per point   (stage, u, v, u - bf/z, |Pc|, viewCos, level, 0); stage 0: rejected before
 //      the projection was stored, 1: mTrackProjX/Y stored then rejected, 2: in view.
 // --------------------------------------------------------------------------------------------
-struct FrustumFrame { float R[9], t[3], O[3], fx, fy, cx, cy, bf, min_x, max_x, min_y, max_y, log_sf, cos_limit; int levels; };
+struct FrustumFrame { float R[9], t[3], O[3], fx, fy, cx, cy, bf, min_x, max_x, min_y, max_y, log_sf, cos_limit; int levels; int fisheye; float kb[4]; };
 
 // plain operators with contraction switched off per function (HIP's __fmul_rn / __fadd_rn are inline functions compiled with
 // the default contract flag: after inlining their results still fuse into FMAs)
@@ -296,8 +296,19 @@ __global__ __launch_bounds__(256) void k_frustum(FrustumFrame f, int n, const fl
   if (!(Pc[2] < 0.0f)) {
     const float invz = (1.0f / Pc[2]);
     // Pinhole::project(Vector3f): fx * x / z + cx  (src/CameraModels/Pinhole.cpp:43-49)
-    const float pu = f.fx * Pc[0] / Pc[2] + f.cx;
-    const float pv = f.fy * Pc[1] / Pc[2] + f.cy;
+    float pu = f.fx * Pc[0] / Pc[2] + f.cx;
+    float pv = f.fy * Pc[1] / Pc[2] + f.cy;
+    if (f.fisheye) {
+      // KannalaBrandt8::project(Vector3f) (src/CameraModels/KannalaBrandt8.cpp:66-84): float32 throughout; atan2f / cosf / sinf
+      // taken as their correctly rounded values (FP64 function rounded once) so the result does not depend on the libm
+      const float x2y2 = Pc[0] * Pc[0] + Pc[1] * Pc[1];
+      const float theta = (float)atan2((double)sqrt_rn(x2y2), (double)Pc[2]);
+      const float psi = (float)atan2((double)Pc[1], (double)Pc[0]);
+      const float t2 = theta * theta, t3 = theta * t2, t5 = t3 * t2, t7 = t5 * t2, t9 = t7 * t2;
+      const float rr = theta + f.kb[0] * t3 + f.kb[1] * t5 + f.kb[2] * t7 + f.kb[3] * t9;
+      pu = f.fx * rr * (float)cos((double)psi) + f.cx;
+      pv = f.fy * rr * (float)sin((double)psi) + f.cy;
+    }
     if (!(pu < f.min_x || pu > f.max_x) && !(pv < f.min_y || pv > f.max_y)) {
       stage = 1; u = pu; v = pv;
       const float PO[3] = {(P[0] - f.O[0]), (P[1] - f.O[1]), (P[2] - f.O[2])};
@@ -565,6 +576,8 @@ extern "C" int osh_orb_frustum(osh_orb_ctx* c, const osh_frustum_frame* fr, cons
   f.fx = fr->fx; f.fy = fr->fy; f.cx = fr->cx; f.cy = fr->cy; f.bf = fr->bf;
   f.min_x = fr->min_x; f.max_x = fr->max_x; f.min_y = fr->min_y; f.max_y = fr->max_y;
   f.log_sf = fr->log_scale_factor; f.cos_limit = fr->viewing_cos_limit; f.levels = fr->n_scale_levels;
+  f.fisheye = fr->fisheye ? 1 : 0;
+  for (int k = 0; k < 4; ++k) f.kb[k] = fr->fisheye ? fr->kb8[k] : 0.f;
   hipLaunchKernelGGL(k_frustum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, f, n, c->d_fin.as<float4>(), c->d_fout.as<float4>());
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("k_frustum launch failed: %s", hipGetErrorString(e)); return OSH_ERR_DEVICE; }

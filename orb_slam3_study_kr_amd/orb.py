@@ -160,7 +160,7 @@ def replay_local_points(res: dict, pair_index: int, rescan, nn_ratio: float = 0.
     return nmatches, assign, rescans
 
 
-def frustum_frame(Rcw, tcw, fx, fy, cx, cy, bf, bounds, log_scale_factor, n_scale_levels, viewing_cos_limit=0.5):
+def frustum_frame(Rcw, tcw, fx, fy, cx, cy, bf, bounds, log_scale_factor, n_scale_levels, viewing_cos_limit=0.5, kb8=None):
     """osh_frustum_frame from a float32 camera pose; Ow = -Rcw^T tcw formed in float32 like Frame::UpdatePoseMatrices
     (src/Frame.cc:298-307)."""
     R = np.asarray(Rcw, dtype=np.float32).reshape(3, 3)
@@ -173,6 +173,9 @@ def frustum_frame(Rcw, tcw, fx, fy, cx, cy, bf, bounds, log_scale_factor, n_scal
     f.fx, f.fy, f.cx, f.cy, f.bf = fx, fy, cx, cy, bf
     f.min_x, f.max_x, f.min_y, f.max_y = bounds
     f.log_scale_factor, f.n_scale_levels, f.viewing_cos_limit = log_scale_factor, n_scale_levels, viewing_cos_limit
+    if kb8 is not None:      # KannalaBrandt8 frame (monocular fisheye)
+        f.fisheye = 1
+        f.kb8[:] = [float(np.float32(k)) for k in kb8]
     return f
 
 

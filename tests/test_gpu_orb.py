@@ -146,7 +146,7 @@ def test_device_candidate_generation_equals_host_built_lists(hip_lib):
     assert (got["best_idx"][0] >= 0).sum() > 300 and (r == 0).any()
 
 
-def _frustum_scene(seed, n):
+def _frustum_scene(seed, n, kb8=None):
     """A camera with a random float32 pose and map points scattered so that every rejection branch is taken."""
     rng = np.random.Generator(np.random.PCG64(seed))
     a = rng.normal(size=4)
@@ -158,7 +158,7 @@ def _frustum_scene(seed, n):
     t = rng.normal(0, 1.0, 3).astype(np.float32)
     frame = orb.frustum_frame(R, t, float(synth.FX), float(synth.FY), float(synth.CX), float(synth.CY), float(synth.BF),
                               (0.0, float(synth.IMG_W), 0.0, float(synth.IMG_H)), float(np.log(np.float32(synth.SCALE_FACTOR))),
-                              synth.N_LEVELS)
+                              synth.N_LEVELS, kb8=kb8)
     # points in camera coordinates: mostly in front and inside the image, some behind / outside
     zc = rng.uniform(-2.0, 30.0, n)
     xc = rng.normal(0, 0.6, n) * np.abs(zc)
@@ -197,3 +197,18 @@ def test_frustum_empty_batch(matcher):
     frame, P, normal, min_d, max_d = _frustum_scene(4, 1)
     out = matcher.frustum(frame, P[:0], normal[:0], min_d[:0], max_d[:0])
     assert out["stage"].shape == (0,)
+
+
+def test_frustum_projection_fisheye_frame_bit_exact(matcher, ob):
+    """The same through KannalaBrandt8::project(Vector3f) (src/CameraModels/KannalaBrandt8.cpp:66-84), the camera of a monocular
+    fisheye frame."""
+    frame, P, normal, min_d, max_d = _frustum_scene(5, 20000, kb8=synth.KB8_K)
+    got = matcher.frustum(frame, P, normal, min_d, max_d)
+    ref = ob.frustum(frame, P, normal, min_d, max_d)
+    np.testing.assert_array_equal(got["stage"], ref["stage"])
+    np.testing.assert_array_equal(got["level"], ref["level"])
+    for k in ("proj_x", "proj_y", "proj_xr", "depth", "view_cos"):
+        np.testing.assert_array_equal(got[k].view(np.uint32), ref[k].view(np.uint32), err_msg=k)
+    pin = ob.frustum(_frustum_scene(5, 20000)[0], P, normal, min_d, max_d)
+    both = (ref["stage"] >= 1) & (pin["stage"] >= 1)
+    assert both.sum() > 2000 and np.abs(ref["proj_x"][both] - pin["proj_x"][both]).max() > 5.0      # a different camera model indeed
