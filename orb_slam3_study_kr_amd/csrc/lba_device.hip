@@ -102,8 +102,8 @@ struct BatchView {
   const int* e_pose;         // [NE] window-local pose index
   const int* e_point;        // [NE] window-local landmark index
   const unsigned char* e_kind;
-  const double* e_obs;       // [NE*3]
-  const double* e_info;      // [NE]
+  const double* e_rec;       // [NE*4] u v u_right invSigma2 of every sorted edge: one 32-byte record (the observation and its
+                             // weight are always read together; as two arrays they cost two partial cache lines per landmark)
   const int* e_orig;         // [NE] index in the caller's edge order
   const int* lm_off;         // per window L+1 offsets (window-local edge index)
   const int* lm_nfree;       // [NL] free-pose edges of each landmark
@@ -229,8 +229,8 @@ __global__ __launch_bounds__(kBlock) void k_residual(BatchView bv) {
 #pragma unroll
     for (int k = 0; k < 5; ++k) cam[k] = cams[(size_t)ip * 5 + k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { X[k] = pts[(size_t)il * 3 + k]; obs[k] = bv.e_obs[ge * 3 + k]; }
-    const double chi2 = win_edge_residual<KB8>(wd, kind, qt, cam, X, obs, bv.e_info[ge], r, Xc);
+    for (int k = 0; k < 3; ++k) { X[k] = pts[(size_t)il * 3 + k]; obs[k] = bv.e_rec[ge * 4 + k]; }
+    const double chi2 = win_edge_residual<KB8>(wd, kind, qt, cam, X, obs, bv.e_rec[ge * 4 + 3], r, Xc);
     double rho0, rho1;
     dev::huber(chi2, kind == OSH_EDGE_MONO ? wd.huber_mono : wd.huber_stereo, rho0, rho1);
     chi_acc += rho0;
@@ -571,9 +571,9 @@ __global__ __launch_bounds__(64, 2) void k_lin_items(BatchView bv) {
   auto load_in = [&](const Cur& cu, In& in) {
     const size_t ge = min((size_t)wd.edge_off + cu.e_first + (cu.xo != kAbsent ? (int)cu.xo : 0), last_edge);
     in.kind = bv.e_kind[ge];
-    in.info = bv.e_info[ge];
+    in.info = bv.e_rec[ge * 4 + 3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { in.X[k] = pts[(size_t)cu.lm * 3 + k]; in.obs[k] = bv.e_obs[ge * 3 + k]; }
+    for (int k = 0; k < 3; ++k) { in.X[k] = pts[(size_t)cu.lm * 3 + k]; in.obs[k] = bv.e_rec[ge * 4 + k]; }
   };
   auto process = [&](const Cur& cur, const In& inp) {
     const bool owner = (cur.flags & 1) != 0;
@@ -763,14 +763,14 @@ __global__ __launch_bounds__(64) void k_lin_aux(BatchView bv) {
     const size_t ge = (size_t)wd.edge_off + en.y;
     const int ip = bv.e_pose[ge];
     const int kind = bv.e_kind[ge];
-    const double info = bv.e_info[ge];
+    const double info = bv.e_rec[ge * 4 + 3];
     double qt[7], cam[5], X[3], obs[3], r[3], Xc[3];
 #pragma unroll
     for (int k = 0; k < 7; ++k) qt[k] = poses[(size_t)ip * 7 + k];
 #pragma unroll
     for (int k = 0; k < 5; ++k) cam[k] = cams[(size_t)ip * 5 + k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { X[k] = pts[(size_t)en.x * 3 + k]; obs[k] = bv.e_obs[ge * 3 + k]; }
+    for (int k = 0; k < 3; ++k) { X[k] = pts[(size_t)en.x * 3 + k]; obs[k] = bv.e_rec[ge * 4 + k]; }
     const double chi2 = win_edge_residual<KB8>(wd, kind, qt, cam, X, obs, info, r, Xc);
     double rho0, rho1;
     dev::huber(chi2, kind == OSH_EDGE_MONO ? wd.huber_mono : wd.huber_stereo, rho0, rho1);
@@ -966,7 +966,7 @@ __global__ __launch_bounds__(kBlock) void k_backsub(BatchView bv) {
       if (ip < wd.P) {
         const int il = bv.e_point[ge];
         const int kind = bv.e_kind[ge];
-        const double info = bv.e_info[ge];
+        const double info = bv.e_rec[ge * 4 + 3];
         double qt[7], R[9], cam[5], X[3], obs[3], r[3], Xc[3], JX[9], Jp[18];
 #pragma unroll
         for (int k = 0; k < 7; ++k) qt[k] = sh_pose[ip * kBsPoseStride + k];
@@ -975,7 +975,7 @@ __global__ __launch_bounds__(kBlock) void k_backsub(BatchView bv) {
 #pragma unroll
         for (int k = 0; k < 5; ++k) cam[k] = cams[(size_t)ip * 5 + k];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { X[k] = pts[(size_t)il * 3 + k]; obs[k] = bv.e_obs[ge * 3 + k]; }
+        for (int k = 0; k < 3; ++k) { X[k] = pts[(size_t)il * 3 + k]; obs[k] = bv.e_rec[ge * 4 + k]; }
         const double chi2 = win_edge_residual<KB8>(wd, kind, qt, cam, X, obs, info, r, Xc);
         double rho0, rho1;
         dev::huber(chi2, kind == OSH_EDGE_MONO ? wd.huber_mono : wd.huber_stereo, rho0, rho1);
@@ -1167,7 +1167,7 @@ __global__ __launch_bounds__(kBlock) void k_finalize(BatchView bv) {
 #pragma unroll
     for (int k = 0; k < 5; ++k) cam[k] = bv.pose_cam[((size_t)wd.pose_off + ip) * 5 + k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) obs[k] = bv.e_obs[ge * 3 + k];
+    for (int k = 0; k < 3; ++k) obs[k] = bv.e_rec[ge * 4 + k];
     double chi2 = 0.0;
     if (evaluated) {
       const int s = st.last_eval_sel;
@@ -1175,7 +1175,7 @@ __global__ __launch_bounds__(kBlock) void k_finalize(BatchView bv) {
       for (int k = 0; k < 7; ++k) qt[k] = bv.pose_state[s][((size_t)wd.pose_off + ip) * 7 + k];
 #pragma unroll
       for (int k = 0; k < 3; ++k) X[k] = bv.pt_state[s][((size_t)wd.pt_off + il) * 3 + k];
-      chi2 = win_edge_residual<KB8>(wd, kind, qt, cam, X, obs, bv.e_info[ge], r, Xc);
+      chi2 = win_edge_residual<KB8>(wd, kind, qt, cam, X, obs, bv.e_rec[ge * 4 + 3], r, Xc);
     }
     const int f = st.sel;
 #pragma unroll
@@ -1345,7 +1345,7 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   c->NP = NP; c->NFP = NFP; c->NL = NL; c->NE = NE; c->NEf = NEf; c->S_total = S_total; c->n_max = n_max;
 
   // ---- pass 2: build sorted structure
-  std::vector<double> h_pose(NP * 7), h_cam(NP * 5), h_pt(NL * 3), h_obs(NE * 3), h_info(NE);
+  std::vector<double> h_pose(NP * 7), h_cam(NP * 5), h_pt(NL * 3), h_rec(NE * 4);
   std::vector<int> h_epose(NE), h_epoint(NE), h_eorig(NE), h_lmoff(NLO), h_lmnfree(NL), h_peloff(NPO), h_pel(NEf), h_fpw(NFP);
   std::vector<unsigned char> h_kind(NE);
   std::vector<Chunk> h_chunks;
@@ -1404,8 +1404,8 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
       const int e = order[x];
       const size_t g = (size_t)d.edge_off + x;
       h_epose[g] = p.edge_pose[e]; h_epoint[g] = p.edge_point[e]; h_kind[g] = p.edge_kind[e]; h_eorig[g] = e;
-      h_info[g] = p.edge_info[e];
-      for (int k = 0; k < 3; ++k) h_obs[g * 3 + k] = p.edge_obs[3 * e + k];
+      h_rec[g * 4 + 3] = p.edge_info[e];
+      for (int k = 0; k < 3; ++k) h_rec[g * 4 + k] = p.edge_obs[3 * e + k];
     }
     // per-pose edge lists (landmark order)
     int* po = &h_peloff[d.peloff_off];
@@ -1509,8 +1509,7 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   OSH_TRY(upload_vec(c->d_e_pose, h_epose, s));
   OSH_TRY(upload_vec(c->d_e_point, h_epoint, s));
   OSH_TRY(upload_vec(c->d_e_kind, h_kind, s));
-  OSH_TRY(upload_vec(c->d_e_obs, h_obs, s));
-  OSH_TRY(upload_vec(c->d_e_info, h_info, s));
+  OSH_TRY(upload_vec(c->d_e_obs, h_rec, s));
   OSH_TRY(upload_vec(c->d_e_orig, h_eorig, s));
   OSH_TRY(upload_vec(c->d_lm_off, h_lmoff, s));
   OSH_TRY(upload_vec(c->d_lm_nfree, h_lmnfree, s));
@@ -1553,7 +1552,7 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   for (int k = 0; k < 2; ++k) { bv.pose_state[k] = c->d_pose[k].as<double>(); bv.pt_state[k] = c->d_pt[k].as<double>(); }
   bv.pose_cam = c->d_cam.as<double>();
   bv.e_pose = c->d_e_pose.as<int>(); bv.e_point = c->d_e_point.as<int>(); bv.e_kind = c->d_e_kind.as<unsigned char>();
-  bv.e_obs = c->d_e_obs.as<double>(); bv.e_info = c->d_e_info.as<double>(); bv.e_orig = c->d_e_orig.as<int>();
+  bv.e_rec = c->d_e_obs.as<double>(); bv.e_orig = c->d_e_orig.as<int>();
   bv.lm_off = c->d_lm_off.as<int>(); bv.lm_nfree = c->d_lm_nfree.as<int>();
   bv.pel_off = c->d_pel_off.as<int>(); bv.pel_edge = c->d_pel_edge.as<int>();
   bv.sitems = c->d_sitems.as<SItem>(); bv.srecs = c->d_srecs.as<SRec>(); bv.spair = c->d_spair.as<int>(); bv.scslot = c->d_scslot.as<int>();
