@@ -36,6 +36,7 @@ namespace osh {
 
 constexpr int kBlock = 256;        // threads per block of the edge/landmark kernels
 constexpr int kChunkEdges = 256;   // edges handled per pass of a chunk (== kBlock)
+constexpr int kResidualSplit = 4;    // blocks of k_residual per chunk (kChunkMaxEdges / kChunkEdges)
 constexpr int kChunkMaxEdges = 1024;   // edges of one chunk (= one block of k_residual / k_backsub / k_finalize): four passes amortise
                                        // the per-block staging of the window's poses and x_p in k_backsub
 constexpr double kTau = 1e-5;      // OptimizationAlgorithmLevenberg::_tau
@@ -137,7 +138,7 @@ struct BatchView {
   double* S;                 // per window (6P)^2, upper triangle valid
   double* bs;                // [NFP*6]
   double* xp;                // [NFP*6]
-  double* chi_part;          // [n_chunks]
+  double* chi_part;          // [n_chunks * kResidualSplit]
   double* scale_part;        // [n_chunks]
   double* dmax_pose;         // [NFP]
   int* n_active;             // [1]
@@ -208,7 +209,10 @@ __device__ __forceinline__ void win_edge_jacobians(const WinDesc& wd, int kind, 
 template <bool KB8>
 __global__ __launch_bounds__(kBlock) void k_residual(BatchView bv) {
   __shared__ double sh4[4];
-  const Chunk ch = bv.chunks[blockIdx.x];
+  // kResidualSplit blocks per chunk (a chunk holds up to kChunkMaxEdges edges for k_backsub's sake): block q takes the passes
+  // q, q + kResidualSplit, ... of the chunk, so every edge still has its own lane in the common case
+  const Chunk ch = bv.chunks[blockIdx.x / kResidualSplit];
+  const int q = blockIdx.x % kResidualSplit;
   const WinDesc wd = bv.win[ch.win];   // by value: the fields stay in SGPRs across the kernel's stores
   const LmView st = lm_view(bv.lm, ch.win);
   if (!st.active) return;
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(kBlock) void k_residual(BatchView bv) {
   const int* lmo = bv.lm_off + wd.lmoff_off;
   const int e0 = lmo[ch.lm0], e1 = lmo[ch.lm1];
   double chi_acc = 0.0;
-  for (int e = e0 + threadIdx.x; e < e1; e += kBlock) {
+  for (int e = e0 + q * kBlock + threadIdx.x; e < e1; e += kResidualSplit * kBlock) {
     const size_t ge = (size_t)wd.edge_off + e;
     const int ip = bv.e_pose[ge], il = bv.e_point[ge];
     const int kind = bv.e_kind[ge];
@@ -1051,7 +1055,7 @@ __global__ __launch_bounds__(64) void k_control(BatchView bv, int phase) {
     for (int c = lane; c < wd.n_sitems; c += 64) chi += bv.chi_item[wd.sitem_off + c];
     for (int c = lane; c < wd.n_aux; c += 64) chi += bv.chi_aux[wd.aux_off + c];
   }
-  else { for (int c = lane; c < wd.n_chunks; c += 64) chi += bv.chi_part[wd.chunk_off + c]; }
+  else { for (int c = lane; c < wd.n_chunks * kResidualSplit; c += 64) chi += bv.chi_part[(size_t)wd.chunk_off * kResidualSplit + c]; }
   chi = dev::wave_sum(chi);
   if (phase == 0) {
     if (!st.need_lin) return;
@@ -1534,7 +1538,7 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   OSH_TRY(R(c->d_Hpl, NE * 18 * 8)); OSH_TRY(R(c->d_Hll, NL * 6 * 8)); OSH_TRY(R(c->d_bl, NL * 3 * 8));
   OSH_TRY(R(c->d_Hpp, NFP * 36 * 8)); OSH_TRY(R(c->d_bp, NFP * 6 * 8)); OSH_TRY(R(c->d_S, S_total * 8));
   OSH_TRY(R(c->d_bs, NFP * 6 * 8)); OSH_TRY(R(c->d_xp, NFP * 6 * 8));
-  OSH_TRY(R(c->d_chi, c->n_chunks * 8)); OSH_TRY(R(c->d_scale, c->n_chunks * 8));
+  OSH_TRY(R(c->d_chi, c->n_chunks * kResidualSplit * 8)); OSH_TRY(R(c->d_scale, c->n_chunks * 8));
   OSH_TRY(R(c->d_dmaxp, NFP * 8)); OSH_TRY(R(c->d_nactive, sizeof(int)));
   OSH_TRY(R(c->d_out_chi2, NE * 8)); OSH_TRY(R(c->d_out_depth, NE)); OSH_TRY(R(c->d_stop, nw));
   if (c->h_stop_cap < (size_t)nw) {
@@ -1676,7 +1680,7 @@ extern "C" int osh_lba_optimize(osh_lba_ctx* c) {
       if (_t) c->timer.end(s);
     }
     LAUNCH(OSH_K_BACKSUB, c->kp_backsub, c->n_chunks, kBlock, c->backsub_lds, c->bv);
-    LAUNCH(OSH_K_RESIDUAL, c->kp_residual, c->n_chunks, kBlock, 0, c->bv);
+    LAUNCH(OSH_K_RESIDUAL, c->kp_residual, c->n_chunks * kResidualSplit, kBlock, 0, c->bv);
     if (c->any_stop) {
       // terminate() is polled after every trial (levenberg.cpp:149) and before every iteration
       snapshot_stop(c);
