@@ -1480,9 +1480,10 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   // ---- LDS budgets
   c->backsub_lds = (size_t)(3 * kChunkEdges + 4 + std::max(n_max, 1) + (std::max(n_max, 6) / 6) * kBsPoseStride) * sizeof(double);
   {
-    // Many windows: two 256-thread blocks per CU (75 KB each) as long as that leaves a panel width of at least 12 columns.
-    // Fewer windows than half the CUs: one 512-thread block per window with the widest panel that fits.
-    const bool latency = nw <= 128;
+    // One 512-thread block per window with the widest panel that fits (one block per CU).  Two 256-thread blocks per CU with
+    // 12-wide panels used to win for batches (their pivot-chain latencies overlapped); since the factorisation was rewritten the
+    // wide panel is faster there too (halves the trailing-update traffic: 0.80 -> 0.66 ms per 512 windows), so it is used always.
+    const bool latency = true;
     c->solve_threads = latency ? kSolveThreadsLatency : kSolveThreadsBatch;
     auto need = [&](int b) { return ldlt_lds_doubles(b, ldlt_row_stride(n_max), c->solve_threads) * sizeof(double); };
     int nb = 0;
