@@ -23,6 +23,10 @@
 //   k_finalize    per-edge chi2 / isDepthPositive for the outlier test, src/Optimizer.cc:1413-1460
 #include "common.h"
 #include <type_traits>
+#include <cstdlib>
+#include <cstdio>
+#include <atomic>
+#include <thread>
 #include "lba_math.h"
 #include "ldlt_block.h"
 #include "schur_plan.h"
@@ -1358,8 +1362,20 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   std::vector<int2> h_aux_entries;
   std::vector<plan_detail::Build> builds;
   std::vector<int> build_win;
-  std::vector<int> cnt, fill, order;
-  for (int w = 0; w < nw; ++w) {
+  // The windows are independent: every window is packed by one host thread into its own slices of the flat arrays (offsets
+  // from pass 1) and into window-local lists, which are merged in window order afterwards (contribution slots rebased).
+  struct WinLocal {
+    std::vector<Chunk> chunks;
+    std::vector<int4> aux_chunks;
+    std::vector<int2> aux_entries;
+    std::vector<plan_detail::Build> builds;
+    SchurPlan plan;
+    int err = OSH_OK;
+    char msg[320];
+  };
+  std::vector<WinLocal> locals(nw);
+  auto pack_window = [&](int w, std::vector<int>& cnt, std::vector<int>& fill, std::vector<int>& order) {
+    WinLocal& L = locals[w];
     const osh_lba_problem& p = pr[w];
     WinDesc& d = c->h_win[w];
     const int NPw = p.n_free + p.n_fixed;
@@ -1397,9 +1413,10 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
       for (int x = lo; x < hi; ++x) {
         if (p.edge_pose[order[x]] < p.n_free) ++nf;
         if (x > lo && p.edge_pose[order[x]] == p.edge_pose[order[x - 1]]) {
-          set_error("window %d: landmark %d is observed twice by pose %d (two edges on one Hessian block); "
-                    "not supported by the device path yet", w, j, p.edge_pose[order[x]]);
-          return OSH_ERR_UNSUPPORTED;
+          std::snprintf(L.msg, sizeof(L.msg), "window %d: landmark %d is observed twice by pose %d (two edges on one Hessian block); "
+                        "not supported by the device path yet", w, j, p.edge_pose[order[x]]);
+          L.err = OSH_ERR_UNSUPPORTED;
+          return;
         }
       }
       h_lmnfree[(size_t)d.pt_off + j] = nf;
@@ -1423,42 +1440,78 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
     }
     // Schur work plan: landmarks grouped by observer set (schur_plan.h)
     {
-      const size_t b0 = builds.size();
-      if (!plan_window(w, p.n_free, p.n_points, lmo, &h_lmnfree[(size_t)d.pt_off], &h_epose[(size_t)d.edge_off], builds, plan)) {
-        set_error("window %d: a landmark has more than 254 optimisable observers", w);
-        return OSH_ERR_UNSUPPORTED;
+      if (!plan_window(w, p.n_free, p.n_points, lmo, &h_lmnfree[(size_t)d.pt_off], &h_epose[(size_t)d.edge_off], L.builds, L.plan)) {
+        std::snprintf(L.msg, sizeof(L.msg), "window %d: a landmark has more than 254 optimisable observers", w);
+        L.err = OSH_ERR_UNSUPPORTED;
+        return;
       }
-      build_win.resize(builds.size(), w);
-      (void)b0;
     }
     // k_lin_aux work list: per landmark the edges beyond its first 8 optimisable observers (fixed keyframes included)
     {
-      d.aux_off = (int)h_aux_chunks.size();
-      int first = (int)h_aux_entries.size(), n = 0;
-      auto close = [&]() { if (n > 0) h_aux_chunks.push_back(make_int4(w, first, n, 0)); first = (int)h_aux_entries.size(); n = 0; };
+      int first = 0, n = 0;   // entry indices are window-local here and rebased when the windows are merged
+      auto close = [&]() { if (n > 0) L.aux_chunks.push_back(make_int4(w, first, n, 0)); first = (int)L.aux_entries.size(); n = 0; };
       for (int j = 0; j < p.n_points; ++j) {
         const int n0 = std::min(h_lmnfree[(size_t)d.pt_off + j], kItemPoses);
         const int cnt_j = (lmo[j + 1] - lmo[j]) - n0;
         if (cnt_j <= 0) continue;
         if (n + cnt_j > 64) close();
-        for (int x = lmo[j] + n0; x < lmo[j + 1]; ++x) h_aux_entries.push_back(make_int2(j, x));
+        for (int x = lmo[j] + n0; x < lmo[j + 1]; ++x) L.aux_entries.push_back(make_int2(j, x));
         n += cnt_j;
         if (n >= 64) close();
       }
       close();
-      d.n_aux = (int)h_aux_chunks.size() - d.aux_off;
     }
     // chunks: consecutive landmarks, <= kChunkMaxEdges edges and <= kBlock landmarks (a single
     // landmark with more edges gets its own multi-pass chunk)
-    d.chunk_off = (int)h_chunks.size();
     int j = 0;
     while (j < p.n_points) {
       int j1 = j + 1;
       while (j1 < p.n_points && (j1 - j) < kBlock && (lmo[j1 + 1] - lmo[j]) <= kChunkMaxEdges) ++j1;
-      h_chunks.push_back(Chunk{w, j, j1});
+      L.chunks.push_back(Chunk{w, j, j1});
       j = j1;
     }
-    d.n_chunks = (int)h_chunks.size() - d.chunk_off;
+    };
+  {
+    int n_threads = 1;
+    if (nw > 1) {
+      const char* env = std::getenv("ORBSLAM3_HIP_UPLOAD_THREADS");
+      const unsigned hw = std::thread::hardware_concurrency();
+      n_threads = env ? std::atoi(env) : (int)std::min<unsigned>(hw ? hw : 1u, 16u);
+      n_threads = std::max(1, std::min(n_threads, nw));
+    }
+    std::atomic<int> next{0};
+    auto worker = [&]() {
+      std::vector<int> cnt, fill, order;
+      for (int w = next.fetch_add(1); w < nw; w = next.fetch_add(1)) pack_window(w, cnt, fill, order);
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_threads; ++t) pool.emplace_back(worker);
+    worker();
+    for (std::thread& t : pool) t.join();
+  }
+  for (int w = 0; w < nw; ++w) {
+    WinLocal& L = locals[w];
+    if (L.err != OSH_OK) { set_error("%s", L.msg); return L.err; }
+    WinDesc& d = c->h_win[w];
+    d.chunk_off = (int)h_chunks.size();
+    h_chunks.insert(h_chunks.end(), L.chunks.begin(), L.chunks.end());
+    d.n_chunks = (int)L.chunks.size();
+    d.aux_off = (int)h_aux_chunks.size();
+    const int base_e = (int)h_aux_entries.size();
+    for (int4 ch : L.aux_chunks) { ch.y += base_e; h_aux_chunks.push_back(ch); }
+    h_aux_entries.insert(h_aux_entries.end(), L.aux_entries.begin(), L.aux_entries.end());
+    d.n_aux = (int)L.aux_chunks.size();
+    const int base_c = (int)plan.n_contrib, base_cc = (int)plan.n_ccontrib;
+    for (RBlk rb : L.plan.rblk) { rb.start += (((rb.ij >> 16) & 0xffff) == 0xffff) ? base_cc : base_c; plan.rblk.push_back(rb); }
+    for (plan_detail::Build& bd : L.builds) {
+      for (int k = 0; k < 64; ++k) if (bd.pair_slot[k] >= 0) bd.pair_slot[k] += base_c;
+      for (int k = 0; k < 8; ++k) if (bd.c_slot[k] >= 0) bd.c_slot[k] += base_cc;
+      builds.push_back(std::move(bd));
+      build_win.push_back(w);
+    }
+    plan.n_contrib += L.plan.n_contrib; plan.n_ccontrib += L.plan.n_ccontrib;
+    plan.tile_steps += L.plan.tile_steps; plan.pair_blocks += L.plan.pair_blocks;
+    L = WinLocal();
   }
   c->n_chunks = h_chunks.size();
   finish_plan(build_win, builds, plan);
