@@ -325,7 +325,7 @@ def main():
                    "parallelism": f"independent windows, w mod {n_gpus}", "lm_iterations_mean": float(np.mean([r.iterations for r in res])),
                    "lm_trials_mean": float(np.mean([r.trials for r in res]))},
         "roofline": roofline,
-        "kernels": kernels, "steps": steps,
+        "kernels": kernels, "step_times": steps,
         "whole_job_alg_GBps_per_gpu": whole_bytes / (ms_per_step * 1e-3) / 1e9,
         "upload_s_per_batch": lba_out["upload_s"],
     }
