@@ -66,6 +66,39 @@ class State:
         self.X = self.X + x[6 * self.P:].reshape(-1, 3)
 
 
+def kb8_edge_error(T, cam, kb, X, obs):
+    """Monocular edge through KannalaBrandt8::project(Vector3d) (src/CameraModels/KannalaBrandt8.cpp:45-63): theta and psi are
+    float32 values there (atan2f / sqrtf on double arguments); float32 atan2 is taken as the correctly rounded value."""
+    fx, fy, cx, cy = cam[:4]
+    Xc = T[:3, :3] @ X + T[:3, 3]
+    rho = np.float32(np.sqrt(np.float32(Xc[0] * Xc[0] + Xc[1] * Xc[1])))
+    theta = float(np.float32(np.arctan2(float(rho), float(np.float32(Xc[2])))))
+    psi = float(np.float32(np.arctan2(float(np.float32(Xc[1])), float(np.float32(Xc[0])))))
+    r = theta + kb[0] * theta**3 + kb[1] * theta**5 + kb[2] * theta**7 + kb[3] * theta**9
+    return np.array([obs[0] - (fx * r * np.cos(psi) + cx), obs[1] - (fy * r * np.sin(psi) + cy)])
+
+
+def kb8_analytic_jacobians(T, cam, kb, X):
+    """Chain rule on u = fx r(theta) x / rho + cx, v = fy r(theta) y / rho + cy with theta = atan2(rho, z), rho = |(x, y)|
+    (an independent derivation; the reference's closed form is KannalaBrandt8::projectJac, KannalaBrandt8.cpp:147-175)."""
+    fx, fy = cam[0], cam[1]
+    R = T[:3, :3]
+    Xc = R @ X + T[:3, 3]
+    x, y, z = Xc
+    rho = np.hypot(x, y)
+    theta = np.arctan2(rho, z)
+    r = theta + kb[0] * theta**3 + kb[1] * theta**5 + kb[2] * theta**7 + kb[3] * theta**9
+    dr = 1 + 3 * kb[0] * theta**2 + 5 * kb[1] * theta**4 + 7 * kb[2] * theta**6 + 9 * kb[3] * theta**8
+    d2 = rho * rho + z * z
+    dtheta = np.array([z * x / (rho * d2), z * y / (rho * d2), -rho / d2])
+    dcos = np.array([1 / rho - x * x / rho**3, -x * y / rho**3, 0.0])      # d(x / rho)
+    dsin = np.array([-x * y / rho**3, 1 / rho - y * y / rho**3, 0.0])      # d(y / rho)
+    dpi = np.vstack([fx * (dr * dtheta * x / rho + r * dcos), fy * (dr * dtheta * y / rho + r * dsin)])
+    J_X = -dpi @ R
+    J_xi = -dpi @ np.hstack([-hat(Xc), np.eye(3)])
+    return J_X, J_xi
+
+
 def edge_error(kind, T, cam, X, obs):
     """obs - projection.  The stereo residual reproduces the float32 1/z and bf
     of g2o::EdgeStereoSE3ProjectXYZ::cam_project (types_six_dof_expmap.cpp:190-197)."""
@@ -138,7 +171,10 @@ def errors(w, st):
     out = []
     for e in range(w.n_edges):
         ip, il = w.edge_pose[e], w.edge_point[e]
-        out.append(edge_error(w.edge_kind[e], st.T[ip], w.pose_cam[ip], st.X[il], w.edge_obs[e]))
+        if getattr(w, "kb8", None) is not None and w.edge_kind[e] == MONO:
+            out.append(kb8_edge_error(st.T[ip], w.pose_cam[ip], w.kb8, st.X[il], w.edge_obs[e]))
+        else:
+            out.append(edge_error(w.edge_kind[e], st.T[ip], w.pose_cam[ip], st.X[il], w.edge_obs[e]))
     return out
 
 
@@ -163,7 +199,10 @@ def build_dense_system(w, st, errs):
         ip, il = w.edge_pose[e], w.edge_point[e]
         kind = w.edge_kind[e]
         r = errs[e]
-        J_X, J_xi = analytic_jacobians(kind, st.T[ip], w.pose_cam[ip], st.X[il])
+        if getattr(w, "kb8", None) is not None and kind == MONO:
+            J_X, J_xi = kb8_analytic_jacobians(st.T[ip], w.pose_cam[ip], w.kb8, st.X[il])
+        else:
+            J_X, J_xi = analytic_jacobians(kind, st.T[ip], w.pose_cam[ip], st.X[il])
         info = w.edge_info[e]
         c = float(r @ (info * r))
         delta = w.huber_mono if kind == MONO else w.huber_stereo

@@ -24,7 +24,8 @@ def window_arrays(w):
     return dict(n_free=w.n_free, n_fixed=w.n_fixed, pose_qt=w.pose_qt, pose_cam=w.pose_cam, points=w.points,
                 edge_pose=w.edge_pose, edge_point=w.edge_point, edge_kind=w.edge_kind, edge_obs=w.edge_obs,
                 edge_info=w.edge_info, huber_mono=w.huber_mono, huber_stereo=w.huber_stereo,
-                lambda_init=w.lambda_init, max_iterations=w.max_iterations)
+                lambda_init=w.lambda_init, max_iterations=w.max_iterations,
+                kb8=w.kb8 if w.kb8 is not None else np.zeros(0))
 
 
 def lba_fixture(name, w):
@@ -65,4 +66,6 @@ if __name__ == "__main__":
     rej = dict(n_free=3, n_fixed=2, n_points=40, track_len=(2, 5), pose_noise=(0.08, 0.4), point_noise=1.5, lambda_init=1e-4)
     lba_fixture("lba_tiny_reject_stereo", synth.make_window(40, stereo=True, **rej))
     lba_fixture("lba_tiny_reject_mono", synth.make_window(51, stereo=False, **rej))
+    # monocular KannalaBrandt8 (fisheye) window: the independent numpy model of oracle/lm_numpy.py (own Jacobian derivation)
+    lba_fixture("lba_tiny_fisheye", synth.make_window(61, n_free=3, n_fixed=2, n_points=40, stereo=False, track_len=(2, 5), fisheye=True))
     orb_fixture()

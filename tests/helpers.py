@@ -6,7 +6,7 @@ import numpy as np
 from orb_slam3_study_kr_amd import synth
 
 GOLDEN = Path(__file__).resolve().parent / "golden"
-LBA_FIXTURES = ["lba_tiny_mono", "lba_tiny_stereo", "lba_tiny_mixed", "lba_tiny_reject_stereo", "lba_tiny_reject_mono"]
+LBA_FIXTURES = ["lba_tiny_mono", "lba_tiny_stereo", "lba_tiny_mixed", "lba_tiny_reject_stereo", "lba_tiny_reject_mono", "lba_tiny_fisheye"]
 
 
 def load_lba_fixture(name):
@@ -16,7 +16,8 @@ def load_lba_fixture(name):
         points=z["points"], edge_pose=z["edge_pose"], edge_point=z["edge_point"], edge_kind=z["edge_kind"],
         edge_obs=z["edge_obs"], edge_info=z["edge_info"], huber_mono=float(z["huber_mono"]),
         huber_stereo=float(z["huber_stereo"]), lambda_init=float(z["lambda_init"]),
-        max_iterations=int(z["max_iterations"])).normalise()
+        max_iterations=int(z["max_iterations"]),
+        kb8=(z["kb8"] if "kb8" in z.files and z["kb8"].size == 4 else None)).normalise()
     return w, z
 
 
