@@ -26,6 +26,7 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 from orb_slam3_study_kr_amd import dist as osh_dist  # noqa: E402
+from orb_slam3_study_kr_amd import launch as osh_launch  # noqa: E402
 from orb_slam3_study_kr_amd import synth  # noqa: E402
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (= vector) peak, AMD product figure; v_mfma_f64_16x16x4 measured at 64 cycles
@@ -73,7 +74,7 @@ def make_lba_inputs(args, rank, world):
     """Pure-numpy input generation; runs BEFORE anything touches the GPU (it forks worker processes)."""
     my = osh_dist.shard_indices(args.windows * world, rank, world)   # window w -> rank w mod G
     seeds = [100 + w for w in my]
-    cache = Path(args.cache_inputs) if args.cache_inputs else None
+    cache = Path(args.cache_inputs + (f".rank{rank}" if world > 1 else "")) if args.cache_inputs else None   # one file per rank
     if cache is not None and cache.exists():
         import pickle
         with open(cache, "rb") as f:          # written by this script (own file), see --prepare-only
@@ -247,6 +248,29 @@ def cpu_baseline(windows, budget_s=12.0):
                 march="native" if native else "x86-64-v3")
 
 
+def stub_main(args):
+    """The rank plumbing of main() with the solver stubbed out (tests/test_bench_launch_cpu.py, gloo on CPU): same
+    sharding, barriers, max-over-ranks timing and rank-0 JSON line; a step is a 10 ms sleep."""
+    info = osh_dist.init_from_env(backend="gloo")
+    osh_launch.check_world(args.gpus, info.world)
+    my = osh_dist.shard_indices(args.windows * info.world, info.rank, info.world)
+    for _ in range(args.warmup):
+        time.sleep(0.01)
+    osh_dist.barrier(info)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.01)
+    osh_dist.barrier(info)
+    elapsed = osh_dist.all_reduce_max(info, time.perf_counter() - t0)
+    done = osh_dist.all_reduce_sum(info, [float(len(my))])[0]
+    if info.rank == 0:
+        ms = elapsed / args.steps * 1e3
+        print(json.dumps({"metric": "stub", "stub": True, "value": done / (ms * 1e-3), "unit": "windows/s", "n_gpus": info.world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "scaling": "weak",
+                          "config": {"windows_per_gpu": args.windows, "global_windows": int(done)}}))
+    osh_dist.finalize(info)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -262,16 +286,24 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-orb", action="store_true")
     ap.add_argument("--inertial-windows", type=int, default=128, help="config-4 windows per osh_liba_solve call (0 = skip)")
+    ap.add_argument("--stub-solver", action="store_true", help="CPU rehearsal of the rank plumbing (gloo): no GPU work, the "
+                    "timed step is a fixed sleep; the JSON line is marked \"stub\" and is not a measurement")
     args = ap.parse_args()
 
+    if osh_launch.needs_spawn(args.gpus):
+        # `python bench.py --gpus N` outside a rendezvous: start the N ranks as a CHILD process (never exec; this parent
+        # has not touched the GPU) and hand its exit code back
+        raise SystemExit(osh_launch.spawn_ranks(str(Path(__file__).resolve()), args.gpus, sys.argv[1:]))
     env_rank, env_world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    osh_launch.check_world(args.gpus, env_world)
+    if args.stub_solver:
+        return stub_main(args)
     windows = make_lba_inputs(args, env_rank, env_world)
     if args.prepare_only:
         return
     inertial_windows = make_inertial_inputs(args) if args.inertial_windows > 0 else None
     info = osh_dist.init_from_env()
-    if info.world != args.gpus and info.rank == 0 and info.world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={info.world}", file=sys.stderr)
+    osh_launch.check_world(args.gpus, info.world)
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
