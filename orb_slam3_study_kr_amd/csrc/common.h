@@ -25,6 +25,10 @@ const char* get_error();
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }   // owners that live in thread_local storage give their memory back when the thread exits
   int reserve(size_t bytes) {
     if (bytes <= cap) return OSH_OK;
     if (p) { (void)hipFree(p); p = nullptr; cap = 0; }

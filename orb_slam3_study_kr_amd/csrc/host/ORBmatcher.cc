@@ -39,16 +39,21 @@ float ORBmatcher::RadiusByViewingCos(const float& viewCos) { return viewCos > 0.
 
 namespace {
 
+struct ThreadCtx {   // destroyed at thread exit (Tracking / LoopClosing threads come and go with System instances)
+  osh_orb_ctx* ctx = nullptr;
+  ~ThreadCtx() { if (ctx) osh_orb_destroy(ctx); }
+};
+
 osh_orb_ctx* thread_ctx() {
-  static thread_local osh_orb_ctx* ctx = nullptr;
-  if (!ctx) {
+  static thread_local ThreadCtx holder;
+  if (!holder.ctx) {
     const char* dev = std::getenv("ORBSLAM3_HIP_DEVICE");
-    if (osh_orb_create(dev ? std::atoi(dev) : 0, &ctx) != OSH_OK) {
+    if (osh_orb_create(dev ? std::atoi(dev) : 0, &holder.ctx) != OSH_OK) {
       std::fprintf(stderr, "ORBmatcher: cannot create the HIP matcher context: %s\n", osh_last_error());
-      ctx = nullptr;
+      holder.ctx = nullptr;
     }
   }
-  return ctx;
+  return holder.ctx;
 }
 
 }  // namespace

@@ -21,17 +21,24 @@ namespace ORB_SLAM3 {
 
 namespace {
 
+// One solver context (HIP stream + reusable device buffers) per calling thread, destroyed when the thread exits: the reference
+// runs every GlobalBundleAdjustment in a freshly created std::thread (LoopClosing), so a context that outlived its thread would
+// leak a stream, pinned memory and the largest device buffers of the process per loop closure.
+struct ThreadCtx {
+  osh_lba_ctx* ctx = nullptr;
+  ~ThreadCtx() { if (ctx) osh_lba_destroy(ctx); }
+};
+
 osh_lba_ctx* thread_ctx() {
-  // one solver context (HIP stream + reusable device buffers) per calling thread; LocalMapping is one thread
-  static thread_local osh_lba_ctx* ctx = nullptr;
-  if (!ctx) {
+  static thread_local ThreadCtx holder;
+  if (!holder.ctx) {
     const char* dev = std::getenv("ORBSLAM3_HIP_DEVICE");
-    if (osh_lba_create(dev ? std::atoi(dev) : 0, &ctx) != OSH_OK) {
+    if (osh_lba_create(dev ? std::atoi(dev) : 0, &holder.ctx) != OSH_OK) {
       std::fprintf(stderr, "LM-LBA: cannot create the HIP solver context: %s\n", osh_last_error());
-      ctx = nullptr;
+      holder.ctx = nullptr;
     }
   }
-  return ctx;
+  return holder.ctx;
 }
 
 }  // namespace

@@ -105,6 +105,27 @@ void PackBundleAdjustment(const std::vector<KeyFrame*>& vpKFs, const std::vector
   pk.camera_models_ok();
 }
 
+// Failure at the boundary must be SAFE for the reference caller: LoopClosing::RunGlobalBundleAdjustment
+// (src/LoopClosing.cc:2330-2386) starts from the origin keyframes' mTcwGBA, propagates `Tchildc * pKF->mTcwGBA` down the
+// spanning tree to every keyframe whose mnBAGlobalForKF != nLoopKF and then calls SetPose(mTcwGBA) / SetWorldPos(mPosGBA).
+// When the device path cannot produce a result, the IDENTITY result is written (mTcwGBA = current pose, mPosGBA = current
+// position, both stamped with nLoopKF), so that propagation is a no-op instead of reading stale or default members.  In the
+// origin case (nLoopKF == origin keyframe) the reference writes poses directly and leaving them as they are is the no-op.
+static void WriteIdentityGBA(const std::vector<KeyFrame*>& vpKFs, const std::vector<MapPoint*>& vpMP, Map* pMap,
+                             const unsigned long nLoopKF) {
+  if (nLoopKF == pMap->GetOriginKF()->mnId) return;
+  for (KeyFrame* pKF : vpKFs) {
+    if (!pKF || pKF->isBad()) continue;
+    pKF->mTcwGBA = pKF->GetPose();
+    pKF->mnBAGlobalForKF = nLoopKF;
+  }
+  for (MapPoint* pMP : vpMP) {
+    if (!pMP || pMP->isBad()) continue;
+    pMP->mPosGBA = pMP->GetWorldPos();
+    pMP->mnBAGlobalForKF = nLoopKF;
+  }
+}
+
 void Optimizer::GlobalBundleAdjustemnt(Map* pMap, int nIterations, bool* pbStopFlag, const unsigned long nLoopKF, const bool bRobust) {
   std::vector<KeyFrame*> vpKFs = pMap->GetAllKeyFrames();
   std::vector<MapPoint*> vpMP = pMap->GetAllMapPoints();
@@ -118,11 +139,12 @@ void Optimizer::BundleAdjustment(const std::vector<KeyFrame*>& vpKFs, const std:
   PackBundleAdjustment(vpKFs, vpMP, pk, vbNotIncludedMP);
   Map* pMap = vpKFs[0]->GetMap();
   if (pk.unsupported) {
-    std::fprintf(stderr, "BA: %s is not supported by the MI355X path yet; map left untouched\n", pk.unsupported);
+    std::fprintf(stderr, "BA: %s is not supported by the MI355X path yet; identity result written\n", pk.unsupported);
+    WriteIdentityGBA(vpKFs, vpMP, pMap, nLoopKF);
     return;
   }
   osh_lba_ctx* ctx = HostSolverContext();
-  if (!ctx) return;
+  if (!ctx) { WriteIdentityGBA(vpKFs, vpMP, pMap, nLoopKF); return; }
   osh_lba_problem prob;
   pk.fill(prob);
   // const float thHuber2D = sqrt(5.99); const float thHuber3D = sqrt(7.815) (:130-131); no kernel at all unless bRobust
@@ -135,7 +157,8 @@ void Optimizer::BundleAdjustment(const std::vector<KeyFrame*>& vpKFs, const std:
   osh_lba_result res;
   res.pose_qt = out_pose.data(); res.points = out_pts.data(); res.edge_chi2 = nullptr; res.edge_depth_pos = nullptr;
   if (osh_lba_solve(ctx, 1, &prob, &res) != OSH_OK) {
-    std::fprintf(stderr, "BA: device solve failed (%s); map left untouched\n", osh_last_error());
+    std::fprintf(stderr, "BA: device solve failed (%s); identity result written\n", osh_last_error());
+    WriteIdentityGBA(vpKFs, vpMP, pMap, nLoopKF);
     return;
   }
   // keyframes (:303-379).  The statistics block for keyframes that moved by more than 1 m (:323-377) has no side effect.

@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <atomic>
+#include <mutex>
 #include <thread>
 #include "lba_math.h"
 #include "ldlt_block.h"
@@ -1298,7 +1299,7 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   OSH_HIP(hipSetDevice(c->device));
   OSH_HIP(hipStreamSynchronize(c->stream));
   c->optimized = false;
-  c->n_windows = nw;
+  c->n_windows = 0;                  // stays 0 (nothing uploaded) unless this upload completes
   c->h_win.assign(nw, WinDesc{});
   c->stop_ptr.assign(nw, nullptr);
   c->any_stop = false;
@@ -1638,17 +1639,20 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
     c->kp_residual = k_residual<false>; c->kp_finalize = k_finalize<false>; c->kp_backsub = k_backsub<false>;
   }
 
-  // opt in to large dynamic LDS once per process
-  static bool attr_done = false;
-  if (!attr_done) {
+  // opt in to large dynamic LDS: the attribute is per device, so once per device of the process
+  static std::mutex attr_mu;
+  static std::vector<int> attr_devices;
+  std::lock_guard<std::mutex> attr_lock(attr_mu);
+  if (std::find(attr_devices.begin(), attr_devices.end(), c->device) == attr_devices.end()) {
 #define OSH_SOLVE_ATTR(NB, NT) OSH_HIP(hipFuncSetAttribute((const void*)k_solve<NB, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64))
     OSH_SOLVE_ATTR(24, kSolveThreadsBatch); OSH_SOLVE_ATTR(12, kSolveThreadsBatch); OSH_SOLVE_ATTR(6, kSolveThreadsBatch);
     OSH_SOLVE_ATTR(24, kSolveThreadsLatency); OSH_SOLVE_ATTR(12, kSolveThreadsLatency); OSH_SOLVE_ATTR(6, kSolveThreadsLatency);
 #undef OSH_SOLVE_ATTR
     OSH_HIP(hipFuncSetAttribute((const void*)k_backsub<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     OSH_HIP(hipFuncSetAttribute((const void*)k_backsub<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-    attr_done = true;
+    attr_devices.push_back(c->device);
   }
+  c->n_windows = nw;
   return OSH_OK;
 }
 

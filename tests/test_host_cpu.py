@@ -101,3 +101,28 @@ def test_global_ba_pack_selects_every_keyframe_and_skips_bad_and_unobserved_poin
         pw3, o3 = g.packed_global_window()
         assert o3["n_not_included"] >= 1 and int(g.mp_id[7]) not in set(o3["point_mp_id"].tolist())
         assert pw3.n_free + pw3.n_fixed == w.n_free + w.n_fixed - len(obs7)
+
+
+def test_gba_failure_writes_the_identity_result():
+    """When the device solve cannot run (no GPU in this container -> HostSolverContext() fails) BundleAdjustment must leave
+    what LoopClosing::RunGlobalBundleAdjustment (src/LoopClosing.cc:2330-2386) reads in a state where its propagation
+    `SetPose(mTcwGBA)` / `SetWorldPos(mPosGBA)` is a no-op: mTcwGBA = pose, mPosGBA = position, stamped with nLoopKF."""
+    lib = capi.load_library()
+    if lib.osh_device_count() > 0:
+        import pytest
+        pytest.skip("a GPU is visible: the failure path is exercised by tests/test_gpu_host.py instead")
+    w = synth.make_window(5, n_free=4, n_fixed=2, n_points=60, stereo=True)
+    with host.HostGraph(w, init_kf_fixed=True) as g:
+        n_kf = w.n_free + w.n_fixed
+        before_kf = [g.kf_pose(i).copy() for i in range(n_kf)]
+        before_mp = [g.mp_pos(j).copy() for j in range(w.n_points)]
+        g.run_gba(n_iterations=3, n_loop_kf=77, robust=True)
+        for i in range(n_kf):
+            mark, T = g.kf_pose_gba(i)
+            assert mark == 77
+            np.testing.assert_array_equal(T, before_kf[i])
+            np.testing.assert_array_equal(g.kf_pose(i), before_kf[i])
+        for j in range(w.n_points):
+            mark, X = g.mp_pos_gba(j)
+            assert mark == 77
+            np.testing.assert_array_equal(X, before_mp[j])
