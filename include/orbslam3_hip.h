@@ -49,6 +49,9 @@ int osh_device_count(void);
 /* Edge kinds (the three visual edge types of src/Optimizer.cc:1302-1400). */
 #define OSH_EDGE_MONO    0   /* ORB_SLAM3::EdgeSE3ProjectXYZ      include/OptimizableTypes.h:88-115      */
 #define OSH_EDGE_STEREO  1   /* g2o::EdgeStereoSE3ProjectXYZ      types_six_dof_expmap.h:146-175         */
+#define OSH_EDGE_BODY    2   /* ORB_SLAM3::EdgeSE3ProjectXYZToBody include/OptimizableTypes.h:117-144, src/OptimizableTypes.cpp:192-213: */
+                             /* the right-camera observation of a fisheye stereo rig, through Trl and the second camera;        */
+                             /* it may share its (keyframe, landmark) pair with an OSH_EDGE_MONO edge (src/Optimizer.cc:1365-1399) */
 
 /*
  * One local-BA window as flat structure-of-arrays.
@@ -81,8 +84,13 @@ typedef struct osh_lba_problem {
   int32_t max_iterations;    /* optimizer.optimize(N), 10 at Optimizer.cc:1411     */
   const volatile unsigned char* stop_flag; /* pbStopFlag (may be NULL); polled once per LM trial */
   const double* kb8;         /* NULL: pinhole.  [4] k1..k4 (KannalaBrandt8 mvParameters[4..7]): the window's camera is a      */
-                             /* fisheye, every edge must be OSH_EDGE_MONO and projects through KannalaBrandt8::project /     */
-                             /* projectJac (src/CameraModels/KannalaBrandt8.cpp:45-63,147-175) with pose_cam's fx fy cx cy   */
+                             /* fisheye, edges are OSH_EDGE_MONO (or OSH_EDGE_BODY, below) and project through               */
+                             /* KannalaBrandt8::project / projectJac (src/CameraModels/KannalaBrandt8.cpp:45-63,147-175)     */
+                             /* with pose_cam's fx fy cx cy                                                                  */
+  const double* cam2;        /* NULL, or (with kb8 and trl) the right camera of a fisheye stereo rig: [8] fx fy cx cy k1..k4 */
+                             /* (KeyFrame::mpCamera2, src/Optimizer.cc:1392)                                                 */
+  const double* trl;         /* NULL, or [7] qx qy qz qw tx ty tz of KeyFrame::GetRelativePoseTrl() widened to double        */
+                             /* (src/Optimizer.cc:1389-1390); OSH_EDGE_BODY edges need kb8, cam2 and trl                     */
 } osh_lba_problem;
 
 /* -------------------------------------------------------- local BA: output */
@@ -167,6 +175,8 @@ int osh_lba_debug_trial(osh_lba_ctx* ctx, int32_t window, double lambda, double*
 int osh_lba_set_profiling(osh_lba_ctx* ctx, int enable);
 /* launches[k], total_ms[k] accumulated since profiling was (re)enabled */
 int osh_lba_get_profile(osh_lba_ctx* ctx, int64_t launches[OSH_K_COUNT], double total_ms[OSH_K_COUNT]);
+/* Host-side cost of the last osh_lba_upload: ms[0] packing (sort, Schur plan, staging), ms[1] host-to-device copies. */
+int osh_lba_get_upload_times(osh_lba_ctx* ctx, double ms[2]);
 const char* osh_lba_kernel_name(int kernel_id);
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -213,6 +223,13 @@ int osh_lba_get_plan_stats(osh_lba_ctx* ctx, int64_t stats[6]);
  * stats = {items, symmetric items, records, contributions, rhs contributions, MFMA instructions
  * per pass, useful 6x6 products per pass, reduce entries}. */
 int osh_lba_schur_plan_stats(const osh_lba_problem* problem, int64_t stats[8]);
+
+/* Host-only self check + timing of the batch packer osh_lba_upload runs before its copies (needs no GPU): landmark-major
+ * edge order, landmark renumbering along the Schur plan, sign-coded observation records, merged fisheye-rig edges, chunks,
+ * rebased contribution slots.  n_threads <= 0: the upload's own default.  stats = {items, symmetric items, records,
+ * contributions, chunks, staging bytes, merged left/right edge pairs, reduce entries}; *pack_ms (may be NULL) = wall time
+ * of the packing. */
+int osh_lba_pack_check(int32_t n_windows, const osh_lba_problem* problems, int32_t n_threads, int64_t stats[8], double* pack_ms);
 
 /* ----------------------------------------------- local inertial BA (config 4) */
 /*

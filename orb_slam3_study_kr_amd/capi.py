@@ -23,6 +23,7 @@ OSH_ERR_UNSUPPORTED = -3
 OSH_ERR_NO_DEVICE = -4
 OSH_EDGE_MONO = 0
 OSH_EDGE_STEREO = 1
+OSH_EDGE_BODY = 2
 OSH_LBA_MAX_TRACE = 128
 OSH_K_COUNT = 11
 KERNEL_NAMES = ["linearize", "pose_hess", "schur", "solve", "backsub", "residual", "control", "schur_reduce", "schur_cross", "lin_aux", "lin_pose"]
@@ -44,7 +45,7 @@ class LbaProblem(C.Structure):
         ("edge_obs", c_double_p), ("edge_info", c_double_p),
         ("huber_mono", C.c_double), ("huber_stereo", C.c_double),
         ("lambda_init", C.c_double), ("max_iterations", C.c_int32),
-        ("stop_flag", c_uint8_p), ("kb8", c_double_p),
+        ("stop_flag", c_uint8_p), ("kb8", c_double_p), ("cam2", c_double_p), ("trl", c_double_p),
     ]
 
 
@@ -192,7 +193,9 @@ _SIGNATURES = {
     "osh_lba_kernel_name": (C.c_char_p, [C.c_int]),
     "osh_pose_optimize": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(PoseProblem), C.POINTER(PoseResult)]),
     "osh_lba_get_plan_stats": (C.c_int, [C.c_void_p, c_int64_p]),
+    "osh_lba_get_upload_times": (C.c_int, [C.c_void_p, c_double_p]),
     "osh_lba_schur_plan_stats": (C.c_int, [C.POINTER(LbaProblem), c_int64_p]),
+    "osh_lba_pack_check": (C.c_int, [C.c_int32, C.POINTER(LbaProblem), C.c_int32, c_int64_p, c_double_p]),
     "osh_orb_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "osh_orb_destroy": (None, [C.c_void_p]),
     "osh_orb_upload": (C.c_int, [C.c_void_p, C.POINTER(OrbBatch)]),

@@ -59,6 +59,7 @@ struct LbaPack {
     p.edge_obs = edge_obs.data(); p.edge_info = edge_info.data();
     p.huber_mono = p.huber_stereo = 0; p.lambda_init = 0; p.max_iterations = 10; p.stop_flag = nullptr;
     p.kb8 = has_kb8 ? kb8 : nullptr;
+    p.cam2 = nullptr; p.trl = nullptr;
   }
 };
 struct LibaPack {

@@ -294,6 +294,231 @@ __device__ __forceinline__ void edge_jacobians_kb8(const double* R, const double
   for (int j = 0; j < 6; ++j) Jp[12 + j] = 0.0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Compact description of a visual edge at the linearisation point.  Both reference Jacobians factor through the
+// camera-frame point Xc = R X + t:   d err / d X = Pm R,   d err / d pose = Pm [ -[Xc]x | I ]   with Pm = -projectJac(Xc)
+// (src/OptimizableTypes.cpp:139-160, types_six_dof_expmap.cpp:228-273: SE3deriv IS [ -[Xc]x | I ]; for the body edge of a
+// fisheye rig Pm = -projectJac2(Xr) Rrl, src/OptimizableTypes.cpp:192-213).  With the robustified weight w = rho' invSigma2:
+//   Q = w Pm^T Pm (3x3 symmetric)      g = Pm^T (-w r)
+//   Hll += R^T Q R     b_l += R^T g     Hpl = D^T Q R     Hpp += D^T Q D     b_p += D^T g       D = [ -[Xc]x | I ]
+// so an edge is described by Xc, the six entries of Q and g; two edges on one (keyframe, landmark) block simply add their
+// Q and g.  Every kernel below forms its blocks from this description; nothing of size 6x3 is ever stored.
+// Q is stored as 00 01 02 11 12 22.  For a pinhole camera Q01 == 0 (fx and fy rows do not mix).
+// ---------------------------------------------------------------------------------------------------------------------
+
+// Pinhole mono / rectified-stereo edge.  rec = u v u_r +-invSigma2 (sign bit set: monocular).  Returns rho(chi2) in rho0.
+__device__ __forceinline__ void edge_core_pinhole(const double* qt, const double* cam, const double* X, const double* rec,
+                                                  double huber_mono, double huber_stereo, double* Xc, double* Q, double* g,
+                                                  double& rho0) {
+  const bool stereo = rec[3] > 0.0;
+  const double info = fabs(rec[3]);
+  double r[3];
+  const double chi2 = edge_residual(stereo ? OSH_EDGE_STEREO : OSH_EDGE_MONO, qt, cam, X, rec, info, r, Xc);
+  double rho1;
+  huber(chi2, stereo ? huber_stereo : huber_mono, rho0, rho1);
+  const double ww = rho1 * info;                       // robustInformation (first order only, base_edge.h:96-102)
+  const double wr0 = -(info * r[0]) * rho1, wr1 = -(info * r[1]) * rho1, wr2 = -(info * r[2]) * rho1;   // r[2] == 0 for mono
+  const double iz = 1.0 / Xc[2], iz2 = iz * iz;
+  const double pa = cam[0] * iz, pb = cam[1] * iz, pc = cam[0] * Xc[0] * iz2, pd = cam[1] * Xc[1] * iz2;
+  const double pce = stereo ? pc - cam[4] * iz2 : 0.0;   // third row of Pm: (-pa, 0, pc - bf/z^2); absent for mono
+  // rows of Pm: (-pa, 0, pc)  (0, -pb, pd)  [(-pa, 0, pce)]
+  g[0] = -pa * (wr0 + wr2);
+  g[1] = -pb * wr1;
+  g[2] = pc * wr0 + pd * wr1 + pce * wr2;
+  const double wa = ww * pa, wb = ww * pb;
+  Q[0] = stereo ? wa * pa + wa * pa : wa * pa;
+  Q[1] = 0.0;
+  Q[2] = -(wa * (pc + pce));
+  Q[3] = wb * pb;
+  Q[4] = -(wb * pd);
+  Q[5] = ww * (pc * pc + pd * pd + pce * pce);
+}
+
+// Adds w Pm^T Pm and Pm^T (-w r) of a two-row edge with dense Pm (2x3 row-major) to Q / g.
+__device__ __forceinline__ void edge_core_add_rows2(const double* Pm, double ww, double wr0, double wr1, double* Q, double* g) {
+  g[0] += Pm[0] * wr0 + Pm[3] * wr1;
+  g[1] += Pm[1] * wr0 + Pm[4] * wr1;
+  g[2] += Pm[2] * wr0 + Pm[5] * wr1;
+  const double a0 = ww * Pm[0], a1 = ww * Pm[1], a2 = ww * Pm[2], b0 = ww * Pm[3], b1 = ww * Pm[4], b2 = ww * Pm[5];
+  Q[0] += a0 * Pm[0] + b0 * Pm[3];
+  Q[1] += a0 * Pm[1] + b0 * Pm[4];
+  Q[2] += a0 * Pm[2] + b0 * Pm[5];
+  Q[3] += a1 * Pm[1] + b1 * Pm[4];
+  Q[4] += a1 * Pm[2] + b1 * Pm[5];
+  Q[5] += a2 * Pm[2] + b2 * Pm[5];
+}
+
+// KannalaBrandt8 window: kind is one of the sorted-edge kinds 0 mono (left camera), 2 body (right camera through Trl),
+// 3 both on one block.  rec = left observation record, rec2 = right observation record (u v - invSigma2).
+// chi_l / chi_r: chi2 of the left / right edge (0 when absent); rho0: sum of the robustified chi2 of the edges present.
+__device__ __forceinline__ void edge_core_kb8(int kind, const double* qt, const double* cam, const double* kb, const double* cam2,
+                                              const double* trl, const double* X, const double* rec, const double* rec2,
+                                              double huber_mono, double* Xc, double* Q, double* g, double& rho0,
+                                              double& chi_l, double& chi_r) {
+  double rot[3];
+  quat_rotate(qt, X, rot);
+  Xc[0] = rot[0] + qt[4]; Xc[1] = rot[1] + qt[5]; Xc[2] = rot[2] + qt[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) Q[k] = 0.0;
+  g[0] = g[1] = g[2] = 0.0;
+  rho0 = 0.0; chi_l = 0.0; chi_r = 0.0;
+  if (kind != 2) {   // left edge: EdgeSE3ProjectXYZ through KannalaBrandt8 (src/OptimizableTypes.cpp:139-160)
+    const double info = fabs(rec[3]);
+    double u, v;
+    kb8_project(cam, kb, Xc, u, v);
+    const double r0 = rec[0] - u, r1 = rec[1] - v;
+    chi_l = r0 * (info * r0) + r1 * (info * r1);
+    double rh0, rh1;
+    huber(chi_l, huber_mono, rh0, rh1);
+    rho0 += rh0;
+    double Pm[6];
+    kb8_project_jac(cam, kb, Xc, Pm);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Pm[k] = -Pm[k];
+    edge_core_add_rows2(Pm, rh1 * info, -(info * r0) * rh1, -(info * r1) * rh1, Q, g);
+  }
+  if (kind >= 2) {   // right edge: EdgeSE3ProjectXYZToBody (include/OptimizableTypes.h:125-130, src/OptimizableTypes.cpp:192-213)
+    const double* ro = (kind == 2) ? rec : rec2;
+    const double info = fabs(ro[3]);
+    double Rrl[9], Xr[3];
+    quat_to_R(trl, Rrl);
+    // (mTrl * v1->estimate()).map(X): the product SE3Quat is formed first in the reference; mapping through the two
+    // transforms one after the other differs from it only by rounding
+    quat_rotate(trl, Xc, Xr);
+    Xr[0] += trl[4]; Xr[1] += trl[5]; Xr[2] += trl[6];
+    double u, v;
+    kb8_project(cam2, cam2 + 4, Xr, u, v);
+    const double r0 = ro[0] - u, r1 = ro[1] - v;
+    chi_r = r0 * (info * r0) + r1 * (info * r1);
+    double rh0, rh1;
+    huber(chi_r, huber_mono, rh0, rh1);    // rk->setDelta(thHuberMono) (src/Optimizer.cc:1386)
+    rho0 += rh0;
+    double J2[6], Pm[6];
+    kb8_project_jac(cam2, cam2 + 4, Xr, J2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Pm[3 * i + j] = -(J2[3 * i] * Rrl[j] + J2[3 * i + 1] * Rrl[3 + j] + J2[3 * i + 2] * Rrl[6 + j]);
+    edge_core_add_rows2(Pm, rh1 * info, -(info * r0) * rh1, -(info * r1) * rh1, Q, g);
+  }
+}
+
+// M = Q R  (R row-major 3x3).  DENSE: Q01 may be non-zero (fisheye); the pinhole kernels skip those terms.
+template <bool DENSE>
+__device__ __forceinline__ void core_QR(const double* Q, const double* R, double* M) {
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    M[j] = Q[0] * R[j] + Q[2] * R[6 + j];
+    M[3 + j] = Q[3] * R[3 + j] + Q[4] * R[6 + j];
+    M[6 + j] = Q[2] * R[j] + Q[4] * R[3 + j] + Q[5] * R[6 + j];
+    if (DENSE) { M[j] += Q[1] * R[3 + j]; M[3 + j] += Q[1] * R[j]; }
+  }
+}
+
+// hl[0..5] = upper(R^T Q R), hl[6..8] = R^T g: the edge's share of Hll and b_l.
+template <bool DENSE>
+__device__ __forceinline__ void core_landmark_side(const double* Q, const double* g, const double* R, double* hl) {
+  double M[9];
+  core_QR<DENSE>(Q, R, M);
+  hl[0] = R[0] * M[0] + R[3] * M[3] + R[6] * M[6];
+  hl[1] = R[0] * M[1] + R[3] * M[4] + R[6] * M[7];
+  hl[2] = R[0] * M[2] + R[3] * M[5] + R[6] * M[8];
+  hl[3] = R[1] * M[1] + R[4] * M[4] + R[7] * M[7];
+  hl[4] = R[1] * M[2] + R[4] * M[5] + R[7] * M[8];
+  hl[5] = R[2] * M[2] + R[5] * M[5] + R[8] * M[8];
+  hl[6] = R[0] * g[0] + R[3] * g[1] + R[6] * g[2];
+  hl[7] = R[1] * g[0] + R[4] * g[1] + R[7] * g[2];
+  hl[8] = R[2] * g[0] + R[5] * g[1] + R[8] * g[2];
+}
+
+// Rows of the Hpl block W = D^T Q R times the landmark factor F (upper triangular, F F^T = (Hll + lambda I)^-1,
+// stored 00 01 02 11 12 22): WF[r*3 + m], r = 0..5 (rotation rows first), m = 0..2.
+template <bool DENSE>
+__device__ __forceinline__ void core_WF(const double* Xc, const double* Q, const double* R, const double* F, double* WF) {
+  double M[9];
+  core_QR<DENSE>(Q, R, M);
+  double* T = WF + 9;   // rows 3..5 of W F are T = Q R F
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    T[3 * i] = M[3 * i] * F[0];
+    T[3 * i + 1] = M[3 * i] * F[1] + M[3 * i + 1] * F[3];
+    T[3 * i + 2] = M[3 * i] * F[2] + M[3 * i + 1] * F[4] + M[3 * i + 2] * F[5];
+  }
+  // rows 0..2: [Xc]x T, column by column: Xc x T[:, m]
+  const double x = Xc[0], y = Xc[1], z = Xc[2];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    WF[m] = y * T[6 + m] - z * T[3 + m];
+    WF[3 + m] = z * T[m] - x * T[6 + m];
+    WF[6 + m] = x * T[3 + m] - y * T[m];
+  }
+}
+
+// Hpp (upper triangle, 21 entries row-major) += D^T Q D and b_p += D^T g.
+template <bool DENSE>
+__device__ __forceinline__ void core_pose_side(const double* Xc, const double* Q, const double* g, double* H, double* b) {
+  const double x = Xc[0], y = Xc[1], z = Xc[2];
+  // Mx = [Xc]x Q : column j = Xc x Q[:, j]
+  const double q00 = Q[0], q01 = DENSE ? Q[1] : 0.0, q02 = Q[2], q11 = Q[3], q12 = Q[4], q22 = Q[5];
+  double m00, m01, m02, m10, m11, m12, m20, m21, m22;
+  if (DENSE) {
+    m00 = y * q02 - z * q01; m10 = z * q00 - x * q02; m20 = x * q01 - y * q00;
+    m01 = y * q12 - z * q11; m11 = z * q01 - x * q12; m21 = x * q11 - y * q01;
+  } else {
+    m00 = y * q02;           m10 = z * q00 - x * q02; m20 = -(y * q00);
+    m01 = y * q12 - z * q11; m11 = -(x * q12);        m21 = x * q11;
+  }
+  m02 = y * q22 - z * q12; m12 = z * q02 - x * q22; m22 = x * q12 - y * q02;
+  (void)q01;
+  // top-left A = Mx [Xc]x^T : A[i][0] = y M[i][2] - z M[i][1], A[i][1] = z M[i][0] - x M[i][2], A[i][2] = x M[i][1] - y M[i][0]
+  H[0] += y * m02 - z * m01;  H[1] += z * m00 - x * m02;  H[2] += x * m01 - y * m00;
+  H[3] += m00; H[4] += m01; H[5] += m02;                      // top-right Mx, row 0
+  H[6] += z * m10 - x * m12;  H[7] += x * m11 - y * m10;
+  H[8] += m10; H[9] += m11; H[10] += m12;
+  H[11] += x * m21 - y * m20;
+  H[12] += m20; H[13] += m21; H[14] += m22;
+  H[15] += q00; if (DENSE) H[16] += Q[1]; H[17] += q02;       // bottom-right Q
+  H[18] += q11; H[19] += q12;
+  H[20] += q22;
+  b[0] += y * g[2] - z * g[1];
+  b[1] += z * g[0] - x * g[2];
+  b[2] += x * g[1] - y * g[0];
+  b[3] += g[0]; b[4] += g[1]; b[5] += g[2];
+}
+
+// -(Hpl^T x) of one edge for the back-substitution: -R^T Q (D x),  D x = x[3..5] + x[0..2] x Xc
+template <bool DENSE>
+__device__ __forceinline__ void core_backsub(const double* Xc, const double* Q, const double* R, const double* xp, double* c) {
+  const double v0 = xp[3] + (xp[1] * Xc[2] - xp[2] * Xc[1]);
+  const double v1 = xp[4] + (xp[2] * Xc[0] - xp[0] * Xc[2]);
+  const double v2 = xp[5] + (xp[0] * Xc[1] - xp[1] * Xc[0]);
+  double s0 = Q[0] * v0 + Q[2] * v2, s1 = Q[3] * v1 + Q[4] * v2;
+  const double s2 = Q[2] * v0 + Q[4] * v1 + Q[5] * v2;
+  if (DENSE) { s0 += Q[1] * v1; s1 += Q[1] * v0; }
+  c[0] = -(R[0] * s0 + R[3] * s1 + R[6] * s2);
+  c[1] = -(R[1] * s0 + R[4] * s1 + R[7] * s2);
+  c[2] = -(R[2] * s0 + R[5] * s1 + R[8] * s2);
+}
+
+// Landmark factor: D = Hll + lambda I = C C^T (Cholesky), F = C^-T (upper triangular, F F^T = D^-1), u = F^T b_l.
+// This is the role of `D->inverse()` at block_solver.hpp:389: the Schur products B_i D^-1 B_j^T are formed as
+// (B_i F)(B_j F)^T and the solution D^-1 c as F (F^T c).  Output dl[0..5] = F 00 01 02 11 12 22, dl[6..8] = u.
+__device__ __forceinline__ void landmark_factor(const double* hl, const double* bl, double lambda, double* dl) {
+  const double d00 = hl[0] + lambda, d01 = hl[1], d02 = hl[2], d11 = hl[3] + lambda, d12 = hl[4], d22 = hl[5] + lambda;
+  const double c00 = sqrt(d00), i00 = 1.0 / c00;
+  const double c10 = d01 * i00, c20 = d02 * i00;
+  const double c11 = sqrt(d11 - c10 * c10), i11 = 1.0 / c11;
+  const double c21 = (d12 - c20 * c10) * i11;
+  const double c22 = sqrt(d22 - c20 * c20 - c21 * c21), i22 = 1.0 / c22;
+  const double n10 = -(c10 * i00) * i11;                 // C^-1 (lower): n10, n20, n21 below the diagonal i00, i11, i22
+  const double n21 = -(c21 * i11) * i22;
+  const double n20 = -(c20 * i00 + c21 * n10) * i22;
+  dl[0] = i00; dl[1] = n10; dl[2] = n20; dl[3] = i11; dl[4] = n21; dl[5] = i22;
+  dl[6] = i00 * bl[0];
+  dl[7] = n10 * bl[0] + i11 * bl[1];
+  dl[8] = n20 * bl[0] + n21 * bl[1] + i22 * bl[2];
+}
+
 // 64-lane butterfly sum: every lane ends with the same total (deterministic order).
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -61,6 +61,8 @@ class LbaWindow:
     max_iterations: int = 10
     stop_flag: np.ndarray | None = None   # u8[1] or None
     kb8: np.ndarray | None = None         # [4] f64 KannalaBrandt8 k1..k4: mono edges project through the fisheye model
+    cam2: np.ndarray | None = None        # [8] f64 right camera of a fisheye stereo rig: fx fy cx cy k1..k4
+    trl: np.ndarray | None = None         # [7] f64 Trl (left -> right camera): qx qy qz qw tx ty tz
     gt_pose_qt: np.ndarray | None = None  # ground truth (not part of the problem)
     gt_points: np.ndarray | None = None
     outlier_mask: np.ndarray | None = None
@@ -108,6 +110,12 @@ class LbaWindow:
         if self.kb8 is not None:
             self.kb8 = np.ascontiguousarray(self.kb8, dtype=np.float64)
         p.kb8 = capi.ptr(self.kb8, capi.c_double_p)
+        if self.cam2 is not None:
+            self.cam2 = np.ascontiguousarray(self.cam2, dtype=np.float64)
+        if self.trl is not None:
+            self.trl = np.ascontiguousarray(self.trl, dtype=np.float64)
+        p.cam2 = capi.ptr(self.cam2, capi.c_double_p)
+        p.trl = capi.ptr(self.trl, capi.c_double_p)
         return p
 
     def algorithmic_bytes(self) -> dict:

@@ -31,8 +31,8 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_sizes_match_header_layout():
-    # 4 ints + 8 pointers + 3 doubles + int (+pad) + 2 pointers (stop_flag, kb8)
-    assert C.sizeof(capi.LbaProblem) == 16 + 8 * 8 + 24 + 8 + 16
+    # 4 ints + 8 pointers + 3 doubles + int (+pad) + 4 pointers (stop_flag, kb8, cam2, trl)
+    assert C.sizeof(capi.LbaProblem) == 16 + 8 * 8 + 24 + 8 + 32
     assert C.sizeof(capi.LbaResult) == 4 * 8 + 16 + 128 * 8 * 2 + 128 * 4 + 8
     assert C.sizeof(capi.OrbBatch) == 16 + 6 * 8
 

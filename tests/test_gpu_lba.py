@@ -216,11 +216,15 @@ def test_randomised_small_windows_in_one_batch(solver, ob):
         r = ob.lba_solve(w)
         assert g.iterations == r.iterations
         np.testing.assert_array_equal(g.trials_trace, r.trials_trace)
-        np.testing.assert_allclose(g.chi2_trace, r.chi2_trace, rtol=1e-6)
         # the estimates are only comparable where the gauge is fixed: a stereo window needs one fixed keyframe, a window
-        # with monocular edges only needs two (scale); otherwise the cost agrees but the state may drift along the gauge
+        # with monocular edges only needs two (scale); otherwise the cost agrees but the state may drift along the gauge.
+        # In a gauge-free window S is singular up to lambda (cond ~1e8 with a user lambda of 1e-3), so the cost trace carries
+        # the rounding of the implementation: on window 901 (9 free, 0 fixed keyframes) oracle/lba_oracle.c and the
+        # independent oracle/lm_numpy.py disagree by 1.35e-6 on one entry, and the device agrees with the numpy model to 4e-8
         all_mono = bool((w.edge_kind == 0).all())
-        if w.n_fixed >= (2 if all_mono else 1):
+        gauge_fixed = w.n_fixed >= (2 if all_mono else 1)
+        np.testing.assert_allclose(g.chi2_trace, r.chi2_trace, rtol=1e-6 if gauge_fixed else 2e-5)
+        if gauge_fixed:
             worst = max(worst, rel_translation_error(g.pose_qt, r.pose_qt))
             np.testing.assert_allclose(g.points, r.points, rtol=1e-5, atol=1e-5, err_msg=f"window {w.n_free}+{w.n_fixed} KF, {w.n_points} points")
     assert worst < 1e-6
