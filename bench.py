@@ -47,8 +47,8 @@ def generate_windows(seeds, workers=8):
 
 # Steps of the reference loop -> the device kernels that implement them (names of capi.KERNEL_NAMES).
 STEP_KERNELS = {
-    "linearize": ["linearize", "lin_pose", "lin_aux", "pose_hess"],   # k_lin_items<0, KB8>, <1, KB8>, k_lin_aux<KB8>, k_pose_reduce
-    "schur": ["schur", "schur_cross", "schur_reduce"],                # k_schur_items<true>, <false>, k_schur_reduce
+    "linearize": ["linearize", "lin_aux", "lin_pose", "pose_hess"],   # k_lin_lm (+ its factors-only launch), k_schur_fused mode 0, k_pose_reduce
+    "schur": ["schur", "schur_cross", "schur_reduce"],                # k_schur_fused<true> / <false> mode 1 (pose side + Schur), k_schur_reduce
     "solve": ["solve"], "backsub": ["backsub"], "residual": ["residual"],
 }
 

@@ -44,7 +44,7 @@
 
 namespace osh {
 
-constexpr int kResidualSplit = 4;    // blocks of k_residual per chunk (kChunkMaxEdges / kChunkEdges)
+constexpr int kResidualSplit = 1;    // blocks of k_residual per chunk
 constexpr double kTau = 1e-5;      // OptimizationAlgorithmLevenberg::_tau
 constexpr int kMaxTrials = 10;     // maxTrialsAfterFailure
 constexpr int kSolveThreadsBatch = 256, kSolveThreadsLatency = 512;
@@ -241,46 +241,89 @@ __device__ __forceinline__ void fetch_pose(bool staged, const double* sh_pose, c
 }
 
 // --------------------------------------------------------------------------------------------
-// k_residual: computeActiveErrors + activeRobustChi2 at the TRIAL estimates (every active window),
-// kResidualSplit blocks per chunk of consecutive landmarks, lane per edge; partial sums in fixed order.
+// Landmark-major kernels (k_lin_lm, k_backsub, k_residual): one block per chunk of consecutive landmarks (<= 1024 edges,
+// <= 256 landmarks), lane per edge in kPasses passes of 256.  The block first requests everything it will touch -- the
+// lane's edges of all passes (pose index, landmark index, observation record), the chunk's landmarks (coalesced) and the
+// window's poses -- parks the shared part in LDS behind ONE barrier and then only computes: one memory round trip per block
+// instead of two per pass.  (A wavefront-granular variant -- chunks of 64 edges, no block barriers, per-landmark sums as
+// parallel (landmark, component) tasks -- was measured 2x SLOWER: the per-chunk reduction and the cold start of every
+// short-lived wavefront cost more than the four barriers of a 1024-edge block.)
+// --------------------------------------------------------------------------------------------
+constexpr int kPasses = kChunkMaxEdges / kChunkEdges;
+
+struct LaneEdges { int ip[kPasses], il[kPasses]; double2 ra[kPasses], rb[kPasses]; };
+
+// edges base + p * 256 + tid, p = 0..kPasses-1, clamped to the last edge of the chunk (validity is applied at use)
+__device__ __forceinline__ void load_lane_edges(const BatchView& bv, const WinDesc& wd, int base, int e1, int tid, LaneEdges& le) {
+  const int last = max(e1 - 1, 0);
+#pragma unroll
+  for (int p = 0; p < kPasses; ++p) {
+    const size_t ge = (size_t)wd.edge_off + min(base + p * kChunkEdges + tid, last);
+    le.ip[p] = bv.e_pose[ge];
+    le.il[p] = bv.e_point[ge];
+    const double2* r = reinterpret_cast<const double2*>(bv.e_rec + ge * 4);
+    le.ra[p] = r[0]; le.rb[p] = r[1];
+  }
+}
+
+// the chunk's landmarks -> LDS [nl][3] (coalesced: consecutive landmarks are consecutive in memory)
+__device__ __forceinline__ void stage_points(double* sh_X, const double* pts, int lm0, int nl, int tid) {
+  for (int k = tid; k < 3 * nl; k += kBlock) sh_X[k] = pts[(size_t)lm0 * 3 + k];
+}
+
+// --------------------------------------------------------------------------------------------
+// k_residual: computeActiveErrors + activeRobustChi2 at the TRIAL estimates (every active window); chunk partial sums in
+// fixed order.
 // --------------------------------------------------------------------------------------------
 template <bool KB8>
 __global__ __launch_bounds__(kBlock) void k_residual(BatchView bv) {
-  __shared__ double sh4[4];
-  const Chunk ch = bv.chunks[blockIdx.x / kResidualSplit];
-  const int q = blockIdx.x % kResidualSplit;
+  extern __shared__ __attribute__((aligned(16))) double sh_rs[];   // [4] reduce, [256*3] landmarks, staged poses
+  const Chunk ch = bv.chunks[blockIdx.x];
   const WinDesc wd = bv.win[ch.win];   // by value: the fields stay in SGPRs across the kernel's stores
   const LmView st = lm_view(bv.lm, ch.win);
   if (!st.active) return;
+  const int tid = threadIdx.x;
   const int sel = st.sel ^ 1;
+  double* sh4 = sh_rs;
+  double* sh_X = sh4 + 4;
+  double* sh_pose = sh_X + 3 * kBlock;
   const double* poses = bv.pose_state[sel] + (size_t)wd.pose_off * 7;
   const double* pts = bv.pt_state[sel] + (size_t)wd.pt_off * 3;
   const double* cams = bv.pose_cam + (size_t)wd.pose_off * 5;
   const int* lmo = bv.lm_off + wd.lmoff_off;
   const int e0 = lmo[ch.lm0], e1 = lmo[ch.lm1];
+  const int nl = ch.lm1 - ch.lm0;
+  const bool staged = (wd.P + wd.F) <= kLdsPoses;
   double chi_acc = 0.0;
-  for (int e = e0 + q * kBlock + threadIdx.x; e < e1; e += kResidualSplit * kBlock) {
-    const size_t ge = (size_t)wd.edge_off + e;
-    const int ip = bv.e_pose[ge], il = bv.e_point[ge];
-    double qt[7], cam[5], X[3], rec[4];
+  for (int base = e0; base < e1; base += kChunkMaxEdges) {
+    LaneEdges le;
+    load_lane_edges(bv, wd, base, e1, tid, le);
+    if (base == e0) {
+      stage_points(sh_X, pts, ch.lm0, nl, tid);
+      if (staged) stage_poses(sh_pose, poses, cams, wd.P + wd.F, tid, kBlock);
+      __syncthreads();
+    }
 #pragma unroll
-    for (int k = 0; k < 7; ++k) qt[k] = poses[(size_t)ip * 7 + k];
+    for (int p = 0; p < kPasses; ++p) {
+      const int e = base + p * kChunkEdges + tid;
+      if (e < e1) {
+        double qt[7], cam[5], R[9], X[3];
+        fetch_pose(staged, sh_pose, poses, cams, le.ip[p], qt, cam, R);
 #pragma unroll
-    for (int k = 0; k < 5; ++k) cam[k] = cams[(size_t)ip * 5 + k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) X[k] = pts[(size_t)il * 3 + k];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) rec[k] = bv.e_rec[ge * 4 + k];
-    double cl, cr;
-    chi_acc += win_edge_rho<KB8>(wd, bv, ge, rec, qt, cam, X, cl, cr);
+        for (int k = 0; k < 3; ++k) X[k] = sh_X[(le.il[p] - ch.lm0) * 3 + k];
+        const double rec[4] = {le.ra[p].x, le.ra[p].y, le.rb[p].x, le.rb[p].y};
+        double cl, cr;
+        chi_acc += win_edge_rho<KB8>(wd, bv, (size_t)wd.edge_off + e, rec, qt, cam, X, cl, cr);
+      }
+    }
   }
   const double chi = block_sum(chi_acc, sh4);
-  if (threadIdx.x == 0) bv.chi_part[blockIdx.x] = chi;
+  if (tid == 0) bv.chi_part[blockIdx.x] = chi;
 }
 
 // --------------------------------------------------------------------------------------------
-// k_lin_lm: the landmark side of the linearisation, one block per chunk of consecutive landmarks (<= 1024 edges), lane per
-// edge: residual, Huber weight, d err / d point of EVERY edge of the landmark (optimisable and fixed keyframes) ->
+// k_lin_lm: the landmark side of the linearisation: residual, Huber weight, d err / d point of EVERY edge of the landmark
+// (optimisable and fixed keyframes) ->
 //   Hll_j = sum R^T Q R,  b_l(j) = sum R^T g   (summed per landmark in edge order by the landmark's own lane: fixed order)
 //   chi2 partial and the largest Hll diagonal entry of the chunk (computeLambdaInit),
 // then the landmark factor for the current lambda (landmark_factor(): setLambda + D->inverse(), block_solver.hpp:389,582-587).
@@ -289,7 +332,7 @@ __global__ __launch_bounds__(kBlock) void k_residual(BatchView bv) {
 // --------------------------------------------------------------------------------------------
 template <bool KB8>
 __global__ __launch_bounds__(kBlock) void k_lin_lm(BatchView bv) {
-  extern __shared__ __attribute__((aligned(16))) double sh_lm[];   // [9*256] partials, [4] reduce, staged poses
+  extern __shared__ __attribute__((aligned(16))) double sh_lm[];   // [9*256] partials, [4] reduce, [256*3] landmarks, staged poses
   const Chunk ch = bv.chunks[blockIdx.x];
   const WinDesc wd = bv.win[ch.win];   // by value: the fields stay in SGPRs across the kernel's stores
   const LmView st = lm_view(bv.lm, ch.win);
@@ -313,50 +356,58 @@ __global__ __launch_bounds__(kBlock) void k_lin_lm(BatchView bv) {
   }
   double* sh_c = sh_lm;
   double* sh4 = sh_lm + 9 * kChunkEdges;
-  double* sh_pose = sh4 + 4;
+  double* sh_X = sh4 + 4;
+  double* sh_pose = sh_X + 3 * kBlock;
   const double* poses = bv.pose_state[st.sel] + (size_t)wd.pose_off * 7;
   const double* pts = bv.pt_state[st.sel] + (size_t)wd.pt_off * 3;
   const double* cams = bv.pose_cam + (size_t)wd.pose_off * 5;
   const bool staged = (wd.P + wd.F) <= kLdsPoses;
-  if (staged) stage_poses(sh_pose, poses, cams, wd.P + wd.F, tid, kBlock);
-  __syncthreads();
   const int* lmo = bv.lm_off + wd.lmoff_off;
   const int e0 = lmo[ch.lm0], e1 = lmo[ch.lm1];
+  int my_lo = 0, my_hi = 0;
+  if (tid < nl) { my_lo = lmo[ch.lm0 + tid]; my_hi = lmo[ch.lm0 + tid + 1]; }
   double acc[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) acc[k] = 0.0;
   double chi_acc = 0.0;
-  int my_lo = 0, my_hi = 0;
-  if (tid < nl) { my_lo = lmo[ch.lm0 + tid]; my_hi = lmo[ch.lm0 + tid + 1]; }
-  for (int base = e0; base < e1; base += kChunkEdges) {
-    const int e = base + tid;
-    double hl[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) hl[k] = 0.0;
-    if (e < e1) {
-      const size_t ge = (size_t)wd.edge_off + e;
-      const int ip = bv.e_pose[ge], il = bv.e_point[ge];
-      double qt[7], cam[5], R[9], X[3], rec[4], Xc[3], Q[6], g[3], rho0;
-      fetch_pose(staged, sh_pose, poses, cams, ip, qt, cam, R);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) X[k] = pts[(size_t)il * 3 + k];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) rec[k] = bv.e_rec[ge * 4 + k];
-      win_edge_core<KB8>(wd, bv, ge, rec, qt, cam, X, Xc, Q, g, rho0);
-      chi_acc += rho0;
-      dev::core_landmark_side<KB8>(Q, g, R, hl);
+  for (int base = e0; base < e1; base += kChunkMaxEdges) {
+    LaneEdges le;
+    load_lane_edges(bv, wd, base, e1, tid, le);
+    if (base == e0) {
+      stage_points(sh_X, pts, ch.lm0, nl, tid);
+      if (staged) stage_poses(sh_pose, poses, cams, wd.P + wd.F, tid, kBlock);
+      __syncthreads();
     }
 #pragma unroll
-    for (int k = 0; k < 9; ++k) sh_c[k * kChunkEdges + tid] = hl[k];
-    __syncthreads();
-    if (tid < nl) {
-      const int lo = max(my_lo, base), hi = min(my_hi, base + kChunkEdges);
-      for (int x = lo; x < hi; ++x) {
+    for (int p = 0; p < kPasses; ++p) {
+      const int pbase = base + p * kChunkEdges;
+      if (pbase >= e1) break;     // uniform over the block
+      const int e = pbase + tid;
+      double hl[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) acc[k] += sh_c[k * kChunkEdges + x - base];
+      for (int k = 0; k < 9; ++k) hl[k] = 0.0;
+      if (e < e1) {
+        double qt[7], cam[5], R[9], X[3], Xc[3], Q[6], g[3], rho0;
+        fetch_pose(staged, sh_pose, poses, cams, le.ip[p], qt, cam, R);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) X[k] = sh_X[(le.il[p] - ch.lm0) * 3 + k];
+        const double rec[4] = {le.ra[p].x, le.ra[p].y, le.rb[p].x, le.rb[p].y};
+        win_edge_core<KB8>(wd, bv, (size_t)wd.edge_off + e, rec, qt, cam, X, Xc, Q, g, rho0);
+        chi_acc += rho0;
+        dev::core_landmark_side<KB8>(Q, g, R, hl);
       }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) sh_c[k * kChunkEdges + tid] = hl[k];
+      __syncthreads();
+      if (tid < nl) {
+        const int lo = max(my_lo, pbase), hi = min(my_hi, pbase + kChunkEdges);
+        for (int x = lo; x < hi; ++x) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) acc[k] += sh_c[k * kChunkEdges + x - pbase];
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
   double dmax = 0.0;
   if (tid < nl) {
@@ -549,27 +600,21 @@ __global__ __launch_bounds__(64, 2) void k_schur_fused(BatchView bv, int item_ba
     }
   };
   using std::integral_constant;
-  auto multiply = [&]() {
-    if (SYM) {   // TX == TY
-      if (TX == 3) multiply_t(integral_constant<int, 3>{}, integral_constant<int, 3>{});
-      else if (TX == 2) multiply_t(integral_constant<int, 2>{}, integral_constant<int, 2>{});
-      else multiply_t(integral_constant<int, 1>{}, integral_constant<int, 1>{});
-    } else {
-      // cross items keep run-time tile tests: nine instantiations cost registers for no gain
+  auto multiply_cross = [&]() {
+    // cross items keep run-time tile tests: nine instantiations cost registers for no gain
 #pragma unroll
-      for (int ks = 0; ks < (3 * kSiLm) / 4; ++ks) {
-        double a[3], b[3];
+    for (int ks = 0; ks < (3 * kSiLm) / 4; ++ks) {
+      double a[3], b[3];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-          a[t] = (t < TX) ? shA[(16 * t + mrow) * kSiKS + 4 * ks + mk] : 0.0;
-          b[t] = (t < TY) ? shB[(16 * t + mrow) * kSiKS + 4 * ks + mk] : 0.0;
-        }
-#pragma unroll
-        for (int ti = 0; ti < 3; ++ti)
-#pragma unroll
-          for (int tj = 0; tj < 3; ++tj)
-            if (ti < TX && tj < TY) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+      for (int t = 0; t < 3; ++t) {
+        a[t] = (t < TX) ? shA[(16 * t + mrow) * kSiKS + 4 * ks + mk] : 0.0;
+        b[t] = (t < TY) ? shB[(16 * t + mrow) * kSiKS + 4 * ks + mk] : 0.0;
       }
+#pragma unroll
+      for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 3; ++tj)
+          if (ti < TX && tj < TY) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
     }
   };
   int4 rc0, rc1, rn0, rn1;
@@ -578,13 +623,26 @@ __global__ __launch_bounds__(64, 2) void k_schur_fused(BatchView bv, int item_ba
   load_rec(kSiLm, rn0, rn1);
   load_dat(rc0, rc1, d);
   wave_sync();   // the staged poses are visible
-  for (int c0 = 0; c0 < it.n_lm; c0 += kSiLm) {
-    park(c0, rc0, rc1, d);                 // edge descriptions, W F rows of chunk c0 -> LDS (consumes d)
-    wave_sync();
-    rc0 = rn0; rc1 = rn1;                  // loaded one iteration ago
-    load_dat(rc0, rc1, d);                 // chunk c0 + 1: in flight during the MFMAs below
-    load_rec(c0 + 2 * kSiLm, rn0, rn1);
-    if (do_schur) multiply();
+  // The chunk loop is instantiated per tile count (dispatched ONCE per item): a dispatch inside the loop makes the compiler
+  // reconcile the register assignment of the accumulators at every merge (dozens of 64-bit moves per chunk).
+  auto chunk_loop = [&](auto txc) {
+    for (int c0 = 0; c0 < it.n_lm; c0 += kSiLm) {
+      park(c0, rc0, rc1, d);                 // edge descriptions, W F rows of chunk c0 -> LDS (consumes d)
+      wave_sync();
+      rc0 = rn0; rc1 = rn1;                  // loaded one iteration ago
+      load_dat(rc0, rc1, d);                 // chunk c0 + 1: in flight during the MFMAs below
+      load_rec(c0 + 2 * kSiLm, rn0, rn1);
+      if (do_schur) {
+        if (SYM) multiply_t(txc, txc); else multiply_cross();
+      }
+    }
+  };
+  if (SYM && do_schur) {   // TX == TY
+    if (TX == 3) chunk_loop(integral_constant<int, 3>{});
+    else if (TX == 2) chunk_loop(integral_constant<int, 2>{});
+    else chunk_loop(integral_constant<int, 1>{});
+  } else {
+    chunk_loop(integral_constant<int, 0>{});
   }
   wave_sync();
   if (do_schur) {
@@ -773,16 +831,17 @@ __global__ __launch_bounds__(NT) void k_solve(BatchView bv, int W) {
 
 // --------------------------------------------------------------------------------------------
 // k_backsub: x_l = (Hll + lambda I)^-1 (b_l - Hpl^T x_p) = F F^T (...), X_trial = X + x_l, landmark part of computeScale
-// (block_solver.hpp:461-483, sparse_block_matrix_ccs.h:103-129).  One block per chunk of consecutive landmarks, lane per
-// edge for the products -Hpl^T x_p = -R^T Q (D x_p) formed from the edge description (lba_math.h), lane per landmark for the
-// ordered sum; the optimisable poses of the window and x_p sit in LDS.
+// (block_solver.hpp:461-483, sparse_block_matrix_ccs.h:103-129).  Landmark-major (see above): lane per edge for the products
+// -Hpl^T x_p = -R^T Q (D x_p) formed from the edge description (lba_math.h), lane per landmark for the ordered sum; the
+// optimisable poses of the window and x_p sit in LDS.
 // --------------------------------------------------------------------------------------------
 template <bool KB8>
 __global__ __launch_bounds__(kBlock) void k_backsub(BatchView bv) {
-  extern __shared__ __attribute__((aligned(16))) double sh_bs[];  // [3*256] partials, [4] reduce, [n] x_p, [P*21] poses
+  extern __shared__ __attribute__((aligned(16))) double sh_bs[];  // [3*256] partials, [4] reduce, [256*3] landmarks, [n] x_p, [P*21] poses
   double* sh_c = sh_bs;
   double* sh4 = sh_bs + 3 * kChunkEdges;
-  double* sh_x = sh4 + 4;
+  double* sh_X = sh4 + 4;
+  double* sh_x = sh_X + 3 * kBlock;
   const Chunk ch = bv.chunks[blockIdx.x];
   const WinDesc wd = bv.win[ch.win];   // by value: the fields stay in SGPRs across the kernel's stores
   const LmView st = lm_view(bv.lm, ch.win);
@@ -791,59 +850,73 @@ __global__ __launch_bounds__(kBlock) void k_backsub(BatchView bv) {
   const int n = wd.n;
   const double* poses = bv.pose_state[st.sel] + (size_t)wd.pose_off * 7;
   const double* cams = bv.pose_cam + (size_t)wd.pose_off * 5;
+  const double* pts = bv.pt_state[st.sel] + (size_t)wd.pt_off * 3;
   const bool staged = wd.P <= kLdsPoses;
   const double* xp = bv.xp + (size_t)wd.fpose_off * 6;
   double* sh_pose = sh_x + (staged ? n : 0);
-  if (staged) {
-    for (int k = tid; k < n; k += kBlock) sh_x[k] = xp[k];
-    stage_poses(sh_pose, poses, cams, wd.P, tid, kBlock);
-  }
-  __syncthreads();
   const int* lmo = bv.lm_off + wd.lmoff_off;
   const int e0 = lmo[ch.lm0], e1 = lmo[ch.lm1];
   const int nl = ch.lm1 - ch.lm0;
   const double lambda = st.lambda;
-  const double* pts = bv.pt_state[st.sel] + (size_t)wd.pt_off * 3;
   double acc[3] = {0, 0, 0};
   int my_lo = 0, my_hi = 0;
-  if (tid < nl) { my_lo = lmo[ch.lm0 + tid]; my_hi = lmo[ch.lm0 + tid + 1]; }
-  for (int base = e0; base < e1; base += kChunkEdges) {
-    const int e = base + tid;
-    double c[3] = {0, 0, 0};
-    if (e < e1) {
-      const size_t ge = (size_t)wd.edge_off + e;
-      const int ip = bv.e_pose[ge];
-      if (ip < wd.P) {
-        const int il = bv.e_point[ge];
-        double qt[7], R[9], cam[5], X[3], rec[4], Xc[3], Q[6], g[3], rho0, x6[6];
+  double F[6], b3[3], Xcur[3];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) F[k] = 0.0;
+  b3[0] = b3[1] = b3[2] = 0.0; Xcur[0] = Xcur[1] = Xcur[2] = 0.0;
+  if (tid < nl) {
+    // the landmark's own data is requested with everything else
+    const size_t gl = (size_t)wd.pt_off + ch.lm0 + tid;
+    my_lo = lmo[ch.lm0 + tid]; my_hi = lmo[ch.lm0 + tid + 1];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) F[k] = bv.DL[gl * 9 + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { b3[k] = bv.bl[gl * 3 + k]; Xcur[k] = pts[(size_t)(ch.lm0 + tid) * 3 + k]; }
+  }
+  for (int base = e0; base < e1; base += kChunkMaxEdges) {
+    LaneEdges le;
+    load_lane_edges(bv, wd, base, e1, tid, le);
+    if (base == e0) {
+      stage_points(sh_X, pts, ch.lm0, nl, tid);
+      if (staged) {
+        for (int k = tid; k < n; k += kBlock) sh_x[k] = xp[k];
+        stage_poses(sh_pose, poses, cams, wd.P, tid, kBlock);
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int p = 0; p < kPasses; ++p) {
+      const int pbase = base + p * kChunkEdges;
+      if (pbase >= e1) break;     // uniform over the block
+      const int e = pbase + tid;
+      double c[3] = {0, 0, 0};
+      if (e < e1 && le.ip[p] < wd.P) {
+        const int ip = le.ip[p];
+        double qt[7], R[9], cam[5], X[3], Xc[3], Q[6], g[3], rho0, x6[6];
         fetch_pose(staged, sh_pose, poses, cams, ip, qt, cam, R);
 #pragma unroll
         for (int k = 0; k < 6; ++k) x6[k] = staged ? sh_x[6 * ip + k] : xp[6 * ip + k];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) X[k] = pts[(size_t)il * 3 + k];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) rec[k] = bv.e_rec[ge * 4 + k];
-        win_edge_core<KB8>(wd, bv, ge, rec, qt, cam, X, Xc, Q, g, rho0);
+        for (int k = 0; k < 3; ++k) X[k] = sh_X[(le.il[p] - ch.lm0) * 3 + k];
+        const double rec[4] = {le.ra[p].x, le.ra[p].y, le.rb[p].x, le.rb[p].y};
+        win_edge_core<KB8>(wd, bv, (size_t)wd.edge_off + e, rec, qt, cam, X, Xc, Q, g, rho0);
         dev::core_backsub<KB8>(Xc, Q, R, x6, c);
       }
-    }
-    sh_c[tid] = c[0]; sh_c[kChunkEdges + tid] = c[1]; sh_c[2 * kChunkEdges + tid] = c[2];
-    __syncthreads();
-    if (tid < nl) {
-      const int lo = max(my_lo, base), hi = min(my_hi, base + kChunkEdges);
-      for (int x = lo; x < hi; ++x) {
-        acc[0] += sh_c[x - base]; acc[1] += sh_c[kChunkEdges + x - base]; acc[2] += sh_c[2 * kChunkEdges + x - base];
+      sh_c[tid] = c[0]; sh_c[kChunkEdges + tid] = c[1]; sh_c[2 * kChunkEdges + tid] = c[2];
+      __syncthreads();
+      if (tid < nl) {
+        const int lo = max(my_lo, pbase), hi = min(my_hi, pbase + kChunkEdges);
+        for (int x = lo; x < hi; ++x) {
+          acc[0] += sh_c[x - pbase]; acc[1] += sh_c[kChunkEdges + x - pbase]; acc[2] += sh_c[2 * kChunkEdges + x - pbase];
+        }
       }
+      __syncthreads();
     }
-    __syncthreads();
   }
   double sc = 0.0;
   if (tid < nl) {
     const size_t gl = (size_t)wd.pt_off + ch.lm0 + tid;
-    double F[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) F[k] = bv.DL[gl * 9 + k];
-    const double b0 = bv.bl[gl * 3], b1 = bv.bl[gl * 3 + 1], b2 = bv.bl[gl * 3 + 2];
+    const double b0 = b3[0], b1 = b3[1], b2 = b3[2];
     const double c0 = b0 + acc[0], c1 = b1 + acc[1], c2 = b2 + acc[2];
     double xl[3];
     if (st.solve_ok) {
@@ -855,9 +928,8 @@ __global__ __launch_bounds__(kBlock) void k_backsub(BatchView bv) {
     } else {
       xl[0] = xl[1] = xl[2] = 0.0;
     }
-    const double* Xc = bv.pt_state[st.sel] + gl * 3;
     double* Xt = bv.pt_state[st.sel ^ 1] + gl * 3;
-    Xt[0] = Xc[0] + xl[0]; Xt[1] = Xc[1] + xl[1]; Xt[2] = Xc[2] + xl[2];
+    Xt[0] = Xcur[0] + xl[0]; Xt[1] = Xcur[1] + xl[1]; Xt[2] = Xcur[2] + xl[2];
     sc = xl[0] * (lambda * xl[0] + b0) + xl[1] * (lambda * xl[1] + b1) + xl[2] * (lambda * xl[2] + b2);
   }
   sc = block_sum(sc, sh4);
@@ -1138,7 +1210,7 @@ struct osh_lba_ctx {
   std::vector<const volatile unsigned char*> stop_ptr;
   bool any_stop = false;
   int solve_nb = 24, solve_W = 0, solve_threads = kSolveThreadsLatency;
-  size_t solve_lds = 0, backsub_lds = 0, lin_lds = 0;
+  size_t solve_lds = 0, backsub_lds = 0, lin_lds = 0, resid_lds = 0;
   double upload_pack_ms = 0, upload_copy_ms = 0;
   // edge kernels of the batch's camera models: the KannalaBrandt8 instantiations only when a window asks for them
   void (*kp_lin_lm)(BatchView) = nullptr;
@@ -1229,9 +1301,10 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   // ---- LDS budgets
   {
     const int staged = std::min(pb.np_max, kLdsPoses);
-    c->lin_lds = (size_t)(9 * kChunkEdges + 4 + staged * kPoseRec) * sizeof(double);
+    c->lin_lds = (size_t)(9 * kChunkEdges + 4 + 3 * kBlock + staged * kPoseRec) * sizeof(double);
+    c->resid_lds = (size_t)(4 + 3 * kBlock + staged * kPoseRec) * sizeof(double);
     const int pmax = pb.n_max / 6;
-    c->backsub_lds = (size_t)(3 * kChunkEdges + 4 + (pmax <= kLdsPoses ? pb.n_max + pmax * kPoseRec : 0)) * sizeof(double);
+    c->backsub_lds = (size_t)(3 * kChunkEdges + 4 + 3 * kBlock + (pmax <= kLdsPoses ? pb.n_max + pmax * kPoseRec : 0)) * sizeof(double);
     // One 512-thread block per window with the widest panel that fits (one block per CU).
     c->solve_threads = kSolveThreadsLatency;
     auto need = [&](int b) { return ldlt_lds_doubles(b, ldlt_row_stride(pb.n_max), c->solve_threads) * sizeof(double); };
@@ -1325,6 +1398,8 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
     OSH_HIP(hipFuncSetAttribute((const void*)k_backsub<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     OSH_HIP(hipFuncSetAttribute((const void*)k_lin_lm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     OSH_HIP(hipFuncSetAttribute((const void*)k_lin_lm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    OSH_HIP(hipFuncSetAttribute((const void*)k_residual<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    OSH_HIP(hipFuncSetAttribute((const void*)k_residual<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     attr_devices.push_back(c->device);
   }
   c->n_windows = nw;
@@ -1439,7 +1514,7 @@ extern "C" int osh_lba_optimize(osh_lba_ctx* c) {
       LAUNCH(OSH_K_CONTROL, k_control, c->n_windows, 64, 0, c->bv, 0);
     }
     OSH_TRY(trial_kernels(c, round > 0));
-    LAUNCH(OSH_K_RESIDUAL, c->kp_residual, pb.n_chunks * kResidualSplit, kBlock, 0, c->bv);
+    LAUNCH(OSH_K_RESIDUAL, c->kp_residual, pb.n_chunks * kResidualSplit, kBlock, c->resid_lds, c->bv);
     if (c->any_stop) {
       // terminate() is polled after every trial (levenberg.cpp:149) and before every iteration
       snapshot_stop(c);

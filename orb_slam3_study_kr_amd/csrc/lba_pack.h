@@ -254,11 +254,13 @@ inline int pack_batch(int nw, const osh_lba_problem* pr, const std::function<voi
     int* lmo = &h_lmoff[d.lmoff_off];
     lmo[0] = 0;
     for (int jn = 0; jn < p.n_points; ++jn) { const int jo = perm[jn]; lmo[jn + 1] = lmo[jn] + (old_lmo[jo + 1] - old_lmo[jo]); }
-    for (int jn = 0; jn < p.n_points; ++jn) {
-      const int jo = perm[jn];
+    // The caller's arrays are walked in their own (old) order -- sequential reads -- and every landmark's run is written to
+    // its renumbered place: scattered stores retire from the store buffer, scattered loads would each wait for memory.
+    for (int jo = 0; jo < p.n_points; ++jo) {
+      const int jn = old2new[jo];
       for (int k = 0; k < 3; ++k) h_pt[((size_t)d.pt_off + jn) * 3 + k] = p.points[3 * (size_t)jo + k];
-      int xo = old_lmo[jo];
-      for (int x = lmo[jn]; x < lmo[jn + 1]; ++x, ++xo) {
+      int x = lmo[jn];
+      for (int xo = old_lmo[jo]; xo < old_lmo[jo + 1]; ++xo, ++x) {
         const int e = order[xo], e2 = second[xo];
         const size_t g = (size_t)d.edge_off + x;
         const int kd = p.edge_kind[e];
