@@ -316,7 +316,7 @@ static double edge_chi2(const ostate* s, int e) {
   /* BaseEdge::chi2 = _error.dot(information()*_error), g2o/core/base_edge.h:58-61 */
   const double w = s->pr->edge_info[e];
   const double* r = s->err + 3 * e;
-  if (s->pr->edge_kind[e] == OSH_EDGE_MONO) return r[0] * (w * r[0]) + r[1] * (w * r[1]);
+  if (s->pr->edge_kind[e] != OSH_EDGE_STEREO) return r[0] * (w * r[0]) + r[1] * (w * r[1]);   /* mono and body edges: 2 rows */
   return r[0] * (w * r[0]) + r[1] * (w * r[1]) + r[2] * (w * r[2]);
 }
 
@@ -401,8 +401,72 @@ void oracle_edge_jacobians_kb8(const double qt[7], const double cam[5], const do
     }
 }
 
+/* ---- right-camera edge of a fisheye stereo rig: ORB_SLAM3::EdgeSE3ProjectXYZToBody
+ * (include/OptimizableTypes.h:117-144, src/OptimizableTypes.cpp:192-213), created at src/Optimizer.cc:1365-1399 with
+ * mTrl = SE3Quat(Trl) and pCamera = mpCamera2.  cam2 = fx fy cx cy k1..k4 of the right camera, trl = qx qy qz qw tx ty tz.
+ * T_rw = mTrl * T_lw is the SE3Quat product (se3quat.h:104-110: rotation product normalised, t = r1 * t2 + t1). */
+static void body_T_rw(const double trl[7], const double qt[7], double T_rw[7]) {
+  double q[4], rt[3];
+  quat_mul(trl, qt, q);
+  quat_normalize_rotation(q);
+  quat_rotate(trl, qt + 4, rt);
+  T_rw[0] = q[0]; T_rw[1] = q[1]; T_rw[2] = q[2]; T_rw[3] = q[3];
+  T_rw[4] = rt[0] + trl[4]; T_rw[5] = rt[1] + trl[5]; T_rw[6] = rt[2] + trl[6];
+}
+
+void oracle_edge_error_body(const double qt[7], const double cam2[8], const double trl[7],
+                            const double X[3], const double obs[3], double err[3]) {
+  /* _error = obs - pCamera->project((mTrl * v1->estimate()).map(v2->estimate())) */
+  double T_rw[7], Xr[3], uv[2];
+  body_T_rw(trl, qt, T_rw);
+  se3_map(T_rw, X, Xr);
+  oracle_kb8_project(cam2, cam2 + 4, Xr, uv);
+  err[0] = obs[0] - uv[0];
+  err[1] = obs[1] - uv[1];
+  err[2] = 0.0;
+}
+
+int oracle_edge_depth_positive_body(const double qt[7], const double trl[7], const double X[3]) {
+  double T_rw[7], Xr[3];
+  body_T_rw(trl, qt, T_rw);
+  se3_map(T_rw, X, Xr);
+  return Xr[2] > 0.0;
+}
+
+void oracle_edge_jacobians_body(const double qt[7], const double cam2[8], const double trl[7],
+                                const double X[3], double Jxi[9], double Jxj[18]) {
+  /* X_l = T_lw.map(X_w); X_r = mTrl.map(T_lw.map(X_w))
+   * _jacobianOplusXi = -projectJac(X_r) * T_rw.rotation();  _jacobianOplusXj = -projectJac(X_r) * mTrl.rotation() * SE3deriv(X_l) */
+  double T_rw[7], Xl[3], Xr[3], Rrw[9], Rrl[9], J[6], pj[6], pjr[6];
+  body_T_rw(trl, qt, T_rw);
+  se3_map(qt, X, Xl);
+  se3_map(trl, Xl, Xr);
+  quat_to_R(T_rw, Rrw);
+  quat_to_R(trl, Rrl);
+  memset(Jxi, 0, 9 * sizeof(double));
+  memset(Jxj, 0, 18 * sizeof(double));
+  oracle_kb8_project_jac(cam2, cam2 + 4, Xr, J);
+  for (int k = 0; k < 6; ++k) pj[k] = -J[k];
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double a = 0, b = 0;
+      for (int k = 0; k < 3; ++k) { a += pj[i * 3 + k] * Rrw[k * 3 + j]; b += pj[i * 3 + k] * Rrl[k * 3 + j]; }
+      Jxi[i * 3 + j] = a;
+      pjr[i * 3 + j] = b;
+    }
+  const double x = Xl[0], y = Xl[1], z = Xl[2];
+  const double D[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 6; ++j) {
+      double a = 0;
+      for (int k = 0; k < 3; ++k) a += pjr[i * 3 + k] * D[k * 6 + j];
+      Jxj[i * 6 + j] = a;
+    }
+}
+
 static double edge_delta(const ostate* s, int e) {
-  return s->pr->edge_kind[e] == OSH_EDGE_MONO ? s->pr->huber_mono : s->pr->huber_stereo;
+  /* rk->setDelta(thHuberMono) for the mono and the body edge (src/Optimizer.cc:1321,1386), thHuberStereo for the stereo edge */
+  return s->pr->edge_kind[e] != OSH_EDGE_STEREO ? s->pr->huber_mono : s->pr->huber_stereo;
 }
 
 /* SparseOptimizer::computeActiveErrors, g2o/core/sparse_optimizer.cpp:61-88 */
@@ -410,7 +474,9 @@ static void compute_active_errors(ostate* s) {
   const osh_lba_problem* p = s->pr;
   for (int e = 0; e < s->E; ++e) {
     const int ip = p->edge_pose[e], il = p->edge_point[e];
-    if (p->kb8 && p->edge_kind[e] == OSH_EDGE_MONO)
+    if (p->edge_kind[e] == OSH_EDGE_BODY)
+      oracle_edge_error_body(s->qt + 7 * ip, p->cam2, p->trl, s->X + 3 * il, p->edge_obs + 3 * e, s->err + 3 * e);
+    else if (p->kb8 && p->edge_kind[e] == OSH_EDGE_MONO)
       oracle_edge_error_kb8(s->qt + 7 * ip, p->pose_cam + 5 * ip, p->kb8, s->X + 3 * il, p->edge_obs + 3 * e, s->err + 3 * e);
     else
       oracle_edge_error(p->edge_kind[e], s->qt + 7 * ip, p->pose_cam + 5 * ip, s->X + 3 * il,
@@ -442,9 +508,10 @@ static void build_system(ostate* s) {
   for (int e = 0; e < s->E; ++e) {
     const int ip = p->edge_pose[e], il = p->edge_point[e];
     const int kind = p->edge_kind[e];
-    const int D = (kind == OSH_EDGE_MONO) ? 2 : 3;
+    const int D = (kind != OSH_EDGE_STEREO) ? 2 : 3;
     double A[9], B[18];
-    if (p->kb8 && kind == OSH_EDGE_MONO) oracle_edge_jacobians_kb8(s->qt + 7 * ip, p->pose_cam + 5 * ip, p->kb8, s->X + 3 * il, A, B);
+    if (kind == OSH_EDGE_BODY) oracle_edge_jacobians_body(s->qt + 7 * ip, p->cam2, p->trl, s->X + 3 * il, A, B);
+    else if (p->kb8 && kind == OSH_EDGE_MONO) oracle_edge_jacobians_kb8(s->qt + 7 * ip, p->pose_cam + 5 * ip, p->kb8, s->X + 3 * il, A, B);
     else oracle_edge_jacobians(kind, s->qt + 7 * ip, p->pose_cam + 5 * ip, s->X + 3 * il, A, B);
     const double w = p->edge_info[e];
     const double* r = s->err + 3 * e;
@@ -680,8 +747,9 @@ static int validate(const osh_lba_problem* p) {
   for (int e = 0; e < p->n_edges; ++e) {
     if (p->edge_pose[e] < 0 || p->edge_pose[e] >= p->n_free + p->n_fixed) return 0;
     if (p->edge_point[e] < 0 || p->edge_point[e] >= p->n_points) return 0;
-    if (p->edge_kind[e] > OSH_EDGE_STEREO) return 0;
-    if (p->kb8 && p->edge_kind[e] != OSH_EDGE_MONO) return 0;   /* a fisheye window is monocular */
+    if (p->edge_kind[e] > OSH_EDGE_BODY) return 0;
+    if (p->kb8 && p->edge_kind[e] == OSH_EDGE_STEREO) return 0;   /* a fisheye window has no rectified-stereo edges */
+    if (p->edge_kind[e] == OSH_EDGE_BODY && !(p->kb8 && p->cam2 && p->trl)) return 0;
   }
   return 1;
 }
@@ -861,7 +929,9 @@ int oracle_lba_solve(const osh_lba_problem* p, osh_lba_result* res) {
   if (res->edge_chi2) for (int e = 0; e < s.E; ++e) res->edge_chi2[e] = edge_chi2(&s, e);
   if (res->edge_depth_pos)
     for (int e = 0; e < s.E; ++e)
-      res->edge_depth_pos[e] = (uint8_t)oracle_edge_depth_positive(s.qt + 7 * p->edge_pose[e], s.X + 3 * p->edge_point[e]);
+      res->edge_depth_pos[e] = (uint8_t)(p->edge_kind[e] == OSH_EDGE_BODY
+          ? oracle_edge_depth_positive_body(s.qt + 7 * p->edge_pose[e], p->trl, s.X + 3 * p->edge_point[e])
+          : oracle_edge_depth_positive(s.qt + 7 * p->edge_pose[e], s.X + 3 * p->edge_point[e]));
   state_free(&s);
   return OSH_OK;
 }

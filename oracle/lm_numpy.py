@@ -20,7 +20,7 @@ from __future__ import annotations
 import numpy as np
 from scipy.linalg import expm
 
-MONO, STEREO = 0, 1
+MONO, STEREO, BODY = 0, 1, 2
 
 
 def quat_to_R(q):
@@ -99,6 +99,57 @@ def kb8_analytic_jacobians(T, cam, kb, X):
     return J_X, J_xi
 
 
+def _kb8_project_f32(cam, kb, Xc):
+    """KannalaBrandt8::project(Vector3d) with its float32 theta / psi (see kb8_edge_error)."""
+    fx, fy, cx, cy = cam[:4]
+    rho = np.float32(np.sqrt(np.float32(Xc[0] * Xc[0] + Xc[1] * Xc[1])))
+    theta = float(np.float32(np.arctan2(float(rho), float(np.float32(Xc[2])))))
+    psi = float(np.float32(np.arctan2(float(np.float32(Xc[1])), float(np.float32(Xc[0])))))
+    r = theta + kb[0] * theta**3 + kb[1] * theta**5 + kb[2] * theta**7 + kb[3] * theta**9
+    return np.array([fx * r * np.cos(psi) + cx, fy * r * np.sin(psi) + cy])
+
+
+def _kb8_dpi(cam, kb, Xc):
+    """d (u, v) / d Xc of the KannalaBrandt8 projection by the chain rule (as in kb8_analytic_jacobians)."""
+    fx, fy = cam[0], cam[1]
+    x, y, z = Xc
+    rho = np.hypot(x, y)
+    theta = np.arctan2(rho, z)
+    r = theta + kb[0] * theta**3 + kb[1] * theta**5 + kb[2] * theta**7 + kb[3] * theta**9
+    dr = 1 + 3 * kb[0] * theta**2 + 5 * kb[1] * theta**4 + 7 * kb[2] * theta**6 + 9 * kb[3] * theta**8
+    d2 = rho * rho + z * z
+    dtheta = np.array([z * x / (rho * d2), z * y / (rho * d2), -rho / d2])
+    dcos = np.array([1 / rho - x * x / rho**3, -x * y / rho**3, 0.0])
+    dsin = np.array([-x * y / rho**3, 1 / rho - y * y / rho**3, 0.0])
+    return np.vstack([fx * (dr * dtheta * x / rho + r * dcos), fy * (dr * dtheta * y / rho + r * dsin)])
+
+
+def _trl_matrix(trl):
+    T = np.eye(4)
+    T[:3, :3] = quat_to_R(np.asarray(trl[:4], dtype=np.float64))
+    T[:3, 3] = trl[4:]
+    return T
+
+
+def body_edge_error(T, cam2, trl, X, obs):
+    """Right-camera observation of a fisheye stereo rig (ORB_SLAM3::EdgeSE3ProjectXYZToBody, include/OptimizableTypes.h:125-130):
+    obs - project2(Trl * T * X), as one 4x4 product here (the reference multiplies the two SE3Quat first as well)."""
+    Trw = _trl_matrix(trl) @ T
+    Xr = Trw[:3, :3] @ X + Trw[:3, 3]
+    uv = _kb8_project_f32(cam2[:4], cam2[4:], Xr)
+    return np.array([obs[0] - uv[0], obs[1] - uv[1]])
+
+
+def body_analytic_jacobians(T, cam2, trl, X):
+    """Chain rule through Xr = Rrl (R X + t) + trl:  d err / d X = -dpi2 Rrl R,  d err / d xi = -dpi2 Rrl [ -hat(Xl) | I ]."""
+    Trl = _trl_matrix(trl)
+    R = T[:3, :3]
+    Xl = R @ X + T[:3, 3]
+    Xr = Trl[:3, :3] @ Xl + Trl[:3, 3]
+    dpi = _kb8_dpi(cam2[:4], cam2[4:], Xr) @ Trl[:3, :3]
+    return -dpi @ R, -dpi @ np.hstack([-hat(Xl), np.eye(3)])
+
+
 def edge_error(kind, T, cam, X, obs):
     """obs - projection.  The stereo residual reproduces the float32 1/z and bf
     of g2o::EdgeStereoSE3ProjectXYZ::cam_project (types_six_dof_expmap.cpp:190-197)."""
@@ -171,7 +222,9 @@ def errors(w, st):
     out = []
     for e in range(w.n_edges):
         ip, il = w.edge_pose[e], w.edge_point[e]
-        if getattr(w, "kb8", None) is not None and w.edge_kind[e] == MONO:
+        if w.edge_kind[e] == BODY:
+            out.append(body_edge_error(st.T[ip], w.cam2, w.trl, st.X[il], w.edge_obs[e]))
+        elif getattr(w, "kb8", None) is not None and w.edge_kind[e] == MONO:
             out.append(kb8_edge_error(st.T[ip], w.pose_cam[ip], w.kb8, st.X[il], w.edge_obs[e]))
         else:
             out.append(edge_error(w.edge_kind[e], st.T[ip], w.pose_cam[ip], st.X[il], w.edge_obs[e]))
@@ -184,7 +237,7 @@ def robust_chi2(w, errs):
     for e, r in enumerate(errs):
         c = float(r @ (w.edge_info[e] * r))
         per_edge[e] = c
-        delta = w.huber_mono if w.edge_kind[e] == MONO else w.huber_stereo
+        delta = w.huber_stereo if w.edge_kind[e] == STEREO else w.huber_mono   # the body edge takes thHuberMono (Optimizer.cc:1386)
         chi += huber(c, delta)[0]
     return chi, per_edge
 
@@ -199,13 +252,15 @@ def build_dense_system(w, st, errs):
         ip, il = w.edge_pose[e], w.edge_point[e]
         kind = w.edge_kind[e]
         r = errs[e]
-        if getattr(w, "kb8", None) is not None and kind == MONO:
+        if kind == BODY:
+            J_X, J_xi = body_analytic_jacobians(st.T[ip], w.cam2, w.trl, st.X[il])
+        elif getattr(w, "kb8", None) is not None and kind == MONO:
             J_X, J_xi = kb8_analytic_jacobians(st.T[ip], w.pose_cam[ip], w.kb8, st.X[il])
         else:
             J_X, J_xi = analytic_jacobians(kind, st.T[ip], w.pose_cam[ip], st.X[il])
         info = w.edge_info[e]
         c = float(r @ (info * r))
-        delta = w.huber_mono if kind == MONO else w.huber_stereo
+        delta = w.huber_stereo if kind == STEREO else w.huber_mono
         _, rho1 = huber(c, delta)
         W = rho1 * info
         sl = slice(6 * P + 3 * il, 6 * P + 3 * il + 3)

@@ -27,6 +27,9 @@ void oracle_kb8_project(const double cam[5], const double kb[4], const double Xc
 void oracle_kb8_project_jac(const double cam[5], const double kb[4], const double Xc[3], double J[6]);
 void oracle_edge_error_kb8(const double qt[7], const double cam[5], const double kb[4], const double X[3], const double obs[3], double err[3]);
 void oracle_edge_jacobians_kb8(const double qt[7], const double cam[5], const double kb[4], const double X[3], double Jxi[9], double Jxj[18]);
+void oracle_edge_error_body(const double qt[7], const double cam2[8], const double trl[7], const double X[3], const double obs[3], double err[3]);
+void oracle_edge_jacobians_body(const double qt[7], const double cam2[8], const double trl[7], const double X[3], double Jxi[9], double Jxj[18]);
+int  oracle_edge_depth_positive_body(const double qt[7], const double trl[7], const double X[3]);
 int  oracle_ldlt_solve(int n, double* A, const double* b, double* x, double* tmp);
 
 /* ---- frustum projection of map points into a frame (frustum_oracle.c) ---- */

@@ -454,7 +454,7 @@ constexpr int kSiKS = 3 * kSiLm + 1;   // LDS row stride (doubles)
 constexpr int kSiRows = 6 * kItemPoses;
 
 template <bool SYM, bool KB8>
-__global__ __launch_bounds__(64, 2) void k_schur_fused(BatchView bv, int item_base, int mode) {
+__global__ __launch_bounds__(64, KB8 ? 1 : 2) void k_schur_fused(BatchView bv, int item_base, int mode) {
   __shared__ double shA[kSiRows * kSiKS];
   __shared__ double shB[SYM ? 1 : kSiRows * kSiKS];
   __shared__ double shPose[(SYM ? 1 : 2) * 8 * kPoseRec];
@@ -1638,8 +1638,12 @@ extern "C" int osh_lba_linearize(osh_lba_ctx* c, int32_t window, double* Hpp, do
     if (d.E) OSH_HIP(hipMemcpy(hs.data(), c->d_dbg.as<double>() + (size_t)d.edge_off * 18, hs.size() * 8, hipMemcpyDeviceToHost));
     std::memset(Hpl, 0, (size_t)d.in_edges * 18 * 8);
     const int* eo = pb.sec<int>(PackedBatch::EORIG) + d.edge_off;
-    // a merged fisheye-rig edge reports the sum of its two blocks at the left edge (the block of S they share)
-    for (int x = 0; x < d.E; ++x) std::memcpy(Hpl + (size_t)eo[x] * 18, &hs[(size_t)x * 18], 18 * 8);
+    const int* eo2 = pb.has_rig ? pb.sec<int>(PackedBatch::EORIG2) + d.edge_off : nullptr;
+    // the two edges of a merged fisheye-rig pair share one Hessian block: both report it (their sum)
+    for (int x = 0; x < d.E; ++x) {
+      std::memcpy(Hpl + (size_t)eo[x] * 18, &hs[(size_t)x * 18], 18 * 8);
+      if (eo2 && eo2[x] >= 0) std::memcpy(Hpl + (size_t)eo2[x] * 18, &hs[(size_t)x * 18], 18 * 8);
+    }
   }
   if (chi2 && d.in_edges) {
     // mark every window evaluated so k_finalize emits chi2 of the current state

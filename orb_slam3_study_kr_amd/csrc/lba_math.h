@@ -380,14 +380,26 @@ __device__ __forceinline__ void edge_core_kb8(int kind, const double* qt, const 
   if (kind >= 2) {   // right edge: EdgeSE3ProjectXYZToBody (include/OptimizableTypes.h:125-130, src/OptimizableTypes.cpp:192-213)
     const double* ro = (kind == 2) ? rec : rec2;
     const double info = fabs(ro[3]);
-    double Rrl[9], Xr[3];
+    double Rrl[9], Xr[3], Xe[3];
     quat_to_R(trl, Rrl);
-    // (mTrl * v1->estimate()).map(X): the product SE3Quat is formed first in the reference; mapping through the two
-    // transforms one after the other differs from it only by rounding
+    // linearizeOplus maps through the two transforms one after the other (X_r = mTrl.map(T_lw.map(X_w)), OptimizableTypes.cpp:198),
+    // computeError through their SE3Quat product ((mTrl * v1->estimate()).map(X), OptimizableTypes.h:129): with float32 theta /
+    // psi inside the projection the two differ by a staircase step now and then, so each is restated as it is
     quat_rotate(trl, Xc, Xr);
     Xr[0] += trl[4]; Xr[1] += trl[5]; Xr[2] += trl[6];
+    {
+      double q[4], tr[3], rx[3];
+      q[3] = trl[3] * qt[3] - trl[0] * qt[0] - trl[1] * qt[1] - trl[2] * qt[2];
+      q[0] = trl[3] * qt[0] + trl[0] * qt[3] + trl[1] * qt[2] - trl[2] * qt[1];
+      q[1] = trl[3] * qt[1] + trl[1] * qt[3] + trl[2] * qt[0] - trl[0] * qt[2];
+      q[2] = trl[3] * qt[2] + trl[2] * qt[3] + trl[0] * qt[1] - trl[1] * qt[0];
+      quat_normalize_rotation(q);                     // SE3Quat::operator* normalises (se3quat.h:104-110)
+      quat_rotate(trl, qt + 4, tr);
+      quat_rotate(q, X, rx);
+      Xe[0] = rx[0] + (tr[0] + trl[4]); Xe[1] = rx[1] + (tr[1] + trl[5]); Xe[2] = rx[2] + (tr[2] + trl[6]);
+    }
     double u, v;
-    kb8_project(cam2, cam2 + 4, Xr, u, v);
+    kb8_project(cam2, cam2 + 4, Xe, u, v);
     const double r0 = ro[0] - u, r1 = ro[1] - v;
     chi_r = r0 * (info * r0) + r1 * (info * r1);
     double rh0, rh1;

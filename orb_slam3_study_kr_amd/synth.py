@@ -179,6 +179,13 @@ def _quat_from_R(R: np.ndarray) -> np.ndarray:
     return q / np.linalg.norm(q)
 
 
+def _quat_to_R(q: np.ndarray) -> np.ndarray:
+    x, y, z, w = q / np.linalg.norm(q)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
 def _rodrigues(w: np.ndarray) -> np.ndarray:
     th = np.linalg.norm(w)
     K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
@@ -311,6 +318,50 @@ def make_window(seed: int, n_free: int = 50, n_fixed: int = 10, n_points: int = 
         gt_pose_qt=gt_qt, gt_points=pts_gt, outlier_mask=is_out, kb8=KB8_K.copy() if fisheye else None,
     )
     return w.normalise()
+
+
+def make_rig_window(seed: int, right_frac: float = 0.6, right_only_frac: float = 0.1, **kwargs) -> LbaWindow:
+    """A fisheye STEREO rig window (KannalaBrandt8 left + right camera, src/Optimizer.cc:1305-1399): the monocular fisheye window
+    of ``make_window(fisheye=True)`` whose observations gain, with probability ``right_frac``, a right-camera observation of the
+    same landmark in the same keyframe (OSH_EDGE_BODY on the same Hessian block) and are, with probability ``right_only_frac``,
+    replaced by a right-camera observation alone.  Right camera: slightly different intrinsics, Trl = a 10 cm baseline with a
+    small rotation.  Edge order as the reference inserts them: left edge, then right edge, landmark by landmark."""
+    w = make_window(seed, stereo=False, fisheye=True, **kwargs)
+    rng = np.random.Generator(np.random.PCG64(seed + 104729))
+    cam2 = np.array([float(FX) * 1.01, float(FY) * 0.99, float(CX) + 3.0, float(CY) - 2.0, *(KB8_K * np.array([1.05, 0.9, 1.1, 1.0]))])
+    cam2[:4] = cam2[:4].astype(np.float32).astype(np.float64)
+    cam2[4:] = cam2[4:].astype(np.float32).astype(np.float64)
+    rv = np.array([0.01, -0.02, 0.005])
+    ang = np.linalg.norm(rv)
+    q = np.concatenate([np.sin(ang / 2) * rv / ang, [np.cos(ang / 2)]])
+    trl = np.concatenate([q, [-0.1, 0.002, 0.001]]).astype(np.float32).astype(np.float64)   # Sophus::SE3f storage
+    Rrl = _quat_to_R(trl[:4] / np.linalg.norm(trl[:4]))
+    E = w.n_edges
+    u = rng.uniform(0, 1, E)
+    add_right = u < right_frac
+    right_only = (u >= right_frac) & (u < right_frac + right_only_frac)
+    ep, el, ek, eo, ei = [], [], [], [], []
+    for e in range(E):
+        ip, il = int(w.edge_pose[e]), int(w.edge_point[e])
+        if add_right[e] or right_only[e]:
+            qt = w.gt_pose_qt[ip]
+            Xl = _quat_to_R(qt[:4]) @ w.gt_points[il] + qt[4:]
+            Xr = Rrl @ Xl + trl[4:]
+            rho = np.hypot(Xr[0], Xr[1])
+            theta = np.arctan2(rho, Xr[2])
+            rr = theta + cam2[4] * theta**3 + cam2[5] * theta**5 + cam2[6] * theta**7 + cam2[7] * theta**9
+            octave = int(rng.integers(0, N_LEVELS))
+            uv = np.array([cam2[0] * rr * Xr[0] / rho + cam2[2], cam2[1] * rr * Xr[1] / rho + cam2[3]])
+            uv = uv + rng.standard_normal(2) * float(SCALE_FACTORS[octave]) + (rng.standard_normal(2) * 20.0 if rng.uniform() < 0.03 else 0.0)
+        if not right_only[e]:
+            ep.append(ip); el.append(il); ek.append(capi.OSH_EDGE_MONO); eo.append(w.edge_obs[e]); ei.append(w.edge_info[e])
+        if add_right[e] or right_only[e]:
+            ep.append(ip); el.append(il); ek.append(capi.OSH_EDGE_BODY); eo.append([uv[0], uv[1], -1.0]); ei.append(float(INV_LEVEL_SIGMA2[octave]))
+    return LbaWindow(n_free=w.n_free, n_fixed=w.n_fixed, pose_qt=w.pose_qt, pose_cam=w.pose_cam, points=w.points,
+                     edge_pose=np.array(ep, dtype=np.int32), edge_point=np.array(el, dtype=np.int32), edge_kind=np.array(ek, dtype=np.uint8),
+                     edge_obs=_f32(np.array(eo, dtype=np.float64)), edge_info=np.array(ei, dtype=np.float64),
+                     lambda_init=w.lambda_init, max_iterations=w.max_iterations, gt_pose_qt=w.gt_pose_qt, gt_points=w.gt_points,
+                     kb8=w.kb8, cam2=cam2, trl=trl).normalise()
 
 
 def make_config1(seed: int = 1) -> LbaWindow:

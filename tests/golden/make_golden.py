@@ -25,7 +25,8 @@ def window_arrays(w):
                 edge_pose=w.edge_pose, edge_point=w.edge_point, edge_kind=w.edge_kind, edge_obs=w.edge_obs,
                 edge_info=w.edge_info, huber_mono=w.huber_mono, huber_stereo=w.huber_stereo,
                 lambda_init=w.lambda_init, max_iterations=w.max_iterations,
-                kb8=w.kb8 if w.kb8 is not None else np.zeros(0))
+                kb8=w.kb8 if w.kb8 is not None else np.zeros(0), cam2=w.cam2 if w.cam2 is not None else np.zeros(0),
+                trl=w.trl if w.trl is not None else np.zeros(0))
 
 
 def lba_fixture(name, w):
@@ -57,7 +58,9 @@ def orb_fixture():
     print("orb_64x64", dist.min(), dist.max())
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "rig":
+    lba_fixture("lba_tiny_rig", synth.make_rig_window(71, n_free=3, n_fixed=2, n_points=40, track_len=(2, 5)))
+elif __name__ == "__main__":
     lba_fixture("lba_tiny_mono", synth.make_window(11, n_free=3, n_fixed=2, n_points=40, stereo=False, track_len=(2, 5)))
     lba_fixture("lba_tiny_stereo", synth.make_window(12, n_free=3, n_fixed=2, n_points=40, stereo=True, track_len=(2, 5)))
     lba_fixture("lba_tiny_mixed", synth.make_window(13, n_free=4, n_fixed=1, n_points=30, stereo=True, track_len=(2, 5),
@@ -68,4 +71,6 @@ if __name__ == "__main__":
     lba_fixture("lba_tiny_reject_mono", synth.make_window(51, stereo=False, **rej))
     # monocular KannalaBrandt8 (fisheye) window: the independent numpy model of oracle/lm_numpy.py (own Jacobian derivation)
     lba_fixture("lba_tiny_fisheye", synth.make_window(61, n_free=3, n_fixed=2, n_points=40, stereo=False, track_len=(2, 5), fisheye=True))
+    # fisheye STEREO rig: left KannalaBrandt8 edges + right-camera body edges (EdgeSE3ProjectXYZToBody) sharing Hessian blocks
+    lba_fixture("lba_tiny_rig", synth.make_rig_window(71, n_free=3, n_fixed=2, n_points=40, track_len=(2, 5)))
     orb_fixture()

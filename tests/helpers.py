@@ -6,7 +6,7 @@ import numpy as np
 from orb_slam3_study_kr_amd import synth
 
 GOLDEN = Path(__file__).resolve().parent / "golden"
-LBA_FIXTURES = ["lba_tiny_mono", "lba_tiny_stereo", "lba_tiny_mixed", "lba_tiny_reject_stereo", "lba_tiny_reject_mono", "lba_tiny_fisheye"]
+LBA_FIXTURES = ["lba_tiny_mono", "lba_tiny_stereo", "lba_tiny_mixed", "lba_tiny_reject_stereo", "lba_tiny_reject_mono", "lba_tiny_fisheye", "lba_tiny_rig"]
 
 
 def load_lba_fixture(name):
@@ -17,7 +17,9 @@ def load_lba_fixture(name):
         edge_obs=z["edge_obs"], edge_info=z["edge_info"], huber_mono=float(z["huber_mono"]),
         huber_stereo=float(z["huber_stereo"]), lambda_init=float(z["lambda_init"]),
         max_iterations=int(z["max_iterations"]),
-        kb8=(z["kb8"] if "kb8" in z.files and z["kb8"].size == 4 else None)).normalise()
+        kb8=(z["kb8"] if "kb8" in z.files and z["kb8"].size == 4 else None),
+        cam2=(z["cam2"] if "cam2" in z.files and z["cam2"].size == 8 else None),
+        trl=(z["trl"] if "trl" in z.files and z["trl"].size == 7 else None)).normalise()
     return w, z
 
 
