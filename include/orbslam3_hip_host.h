@@ -23,9 +23,16 @@ osh_host_graph* osh_host_graph_create(int32_t n_kf, const int64_t* kf_id, const 
                                       int32_t n_mp, const int64_t* mp_id, const float* mp_pos,
                                       int32_t n_obs, const int32_t* obs_kf, const int32_t* obs_mp, const float* obs_uvr,
                                       const int32_t* obs_octave, int64_t init_kf_id, int32_t inertial);
+/* Turn the map into a fisheye STEREO rig (call after osh_host_graph_set_fisheye): right camera cam2 = fx fy cx cy k1..k4,
+ * Trl = qx qy qz qw tx ty tz, and n_obs right-camera observations (keyframe index, map point index, u v, octave) which become
+ * mvKeysRight entries observed through the right slot of MapPoint::GetObservations()'s tuples. */
+int osh_host_graph_set_rig(osh_host_graph* g, const float cam2[8], const float trl_qt[7], int32_t n_obs, const int32_t* obs_kf,
+                           const int32_t* obs_mp, const float* obs_uv, const int32_t* obs_octave);
 void osh_host_graph_destroy(osh_host_graph* g);
 /* Camera model of the window the last osh_host_pack_lba / _gba / _welding call built: 1 + k1..k4 for KannalaBrandt8, else 0. */
 int osh_host_last_pack_kb8(osh_host_graph* g, double k[4]);
+/* Same for the rig description of a fisheye stereo window: returns 1 and fills cam2[8] / trl[7], else 0. */
+int osh_host_last_pack_rig(osh_host_graph* g, double cam2[8], double trl[7]);
 /* Switch the map's camera to a KannalaBrandt8 (same fx fy cx cy, coefficients k1..k4): a monocular fisheye map. */
 void osh_host_graph_set_fisheye(osh_host_graph* g, const float k[4]);
 /* covisibility list returned by KeyFrame::GetVectorCovisibleKeyFrames() of keyframe kf_index */

@@ -139,9 +139,8 @@ bool PackLocalBA(KeyFrame* pKF, Map* pMap, LbaPack& pk) {
         pk.vEdgeMP.push_back(pMP);
       }
       if (pKFi->mpCamera2 && std::get<1>(ob.second) != -1) {
-        // EdgeSE3ProjectXYZToBody (:1365-1399): second edge on the same Hessian block -- next row
-        pk.unsupported = "right-camera (fisheye stereo) observation";
-        return true;
+        // EdgeSE3ProjectXYZToBody (:1365-1399): the right-camera observation, a second edge on the pair's Hessian block
+        if (!pk.add_body_edge(pKFi, pMP, std::get<1>(ob.second), poseIndex.at(pKFi), pointIndex.at(pMP))) return true;
       }
     }
   }
@@ -191,12 +190,12 @@ void Optimizer::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap
     return;
   }
 
-  // 9. outlier observations (:1413-1460): mono edges first, then stereo, each in insertion order
+  // 9. outlier observations (:1413-1460): mono edges first, then the right-camera (body) edges, then stereo, each in insertion order
   std::vector<std::pair<KeyFrame*, MapPoint*>> vToErase;
   vToErase.reserve(pk.edge_pose.size());
-  for (int pass = 0; pass < 2; ++pass) {
-    const int kind = pass == 0 ? OSH_EDGE_MONO : OSH_EDGE_STEREO;
-    const double th = pass == 0 ? 5.991 : 7.815;
+  for (int pass = 0; pass < 3; ++pass) {
+    const int kind = pass == 0 ? OSH_EDGE_MONO : (pass == 1 ? OSH_EDGE_BODY : OSH_EDGE_STEREO);
+    const double th = pass == 2 ? 7.815 : 5.991;
     for (size_t e = 0; e < pk.edge_kind.size(); ++e) {
       if (pk.edge_kind[e] != kind) continue;
       MapPoint* pMP = pk.vEdgeMP[e];

@@ -51,7 +51,7 @@ void PackBundleAdjustment(const std::vector<KeyFrame*>& vpKFs, const std::vector
   }
   // point vertices and edges (:134-300) in g2o insertion order: vpMP order x observation-map order.  A point without any
   // edge is removed again (:289-293); the others keep the Hessian order of their ids (ascending mnId).
-  struct Ed { KeyFrame* kf; MapPoint* mp; int pose; uint8_t kind; double obs[3]; double info; };
+  struct Ed { KeyFrame* kf; MapPoint* mp; int pose; uint8_t kind; double obs[3]; double info; int right; };
   std::vector<Ed> edges;
   std::vector<MapPoint*> included;
   for (size_t i = 0; i < vpMP.size(); i++) {
@@ -75,11 +75,19 @@ void PackBundleAdjustment(const std::vector<KeyFrame*>& vpKFs, const std::vector
         e.kf = pKF; e.mp = pMP; e.pose = pit->second; e.kind = stereo ? OSH_EDGE_STEREO : OSH_EDGE_MONO;
         e.obs[0] = kpUn.pt.x; e.obs[1] = kpUn.pt.y; e.obs[2] = stereo ? kp_ur : -1.0;
         e.info = pKF->mvInvLevelSigma2[kpUn.octave];
+        e.right = -1;
         edges.push_back(e);
       }
-      if (pKF->mpCamera2 && std::get<1>(ob.second) != -1) {
-        pk.unsupported = "right-camera (fisheye stereo) observation";   // EdgeSE3ProjectXYZToBody (:235-283)
-        return;
+      // (the reference compares the UNSHIFTED index with mvKeysRight.size() here, :232: kept as it is)
+      if (pKF->mpCamera2 && std::get<1>(ob.second) != -1 && std::get<1>(ob.second) < (int)pKF->mvKeysRight.size()) {
+        // EdgeSE3ProjectXYZToBody (:235-283): right-camera observation; the (float) Huber delta is thHuber2D as for the left edge
+        if (!pk.rig_camera(pKF)) return;
+        Ed e;
+        e.kf = pKF; e.mp = pMP; e.pose = pit->second; e.kind = OSH_EDGE_BODY; e.right = std::get<1>(ob.second);
+        const cv::KeyPoint& kp = pKF->mvKeysRight[e.right - pKF->NLeft];
+        e.obs[0] = kp.pt.x; e.obs[1] = kp.pt.y; e.obs[2] = -1.0;
+        e.info = pKF->mvInvLevelSigma2[kp.octave];
+        edges.push_back(e);
       }
     }
     if (nEdges == 0) vbNotIncludedMP[i] = true;

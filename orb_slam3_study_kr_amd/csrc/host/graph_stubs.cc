@@ -36,9 +36,13 @@ void KeyFrame::EraseMapPointMatch(MapPoint* pMP) {
 }
 
 void MapPoint::AddObservation(KeyFrame* pKF, int idx) {
-  if (mObservations.count(pKF)) return;
-  mObservations[pKF] = std::make_tuple(idx, -1);
-  nObs += (pKF->mvuRight[idx] >= 0) ? 2 : 1;   // src/MapPoint.cc:150-165
+  // src/MapPoint.cc:140-165: the index selects the left / right slot of the (left, right) tuple of a fisheye rig
+  std::tuple<int, int> indexes = mObservations.count(pKF) ? mObservations[pKF] : std::tuple<int, int>(-1, -1);
+  if (pKF->NLeft != -1 && idx >= pKF->NLeft) std::get<1>(indexes) = idx;
+  else std::get<0>(indexes) = idx;
+  mObservations[pKF] = indexes;
+  if (!pKF->mpCamera2 && pKF->mvuRight[idx] >= 0) nObs += 2;
+  else nObs++;
 }
 
 // src/MapPoint.cc:168-201: drop the observation; a point left with <= 2 observations goes bad
@@ -89,8 +93,9 @@ std::vector<size_t> KeyFrame::GetFeaturesInArea(const float& x, const float& y, 
 void MapPoint::EraseObservation(KeyFrame* pKF) {
   auto it = mObservations.find(pKF);
   if (it == mObservations.end()) return;
-  const int leftIndex = std::get<0>(it->second);
-  if (leftIndex != -1) nObs -= (pKF->mvuRight[leftIndex] >= 0) ? 2 : 1;
+  const int leftIndex = std::get<0>(it->second), rightIndex = std::get<1>(it->second);
+  if (leftIndex != -1) nObs -= (!pKF->mpCamera2 && pKF->mvuRight[leftIndex] >= 0) ? 2 : 1;
+  if (rightIndex != -1) nObs--;
   mObservations.erase(it);
   if (nObs <= 2) mbBad = true;
 }

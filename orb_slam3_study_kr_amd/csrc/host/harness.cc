@@ -16,13 +16,15 @@ using namespace ORB_SLAM3;
 
 struct osh_host_graph {
   Map map;
-  std::unique_ptr<GeometricCamera> cam;
+  std::unique_ptr<GeometricCamera> cam, cam2;
   std::vector<std::unique_ptr<KeyFrame>> kfs;
   std::vector<std::unique_ptr<MapPoint>> mps;
   std::vector<std::unique_ptr<IMU::Preintegrated>> preints;
   LibaPack liba;   // storage behind osh_host_pack_liba
   bool last_has_kb8 = false;   // camera model of the last osh_host_pack_lba / _gba / _welding
   double last_kb8[4] = {0, 0, 0, 0};
+  bool last_has_rig = false;
+  double last_cam2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_trl[7] = {0, 0, 0, 1, 0, 0, 0};
 };
 
 static Sophus::SE3f pose_from(const float* qt) {
@@ -79,6 +81,34 @@ extern "C" void osh_host_graph_set_fisheye(osh_host_graph* g, const float k[4]) 
   for (auto& kf : g->kfs) kf->mpCamera = g->cam.get();
 }
 
+// Turn the map into a fisheye STEREO rig (after osh_host_graph_set_fisheye): every keyframe gets mpCamera2 = KannalaBrandt8(cam2),
+// Trl, NLeft = its number of left keypoints, and the right-camera observations obs_kf/obs_mp/obs_uv/obs_octave are appended to
+// mvKeysRight and registered with MapPoint::AddObservation(kf, NLeft + index) (src/MapPoint.cc:140-165).
+extern "C" int osh_host_graph_set_rig(osh_host_graph* g, const float cam2[8], const float trl_qt[7], int32_t n_obs, const int32_t* obs_kf,
+                                      const int32_t* obs_mp, const float* obs_uv, const int32_t* obs_octave) {
+  if (!g || g->kfs.empty()) return -1;
+  g->cam2.reset(new KannalaBrandt8(std::vector<float>(cam2, cam2 + 8)));
+  for (auto& kf : g->kfs) {
+    kf->mpCamera2 = g->cam2.get();
+    kf->mTrl = pose_from(trl_qt);
+    kf->NLeft = (int)kf->mvKeysUn.size();
+  }
+  for (int o = 0; o < n_obs; ++o) {
+    KeyFrame* kf = g->kfs[obs_kf[o]].get();
+    MapPoint* mp = g->mps[obs_mp[o]].get();
+    cv::KeyPoint kp;
+    kp.pt.x = obs_uv[2 * o]; kp.pt.y = obs_uv[2 * o + 1]; kp.octave = obs_octave[o];
+    const int ridx = (int)kf->mvKeysRight.size();
+    kf->mvKeysRight.push_back(kp);
+    // the keyframe's match table covers left and right keypoints (indices >= NLeft are right ones)
+    if ((int)kf->mvpMapPoints.size() < kf->NLeft + ridx + 1) kf->mvpMapPoints.resize(kf->NLeft + ridx + 1, nullptr);
+    kf->mvpMapPoints[kf->NLeft + ridx] = mp;
+    kf->mvuRight.resize(kf->mvpMapPoints.size(), -1.f);
+    mp->AddObservation(kf, kf->NLeft + ridx);
+  }
+  return 0;
+}
+
 extern "C" void osh_host_graph_destroy(osh_host_graph* g) { delete g; }
 
 extern "C" int osh_host_graph_set_covisible(osh_host_graph* g, int32_t kf_index, int32_t n, const int32_t* kf_indices) {
@@ -103,6 +133,7 @@ extern "C" int osh_host_pack_lba(osh_host_graph* g, int32_t kf_index, int32_t si
   if (!ok) return 1;
   if (pk.unsupported) return -3;
   g->last_has_kb8 = pk.has_kb8; for (int k = 0; k < 4; ++k) g->last_kb8[k] = pk.kb8[k];
+  g->last_has_rig = pk.has_rig; for (int k = 0; k < 8; ++k) g->last_cam2[k] = pk.cam2[k]; for (int k = 0; k < 7; ++k) g->last_trl[k] = pk.trl[k];
   auto cp = [](auto* dst, const auto& src) { if (dst) std::copy(src.begin(), src.end(), dst); };
   cp(pose_qt, pk.pose_qt); cp(pose_cam, pk.pose_cam); cp(points, pk.points); cp(edge_pose, pk.edge_pose);
   cp(edge_point, pk.edge_point); cp(edge_kind, pk.edge_kind); cp(edge_obs, pk.edge_obs); cp(edge_info, pk.edge_info);
@@ -127,6 +158,14 @@ extern "C" int osh_host_last_pack_kb8(osh_host_graph* g, double k[4]) {
   return 1;
 }
 
+// Rig of the window the last pack call produced: returns 1 and fills cam2[8], trl[7] for a fisheye stereo rig window, else 0.
+extern "C" int osh_host_last_pack_rig(osh_host_graph* g, double cam2[8], double trl[7]) {
+  if (!g || !g->last_has_rig) return 0;
+  for (int i = 0; i < 8; ++i) cam2[i] = g->last_cam2[i];
+  for (int i = 0; i < 7; ++i) trl[i] = g->last_trl[i];
+  return 1;
+}
+
 // ---- Optimizer::GlobalBundleAdjustemnt (csrc/host/OptimizerGlobal.cc)
 extern "C" int osh_host_pack_gba(osh_host_graph* g, int32_t sizes[5], double* pose_qt, double* pose_cam, double* points,
                                  int32_t* edge_pose, int32_t* edge_point, uint8_t* edge_kind, double* edge_obs, double* edge_info,
@@ -139,6 +178,7 @@ extern "C" int osh_host_pack_gba(osh_host_graph* g, int32_t sizes[5], double* po
   sizes[4] = (int32_t)std::count(notIncluded.begin(), notIncluded.end(), true);
   if (pk.unsupported) return -3;
   g->last_has_kb8 = pk.has_kb8; for (int k = 0; k < 4; ++k) g->last_kb8[k] = pk.kb8[k];
+  g->last_has_rig = pk.has_rig; for (int k = 0; k < 8; ++k) g->last_cam2[k] = pk.cam2[k]; for (int k = 0; k < 7; ++k) g->last_trl[k] = pk.trl[k];
   auto cp = [](auto* dst, const auto& src) { if (dst) std::copy(src.begin(), src.end(), dst); };
   cp(pose_qt, pk.pose_qt); cp(pose_cam, pk.pose_cam); cp(points, pk.points); cp(edge_pose, pk.edge_pose);
   cp(edge_point, pk.edge_point); cp(edge_kind, pk.edge_kind); cp(edge_obs, pk.edge_obs); cp(edge_info, pk.edge_info);
@@ -168,6 +208,7 @@ extern "C" int osh_host_pack_welding(osh_host_graph* g, int32_t main_index, int3
   sizes[0] = pk.n_free; sizes[1] = pk.n_fixed; sizes[2] = (int32_t)pk.vPointMPs.size(); sizes[3] = (int32_t)pk.edge_pose.size(); sizes[4] = 0;
   if (pk.unsupported) return -3;
   g->last_has_kb8 = pk.has_kb8; for (int k = 0; k < 4; ++k) g->last_kb8[k] = pk.kb8[k];
+  g->last_has_rig = pk.has_rig; for (int k = 0; k < 8; ++k) g->last_cam2[k] = pk.cam2[k]; for (int k = 0; k < 7; ++k) g->last_trl[k] = pk.trl[k];
   auto cp = [](auto* dst, const auto& src) { if (dst) std::copy(src.begin(), src.end(), dst); };
   cp(pose_qt, pk.pose_qt); cp(pose_cam, pk.pose_cam); cp(points, pk.points); cp(edge_pose, pk.edge_pose);
   cp(edge_point, pk.edge_point); cp(edge_kind, pk.edge_kind); cp(edge_obs, pk.edge_obs); cp(edge_info, pk.edge_info);

@@ -25,6 +25,43 @@ struct LbaPack {
   bool has_kb8 = false;       // the keyframes' camera is a KannalaBrandt8 (monocular fisheye)
   double kb8[4] = {0, 0, 0, 0};
   int n_pinhole_mono = 0;
+  bool has_rig = false;       // fisheye stereo rig: right-camera (body) edges through cam2 / trl
+  double cam2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double trl[7] = {0, 0, 0, 1, 0, 0, 0};
+  // Right camera of a keyframe with a right-camera observation (e->pCamera = pKFi->mpCamera2, e->mTrl = GetRelativePoseTrl(),
+  // src/Optimizer.cc:1389-1392): one KannalaBrandt8 model and one Trl shared by the whole window (a rig is rigid).
+  bool rig_camera(KeyFrame* pKF) {
+    GeometricCamera* cam = pKF->mpCamera2;
+    if (!cam || cam->GetType() != GeometricCamera::CAM_FISHEYE) { unsupported = "right camera that is not a KannalaBrandt8"; return false; }
+    double c[8], t[7];
+    for (int i = 0; i < 8; ++i) c[i] = cam->getParameter(i);
+    const Sophus::SE3f Trl = pKF->GetRelativePoseTrl();
+    const Eigen::Quaterniond q = Trl.unit_quaternion().cast<double>();
+    const Eigen::Vector3d tt = Trl.translation().cast<double>();
+    t[0] = q.x(); t[1] = q.y(); t[2] = q.z(); t[3] = q.w(); t[4] = tt[0]; t[5] = tt[1]; t[6] = tt[2];
+    if (has_rig) {
+      for (int i = 0; i < 8; ++i) if (c[i] != cam2[i]) { unsupported = "keyframes with different right cameras in one window"; return false; }
+      for (int i = 0; i < 7; ++i) if (t[i] != trl[i]) { unsupported = "keyframes with different Trl in one window"; return false; }
+    }
+    has_rig = true;
+    for (int i = 0; i < 8; ++i) cam2[i] = c[i];
+    for (int i = 0; i < 7; ++i) trl[i] = t[i];
+    return true;
+  }
+  // the right-camera edge of (pKF, pMP): appended right after the pair's left edge, as the reference inserts it
+  bool add_body_edge(KeyFrame* pKF, MapPoint* pMP, int rightIndex, int pose, int point) {
+    if (!rig_camera(pKF)) return false;
+    rightIndex -= pKF->NLeft;                                   // :1369
+    const cv::KeyPoint& kp = pKF->mvKeysRight[rightIndex];      // :1372
+    edge_pose.push_back(pose);
+    edge_point.push_back(point);
+    edge_kind.push_back(OSH_EDGE_BODY);
+    edge_obs.push_back(kp.pt.x); edge_obs.push_back(kp.pt.y); edge_obs.push_back(-1.0);
+    edge_info.push_back(pKF->mvInvLevelSigma2[kp.octave]);      // :1380-1381
+    vEdgeKF.push_back(pKF);
+    vEdgeMP.push_back(pMP);
+    return true;
+  }
   // Camera of a monocular observation (the edge projects through pKF->mpCamera, src/Optimizer.cc:1323): the keyframe's own
   // pinhole model, or one KannalaBrandt8 model shared by the whole window.  Anything else sets `unsupported`.
   bool mono_camera(GeometricCamera* cam, float fx, float fy, float cx, float cy) {
@@ -49,7 +86,8 @@ struct LbaPack {
   // a fisheye window is monocular on the device (no rectified-stereo edges next to KannalaBrandt8 ones)
   bool camera_models_ok() {
     if (has_kb8)
-      for (uint8_t k : edge_kind) if (k != OSH_EDGE_MONO) { unsupported = "rectified-stereo observation in a KannalaBrandt8 window"; return false; }
+      for (uint8_t k : edge_kind) if (k == OSH_EDGE_STEREO) { unsupported = "rectified-stereo observation in a KannalaBrandt8 window"; return false; }
+    if (has_rig && !has_kb8) { unsupported = "right-camera observations without a KannalaBrandt8 left camera"; return false; }
     return true;
   }
   void fill(osh_lba_problem& p) const {
@@ -59,7 +97,7 @@ struct LbaPack {
     p.edge_obs = edge_obs.data(); p.edge_info = edge_info.data();
     p.huber_mono = p.huber_stereo = 0; p.lambda_init = 0; p.max_iterations = 10; p.stop_flag = nullptr;
     p.kb8 = has_kb8 ? kb8 : nullptr;
-    p.cam2 = nullptr; p.trl = nullptr;
+    p.cam2 = has_rig ? cam2 : nullptr; p.trl = has_rig ? trl : nullptr;
   }
 };
 struct LibaPack {

@@ -35,9 +35,13 @@ class HostGraph:
         pose = _f32(w.pose_qt)
         cam5 = _f32(w.pose_cam[0])
         inv = _f32(synth.INV_LEVEL_SIGMA2)
-        octave = _i32(np.round(np.log(1.0 / w.edge_info) / np.log(1.44)).astype(np.int32))
-        obs = _f32(w.edge_obs)
-        obs[w.edge_kind == capi.OSH_EDGE_MONO, 2] = -1.0
+        # a fisheye rig window: OSH_EDGE_BODY edges are right-camera observations, added after the left ones (set_rig below)
+        body = w.edge_kind == capi.OSH_EDGE_BODY
+        left = ~body
+        all_octave = _i32(np.round(np.log(1.0 / w.edge_info) / np.log(1.44)).astype(np.int32))
+        octave = _i32(all_octave[left])
+        obs = _f32(w.edge_obs[left])
+        obs[w.edge_kind[left] == capi.OSH_EDGE_MONO, 2] = -1.0
         init_id = int(self.kf_id[0]) if init_kf_fixed else -1 & 0x7FFFFFFF
         if init_kf_id_index is not None:      # the map's initial keyframe (Map::GetInitKFid / GetOriginKF) is keyframe number ...
             init_id = int(self.kf_id[init_kf_id_index])
@@ -47,11 +51,18 @@ class HostGraph:
         self.g = C.c_void_p(self.lib.osh_host_graph_create(
             P + F, capi.ptr(self.kf_id, capi.c_int64_p), capi.ptr(pose, capi.c_float_p), capi.ptr(cam5, capi.c_float_p),
             capi.ptr(inv, capi.c_float_p), len(inv), w.n_points, capi.ptr(self.mp_id, capi.c_int64_p),
-            capi.ptr(mp_pos, capi.c_float_p), w.n_edges, capi.ptr(_i32(w.edge_pose), capi.c_int32_p),
-            capi.ptr(_i32(w.edge_point), capi.c_int32_p), capi.ptr(obs, capi.c_float_p), capi.ptr(octave, capi.c_int32_p),
+            capi.ptr(mp_pos, capi.c_float_p), int(left.sum()), capi.ptr(_i32(w.edge_pose[left]), capi.c_int32_p),
+            capi.ptr(_i32(w.edge_point[left]), capi.c_int32_p), capi.ptr(obs, capi.c_float_p), capi.ptr(octave, capi.c_int32_p),
             init_id, int(inertial)))
         if w.kb8 is not None:     # monocular fisheye map: every keyframe's mpCamera is one KannalaBrandt8
             self.lib.osh_host_graph_set_fisheye(self.g, capi.ptr(_f32(w.kb8), capi.c_float_p))
+        if w.cam2 is not None:    # fisheye stereo rig: right camera, Trl and the right-camera observations
+            r_uv = _f32(w.edge_obs[body][:, :2])
+            rc = self.lib.osh_host_graph_set_rig(self.g, capi.ptr(_f32(w.cam2), capi.c_float_p), capi.ptr(_f32(w.trl), capi.c_float_p),
+                                                 int(body.sum()), capi.ptr(_i32(w.edge_pose[body]), capi.c_int32_p),
+                                                 capi.ptr(_i32(w.edge_point[body]), capi.c_int32_p), capi.ptr(r_uv, capi.c_float_p),
+                                                 capi.ptr(_i32(all_octave[body]), capi.c_int32_p))
+            assert rc == 0
         self.cur = P - 1
         cov = _i32([i for i in range(P) if i != self.cur])
         self.lib.osh_host_graph_set_covisible(self.g, self.cur, len(cov), capi.ptr(cov, capi.c_int32_p))
@@ -94,7 +105,12 @@ class HostGraph:
         assert rc == 0, rc
         return LbaWindow(n_free=int(sizes[0]), n_fixed=int(sizes[1]), pose_qt=o["pose_qt"], pose_cam=o["pose_cam"], points=o["points"],
                          edge_pose=o["edge_pose"], edge_point=o["edge_point"], edge_kind=o["edge_kind"], edge_obs=o["edge_obs"],
-                         edge_info=o["edge_info"], lambda_init=0.0, max_iterations=10, kb8=self._last_kb8()).normalise(), o
+                         edge_info=o["edge_info"], lambda_init=0.0, max_iterations=10, kb8=self._last_kb8(),
+                         cam2=self._last_rig()[0], trl=self._last_rig()[1]).normalise(), o
+
+    def _last_rig(self):
+        c, t = np.zeros(8), np.zeros(7)
+        return (c, t) if self.lib.osh_host_last_pack_rig(self.g, capi.ptr(c, capi.c_double_p), capi.ptr(t, capi.c_double_p)) else (None, None)
 
     def _last_kb8(self):
         k = np.zeros(4)
@@ -126,7 +142,8 @@ class HostGraph:
         assert rc == 0, rc
         w = LbaWindow(n_free=P, n_fixed=F, pose_qt=o["pose_qt"], pose_cam=o["pose_cam"], points=o["points"],
                       edge_pose=o["edge_pose"], edge_point=o["edge_point"], edge_kind=o["edge_kind"], edge_obs=o["edge_obs"],
-                      edge_info=o["edge_info"], lambda_init=0.0, max_iterations=max_iterations, kb8=self._last_kb8()).normalise()
+                      edge_info=o["edge_info"], lambda_init=0.0, max_iterations=max_iterations, kb8=self._last_kb8(),
+                      cam2=self._last_rig()[0], trl=self._last_rig()[1]).normalise()
         # const float thHuber2D = sqrt(5.99), thHuber3D = sqrt(7.815) (src/Optimizer.cc:130-131); none unless bRobust
         w.huber_mono = float(np.float32(np.sqrt(5.99))) if robust else float("inf")
         w.huber_stereo = float(np.float32(np.sqrt(7.815))) if robust else float("inf")

@@ -16,7 +16,7 @@ def ob(hip_lib):
     return binding
 
 
-def _run_and_check(w, ob, init_kf_fixed=False):
+def _run_and_check(w, ob, init_kf_fixed=False, tol=2e-6):
     with host.HostGraph(w, init_kf_fixed=init_kf_fixed) as g:
         pw, o = g.packed_window()
         ref = ob.lba_solve(pw)
@@ -35,26 +35,38 @@ def _run_and_check(w, ob, init_kf_fixed=False):
         assert rotation_error(got_qt, ref.pose_qt) < 2e-6
         mp_index = {int(i): k for k, i in enumerate(g.mp_id)}
         got_pts = np.stack([g.mp_pos(mp_index[int(i)]) for i in o["point_mp_id"]]).astype(np.float64)
-        np.testing.assert_allclose(got_pts, ref.points, rtol=2e-6, atol=2e-6)
-        # outlier observations are erased on both sides (KeyFrame::EraseMapPointMatch + MapPoint::EraseObservation)
-        thr = np.where(pw.edge_kind == 0, synth.CHI2_MONO, synth.CHI2_STEREO)
+        np.testing.assert_allclose(got_pts, ref.points, rtol=tol, atol=tol)
+        # outlier observations are erased on both sides (KeyFrame::EraseMapPointMatch + MapPoint::EraseObservation);
+        # a (keyframe, point) pair of a fisheye rig goes when EITHER of its two edges fails (mono, body, stereo passes, :1413-1460)
+        thr = np.where(pw.edge_kind == 1, synth.CHI2_STEREO, synth.CHI2_MONO)
         out = (ref.edge_chi2 > thr) | (ref.edge_depth_pos == 0)
-        near = np.abs(ref.edge_chi2 - thr) < 1e-4 * thr
+        near = np.abs(ref.edge_chi2 - thr) < max(1e-4, 50 * tol) * thr
         assert out.sum() > 0
-        for e in np.nonzero(~near)[0]:
-            k, j = kf_index[int(o["pose_kf_id"][pw.edge_pose[e]])], mp_index[int(o["point_mp_id"][pw.edge_point[e]])]
-            assert g.lib.osh_host_kf_observes(g.g, k, j) == (0 if out[e] else 1)
+        pair_out, pair_near = {}, {}
+        for e in range(pw.n_edges):
+            kj = (kf_index[int(o["pose_kf_id"][pw.edge_pose[e]])], mp_index[int(o["point_mp_id"][pw.edge_point[e]])])
+            pair_out[kj] = pair_out.get(kj, False) or bool(out[e])
+            pair_near[kj] = pair_near.get(kj, False) or bool(near[e])
+        for (k, j), is_out in pair_out.items():
+            if not pair_near[(k, j)]:
+                assert g.lib.osh_host_kf_observes(g.g, k, j) == (0 if is_out else 1)
         assert g.lib.osh_host_map_change_index(g.g) == 1
         for i in range(n_local):
             assert g.lib.osh_host_kf_pose_sets(g.g, i) == 1                  # every local keyframe gets SetPose once
         for i in range(w.n_free, w.n_free + w.n_fixed):
             assert g.lib.osh_host_kf_pose_sets(g.g, i) == 0                  # fixed observers are never written
         erased = sum(before[j] - g.lib.osh_host_mp_num_observations(g.g, j) for j in range(w.n_points))
-        assert erased >= (out & ~near).sum()
+        assert erased >= sum(1 for kj, is_out in pair_out.items() if is_out and not pair_near[kj])   # one map entry per (keyframe, point) pair
 
 
 def test_local_bundle_adjustment_stereo_window(ob):
     _run_and_check(synth.make_window(41, n_free=7, n_fixed=3, n_points=600, stereo=True), ob)
+
+
+def test_local_bundle_adjustment_fisheye_stereo_rig(ob):
+    """keyframes with mpCamera2, right-camera observations as EdgeSE3ProjectXYZToBody
+    (src/Optimizer.cc:1365-1399), outlier pass over mono, body and stereo edges (:1413-1460)."""
+    _run_and_check(synth.make_rig_window(83, n_free=7, n_fixed=3, n_points=500, track_len=(3, 8)), ob, tol=1e-4)
 
 
 def test_local_bundle_adjustment_mono_window_config1(ob):
@@ -123,6 +135,31 @@ def test_global_bundle_adjustment_for_a_loop_keeps_results_beside_the_live_map(o
         np.testing.assert_array_equal(np.stack([g.kf_pose(i) for i in range(w.n_free + 1)]), live_before)
         assert all(g.lib.osh_host_kf_pose_sets(g.g, i) == 0 for i in range(w.n_free + 1))
         assert g.lib.osh_host_map_change_index(g.g) == 0
+
+
+def test_global_bundle_adjustment_fisheye_stereo_rig(ob):
+    """BundleAdjustment over a fisheye stereo rig map: right-camera edges created at src/Optimizer.cc:229-262 (EdgeSE3ProjectXYZToBody)."""
+    w = synth.make_rig_window(85, n_free=6, n_fixed=1, n_points=300, track_len=(2, 6), right_frac=0.3, right_only_frac=0.6)
+    with host.HostGraph(w, init_kf_id_index=w.n_free) as g:
+        pw, o, ref = _gba_reference(g, ob, 10, True)
+        # the reference admits a right-camera observation here only while its UNSHIFTED index (NLeft + r) is below
+        # mvKeysRight.size() (src/Optimizer.cc:232) -- mirrored, quirk included
+        expected = 0
+        for k in range(w.n_free + w.n_fixed):
+            n_left = int(((w.edge_pose == k) & (w.edge_kind == capi.OSH_EDGE_MONO)).sum())
+            n_right = int(((w.edge_pose == k) & (w.edge_kind == capi.OSH_EDGE_BODY)).sum())
+            expected += max(0, min(n_right, n_right - n_left))
+        assert int((pw.edge_kind == capi.OSH_EDGE_BODY).sum()) == expected > 100 and pw.cam2 is not None
+        g.run_gba(10, n_loop_kf=55, robust=True)
+        kf_index = {int(i): k for k, i in enumerate(g.kf_id)}
+        marks, poses = zip(*[g.kf_pose_gba(kf_index[int(i)]) for i in o["pose_kf_id"][:pw.n_free]])
+        assert set(marks) == {55}
+        # one fixed keyframe and monocular left edges: the scale of this map hangs on the admitted right-camera edges alone
+        # (weak gauge), which amplifies the float32 staircase of the fisheye residuals
+        assert rel_translation_error(np.stack(poses).astype(np.float64), ref.pose_qt) < 2e-5
+        mp_index = {int(i): k for k, i in enumerate(g.mp_id)}
+        marks, pts = zip(*[g.mp_pos_gba(mp_index[int(i)]) for i in o["point_mp_id"]])
+        np.testing.assert_allclose(np.stack(pts).astype(np.float64), ref.points, rtol=1e-4, atol=1e-4)
 
 
 def test_welding_local_bundle_adjustment_two_stages(ob):

@@ -126,3 +126,30 @@ def test_gba_failure_writes_the_identity_result():
             mark, X = g.mp_pos_gba(j)
             assert mark == 77
             np.testing.assert_array_equal(X, before_mp[j])
+
+
+def test_pack_fisheye_stereo_rig_window_adds_body_edges():
+    """a keyframe with mpCamera2 contributes, besides the left edge, an EdgeSE3ProjectXYZToBody for a
+    right-camera observation (rightIndex - NLeft into mvKeysRight, src/Optimizer.cc:1365-1399): same multiset of edges as the
+    window the graph was built from, body edges carrying Trl and the right camera."""
+    w = synth.make_rig_window(73, n_free=5, n_fixed=2, n_points=150, track_len=(2, 6))
+    with host.HostGraph(w) as g:
+        pw, o = g.packed_window()
+        assert pw.n_edges == w.n_edges
+        assert np.array_equal(np.bincount(pw.edge_kind, minlength=3), np.bincount(w.edge_kind, minlength=3))
+        np.testing.assert_array_equal(pw.cam2, w.cam2.astype(np.float32).astype(np.float64))
+        # Sophus::SE3f re-normalises the float quaternion of Trl (one float ulp)
+        np.testing.assert_allclose(pw.trl, w.trl, rtol=0, atol=2e-7)
+        kf_of_pose = {int(i): k for k, i in enumerate(g.kf_id)}
+        order = np.array([kf_of_pose[int(i)] for i in o["pose_kf_id"]])
+        mp_of_point = {int(i): k for k, i in enumerate(g.mp_id)}
+        pts = np.array([mp_of_point[int(i)] for i in o["point_mp_id"]])
+
+        def key(pose, point, kind, obs, info):
+            return sorted(zip(pose.tolist(), point.tolist(), kind.tolist(), map(tuple, np.round(obs[:, :2], 3).tolist()), np.round(info, 6).tolist()))
+        assert key(order[pw.edge_pose], pts[pw.edge_point], pw.edge_kind, pw.edge_obs, pw.edge_info) == \
+            key(w.edge_pose, w.edge_point, w.edge_kind, w.edge_obs.astype(np.float32).astype(np.float64), w.edge_info)
+        # the reference inserts the right edge directly after the pair's left edge
+        body = np.nonzero(pw.edge_kind == capi.OSH_EDGE_BODY)[0]
+        paired = [e for e in body if e > 0 and pw.edge_kind[e - 1] == 0 and pw.edge_pose[e - 1] == pw.edge_pose[e] and pw.edge_point[e - 1] == pw.edge_point[e]]
+        assert len(paired) > 0.5 * len(body)
