@@ -45,6 +45,32 @@ class LbaSolver:
     def optimize(self):
         capi.check(self.lib.osh_lba_optimize(self.ctx), "osh_lba_optimize", self.lib)
 
+    # -- the same life cycle on prepared ctypes arrays (bench.py's end-to-end pipeline: nothing but the C-ABI calls is timed) --
+    def prepare(self, windows: list[LbaWindow]):
+        """(problem array, result array, result holders) for upload_prepared / download_prepared."""
+        n = len(windows)
+        probs = (capi.LbaProblem * n)()
+        for i, w in enumerate(windows):
+            probs[i] = w.as_struct()
+        outs = [LbaResultArrays(w) for w in windows]
+        res = (capi.LbaResult * n)()
+        for i, o in enumerate(outs):
+            o.bind(res[i])
+        return probs, res, outs
+
+    def upload_prepared(self, windows, probs):
+        self._windows = windows
+        self._problems = probs
+        capi.check(self.lib.osh_lba_upload(self.ctx, len(windows), probs), "osh_lba_upload", self.lib)
+
+    def download_prepared(self, res):
+        capi.check(self.lib.osh_lba_download(self.ctx, len(res), res), "osh_lba_download", self.lib)
+
+    def upload_times(self) -> dict:
+        ms = np.zeros(2, dtype=np.float64)
+        capi.check(self.lib.osh_lba_get_upload_times(self.ctx, capi.ptr(ms, capi.c_double_p)), "osh_lba_get_upload_times", self.lib)
+        return dict(pack_ms=float(ms[0]), copy_ms=float(ms[1]))
+
     def download(self) -> list[LbaResultArrays]:
         n = len(self._windows)
         outs = [LbaResultArrays(w) for w in self._windows]
