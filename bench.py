@@ -181,23 +181,27 @@ def run_end_to_end(args, info, windows):
     n_ctx = 2
     solvers = [lba.LbaSolver(info.local_rank) for _ in range(n_ctx)]
     prepared = [sv.prepare(windows) for sv in solvers]
-    n_batches = max(4, 2 * args.e2e_batches)
+    per_ctx = max(2, args.e2e_batches)
+    n_batches = n_ctx * per_ctx
 
-    def one(k):
-        sv = solvers[k % n_ctx]
-        probs, res, _ = prepared[k % n_ctx]
-        sv.upload_prepared(windows, probs)
-        t_up = sv.upload_times()
-        sv.optimize()
-        sv.download_prepared(res)
-        return t_up
+    def drive(k, n):
+        """One host thread owns one context and runs its batches one after the other (a context is not thread safe)."""
+        sv = solvers[k]
+        probs, res, _ = prepared[k]
+        ups = []
+        for _ in range(n):
+            sv.upload_prepared(windows, probs)
+            ups.append(sv.upload_times())
+            sv.optimize()
+            sv.download_prepared(res)
+        return ups
 
     pool = ThreadPoolExecutor(n_ctx)
-    list(pool.map(one, range(n_ctx)))            # warm-up: staging buffers, device buffers
+    list(pool.map(lambda k: drive(k, 1), range(n_ctx)))            # warm-up: staging buffers, device buffers
     torch.cuda.synchronize()
     osh_dist.barrier(info)
     t0 = time.perf_counter()
-    ups = list(pool.map(one, range(n_batches)))
+    ups = sum(pool.map(lambda k: drive(k, per_ctx), range(n_ctx)), [])
     torch.cuda.synchronize()
     osh_dist.barrier(info)
     elapsed = osh_dist.all_reduce_max(info, time.perf_counter() - t0)

@@ -1179,6 +1179,16 @@ __global__ __launch_bounds__(256) void k_gather_out(BatchView bv, const int* lm_
   }
 }
 
+// float32 observation records -> the 32-byte records the kernels read (lba_pack.h: rec_f32)
+__global__ __launch_bounds__(256) void k_widen_rec(const float4* src, double* dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 v = src[i];
+  double2* d = reinterpret_cast<double2*>(dst + i * 4);
+  d[0] = make_double2((double)v.x, (double)v.y);
+  d[1] = make_double2((double)v.z, (double)v.w);
+}
+
 // Pinned host buffer (grow-only).
 struct PinBuf {
   void* p = nullptr;
@@ -1222,7 +1232,7 @@ struct osh_lba_ctx {
   void (*kp_debug_hpl)(BatchView, double*) = nullptr;
   // staging + device buffers
   PinBuf h_arena[2], h_out;
-  DevBuf d_arena[2], d_ptwin;
+  DevBuf d_arena[2], d_ptwin, d_erec;
   DevBuf d_lm, d_pose[2], d_pt[2], d_hcontrib, d_chi_lin, d_dmax_lin, d_contrib, d_ccontrib;
   DevBuf d_Hll, d_bl, d_DL, d_Hpp, d_bp, d_S, d_bs, d_xp, d_chi, d_scale, d_dmaxp, d_nactive, d_out_chi2, d_out_depth, d_stop;
   DevBuf d_out_pose, d_out_pts, d_dbg;
@@ -1356,6 +1366,14 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   bv.e_pose = c->dsec<int>(PackedBatch::EPOSE); bv.e_point = c->dsec<int>(PackedBatch::EPOINT);
   bv.e_kind = c->dsec<unsigned char>(PackedBatch::EKIND);
   bv.e_rec = c->dsec<double>(PackedBatch::EREC); bv.e_rec2 = c->dsec<double>(PackedBatch::EREC2);
+  if (pb.rec_f32) {
+    OSH_TRY(R(c->d_erec, pb.NE * 32));
+    if (pb.NE) {
+      hipLaunchKernelGGL(k_widen_rec, dim3((unsigned)((pb.NE + 255) / 256)), dim3(256), 0, s, c->dsec<float4>(PackedBatch::EREC), c->d_erec.as<double>(), pb.NE);
+      OSH_TRY(launch_check("k_widen_rec"));
+    }
+    bv.e_rec = c->d_erec.as<double>();
+  }
   bv.e_orig = c->dsec<int>(PackedBatch::EORIG); bv.e_orig2 = c->dsec<int>(PackedBatch::EORIG2);
   bv.lm_off = c->dsec<int>(PackedBatch::LMOFF);
   bv.sitems = c->dsec<SItem>(PackedBatch::ITEMS); bv.srecs = c->dsec<SRec>(PackedBatch::RECS);

@@ -68,6 +68,8 @@ struct PackedBatch {
   long long tile_steps = 0, pair_blocks = 0;
   int n_max = 0, np_max = 0;
   bool has_kb8 = false, has_rig = false;
+  bool rec_f32 = false;   // every observation / information value of the batch is a float32 value (what the reference stores:
+                          // cv::KeyPoint::pt, mvuRight, mvInvLevelSigma2): the records travel as 16 bytes and are widened on the device
   // arena 0: sections whose sizes follow from the problem sizes; arena 1: plan sections
   enum Sec { POSE, CAM, PT, EREC, EREC2, EPOSE, EPOINT, EORIG, EORIG2, LMOFF, LMPERM, FPW, EKIND, A0_COUNT,
              WIN = A0_COUNT, CHUNKS, ITEMS, RECS, SPAIR, SCSLOT, POSEX, POSEY, RBLK, CRANGE, SEC_COUNT };
@@ -139,11 +141,30 @@ inline int pack_batch(int nw, const osh_lba_problem* pr, const std::function<voi
   // NE here is an upper bound (merged rig edges shrink it); the sorted edges of a window start at the caller's edge offset,
   // the tail of a window with merged edges stays unused.
   pb.NE = NE;
+  n_threads = std::max(1, std::min(n_threads, nw));
+  {
+    // are all observation records float32 values?  (parallel scan of edge_obs / edge_info; rig batches keep doubles)
+    std::atomic<int> next{0}, inexact{pb.has_rig ? 1 : 0};
+    auto worker = [&]() {
+      for (int w = next.fetch_add(1); w < nw && !inexact.load(std::memory_order_relaxed); w = next.fetch_add(1)) {
+        const osh_lba_problem& p = pr[w];
+        bool ok = true;
+        for (size_t k = 0, n = (size_t)p.n_edges * 3; k < n && ok; ++k) ok = (double)(float)p.edge_obs[k] == p.edge_obs[k];
+        for (int e = 0; e < p.n_edges && ok; ++e) ok = (double)(float)p.edge_info[e] == p.edge_info[e];
+        if (!ok) inexact.store(1, std::memory_order_relaxed);
+      }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_threads; ++t) pool.emplace_back(worker);
+    worker();
+    for (std::thread& t : pool) t.join();
+    pb.rec_f32 = inexact.load() == 0;
+  }
   {
     size_t o = 0;
     auto put = [&](int s, size_t b) { pb.off[s] = o; pb.bytes[s] = b; o += align_up(std::max<size_t>(b, 8)); };
     put(PackedBatch::POSE, NP * 7 * 8); put(PackedBatch::CAM, NP * 5 * 8); put(PackedBatch::PT, NL * 3 * 8);
-    put(PackedBatch::EREC, NE * 32); put(PackedBatch::EREC2, pb.has_rig ? NE * 32 : 0);
+    put(PackedBatch::EREC, NE * (pb.rec_f32 ? 16 : 32)); put(PackedBatch::EREC2, pb.has_rig ? NE * 32 : 0);
     put(PackedBatch::EPOSE, NE * 4); put(PackedBatch::EPOINT, NE * 4); put(PackedBatch::EORIG, NE * 4);
     put(PackedBatch::EORIG2, pb.has_rig ? NE * 4 : 0);
     put(PackedBatch::LMOFF, NLO * 4); put(PackedBatch::LMPERM, NL * 4); put(PackedBatch::FPW, NFP * 4); put(PackedBatch::EKIND, NE);
@@ -155,6 +176,8 @@ inline int pack_batch(int nw, const osh_lba_problem* pr, const std::function<voi
   double* h_cam = pb.sec<double>(PackedBatch::CAM);
   double* h_pt = pb.sec<double>(PackedBatch::PT);
   double* h_rec = pb.sec<double>(PackedBatch::EREC);
+  float* h_recf = pb.sec<float>(PackedBatch::EREC);
+  const bool rec_f32 = pb.rec_f32;
   double* h_rec2 = pb.sec<double>(PackedBatch::EREC2);
   int* h_epose = pb.sec<int>(PackedBatch::EPOSE);
   int* h_epoint = pb.sec<int>(PackedBatch::EPOINT);
@@ -267,8 +290,14 @@ inline int pack_batch(int nw, const osh_lba_problem* pr, const std::function<voi
         const int kind = e2 >= 0 ? kKindBoth : (kd == OSH_EDGE_BODY ? kKindBody : kd);
         h_epose[g] = p.edge_pose[e]; h_epoint[g] = jn; h_kind[g] = (unsigned char)kind; h_eorig[g] = e;
         // the sign of the information carries the edge kind for the pinhole kernels (negative = monocular)
-        h_rec[g * 4] = p.edge_obs[3 * (size_t)e]; h_rec[g * 4 + 1] = p.edge_obs[3 * (size_t)e + 1]; h_rec[g * 4 + 2] = p.edge_obs[3 * (size_t)e + 2];
-        h_rec[g * 4 + 3] = (kd == OSH_EDGE_STEREO) ? p.edge_info[e] : -p.edge_info[e];
+        const double inf = (kd == OSH_EDGE_STEREO) ? p.edge_info[e] : -p.edge_info[e];
+        if (rec_f32) {
+          h_recf[g * 4] = (float)p.edge_obs[3 * (size_t)e]; h_recf[g * 4 + 1] = (float)p.edge_obs[3 * (size_t)e + 1];
+          h_recf[g * 4 + 2] = (float)p.edge_obs[3 * (size_t)e + 2]; h_recf[g * 4 + 3] = (float)inf;
+        } else {
+          h_rec[g * 4] = p.edge_obs[3 * (size_t)e]; h_rec[g * 4 + 1] = p.edge_obs[3 * (size_t)e + 1]; h_rec[g * 4 + 2] = p.edge_obs[3 * (size_t)e + 2];
+          h_rec[g * 4 + 3] = inf;
+        }
         if (pb.has_rig) {
           h_eorig2[g] = e2;
           const int er = e2 >= 0 ? e2 : e;   // a lone body edge keeps its observation in the first record too
@@ -291,7 +320,6 @@ inline int pack_batch(int nw, const osh_lba_problem* pr, const std::function<voi
       j = j1;
     }
   };
-  n_threads = std::max(1, std::min(n_threads, nw));
   {
     std::atomic<int> next{0};
     auto worker = [&]() {

@@ -27,7 +27,13 @@ extern "C" int osh_lba_pack_check(int32_t nw, const osh_lba_problem* pr, int32_t
   auto done = [&](int code) { std::free(mem[0]); std::free(mem[1]); return code; };
   if (rc != OSH_OK) { set_error("%s", pb.msg); return done(rc); }
 #define CHECK(cond, ...) do { if (!(cond)) { set_error(__VA_ARGS__); return done(OSH_ERR_DEVICE); } } while (0)
-  const double* rec = pb.sec<double>(PackedBatch::EREC);
+  // the checks below read the records as doubles: widen a float32 batch first
+  std::vector<double> rec_wide;
+  if (pb.rec_f32) {
+    const float* rf = pb.sec<float>(PackedBatch::EREC);
+    rec_wide.assign(rf, rf + pb.NE * 4);
+  }
+  const double* rec = pb.rec_f32 ? rec_wide.data() : pb.sec<double>(PackedBatch::EREC);
   const double* rec2 = pb.sec<double>(PackedBatch::EREC2);
   const int* epose = pb.sec<int>(PackedBatch::EPOSE);
   const int* epoint = pb.sec<int>(PackedBatch::EPOINT);

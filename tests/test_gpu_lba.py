@@ -291,3 +291,14 @@ def test_fisheye_stereo_rig_body_edges(solver, ob):
     bad.edge_kind[3] = capi.OSH_EDGE_BODY
     with pytest.raises(RuntimeError, match="body edge"):
         solver.upload([bad])
+
+
+def test_observations_that_are_not_float32_values_take_the_double_records(solver, ob):
+    """osh_lba_upload ships the observation records as float32 when every value is one (what the reference stores) and as
+    doubles otherwise: both paths against the oracle."""
+    w = synth.make_window(91, n_free=6, n_fixed=2, n_points=300, stereo=True)
+    _check_result(solver.solve([w])[0], ob.lba_solve(w), w)
+    w.edge_obs = w.edge_obs + 1e-7 * np.sin(np.arange(w.edge_obs.size)).reshape(w.edge_obs.shape)
+    w.edge_info = w.edge_info * (1 + 1e-9)
+    assert np.any(w.edge_obs.astype(np.float32).astype(np.float64) != w.edge_obs)
+    _check_result(solver.solve([w])[0], ob.lba_solve(w), w)
