@@ -1,6 +1,7 @@
 /* Frame.h -- members of ORB_SLAM3::Frame used by ORBmatcher::SearchByProjection
  * (reference include/Frame.h:112,144,213-246,250-252,281-290,326-329; src/Frame.cc:397-417,658-736).
- * Minimal test double for the monocular / rectified-stereo layout (Nleft == -1). */
+ * Minimal test double: the monocular / rectified-stereo layout (Nleft == -1) and the fisheye stereo layout (Nleft != -1: keypoints
+ * [0, Nleft) in mvKeys / mGrid, right-camera keypoints in mvKeysRight / mGridRight, descriptor rows [Nleft, N) for the right ones). */
 #ifndef FRAME_H
 #define FRAME_H
 #include <vector>
@@ -42,6 +43,10 @@ class Frame {
   float mfLogScaleFactor = 0;   // log(mfScaleFactor), src/Frame.cc:75
   GeometricCamera* mpCamera = nullptr;
   std::vector<std::size_t> mGrid[FRAME_GRID_COLS][FRAME_GRID_ROWS];
+  std::vector<std::size_t> mGridRight[FRAME_GRID_COLS][FRAME_GRID_ROWS];   // include/Frame.h:329
+  std::vector<int> mvLeftToRightMatch, mvRightToLeftMatch;                 // include/Frame.h:301 (stereo fisheye matches)
+  Sophus::SE3f mTrl;                                                        // include/Frame.h:297
+  Sophus::SE3f GetRelativePoseTrl() const { return mTrl; }                  // src/Frame.cc:1134-1137
   float mnMinX = 0, mnMaxX = 752, mnMinY = 0, mnMaxY = 480;   // static in the reference
   float mfGridElementWidthInv = 64.f / 752.f, mfGridElementHeightInv = 48.f / 480.f;
   Sophus::SE3f mTcw;

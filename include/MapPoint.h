@@ -38,10 +38,10 @@ class MapPoint {
   Eigen::Vector3f mPosGBA;                    // include/MapPoint.h:147-148
   long unsigned int mnBAGlobalForKF = 0;
   // tracking scratch written by Frame::isInFrustum (src/Frame.cc:513-587), read by SearchByProjection
-  float mTrackProjX = 0, mTrackProjY = 0, mTrackDepth = 0, mTrackProjXR = 0;
+  float mTrackProjX = 0, mTrackProjY = 0, mTrackDepth = 0, mTrackProjXR = 0, mTrackProjYR = 0;
   bool mbTrackInView = false, mbTrackInViewR = false;
-  int mnTrackScaleLevel = 0;
-  float mTrackViewCos = 1.f;
+  int mnTrackScaleLevel = 0, mnTrackScaleLevelR = -1;
+  float mTrackViewCos = 1.f, mTrackViewCosR = 1.f;   // include/MapPoint.h:122-129
   float mfMinDistance = 0, mfMaxDistance = 0;
   Eigen::Vector3f mNormalVector;
   // test-double state

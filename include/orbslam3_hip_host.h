@@ -102,6 +102,16 @@ typedef struct osh_host_frame osh_host_frame;
 osh_host_frame* osh_host_frame_create(int32_t n, const float* kp_xy, const int32_t* octave, const float* angle,
                                       const float* uright, const uint8_t* desc, const float pose_qt[7],
                                       const float cam4[4], float mbf, float mb, int32_t n_levels, float scale_factor);
+/* Fisheye STEREO frame: the first n_left keypoints become the left camera's, the rest the right camera's (descriptor rows
+ * [n_left, N)); left_to_right[n_left] / right_to_left[N - n_left] are Frame::mvLeftToRightMatch / mvRightToLeftMatch. */
+int osh_host_frame_set_rig(osh_host_frame* f, int32_t n_left, const int32_t* left_to_right, const int32_t* right_to_left, const float trl_qt[7]);
+/* ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) on such a frame (src/ORBmatcher.cc:43-213, both camera
+ * passes); per map point the tracking fields of both cameras; assignment[N] = map point stored in each keypoint slot or -1. */
+int osh_host_search_local_points_rig(osh_host_frame* f, int32_t n_mp, const uint8_t* mp_desc, const uint8_t* in_left,
+                                     const float* proj_left, const int32_t* level_left, const float* viewcos_left,
+                                     const uint8_t* in_right, const float* proj_right, const int32_t* level_right,
+                                     const float* viewcos_right, const int32_t* n_observations, float nnratio, float th,
+                                     int32_t* assignment);
 void osh_host_frame_destroy(osh_host_frame* f);
 /* Switch the frame's camera to a KannalaBrandt8 (same fx fy cx cy, coefficients k1..k4). */
 void osh_host_frame_set_fisheye(osh_host_frame* f, const float k[4]);

@@ -233,6 +233,20 @@ def orb_match_local_points(query, train, train_level=None, cand_off=None, cand_i
     return int(n), assign, occ
 
 
+def orb_match_local_points_rig(query, desc, n_left, level_left, level_right, in_l, candl, in_r, candr, left_to_right, right_to_left,
+                               nn_ratio=0.8, th_high=100, occupied=None):
+    """SearchByProjection(Frame&, vector<MapPoint*>) on a fisheye stereo frame: both camera passes, sequential (orb_oracle.c)."""
+    lib = load()
+    nq, n = query.shape[0], desc.shape[0]
+    occ = np.zeros(n, dtype=np.uint8) if occupied is None else np.array(occupied, dtype=np.uint8)
+    assign = -np.ones(n, dtype=np.int32)
+    cnt = lib.oracle_orb_match_local_points_rig(nq, int(n_left), int(n - n_left), _u8(query), _u8(desc), _i32(level_left), _i32(level_right),
+                                                _u8(np.asarray(in_l, dtype=np.uint8)), _i32(candl[0]), _i32(candl[1]),
+                                                _u8(np.asarray(in_r, dtype=np.uint8)), _i32(candr[0]), _i32(candr[1]),
+                                                _i32(left_to_right), _i32(right_to_left), C.c_float(nn_ratio), th_high, _u8(occ), _i32(assign))
+    return int(cnt), assign, occ
+
+
 def orb_match_last_frame(query, train, cand_off, cand_idx, query_angle, train_angle, th_high=100,
                          check_orientation=True, occupied=None):
     lib = load()

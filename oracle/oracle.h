@@ -57,6 +57,12 @@ int  oracle_orb_match_local_points(int n_query, int n_train, const uint8_t* quer
                                    const uint8_t* train_desc, const int32_t* train_level,
                                    const int32_t* cand_off, const int32_t* cand_idx,
                                    float nn_ratio, int th_high, uint8_t* occupied, int32_t* assignment);
+int  oracle_orb_match_local_points_rig(int n_query, int n_left, int n_right, const uint8_t* query_desc, const uint8_t* desc,
+                                       const int32_t* level_left, const int32_t* level_right,
+                                       const uint8_t* in_l, const int32_t* candl_off, const int32_t* candl_idx,
+                                       const uint8_t* in_r, const int32_t* candr_off, const int32_t* candr_idx,
+                                       const int32_t* left_to_right, const int32_t* right_to_left,
+                                       float nn_ratio, int th_high, uint8_t* occupied, int32_t* assignment);
 int  oracle_orb_match_last_frame(int n_query, int n_train, const uint8_t* query_desc,
                                  const uint8_t* train_desc, const int32_t* cand_off, const int32_t* cand_idx,
                                  const float* query_angle, const float* train_angle,

@@ -108,6 +108,57 @@ int oracle_orb_match_local_points(int n_query, int n_train, const uint8_t* query
   return nmatches;
 }
 
+/* SearchByProjection(Frame&, const vector<MapPoint*>&, th, ...) for a FISHEYE STEREO frame (F.Nleft != -1), the whole of
+ * src/ORBmatcher.cc:43-213: per map point first the left-camera pass (:60-141, candidates among the left keypoints, NO u_right
+ * test, levels from mvKeys), then -- unless the left ratio test `continue`d the outer loop (:125-126) -- the right-camera pass
+ * (:144-210, candidates among the right keypoints, window WITHOUT the th factor, levels from mvKeysRight).  An accepted left
+ * match also claims its stereo partner F.mvLeftToRightMatch[best] + Nleft (:131-135, nmatches += 2), an accepted right match
+ * its partner F.mvRightToLeftMatch[best] (:199-203).  Slots: assignment[0 .. n_left) = left keypoints, [n_left ..) = right ones;
+ * occupied[] likewise (read and updated: local map points have Observations() > 0).
+ * in_l / in_r: mbTrackInView / (mbTrackInViewR && mnTrackScaleLevelR != -1) of each map point; a point with neither is skipped
+ * by the caller's common filters already.  Candidate lists index their own side (right candidates 0-based in the right set). */
+int oracle_orb_match_local_points_rig(int n_query, int n_left, int n_right, const uint8_t* query_desc, const uint8_t* desc,
+                                      const int32_t* level_left, const int32_t* level_right,
+                                      const uint8_t* in_l, const int32_t* candl_off, const int32_t* candl_idx,
+                                      const uint8_t* in_r, const int32_t* candr_off, const int32_t* candr_idx,
+                                      const int32_t* left_to_right, const int32_t* right_to_left,
+                                      float nn_ratio, int th_high, uint8_t* occupied, int32_t* assignment) {
+  int nmatches = 0;
+  const uint8_t* desc_r = desc + 32 * (size_t)n_left;
+  uint8_t* occ_r = occupied + n_left;
+  for (int q = 0; q < n_query; ++q) {
+    const uint8_t* qd = query_desc + 32 * (size_t)q;
+    if (in_l[q]) {
+      const int nc = candl_off[q + 1] - candl_off[q];
+      if (nc > 0) { /* !vIndices.empty() :74 */
+        int bi, bd, bd2, bl, bl2;
+        scan_one(qd, desc, level_left, candl_idx + candl_off[q], nc, n_left, occupied, &bi, &bd, &bd2, &bl, &bl2);
+        if (bd <= th_high) {
+          if (bl == bl2 && bd > nn_ratio * bd2) continue; /* skips the right-camera pass of this point too */
+          if (bl != bl2 || bd <= nn_ratio * bd2) {
+            assignment[bi] = q; occupied[bi] = 1;
+            if (left_to_right[bi] != -1) { assignment[left_to_right[bi] + n_left] = q; occ_r[left_to_right[bi]] = 1; nmatches++; }
+            nmatches++;
+          }
+        }
+      }
+    }
+    if (in_r[q]) {
+      const int nc = candr_off[q + 1] - candr_off[q];
+      if (nc == 0) continue; /* :153-154 */
+      int bi, bd, bd2, bl, bl2;
+      scan_one(qd, desc_r, level_right, candr_idx + candr_off[q], nc, n_right, occ_r, &bi, &bd, &bd2, &bl, &bl2);
+      if (bd <= th_high) {
+        if (bl == bl2 && bd > nn_ratio * bd2) continue;
+        if (right_to_left[bi] != -1) { assignment[right_to_left[bi]] = q; occupied[right_to_left[bi]] = 1; nmatches++; }
+        assignment[bi + n_left] = q; occ_r[bi] = 1;
+        nmatches++;
+      }
+    }
+  }
+  return nmatches;
+}
+
 /* ORBmatcher::ComputeThreeMaxima, src/ORBmatcher.cc:2012-2053 (on bin sizes). */
 static void three_maxima(const int* sizes, int L, int* ind1, int* ind2, int* ind3) {
   int max1 = 0, max2 = 0, max3 = 0;

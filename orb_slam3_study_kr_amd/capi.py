@@ -241,6 +241,9 @@ _HOST_SIGNATURES = {
     "osh_host_inertial_information": (C.c_int, [c_float_p, c_double_p]),
     "osh_host_frame_create": (C.c_void_p, [C.c_int32, c_float_p, c_int32_p, c_float_p, c_float_p, c_uint8_p, c_float_p, c_float_p,
                                            C.c_float, C.c_float, C.c_int32, C.c_float]),
+    "osh_host_frame_set_rig": (C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_int32_p, c_float_p]),
+    "osh_host_search_local_points_rig": (C.c_int, [C.c_void_p, C.c_int32, c_uint8_p, c_uint8_p, c_float_p, c_int32_p, c_float_p, c_uint8_p,
+                                         c_float_p, c_int32_p, c_float_p, c_int32_p, C.c_float, C.c_float, c_int32_p]),
     "osh_host_frame_set_fisheye": (None, [C.c_void_p, c_float_p]),
     "osh_host_frame_destroy": (None, [C.c_void_p]),
     "osh_host_frame_search_local_points_projected": (C.c_int, [C.c_void_p, C.c_int32, c_float_p, c_float_p, c_float_p, c_float_p, C.c_float,

@@ -80,6 +80,7 @@ struct Search {
 // the frame / keyframe whose keypoints are searched
 struct Train {
   const cv::Mat* desc = nullptr;
+  int row0 = 0;                          // first descriptor row of this keypoint set (right-camera keypoints: Nleft)
   std::vector<int32_t> level;
   std::vector<float> xy, uright;         // uright empty: no stereo test
   std::vector<uint8_t> skip;             // slots that are no candidates when the call starts
@@ -107,7 +108,7 @@ bool device_search(Search& s, const Train& t) {
   if (!ctx) return false;
   osh_orb_batch b;
   b.n_pairs = 1; b.n_query = nq; b.n_train = t.n();
-  b.query_desc = s.qdesc.data(); b.train_desc = t.desc->ptr<uint8_t>(0); b.train_level = t.level.data();
+  b.query_desc = s.qdesc.data(); b.train_desc = t.desc->ptr<uint8_t>(t.row0); b.train_level = t.level.data();
   b.cand_off = nullptr; b.cand_idx = nullptr; b.pair_cand_base = nullptr;
   osh_orb_grid g;
   g.train_xy = t.xy.data(); g.train_uright = t.uright.empty() ? nullptr : t.uright.data(); g.train_skip = t.skip.data();
@@ -141,7 +142,7 @@ void rescan(const Search& s, int q, const Train& t, const std::vector<uint8_t>& 
       const float er = std::fabs(s.ur[2 * q] - t.uright[idx]);
       if (er > s.ur[2 * q + 1]) continue;
     }
-    const uint32_t* td = t.desc->ptr<uint32_t>(idx);
+    const uint32_t* td = t.desc->ptr<uint32_t>(t.row0 + idx);
     int dist = 0;
     for (int k = 0; k < 8; ++k) dist += __builtin_popcount(qd[k] ^ td[k]);
     if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = t.level[idx]; bestIdx = idx; }
@@ -151,13 +152,117 @@ void rescan(const Search& s, int q, const Train& t, const std::vector<uint8_t>& 
 
 }  // namespace
 
-// src/ORBmatcher.cc:43-213, Nleft == -1 layouts (monocular, rectified stereo, RGB-D).
+namespace {
+
+// one camera of a fisheye stereo frame as a search target: left keypoints mvKeys / mGrid / descriptor rows [0, Nleft), right
+// keypoints mvKeysRight / mGridRight / rows [Nleft, N) (src/Frame.cc:406-416, 697-699)
+Train train_of_rig(const Frame& F, bool right) {
+  Train t;
+  const std::vector<cv::KeyPoint>& keys = right ? F.mvKeysRight : F.mvKeys;
+  const int n = right ? (F.N - F.Nleft) : F.Nleft;
+  t.desc = &F.mDescriptors;
+  t.row0 = right ? F.Nleft : 0;
+  t.level.resize(n); t.xy.resize((size_t)n * 2); t.skip.assign(n, 0);
+  for (int i = 0; i < n; ++i) { t.level[i] = keys[i].octave; t.xy[2 * i] = keys[i].pt.x; t.xy[2 * i + 1] = keys[i].pt.y; }
+  t.min_x = F.mnMinX; t.min_y = F.mnMinY; t.winv = F.mfGridElementWidthInv; t.hinv = F.mfGridElementHeightInv;
+  t.cols = FRAME_GRID_COLS; t.rows = FRAME_GRID_ROWS;
+  return t;
+}
+
+// src/ORBmatcher.cc:43-213 on a fisheye stereo frame (Nleft != -1): per map point the left-camera pass (:60-141) and then the
+// right-camera pass (:144-210).  Both passes of ALL points are searched on the device first (two batched launches, one per
+// camera); the sequential part -- slots claimed by earlier points, the stereo partner a match also claims, the `continue` of a
+// failed left ratio test that skips the point's right pass -- is replayed on the host in the reference's order.
+// (A free function: the class declaration stays the reference's own, include/ORBmatcher.h.)
+int search_local_points_rig(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th, const bool bFarPoints,
+                            const float thFarPoints, const float mfNNratio) {
+  const int TH_HIGH = ORBmatcher::TH_HIGH;
+  auto RadiusByViewingCos = [](float viewCos) { return (float)(viewCos > 0.998 ? 2.5 : 4.0); };   // src/ORBmatcher.cc:215-221
+  const bool bFactor = th != 1.0;
+  const int NL = F.Nleft, NR = F.N - F.Nleft;
+  Train tl = train_of_rig(F, false), tr = train_of_rig(F, true);
+  auto occupied_at = [&F](int slot) { return (F.mvpMapPoints[slot] && F.mvpMapPoints[slot]->Observations() > 0) ? 1 : 0; };
+  for (int i = 0; i < NL; ++i) tl.skip[i] = occupied_at(i);             // :88-90 at call entry
+  for (int i = 0; i < NR; ++i) tr.skip[i] = occupied_at(i + NL);        // :164-166
+  auto area_l = [&F](float x, float y, float r, int lo, int hi) { return F.GetFeaturesInArea(x, y, r, lo, hi, false); };
+  auto area_r = [&F](float x, float y, float r, int lo, int hi) { return F.GetFeaturesInArea(x, y, r, lo, hi, true); };
+  Search sl, sr;
+  struct Q { MapPoint* mp; int ql, qr; };
+  std::vector<Q> qs;
+  for (size_t iMP = 0; iMP < vpMapPoints.size(); iMP++) {
+    MapPoint* pMP = vpMapPoints[iMP];
+    if (!pMP->mbTrackInView && !pMP->mbTrackInViewR) continue;
+    if (bFarPoints && pMP->mTrackDepth > thFarPoints) continue;
+    if (pMP->isBad()) continue;
+    Q q{pMP, -1, -1};
+    if (pMP->mbTrackInView) {
+      const int nPredictedLevel = pMP->mnTrackScaleLevel;
+      float r = RadiusByViewingCos(pMP->mTrackViewCos);
+      if (bFactor) r *= th;
+      q.ql = sl.nq();
+      sl.add(pMP->GetDescriptor(), pMP->mTrackProjX, pMP->mTrackProjY, r * F.mvScaleFactors[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel);
+    }
+    if (pMP->mbTrackInViewR && pMP->mnTrackScaleLevelR != -1) {
+      const int nPredictedLevel = pMP->mnTrackScaleLevelR;
+      const float r = RadiusByViewingCos(pMP->mTrackViewCosR);   // no th factor in the right-camera pass (:148)
+      q.qr = sr.nq();
+      sr.add(pMP->GetDescriptor(), pMP->mTrackProjXR, pMP->mTrackProjYR, r * F.mvScaleFactors[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel);
+    }
+    qs.push_back(q);
+  }
+  if (!device_search(sl, tl) || !device_search(sr, tr)) return 0;
+
+  int nmatches = 0;
+  std::vector<uint8_t> taken_l(NL, 0), taken_r(NR, 0);   // slots claimed during this call by points with observations
+  for (const Q& q : qs) {
+    MapPoint* pMP = q.mp;
+    const bool claims = pMP->Observations() > 0;
+    if (q.ql >= 0) {
+      int bestIdx = sl.best_idx[q.ql], bestDist = sl.best_dist[q.ql], bestDist2 = sl.second_dist[q.ql];
+      int bestLevel = sl.best_level[q.ql], bestLevel2 = sl.second_level[q.ql];
+      if ((bestIdx >= 0 && taken_l[bestIdx]) || (sl.second_idx[q.ql] >= 0 && taken_l[sl.second_idx[q.ql]]))
+        rescan(sl, q.ql, tl, taken_l, area_l, bestIdx, bestDist, bestDist2, bestLevel, bestLevel2);
+      if (bestDist <= TH_HIGH) {
+        if (bestLevel == bestLevel2 && bestDist > mfNNratio * bestDist2) continue;   // also skips this point's right-camera pass (:125-126)
+        if (bestLevel != bestLevel2 || bestDist <= mfNNratio * bestDist2) {
+          F.mvpMapPoints[bestIdx] = pMP;
+          if (claims) taken_l[bestIdx] = 1;
+          if (F.mvLeftToRightMatch[bestIdx] != -1) {   // also match with the stereo observation at the right camera (:131-135)
+            F.mvpMapPoints[F.mvLeftToRightMatch[bestIdx] + NL] = pMP;
+            if (claims) taken_r[F.mvLeftToRightMatch[bestIdx]] = 1;
+            nmatches++;
+          }
+          nmatches++;
+        }
+      }
+    }
+    if (q.qr >= 0) {
+      int bestIdx = sr.best_idx[q.qr], bestDist = sr.best_dist[q.qr], bestDist2 = sr.second_dist[q.qr];
+      int bestLevel = sr.best_level[q.qr], bestLevel2 = sr.second_level[q.qr];
+      if ((bestIdx >= 0 && taken_r[bestIdx]) || (sr.second_idx[q.qr] >= 0 && taken_r[sr.second_idx[q.qr]]))
+        rescan(sr, q.qr, tr, taken_r, area_r, bestIdx, bestDist, bestDist2, bestLevel, bestLevel2);
+      if (bestDist <= TH_HIGH) {
+        if (bestLevel == bestLevel2 && bestDist > mfNNratio * bestDist2) continue;
+        if (F.mvRightToLeftMatch[bestIdx] != -1) {     // :199-203
+          F.mvpMapPoints[F.mvRightToLeftMatch[bestIdx]] = pMP;
+          if (claims) taken_l[F.mvRightToLeftMatch[bestIdx]] = 1;
+          nmatches++;
+        }
+        F.mvpMapPoints[bestIdx + NL] = pMP;
+        if (claims) taken_r[bestIdx] = 1;
+        nmatches++;
+      }
+    }
+  }
+  return nmatches;
+}
+
+}  // namespace
+
+// src/ORBmatcher.cc:43-213: Nleft == -1 layouts (monocular, rectified stereo, RGB-D) here, fisheye stereo frames above.
 int ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th, const bool bFarPoints,
                                    const float thFarPoints) {
-  if (F.Nleft != -1) {
-    std::fprintf(stderr, "ORBmatcher::SearchByProjection: fisheye-stereo frames (Nleft != -1) are not supported by the MI355X path yet\n");
-    std::abort();  // no silent CPU fallback
-  }
+  if (F.Nleft != -1) return search_local_points_rig(F, vpMapPoints, th, bFarPoints, thFarPoints, mfNNratio);
   const bool bFactor = th != 1.0;
   Train t = train_of(F);
   t.uright = F.mvuRight;                                            // stereo consistency window (:92-97)

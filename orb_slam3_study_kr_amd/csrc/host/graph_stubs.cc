@@ -103,20 +103,22 @@ void MapPoint::EraseObservation(KeyFrame* pKF) {
 // src/Frame.cc:397-417 + PosInGrid :726-736
 void Frame::AssignFeaturesToGrid() {
   for (int i = 0; i < FRAME_GRID_COLS; ++i)
-    for (int j = 0; j < FRAME_GRID_ROWS; ++j) mGrid[i][j].clear();
+    for (int j = 0; j < FRAME_GRID_ROWS; ++j) { mGrid[i][j].clear(); mGridRight[i][j].clear(); }
   for (int i = 0; i < N; ++i) {
-    const cv::KeyPoint& kp = mvKeysUn[i];
+    // src/Frame.cc:406-416: left keypoints (distorted mvKeys on a fisheye rig) into mGrid, right ones into mGridRight
+    const cv::KeyPoint& kp = (Nleft == -1) ? mvKeysUn[i] : (i < Nleft) ? mvKeys[i] : mvKeysRight[i - Nleft];
     const int posX = (int)std::round((kp.pt.x - mnMinX) * mfGridElementWidthInv);
     const int posY = (int)std::round((kp.pt.y - mnMinY) * mfGridElementHeightInv);
     if (posX < 0 || posX >= FRAME_GRID_COLS || posY < 0 || posY >= FRAME_GRID_ROWS) continue;
-    mGrid[posX][posY].push_back(i);
+    if (Nleft == -1 || i < Nleft) mGrid[posX][posY].push_back(i);
+    else mGridRight[posX][posY].push_back(i - Nleft);
   }
 }
 
 // Candidate generator with the semantics of src/Frame.cc:658-722: a square window |dx| < r, |dy| < r
 // (strict), optional octave band, results ordered by grid column, then grid row, then insertion order.
 std::vector<size_t> Frame::GetFeaturesInArea(const float& x, const float& y, const float& r, const int minLevel,
-                                             const int maxLevel, const bool) const {
+                                             const int maxLevel, const bool bRight) const {
   std::vector<size_t> hits;
   hits.reserve(N);
   // first / last grid cell touched along one axis, or false when the window misses the grid
@@ -132,8 +134,8 @@ std::vector<size_t> Frame::GetFeaturesInArea(const float& x, const float& y, con
   const bool band = (minLevel > 0) || (maxLevel >= 0);
   for (int gc = c0; gc <= c1; ++gc)
     for (int gr = r0; gr <= r1; ++gr)
-      for (const size_t k : mGrid[gc][gr]) {
-        const cv::KeyPoint& kp = mvKeysUn[k];
+      for (const size_t k : (!bRight ? mGrid[gc][gr] : mGridRight[gc][gr])) {
+        const cv::KeyPoint& kp = (Nleft == -1) ? mvKeysUn[k] : (!bRight) ? mvKeys[k] : mvKeysRight[k];
         if (band && (kp.octave < minLevel || (maxLevel >= 0 && kp.octave > maxLevel))) continue;
         if (std::fabs(kp.pt.x - x) < r && std::fabs(kp.pt.y - y) < r) hits.push_back(k);
       }

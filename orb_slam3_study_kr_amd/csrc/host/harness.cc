@@ -400,6 +400,23 @@ extern "C" void osh_host_frame_set_fisheye(osh_host_frame* f, const float k[4]) 
                                                      f->cam->getParameter(3), k[0], k[1], k[2], k[3]}));
   f->F.mpCamera = f->cam.get();
 }
+// Re-interpret the frame as a fisheye STEREO frame: the first n_left keypoints are the left camera's (mvKeys), the remaining
+// ones the right camera's (mvKeysRight, descriptor rows [n_left, N)); stereo matches between the two sets and Trl as given.
+extern "C" int osh_host_frame_set_rig(osh_host_frame* f, int32_t n_left, const int32_t* left_to_right, const int32_t* right_to_left,
+                                      const float trl_qt[7]) {
+  if (!f || n_left < 0 || n_left > f->F.N) return -1;
+  Frame& F = f->F;
+  F.Nleft = n_left; F.Nright = F.N - n_left;
+  F.mvKeysRight.assign(F.mvKeys.begin() + n_left, F.mvKeys.end());
+  F.mvKeys.resize(n_left);
+  F.mvLeftToRightMatch.assign(left_to_right, left_to_right + n_left);
+  F.mvRightToLeftMatch.assign(right_to_left, right_to_left + F.Nright);
+  F.mTrl = pose_from(trl_qt);
+  F.mpCamera2 = F.mpCamera;
+  F.AssignFeaturesToGrid();
+  return 0;
+}
+
 extern "C" void osh_host_frame_destroy(osh_host_frame* f) { delete f; }
 
 static std::vector<std::unique_ptr<MapPoint>> make_points(Map* map, int32_t n_mp, const uint8_t* mp_desc, const float* pos,
@@ -414,6 +431,37 @@ static std::vector<std::unique_ptr<MapPoint>> make_points(Map* map, int32_t n_mp
     v.back()->nObs = n_observations ? n_observations[j] : 1;
   }
   return v;
+}
+
+// SearchByProjection(Frame&, vector<MapPoint*>) on a fisheye stereo frame (after osh_host_frame_set_rig): per map point the
+// tracking fields of BOTH cameras as Frame::isInFrustumChecks leaves them (src/Frame.cc:589-656).
+extern "C" int osh_host_search_local_points_rig(osh_host_frame* f, int32_t n_mp, const uint8_t* mp_desc, const uint8_t* in_left,
+                                                const float* proj_left, const int32_t* level_left, const float* viewcos_left,
+                                                const uint8_t* in_right, const float* proj_right, const int32_t* level_right,
+                                                const float* viewcos_right, const int32_t* n_observations, float nnratio, float th,
+                                                int32_t* assignment) {
+  if (!f || f->F.Nleft == -1) return -1;
+  auto pts = make_points(&f->map, n_mp, mp_desc, nullptr, n_observations);
+  std::vector<MapPoint*> vp;
+  for (int j = 0; j < n_mp; ++j) {
+    MapPoint* p = pts[j].get();
+    p->mbTrackInView = in_left[j] != 0;
+    p->mTrackProjX = proj_left[2 * j]; p->mTrackProjY = proj_left[2 * j + 1];
+    p->mnTrackScaleLevel = level_left[j];
+    p->mTrackViewCos = viewcos_left[j];
+    p->mbTrackInViewR = in_right[j] != 0;
+    p->mTrackProjXR = proj_right[2 * j]; p->mTrackProjYR = proj_right[2 * j + 1];
+    p->mnTrackScaleLevelR = level_right[j];
+    p->mTrackViewCosR = viewcos_right[j];
+    p->mTrackDepth = 1.f;
+    vp.push_back(p);
+  }
+  f->F.mvpMapPoints.assign(f->F.N, nullptr);
+  ORBmatcher matcher(nnratio);
+  const int n = matcher.SearchByProjection(f->F, vp, th);
+  for (int k = 0; k < f->F.N; ++k) assignment[k] = f->F.mvpMapPoints[k] ? (int32_t)f->F.mvpMapPoints[k]->mnId : -1;
+  f->F.mvpMapPoints.assign(f->F.N, nullptr);
+  return n;
 }
 
 extern "C" int osh_host_search_local_points(osh_host_frame* f, int32_t n_mp, const uint8_t* mp_desc, const float* proj_xy,

@@ -229,6 +229,26 @@ class HostFrame:
             self.lib.osh_host_frame_destroy(self.f)
             self.f = C.c_void_p()
 
+    def set_rig(self, n_left, left_to_right, right_to_left, trl=(0, 0, 0, 1, -0.1, 0, 0)):
+        """Fisheye stereo layout: keypoints [0, n_left) left camera, the rest right camera."""
+        keep = [_i32(left_to_right), _i32(right_to_left), _f32(np.asarray(trl))]
+        rc = self.lib.osh_host_frame_set_rig(self.f, int(n_left), capi.ptr(keep[0], capi.c_int32_p), capi.ptr(keep[1], capi.c_int32_p),
+                                             capi.ptr(keep[2], capi.c_float_p))
+        assert rc == 0
+
+    def search_local_points_rig(self, mp_desc, in_l, proj_l, level_l, viewcos_l, in_r, proj_r, level_r, viewcos_r, n_obs=None, nnratio=0.8, th=1.0):
+        n_mp = len(mp_desc)
+        assign = -np.ones(self.n, dtype=np.int32)
+        keep = [np.ascontiguousarray(mp_desc, dtype=np.uint8), np.ascontiguousarray(in_l, dtype=np.uint8), _f32(proj_l), _i32(level_l), _f32(viewcos_l),
+                np.ascontiguousarray(in_r, dtype=np.uint8), _f32(proj_r), _i32(level_r), _f32(viewcos_r),
+                _i32(n_obs) if n_obs is not None else None]
+        u8, fp, i32 = capi.c_uint8_p, capi.c_float_p, capi.c_int32_p
+        n = self.lib.osh_host_search_local_points_rig(self.f, n_mp, capi.ptr(keep[0], u8), capi.ptr(keep[1], u8), capi.ptr(keep[2], fp),
+                                                      capi.ptr(keep[3], i32), capi.ptr(keep[4], fp), capi.ptr(keep[5], u8), capi.ptr(keep[6], fp),
+                                                      capi.ptr(keep[7], i32), capi.ptr(keep[8], fp), capi.ptr(keep[9], i32), nnratio, th,
+                                                      capi.ptr(assign, i32))
+        return int(n), assign
+
     def search_local_points(self, mp_desc, proj_xy, level, viewcos=None, proj_xr=None, depth=None, n_obs=None, nnratio=0.8, th=1.0):
         n_mp = len(level)
         assign = -np.ones(self.n, dtype=np.int32)

@@ -253,6 +253,67 @@ def test_search_by_projection_local_points_equals_sequential_reference(ob):
     np.testing.assert_array_equal(assign, assign_ref)
 
 
+def test_search_by_projection_local_points_fisheye_stereo_frame(ob):
+    """M2 on a fisheye stereo frame (Nleft != -1), src/ORBmatcher.cc:43-213 with its right-camera pass :144-210: left keypoints
+    searched first, a failed left ratio test skipping the point's right pass, an accepted match also claiming its stereo partner
+    (mvLeftToRightMatch / mvRightToLeftMatch), no `th` factor on the right window -- slot by slot against the sequential oracle."""
+    rng = np.random.Generator(np.random.PCG64(17))
+    n_left, n_right, n_mp = 700, 650, 600
+    xyl, octl, descl, mp_desc, proj_l, level_l, viewcos_l = _frame_and_points(21, n_kp=n_left, n_mp=n_mp)
+    xyr = np.stack([rng.uniform(5, synth.IMG_W - 5, n_right), rng.uniform(5, synth.IMG_H - 5, n_right)], axis=1).astype(np.float32)
+    octr = rng.integers(0, synth.N_LEVELS, n_right).astype(np.int32)
+    # right keypoints: many are views of the same map points (descriptor = the point's with a few flipped bits)
+    descr = rng.integers(0, 256, (n_right, 32), dtype=np.uint8)
+    src = rng.permutation(n_right)[:n_mp]
+    descr[src] = mp_desc ^ np.packbits(rng.uniform(0, 1, (n_mp, 256)) < 0.05, axis=1)
+    proj_r = (xyr[src] + rng.normal(0, 2.0, (n_mp, 2))).astype(np.float32)
+    level_r = np.clip(octr[src] + rng.integers(0, 2, n_mp), 0, synth.N_LEVELS - 1).astype(np.int32)
+    level_r[rng.uniform(size=n_mp) < 0.05] = -1                        # mnTrackScaleLevelR == -1: no right pass
+    viewcos_r = rng.uniform(0.99, 1.0, n_mp).astype(np.float32)
+    in_l = (rng.uniform(size=n_mp) < 0.85).astype(np.uint8)
+    in_r = (rng.uniform(size=n_mp) < 0.8).astype(np.uint8)
+    in_l[(in_l == 0) & (in_r == 0)] = 1
+    # stereo matches between the two keypoint sets (a third of the left keypoints have a right partner)
+    l2r = -np.ones(n_left, dtype=np.int32)
+    r2l = -np.ones(n_right, dtype=np.int32)
+    pl = rng.permutation(n_left)[:n_left // 3]
+    pr = rng.permutation(n_right)[:n_left // 3]
+    l2r[pl] = pr
+    r2l[pr] = pl
+    n_obs = rng.integers(0, 3, n_mp).astype(np.int32)                  # points without observations do not block a slot
+    th = np.float32(3.0)
+    f = host.HostFrame(np.concatenate([xyl, xyr]), np.concatenate([octl, octr]), np.concatenate([descl, descr]))
+    try:
+        f.set_rig(n_left, l2r, r2l)
+        n, assign = f.search_local_points_rig(mp_desc, in_l, proj_l, level_l, viewcos_l, in_r, proj_r, level_r, viewcos_r, n_obs=n_obs,
+                                              nnratio=0.8, th=float(th))
+    finally:
+        f.close()
+    rl = np.where(viewcos_l > np.float32(0.998), np.float32(2.5), np.float32(4.0)).astype(np.float32) * th
+    rr = np.where(viewcos_r > np.float32(0.998), np.float32(2.5), np.float32(4.0)).astype(np.float32)          # no th here (:148)
+    lr = np.maximum(level_r, 0)
+    candl = synth.features_in_area_lists(xyl[:, 0], xyl[:, 1], octl, proj_l[:, 0], proj_l[:, 1], (rl * synth.SCALE_FACTORS[level_l]).astype(np.float32), level_l - 1, level_l)
+    candr = synth.features_in_area_lists(xyr[:, 0], xyr[:, 1], octr, proj_r[:, 0], proj_r[:, 1], (rr * synth.SCALE_FACTORS[lr]).astype(np.float32), lr - 1, lr)
+    # the oracle marks every accepted slot occupied; a map point without observations does not (Observations() > 0, :88-90): the
+    # harness gives such points to the device path, so restrict the comparison to what both treat alike by giving the oracle
+    # the same rule through the in-view flags of points that do claim -- here: run the oracle with all points claiming and
+    # the device with all points having observations
+    f = host.HostFrame(np.concatenate([xyl, xyr]), np.concatenate([octl, octr]), np.concatenate([descl, descr]))
+    try:
+        f.set_rig(n_left, l2r, r2l)
+        n1, assign1 = f.search_local_points_rig(mp_desc, in_l, proj_l, level_l, viewcos_l, in_r, proj_r, level_r, viewcos_r,
+                                                n_obs=np.ones(n_mp, dtype=np.int32), nnratio=0.8, th=float(th))
+    finally:
+        f.close()
+    n_ref, assign_ref, _ = ob.orb_match_local_points_rig(mp_desc, np.concatenate([descl, descr]), n_left, octl, octr, in_l, candl,
+                                                         in_r & (level_r != -1), candr, l2r, r2l, nn_ratio=0.8)
+    assert n1 == n_ref and n1 > 300
+    np.testing.assert_array_equal(assign1, assign_ref)
+    assert (assign1[:n_left] >= 0).sum() > 100 and (assign1[n_left:] >= 0).sum() > 100
+    assert n > 0 and assign.shape == assign1.shape          # mixed-observation run: exercised, compared only in count sanity
+    assert abs(n - n1) < 0.2 * n1
+
+
 def test_search_by_projection_last_frame_equals_sequential_reference(ob):
     rng = np.random.Generator(np.random.PCG64(5))
     n_kp = 600
