@@ -327,3 +327,16 @@ def log_so3(R):
     o = np.zeros(3)
     lib.oracle_log_so3(_d(R), _d(o))
     return o
+
+
+def orb_match_last_frame_rig(query, desc, n_left, candl, candr, query_angle, angle_left, angle_right, th_high=100, check_orientation=True):
+    """SearchByProjection(CurrentFrame, LastFrame) with a fisheye stereo current frame: both camera searches (orb_oracle.c)."""
+    lib = load()
+    nq, n = query.shape[0], desc.shape[0]
+    occ = np.zeros(n, dtype=np.uint8)
+    assign = -np.ones(n, dtype=np.int32)
+    qa, al, ar = (np.ascontiguousarray(a, dtype=np.float32) for a in (query_angle, angle_left, angle_right))
+    fp = capi.c_float_p
+    cnt = lib.oracle_orb_match_last_frame_rig(nq, int(n_left), int(n - n_left), _u8(query), _u8(desc), _i32(candl[0]), _i32(candl[1]),
+                                              _i32(candr[0]), _i32(candr[1]), capi.ptr(qa, fp), capi.ptr(al, fp), capi.ptr(ar, fp), th_high, int(check_orientation), _u8(occ), _i32(assign))
+    return int(cnt), assign, occ

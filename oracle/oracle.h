@@ -67,6 +67,10 @@ int  oracle_orb_match_last_frame(int n_query, int n_train, const uint8_t* query_
                                  const uint8_t* train_desc, const int32_t* cand_off, const int32_t* cand_idx,
                                  const float* query_angle, const float* train_angle,
                                  int th_high, int check_orientation, uint8_t* occupied, int32_t* assignment);
+int  oracle_orb_match_last_frame_rig(int n_query, int n_left, int n_right, const uint8_t* query_desc, const uint8_t* desc,
+                                     const int32_t* candl_off, const int32_t* candl_idx, const int32_t* candr_off, const int32_t* candr_idx,
+                                     const float* query_angle, const float* angle_left, const float* angle_right,
+                                     int th_high, int check_orientation, uint8_t* occupied, int32_t* assignment);
 #ifdef __cplusplus
 }
 #endif

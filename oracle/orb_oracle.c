@@ -226,3 +226,61 @@ int oracle_orb_match_last_frame(int n_query, int n_train, const uint8_t* query_d
   for (int i = 0; i < HISTO_LENGTH; ++i) free(hist[i]);
   return nmatches;
 }
+
+/* SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) with a FISHEYE STEREO current frame
+ * (CurrentFrame.Nleft != -1), src/ORBmatcher.cc:1676-1887 including the right-camera block :1794-1858.  Per query (a map point
+ * of the last frame that passed the projection tests): best-only search among the left keypoints -- an EMPTY left candidate list
+ * `continue`s past the right-camera block (:1731-1732) --, then best-only search among the right keypoints; accept <= TH_HIGH;
+ * rotation histogram over both (right slots enter as index + n_left), three dominant bins kept.  Slots / occupied as in
+ * oracle_orb_match_local_points_rig.  query_angle: angle of the last frame's keypoint; angle_left / angle_right: current frame. */
+int oracle_orb_match_last_frame_rig(int n_query, int n_left, int n_right, const uint8_t* query_desc, const uint8_t* desc,
+                                    const int32_t* candl_off, const int32_t* candl_idx, const int32_t* candr_off, const int32_t* candr_idx,
+                                    const float* query_angle, const float* angle_left, const float* angle_right,
+                                    int th_high, int check_orientation, uint8_t* occupied, int32_t* assignment) {
+  enum { HISTO_LENGTH = 30 };
+  int nmatches = 0;
+  int* hist[HISTO_LENGTH];
+  int hsize[HISTO_LENGTH];
+  for (int i = 0; i < HISTO_LENGTH; ++i) { hist[i] = (int*)malloc(sizeof(int) * (size_t)(2 * n_query + 1)); hsize[i] = 0; }
+  const float factor = 1.0f / HISTO_LENGTH;
+  const uint8_t* desc_r = desc + 32 * (size_t)n_left;
+  uint8_t* occ_r = occupied + n_left;
+  for (int q = 0; q < n_query; ++q) {
+    const uint8_t* qd = query_desc + 32 * (size_t)q;
+    const int ncl = candl_off[q + 1] - candl_off[q];
+    if (ncl == 0) continue;
+    int bi, bd, bd2, bl, bl2;
+    scan_one(qd, desc, NULL, candl_idx + candl_off[q], ncl, n_left, occupied, &bi, &bd, &bd2, &bl, &bl2);
+    if (bd <= th_high) {
+      assignment[bi] = q; occupied[bi] = 1; nmatches++;
+      if (check_orientation) {
+        float rot = query_angle[q] - angle_left[bi];
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)roundf(rot * factor);
+        if (bin == HISTO_LENGTH) bin = 0;
+        hist[bin][hsize[bin]++] = bi;
+      }
+    }
+    const int ncr = candr_off[q + 1] - candr_off[q];
+    scan_one(qd, desc_r, NULL, candr_idx + candr_off[q], ncr, n_right, occ_r, &bi, &bd, &bd2, &bl, &bl2);
+    if (ncr > 0 && bd <= th_high) {
+      assignment[bi + n_left] = q; occ_r[bi] = 1; nmatches++;
+      if (check_orientation) {
+        float rot = query_angle[q] - angle_right[bi];
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)roundf(rot * factor);
+        if (bin == HISTO_LENGTH) bin = 0;
+        hist[bin][hsize[bin]++] = bi + n_left;
+      }
+    }
+  }
+  if (check_orientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(hsize, HISTO_LENGTH, &ind1, &ind2, &ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++)
+      if (i != ind1 && i != ind2 && i != ind3)
+        for (int j = 0; j < hsize[i]; j++) { assignment[hist[i][j]] = -1; nmatches--; }
+  }
+  for (int i = 0; i < HISTO_LENGTH; ++i) free(hist[i]);
+  return nmatches;
+}

@@ -320,12 +320,124 @@ void ORBmatcher::ComputeThreeMaxima(std::vector<int>* histo, const int L, int& i
   else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
 }
 
-// src/ORBmatcher.cc:1676-1887, Nleft == -1 layouts.
-int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono) {
-  if (CurrentFrame.Nleft != -1 || LastFrame.Nleft != -1) {
-    std::fprintf(stderr, "ORBmatcher::SearchByProjection: fisheye-stereo frames are not supported by the MI355X path yet\n");
-    std::abort();
+namespace {
+
+// src/ORBmatcher.cc:1676-1887 on fisheye stereo frames (CurrentFrame.Nleft != -1): per map point of the last frame the search
+// among the current frame's LEFT keypoints (:1696-1792, no u_right test) and then, unless the left candidate list was empty
+// (`continue` at :1732), among its RIGHT keypoints with the point moved through Trl and projected with mpCamera (:1794-1858).
+// Both searches of all points run on the device first; the sequential part is replayed on the host.
+int search_last_frame_rig(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bForward, const bool bBackward,
+                          const bool mbCheckOrientation, void (*three_maxima)(std::vector<int>*, int, int&, int&, int&)) {
+  const int HISTO_LENGTH = ORBmatcher::HISTO_LENGTH, TH_HIGH = ORBmatcher::TH_HIGH;
+  std::vector<int> rotHist[30];
+  for (int i = 0; i < HISTO_LENGTH; i++) rotHist[i].reserve(500);
+  const float factor = 1.0f / HISTO_LENGTH;
+  const Sophus::SE3f Tcw = CurrentFrame.GetPose();
+  const int NL = CurrentFrame.Nleft, NR = CurrentFrame.N - CurrentFrame.Nleft;
+  Train tl = train_of_rig(CurrentFrame, false), tr = train_of_rig(CurrentFrame, true);
+  auto occupied_at = [&CurrentFrame](int slot) { return (CurrentFrame.mvpMapPoints[slot] && CurrentFrame.mvpMapPoints[slot]->Observations() > 0) ? 1 : 0; };
+  for (int i = 0; i < NL; ++i) tl.skip[i] = occupied_at(i);
+  for (int i = 0; i < NR; ++i) tr.skip[i] = occupied_at(i + NL);
+  auto area_l = [&CurrentFrame](float x, float y, float r, int lo, int hi) { return CurrentFrame.GetFeaturesInArea(x, y, r, lo, hi, false); };
+  auto area_r = [&CurrentFrame](float x, float y, float r, int lo, int hi) { return CurrentFrame.GetFeaturesInArea(x, y, r, lo, hi, true); };
+  Search sl, sr;
+  std::vector<int> qLast;
+  for (int i = 0; i < LastFrame.N; i++) {
+    MapPoint* pMP = LastFrame.mvpMapPoints[i];
+    if (!pMP || LastFrame.mvbOutlier[i]) continue;
+    const Eigen::Vector3f x3Dc = Tcw * pMP->GetWorldPos();
+    const float invzc = 1.0 / x3Dc(2);
+    if (invzc < 0) continue;
+    const Eigen::Vector2f uv = CurrentFrame.mpCamera->project(x3Dc);
+    if (uv(0) < CurrentFrame.mnMinX || uv(0) > CurrentFrame.mnMaxX) continue;
+    if (uv(1) < CurrentFrame.mnMinY || uv(1) > CurrentFrame.mnMaxY) continue;
+    const int nLastOctave = (LastFrame.Nleft == -1 || i < LastFrame.Nleft) ? LastFrame.mvKeys[i].octave : LastFrame.mvKeysRight[i - LastFrame.Nleft].octave;
+    const float radius = th * CurrentFrame.mvScaleFactors[nLastOctave];
+    int lo, hi;
+    if (bForward) { lo = nLastOctave; hi = -1; }
+    else if (bBackward) { lo = 0; hi = nLastOctave; }
+    else { lo = nLastOctave - 1; hi = nLastOctave + 1; }
+    sl.add(pMP->GetDescriptor(), uv(0), uv(1), radius, lo, hi);
+    const Eigen::Vector3f x3Dr = CurrentFrame.GetRelativePoseTrl() * x3Dc;       // :1795
+    const Eigen::Vector2f uvr = CurrentFrame.mpCamera->project(x3Dr);            // :1796 (mpCamera, as in the reference)
+    sr.add(pMP->GetDescriptor(), uvr(0), uvr(1), radius, lo, hi);
+    qLast.push_back(i);
   }
+  if (!device_search(sl, tl) || !device_search(sr, tr)) return 0;
+
+  int nmatches = 0;
+  std::vector<uint8_t> taken_l(NL, 0), taken_r(NR, 0);
+  auto last_kp = [&LastFrame](int i) -> const cv::KeyPoint& {
+    return (LastFrame.Nleft == -1) ? LastFrame.mvKeysUn[i] : (i < LastFrame.Nleft) ? LastFrame.mvKeys[i] : LastFrame.mvKeysRight[i - LastFrame.Nleft];
+  };
+  for (int q = 0; q < sl.nq(); ++q) {
+    MapPoint* pMP = LastFrame.mvpMapPoints[qLast[q]];
+    const bool claims = pMP->Observations() > 0;
+    int d2, l1, l2;
+    {
+      int bestIdx2 = sl.best_idx[q], bestDist = sl.best_dist[q];
+      if (bestIdx2 >= 0 && taken_l[bestIdx2]) rescan(sl, q, tl, taken_l, area_l, bestIdx2, bestDist, d2, l1, l2);
+      // `if(vIndices2.empty()) continue;` (:1731-1732) also skips the right-camera search of this point: the device reports
+      // "no candidate" for an empty list AND for a list whose entries are all occupied, so the (rare) no-candidate case asks
+      if (bestIdx2 < 0 && area_l(sl.win[3 * q], sl.win[3 * q + 1], sl.win[3 * q + 2], sl.lev[2 * q], sl.lev[2 * q + 1]).empty()) continue;
+      if (bestDist <= TH_HIGH) {
+        CurrentFrame.mvpMapPoints[bestIdx2] = pMP;
+        if (claims) taken_l[bestIdx2] = 1;
+        nmatches++;
+        if (mbCheckOrientation) {
+          float rot = last_kp(qLast[q]).angle - CurrentFrame.mvKeys[bestIdx2].angle;
+          if (rot < 0.0) rot += 360.0f;
+          int bin = (int)std::round(rot * factor);
+          if (bin == HISTO_LENGTH) bin = 0;
+          rotHist[bin].push_back(bestIdx2);
+        }
+      }
+    }
+    {
+      int bestIdx2 = sr.best_idx[q], bestDist = sr.best_dist[q];
+      if (bestIdx2 >= 0 && taken_r[bestIdx2]) rescan(sr, q, tr, taken_r, area_r, bestIdx2, bestDist, d2, l1, l2);
+      if (bestDist <= TH_HIGH) {
+        CurrentFrame.mvpMapPoints[bestIdx2 + NL] = pMP;
+        if (claims) taken_r[bestIdx2] = 1;
+        nmatches++;
+        if (mbCheckOrientation) {
+          float rot = last_kp(qLast[q]).angle - CurrentFrame.mvKeysRight[bestIdx2].angle;
+          if (rot < 0.0) rot += 360.0f;
+          int bin = (int)std::round(rot * factor);
+          if (bin == HISTO_LENGTH) bin = 0;
+          rotHist[bin].push_back(bestIdx2 + NL);
+        }
+      }
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (const int slot : rotHist[i]) { CurrentFrame.mvpMapPoints[slot] = nullptr; nmatches--; }
+    }
+  }
+  return nmatches;
+}
+
+// ComputeThreeMaxima is a protected member; the rig search above (a free function) gets this restatement of :2012-2053
+void three_maxima_fn(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3) {
+  int max1 = 0, max2 = 0, max3 = 0;
+  for (int i = 0; i < L; i++) {
+    const int n = (int)histo[i].size();
+    if (n > max1) { max3 = max2; max2 = max1; max1 = n; ind3 = ind2; ind2 = ind1; ind1 = i; }
+    else if (n > max2) { max3 = max2; max2 = n; ind3 = ind2; ind2 = i; }
+    else if (n > max3) { max3 = n; ind3 = i; }
+  }
+  if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+  else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+}  // namespace
+
+// src/ORBmatcher.cc:1676-1887.
+int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono) {
   std::vector<int> rotHist[30];
   for (int i = 0; i < HISTO_LENGTH; i++) rotHist[i].reserve(500);
   const float factor = 1.0f / HISTO_LENGTH;
@@ -338,6 +450,7 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
   const Eigen::Vector3f tlc = LastFrame.GetPose() * twc;
   const bool bForward = tlc(2) > CurrentFrame.mb && !bMono;
   const bool bBackward = -tlc(2) > CurrentFrame.mb && !bMono;
+  if (CurrentFrame.Nleft != -1) return search_last_frame_rig(CurrentFrame, LastFrame, th, bForward, bBackward, mbCheckOrientation, three_maxima_fn);
 
   Train t = train_of(CurrentFrame);
   t.uright = CurrentFrame.mvuRight;
@@ -355,7 +468,7 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
     const Eigen::Vector2f uv = CurrentFrame.mpCamera->project(x3Dc);
     if (uv(0) < CurrentFrame.mnMinX || uv(0) > CurrentFrame.mnMaxX) continue;
     if (uv(1) < CurrentFrame.mnMinY || uv(1) > CurrentFrame.mnMaxY) continue;
-    const int nLastOctave = LastFrame.mvKeys[i].octave;
+    const int nLastOctave = (LastFrame.Nleft == -1 || i < LastFrame.Nleft) ? LastFrame.mvKeys[i].octave : LastFrame.mvKeysRight[i - LastFrame.Nleft].octave;
     const float radius = th * CurrentFrame.mvScaleFactors[nLastOctave];   // window scales with the octave
     // level range by the motion direction (:1744-1750): forward -> [octave, inf), backward -> [0, octave], else octave +- 1
     int lo, hi;
@@ -402,10 +515,6 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
 // call; accept bestDist <= ORBdist; rotation histogram with the keyframe keypoint's angle.
 int ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, const float th,
                                    const int ORBdist) {
-  if (CurrentFrame.Nleft != -1) {
-    std::fprintf(stderr, "ORBmatcher::SearchByProjection: fisheye-stereo frames are not supported by the MI355X path yet\n");
-    std::abort();
-  }
   const Sophus::SE3f Tcw = CurrentFrame.GetPose();
   const Eigen::Vector3f Ow = Tcw.inverse().translation();
   std::vector<int> rotHist[30];
@@ -413,8 +522,9 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std
   const float factor = 1.0f / HISTO_LENGTH;
   const std::vector<MapPoint*> vpMPs = pKF->GetMapPointMatches();
 
-  Train t = train_of(CurrentFrame);
-  for (int i = 0; i < CurrentFrame.N; ++i) t.skip[i] = CurrentFrame.mvpMapPoints[i] ? 1 : 0;   // any matched slot (:1952)
+  // on a fisheye stereo frame the reference searches the LEFT keypoints only here (GetFeaturesInArea's bRight defaults to false)
+  Train t = CurrentFrame.Nleft == -1 ? train_of(CurrentFrame) : train_of_rig(CurrentFrame, false);
+  for (int i = 0; i < t.n(); ++i) t.skip[i] = CurrentFrame.mvpMapPoints[i] ? 1 : 0;   // any matched slot (:1952)
   auto area = [&CurrentFrame](float x, float y, float r, int lo, int hi) { return CurrentFrame.GetFeaturesInArea(x, y, r, lo, hi); };
   Search s;
   std::vector<int> qKF;  // keypoint index in pKF of every query
@@ -449,7 +559,8 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std
     taken[bestIdx2] = 1;
     nmatches++;
     if (mbCheckOrientation) {
-      float rot = pKF->mvKeysUn[qKF[q]].angle - CurrentFrame.mvKeysUn[bestIdx2].angle;
+      const cv::KeyPoint& kpCF = CurrentFrame.Nleft == -1 ? CurrentFrame.mvKeysUn[bestIdx2] : CurrentFrame.mvKeys[bestIdx2];
+      float rot = pKF->mvKeysUn[qKF[q]].angle - kpCF.angle;
       if (rot < 0.0) rot += 360.0f;
       int bin = (int)std::round(rot * factor);
       if (bin == HISTO_LENGTH) bin = 0;

@@ -347,6 +347,61 @@ def test_search_by_projection_last_frame_equals_sequential_reference(ob):
     np.testing.assert_array_equal(assign, assign_ref)
 
 
+def test_search_by_projection_last_frame_fisheye_stereo_frame(ob):
+    """M3 with a fisheye stereo current frame, src/ORBmatcher.cc:1676-1887 including the right-camera block :1794-1858: the last
+    frame's map points are searched among the left keypoints and then -- through Trl, projected with mpCamera as the reference
+    does -- among the right keypoints; rotation histogram over both; against the sequential oracle."""
+    rng = np.random.Generator(np.random.PCG64(23))
+    n_left, n_right = 500, 450
+    xyl, octl, descl, _, _, _, _ = _frame_and_points(31, n_kp=n_left, n_mp=10)
+    angl = rng.uniform(0, 360, n_left).astype(np.float32)
+    trl = np.array([0, 0, 0, 1, -0.1, 0.0, 0.0], dtype=np.float32)
+    # last frame (monocular layout): its keypoints hold map points on the viewing rays of the current left keypoints
+    n_last = n_left
+    last_xy = (xyl + rng.normal(0, 1.5, xyl.shape)).astype(np.float32)
+    depth = rng.uniform(4, 10, n_last)
+    pos = np.stack([(last_xy[:, 0] - float(synth.CX)) / float(synth.FX) * depth,
+                    (last_xy[:, 1] - float(synth.CY)) / float(synth.FY) * depth, depth], axis=1).astype(np.float32)
+    mp_desc = descl ^ np.packbits(rng.uniform(0, 1, (n_last, 256)) < 0.05, axis=1)
+    last_angle = ((angl + rng.choice([0.0, 1.0, 95.0], n_last, p=[0.6, 0.3, 0.1])) % 360).astype(np.float32)
+    # right keypoints: near the right-camera projection of many of the points, descriptors close to the points'
+    fx, fy, cx, cy = (np.float32(v) for v in (synth.FX, synth.FY, synth.CX, synth.CY))
+    xr = pos + trl[4:7]                                                   # Trl * x3Dc with identity rotation (float32)
+    ur = (fx * xr[:, 0] / xr[:, 2] + cx).astype(np.float32)
+    vr = (fy * xr[:, 1] / xr[:, 2] + cy).astype(np.float32)
+    xyr = np.stack([rng.uniform(5, synth.IMG_W - 5, n_right), rng.uniform(5, synth.IMG_H - 5, n_right)], axis=1).astype(np.float32)
+    octr = rng.integers(0, synth.N_LEVELS, n_right).astype(np.int32)
+    descr = rng.integers(0, 256, (n_right, 32), dtype=np.uint8)
+    src = rng.permutation(n_last)[:n_right]
+    xyr[:] = np.stack([ur[src], vr[src]], axis=1) + rng.normal(0, 1.5, (n_right, 2)).astype(np.float32)
+    octr[:] = octl[src]
+    descr[:] = mp_desc[src] ^ np.packbits(rng.uniform(0, 1, (n_right, 256)) < 0.04, axis=1)
+    angr = rng.uniform(0, 360, n_right).astype(np.float32)
+    angr[: n_right // 2] = last_angle[src][: n_right // 2]
+    l2r = -np.ones(n_left, dtype=np.int32)
+    r2l = -np.ones(n_right, dtype=np.int32)
+    cur = host.HostFrame(np.concatenate([xyl, xyr]), np.concatenate([octl, octr]), np.concatenate([descl, descr]), angle=np.concatenate([angl, angr]))
+    last = host.HostFrame(last_xy, octl, mp_desc, angle=last_angle)
+    th = 15.0
+    try:
+        cur.set_rig(n_left, l2r, r2l, trl=trl)
+        n, assign = cur.search_last_frame(last, np.arange(n_last), pos, mp_desc, th=th, mono=True, check_ori=True)
+    finally:
+        cur.close(); last.close()
+    u = (fx * pos[:, 0] / pos[:, 2] + cx).astype(np.float32)
+    v = (fy * pos[:, 1] / pos[:, 2] + cy).astype(np.float32)
+    radius = (np.float32(th) * synth.SCALE_FACTORS[octl]).astype(np.float32)
+    inb = (u >= 0) & (u <= synth.IMG_W) & (v >= 0) & (v <= synth.IMG_H)
+    q = np.nonzero(inb)[0]                                                 # queries that pass the projection tests (:1713-1716)
+    candl = synth.features_in_area_lists(xyl[:, 0], xyl[:, 1], octl, u[q], v[q], radius[q], octl[q] - 1, octl[q] + 1)
+    candr = synth.features_in_area_lists(xyr[:, 0], xyr[:, 1], octr, ur[q], vr[q], radius[q], octl[q] - 1, octl[q] + 1)
+    n_ref, assign_ref, _ = ob.orb_match_last_frame_rig(mp_desc[q], np.concatenate([descl, descr]), n_left, candl, candr, last_angle[q], angl, angr)
+    assign_ref = np.where(assign_ref >= 0, q[np.maximum(assign_ref, 0)], -1)
+    assert n == n_ref and n > 100
+    np.testing.assert_array_equal(assign, assign_ref)
+    assert (assign[n_left:] >= 0).sum() > 30 and (assign[:n_left] >= 0).sum() > 30
+
+
 def test_search_by_projection_keyframe_relocalisation_equals_sequential_reference(ob):
     """M4, src/ORBmatcher.cc:1889-2010: projection with the current pose, predicted level from the distance, any occupied slot
     skipped, accept <= ORBdist, rotation histogram; bad / already-found map points and out-of-range distances are dropped."""
