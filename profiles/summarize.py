@@ -17,6 +17,14 @@ dst = Path(__file__).resolve().parent
 stats = src / "trace" / "trace_kernel_stats.csv"
 if stats.exists():
     shutil.copy(stats, dst / f"{tag}_kernel_stats.csv")
+other = src / "other_trace" / "trace_kernel_stats.csv"
+if other.exists():
+    shutil.copy(other, dst / f"{tag}_other_kernel_stats.csv")
+opm = sorted(glob.glob(str(src / "other_pmc*" / "pmc_counter_collection.csv")))
+if opm:
+    od = pd.concat([pd.read_csv(f).groupby(["Kernel_Name", "Counter_Name"])["Counter_Value"].mean().reset_index() for f in opm])
+    od["Kernel_Name"] = od["Kernel_Name"].str.replace(r"\(.*", "", regex=True).str.replace("osh::", "")
+    od.pivot_table(index="Counter_Name", columns="Kernel_Name", values="Counter_Value").to_csv(dst / f"{tag}_other_pmc_summary.csv", float_format="%.6g")
 rows = []
 for f in sorted(glob.glob(str(src / "pmc*" / "pmc_counter_collection.csv"))):
     df = pd.read_csv(f)
