@@ -356,6 +356,19 @@ int osh_orb_upload_grid(osh_orb_ctx* ctx, const osh_orb_batch* batch, const osh_
 int osh_orb_upload(osh_orb_ctx* ctx, const osh_orb_batch* batch);
 /* Run the search on the resident batch; synchronous. */
 int osh_orb_match(osh_orb_ctx* ctx);
+/* The whole matching loop of ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th, ...) (src/ORBmatcher.cc:43-141)
+ * on the resident batch, sequential slot occupancy included: query q sees the candidates minus the keypoint slots that hold a
+ * map point with Observations() > 0 (:88-90) -- the slots in `occupied` at call entry and the slots claimed by accepted queries
+ * before q (:131-136).  The device runs the unrestricted search, then fixed-point rounds (claim, close the claimed slots for
+ * later queries, search the contested queries again) until the claims repeat; the result equals the sequential loop bit for bit.
+ *   occupied      [n_pairs*n_train] 1: slot taken at call entry, or NULL
+ *   query_blocks  [n_pairs*n_query] 1: the query's map point has Observations() > 0 (its match closes the slot), NULL: all do
+ *   assignment    [n_pairs*n_train] out: query stored into each slot (F.mvpMapPoints[slot]) or -1
+ *   n_matches     [n_pairs] out: the function's return value per pair
+ *   query_slot    [n_pairs*n_query] out (may be NULL): slot claimed by each query or -1
+ *   rounds        out (may be NULL): fixed-point rounds run */
+int osh_orb_match_local_points(osh_orb_ctx* ctx, float nn_ratio, int32_t th_high, const uint8_t* occupied, const uint8_t* query_blocks,
+                               int32_t* assignment, int32_t* n_matches, int32_t* query_slot, int32_t* rounds);
 /* Copy the per-query results back. Each array has n_pairs*n_query entries. */
 int osh_orb_download(osh_orb_ctx* ctx, int32_t* best_idx, int32_t* best_dist,
                      int32_t* second_dist, int32_t* best_level, int32_t* second_level,
@@ -363,6 +376,8 @@ int osh_orb_download(osh_orb_ctx* ctx, int32_t* best_idx, int32_t* best_dist,
 /* Average duration of the match kernel over the launches since the last upload. */
 int osh_orb_get_profile(osh_orb_ctx* ctx, int64_t* launches, double* total_ms);
 int osh_orb_set_profiling(osh_orb_ctx* ctx, int enable);
+/* The occupancy rounds of osh_orb_match_local_points (everything after the unrestricted search), summed per call. */
+int osh_orb_get_resolve_profile(osh_orb_ctx* ctx, int64_t* launches, double* total_ms);
 
 /* ------------------------------------------------- frustum projection (candidate generation) */
 /*

@@ -202,9 +202,11 @@ _SIGNATURES = {
     "osh_orb_upload_grid": (C.c_int, [C.c_void_p, C.POINTER(OrbBatch), C.POINTER(OrbGrid)]),
     "osh_orb_frustum": (C.c_int, [C.c_void_p, C.POINTER(FrustumFrame), C.POINTER(FrustumPoints), C.POINTER(FrustumResult)]),
     "osh_orb_match": (C.c_int, [C.c_void_p]),
+    "osh_orb_match_local_points": (C.c_int, [C.c_void_p, C.c_float, C.c_int32, c_uint8_p, c_uint8_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p]),
     "osh_orb_download": (C.c_int, [C.c_void_p] + [c_int32_p] * 6),
     "osh_orb_get_profile": (C.c_int, [C.c_void_p, c_int64_p, c_double_p]),
     "osh_orb_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "osh_orb_get_resolve_profile": (C.c_int, [C.c_void_p, c_int64_p, c_double_p]),
     "osh_orb_distance_matrix": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_uint8_p, c_uint8_p, c_int32_p]),
 }
 

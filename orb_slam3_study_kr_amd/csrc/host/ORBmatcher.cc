@@ -99,22 +99,34 @@ Train train_of(const Frame& F) {
   return t;
 }
 
-// one batched device search of all queries; the candidates come from the train side's grid
-bool device_search(Search& s, const Train& t) {
-  const int nq = s.nq();
-  for (auto* v : {&s.best_idx, &s.best_dist, &s.second_dist, &s.best_level, &s.second_level, &s.second_idx}) v->assign(nq, -1);
-  if (nq == 0) return true;
+// queries and the train side's grid become device resident; nullptr (and a message) on failure or for an empty search
+osh_orb_ctx* upload_search(const Search& s, const Train& t) {
+  if (s.nq() == 0) return nullptr;
   osh_orb_ctx* ctx = thread_ctx();
-  if (!ctx) return false;
+  if (!ctx) return nullptr;
   osh_orb_batch b;
-  b.n_pairs = 1; b.n_query = nq; b.n_train = t.n();
+  b.n_pairs = 1; b.n_query = s.nq(); b.n_train = t.n();
   b.query_desc = s.qdesc.data(); b.train_desc = t.desc->ptr<uint8_t>(t.row0); b.train_level = t.level.data();
   b.cand_off = nullptr; b.cand_idx = nullptr; b.pair_cand_base = nullptr;
   osh_orb_grid g;
   g.train_xy = t.xy.data(); g.train_uright = t.uright.empty() ? nullptr : t.uright.data(); g.train_skip = t.skip.data();
   g.min_x = t.min_x; g.min_y = t.min_y; g.cell_w_inv = t.winv; g.cell_h_inv = t.hinv; g.cols = t.cols; g.rows = t.rows;
   g.query_window = s.win.data(); g.query_levels = s.lev.data(); g.query_uright = s.ur.empty() ? nullptr : s.ur.data();
-  if (osh_orb_upload_grid(ctx, &b, &g) != OSH_OK || osh_orb_match(ctx) != OSH_OK ||
+  if (osh_orb_upload_grid(ctx, &b, &g) != OSH_OK) {
+    std::fprintf(stderr, "ORBmatcher: device upload failed: %s\n", osh_last_error());
+    return nullptr;
+  }
+  return ctx;
+}
+
+// one batched device search of all queries; the candidates come from the train side's grid
+bool device_search(Search& s, const Train& t) {
+  const int nq = s.nq();
+  for (auto* v : {&s.best_idx, &s.best_dist, &s.second_dist, &s.best_level, &s.second_level, &s.second_idx}) v->assign(nq, -1);
+  if (nq == 0) return true;
+  osh_orb_ctx* ctx = upload_search(s, t);
+  if (!ctx) return false;
+  if (osh_orb_match(ctx) != OSH_OK ||
       osh_orb_download(ctx, s.best_idx.data(), s.best_dist.data(), s.second_dist.data(), s.best_level.data(),
                        s.second_level.data(), s.second_idx.data()) != OSH_OK) {
     std::fprintf(stderr, "ORBmatcher: device search failed: %s\n", osh_last_error());
@@ -267,7 +279,6 @@ int ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMap
   Train t = train_of(F);
   t.uright = F.mvuRight;                                            // stereo consistency window (:92-97)
   for (int i = 0; i < F.N; ++i) t.skip[i] = (F.mvpMapPoints[i] && F.mvpMapPoints[i]->Observations() > 0) ? 1 : 0;   // :88-90 at call entry
-  auto area = [&F](float x, float y, float r, int lo, int hi) { return F.GetFeaturesInArea(x, y, r, lo, hi); };
   Search s;
   std::vector<MapPoint*> qMP;
   for (size_t iMP = 0; iMP < vpMapPoints.size(); iMP++) {
@@ -285,25 +296,18 @@ int ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMap
     s.ur.push_back(pMP->mTrackProjXR); s.ur.push_back(win);
     qMP.push_back(pMP);
   }
-  if (!device_search(s, t)) return 0;
-
-  int nmatches = 0;
-  std::vector<uint8_t> taken(F.N, 0);  // slots claimed during this call
-  for (int q = 0; q < s.nq(); ++q) {
-    int bestIdx = s.best_idx[q], bestDist = s.best_dist[q], bestDist2 = s.second_dist[q];
-    int bestLevel = s.best_level[q], bestLevel2 = s.second_level[q];
-    if ((bestIdx >= 0 && taken[bestIdx]) || (s.second_idx[q] >= 0 && taken[s.second_idx[q]]))
-      rescan(s, q, t, taken, area, bestIdx, bestDist, bestDist2, bestLevel, bestLevel2);
-    // ratio to the second match only if both are in the same scale level; the product is a float (:123-139)
-    if (bestDist <= TH_HIGH) {
-      if (bestLevel == bestLevel2 && bestDist > mfNNratio * bestDist2) continue;
-      if (bestLevel != bestLevel2 || bestDist <= mfNNratio * bestDist2) {
-        F.mvpMapPoints[bestIdx] = qMP[q];
-        if (qMP[q]->Observations() > 0) taken[bestIdx] = 1;
-        nmatches++;
-      }
-    }
+  // search, acceptance rule (:123-139) and the sequential slot occupancy (:88-90) all on the device: osh_orb_match_local_points
+  osh_orb_ctx* ctx = upload_search(s, t);
+  if (!ctx) return 0;
+  std::vector<uint8_t> blocks(qMP.size());
+  for (size_t q = 0; q < qMP.size(); ++q) blocks[q] = qMP[q]->Observations() > 0 ? 1 : 0;
+  std::vector<int32_t> assignment(F.N, -1);
+  int32_t nmatches = 0;
+  if (osh_orb_match_local_points(ctx, mfNNratio, TH_HIGH, nullptr, blocks.data(), assignment.data(), &nmatches, nullptr, nullptr) != OSH_OK) {
+    std::fprintf(stderr, "ORBmatcher: device search failed: %s\n", osh_last_error());
+    return 0;
   }
+  for (int i = 0; i < F.N; ++i) if (assignment[i] >= 0) F.mvpMapPoints[i] = qMP[assignment[i]];
   return nmatches;
 }
 

@@ -246,6 +246,176 @@ __global__ __launch_bounds__(kQBlock) void k_orb_grid(OrbView v) {
   }
 }
 
+// --------------------------------------------------------------------------------------------
+// Sequential slot occupancy of SearchByProjection(Frame&, vector<MapPoint*>&) resolved on the device
+// (src/ORBmatcher.cc:84-139).  The reference walks the map points in order; a keypoint slot that already holds a map point
+// with Observations() > 0 is skipped (:88-90), and an accepted match stores its map point into the slot (:131-136).  So the
+// result of query q is the search over the candidates minus the slots claimed by accepted, blocking queries q' < q.
+// Fixed-point rounds: with `owner[s]` = lowest blocking claimant of slot s under the claims of the previous round, every
+// query is searched again with the slots { s : owner[s] < q } closed, and claims anew.  Round k makes the claims of the
+// first k queries final (query q only depends on queries before it), so the rounds reach a state that repeats, and that
+// state is the sequential result; dependency chains are short, a handful of rounds in practice.  A query whose unrestricted
+// best and second-best slots are both open keeps its unrestricted result (closing slots only removes candidates).
+// --------------------------------------------------------------------------------------------
+struct ResolveView {
+  int* claim;                    // [n_pairs*n_query] slot claimed in the last round, -1 none
+  int* owner[2];                 // [n_pairs*n_train] lowest blocking claimant, INT_MAX none (double buffered by round parity)
+  const unsigned char* pre;      // [n_pairs*n_train] slot occupied at call entry, or null
+  const unsigned char* blocks;   // [n_pairs*n_query] 1: an accepted match of this query closes its slot, or null (all do)
+  int* cur[5];                   // best_idx, best_dist, second_dist, best_level, second_level under the current occupancy
+  int* state;                    // [0] claims changed this round, [1] done, [2] rounds run
+  float nn_ratio; int th_high;
+};
+
+__global__ void k_orb_claim(OrbView v, ResolveView r, int round) {
+  if (r.state[1]) return;
+  const size_t nq_total = (size_t)v.n_pairs * v.n_query;
+  const size_t gq = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gq >= nq_total) return;
+  const int pair = (int)(gq / v.n_query), q = (int)(gq - (size_t)pair * v.n_query);
+  const int bi = round ? r.cur[0][gq] : v.best_idx[gq], bd = round ? r.cur[1][gq] : v.best_dist[gq];
+  const int sd = round ? r.cur[2][gq] : v.second_dist[gq];
+  const int bl = round ? r.cur[3][gq] : v.best_level[gq], sl = round ? r.cur[4][gq] : v.second_level[gq];
+  // src/ORBmatcher.cc:123-128: TH_HIGH, then the ratio test between two candidates of the same pyramid level (float compare)
+  const bool accept = bi >= 0 && bd <= r.th_high && !(bl == sl && (float)bd > r.nn_ratio * (float)sd);
+  const int c = accept ? bi : -1;
+  if (c != r.claim[gq]) { atomicAdd(&r.state[0], 1); r.claim[gq] = c; }
+  if (c >= 0 && (!r.blocks || r.blocks[gq])) atomicMin(&r.owner[round & 1][(size_t)pair * v.n_train + c], q);
+}
+
+__global__ void k_orb_round_end(OrbView v, ResolveView r, int round) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (size_t)v.n_pairs * v.n_train) r.owner[(round + 1) & 1][i] = INT_MAX;
+  if (i == 0 && !r.state[1]) {
+    r.state[2] = round + 1;
+    if (r.state[0] == 0) r.state[1] = 1;
+    r.state[0] = 0;
+  }
+}
+
+// One wavefront per query: the search of k_orb_bruteforce / k_orb_windowed / k_orb_grid with the closed slots removed.
+template <int MODE>  // 0 brute force, 1 candidate lists, 2 grid
+__global__ __launch_bounds__(kQBlock) void k_orb_research(OrbView v, ResolveView r, int round) {
+  if (r.state[1]) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t gq = (size_t)blockIdx.x * (kQBlock / 64) + wave;
+  const size_t nq_total = (size_t)v.n_pairs * v.n_query;
+  if (gq >= nq_total) return;
+  const int pair = (int)(gq / v.n_query), q = (int)(gq - (size_t)pair * v.n_query);
+  const size_t tb = (size_t)pair * v.n_train;
+  const int* owner = r.owner[round & 1] + tb;
+  const unsigned char* pre = r.pre ? r.pre + tb : nullptr;
+  auto closed = [&](int t) { return (pre && pre[t]) || owner[t] < q; };
+  const int b0i = v.best_idx[gq], s0i = v.second_idx[gq];
+  const bool contested = (b0i >= 0 && closed(b0i)) || (s0i >= 0 && closed(s0i));
+  if (!contested) {
+    if (lane == 0) {
+      r.cur[0][gq] = b0i; r.cur[1][gq] = v.best_dist[gq]; r.cur[2][gq] = v.second_dist[gq];
+      r.cur[3][gq] = v.best_level[gq]; r.cur[4][gq] = v.second_level[gq];
+    }
+    return;
+  }
+  const uint4 a0 = v.query[gq * 2], a1 = v.query[gq * 2 + 1];
+  const uint4* tr = v.train + tb * 2;
+  unsigned best = kKeyNone, second = kKeyNone;
+  int bi = -1, si = -1;
+  if (MODE == 0) {
+    for (int t = lane; t < v.n_train; t += 64) {
+      if (closed(t)) continue;
+      const unsigned d = hamming256(a0, a1, tr[(size_t)t * 2], tr[(size_t)t * 2 + 1]);
+      top2_insert((d << kPosBits) | (unsigned)t, best, second);
+    }
+  } else if (MODE == 1) {
+    const int* off = v.cand_off + (size_t)pair * (v.n_query + 1);
+    const int* cand = v.cand_idx + v.pair_cand_base[pair] + off[q];
+    const int nc = off[q + 1] - off[q];
+    for (int c = lane; c < nc; c += 64) {
+      const int idx = cand[c];
+      if (closed(idx)) continue;
+      const unsigned d = hamming256(a0, a1, tr[(size_t)idx * 2], tr[(size_t)idx * 2 + 1]);
+      top2_insert((d << kPosBits) | (unsigned)c, best, second);
+    }
+  } else {
+    // the candidate walk of k_orb_grid
+    const int* coff = v.cell_off + (size_t)pair * (v.cols * v.rows + 1);
+    const int* cidx = v.cell_idx + tb;
+    const float x = v.qwin[gq * 3], y = v.qwin[gq * 3 + 1], rad = v.qwin[gq * 3 + 2];
+    const int2 lev = v.qlev[gq];
+    int c0x = 0, c0y = 0, ncx = 0, ncy = 0;
+    if (rad > 0.0f) {
+      const int nMinCellX = max(0, (int)floorf((x - v.min_x - rad) * v.winv));
+      const int nMaxCellX = min(v.cols - 1, (int)ceilf((x - v.min_x + rad) * v.winv));
+      const int nMinCellY = max(0, (int)floorf((y - v.min_y - rad) * v.hinv));
+      const int nMaxCellY = min(v.rows - 1, (int)ceilf((y - v.min_y + rad) * v.hinv));
+      if (nMinCellX < v.cols && nMaxCellX >= 0 && nMinCellY < v.rows && nMaxCellY >= 0 && nMaxCellX >= nMinCellX && nMaxCellY >= nMinCellY) {
+        c0x = nMinCellX; c0y = nMinCellY; ncx = nMaxCellX - nMinCellX + 1; ncy = nMaxCellY - nMinCellY + 1;
+      }
+    }
+    const bool check_ur = v.qur != nullptr && v.train_uright != nullptr;
+    float q_ur = 0.f, q_tol = 0.f;
+    if (check_ur) { const float2 u = v.qur[gq]; q_ur = u.x; q_tol = u.y; }
+    for (int c = lane; c < ncx * ncy; c += 64) {
+      const int cx = c / ncy, cy = c - cx * ncy;
+      const int cell = (c0x + cx) * v.rows + (c0y + cy);
+      const int k0 = coff[cell], k1 = coff[cell + 1];
+      for (int k = k0; k < k1; ++k) {
+        const int idx = cidx[k];
+        if ((v.train_skip && v.train_skip[tb + idx]) || closed(idx)) continue;
+        const int oct = v.train_level ? v.train_level[tb + idx] : 0;
+        if (oct < lev.x || (lev.y >= 0 && oct > lev.y)) continue;
+        const float2 p = v.train_xy[tb + idx];
+        if (!(fabsf(p.x - x) < rad && fabsf(p.y - y) < rad)) continue;
+        if (check_ur) { const float tur = v.train_uright[tb + idx]; if (tur > 0.f && fabsf(q_ur - tur) > q_tol) continue; }
+        const unsigned d = hamming256(a0, a1, tr[(size_t)idx * 2], tr[(size_t)idx * 2 + 1]);
+        top2_insert((d << kPosBits) | ((unsigned)c << 8) | (unsigned)(k - k0), best, second);
+      }
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) top2_merge(__shfl_xor(best, m, 64), __shfl_xor(second, m, 64), best, second);
+    if (lane == 0) {
+      auto decode = [&](unsigned key) {
+        const unsigned pos = key & kPosMask;
+        const int c = (int)(pos >> 8), k = (int)(pos & 0xff);
+        const int cx = c / ncy, cy = c - cx * ncy;
+        return cidx[coff[(c0x + cx) * v.rows + (c0y + cy)] + k];
+      };
+      if (best != kKeyNone && (best >> kPosBits) < 256) {
+        bi = decode(best);
+        if (second != kKeyNone && (second >> kPosBits) < 256) si = decode(second);
+      }
+    }
+  }
+  if (MODE != 2) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) top2_merge(__shfl_xor(best, m, 64), __shfl_xor(second, m, 64), best, second);
+    if (lane == 0 && best != kKeyNone && (best >> kPosBits) < 256) {
+      const int* cand = MODE == 1 ? v.cand_idx + v.pair_cand_base[pair] + v.cand_off[(size_t)pair * (v.n_query + 1) + q] : nullptr;
+      const int pos = (int)(best & kPosMask);
+      bi = cand ? cand[pos] : pos;
+      if (second != kKeyNone && (second >> kPosBits) < 256) { const int p2 = (int)(second & kPosMask); si = cand ? cand[p2] : p2; }
+    }
+  }
+  if (lane == 0) {
+    r.cur[0][gq] = bi;
+    r.cur[1][gq] = bi >= 0 ? (int)(best >> kPosBits) : 256;
+    r.cur[2][gq] = si >= 0 ? (int)(second >> kPosBits) : 256;
+    r.cur[3][gq] = bi >= 0 ? (v.train_level ? v.train_level[tb + bi] : 0) : -1;
+    r.cur[4][gq] = si >= 0 ? (v.train_level ? v.train_level[tb + si] : 0) : -1;
+  }
+}
+
+__global__ void k_orb_assign(OrbView v, ResolveView r, int* assignment, int* n_matches) {
+  const size_t nq_total = (size_t)v.n_pairs * v.n_query;
+  const size_t gq = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gq >= nq_total) return;
+  const int c = r.claim[gq];
+  if (c < 0) return;
+  const int pair = (int)(gq / v.n_query), q = (int)(gq - (size_t)pair * v.n_query);
+  // several non-blocking claimants may store into one slot in turn (:131-136): the last writer stays
+  atomicMax(&assignment[(size_t)pair * v.n_train + c], q);
+  atomicAdd(&n_matches[pair], 1);
+}
+
 __global__ void k_orb_distance_matrix(int n, int m, const uint4* a, const uint4* b, int* out) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)n * m) return;
@@ -341,6 +511,7 @@ struct osh_orb_ctx {
   DevBuf d_query, d_train, d_level, d_off, d_idx, d_base, d_part, d_out[6], d_a, d_b, d_dm;
   DevBuf d_txy, d_tur, d_tskip, d_coff, d_cidx, d_qwin, d_qlev, d_qur;
   DevBuf d_fin, d_fout;
+  DevBuf d_claim, d_owner[2], d_pre, d_blocks, d_cur[5], d_state, d_assign, d_nmatch;   // osh_orb_match_local_points
   std::vector<float> h_fin, h_fout;
   OrbView v{};
   bool uploaded = false, matched = false, windowed = false, grid = false;
@@ -367,7 +538,9 @@ extern "C" void osh_orb_destroy(osh_orb_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DevBuf* bufs[] = {&c->d_query, &c->d_train, &c->d_level, &c->d_off, &c->d_idx, &c->d_base, &c->d_part,
                     &c->d_out[0], &c->d_out[1], &c->d_out[2], &c->d_out[3], &c->d_out[4], &c->d_out[5], &c->d_a, &c->d_b, &c->d_dm,
-                    &c->d_txy, &c->d_tur, &c->d_tskip, &c->d_coff, &c->d_cidx, &c->d_qwin, &c->d_qlev, &c->d_qur};
+                    &c->d_txy, &c->d_tur, &c->d_tskip, &c->d_coff, &c->d_cidx, &c->d_qwin, &c->d_qlev, &c->d_qur,
+                    &c->d_claim, &c->d_owner[0], &c->d_owner[1], &c->d_pre, &c->d_blocks, &c->d_cur[0], &c->d_cur[1], &c->d_cur[2], &c->d_cur[3],
+                    &c->d_cur[4], &c->d_state, &c->d_assign, &c->d_nmatch, &c->d_fin, &c->d_fout};
   for (DevBuf* b : bufs) b->release();
   c->timer.destroy();
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -523,6 +696,103 @@ extern "C" int osh_orb_match(osh_orb_ctx* c) {
   return OSH_OK;
 }
 
+static int launch_search(osh_orb_ctx* c, hipStream_t s) {
+  const OrbView& v = c->v;
+  const size_t nq = (size_t)v.n_pairs * v.n_query;
+  if (c->grid) {
+    const unsigned grid = (unsigned)((nq + (kQBlock / 64) - 1) / (kQBlock / 64));
+    hipLaunchKernelGGL(k_orb_grid, dim3(grid), dim3(kQBlock), 0, s, v);
+  } else if (c->windowed) {
+    const unsigned grid = (unsigned)((nq + (kQBlock / 64) - 1) / (kQBlock / 64));
+    hipLaunchKernelGGL(k_orb_windowed, dim3(grid), dim3(kQBlock), 0, s, v);
+  } else {
+    const int qblocks = (v.n_query + kQBlock - 1) / kQBlock;
+    hipLaunchKernelGGL(k_orb_bruteforce, dim3((unsigned)(v.n_pairs * qblocks), (unsigned)v.n_split), dim3(kQBlock), 0, s, v);
+    if (v.n_split > 1) hipLaunchKernelGGL(k_orb_merge, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, v);
+  }
+  return OSH_OK;
+}
+
+extern "C" int osh_orb_match_local_points(osh_orb_ctx* c, float nn_ratio, int32_t th_high, const uint8_t* occupied, const uint8_t* query_blocks,
+                                          int32_t* assignment, int32_t* n_matches, int32_t* query_slot, int32_t* rounds) {
+  if (!c || !c->uploaded || !assignment || !n_matches) { set_error("osh_orb_match_local_points: nothing uploaded or NULL outputs"); return OSH_ERR_INVALID; }
+  OSH_HIP(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const OrbView& v = c->v;
+  const size_t nq = (size_t)v.n_pairs * v.n_query, nt = (size_t)v.n_pairs * v.n_train;
+  if (rounds) *rounds = 0;
+  for (int p = 0; p < v.n_pairs; ++p) n_matches[p] = 0;
+  for (size_t i = 0; i < nt; ++i) assignment[i] = -1;
+  if (query_slot) for (size_t i = 0; i < nq; ++i) query_slot[i] = -1;
+  if (nq == 0 || nt == 0) { c->matched = true; return OSH_OK; }
+  OSH_TRY(c->d_claim.reserve(nq * 4));
+  for (int k = 0; k < 2; ++k) OSH_TRY(c->d_owner[k].reserve(nt * 4));
+  for (int k = 0; k < 5; ++k) OSH_TRY(c->d_cur[k].reserve(nq * 4));
+  OSH_TRY(c->d_state.reserve(16)); OSH_TRY(c->d_assign.reserve(nt * 4)); OSH_TRY(c->d_nmatch.reserve((size_t)v.n_pairs * 4));
+  ResolveView r{};
+  r.claim = c->d_claim.as<int>();
+  r.owner[0] = c->d_owner[0].as<int>(); r.owner[1] = c->d_owner[1].as<int>();
+  for (int k = 0; k < 5; ++k) r.cur[k] = c->d_cur[k].as<int>();
+  r.state = c->d_state.as<int>();
+  r.nn_ratio = nn_ratio; r.th_high = th_high;
+  if (occupied) {
+    OSH_TRY(c->d_pre.reserve(nt));
+    OSH_HIP(hipMemcpyAsync(c->d_pre.p, occupied, nt, hipMemcpyHostToDevice, s));
+    r.pre = c->d_pre.as<unsigned char>();
+  }
+  if (query_blocks) {
+    OSH_TRY(c->d_blocks.reserve(nq));
+    OSH_HIP(hipMemcpyAsync(c->d_blocks.p, query_blocks, nq, hipMemcpyHostToDevice, s));
+    r.blocks = c->d_blocks.as<unsigned char>();
+  }
+  if (c->timer.enabled) OSH_TRY(c->timer.init());
+  const bool t = c->timer.begin(0, s);
+  OSH_TRY(launch_search(c, s));
+  if (t) c->timer.end(s);
+  const bool t1 = c->timer.begin(1, s);
+  OSH_HIP(hipMemsetAsync(c->d_claim.p, 0xFE, nq * 4, s));            // no claim equals this value: round 0 always counts as a change
+  OSH_HIP(hipMemsetAsync(c->d_owner[0].p, 0x7F, nt * 4, s));         // 0x7f7f7f7f: above every query index
+  OSH_HIP(hipMemsetAsync(c->d_owner[1].p, 0x7F, nt * 4, s));
+  OSH_HIP(hipMemsetAsync(c->d_state.p, 0, 16, s));
+  OSH_HIP(hipMemsetAsync(c->d_assign.p, 0xFF, nt * 4, s));
+  OSH_HIP(hipMemsetAsync(c->d_nmatch.p, 0, (size_t)v.n_pairs * 4, s));
+  const unsigned gq256 = (unsigned)((nq + 255) / 256), gt256 = (unsigned)((nt + 255) / 256);
+  const unsigned gwave = (unsigned)((nq + (kQBlock / 64) - 1) / (kQBlock / 64));
+  int state[3] = {0, 0, 0};
+  int round = 0;
+  // a pre-occupied slot closes candidates for every query from the start: round 0 searches again where the unrestricted result touches one
+  if (r.pre) {
+    if (c->grid) hipLaunchKernelGGL(k_orb_research<2>, dim3(gwave), dim3(kQBlock), 0, s, v, r, 1);   // owner[1]: all open
+    else if (c->windowed) hipLaunchKernelGGL(k_orb_research<1>, dim3(gwave), dim3(kQBlock), 0, s, v, r, 1);
+    else hipLaunchKernelGGL(k_orb_research<0>, dim3(gwave), dim3(kQBlock), 0, s, v, r, 1);
+  }
+  const int max_rounds = v.n_query + 2;
+  while (!state[1]) {
+    if (round >= max_rounds) { set_error("osh_orb_match_local_points: occupancy rounds did not settle"); return OSH_ERR_DEVICE; }
+    for (int k = 0; k < 4; ++k, ++round) {
+      hipLaunchKernelGGL(k_orb_claim, dim3(gq256), dim3(256), 0, s, v, r, (round == 0 && !r.pre) ? 0 : round + 2);
+      hipLaunchKernelGGL(k_orb_round_end, dim3(gt256), dim3(256), 0, s, v, r, round);
+      if (c->grid) hipLaunchKernelGGL(k_orb_research<2>, dim3(gwave), dim3(kQBlock), 0, s, v, r, round);
+      else if (c->windowed) hipLaunchKernelGGL(k_orb_research<1>, dim3(gwave), dim3(kQBlock), 0, s, v, r, round);
+      else hipLaunchKernelGGL(k_orb_research<0>, dim3(gwave), dim3(kQBlock), 0, s, v, r, round);
+    }
+    OSH_HIP(hipMemcpyAsync(state, c->d_state.p, 12, hipMemcpyDeviceToHost, s));
+    OSH_HIP(hipStreamSynchronize(s));
+  }
+  hipLaunchKernelGGL(k_orb_assign, dim3(gq256), dim3(256), 0, s, v, r, c->d_assign.as<int>(), c->d_nmatch.as<int>());
+  if (t1) c->timer.end(s);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("orb kernel launch failed: %s", hipGetErrorString(e)); return OSH_ERR_DEVICE; }
+  OSH_HIP(hipMemcpyAsync(assignment, c->d_assign.p, nt * 4, hipMemcpyDeviceToHost, s));
+  OSH_HIP(hipMemcpyAsync(n_matches, c->d_nmatch.p, (size_t)v.n_pairs * 4, hipMemcpyDeviceToHost, s));
+  if (query_slot) OSH_HIP(hipMemcpyAsync(query_slot, c->d_claim.p, nq * 4, hipMemcpyDeviceToHost, s));
+  OSH_HIP(hipStreamSynchronize(s));
+  if (c->timer.enabled) c->timer.collect();
+  if (rounds) *rounds = state[2];
+  c->matched = true;
+  return OSH_OK;
+}
+
 extern "C" int osh_orb_download(osh_orb_ctx* c, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist,
                                 int32_t* best_level, int32_t* second_level, int32_t* second_idx) {
   if (!c || !c->matched) { set_error("osh_orb_download: call osh_orb_match first"); return OSH_ERR_INVALID; }
@@ -548,6 +818,13 @@ extern "C" int osh_orb_get_profile(osh_orb_ctx* c, int64_t* launches, double* to
   if (!c || !launches || !total_ms) return OSH_ERR_INVALID;
   *launches = c->timer.launches[0];
   *total_ms = c->timer.total_ms[0];
+  return OSH_OK;
+}
+
+extern "C" int osh_orb_get_resolve_profile(osh_orb_ctx* c, int64_t* launches, double* total_ms) {
+  if (!c || !launches || !total_ms) return OSH_ERR_INVALID;
+  *launches = c->timer.launches[1];
+  *total_ms = c->timer.total_ms[1];
   return OSH_OK;
 }
 

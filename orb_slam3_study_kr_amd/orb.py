@@ -51,6 +51,7 @@ class OrbMatcher:
             keep += [off, idx, base]
         self._keep = keep
         self._shape = (n_pairs, nq)
+        self._n_train = nt
         capi.check(self.lib.osh_orb_upload(self.ctx, C.byref(b)), "osh_orb_upload", self.lib)
 
     def upload_grid(self, query_desc, train_desc, train_level, train_xy, query_window, query_levels, train_uright=None,
@@ -80,6 +81,7 @@ class OrbMatcher:
         g.cols, g.rows = synth.FRAME_GRID_COLS, synth.FRAME_GRID_ROWS
         self._keep = keep
         self._shape = (1, q.shape[0])
+        self._n_train = t.shape[0]
         capi.check(self.lib.osh_orb_upload_grid(self.ctx, C.byref(b), C.byref(g)), "osh_orb_upload_grid", self.lib)
 
     def frustum(self, frame: "capi.FrustumFrame", pos, normal, min_dist, max_dist) -> dict:
@@ -90,6 +92,23 @@ class OrbMatcher:
 
     def match(self):
         capi.check(self.lib.osh_orb_match(self.ctx), "osh_orb_match", self.lib)
+
+    def match_local_points(self, nn_ratio: float = 0.8, th_high: int = 100, occupied=None, query_blocks=None, n_train: int | None = None):
+        """SearchByProjection(Frame&, vector<MapPoint*>&) with the sequential slot occupancy resolved on the device
+        (osh_orb_match_local_points): (n_matches[n_pairs], assignment[n_pairs, n_train], query_slot[n_pairs, n_query], rounds)."""
+        n_pairs, n_query = self._shape
+        n_train = int(n_train if n_train is not None else self._n_train)
+        occ = None if occupied is None else np.ascontiguousarray(occupied, dtype=np.uint8).reshape(n_pairs, n_train)
+        blk = None if query_blocks is None else np.ascontiguousarray(query_blocks, dtype=np.uint8).reshape(n_pairs, n_query)
+        assign = np.zeros((n_pairs, n_train), dtype=np.int32)
+        n = np.zeros(n_pairs, dtype=np.int32)
+        slot = np.zeros((n_pairs, n_query), dtype=np.int32)
+        rounds = C.c_int32(0)
+        capi.check(self.lib.osh_orb_match_local_points(self.ctx, float(nn_ratio), int(th_high), capi.ptr(occ, capi.c_uint8_p),
+                                                       capi.ptr(blk, capi.c_uint8_p), capi.ptr(assign, capi.c_int32_p),
+                                                       capi.ptr(n, capi.c_int32_p), capi.ptr(slot, capi.c_int32_p), C.byref(rounds)),
+                   "osh_orb_match_local_points", self.lib)
+        return n, assign, slot, int(rounds.value)
 
     def download(self) -> dict:
         names = ["best_idx", "best_dist", "second_dist", "best_level", "second_level", "second_idx"]
@@ -117,6 +136,12 @@ class OrbMatcher:
     def profile(self):
         n, ms = C.c_int64(0), C.c_double(0)
         capi.check(self.lib.osh_orb_get_profile(self.ctx, C.byref(n), C.byref(ms)), "osh_orb_get_profile", self.lib)
+        return int(n.value), float(ms.value)
+
+
+    def resolve_profile(self):
+        n, ms = C.c_int64(0), C.c_double(0)
+        capi.check(self.lib.osh_orb_get_resolve_profile(self.ctx, C.byref(n), C.byref(ms)), "osh_orb_get_resolve_profile", self.lib)
         return int(n.value), float(ms.value)
 
 

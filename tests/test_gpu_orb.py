@@ -48,6 +48,57 @@ def test_config3_bruteforce_2000x2000_bit_exact(matcher, ob):
     assert 0 < rescans < 2000   # brute force: ~half the queries see a claimed best/second slot (919 measured)
 
 
+def test_sequential_occupancy_resolved_on_device_bruteforce(matcher, ob):
+    """osh_orb_match_local_points == the sequential loop of src/ORBmatcher.cc:43-141 (oracle_orb_match_local_points), brute force:
+    no host replay, the claims settle in fixed-point rounds on the device.  Batched pairs resolve independently."""
+    pairs = [synth.make_orb_pair(7 + i, 2000, 2000, same_level=False) for i in range(3)]
+    matcher.upload(pairs)
+    n, assign, slot, rounds = matcher.match_local_points()
+    assert 1 < rounds < 64
+    for i, p in enumerate(pairs):
+        n_ref, assign_ref, _ = ob.orb_match_local_points(p.query_desc, p.train_desc, p.train_level)
+        assert n[i] == n_ref and n_ref > 500
+        np.testing.assert_array_equal(assign[i], assign_ref)
+        ok = slot[i] >= 0
+        assert np.array_equal(assign[i][slot[i][ok]], np.nonzero(ok)[0])
+
+
+def test_sequential_occupancy_pre_occupied_slots_and_non_blocking_points(matcher, ob):
+    """Slots occupied at call entry are never candidates (:88-90); a match of a map point without observations does not close
+    its slot, a later point may overwrite it (:131-136).  Checked against a plain restatement of the loop over the oracle's scan."""
+    rng = np.random.Generator(np.random.PCG64(3))
+    p = synth.make_orb_pair(31, 600, 500, same_level=False)
+    occupied = (rng.uniform(size=500) < 0.2).astype(np.uint8)
+    blocks = (rng.uniform(size=600) < 0.7).astype(np.uint8)
+    matcher.upload([p])
+    n, assign, slot, rounds = matcher.match_local_points(occupied=occupied, query_blocks=blocks)
+    occ = occupied.copy()
+    exp = -np.ones(500, dtype=np.int32)
+    n_ref = 0
+    for q in range(600):
+        r = ob.orb_search(p.query_desc[q:q + 1], p.train_desc, p.train_level, occupied=occ)
+        b, d1, d2, l1, l2 = (int(r[k][0]) for k in KEYS[:5])
+        if b < 0 or d1 > 100 or (l1 == l2 and np.float32(d1) > np.float32(0.8) * np.float32(d2)):
+            continue
+        exp[b] = q
+        n_ref += 1
+        if blocks[q]:
+            occ[b] = 1
+    assert n[0] == n_ref and n_ref > 100
+    np.testing.assert_array_equal(assign[0], exp)
+    assert not np.any(assign[0][occupied == 1] >= 0)
+
+
+def test_sequential_occupancy_candidate_lists(matcher, ob):
+    pairs = [synth.make_orb_pair(50 + i, 400, 600, windowed=True, same_level=False) for i in range(3)]
+    matcher.upload(pairs, windowed=True)
+    n, assign, _, rounds = matcher.match_local_points()
+    for i, p in enumerate(pairs):
+        n_ref, assign_ref, _ = ob.orb_match_local_points(p.query_desc, p.train_desc, p.train_level, p.cand_off, p.cand_idx)
+        assert n[i] == n_ref
+        np.testing.assert_array_equal(assign[i], assign_ref)
+
+
 def test_batched_pairs_and_odd_sizes(matcher, ob):
     pairs = [synth.make_orb_pair(20 + i, 333, 777, same_level=False) for i in range(5)]
     got = matcher.search(pairs)
@@ -129,6 +180,7 @@ def test_device_candidate_generation_equals_host_built_lists(hip_lib):
                       train_skip=skip, query_uright=qur)
         m.match()
         got = m.download()
+        n_dev, assign_dev, _, _ = m.match_local_points(nn_ratio=0.9)
     # host-built lists in the reference's order with the same static filters
     off, idx = synth.features_in_area_lists(xy[:, 0], xy[:, 1], level, qx, qy, r, lo, hi)
     keep_off, keep_idx = [0], []
@@ -144,6 +196,11 @@ def test_device_candidate_generation_equals_host_built_lists(hip_lib):
     for name in ("best_idx", "best_dist", "second_dist", "best_level", "second_level"):
         np.testing.assert_array_equal(got[name][0], ref[name], err_msg=name)
     assert (got["best_idx"][0] >= 0).sum() > 300 and (r == 0).any()
+    # the sequential occupancy on top of the device-generated candidates (descriptor ties everywhere: the earliest candidate wins)
+    n_ref, assign_ref, _ = ob.orb_match_local_points(qdesc, tdesc, level, np.asarray(keep_off, dtype=np.int32), np.asarray(keep_idx, dtype=np.int32),
+                                                     nn_ratio=0.9)
+    assert n_dev[0] == n_ref and n_ref > 100
+    np.testing.assert_array_equal(assign_dev[0], assign_ref)
 
 
 def _frustum_scene(seed, n, kb8=None):
