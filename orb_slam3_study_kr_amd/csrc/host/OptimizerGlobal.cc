@@ -3,7 +3,8 @@
 // Same vertices, edge types and BlockSolver_6_3 as the local bundle adjustment; only the graph
 // selection differs: every keyframe and map point handed in, the map's initial keyframe fixed, optional Huber kernel,
 // ONE optimizer.optimize(nIterations) and no outlier pass (src/Optimizer.cc:61-392).  The device path is the one of
-// Optimizer.cc; the reduced camera system of a window must fit the LDS-resident factorisation (about 230 keyframes).
+// Optimizer.cc; a map of more than ~240 keyframes has its reduced camera system factored in global memory (csrc/big_solve.h,
+// up to 4000 keyframes: the system is held dense).
 #include <algorithm>
 #include <cmath>
 #include <cstdio>

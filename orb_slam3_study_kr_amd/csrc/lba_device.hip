@@ -34,6 +34,7 @@
 #include <thread>
 #include "lba_math.h"
 #include "ldlt_block.h"
+#include "big_solve.h"
 #include "schur_plan.h"
 #include "lba_pack.h"
 #include <algorithm>
@@ -779,34 +780,18 @@ __global__ __launch_bounds__(64) void k_pose_reduce(BatchView bv, int mode) {
   }
 }
 
-// --------------------------------------------------------------------------------------------
-// k_solve: dense blocked LDL^T (no pivoting, upper storage) of the reduced camera system of
-// one window per block, forward elimination fused (rhs carried as an extra column), blocked
-// back-substitution, then the pose update T <- exp(x) T and the pose part of computeScale.
-// LDS: U panel [nb][W] (unscaled rows), L panel [nb][W] (rows / pivot), x [n], d [nb].
-// --------------------------------------------------------------------------------------------
-template <int NB, int NT>
-__global__ __launch_bounds__(NT) void k_solve(BatchView bv, int W) {
-  constexpr int kSolveThreads = NT;
-  extern __shared__ __attribute__((aligned(16))) double sh[];   // all LDS scratch is dynamic (16-B aligned base)
-  const int w = blockIdx.x;
-  const WinDesc& wd = bv.win[w];
-  LmState& st = bv.lm[w];
-  if (!st.active) return;
-  const int n = wd.n;
-  const int tid = threadIdx.x;
-  double* A = bv.S + wd.S_off;
-  double* rhs = bv.bs + (size_t)wd.fpose_off * 6;
-  double *xs, *shw;
-  const bool ok = ldlt_solve_block<NB, kSolveThreads>(A, rhs, n, W, sh, xs, shw);
+// Tail of the reduced-system solve of one window: x_p out, pose update T <- exp(x) T into the trial buffer and the pose part of
+// computeScale.  `xs`: the solution (n doubles, LDS or global), `shw`: NT/64 doubles of LDS scratch.
+template <int NT>
+__device__ void solve_tail(BatchView& bv, const WinDesc& wd, LmState& st, const double* xs, double* shw, bool ok) {
+  const int tid = threadIdx.x, n = wd.n;
   double* xp = bv.xp + (size_t)wd.fpose_off * 6;
-  for (int k = tid; k < n; k += kSolveThreads) xp[k] = xs[k];   // zeros when the factorisation failed
+  for (int k = tid; k < n; k += NT) xp[k] = xs[k];   // zeros when the factorisation failed
   __syncthreads();
-  // pose update into the trial buffer + pose part of computeScale
   const int cur = st.sel, tr_sel = st.sel ^ 1;
   const double lambda = st.lambda;
   double sc = 0.0;
-  for (int i = tid; i < wd.P; i += kSolveThreads) {
+  for (int i = tid; i < wd.P; i += NT) {
     double u[6], qin[7], qout[7];
 #pragma unroll
     for (int k = 0; k < 6; ++k) u[k] = xs[6 * i + k];
@@ -824,9 +809,47 @@ __global__ __launch_bounds__(NT) void k_solve(BatchView bv, int W) {
   __syncthreads();
   if (tid == 0) {
     double tot = 0.0;
-    for (int k = 0; k < kSolveThreads / 64; ++k) tot += shw[k];
+    for (int k = 0; k < NT / 64; ++k) tot += shw[k];
     st.scale_pose = tot; st.solve_ok = ok ? 1 : 0;
   }
+}
+
+// --------------------------------------------------------------------------------------------
+// k_solve: dense blocked LDL^T (no pivoting, upper storage) of the reduced camera system of
+// one window per block, forward elimination fused (rhs carried as an extra column), blocked
+// back-substitution, then the pose update T <- exp(x) T and the pose part of computeScale.
+// LDS: U panel [nb][W] (unscaled rows), L panel [nb][W] (rows / pivot), x [n], d [nb].
+// --------------------------------------------------------------------------------------------
+template <int NB, int NT>
+__global__ __launch_bounds__(NT) void k_solve(BatchView bv, int W) {
+  constexpr int kSolveThreads = NT;
+  extern __shared__ __attribute__((aligned(16))) double sh[];   // all LDS scratch is dynamic (16-B aligned base)
+  const int w = blockIdx.x;
+  const WinDesc& wd = bv.win[w];
+  LmState& st = bv.lm[w];
+  if (!st.active) return;
+  const int n = wd.n;
+  double* A = bv.S + wd.S_off;
+  double* rhs = bv.bs + (size_t)wd.fpose_off * 6;
+  double *xs, *shw;
+  const bool ok = ldlt_solve_block<NB, kSolveThreads>(A, rhs, n, W, sh, xs, shw);
+  solve_tail<kSolveThreads>(bv, wd, st, xs, shw, ok);
+}
+
+// One reduced system too large for the LDS-resident factorisation (global BA of a long session): big_solve.h has factored and
+// solved it in global memory, the solution sits in the window's `bs`; this is the tail of k_solve for that window.
+__global__ __launch_bounds__(256) void k_big_finish(BatchView bv, int w, const int* fail) {
+  __shared__ double shw[8];
+  const WinDesc& wd = bv.win[w];
+  LmState& st = bv.lm[w];
+  if (!st.active) return;
+  double* x = bv.bs + (size_t)wd.fpose_off * 6;
+  const bool ok = *fail == 0;
+  if (!ok) {
+    for (int k = threadIdx.x; k < wd.n; k += 256) x[k] = 0.0;    // zeros when the factorisation failed
+    __syncthreads();
+  }
+  solve_tail<256>(bv, wd, st, x, shw, ok);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1220,6 +1243,8 @@ struct osh_lba_ctx {
   std::vector<const volatile unsigned char*> stop_ptr;
   bool any_stop = false;
   int solve_nb = 24, solve_W = 0, solve_threads = kSolveThreadsLatency;
+  bool solve_big = false;            // a window's reduced system exceeds the LDS-resident factorisation: big_solve.h
+  DevBuf d_bigV, d_bigz, d_bigfail;
   size_t solve_lds = 0, backsub_lds = 0, lin_lds = 0, resid_lds = 0;
   double upload_pack_ms = 0, upload_copy_ms = 0;
   // edge kernels of the batch's camera models: the KannalaBrandt8 instantiations only when a window asks for them
@@ -1320,13 +1345,19 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
     auto need = [&](int b) { return ldlt_lds_doubles(b, ldlt_row_stride(pb.n_max), c->solve_threads) * sizeof(double); };
     int nb = 24;
     while (nb > 6 && need(nb) > (size_t)150 * 1024) nb /= 2;  // 24 -> 12 -> 6 (template instantiations of k_solve)
-    if (need(nb) > (size_t)150 * 1024) {
-      set_error("window with %d optimisable poses exceeds the LDS budget of the reduced-system kernels", pb.n_max / 6);
-      return OSH_ERR_UNSUPPORTED;
+    c->solve_big = need(nb) > (size_t)150 * 1024;
+    if (c->solve_big) {
+      // beyond ~240 optimisable poses (global BA of a long session) the system is factored in global memory, one window at a time
+      if (pb.n_max / 6 > kBigMaxPoses) {
+        set_error("window with %d optimisable poses: the dense reduced system is limited to %d poses", pb.n_max / 6, kBigMaxPoses);
+        return OSH_ERR_UNSUPPORTED;
+      }
+      OSH_TRY(c->d_bigV.reserve((size_t)kBigNB * pb.n_max * 8)); OSH_TRY(c->d_bigz.reserve((size_t)pb.n_max * 8)); OSH_TRY(c->d_bigfail.reserve(sizeof(int)));
+      nb = 6;
     }
     c->solve_nb = nb;
     c->solve_W = ldlt_row_stride(pb.n_max);
-    c->solve_lds = need(nb);
+    c->solve_lds = c->solve_big ? 0 : need(nb);
   }
 
   // ---- work buffers
@@ -1446,6 +1477,29 @@ static bool snapshot_stop(osh_lba_ctx* c) {
 
 // the instantiation of k_solve chosen at upload time (panel width x threads per block)
 static int launch_solve(osh_lba_ctx* c, hipStream_t s) {
+  if (c->solve_big) {
+    for (int w = 0; w < c->n_windows; ++w) {
+      const WinDesc& d = c->pb.win[w];
+      if (d.n == 0) continue;
+      BigSolve g;
+      g.A = c->d_S.as<double>() + d.S_off; g.b = c->d_bs.as<double>() + (size_t)d.fpose_off * 6;
+      g.V = c->d_bigV.as<double>(); g.z = c->d_bigz.as<double>(); g.fail = c->d_bigfail.as<int>();
+      g.active = &(c->d_lm.as<LmState>() + w)->active;
+      g.n = d.n;
+      OSH_HIP(hipMemsetAsync(g.fail, 0, sizeof(int), s));
+      for (int k0 = 0; k0 < d.n; k0 += kBigNB) {
+        hipLaunchKernelGGL(k_big_diag, dim3(1), dim3(64), 0, s, g, k0);
+        const int tr = d.n - (k0 + kBigNB);   // trailing rows
+        if (tr <= 0) break;
+        hipLaunchKernelGGL(k_big_panel, dim3((unsigned)((tr + 255) / 256)), dim3(256), 0, s, g, k0);
+        const unsigned T = (unsigned)((tr + kBigTile - 1) / kBigTile);
+        hipLaunchKernelGGL(k_big_update, dim3(T, T), dim3(256), 0, s, g, k0);
+      }
+      hipLaunchKernelGGL(k_big_back, dim3(1), dim3(1024), 0, s, g);
+      hipLaunchKernelGGL(k_big_finish, dim3(1), dim3(256), 0, s, c->bv, w, g.fail);
+    }
+    return launch_check("k_big_solve");
+  }
   const dim3 grid((unsigned)c->n_windows);
 #define OSH_SOLVE_CASE(NB, NT) \
   if (c->solve_nb == NB && c->solve_threads == NT) hipLaunchKernelGGL((k_solve<NB, NT>), grid, dim3(NT), c->solve_lds, s, c->bv, c->solve_W);

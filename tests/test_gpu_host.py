@@ -137,6 +137,24 @@ def test_global_bundle_adjustment_for_a_loop_keeps_results_beside_the_live_map(o
         assert g.lib.osh_host_map_change_index(g.g) == 0
 
 
+def test_global_bundle_adjustment_of_a_map_of_320_keyframes(ob):
+    """A EuRoC-sized session: 320 keyframes, one of them (the origin) fixed -- beyond the LDS-resident factorisation, the reduced
+    system (n = 1914) goes through csrc/big_solve.h.  Results against the oracle's dense solve of the same packed window."""
+    w = synth.make_window(46, n_free=319, n_fixed=1, n_points=5000, stereo=True)
+    with host.HostGraph(w, init_kf_id_index=w.n_free) as g:
+        pw, o, ref = _gba_reference(g, ob, 5, True)
+        assert pw.n_free == 319 and pw.n_fixed == 1
+        g.run_gba(5, n_loop_kf=91, robust=True)
+        kf_index = {int(i): k for k, i in enumerate(g.kf_id)}
+        marks, poses = zip(*[g.kf_pose_gba(kf_index[int(i)]) for i in o["pose_kf_id"][:pw.n_free]])
+        assert set(marks) == {91}
+        got_qt = np.stack(poses).astype(np.float64)
+        assert rel_translation_error(got_qt, ref.pose_qt) < 1e-5 and rotation_error(got_qt, ref.pose_qt) < 1e-5
+        mp_index = {int(i): k for k, i in enumerate(g.mp_id)}
+        marks, pts = zip(*[g.mp_pos_gba(mp_index[int(i)]) for i in o["point_mp_id"]])
+        np.testing.assert_allclose(np.stack(pts).astype(np.float64), ref.points, rtol=2e-5, atol=2e-5)
+
+
 def test_global_bundle_adjustment_fisheye_stereo_rig(ob):
     """BundleAdjustment over a fisheye stereo rig map: right-camera edges created at src/Optimizer.cc:229-262 (EdgeSE3ProjectXYZToBody)."""
     w = synth.make_rig_window(85, n_free=6, n_fixed=1, n_points=300, track_len=(2, 6), right_frac=0.3, right_only_frac=0.6)

@@ -110,6 +110,17 @@ def test_config2_stereo_window_full_size(solver, ob):
     _check_result(got, ob.lba_solve(w), w)
 
 
+def test_window_beyond_the_lds_factorisation_uses_the_global_memory_solver(solver, ob):
+    """A reduced system of 300 optimisable keyframes (n = 1800) does not fit the LDS-resident LDL^T of k_solve: it is factored in
+    global memory by big_solve.h (global BA of a long session, src/Optimizer.cc:53-392).  Same LM trace as the oracle's dense solve;
+    a small window in the same batch takes the same path."""
+    big = synth.make_window(900, n_free=300, n_fixed=3, n_points=6000, stereo=True, max_iterations=5)
+    small = synth.make_window(901, n_free=6, n_fixed=2, n_points=300, stereo=True)
+    got = solver.solve([big, small])
+    _check_result(got[0], ob.lba_solve(big), big, t_tol=1e-5, chi_tol=1e-6, pts_tol=1e-5)
+    _check_result(got[1], ob.lba_solve(small), small)
+
+
 def test_batch_of_heterogeneous_windows_equals_single_solves(solver, ob):
     ws = [synth.make_window(200 + i, n_free=4 + 3 * i, n_fixed=1 + i, n_points=150 + 90 * i, stereo=bool(i % 2),
                             mixed_mono_frac=0.3 if i == 3 else 0.0, lambda_init=[0.0, 100.0, 0.0, 1e-3][i],
