@@ -49,6 +49,7 @@ int osh_device_count(void);
 /* Edge kinds (the three visual edge types of src/Optimizer.cc:1302-1400). */
 #define OSH_EDGE_MONO    0   /* ORB_SLAM3::EdgeSE3ProjectXYZ      include/OptimizableTypes.h:88-115      */
 #define OSH_EDGE_STEREO  1   /* g2o::EdgeStereoSE3ProjectXYZ      types_six_dof_expmap.h:146-175         */
+#define OSH_EDGE_RIGHT 2   /* LocalInertialBA: EdgeMono(1), the right camera of a fisheye rig (same value as OSH_EDGE_BODY) */
 #define OSH_EDGE_BODY    2   /* ORB_SLAM3::EdgeSE3ProjectXYZToBody include/OptimizableTypes.h:117-144, src/OptimizableTypes.cpp:192-213: */
                              /* the right-camera observation of a fisheye stereo rig, through Trl and the second camera;        */
                              /* it may share its (keyframe, landmark) pair with an OSH_EDGE_MONO edge (src/Optimizer.cc:1365-1399) */
@@ -276,6 +277,11 @@ typedef struct osh_liba_problem {
   double lambda_init;       /* 1e0, or 1e-2 when bLarge (:2517-2528)                                          */
   int32_t max_iterations;   /* opt_it: 10, or 4 when bLarge                                                   */
   const double* kb8;        /* NULL: pinhole.  [4] k1..k4: the window's camera is a KannalaBrandt8, mono edges only (as osh_lba_problem.kb8) */
+  /* Fisheye stereo rig (KeyFrame::mpCamera2 != NULL, src/Optimizer.cc:2798-2835): edges of kind OSH_EDGE_RIGHT are EdgeMono(1),
+   * the observation of the RIGHT camera (ImuCamPose camera 1: Rcw[1] = Rrl Rcw[0], tcb[1] = Rrl tcb[0] + trl, src/G2oTypes.cc:56-66).
+   * A (keyframe, landmark) pair may carry one OSH_EDGE_MONO and one OSH_EDGE_RIGHT edge.  Needs kb8; both NULL otherwise. */
+  const double* cam2;       /* [8] right camera fx fy cx cy k1 k2 k3 k4 */
+  const double* trl;        /* [12] rows of the 3x4 matrix [Rrl | trl] = KeyFrame::GetRelativePoseTrl().matrix().cast<double>() (float32 values) */
 } osh_liba_problem;
 
 typedef struct osh_liba_result {

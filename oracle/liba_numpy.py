@@ -109,11 +109,35 @@ def inertial_residual(st, l):
     return np.concatenate([er, ev, ep])
 
 
-def visual_residual(st, e):
+def _kb8_project(cam, kb, Xc, smooth):
+    """KannalaBrandt8::project(Vector3d) (src/CameraModels/KannalaBrandt8.cpp:46-65): theta and psi are float32 values there
+    (atan2f / sqrtf); ``smooth`` keeps them in double so that central differences see a differentiable function."""
+    fx, fy, cx, cy = cam[:4]
+    if smooth:
+        theta = np.arctan2(np.hypot(Xc[0], Xc[1]), Xc[2])
+        psi = np.arctan2(Xc[1], Xc[0])
+    else:
+        rho = np.float32(np.sqrt(np.float32(Xc[0] * Xc[0] + Xc[1] * Xc[1])))
+        theta = float(np.float32(np.arctan2(float(rho), float(np.float32(Xc[2])))))
+        psi = float(np.float32(np.arctan2(float(np.float32(Xc[1])), float(np.float32(Xc[0])))))
+    r = theta + kb[0] * theta**3 + kb[1] * theta**5 + kb[2] * theta**7 + kb[3] * theta**9
+    return fx * r * np.cos(psi) + cx, fy * r * np.sin(psi) + cy
+
+
+def visual_residual(st, e, smooth=False):
     w = st.w
     k, l = int(w.edge_pose[e]), int(w.edge_point[e])
     fx, fy, cx, cy, bf = w.cam
+    if w.edge_kind[e] == 2:
+        # EdgeMono(1), the right camera of a fisheye rig: Tc1w = Trl Tc0w (ImuCamPose camera 1, src/G2oTypes.cc:56-66,212-218)
+        T = np.asarray(w.trl).reshape(3, 4)
+        Xc = T[:, :3] @ (st.Rcw[k] @ st.X[l] + st.tcw[k]) + T[:, 3]
+        u, v = _kb8_project(w.cam2[:4], w.cam2[4:], Xc, smooth)
+        return np.array([w.edge_obs[e, 0] - u, w.edge_obs[e, 1] - v])
     Xc = st.Rcw[k] @ st.X[l] + st.tcw[k]
+    if getattr(w, "kb8", None) is not None:
+        u, v = _kb8_project(w.cam[:4], w.kb8, Xc, smooth)
+        return np.array([w.edge_obs[e, 0] - u, w.edge_obs[e, 1] - v])
     u, v = fx * Xc[0] / Xc[2] + cx, fy * Xc[1] / Xc[2] + cy
     if w.edge_kind[e] == 0:
         return np.array([w.edge_obs[e, 0] - u, w.edge_obs[e, 1] - v])
@@ -128,7 +152,7 @@ def huber(c, delta):
     return 2 * s * delta - d2, delta / s
 
 
-def all_residual_blocks(st):
+def all_residual_blocks(st, smooth=False):
     """[(residual, information, huber delta or None)] in g2o edge order: inertial links first, then visual."""
     w = st.w
     out = []
@@ -138,8 +162,8 @@ def all_residual_blocks(st):
         out.append((st.bg[c] - st.bg[a], w.link_info_g[l].reshape(3, 3), None))
         out.append((st.ba[c] - st.ba[a], w.link_info_a[l].reshape(3, 3), None))
     for e in range(w.n_edges):
-        r = visual_residual(st, e)
-        out.append((r, np.eye(len(r)) * w.edge_info[e], w.huber_mono if w.edge_kind[e] == 0 else w.huber_stereo))
+        r = visual_residual(st, e, smooth)
+        out.append((r, np.eye(len(r)) * w.edge_info[e], w.huber_stereo if w.edge_kind[e] == 1 else w.huber_mono))
     return out
 
 
@@ -166,7 +190,7 @@ def numeric_dense_system(st, delta_pose=1e-6, delta_bias=2e-3):
         e = np.zeros(nall); e[j] = d
         sp, sm = st.copy(), st.copy()
         sp.oplus(e); sm.oplus(-e)
-        bp, bm = all_residual_blocks(sp), all_residual_blocks(sm)
+        bp, bm = all_residual_blocks(sp, smooth=True), all_residual_blocks(sm, smooth=True)
         for i in range(len(blocks0)):
             J[i][:, j] = (bp[i][0] - bm[i][0]) / (2 * d)
     for (r, Om, delta), Ji in zip(blocks0, J):

@@ -191,6 +191,11 @@ typedef struct {
   double *H, *b;                    /* n*n dense (symmetric), n + 3L */
   double *Hll, *Hpl;                /* L*9, E*18 (per visual edge with optimisable pose) */
   int *col_off, *blk_edge;          /* CCS of Hpl by landmark: edges sorted by pose */
+  int *slot;                        /* E: the edge whose Hpl block this edge adds to (itself; a right-camera edge sharing its
+                                       (keyframe, landmark) pair with a left edge: that left edge -- ONE Hessian block) */
+  int rig;                          /* fisheye stereo rig: camera 1 of ImuCamPose (src/G2oTypes.cc:56-66) */
+  double *Rcw1, *tcw1;              /* K: Rcw[1], tcw[1] */
+  double Rrl[9], trl[3], Rcb1[9], tcb1[3], tbc1[3];
   double *S, *bs, *coeff, *x, *Dinv, *tmp;
 } istate;
 
@@ -205,6 +210,11 @@ static void cam_from_body(istate* s, int k) { /* ImuCamPose::Update tail, :212-2
   m3_mul(p->Rcb, Rbw, s->Rcw + 9 * k);
   m3_vec(p->Rcb, tbw, t);
   for (int i = 0; i < 3; ++i) s->tcw[3 * k + i] = t[i] + p->tcb[i];
+  if (s->rig) {   /* the loop over pCamera.size() (:214-218): Rcw[1] = Rcb[1] Rbw, tcw[1] = Rcb[1] tbw + tcb[1] */
+    m3_mul(s->Rcb1, Rbw, s->Rcw1 + 9 * k);
+    m3_vec(s->Rcb1, tbw, t);
+    for (int i = 0; i < 3; ++i) s->tcw1[3 * k + i] = t[i] + s->tcb1[i];
+  }
 }
 
 /* EdgeMono / EdgeStereo computeError (include/G2oTypes.h:355-361,438-444) */
@@ -212,6 +222,14 @@ static void vis_error(const istate* s, int e, double* r) {
   const osh_liba_problem* p = s->pr;
   const int k = p->edge_pose[e], l = p->edge_point[e];
   double Xc[3];
+  if (p->edge_kind[e] == OSH_EDGE_RIGHT) {   /* EdgeMono(1): Project(Xw, 1) = pCamera[1]->project(Rcw[1] Xw + tcw[1]) (src/G2oTypes.cc:166-171) */
+    double uv[2];
+    m3_vec(s->Rcw1 + 9 * k, s->X + 3 * l, Xc);
+    for (int i = 0; i < 3; ++i) Xc[i] += s->tcw1[3 * k + i];
+    oracle_kb8_project(p->cam2, p->cam2 + 4, Xc, uv);
+    r[0] = p->edge_obs[3 * e] - uv[0]; r[1] = p->edge_obs[3 * e + 1] - uv[1]; r[2] = 0;
+    return;
+  }
   m3_vec(s->Rcw + 9 * k, s->X + 3 * l, Xc);
   for (int i = 0; i < 3; ++i) Xc[i] += s->tcw[3 * k + i];
   double u = p->cam[0] * Xc[0] / Xc[2] + p->cam[2], v = p->cam[1] * Xc[1] / Xc[2] + p->cam[3];
@@ -231,13 +249,30 @@ static void vis_error(const istate* s, int e, double* r) {
 static double vis_chi2(const istate* s, int e) {
   const double w = s->pr->edge_info[e];
   const double* r = s->err + 3 * e;
-  return (s->pr->edge_kind[e] == OSH_EDGE_MONO) ? r[0] * (w * r[0]) + r[1] * (w * r[1]) : r[0] * (w * r[0]) + r[1] * (w * r[1]) + r[2] * (w * r[2]);
+  return (s->pr->edge_kind[e] != OSH_EDGE_STEREO) ? r[0] * (w * r[0]) + r[1] * (w * r[1]) : r[0] * (w * r[0]) + r[1] * (w * r[1]) + r[2] * (w * r[2]);
 }
 /* linearizeOplus of EdgeMono / EdgeStereo (src/G2oTypes.cc:349-373,397-427): JX 3x3, Jp 3x6 (row 2 zero for mono) */
 static void vis_jac(const istate* s, int e, double* JX, double* Jp) {
   const osh_liba_problem* p = s->pr;
   const int k = p->edge_pose[e], l = p->edge_point[e];
   double Xc[3], Xb[3], Rbc[9];
+  if (p->edge_kind[e] == OSH_EDGE_RIGHT) {   /* cam_idx = 1: Rcw[1], tcw[1], Rbc[1], tbc[1], Rcb[1], pCamera[1] (src/G2oTypes.cc:354-372) */
+    double pj1[9], M1[9];
+    m3_vec(s->Rcw1 + 9 * k, s->X + 3 * l, Xc);
+    for (int i = 0; i < 3; ++i) Xc[i] += s->tcw1[3 * k + i];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rbc[i * 3 + j] = s->Rcb1[j * 3 + i];
+    m3_vec(Rbc, Xc, Xb);
+    for (int i = 0; i < 3; ++i) Xb[i] += s->tbc1[i];
+    memset(pj1, 0, sizeof(pj1));
+    oracle_kb8_project_jac(p->cam2, p->cam2 + 4, Xc, pj1);
+    m3_mul(pj1, s->Rcw1 + 9 * k, M1);
+    for (int i = 0; i < 9; ++i) JX[i] = -M1[i];
+    const double x1 = Xb[0], y1 = Xb[1], z1 = Xb[2];
+    const double D1[18] = {0, z1, -y1, 1, 0, 0, -z1, 0, x1, 0, 1, 0, y1, -x1, 0, 0, 0, 1};
+    m3_mul(pj1, s->Rcb1, M1);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 6; ++j) Jp[i * 6 + j] = M1[i * 3] * D1[j] + M1[i * 3 + 1] * D1[6 + j] + M1[i * 3 + 2] * D1[12 + j];
+    return;
+  }
   m3_vec(s->Rcw + 9 * k, s->X + 3 * l, Xc);
   for (int i = 0; i < 3; ++i) Xc[i] += s->tcw[3 * k + i];
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rbc[i * 3 + j] = p->Rcb[j * 3 + i];
@@ -375,7 +410,7 @@ static double robust_chi2(const istate* s) {
     chi += quad(s->ierr + 12 * s->NL + 3 * l, p->link_info_a + 9 * (size_t)l, 3);
   }
   for (int e = 0; e < s->E; ++e) {
-    oracle_huber(vis_chi2(s, e), p->edge_kind[e] == OSH_EDGE_MONO ? p->huber_mono : p->huber_stereo, rho);
+    oracle_huber(vis_chi2(s, e), p->edge_kind[e] != OSH_EDGE_STEREO ? p->huber_mono : p->huber_stereo, rho);
     chi += rho[0];
   }
   return chi;
@@ -454,7 +489,7 @@ static void build_system(istate* s) {
     vis_jac(s, e, A, B);
     const double w = p->edge_info[e];
     const double* r = s->err + 3 * e;
-    oracle_huber(vis_chi2(s, e), p->edge_kind[e] == OSH_EDGE_MONO ? p->huber_mono : p->huber_stereo, rho);
+    oracle_huber(vis_chi2(s, e), p->edge_kind[e] != OSH_EDGE_STEREO ? p->huber_mono : p->huber_stereo, rho);
     const double ww = rho[1] * w;
     const double wr[3] = {-(w * r[0]) * rho[1], -(w * r[1]) * rho[1], -(w * r[2]) * rho[1]};
     for (int i = 0; i < 3; ++i) {
@@ -467,7 +502,7 @@ static void build_system(istate* s) {
         for (int j = 0; j < 6; ++j)
           s->H[(size_t)(6 * k + i) * n + 6 * k + j] += (B[i] * ww) * B[j] + (B[6 + i] * ww) * B[6 + j] + (B[12 + i] * ww) * B[12 + j];
         for (int j = 0; j < 3; ++j)
-          s->Hpl[18 * (size_t)e + i * 3 + j] += (B[i] * ww) * A[j] + (B[6 + i] * ww) * A[3 + j] + (B[12 + i] * ww) * A[6 + j];
+          s->Hpl[18 * (size_t)s->slot[e] + i * 3 + j] += (B[i] * ww) * A[j] + (B[6 + i] * ww) * A[3 + j] + (B[12 + i] * ww) * A[6 + j];
       }
     }
   }
@@ -545,6 +580,7 @@ static void state_pack(istate* s, double* dst) {
 #define CP(ptr, cnt) memcpy(dst + o, ptr, sizeof(double) * (cnt)); o += (cnt)
   CP(s->Rcw, 9 * (size_t)s->K); CP(s->tcw, 3 * (size_t)s->K); CP(s->Rwb, 9 * (size_t)s->K); CP(s->twb, 3 * (size_t)s->K);
   CP(s->vel, 3 * (size_t)s->NV); CP(s->bg, 3 * (size_t)s->NV); CP(s->ba, 3 * (size_t)s->NV); CP(s->X, 3 * (size_t)s->L);
+  if (s->rig) { CP(s->Rcw1, 9 * (size_t)s->K); CP(s->tcw1, 3 * (size_t)s->K); }
 #undef CP
 }
 static void state_unpack(istate* s, const double* src) {
@@ -552,6 +588,7 @@ static void state_unpack(istate* s, const double* src) {
 #define CP(ptr, cnt) memcpy(ptr, src + o, sizeof(double) * (cnt)); o += (cnt)
   CP(s->Rcw, 9 * (size_t)s->K); CP(s->tcw, 3 * (size_t)s->K); CP(s->Rwb, 9 * (size_t)s->K); CP(s->twb, 3 * (size_t)s->K);
   CP(s->vel, 3 * (size_t)s->NV); CP(s->bg, 3 * (size_t)s->NV); CP(s->ba, 3 * (size_t)s->NV); CP(s->X, 3 * (size_t)s->L);
+  if (s->rig) { CP(s->Rcw1, 9 * (size_t)s->K); CP(s->tcw1, 3 * (size_t)s->K); }
 #undef CP
 }
 
@@ -565,20 +602,52 @@ static int istate_init(istate* s, const osh_liba_problem* p) {
   const size_t n = s->n, K = s->K, NV = s->NV, L = s->L, E = s->E, NL = s->NL;
   s->Rcw = zalloc(9 * K, 8); s->tcw = zalloc(3 * K, 8); s->Rwb = zalloc(9 * K, 8); s->twb = zalloc(3 * K, 8);
   s->vel = zalloc(3 * NV, 8); s->bg = zalloc(3 * NV, 8); s->ba = zalloc(3 * NV, 8); s->X = zalloc(3 * L, 8);
-  s->bak_len = 24 * K + 9 * NV + 3 * L; s->bak = zalloc(s->bak_len, 8);
+  s->rig = (p->kb8 && p->cam2 && p->trl) ? 1 : 0;
+  s->bak_len = 24 * K + 9 * NV + 3 * L + (s->rig ? 12 * K : 0); s->bak = zalloc(s->bak_len, 8);
   s->err = zalloc(3 * E, 8); s->ierr = zalloc(15 * NL, 8);
   s->H = zalloc(n * n, 8); s->b = zalloc(n + 3 * L, 8); s->Hll = zalloc(9 * L, 8); s->Hpl = zalloc(18 * E, 8);
   s->S = zalloc(n * n, 8); s->bs = zalloc(n, 8); s->coeff = zalloc(n, 8); s->x = zalloc(n + 3 * L, 8); s->Dinv = zalloc(9 * L, 8);
   s->tmp = zalloc(n, 8);
   memcpy(s->Rcw, p->pose_Rcw, 72 * K); memcpy(s->tcw, p->pose_tcw, 24 * K); memcpy(s->Rwb, p->pose_Rwb, 72 * K); memcpy(s->twb, p->pose_twb, 24 * K);
   memcpy(s->vel, p->vel, 24 * NV); memcpy(s->bg, p->bias_g, 24 * NV); memcpy(s->ba, p->bias_a, 24 * NV); memcpy(s->X, p->points, 24 * L);
-  /* CCS of the optimisable-pose visual edges per landmark, rows ascending */
+  s->Rcw1 = zalloc(9 * K, 8); s->tcw1 = zalloc(3 * K, 8);
+  for (size_t e = 0; e < E; ++e) if (p->edge_kind[e] == OSH_EDGE_RIGHT && !s->rig) return 0;
+  if (s->rig) {   /* ImuCamPose(KeyFrame*) for camera 1 (src/G2oTypes.cc:56-66) */
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) s->Rrl[i * 3 + j] = p->trl[i * 4 + j]; s->trl[i] = p->trl[i * 4 + 3]; }
+    double t[3], Rbc1[9];
+    m3_mul(s->Rrl, p->Rcb, s->Rcb1);
+    m3_vec(s->Rrl, p->tcb, t);
+    for (int i = 0; i < 3; ++i) s->tcb1[i] = t[i] + s->trl[i];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rbc1[i * 3 + j] = s->Rcb1[j * 3 + i];
+    m3_vec(Rbc1, s->tcb1, t);
+    for (int i = 0; i < 3; ++i) s->tbc1[i] = -t[i];
+    for (size_t k = 0; k < K; ++k) {
+      m3_mul(s->Rrl, s->Rcw + 9 * k, s->Rcw1 + 9 * k);
+      m3_vec(s->Rrl, s->tcw + 3 * k, t);
+      for (int i = 0; i < 3; ++i) s->tcw1[3 * k + i] = t[i] + s->trl[i];
+    }
+  }
+  /* Hessian block of every edge: the right-camera edge of a (keyframe, landmark) pair that also has a left edge adds to that
+   * left edge's block (the later edge of the pair in the caller's order adds to the earlier one) */
+  s->slot = zalloc(E, sizeof(int));
+  {
+    int* first = zalloc((size_t)L * (s->N ? s->N : 1), sizeof(int));
+    for (size_t q = 0; q < (size_t)L * s->N; ++q) first[q] = -1;
+    for (size_t e = 0; e < E; ++e) {
+      s->slot[e] = (int)e;
+      if (p->edge_pose[e] >= s->N) continue;
+      int* f = &first[(size_t)p->edge_point[e] * s->N + p->edge_pose[e]];
+      if (*f < 0) *f = (int)e; else s->slot[e] = *f;
+    }
+    free(first);
+  }
+  /* CCS of the optimisable-pose visual blocks per landmark, rows ascending */
   s->col_off = zalloc(L + 1, sizeof(int)); s->blk_edge = zalloc(E, sizeof(int));
-  for (size_t e = 0; e < E; ++e) if (p->edge_pose[e] < s->N) s->col_off[p->edge_point[e] + 1]++;
+  for (size_t e = 0; e < E; ++e) if (p->edge_pose[e] < s->N && s->slot[e] == (int)e) s->col_off[p->edge_point[e] + 1]++;
   for (size_t j = 0; j < L; ++j) s->col_off[j + 1] += s->col_off[j];
   int* fill = zalloc(L, sizeof(int));
   for (size_t j = 0; j < L; ++j) fill[j] = s->col_off[j];
-  for (size_t e = 0; e < E; ++e) if (p->edge_pose[e] < s->N) s->blk_edge[fill[p->edge_point[e]]++] = (int)e;
+  for (size_t e = 0; e < E; ++e) if (p->edge_pose[e] < s->N && s->slot[e] == (int)e) s->blk_edge[fill[p->edge_point[e]]++] = (int)e;
   for (size_t j = 0; j < L; ++j)
     for (int a = s->col_off[j] + 1; a < s->col_off[j + 1]; ++a) {
       int v = s->blk_edge[a], b = a - 1;
@@ -591,7 +660,7 @@ static int istate_init(istate* s, const osh_liba_problem* p) {
 static void istate_free(istate* s) {
   free(s->Rcw); free(s->tcw); free(s->Rwb); free(s->twb); free(s->vel); free(s->bg); free(s->ba); free(s->X); free(s->bak);
   free(s->err); free(s->ierr); free(s->H); free(s->b); free(s->Hll); free(s->Hpl); free(s->S); free(s->bs); free(s->coeff);
-  free(s->x); free(s->Dinv); free(s->tmp); free(s->col_off); free(s->blk_edge);
+  free(s->x); free(s->Dinv); free(s->tmp); free(s->col_off); free(s->blk_edge); free(s->slot); free(s->Rcw1); free(s->tcw1);
 }
 
 /* Debug / parity aids */
@@ -683,8 +752,9 @@ int oracle_liba_solve(const osh_liba_problem* p, osh_liba_result* res) {
   if (res->edge_depth_pos)
     for (int e = 0; e < s.E; ++e) {   /* ImuCamPose::isDepthPositive (src/G2oTypes.cc:185-188) */
       const int k = p->edge_pose[e];
-      const double* R = s.Rcw + 9 * k; const double* X = s.X + 3 * p->edge_point[e];
-      res->edge_depth_pos[e] = (R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + s.tcw[3 * k + 2]) > 0.0;
+      const int right = p->edge_kind[e] == OSH_EDGE_RIGHT;   /* isDepthPositive(Xw, cam_idx) */
+      const double* R = (right ? s.Rcw1 : s.Rcw) + 9 * k; const double* X = s.X + 3 * p->edge_point[e];
+      res->edge_depth_pos[e] = (R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + (right ? s.tcw1 : s.tcw)[3 * k + 2]) > 0.0;
     }
   istate_free(&s);
   return OSH_OK;

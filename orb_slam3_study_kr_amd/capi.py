@@ -24,6 +24,7 @@ OSH_ERR_NO_DEVICE = -4
 OSH_EDGE_MONO = 0
 OSH_EDGE_STEREO = 1
 OSH_EDGE_BODY = 2
+OSH_EDGE_RIGHT = 2   # LocalInertialBA: EdgeMono(1), the right camera of a fisheye rig
 OSH_LBA_MAX_TRACE = 128
 OSH_K_COUNT = 11
 KERNEL_NAMES = ["linearize", "pose_hess", "schur", "solve", "backsub", "residual", "control", "schur_reduce", "schur_cross", "lin_aux", "lin_pose"]
@@ -102,6 +103,7 @@ class LibaProblem(C.Structure):
         ("link_info", c_double_p), ("link_info_g", c_double_p), ("link_info_a", c_double_p), ("link_robust", c_uint8_p),
         ("huber_mono", C.c_double), ("huber_stereo", C.c_double), ("huber_inertial", C.c_double),
         ("lambda_init", C.c_double), ("max_iterations", C.c_int32), ("kb8", c_double_p),
+        ("cam2", c_double_p), ("trl", c_double_p),
     ]
 
 

@@ -220,22 +220,25 @@ bool PackLocalInertialBA(KeyFrame* pKF, Map* pMap, bool bLarge, bool bRecInit, L
       auto itk = poseIndex.find(pKFi);
       if (itk == poseIndex.end()) continue;   // marked fixed but never added (the `break` above / the 200 cap)
       const int leftIndex = std::get<0>(ob.second);
+      cv::KeyPoint kpUn;   // declared per observation like the reference's (:2732): default-constructed unless there is a left observation
+      // one KannalaBrandt8 per window: EdgeMono projects through pKFi->mpCamera (ImuCamPose::Project, src/G2oTypes.cc:166-171)
+      auto window_fisheye = [&]() -> bool {
+        GeometricCamera* c = pKFi->mpCamera;
+        if (c->getParameter(0) != pKF->fx || c->getParameter(1) != pKF->fy || c->getParameter(2) != pKF->cx || c->getParameter(3) != pKF->cy) {
+          pk.unsupported = "monocular observation through a camera that is not the window's own model"; return false;
+        }
+        for (int k = 0; k < 4; ++k) {
+          if (pk.has_kb8 && pk.kb8[k] != (double)c->getParameter(4 + k)) { pk.unsupported = "keyframes with different KannalaBrandt8 coefficients"; return false; }
+          pk.kb8[k] = c->getParameter(4 + k);
+        }
+        pk.has_kb8 = true;
+        return true;
+      };
       if (leftIndex != -1) {
-        const cv::KeyPoint& kpUn = pKFi->mvKeysUn[leftIndex];
+        kpUn = pKFi->mvKeysUn[leftIndex];
         const float kp_ur = pKFi->mvuRight[leftIndex];
         const bool stereo = !(kp_ur < 0);
-        if (!stereo && pKFi->mpCamera && pKFi->mpCamera->GetType() == GeometricCamera::CAM_FISHEYE) {
-          // EdgeMono projects through pKFi->mpCamera (ImuCamPose::Project, src/G2oTypes.cc:166-171): one KannalaBrandt8 per window
-          GeometricCamera* c = pKFi->mpCamera;
-          if (c->getParameter(0) != pKF->fx || c->getParameter(1) != pKF->fy || c->getParameter(2) != pKF->cx || c->getParameter(3) != pKF->cy) {
-            pk.unsupported = "monocular observation through a camera that is not the window's own model"; return true;
-          }
-          for (int k = 0; k < 4; ++k) {
-            if (pk.has_kb8 && pk.kb8[k] != (double)c->getParameter(4 + k)) { pk.unsupported = "keyframes with different KannalaBrandt8 coefficients"; return true; }
-            pk.kb8[k] = c->getParameter(4 + k);
-          }
-          pk.has_kb8 = true;
-        }
+        if (!stereo && pKFi->mpCamera && pKFi->mpCamera->GetType() == GeometricCamera::CAM_FISHEYE && !window_fisheye()) return true;
         Eigen::Matrix<double, 2, 1> obs2(kpUn.pt.x, kpUn.pt.y);
         const float unc2 = pKFi->mpCamera->uncertainty2(obs2);
         const float invSigma2 = pKFi->mvInvLevelSigma2[kpUn.octave] / unc2;   // :2741, float division
@@ -247,11 +250,43 @@ bool PackLocalInertialBA(KeyFrame* pKF, Map* pMap, bool bLarge, bool bRecInit, L
         pk.vEdgeKF.push_back(pKFi);
         pk.vEdgeMP.push_back(pMP);
       }
-      if (pKFi->mpCamera2 && std::get<1>(ob.second) != -1) { pk.unsupported = "right-camera (fisheye stereo) observation"; return true; }
+      // monocular right observation (:2798-2835): EdgeMono(1) on camera 1 of the keyframe's ImuCamPose
+      if (pKFi->mpCamera2) {
+        int rightIndex = std::get<1>(ob.second);
+        if (rightIndex != -1) {
+          rightIndex -= pKFi->NLeft;
+          if (pKFi->mpCamera->GetType() != GeometricCamera::CAM_FISHEYE || pKFi->mpCamera2->GetType() != GeometricCamera::CAM_FISHEYE) {
+            pk.unsupported = "right-camera observation of a rig that is not a KannalaBrandt8 pair"; return true;
+          }
+          if (!window_fisheye()) return true;
+          double c2[8], T[12];
+          for (int k = 0; k < 8; ++k) c2[k] = pKFi->mpCamera2->getParameter(k);
+          const Sophus::SE3f Trl = pKFi->GetRelativePoseTrl();       // ImuCamPose: Trl.matrix().cast<double>() (src/G2oTypes.cc:58)
+          const Eigen::Matrix3f Rrl = Trl.rotationMatrix();
+          for (int a = 0; a < 3; ++a) { for (int b = 0; b < 3; ++b) T[a * 4 + b] = (double)Rrl(a, b); T[a * 4 + 3] = (double)Trl.translation()(a); }
+          if (pk.has_rig) {
+            for (int k = 0; k < 8; ++k) if (pk.cam2[k] != c2[k]) { pk.unsupported = "keyframes with different right cameras"; return true; }
+            for (int k = 0; k < 12; ++k) if (pk.trl[k] != T[k]) { pk.unsupported = "keyframes with different left-to-right transforms"; return true; }
+          }
+          std::copy(c2, c2 + 8, pk.cam2); std::copy(T, T + 12, pk.trl);
+          pk.has_rig = true;
+          const cv::KeyPoint kp = pKFi->mvKeysRight[rightIndex];
+          Eigen::Matrix<double, 2, 1> obs2(kp.pt.x, kp.pt.y);
+          const float unc2 = pKFi->mpCamera->uncertainty2(obs2);                  // the LEFT camera's, as the reference has it (:2819)
+          const float invSigma2 = pKFi->mvInvLevelSigma2[kpUn.octave] / unc2;     // kpUn: the left keypoint variable (:2821)
+          pk.edge_pose.push_back(itk->second);
+          pk.edge_point.push_back(pointIndex.at(pMP));
+          pk.edge_kind.push_back(OSH_EDGE_RIGHT);
+          pk.edge_obs.push_back(kp.pt.x); pk.edge_obs.push_back(kp.pt.y); pk.edge_obs.push_back(-1.0);
+          pk.edge_info.push_back(invSigma2);
+          pk.vEdgeKF.push_back(pKFi);
+          pk.vEdgeMP.push_back(pMP);
+        }
+      }
     }
   }
   if (pk.has_kb8)
-    for (uint8_t k : pk.edge_kind) if (k != OSH_EDGE_MONO) { pk.unsupported = "rectified-stereo observation in a KannalaBrandt8 window"; return true; }
+    for (uint8_t k : pk.edge_kind) if (k == OSH_EDGE_STEREO) { pk.unsupported = "rectified-stereo observation in a KannalaBrandt8 window"; return true; }
   return true;
 }
 
@@ -292,7 +327,7 @@ void Optimizer::LocalInertialBA(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int&
   std::vector<std::pair<KeyFrame*, MapPoint*>> vToErase;
   for (int pass = 0; pass < 2; ++pass)
     for (int e = 0; e < E; ++e) {
-      if (pk.edge_kind[e] != (pass == 0 ? OSH_EDGE_MONO : OSH_EDGE_STEREO)) continue;
+      if ((pk.edge_kind[e] == OSH_EDGE_STEREO) != (pass == 1)) continue;   // vpEdgesMono holds EdgeMono(0) and EdgeMono(1) in insertion order
       MapPoint* pMP = pk.vEdgeMP[e];
       if (pass == 0) {
         const bool bClose = pMP->mTrackDepth < 10.f;

@@ -114,6 +114,8 @@ struct LibaPack {
   double Rcb[9], tcb[3], tbc[3], cam[5];
   bool has_kb8 = false;       // the window's camera is a KannalaBrandt8 (monocular fisheye)
   double kb8[4] = {0, 0, 0, 0};
+  bool has_rig = false;       // fisheye stereo rig: OSH_EDGE_RIGHT edges (EdgeMono(1)) through cam2 / trl
+  double cam2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, trl[12] = {0};
   std::vector<int32_t> edge_pose, edge_point, link_prev, link_cur;
   std::vector<uint8_t> edge_kind, link_robust;
   std::vector<float> link_preint;
@@ -128,6 +130,7 @@ struct LibaPack {
     p.link_robust = link_robust.data();
     p.huber_mono = p.huber_stereo = p.huber_inertial = 0; p.lambda_init = 1.0; p.max_iterations = opt_it;
     p.kb8 = has_kb8 ? kb8 : nullptr;
+    p.cam2 = has_rig ? cam2 : nullptr; p.trl = has_rig ? trl : nullptr;
   }
 };
 bool PackLocalInertialBA(KeyFrame* pKF, Map* pMap, bool bLarge, bool bRecInit, LibaPack& pk);

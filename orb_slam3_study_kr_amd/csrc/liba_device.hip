@@ -39,6 +39,8 @@ struct LibaDesc {
   double Rcb[9], tcb[3], tbc[3], cam[5];
   double kb8[4];   // KannalaBrandt8 k1..k4 (osh_liba_problem.kb8)
   int kb8_on;      // 1: mono edges project through KannalaBrandt8
+  int rig_on;      // 1: fisheye stereo rig, OSH_EDGE_RIGHT edges are EdgeMono(1) on camera 1 of ImuCamPose (src/G2oTypes.cc:56-66)
+  double Rrl[9], trl[3], Rcb1[9], tbc1[3], cam2[8];   // Trl; Rcb[1] = Rrl Rcb[0]; tbc[1] = -Rbc[1] tcb[1]; right camera fx fy cx cy k1..k4
   double huber_mono, huber_stereo, huber_inertial, lambda_init;
 };
 
@@ -94,9 +96,21 @@ struct VisEval { double r[3], chi2, Xc[3]; };
 // EdgeMono / EdgeStereo computeError with the ImuCamPose camera pose (include/G2oTypes.h:355-361,438-444)
 __device__ __forceinline__ void vis_residual(const LibaDesc& d, int kind, const double* pose, const double* X, const double* obs,
                                              double info, VisEval& o) {
+  double u, v;
+  if (kind == OSH_EDGE_RIGHT) {
+    // EdgeMono(1): pCamera[1]->project(Rcw[1] Xw + tcw[1]) with Rcw[1] = Rrl Rcw[0], tcw[1] = Rrl tcw[0] + trl
+    double R1[9], t1[3];
+    imu::m3_mul(d.Rrl, pose, R1);
+    imu::m3_vec(d.Rrl, pose + 9, t1);
+    imu::m3_vec(R1, X, o.Xc);
+    o.Xc[0] += t1[0] + d.trl[0]; o.Xc[1] += t1[1] + d.trl[1]; o.Xc[2] += t1[2] + d.trl[2];
+    dev::kb8_project(d.cam2, d.cam2 + 4, o.Xc, u, v);
+    o.r[0] = obs[0] - u; o.r[1] = obs[1] - v; o.r[2] = 0.0;
+    o.chi2 = o.r[0] * (info * o.r[0]) + o.r[1] * (info * o.r[1]);
+    return;
+  }
   imu::m3_vec(pose, X, o.Xc);
   o.Xc[0] += pose[9]; o.Xc[1] += pose[10]; o.Xc[2] += pose[11];
-  double u, v;
   if (d.kb8_on) dev::kb8_project(d.cam, d.kb8, o.Xc, u, v);   // ImuCamPose::Project -> pCamera->project (src/G2oTypes.cc:166-171)
   else { u = d.cam[0] * o.Xc[0] / o.Xc[2] + d.cam[2]; v = d.cam[1] * o.Xc[1] / o.Xc[2] + d.cam[3]; }
   o.r[0] = obs[0] - u; o.r[1] = obs[1] - v; o.r[2] = 0.0;
@@ -111,6 +125,25 @@ __device__ __forceinline__ void vis_residual(const LibaDesc& d, int kind, const 
 // linearizeOplus (src/G2oTypes.cc:349-373,397-427): JX 3x3, Jp 3x6 (row 2 zero for mono)
 __device__ __forceinline__ void vis_jacobians(const LibaDesc& d, int kind, const double* pose, const double* Xc, double* JX, double* Jp) {
   double Xb[3];
+  if (kind == OSH_EDGE_RIGHT) {
+    // cam_idx = 1 (src/G2oTypes.cc:354-372): Xb = Rbc[1] Xc + tbc[1], JX = -projJac Rcw[1], Jp = projJac Rcb[1] SE3deriv(Xb)
+    double pj1[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, R1[9], M1[9];
+    imu::m3_tvec(d.Rcb1, Xc, Xb);
+    Xb[0] += d.tbc1[0]; Xb[1] += d.tbc1[1]; Xb[2] += d.tbc1[2];
+    dev::kb8_project_jac(d.cam2, d.cam2 + 4, Xc, pj1);
+    imu::m3_mul(d.Rrl, pose, R1);
+    imu::m3_mul(pj1, R1, M1);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) JX[i] = -M1[i];
+    const double x1 = Xb[0], y1 = Xb[1], z1 = Xb[2];
+    const double D1[18] = {0, z1, -y1, 1, 0, 0, -z1, 0, x1, 0, 1, 0, y1, -x1, 0, 0, 0, 1};
+    imu::m3_mul(pj1, d.Rcb1, M1);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) Jp[i * 6 + j] = M1[i * 3] * D1[j] + M1[i * 3 + 1] * D1[6 + j] + M1[i * 3 + 2] * D1[12 + j];
+    return;
+  }
   imu::m3_tvec(d.Rcb, Xc, Xb);   // Rbc = Rcb^T
   Xb[0] += d.tbc[0]; Xb[1] += d.tbc[1]; Xb[2] += d.tbc[2];
   double pj[9] = {d.cam[0] / Xc[2], 0, -d.cam[0] * Xc[0] / (Xc[2] * Xc[2]), 0, d.cam[1] / Xc[2], -d.cam[1] * Xc[1] / (Xc[2] * Xc[2]), 0, 0, 0};
@@ -230,7 +263,7 @@ __device__ double eval_chi2(const LibaView& v, const LibaDesc& d, int sel, doubl
       VisEval ev;
       vis_residual(d, kind, poses + 24 * (size_t)v.e_pose[ge], X, v.e_obs + ge * 3, v.e_info[ge], ev);
       double r0, r1;
-      dev::huber(ev.chi2, kind == OSH_EDGE_MONO ? d.huber_mono : d.huber_stereo, r0, r1);
+      dev::huber(ev.chi2, kind == OSH_EDGE_STEREO ? d.huber_stereo : d.huber_mono, r0, r1);
       acc += r0;
     }
   }
@@ -283,7 +316,7 @@ __global__ __launch_bounds__(kLT) void k_liba(LibaView v, int W) {
         VisEval ev;
         vis_residual(d, kind, poses + 24 * (size_t)ip, X, v.e_obs + ge * 3, info, ev);
         double r0, r1, JX[9], Jp[18];
-        dev::huber(ev.chi2, kind == OSH_EDGE_MONO ? d.huber_mono : d.huber_stereo, r0, r1);
+        dev::huber(ev.chi2, kind == OSH_EDGE_STEREO ? d.huber_stereo : d.huber_mono, r0, r1);
         vis_jacobians(d, kind, poses + 24 * (size_t)ip, ev.Xc, JX, Jp);
         const double ww = r1 * info;
         const double wr[3] = {-(info * ev.r[0]) * r1, -(info * ev.r[1]) * r1, -(info * ev.r[2]) * r1};
@@ -296,11 +329,16 @@ __global__ __launch_bounds__(kLT) void k_liba(LibaView v, int W) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) bj[i] += JX[i] * wr[0] + JX[3 + i] * wr[1] + JX[6 + i] * wr[2];
         if (ip < N) {
-          double* Hb = Hpl + (size_t)e * 18;
+          // the right-camera edge of a (keyframe, landmark) pair adds to the block of the left edge sorted just before it
+          const bool second = e > lmo[j] && v.e_pose[ge - 1] == ip;
+          double* Hb = Hpl + (size_t)(second ? e - 1 : e) * 18;
 #pragma unroll
           for (int i = 0; i < 6; ++i)
 #pragma unroll
-            for (int jj = 0; jj < 3; ++jj) Hb[i * 3 + jj] = (Jp[i] * ww) * JX[jj] + (Jp[6 + i] * ww) * JX[3 + jj] + (Jp[12 + i] * ww) * JX[6 + jj];
+            for (int jj = 0; jj < 3; ++jj) {
+              const double hv = (Jp[i] * ww) * JX[jj] + (Jp[6 + i] * ww) * JX[3 + jj] + (Jp[12 + i] * ww) * JX[6 + jj];
+              Hb[i * 3 + jj] = second ? Hb[i * 3 + jj] + hv : hv;
+            }
         }
       }
 #pragma unroll
@@ -324,7 +362,7 @@ __global__ __launch_bounds__(kLT) void k_liba(LibaView v, int W) {
         VisEval ev;
         vis_residual(d, kind, pose, pts + 3 * (size_t)v.e_point[ge], v.e_obs + ge * 3, info, ev);
         double r0, r1, JX[9], Jp[18];
-        dev::huber(ev.chi2, kind == OSH_EDGE_MONO ? d.huber_mono : d.huber_stereo, r0, r1);
+        dev::huber(ev.chi2, kind == OSH_EDGE_STEREO ? d.huber_stereo : d.huber_mono, r0, r1);
         vis_jacobians(d, kind, pose, ev.Xc, JX, Jp);
         const double ww = r1 * info;
         const double wr[3] = {-(info * ev.r[0]) * r1, -(info * ev.r[1]) * r1, -(info * ev.r[2]) * r1};
@@ -476,15 +514,17 @@ __global__ __launch_bounds__(kLT) void k_liba(LibaView v, int W) {
             const int j = v.e_point[(size_t)d.edge_off + e];
             const double* Dj = dinv + (size_t)j * 9;
             const double* Be = Hpl + (size_t)e * 18;
+            // second edge of a (keyframe, landmark) pair: its block lives in the first edge's slot, this entry contributes nothing
+            const bool second = e > lmo[j] && v.e_pose[(size_t)d.edge_off + e - 1] == i;
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
-              const double x0 = Be[r * 3], x1 = Be[r * 3 + 1], x2 = Be[r * 3 + 2];
+              const double x0 = second ? 0.0 : Be[r * 3], x1 = second ? 0.0 : Be[r * 3 + 1], x2 = second ? 0.0 : Be[r * 3 + 2];
               stBD[lane * 18 + r * 3 + 0] = x0 * Dj[0] + x1 * Dj[1] + x2 * Dj[2];
               stBD[lane * 18 + r * 3 + 1] = x0 * Dj[1] + x1 * Dj[3] + x2 * Dj[4];
               stBD[lane * 18 + r * 3 + 2] = x0 * Dj[2] + x1 * Dj[4] + x2 * Dj[5];
               ci[r] += x0 * Dj[6] + x1 * Dj[7] + x2 * Dj[8];
             }
-            for (int p2 = 0; p2 < N; ++p2) stq[lane * kStageMaxN + p2] = lmpe[(size_t)j * N + p2];
+            for (int p2 = 0; p2 < N; ++p2) stq[lane * kStageMaxN + p2] = second ? -1 : lmpe[(size_t)j * N + p2];
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
@@ -542,6 +582,7 @@ __global__ __launch_bounds__(kLT) void k_liba(LibaView v, int W) {
         for (int e = lmo[j]; e < lmo[j + 1]; ++e) {
           const int ip = v.e_pose[(size_t)d.edge_off + e];
           if (ip >= N) continue;
+          if (e > lmo[j] && v.e_pose[(size_t)d.edge_off + e - 1] == ip) continue;   // block already taken with the pair's first edge
           const double* B = Hpl + (size_t)e * 18;
           const double* xp = xg + 6 * ip;
           double a0 = 0, a1 = 0, a2 = 0;
@@ -626,7 +667,15 @@ __global__ __launch_bounds__(kLT) void k_liba(LibaView v, int W) {
       const double* R = pf + 24 * (size_t)ip; const double* X = xf + 3 * (size_t)il;
       const size_t go = (size_t)d.edge_off + v.e_orig[ge];
       v.out_chi2[go] = ev.chi2;
-      v.out_depth[go] = (R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + R[11]) > 0.0 ? 1 : 0;
+      if (v.e_kind[ge] == OSH_EDGE_RIGHT) {   // isDepthPositive(Xw, 1): row 2 of Rcw[1] = Rrl Rcw[0], tcw[1] = Rrl tcw[0] + trl
+        double r2[3], t2 = d.trl[2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) r2[c] = d.Rrl[6] * R[c] + d.Rrl[7] * R[3 + c] + d.Rrl[8] * R[6 + c];
+        t2 += d.Rrl[6] * R[9] + d.Rrl[7] * R[10] + d.Rrl[8] * R[11];
+        v.out_depth[go] = (r2[0] * X[0] + r2[1] * X[1] + r2[2] * X[2] + t2) > 0.0 ? 1 : 0;
+      } else {
+        v.out_depth[go] = (R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + R[11]) > 0.0 ? 1 : 0;
+      }
     }
   }
 }
@@ -679,14 +728,30 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
     d.huber_mono = p.huber_mono; d.huber_stereo = p.huber_stereo; d.huber_inertial = p.huber_inertial; d.lambda_init = p.lambda_init;
     d.kb8_on = p.kb8 ? 1 : 0;
     for (int k = 0; k < 4; ++k) d.kb8[k] = p.kb8 ? p.kb8[k] : 0.0;
+    d.rig_on = (p.kb8 && p.cam2 && p.trl) ? 1 : 0;
+    if (d.rig_on) {
+      // ImuCamPose(KeyFrame*) camera 1 (src/G2oTypes.cc:56-66): Rcb[1] = Rrl Rcb[0], tcb[1] = Rrl tcb[0] + trl, tbc[1] = -Rbc[1] tcb[1]
+      double tcb1[3];
+      for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) d.Rrl[i * 3 + j] = p.trl[i * 4 + j]; d.trl[i] = p.trl[i * 4 + 3]; }
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+          double a = 0.0;
+          for (int k = 0; k < 3; ++k) a += d.Rrl[i * 3 + k] * d.Rcb[k * 3 + j];
+          d.Rcb1[i * 3 + j] = a;
+        }
+      for (int i = 0; i < 3; ++i) tcb1[i] = d.Rrl[i * 3] * d.tcb[0] + d.Rrl[i * 3 + 1] * d.tcb[1] + d.Rrl[i * 3 + 2] * d.tcb[2] + d.trl[i];
+      for (int i = 0; i < 3; ++i) d.tbc1[i] = -(d.Rcb1[i] * tcb1[0] + d.Rcb1[3 + i] * tcb1[1] + d.Rcb1[6 + i] * tcb1[2]);
+      std::memcpy(d.cam2, p.cam2, 64);
+    }
     if (p.kb8)
       for (int e = 0; e < p.n_edges; ++e)
-        if (p.edge_kind[e] != OSH_EDGE_MONO) { set_error("window %d: a KannalaBrandt8 window takes monocular edges only (edge %d)", w, e); return OSH_ERR_UNSUPPORTED; }
+        if (p.edge_kind[e] == OSH_EDGE_STEREO) { set_error("window %d: a KannalaBrandt8 window takes monocular edges only (edge %d)", w, e); return OSH_ERR_UNSUPPORTED; }
     size_t ef = 0;
     for (int e = 0; e < p.n_edges; ++e) {
-      if (p.edge_pose[e] < 0 || p.edge_pose[e] >= d.K || p.edge_point[e] < 0 || p.edge_point[e] >= d.L || p.edge_kind[e] > OSH_EDGE_STEREO) {
+      if (p.edge_pose[e] < 0 || p.edge_pose[e] >= d.K || p.edge_point[e] < 0 || p.edge_point[e] >= d.L || p.edge_kind[e] > OSH_EDGE_RIGHT) {
         set_error("window %d edge %d: index or kind out of range", w, e); return OSH_ERR_INVALID;
       }
+      if (p.edge_kind[e] == OSH_EDGE_RIGHT && !d.rig_on) { set_error("window %d edge %d: a right-camera edge (EdgeMono(1)) needs kb8, cam2 and trl", w, e); return OSH_ERR_INVALID; }
       if (p.edge_pose[e] < d.N) ++ef;
     }
     for (int l = 0; l < p.n_links; ++l)
@@ -729,11 +794,19 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
     for (int e = 0; e < d.E; ++e) order[fill[p.edge_point[e]]++] = e;
     for (int j = 0; j <= d.L; ++j) h_lmo[d.lmoff_off + j] = cnt[j];
     for (int j = 0; j < d.L; ++j) {
-      std::stable_sort(order.begin() + cnt[j], order.begin() + cnt[j + 1], [&](int a, int b) { return p.edge_pose[a] < p.edge_pose[b]; });
+      std::stable_sort(order.begin() + cnt[j], order.begin() + cnt[j + 1], [&](int a, int b) {
+        return p.edge_pose[a] != p.edge_pose[b] ? p.edge_pose[a] < p.edge_pose[b] : p.edge_kind[a] < p.edge_kind[b];
+      });
       for (int x = cnt[j]; x < cnt[j + 1]; ++x) {
         if (x > cnt[j] && p.edge_pose[order[x]] == p.edge_pose[order[x - 1]]) {
-          set_error("window %d: landmark %d observed twice by keyframe %d (right-camera edges are not supported yet)", w, j, p.edge_pose[order[x]]);
-          return OSH_ERR_UNSUPPORTED;
+          // one Hessian block, two edges: only the left EdgeMono(0) + right EdgeMono(1) of a fisheye rig (src/Optimizer.cc:2737-2835)
+          const bool pair = p.edge_kind[order[x]] == OSH_EDGE_RIGHT && p.edge_kind[order[x - 1]] == OSH_EDGE_MONO &&
+                            !(x - 1 > cnt[j] && p.edge_pose[order[x - 2]] == p.edge_pose[order[x]]);
+          if (!pair) {
+            set_error("window %d: landmark %d is observed twice by keyframe %d with edge kinds that do not form a left + right pair", w, j, p.edge_pose[order[x]]);
+            return OSH_ERR_UNSUPPORTED;
+          }
+          continue;   // the pair's block is the first edge's
         }
         if (p.edge_pose[order[x]] < d.N) h_lmpe[(size_t)d.lmpose_off + (size_t)j * d.N + p.edge_pose[order[x]]] = x;
       }

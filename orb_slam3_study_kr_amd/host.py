@@ -356,12 +356,16 @@ class HostInertialGraph:
             pose[k, :4] = _quat_from_R(w.pose_Rcw.reshape(-1, 3, 3)[k])
             pose[k, 4:] = w.pose_tcw.reshape(-1, 3)[k]
         cam5, inv = _f32(w.cam), _f32(synth.INV_LEVEL_SIGMA2)
-        octave = _i32(np.round(np.log(1.0 / w.edge_info) / np.log(1.44)).astype(np.int32))
-        obs, mp_pos = _f32(w.edge_obs), _f32(w.points)
+        # a fisheye rig window: OSH_EDGE_RIGHT edges are right-camera observations, registered after the left ones (set_rig below)
+        right = w.edge_kind == capi.OSH_EDGE_RIGHT
+        left = ~right
+        all_octave = _i32(np.round(np.log(1.0 / w.edge_info) / np.log(1.44)).astype(np.int32))
+        octave = _i32(all_octave[left])
+        obs, mp_pos = _f32(w.edge_obs[left]), _f32(w.points)
         self.g = C.c_void_p(self.lib.osh_host_graph_create(
             K, capi.ptr(self.kf_id, capi.c_int64_p), capi.ptr(pose, capi.c_float_p), capi.ptr(cam5, capi.c_float_p),
             capi.ptr(inv, capi.c_float_p), len(inv), w.n_points, capi.ptr(self.mp_id, capi.c_int64_p), capi.ptr(mp_pos, capi.c_float_p),
-            w.n_edges, capi.ptr(_i32(w.edge_pose), capi.c_int32_p), capi.ptr(_i32(w.edge_point), capi.c_int32_p),
+            int(left.sum()), capi.ptr(_i32(w.edge_pose[left]), capi.c_int32_p), capi.ptr(_i32(w.edge_point[left]), capi.c_int32_p),
             capi.ptr(obs, capi.c_float_p), capi.ptr(octave, capi.c_int32_p), -1 & 0x7FFFFFFF, 1))
         n_imu = N + w.n_fixed_imu
         kf_index = _i32(np.arange(n_imu))
@@ -380,6 +384,13 @@ class HostInertialGraph:
                                              capi.ptr(cov, capi.c_float_p), capi.ptr(tbc_qt, capi.c_float_p))
         if w.kb8 is not None:     # monocular fisheye map: every keyframe's mpCamera is one KannalaBrandt8
             self.lib.osh_host_graph_set_fisheye(self.g, capi.ptr(_f32(w.kb8), capi.c_float_p))
+        if w.cam2 is not None:    # fisheye stereo rig: right camera, Trl and the right-camera observations
+            r_uv = _f32(w.edge_obs[right][:, :2])
+            rc = self.lib.osh_host_graph_set_rig(self.g, capi.ptr(_f32(w.cam2), capi.c_float_p), capi.ptr(_f32(w.gt["trl_qt"]), capi.c_float_p),
+                                                 int(right.sum()), capi.ptr(_i32(w.edge_pose[right]), capi.c_int32_p),
+                                                 capi.ptr(_i32(w.edge_point[right]), capi.c_int32_p), capi.ptr(r_uv, capi.c_float_p),
+                                                 capi.ptr(_i32(all_octave[right]), capi.c_int32_p))
+            assert rc == 0
         self.cur = N - 1
 
     def close(self):
@@ -417,7 +428,7 @@ class HostInertialGraph:
             link_info=arr(p.link_info, NL * 81).reshape(NL, 81), link_info_g=arr(p.link_info_g, NL * 9).reshape(NL, 9),
             link_info_a=arr(p.link_info_a, NL * 9).reshape(NL, 9), link_robust=arr(p.link_robust, NL, np.uint8),
             lambda_init=1e-2 if large else 1.0, max_iterations=4 if large else 10,
-            kb8=arr(p.kb8, 4) if p.kb8 else None).normalise()
+            kb8=arr(p.kb8, 4) if p.kb8 else None, cam2=arr(p.cam2, 8) if p.cam2 else None, trl=arr(p.trl, 12) if p.trl else None).normalise()
         return w, kid[:Kp], mid[:L]
 
     def run(self, large=False, rec_init=False):

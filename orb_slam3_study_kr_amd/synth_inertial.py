@@ -146,6 +146,8 @@ class LibaWindow:
     lambda_init: float = 1.0
     max_iterations: int = 10
     kb8: np.ndarray | None = None   # [4] KannalaBrandt8 k1..k4 (monocular fisheye window)
+    cam2: np.ndarray | None = None  # [8] right camera of a fisheye stereo rig: fx fy cx cy k1..k4 (edges of kind OSH_EDGE_RIGHT)
+    trl: np.ndarray | None = None   # [12] rows of [Rrl | trl] (float32 values)
     gt: dict | None = None
 
     _F64 = ("pose_Rcw", "pose_tcw", "pose_Rwb", "pose_twb", "Rcb", "tcb", "tbc", "cam", "vel", "bias_g", "bias_a", "points",
@@ -190,6 +192,10 @@ class LibaWindow:
         if self.kb8 is not None:
             self.kb8 = np.ascontiguousarray(self.kb8, dtype=np.float64)
         p.kb8 = capi.ptr(self.kb8, capi.c_double_p)
+        if self.cam2 is not None:
+            self.cam2 = np.ascontiguousarray(self.cam2, dtype=np.float64)
+            self.trl = np.ascontiguousarray(self.trl, dtype=np.float64)
+        p.cam2, p.trl = capi.ptr(self.cam2, capi.c_double_p), capi.ptr(self.trl, capi.c_double_p)
         return p
 
 
@@ -362,4 +368,55 @@ def make_inertial_window(seed: int = 11, n_opt: int = 10, n_fixed: int = 20, n_p
         lambda_init=1e-2 if large else 1.0, max_iterations=4 if large else 10,
         gt=dict(Rwb=gt_Rwb, twb=gt_twb, vel=gt_vel, points=Xw, outliers=eout, bg=bg_true, ba=ba_true, link_cov=np.stack(covs),
                 Tbc=T_BC, nga=nga, walk=walk))
+    return w.normalise()
+
+
+def make_inertial_rig_window(seed: int = 11, right_frac: float = 0.5, right_only_frac: float = 0.1, **kwargs) -> LibaWindow:
+    """A LocalInertialBA window of a fisheye STEREO rig (KeyFrame::mpCamera2 != NULL, src/Optimizer.cc:2798-2835): the monocular
+    fisheye window of ``make_inertial_window(fisheye=True)`` whose observations gain, with probability ``right_frac``, an
+    EdgeMono(1) of the same landmark in the same keyframe (OSH_EDGE_RIGHT) and are, with probability ``right_only_frac``, replaced
+    by the right-camera observation alone.  The right edge's information follows the reference's expression
+    ``mvInvLevelSigma2[kpUn.octave]`` with kpUn the LEFT keypoint declared in the same loop iteration (:2821): the left
+    observation's level when there is one, level 0 (a default-constructed cv::KeyPoint) when there is none."""
+    w = make_inertial_window(seed, fisheye=True, **kwargs)
+    rng = np.random.Generator(np.random.PCG64(seed + 15485863))
+    cam2 = np.array([float(synth.FX) * 1.01, float(synth.FY) * 0.99, float(synth.CX) + 3.0, float(synth.CY) - 2.0,
+                     *(synth.KB8_K * np.array([1.05, 0.9, 1.1, 1.0]))]).astype(np.float32).astype(np.float64)
+    rv = np.array([0.01, -0.02, 0.005])
+    ang = np.linalg.norm(rv)
+    q = np.concatenate([np.sin(ang / 2) * rv / ang, [np.cos(ang / 2)]])
+    Rrl = synth._quat_to_R(q).astype(np.float32).astype(np.float64)     # Sophus::SE3f::matrix() holds float32 values
+    trl_t = np.array([-0.1, 0.002, 0.001], dtype=np.float32).astype(np.float64)
+    trl = np.concatenate([Rrl, trl_t[:, None]], axis=1).reshape(12)
+    gt = w.gt
+    Rbc, tbc = gt["Tbc"][:3, :3], gt["Tbc"][:3, 3]
+    E = w.n_edges
+    u = rng.uniform(0, 1, E)
+    add_right = u < right_frac
+    right_only = (u >= right_frac) & (u < right_frac + right_only_frac)
+    ep, el, ek, eo, ei = [], [], [], [], []
+    for e in range(E):
+        ip, il = int(w.edge_pose[e]), int(w.edge_point[e])
+        if add_right[e] or right_only[e]:
+            Rwb, twb = gt["Rwb"][ip], gt["twb"][ip]
+            Rwc = Rwb @ Rbc
+            twc = Rwb @ tbc + twb
+            Xl = Rwc.T @ (gt["points"][il] - twc)
+            Xr = Rrl @ Xl + trl_t
+            rho = np.hypot(Xr[0], Xr[1])
+            theta = np.arctan2(rho, Xr[2])
+            rr = theta + cam2[4] * theta**3 + cam2[5] * theta**5 + cam2[6] * theta**7 + cam2[7] * theta**9
+            sigma = float(synth.SCALE_FACTORS[int(rng.integers(0, synth.N_LEVELS))])
+            uv = np.array([cam2[0] * rr * Xr[0] / rho + cam2[2], cam2[1] * rr * Xr[1] / rho + cam2[3]])
+            uv = uv + rng.standard_normal(2) * sigma + (rng.standard_normal(2) * 20.0 if rng.uniform() < 0.03 else 0.0)
+        if not right_only[e]:
+            ep.append(ip); el.append(il); ek.append(capi.OSH_EDGE_MONO); eo.append(w.edge_obs[e]); ei.append(w.edge_info[e])
+        if add_right[e] or right_only[e]:
+            ep.append(ip); el.append(il); ek.append(capi.OSH_EDGE_RIGHT); eo.append([uv[0], uv[1], -1.0])
+            ei.append(float(w.edge_info[e]) if not right_only[e] else float(synth.INV_LEVEL_SIGMA2[0]))
+    w.edge_pose, w.edge_point, w.edge_kind = np.array(ep, dtype=np.int32), np.array(el, dtype=np.int32), np.array(ek, dtype=np.uint8)
+    w.edge_obs = np.asarray(eo, dtype=np.float32).astype(np.float64)
+    w.edge_info = np.array(ei, dtype=np.float64)
+    w.cam2, w.trl = cam2, trl
+    w.gt["trl_qt"] = np.concatenate([q, trl_t]).astype(np.float32)      # the Sophus::SE3f a KeyFrame stores (mTrl)
     return w.normalise()

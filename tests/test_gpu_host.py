@@ -639,6 +639,43 @@ def test_local_inertial_ba_through_the_reference_signature(ob, fisheye):
             assert g.lib.osh_host_kf_observes(g.g, k, j) == (0 if out[e] else 1)
 
 
+def test_local_inertial_ba_fisheye_stereo_rig(ob):
+    """LocalInertialBA on a fisheye stereo rig map (KeyFrame::mpCamera2): EdgeMono(1) edges through the reference signature, against
+    the oracle on the packed problem; an outlying right-camera observation erases the (keyframe, map point) pair like a left one
+    (vpEdgesMono holds both, src/Optimizer.cc:2828-2831, 2855-2873)."""
+    from orb_slam3_study_kr_amd import synth_inertial as si
+    w = si.make_inertial_rig_window(53, n_opt=6, n_fixed=5, n_points=500)
+    with host.HostInertialGraph(w) as g:
+        pw, kid, mid = g.packed_window()
+        assert (pw.edge_kind == capi.OSH_EDGE_RIGHT).sum() > 400
+        ref = ob.liba_solve(pw)
+        assert g.run() == 0
+        kf_index = {int(i): k for k, i in enumerate(g.kf_id)}
+        for n, kf in enumerate(kid[:pw.n_opt]):
+            k = kf_index[int(kf)]
+            qt = g.kf_pose(k).astype(np.float64)
+            np.testing.assert_allclose(qt[4:], ref.pose_tcw[n], rtol=2e-6, atol=2e-6)
+            np.testing.assert_allclose(quat_R(qt[:4]), ref.pose_Rcw[n], atol=2e-6)
+            np.testing.assert_allclose(g.kf_velocity(k), ref.vel[n], rtol=1e-5, atol=2e-6)
+        mp_index = {int(i): k for k, i in enumerate(g.mp_id)}
+        got_pts = np.stack([g.mp_pos(mp_index[int(i)]) for i in mid]).astype(np.float64)
+        np.testing.assert_allclose(got_pts, ref.points, rtol=2e-3, atol=2e-3)
+        thr = float(np.float32(1.5) * np.float32(5.991))           # test-double map points have mTrackDepth 0: "close"
+        out = (ref.edge_chi2 > thr) | (ref.edge_depth_pos == 0)
+        near = np.abs(ref.edge_chi2 - thr) < 1e-3
+        # the pair (keyframe, map point) is erased when ANY of its edges is an outlier
+        erased, unsure = {}, set()
+        for e in range(pw.n_edges):
+            key = (kf_index[int(kid[pw.edge_pose[e]])], mp_index[int(mid[pw.edge_point[e]])])
+            erased[key] = erased.get(key, False) or bool(out[e])
+            if near[e]:
+                unsure.add(key)
+        assert sum(erased.values()) > 5
+        for key, gone in erased.items():
+            if key not in unsure:
+                assert g.lib.osh_host_kf_observes(g.g, key[0], key[1]) == (0 if gone else 1)
+
+
 def quat_R(q):
     return synth.quat_to_R(np.asarray(q) / np.linalg.norm(q))
 

@@ -88,3 +88,22 @@ def test_monocular_fisheye_inertial_window(solver, ob):
     w.edge_kind[5] = 1
     with pytest.raises(RuntimeError, match="KannalaBrandt8"):
         solver.solve_inertial([w])
+
+
+def test_fisheye_stereo_rig_right_camera_edges(solver, ob):
+    """LocalInertialBA of a fisheye stereo rig (KeyFrame::mpCamera2, src/Optimizer.cc:2798-2835): EdgeMono(1) edges on camera 1 of
+    ImuCamPose, alone or on the same (keyframe, landmark) Hessian block as the left EdgeMono(0); the right edge's information is the
+    reference's `mvInvLevelSigma2[kpUn.octave]` of the LEFT keypoint variable."""
+    w = si.make_inertial_rig_window(17, n_opt=6, n_fixed=6, n_points=700)
+    k = w.edge_kind
+    assert (k == 2).sum() > 500 and ((k[1:] == 2) & (k[:-1] == 0) & (w.edge_pose[1:] == w.edge_pose[:-1]) & (w.edge_point[1:] == w.edge_point[:-1])).sum() > 300
+    ref = ob.liba_solve(w)
+    assert ref.iterations >= 3 and ref.chi2_final < 0.1 * ref.chi2_initial
+    _check(solver.solve_inertial([w])[0], ref, w, pts_tol=2e-4, edge_tol=2e-3)      # fisheye tolerances, see the monocular test
+    ws = [w, si.make_inertial_window(14, n_opt=4, n_fixed=4, n_points=400), si.make_inertial_rig_window(18, n_opt=3, n_fixed=2, n_points=200)]
+    for g, wi in zip(solver.solve_inertial(ws), ws):
+        _check(g, ob.liba_solve(wi), wi, pts_tol=2e-4 if wi.kb8 is not None else 1e-6, edge_tol=2e-3 if wi.kb8 is not None else 1e-4)
+    w2 = si.make_inertial_window(13, n_opt=3, n_fixed=2, n_points=100, fisheye=True)
+    w2.edge_kind[3] = 2                                            # a right-camera edge without cam2 / trl
+    with pytest.raises(RuntimeError, match="right-camera"):
+        solver.solve_inertial([w2])

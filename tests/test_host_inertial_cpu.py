@@ -62,3 +62,28 @@ def test_window_selection_and_packing():
     with host.HostInertialGraph(w) as g:
         pl, _, _ = g.packed_window(large=True)
     assert (pl.lambda_init, pl.max_iterations) == (1e-2, 4)
+
+
+def test_fisheye_rig_window_packs_right_camera_edges_with_the_left_keypoints_level():
+    """src/Optimizer.cc:2798-2835: a keyframe with mpCamera2 contributes an EdgeMono(1) per right-camera observation; its
+    information is mvInvLevelSigma2[kpUn.octave] with kpUn the LEFT keypoint of the same observation (level 0 when there is none)."""
+    from orb_slam3_study_kr_amd import capi
+    w = si.make_inertial_rig_window(9, n_opt=4, n_fixed=3, n_points=150)
+    with host.HostInertialGraph(w) as g:
+        pw, kid, mid = g.packed_window()
+    assert pw.cam2 is not None and pw.trl is not None and pw.kb8 is not None
+    np.testing.assert_array_equal(pw.cam2, w.cam2)
+    np.testing.assert_allclose(pw.trl, w.trl, atol=1e-6)          # float quaternion -> float rotation matrix in the keyframe
+    right = pw.edge_kind == capi.OSH_EDGE_RIGHT
+    assert right.sum() > 100 and (pw.edge_kind[~right] == capi.OSH_EDGE_MONO).all()
+    # every packed right edge: same (keyframe, landmark) as a window right edge, same observation, the window's information rule
+    key = {(int(w.edge_pose[e]), int(w.edge_point[e])): e for e in np.nonzero(w.edge_kind == capi.OSH_EDGE_RIGHT)[0]}
+    kf_index = {int(i): k for k, i in enumerate(g.kf_id)}
+    mp_index = {int(i): k for k, i in enumerate(g.mp_id)}
+    for e in np.nonzero(right)[0]:
+        src = key[(kf_index[int(kid[pw.edge_pose[e]])], mp_index[int(mid[pw.edge_point[e]])])]
+        np.testing.assert_array_equal(pw.edge_obs[e, :2], np.float32(w.edge_obs[src, :2]).astype(np.float64))
+        assert pw.edge_info[e] == np.float32(w.edge_info[src])
+    # a pair sits left edge first, right edge next (the reference's insertion order)
+    pairs = right[1:] & ~right[:-1] & (pw.edge_pose[1:] == pw.edge_pose[:-1]) & (pw.edge_point[1:] == pw.edge_point[:-1])
+    assert pairs.sum() > 50

@@ -110,3 +110,35 @@ def test_full_inertial_lm_converges_and_is_consistent():
     wl = si.make_inertial_window(12, large=True)
     rl = ob.liba_solve(wl)
     assert rl.iterations <= 4 and abs(rl.lambda_trace[0] - 1e-2 / 3) < 1e-12
+
+
+def test_fisheye_rig_right_camera_edges_vs_numeric_dense_system():
+    """LocalInertialBA on a fisheye stereo rig (src/Optimizer.cc:2798-2835): EdgeMono(1) edges on camera 1 of ImuCamPose, alone or
+    sharing their (keyframe, landmark) Hessian block with the left EdgeMono(0).  The oracle's analytic blocks against central
+    differences of the numpy model (which forms camera 1 as Trl * Tc0w)."""
+    w = si.make_inertial_rig_window(7, n_opt=3, n_fixed=2, n_points=60, right_frac=0.5, right_only_frac=0.2)
+    kinds = w.edge_kind
+    pairs = np.sum((kinds[1:] == 2) & (kinds[:-1] == 0) & (w.edge_pose[1:] == w.edge_pose[:-1]) & (w.edge_point[1:] == w.edge_point[:-1]))
+    assert pairs > 20 and np.sum(kinds == 2) > pairs + 5
+    lin = ob.liba_linearize(w)
+    st = ln.State(w)
+    np.testing.assert_allclose(lin["chi2"], ln.robust_chi2(st), rtol=1e-6)
+    Hn, bn = ln.numeric_dense_system(st)
+    N, L = w.n_opt, w.n_points
+    n = 15 * N
+    H = np.zeros_like(Hn)
+    H[:n, :n] = lin["H"]
+    for j in range(L):
+        H[n + 3 * j:n + 3 * j + 3, n + 3 * j:n + 3 * j + 3] = lin["Hll"][j]
+    for e in range(w.n_edges):
+        k, j = int(w.edge_pose[e]), int(w.edge_point[e])
+        if k < N:   # the second edge of a pair leaves its own slot zero: its block was added to the first's
+            H[6 * k:6 * k + 6, n + 3 * j:n + 3 * j + 3] += lin["Hpl"][e]
+            H[n + 3 * j:n + 3 * j + 3, 6 * k:6 * k + 6] += lin["Hpl"][e].T
+    assert np.abs(H - Hn).max() < 2e-4 * np.abs(Hn).max()
+    assert np.abs(lin["b"] - bn).max() < 2e-4 * np.abs(bn).max()
+    # the full LM loop converges and keeps both cameras consistent with the body pose
+    wf = si.make_inertial_rig_window(13)
+    r = ob.liba_solve(wf)
+    assert 0 < r.iterations <= 10 and r.chi2_final < 0.05 * r.chi2_initial
+    assert np.abs(r.pose_twb - wf.gt["twb"][:wf.n_opt]).max() < 0.01
