@@ -214,6 +214,62 @@ typedef struct osh_pose_result {
 
 int osh_pose_optimize(osh_lba_ctx* ctx, int32_t n, const osh_pose_problem* problems, osh_pose_result* results);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Pose + velocity + bias optimisation of a tracked frame against its IMU preintegration: the solver part of
+ * Optimizer::PoseInertialOptimizationLastKeyFrame (src/Optimizer.cc:4499-4899, mode 0) and
+ * Optimizer::PoseInertialOptimizationLastFrame (src/Optimizer.cc:4901-5299, mode 1).
+ *   vertices  current frame: VertexPose (ImuCamPose, body-frame update), VertexVelocity, VertexGyroBias, VertexAccBias;
+ *             previous state (the last keyframe, FIXED, in mode 0; the previous frame, FREE, in mode 1): the same four
+ *   edges     EdgeMonoOnlyPose / EdgeStereoOnlyPose per matched map point (OSH_EDGE_MONO / _STEREO / _RIGHT = EdgeMonoOnlyPose(Xw, 1)),
+ *             EdgeInertial(previous -> current), EdgeGyroRW, EdgeAccRW, and in mode 1 EdgePriorPoseImu on the previous frame
+ *             (Huber delta `huber_prior`)
+ *   solver    Gauss-Newton, dense Hessian (15 or 30 unknowns), four rounds of optimize(iterations[r]); after each round every visual
+ *             edge is classified (float chi2 against chi2_mono/stereo[r], 1.5x for close points, depth test for mono edges) and
+ *             outliers leave the active set; round 2 drops the Huber kernels of the visual edges.  As in g2o's Gauss-Newton the
+ *             errors an inlier is classified with are the ones computed at the START of the round's last iteration.
+ *   result    the frame's state, mvbOutlier, nInitialCorrespondences - nBad, and the Hessian the reference assembles for the frame's
+ *             ConstraintPoseImu (mode 0: 15x15; mode 1: 30x30 over [previous, current] BEFORE Optimizer::Marginalize), row-major.
+ * One frame per block on the device; `n` frames per call. */
+typedef struct osh_posei_problem {
+  int32_t mode;               /* 0: ...LastKeyFrame, 1: ...LastFrame */
+  int32_t n_edges;
+  int32_t rec_init;           /* bRecInit: skips the recovery pass for frames with fewer than 30 inliers */
+  const double* Rcw; const double* tcw; const double* Rwb; const double* twb;   /* [9] [3] [9] [3] ImuCamPose(Frame*) of the current frame */
+  const double* vel; const double* bias_g; const double* bias_a;                /* [3] each */
+  const double* prev_Rwb; const double* prev_twb; const double* prev_vel; const double* prev_bias_g; const double* prev_bias_a;
+  const double* Rcb; const double* tcb; const double* tbc;   /* [9] [3] [3] mImuCalib */
+  const double* cam;          /* [5] fx fy cx cy bf */
+  const double* kb8;          /* NULL or [4]: the camera is a KannalaBrandt8 */
+  const double* cam2;         /* NULL or [8]: right camera of a fisheye rig (OSH_EDGE_RIGHT edges) */
+  const double* trl;          /* NULL or [12]: rows of [Rrl | trl] as in osh_liba_problem */
+  const float*  preint;       /* [OSH_PREINT_FLOATS] mpImuPreintegrated (mode 0) / mpImuPreintegratedFrame (mode 1) */
+  const double* info_inertial;/* [81] EdgeInertial information */
+  const double* info_g; const double* info_a;   /* [9] each: C.block<3,3>(9,9)^-1, C.block<3,3>(12,12)^-1 */
+  const double* prior_Rwb; const double* prior_twb; const double* prior_vel; const double* prior_bg; const double* prior_ba;   /* mode 1: mpcpi of the previous frame */
+  const double* prior_H;      /* [225] */
+  const double* points;       /* [n_edges*3] */
+  const uint8_t* edge_kind;   /* [n_edges] */
+  const double* edge_obs;     /* [n_edges*3] */
+  const double* edge_info;    /* [n_edges] */
+  const uint8_t* edge_close;  /* [n_edges] 1: pFrame->mvpMapPoints[idx]->mTrackDepth < 10 */
+  double huber_mono, huber_stereo, huber_prior;
+  float chi2_mono[4], chi2_stereo[4];
+  int32_t iterations[4];
+} osh_posei_problem;
+
+typedef struct osh_posei_result {
+  double Rcw[9], tcw[3], Rwb[9], twb[3], vel[3], bias_g[3], bias_a[3];
+  uint8_t* outlier;           /* [n_edges] mvbOutlier at return (may be NULL) */
+  double* edge_chi2;          /* [n_edges] chi2 of every edge as last computed (may be NULL) */
+  int32_t n_bad;              /* nBad at return: the function returns nInitialCorrespondences - n_bad */
+  int32_t n_inliers;          /* nInliers of the last round */
+  int32_t rounds;
+  int32_t status;
+  double H[900];              /* mode 0: 15x15 in the first 225 entries; mode 1: 30x30 */
+} osh_posei_result;
+
+int osh_posei_optimize(osh_lba_ctx* ctx, int32_t n, const osh_posei_problem* problems, osh_posei_result* results);
+
 /* Statistics of the Schur work plan of the resident batch: {items, symmetric items, v_mfma_f64_16x16x4 instructions of one
  * pass over every window, useful 6x6x3 products of one pass (upper triangle), contribution slots, reduce entries}. */
 int osh_lba_get_plan_stats(osh_lba_ctx* ctx, int64_t stats[6]);

@@ -340,3 +340,49 @@ def orb_match_last_frame_rig(query, desc, n_left, candl, candr, query_angle, ang
     cnt = lib.oracle_orb_match_last_frame_rig(nq, int(n_left), int(n - n_left), _u8(query), _u8(desc), _i32(candl[0]), _i32(candl[1]),
                                               _i32(candr[0]), _i32(candr[1]), capi.ptr(qa, fp), capi.ptr(al, fp), capi.ptr(ar, fp), th_high, int(check_orientation), _u8(occ), _i32(assign))
     return int(cnt), assign, occ
+
+
+def posei_optimize(f):
+    """Optimizer::PoseInertialOptimizationLastKeyFrame / LastFrame restatement (liba_oracle.c)."""
+    from orb_slam3_study_kr_amd import synth_inertial as si
+    lib = load()
+    lib.oracle_posei_optimize.restype = C.c_int
+    lib.oracle_posei_optimize.argtypes = [C.POINTER(capi.PoseiProblem), C.POINTER(capi.PoseiResult)]
+    prob = f.as_struct()
+    res = si.PoseiResultArrays(f)
+    rc = lib.oracle_posei_optimize(C.byref(prob), C.byref(res.struct))
+    if rc != 0:
+        raise RuntimeError(f"oracle_posei_optimize failed: {rc}")
+    return res.read(res.struct, f.mode)
+
+
+def posei_linearize(f):
+    lib = load()
+    d = C.POINTER(C.c_double)
+    lib.oracle_posei_linearize.restype = C.c_int
+    lib.oracle_posei_linearize.argtypes = [C.POINTER(capi.PoseiProblem), d, d]
+    n = 30 if f.mode == 1 else 15
+    H, b = np.zeros((n, n)), np.zeros(n)
+    prob = f.as_struct()
+    lib.oracle_posei_linearize(C.byref(prob), _d(H), _d(b))
+    return H, b
+
+
+def marginalize_previous(H30):
+    lib = load()
+    d = C.POINTER(C.c_double)
+    lib.oracle_marginalize_previous.restype = None
+    lib.oracle_marginalize_previous.argtypes = [d, d]
+    H30 = np.ascontiguousarray(H30, dtype=np.float64)
+    out = np.zeros((15, 15))
+    lib.oracle_marginalize_previous(_d(H30), _d(out))
+    return out
+
+
+def constraint_pose_imu_H(H15):
+    lib = load()
+    lib.oracle_constraint_pose_imu_H.restype = None
+    lib.oracle_constraint_pose_imu_H.argtypes = [C.POINTER(C.c_double)]
+    H = np.array(H15, dtype=np.float64).reshape(15, 15).copy()
+    lib.oracle_constraint_pose_imu_H(_d(H))
+    return H

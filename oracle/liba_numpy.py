@@ -198,3 +198,108 @@ def numeric_dense_system(st, delta_pose=1e-6, delta_bias=2e-3):
         H += Ji.T @ (rho1 * Om) @ Ji
         b += -Ji.T @ (rho1 * Om @ r)
     return H, b
+
+
+# --------------------------------------------------------------------------- PoseInertialOptimizationLastKeyFrame / LastFrame
+class PoseiState:
+    """State of Optimizer::PoseInertialOptimization* (src/Optimizer.cc:4499-5299): the frame's ImuCamPose / velocity / biases and the
+    previous state; unknown order [cur pose 6, v 3, bg 3, ba 3] then, in mode 1, the same for the previous frame."""
+
+    def __init__(self, f):
+        self.f = f
+        self.Rwb, self.twb, self.Rcw, self.tcw = f.Rwb.reshape(3, 3).copy(), f.twb.copy(), f.Rcw.reshape(3, 3).copy(), f.tcw.copy()
+        self.v, self.bg, self.ba = f.vel.copy(), f.bias_g.copy(), f.bias_a.copy()
+        self.pRwb, self.ptwb = f.prev_Rwb.reshape(3, 3).copy(), f.prev_twb.copy()
+        self.pv, self.pbg, self.pba = f.prev_vel.copy(), f.prev_bias_g.copy(), f.prev_bias_a.copy()
+
+    def copy(self):
+        s = PoseiState.__new__(PoseiState)
+        s.f = self.f
+        for k in ("Rwb", "twb", "Rcw", "tcw", "v", "bg", "ba", "pRwb", "ptwb", "pv", "pbg", "pba"):
+            setattr(s, k, getattr(self, k).copy())
+        return s
+
+    def oplus(self, x):
+        f = self.f
+        Rcb, tcb = f.Rcb.reshape(3, 3), f.tcb
+        if np.any(x[:6] != 0):
+            self.twb = self.twb + self.Rwb @ x[3:6]
+            self.Rwb = self.Rwb @ exp_so3(x[:3])
+            self.Rcw = Rcb @ self.Rwb.T
+            self.tcw = Rcb @ (-self.Rwb.T @ self.twb) + tcb
+        self.v, self.bg, self.ba = self.v + x[6:9], self.bg + x[9:12], self.ba + x[12:15]
+        if f.mode == 1:
+            self.ptwb = self.ptwb + self.pRwb @ x[18:21]
+            self.pRwb = self.pRwb @ exp_so3(x[15:18])
+            self.pv, self.pbg, self.pba = self.pv + x[21:24], self.pbg + x[24:27], self.pba + x[27:30]
+
+
+class _LinkView:
+    """Adapter: the two states of a PoseiState as a one-link window for ``inertial_residual``."""
+
+    def __init__(self, st):
+        f = st.f
+
+        class W:
+            pass
+        self.w = W()
+        self.w.link_preint, self.w.link_prev, self.w.link_cur = f.preint.reshape(1, -1), np.array([0]), np.array([1])
+        self.Rwb, self.twb = np.stack([st.pRwb, st.Rwb]), np.stack([st.ptwb, st.twb])
+        self.vel, self.bg, self.ba = np.stack([st.pv, st.v]), np.stack([st.pbg, st.bg]), np.stack([st.pba, st.ba])
+
+
+def posei_visual_residual(st, e, smooth=False):
+    f = st.f
+    kind = int(f.edge_kind[e])
+    fx, fy, cx, cy, bf = f.cam
+    Xc = st.Rcw @ f.points[e] + st.tcw
+    if kind == 2:
+        T = np.asarray(f.trl).reshape(3, 4)
+        Xc = T[:, :3] @ Xc + T[:, 3]
+        u, v = _kb8_project(f.cam2[:4], f.cam2[4:], Xc, smooth)
+        return np.array([f.edge_obs[e, 0] - u, f.edge_obs[e, 1] - v])
+    if f.kb8 is not None:
+        u, v = _kb8_project(f.cam[:4], f.kb8, Xc, smooth)
+    else:
+        u, v = fx * Xc[0] / Xc[2] + cx, fy * Xc[1] / Xc[2] + cy
+    if kind == 1:
+        return np.array([f.edge_obs[e, 0] - u, f.edge_obs[e, 1] - v, f.edge_obs[e, 2] - (u - bf / Xc[2])])
+    return np.array([f.edge_obs[e, 0] - u, f.edge_obs[e, 1] - v])
+
+
+def posei_residual_blocks(st, smooth=False):
+    """[(residual, information, huber delta or None)]: visual edges, EdgeInertial, EdgeGyroRW, EdgeAccRW, EdgePriorPoseImu."""
+    f = st.f
+    out = []
+    for e in range(f.n_edges):
+        r = posei_visual_residual(st, e, smooth)
+        out.append((r, np.eye(len(r)) * f.edge_info[e], f.huber_stereo if f.edge_kind[e] == 1 else f.huber_mono))
+    out.append((inertial_residual(_LinkView(st), 0), f.info_inertial.reshape(9, 9), None))
+    out.append((st.bg - st.pbg, f.info_g.reshape(3, 3), None))
+    out.append((st.ba - st.pba, f.info_a.reshape(3, 3), None))
+    if f.mode == 1:
+        Rp = f.prior_Rwb.reshape(3, 3)
+        r = np.concatenate([log_so3(Rp.T @ st.pRwb), Rp.T @ (st.ptwb - f.prior_twb), st.pv - f.prior_vel, st.pbg - f.prior_bg, st.pba - f.prior_ba])
+        out.append((r, f.prior_H.reshape(15, 15), f.huber_prior))
+    return out
+
+
+def posei_numeric_system(st, delta_pose=1e-6, delta_bias=2e-3):
+    """Dense Gauss-Newton system from central differences of every residual block (Huber weights at the current state)."""
+    n = 30 if st.f.mode == 1 else 15
+    blocks0 = posei_residual_blocks(st)
+    J = [np.zeros((len(r), n)) for r, _, _ in blocks0]
+    for j in range(n):
+        d = delta_bias if (j % 15) >= 9 else delta_pose
+        e = np.zeros(n); e[j] = d
+        sp, sm = st.copy(), st.copy()
+        sp.oplus(e); sm.oplus(-e)
+        bp, bm = posei_residual_blocks(sp, smooth=True), posei_residual_blocks(sm, smooth=True)
+        for i in range(len(blocks0)):
+            J[i][:, j] = (bp[i][0] - bm[i][0]) / (2 * d)
+    H, b = np.zeros((n, n)), np.zeros(n)
+    for (r, Om, delta), Ji in zip(blocks0, J):
+        rho1 = huber(float(r @ Om @ r), delta)[1] if delta is not None else 1.0
+        H += Ji.T @ (rho1 * Om) @ Ji
+        b += -Ji.T @ (rho1 * Om @ r)
+    return H, b

@@ -295,39 +295,35 @@ static void vis_jac(const istate* s, int e, double* JX, double* Jp) {
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 6; ++j) Jp[i * 6 + j] = M[i * 3] * D[j] + M[i * 3 + 1] * D[6 + j] + M[i * 3 + 2] * D[12 + j];
 }
 
-/* EdgeInertial::computeError (src/G2oTypes.cc:513-533); also returns pieces for the Jacobians */
-static void inertial_error(const istate* s, int l, double* r) {
-  const osh_liba_problem* p = s->pr;
+/* EdgeInertial::computeError (src/G2oTypes.cc:513-533) on explicit vertex values (1 = earlier, 2 = later state) */
+static void inertial_error_core(const float* rec, const double* Rwb1, const double* twb1, const double* v1, const double* bg1, const double* ba1,
+                                const double* Rwb2, const double* twb2, const double* v2, double* r) {
   preint_t pi;
-  preint_load(p->link_preint + (size_t)l * OSH_PREINT_FLOATS, &pi);
-  const int a = p->link_prev[l], c = p->link_cur[l];
+  preint_load(rec, &pi);
   const double dt = (double)pi.dT;
   double dR[9], dV[3], dP[3];
-  preint_deltas(&pi, s->bg + 3 * a, s->ba + 3 * a, dR, dV, dP, NULL);
-  const double* Rwb1 = s->Rwb + 9 * a; const double* Rwb2 = s->Rwb + 9 * c;
+  preint_deltas(&pi, bg1, ba1, dR, dV, dP, NULL);
   double T[9], eR[9], Rbw1[9];
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rbw1[i * 3 + j] = Rwb1[j * 3 + i];
   m3_tmul(dR, Rbw1, T); /* dR^T Rbw1 */
   m3_mul(T, Rwb2, eR);
   oracle_log_so3(eR, r);
   double t[3];
-  for (int i = 0; i < 3; ++i) t[i] = s->vel[3 * c + i] - s->vel[3 * a + i] - (i == 2 ? -kG : 0.0) * dt;
+  for (int i = 0; i < 3; ++i) t[i] = v2[i] - v1[i] - (i == 2 ? -kG : 0.0) * dt;
   m3_tvec(Rwb1, t, t);
   for (int i = 0; i < 3; ++i) r[3 + i] = t[i] - dV[i];
-  for (int i = 0; i < 3; ++i) t[i] = s->twb[3 * c + i] - s->twb[3 * a + i] - s->vel[3 * a + i] * dt - (i == 2 ? -kG : 0.0) * dt * dt / 2;
+  for (int i = 0; i < 3; ++i) t[i] = twb2[i] - twb1[i] - v1[i] * dt - (i == 2 ? -kG : 0.0) * dt * dt / 2;
   m3_tvec(Rwb1, t, t);
   for (int i = 0; i < 3; ++i) r[6 + i] = t[i] - dP[i];
 }
 /* EdgeInertial::linearizeOplus (src/G2oTypes.cc:535-594): J[v] 9 x dim(v) for v = P1(6) V1(3) G1(3) A1(3) P2(6) V2(3), packed 9 x 24 */
-static void inertial_jac(const istate* s, int l, double* J) {
-  const osh_liba_problem* p = s->pr;
+static void inertial_jac_core(const float* rec, const double* Rwb1, const double* twb1, const double* v1, const double* bg1, const double* ba1,
+                              const double* Rwb2, const double* twb2, const double* v2, double* J) {
   preint_t pi;
-  preint_load(p->link_preint + (size_t)l * OSH_PREINT_FLOATS, &pi);
-  const int a = p->link_prev[l], c = p->link_cur[l];
+  preint_load(rec, &pi);
   const double dt = (double)pi.dT;
   double dR[9], dV[3], dP[3], dbg[3];
-  preint_deltas(&pi, s->bg + 3 * a, s->ba + 3 * a, dR, dV, dP, dbg);
-  const double* Rwb1 = s->Rwb + 9 * a; const double* Rwb2 = s->Rwb + 9 * c;
+  preint_deltas(&pi, bg1, ba1, dR, dV, dP, dbg);
   double Rbw1[9], eR[9], T[9], er[3], invJr[9];
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rbw1[i * 3 + j] = Rwb1[j * 3 + i];
   m3_tmul(dR, Rbw1, T); m3_mul(T, Rwb2, eR);
@@ -339,9 +335,9 @@ static void inertial_jac(const istate* s, int l, double* J) {
   double M[9], v[3], W[9];
   /* Pose 1 */
   m3_tmul(Rwb2, Rwb1, M); m3_mul(invJr, M, M); PUT(0, 0, M, -1.0);
-  for (int i = 0; i < 3; ++i) v[i] = s->vel[3 * c + i] - s->vel[3 * a + i] - (i == 2 ? -kG : 0.0) * dt;
+  for (int i = 0; i < 3; ++i) v[i] = v2[i] - v1[i] - (i == 2 ? -kG : 0.0) * dt;
   m3_vec(Rbw1, v, v); m3_hat(v, W); PUT(3, 0, W, 1.0);
-  for (int i = 0; i < 3; ++i) v[i] = s->twb[3 * c + i] - s->twb[3 * a + i] - s->vel[3 * a + i] * dt - 0.5 * (i == 2 ? -kG : 0.0) * dt * dt;
+  for (int i = 0; i < 3; ++i) v[i] = twb2[i] - twb1[i] - v1[i] * dt - 0.5 * (i == 2 ? -kG : 0.0) * dt * dt;
   m3_vec(Rbw1, v, v); m3_hat(v, W); PUT(6, 0, W, 1.0);
   { const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; PUT(6, 3, I, -1.0); }
   /* Velocity 1 */
@@ -364,6 +360,18 @@ static void inertial_jac(const istate* s, int l, double* J) {
   PUT(3, 21, Rbw1, 1.0);
 #undef PUT
 #undef JB
+}
+static void inertial_error(const istate* s, int l, double* r) {
+  const osh_liba_problem* p = s->pr;
+  const int a = p->link_prev[l], c = p->link_cur[l];
+  inertial_error_core(p->link_preint + (size_t)l * OSH_PREINT_FLOATS, s->Rwb + 9 * a, s->twb + 3 * a, s->vel + 3 * a, s->bg + 3 * a, s->ba + 3 * a,
+                      s->Rwb + 9 * c, s->twb + 3 * c, s->vel + 3 * c, r);
+}
+static void inertial_jac(const istate* s, int l, double* J) {
+  const osh_liba_problem* p = s->pr;
+  const int a = p->link_prev[l], c = p->link_cur[l];
+  inertial_jac_core(p->link_preint + (size_t)l * OSH_PREINT_FLOATS, s->Rwb + 9 * a, s->twb + 3 * a, s->vel + 3 * a, s->bg + 3 * a, s->ba + 3 * a,
+                    s->Rwb + 9 * c, s->twb + 3 * c, s->vel + 3 * c, J);
 }
 
 static int lnk_off(const istate* s, int v /*0..5 vertex of the inertial edge*/, int l, int* dim) {
@@ -757,5 +765,390 @@ int oracle_liba_solve(const osh_liba_problem* p, osh_liba_result* res) {
       res->edge_depth_pos[e] = (R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + (right ? s.tcw1 : s.tcw)[3 * k + 2]) > 0.0;
     }
   istate_free(&s);
+  return OSH_OK;
+}
+
+/* ==================================================================================================================
+ * Optimizer::PoseInertialOptimizationLastKeyFrame (src/Optimizer.cc:4499-4899, mode 0) and
+ * Optimizer::PoseInertialOptimizationLastFrame (src/Optimizer.cc:4901-5299, mode 1): Gauss-Newton
+ * (g2o/core/optimization_algorithm_gauss_newton.cpp:49-90) with the dense LDL^T of LinearSolverDense
+ * (g2o/solvers/linear_solver_dense.h:60-118) on the frame's pose / velocity / biases.
+ * ================================================================================================================== */
+typedef struct {
+  const osh_posei_problem* p;
+  int rig;
+  double Rcw[9], tcw[3], Rwb[9], twb[3], v[3], bg[3], ba[3], Rcw1[9], tcw1[3];   /* current frame, camera 0 and camera 1 */
+  double pRwb[9], ptwb[3], pv[3], pbg[3], pba[3];                                 /* previous state */
+  double Rrl[9], trl[3], Rcb1[9], tcb1[3], tbc1[3];
+} pstate;
+
+static void pi_cams_from_body(pstate* s) {   /* ImuCamPose::Update tail (src/G2oTypes.cc:212-218) */
+  const osh_posei_problem* p = s->p;
+  double Rbw[9], tbw[3], t[3];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rbw[i * 3 + j] = s->Rwb[j * 3 + i];
+  m3_vec(Rbw, s->twb, tbw);
+  for (int i = 0; i < 3; ++i) tbw[i] = -tbw[i];
+  m3_mul(p->Rcb, Rbw, s->Rcw);
+  m3_vec(p->Rcb, tbw, t);
+  for (int i = 0; i < 3; ++i) s->tcw[i] = t[i] + p->tcb[i];
+  if (s->rig) {
+    m3_mul(s->Rcb1, Rbw, s->Rcw1);
+    m3_vec(s->Rcb1, tbw, t);
+    for (int i = 0; i < 3; ++i) s->tcw1[i] = t[i] + s->tcb1[i];
+  }
+}
+static void pi_cam_point(const pstate* s, int e, double* Xc) {
+  const osh_posei_problem* p = s->p;
+  const int right = p->edge_kind[e] == OSH_EDGE_RIGHT;
+  m3_vec(right ? s->Rcw1 : s->Rcw, p->points + 3 * (size_t)e, Xc);
+  for (int i = 0; i < 3; ++i) Xc[i] += (right ? s->tcw1 : s->tcw)[i];
+}
+/* EdgeMonoOnlyPose / EdgeStereoOnlyPose computeError (include/G2oTypes.h:399-405,475-481; ImuCamPose::Project / ProjectStereo) */
+static void pi_vis_error(const pstate* s, int e, double* r) {
+  const osh_posei_problem* p = s->p;
+  const int kind = p->edge_kind[e];
+  double Xc[3], uv[2];
+  pi_cam_point(s, e, Xc);
+  if (kind == OSH_EDGE_RIGHT) oracle_kb8_project(p->cam2, p->cam2 + 4, Xc, uv);
+  else if (p->kb8) oracle_kb8_project(p->cam, p->kb8, Xc, uv);
+  else { uv[0] = p->cam[0] * Xc[0] / Xc[2] + p->cam[2]; uv[1] = p->cam[1] * Xc[1] / Xc[2] + p->cam[3]; }
+  r[0] = p->edge_obs[3 * (size_t)e] - uv[0];
+  r[1] = p->edge_obs[3 * (size_t)e + 1] - uv[1];
+  r[2] = 0;
+  if (kind == OSH_EDGE_STEREO) { const double invZ = 1 / Xc[2]; r[2] = p->edge_obs[3 * (size_t)e + 2] - (uv[0] - p->cam[4] * invZ); }
+}
+static double pi_vis_chi2(const pstate* s, int e, const double* r) {
+  const double w = s->p->edge_info[e];
+  return s->p->edge_kind[e] == OSH_EDGE_STEREO ? r[0] * (w * r[0]) + r[1] * (w * r[1]) + r[2] * (w * r[2]) : r[0] * (w * r[0]) + r[1] * (w * r[1]);
+}
+/* linearizeOplus of the two unary edges (src/G2oTypes.cc:375-395,429-455): Jp 3x6 (row 2 zero for the mono kinds) */
+static void pi_vis_jac(const pstate* s, int e, double* Jp) {
+  const osh_posei_problem* p = s->p;
+  const int kind = p->edge_kind[e], right = kind == OSH_EDGE_RIGHT;
+  double Xc[3], Xb[3], Rbc[9], pj[9], M[9];
+  pi_cam_point(s, e, Xc);
+  const double* Rcb = right ? s->Rcb1 : p->Rcb;
+  const double* tbc = right ? s->tbc1 : p->tbc;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rbc[i * 3 + j] = Rcb[j * 3 + i];
+  m3_vec(Rbc, Xc, Xb);
+  for (int i = 0; i < 3; ++i) Xb[i] += tbc[i];
+  memset(pj, 0, sizeof(pj));
+  if (right) oracle_kb8_project_jac(p->cam2, p->cam2 + 4, Xc, pj);
+  else if (p->kb8) oracle_kb8_project_jac(p->cam, p->kb8, Xc, pj);
+  else { pj[0] = p->cam[0] / Xc[2]; pj[2] = -p->cam[0] * Xc[0] / (Xc[2] * Xc[2]); pj[4] = p->cam[1] / Xc[2]; pj[5] = -p->cam[1] * Xc[1] / (Xc[2] * Xc[2]); }
+  if (kind == OSH_EDGE_STEREO) { const double inv_z2 = 1.0 / (Xc[2] * Xc[2]); pj[6] = pj[0]; pj[7] = pj[1]; pj[8] = pj[2] + p->cam[4] * inv_z2; }
+  const double x = Xb[0], y = Xb[1], z = Xb[2];
+  const double D[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
+  m3_mul(pj, Rcb, M);
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 6; ++j) Jp[i * 6 + j] = M[i * 3] * D[j] + M[i * 3 + 1] * D[6 + j] + M[i * 3 + 2] * D[12 + j];
+}
+static int pi_depth_positive(const pstate* s, int e) {
+  const int right = s->p->edge_kind[e] == OSH_EDGE_RIGHT;
+  const double* R = right ? s->Rcw1 : s->Rcw; const double* X = s->p->points + 3 * (size_t)e;
+  return (R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + (right ? s->tcw1 : s->tcw)[2]) > 0.0;
+}
+/* EdgePriorPoseImu (src/G2oTypes.cc:731-763): residual 15, Jacobian 15 x 15 over (pose 6, v 3, bg 3, ba 3) of the previous frame */
+static void pi_prior(const pstate* s, double* r, double* J) {
+  const osh_posei_problem* p = s->p;
+  double T[9], d[3];
+  m3_tmul(p->prior_Rwb, s->pRwb, T);
+  oracle_log_so3(T, r);
+  for (int i = 0; i < 3; ++i) d[i] = s->ptwb[i] - p->prior_twb[i];
+  m3_tvec(p->prior_Rwb, d, r + 3);
+  for (int i = 0; i < 3; ++i) { r[6 + i] = s->pv[i] - p->prior_vel[i]; r[9 + i] = s->pbg[i] - p->prior_bg[i]; r[12 + i] = s->pba[i] - p->prior_ba[i]; }
+  if (!J) return;
+  double invJr[9];
+  inv_right_jac(r, invJr);
+  memset(J, 0, sizeof(double) * 225);
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { J[i * 15 + j] = invJr[i * 3 + j]; J[(3 + i) * 15 + 3 + j] = T[i * 3 + j]; }
+  for (int i = 6; i < 15; ++i) J[i * 15 + i] = 1.0;
+}
+/* dense LDL^T solve; fails unless every pivot is positive (Eigen::LDLT::isPositive) */
+static int pi_solve(int n, double* A, const double* b, double* x) {
+  for (int k = 0; k < n; ++k) {
+    const double dk = A[k * n + k];
+    if (!(dk > 0.0)) return 0;
+    for (int i = k + 1; i < n; ++i) {
+      const double l = A[k * n + i] / dk;
+      for (int j = i; j < n; ++j) A[i * n + j] -= l * A[k * n + j];
+      A[i * n + k] = l;
+    }
+  }
+  for (int i = 0; i < n; ++i) { double t = b[i]; for (int k = 0; k < i; ++k) t -= A[i * n + k] * x[k]; x[i] = t; }
+  for (int i = 0; i < n; ++i) x[i] /= A[i * n + i];
+  for (int i = n - 1; i >= 0; --i) { double t = x[i]; for (int k = i + 1; k < n; ++k) t -= A[k * n + i] * x[k]; x[i] = t; }
+  return 1;
+}
+/* adds J^T W J (columns ca..ca+da x cb..cb+db of a d-row Jacobian with leading dimension ld) into H at (oa, ob) and its mirror */
+static void pi_add(double* H, int n, const double* J, int ld, int d, const double* W, int ca, int da, int oa, int cb, int db, int ob) {
+  for (int i = 0; i < da; ++i)
+    for (int j = 0; j < db; ++j) {
+      double acc = 0;
+      for (int k = 0; k < d; ++k) { double t = 0; for (int m = 0; m < d; ++m) t += W[k * d + m] * J[m * ld + cb + j]; acc += J[k * ld + ca + i] * t; }
+      H[(size_t)(oa + i) * n + ob + j] += acc;
+      if (oa != ob) H[(size_t)(ob + j) * n + oa + i] += acc;
+    }
+}
+static void pi_pose_update(double* Rwb, double* twb, const double* pu) {   /* ImuCamPose::Update (src/G2oTypes.cc:187-210) */
+  double t[3], E[9];
+  m3_vec(Rwb, pu + 3, t);
+  for (int i = 0; i < 3; ++i) twb[i] += t[i];
+  oracle_exp_so3(pu, E);
+  m3_mul(Rwb, E, Rwb);
+}
+/* symmetric eigen-decomposition by cyclic Jacobi rotations: A (n x n, symmetric) -> eigenvalues w, eigenvectors in the columns of V */
+static void pi_sym_eig(int n, double* A, double* w, double* V) {
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) V[i * n + j] = (i == j);
+  for (int sweep = 0; sweep < 100; ++sweep) {
+    double off = 0;
+    for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) off += A[i * n + j] * A[i * n + j];
+    if (off < 1e-300) break;
+    for (int p = 0; p < n; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        if (A[p * n + q] == 0.0) continue;
+        const double theta = (A[q * n + q] - A[p * n + p]) / (2 * A[p * n + q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+        const double c = 1 / sqrt(t * t + 1), sn = t * c;
+        for (int k = 0; k < n; ++k) { const double akp = A[k * n + p], akq = A[k * n + q]; A[k * n + p] = c * akp - sn * akq; A[k * n + q] = sn * akp + c * akq; }
+        for (int k = 0; k < n; ++k) { const double apk = A[p * n + k], aqk = A[q * n + k]; A[p * n + k] = c * apk - sn * aqk; A[q * n + k] = sn * apk + c * aqk; }
+        for (int k = 0; k < n; ++k) { const double vkp = V[k * n + p], vkq = V[k * n + q]; V[k * n + p] = c * vkp - sn * vkq; V[k * n + q] = sn * vkp + c * vkq; }
+      }
+  }
+  for (int i = 0; i < n; ++i) w[i] = A[i * n + i];
+}
+/* Optimizer::Marginalize(H, 0, 14) of a 30x30 H followed by .block<15,15>(15,15) (src/Optimizer.cc:2967-3050, :5293-5294):
+ * Hc - Hcb pinv(Hb) Hbc with the pseudo-inverse from the singular values above 1e-6 (symmetric Hb: |eigenvalues|) */
+void oracle_marginalize_previous(const double* H30, double* out15) {
+  double Hb[225], w[15], V[225], inv[225];
+  for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) Hb[i * 15 + j] = 0.5 * (H30[i * 30 + j] + H30[j * 30 + i]);
+  pi_sym_eig(15, Hb, w, V);
+  for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) {
+    double t = 0;
+    for (int k = 0; k < 15; ++k) if (fabs(w[k]) > 1e-6) t += V[i * 15 + k] * V[j * 15 + k] / w[k];
+    inv[i * 15 + j] = t;
+  }
+  for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) {
+    double acc = H30[(15 + i) * 30 + 15 + j];
+    for (int k = 0; k < 15; ++k) { double t = 0; for (int m = 0; m < 15; ++m) t += inv[k * 15 + m] * H30[m * 30 + 15 + j]; acc -= H30[(15 + i) * 30 + k] * t; }
+    out15[i * 15 + j] = acc;
+  }
+}
+/* ConstraintPoseImu constructor (include/G2oTypes.h:711-722): symmetrise, zero the eigenvalues below 1e-12, rebuild */
+void oracle_constraint_pose_imu_H(double* H15) {
+  double A[225], w[15], V[225];
+  for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) A[i * 15 + j] = 0.5 * (H15[i * 15 + j] + H15[j * 15 + i]);
+  pi_sym_eig(15, A, w, V);
+  for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) {
+    double t = 0;
+    for (int k = 0; k < 15; ++k) if (!(w[k] < 1e-12)) t += V[i * 15 + k] * w[k] * V[j * 15 + k];
+    H15[i * 15 + j] = t;
+  }
+}
+
+/* computeActiveErrors + buildSystem of one Gauss-Newton iteration: unknowns [cur P V G A] then, in mode 1, [prev P V G A]
+ * (vertex ids 0..3, 4..7); err receives the errors of the active visual edges */
+static void pi_build_system(pstate* s, const unsigned char* level, int robust, double* err, double* H, double* b) {
+  const osh_posei_problem* p = s->p;
+  const int E = p->n_edges, mode1 = p->mode == 1, n = mode1 ? 30 : 15;
+  /* computeActiveErrors */
+  for (int e = 0; e < E; ++e) if (!level[e]) pi_vis_error(s, e, err + 3 * (size_t)e);
+  double ri[9], Ji[9 * 24], rp[15], Jp15[225];
+  inertial_error_core(p->preint, s->pRwb, s->ptwb, s->pv, s->pbg, s->pba, s->Rwb, s->twb, s->v, ri);
+  /* buildSystem: unknowns [cur P V G A] then, in mode 1, [prev P V G A] (vertex ids 0..3, 4..7) */
+  memset(H, 0, sizeof(double) * (size_t)n * n); memset(b, 0, sizeof(double) * n);
+  for (int e = 0; e < E; ++e) {
+    if (level[e]) continue;
+    const double* r = err + 3 * (size_t)e;
+    const double w = p->edge_info[e];
+    double rho[3] = {0, 1, 0}, J[18];
+    if (robust) oracle_huber(pi_vis_chi2(s, e, r), p->edge_kind[e] == OSH_EDGE_STEREO ? p->huber_stereo : p->huber_mono, rho);
+    pi_vis_jac(s, e, J);
+    const double ww = rho[1] * w;
+    for (int i = 0; i < 6; ++i) {
+      b[i] += J[i] * (-(w * r[0]) * rho[1]) + J[6 + i] * (-(w * r[1]) * rho[1]) + J[12 + i] * (-(w * r[2]) * rho[1]);
+      for (int j = 0; j < 6; ++j) H[i * n + j] += (J[i] * ww) * J[j] + (J[6 + i] * ww) * J[6 + j] + (J[12 + i] * ww) * J[12 + j];
+    }
+  }
+  inertial_jac_core(p->preint, s->pRwb, s->ptwb, s->pv, s->pbg, s->pba, s->Rwb, s->twb, s->v, Ji);
+  {
+    /* EdgeInertial vertices (P1 V1 G1 A1 P2 V2): columns 0 6 9 12 15 21; offsets in the unknown vector (-1 fixed) */
+    static const int col[6] = {0, 6, 9, 12, 15, 21}, dim[6] = {6, 3, 3, 3, 6, 3};
+    const int off[6] = {mode1 ? 15 : -1, mode1 ? 21 : -1, mode1 ? 24 : -1, mode1 ? 27 : -1, 0, 6};
+    double wr[9];
+    for (int i = 0; i < 9; ++i) { double t = 0; for (int j = 0; j < 9; ++j) t += p->info_inertial[i * 9 + j] * ri[j]; wr[i] = -t; }
+    for (int va = 0; va < 6; ++va) {
+      if (off[va] < 0) continue;
+      for (int i = 0; i < dim[va]; ++i) { double t = 0; for (int k = 0; k < 9; ++k) t += Ji[k * 24 + col[va] + i] * wr[k]; b[off[va] + i] += t; }
+      for (int vb = va; vb < 6; ++vb) {
+        if (off[vb] < 0) continue;
+        pi_add(H, n, Ji, 24, 9, p->info_inertial, col[va], dim[va], off[va], col[vb], dim[vb], off[vb]);
+      }
+    }
+  }
+  for (int which = 0; which < 2; ++which) {   /* EdgeGyroRW / EdgeAccRW: r = b_cur - b_prev, J = [-I, I] */
+    const double* Og = which == 0 ? p->info_g : p->info_a;
+    const double* c2 = which == 0 ? s->bg : s->ba; const double* c1 = which == 0 ? s->pbg : s->pba;
+    const int o2 = 9 + 3 * which, o1 = mode1 ? 24 + 3 * which : -1;
+    double r[3], Or[3];
+    for (int i = 0; i < 3; ++i) r[i] = c2[i] - c1[i];
+    for (int i = 0; i < 3; ++i) Or[i] = -(Og[i * 3] * r[0] + Og[i * 3 + 1] * r[1] + Og[i * 3 + 2] * r[2]);
+    for (int i = 0; i < 3; ++i) {
+      b[o2 + i] += Or[i];
+      if (o1 >= 0) b[o1 + i] += -Or[i];
+      for (int j = 0; j < 3; ++j) {
+        H[(o2 + i) * n + o2 + j] += Og[i * 3 + j];
+        if (o1 >= 0) { H[(o1 + i) * n + o1 + j] += Og[i * 3 + j]; H[(o1 + i) * n + o2 + j] += -Og[i * 3 + j]; H[(o2 + j) * n + o1 + i] += -Og[i * 3 + j]; }
+      }
+    }
+  }
+  if (mode1) {   /* EdgePriorPoseImu, Huber(huber_prior) */
+    pi_prior(s, rp, Jp15);
+    double rho[3], W[225], wr[15];
+    oracle_huber(quad(rp, p->prior_H, 15), p->huber_prior, rho);
+    for (int i = 0; i < 225; ++i) W[i] = rho[1] * p->prior_H[i];
+    for (int i = 0; i < 15; ++i) { double t = 0; for (int j = 0; j < 15; ++j) t += p->prior_H[i * 15 + j] * rp[j]; wr[i] = -t * rho[1]; }
+    for (int i = 0; i < 15; ++i) { double t = 0; for (int k = 0; k < 15; ++k) t += Jp15[k * 15 + i] * wr[k]; b[15 + i] += t; }
+    /* the prior's four vertices are contiguous in the unknown vector: one 15x15 block (BaseMultiEdge adds every vertex pair) */
+    for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) {
+      double acc = 0;
+      for (int k = 0; k < 15; ++k) { double t = 0; for (int m = 0; m < 15; ++m) t += W[k * 15 + m] * Jp15[m * 15 + j]; acc += Jp15[k * 15 + i] * t; }
+      H[(15 + i) * n + 15 + j] += acc;
+    }
+  }
+}
+
+static int pi_init(pstate* s, const osh_posei_problem* p) {
+  memset(s, 0, sizeof(*s));
+  s->p = p;
+  const int E = p->n_edges;
+  s->rig = (p->kb8 && p->cam2 && p->trl) ? 1 : 0;
+  memcpy(s->Rcw, p->Rcw, 72); memcpy(s->tcw, p->tcw, 24); memcpy(s->Rwb, p->Rwb, 72); memcpy(s->twb, p->twb, 24);
+  memcpy(s->v, p->vel, 24); memcpy(s->bg, p->bias_g, 24); memcpy(s->ba, p->bias_a, 24);
+  memcpy(s->pRwb, p->prev_Rwb, 72); memcpy(s->ptwb, p->prev_twb, 24); memcpy(s->pv, p->prev_vel, 24); memcpy(s->pbg, p->prev_bias_g, 24); memcpy(s->pba, p->prev_bias_a, 24);
+  for (int e = 0; e < E; ++e) if (p->edge_kind[e] == OSH_EDGE_RIGHT && !s->rig) return 0;
+  if (s->rig) {   /* ImuCamPose(Frame*) camera 1 (src/G2oTypes->cc:104-115) */
+    double t[3], Rbc1[9];
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) s->Rrl[i * 3 + j] = p->trl[i * 4 + j]; s->trl[i] = p->trl[i * 4 + 3]; }
+    m3_mul(s->Rrl, s->Rcw, s->Rcw1);
+    m3_vec(s->Rrl, s->tcw, t); for (int i = 0; i < 3; ++i) s->tcw1[i] = t[i] + s->trl[i];
+    m3_mul(s->Rrl, p->Rcb, s->Rcb1);
+    m3_vec(s->Rrl, p->tcb, t); for (int i = 0; i < 3; ++i) s->tcb1[i] = t[i] + s->trl[i];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rbc1[i * 3 + j] = s->Rcb1[j * 3 + i];
+    m3_vec(Rbc1, s->tcb1, t); for (int i = 0; i < 3; ++i) s->tbc1[i] = -t[i];
+  }
+  return 1;
+}
+
+/* Debug / parity aid: the system of the first Gauss-Newton iteration (all edges active, Huber on) */
+int oracle_posei_linearize(const osh_posei_problem* p, double* H, double* b) {
+  pstate s;
+  if (!pi_init(&s, p)) return OSH_ERR_INVALID;
+  unsigned char* level = calloc(p->n_edges ? p->n_edges : 1, 1);
+  double* err = calloc(3 * (size_t)(p->n_edges ? p->n_edges : 1), sizeof(double));
+  pi_build_system(&s, level, 1, err, H, b);
+  free(level); free(err);
+  return OSH_OK;
+}
+
+int oracle_posei_optimize(const osh_posei_problem* p, osh_posei_result* res) {
+  pstate s;
+  if (!pi_init(&s, p)) return OSH_ERR_INVALID;
+  const int E = p->n_edges, mode1 = p->mode == 1, n = mode1 ? 30 : 15;
+  unsigned char* level = calloc(E ? E : 1, 1);     /* 1: outside the active set */
+  unsigned char* outlier = calloc(E ? E : 1, 1);   /* pFrame->mvbOutlier */
+  double* err = calloc(3 * (size_t)(E ? E : 1), sizeof(double));   /* _error of every edge as last computed */
+  double H[900], b[30], x[30], A[900];
+  memset(x, 0, sizeof(x));
+  int robust = 1, n_bad = 0, n_inliers = 0, rounds = 0;
+  const int n_graph_edges = E + (mode1 ? 4 : 3);
+  for (int round = 0; round < 4; ++round) {
+    int ok = 1, any = 0;
+    for (int e = 0; e < E; ++e) any |= !level[e];
+    (void)any;   /* the inertial edges keep the active set non-empty */
+    for (int it = 0; it < p->iterations[round] && ok; ++it) {
+      pi_build_system(&s, level, robust, err, H, b);
+      memcpy(A, H, sizeof(double) * (size_t)n * n);
+      ok = pi_solve(n, A, b, x);   /* on failure x keeps the previous iteration's values and is still applied (update() precedes the check) */
+      pi_pose_update(s.Rwb, s.twb, x);
+      pi_cams_from_body(&s);
+      for (int i = 0; i < 3; ++i) { s.v[i] += x[6 + i]; s.bg[i] += x[9 + i]; s.ba[i] += x[12 + i]; }
+      if (mode1) {
+        pi_pose_update(s.pRwb, s.ptwb, x + 15);
+        for (int i = 0; i < 3; ++i) { s.pv[i] += x[21 + i]; s.pbg[i] += x[24 + i]; s.pba[i] += x[27 + i]; }
+      }
+    }
+    /* classification (:4747-4818 / :5139-5208): an inlier keeps the error of the last computeActiveErrors (start of the last
+     * iteration), an outlier is recomputed at the final estimate; the depth test always uses the final estimate */
+    int bad = 0, inl = 0;
+    const float chi2close = 1.5 * p->chi2_mono[round];
+    for (int pass = 0; pass < 2; ++pass)
+      for (int e = 0; e < E; ++e) {
+        const int stereo = p->edge_kind[e] == OSH_EDGE_STEREO;
+        if (stereo != pass) continue;
+        if (outlier[e]) pi_vis_error(&s, e, err + 3 * (size_t)e);
+        const float chi2 = (float)pi_vis_chi2(&s, e, err + 3 * (size_t)e);
+        int out;
+        if (!stereo) {
+          const int bClose = p->edge_close ? p->edge_close[e] : 0;
+          out = (chi2 > p->chi2_mono[round] && !bClose) || (bClose && chi2 > chi2close) || !pi_depth_positive(&s, e);
+        } else out = chi2 > p->chi2_stereo[round];
+        outlier[e] = (unsigned char)out; level[e] = (unsigned char)out;
+        if (out) ++bad; else ++inl;
+      }
+    n_bad = bad; n_inliers = inl; rounds = round + 1;
+    if (round == 2) robust = 0;
+    if (n_graph_edges < 10) break;
+  }
+  if (n_inliers < 30 && !p->rec_init) {   /* recovery (:4821-4848): every edge re-evaluated, generous thresholds */
+    n_bad = 0;
+    for (int pass = 0; pass < 2; ++pass)
+      for (int e = 0; e < E; ++e) {
+        const int stereo = p->edge_kind[e] == OSH_EDGE_STEREO;
+        if (stereo != pass) continue;
+        pi_vis_error(&s, e, err + 3 * (size_t)e);
+        if (pi_vis_chi2(&s, e, err + 3 * (size_t)e) < (stereo ? 24.f : 18.f)) outlier[e] = 0; else n_bad++;
+      }
+  }
+  /* Hessian of the frame's ConstraintPoseImu (:4858-4893 / :5252-5293): every edge re-linearised at the final estimate, plain information */
+  {
+    double Ji[9 * 24];
+    const int nn = mode1 ? 30 : 15, o2 = mode1 ? 15 : 0;
+    memset(res->H, 0, sizeof(res->H));
+    inertial_jac_core(p->preint, s.pRwb, s.ptwb, s.pv, s.pbg, s.pba, s.Rwb, s.twb, s.v, Ji);
+    if (mode1) pi_add(res->H, nn, Ji, 24, 9, p->info_inertial, 0, 24, 0, 0, 24, 0);                   /* GetHessian(): 24 x 24 at (0,0) */
+    else { pi_add(res->H, nn, Ji, 24, 9, p->info_inertial, 15, 9, 0, 15, 9, 0); }                     /* GetHessian2(): (P2, V2) 9 x 9 */
+    for (int which = 0; which < 2; ++which) {
+      const double* Og = which == 0 ? p->info_g : p->info_a;
+      const int c2 = o2 + 9 + 3 * which, c1 = 9 + 3 * which;
+      for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+        res->H[(c2 + i) * nn + c2 + j] += Og[i * 3 + j];
+        if (mode1) { res->H[(c1 + i) * nn + c1 + j] += Og[i * 3 + j]; res->H[(c1 + i) * nn + c2 + j] += -Og[i * 3 + j]; res->H[(c2 + i) * nn + c1 + j] += -Og[i * 3 + j]; }
+      }
+    }
+    if (mode1) {
+      double rp[15], Jp15[225];
+      pi_prior(&s, rp, Jp15);
+      for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) {
+        double acc = 0;
+        for (int k = 0; k < 15; ++k) { double t = 0; for (int m = 0; m < 15; ++m) t += p->prior_H[k * 15 + m] * Jp15[m * 15 + j]; acc += Jp15[k * 15 + i] * t; }
+        res->H[i * nn + j] += acc;
+      }
+    }
+    for (int pass = 0; pass < 2; ++pass)
+      for (int e = 0; e < E; ++e) {
+        const int stereo = p->edge_kind[e] == OSH_EDGE_STEREO;
+        if (stereo != pass || outlier[e]) continue;
+        double J[18];
+        pi_vis_jac(&s, e, J);
+        const double w = p->edge_info[e];
+        for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) res->H[(o2 + i) * nn + o2 + j] += (J[i] * w) * J[j] + (J[6 + i] * w) * J[6 + j] + (J[12 + i] * w) * J[12 + j];
+      }
+  }
+  memcpy(res->Rcw, s.Rcw, 72); memcpy(res->tcw, s.tcw, 24); memcpy(res->Rwb, s.Rwb, 72); memcpy(res->twb, s.twb, 24);
+  memcpy(res->vel, s.v, 24); memcpy(res->bias_g, s.bg, 24); memcpy(res->bias_a, s.ba, 24);
+  if (res->outlier) memcpy(res->outlier, outlier, E);
+  if (res->edge_chi2) for (int e = 0; e < E; ++e) res->edge_chi2[e] = pi_vis_chi2(&s, e, err + 3 * (size_t)e);
+  res->n_bad = n_bad; res->n_inliers = n_inliers; res->rounds = rounds; res->status = OSH_OK;
+  free(level); free(outlier); free(err);
   return OSH_OK;
 }

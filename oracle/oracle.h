@@ -43,6 +43,10 @@ int  oracle_liba_solve(const osh_liba_problem* p, osh_liba_result* res);
 int  oracle_liba_linearize(const osh_liba_problem* p, double* H, double* b, double* Hll, double* Hpl, double* chi2);
 int  oracle_liba_inertial_edge(const osh_liba_problem* p, int link, double* r9, double* J9x24);
 void oracle_exp_so3(const double* w, double* R);
+int  oracle_posei_optimize(const osh_posei_problem* p, osh_posei_result* res);
+int  oracle_posei_linearize(const osh_posei_problem* p, double* H, double* b);
+void oracle_marginalize_previous(const double* H30, double* out15);
+void oracle_constraint_pose_imu_H(double* H15);
 void oracle_log_so3(const double* R, double* w);
 
 /* ---- ORB matching (orb_oracle.c) ---- */

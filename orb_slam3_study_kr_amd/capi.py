@@ -107,6 +107,35 @@ class LibaProblem(C.Structure):
     ]
 
 
+class PoseiProblem(C.Structure):
+    """``osh_posei_problem`` (include/orbslam3_hip.h)."""
+
+    _fields_ = [
+        ("mode", C.c_int32), ("n_edges", C.c_int32), ("rec_init", C.c_int32),
+        ("Rcw", c_double_p), ("tcw", c_double_p), ("Rwb", c_double_p), ("twb", c_double_p),
+        ("vel", c_double_p), ("bias_g", c_double_p), ("bias_a", c_double_p),
+        ("prev_Rwb", c_double_p), ("prev_twb", c_double_p), ("prev_vel", c_double_p), ("prev_bias_g", c_double_p), ("prev_bias_a", c_double_p),
+        ("Rcb", c_double_p), ("tcb", c_double_p), ("tbc", c_double_p), ("cam", c_double_p), ("kb8", c_double_p), ("cam2", c_double_p),
+        ("trl", c_double_p), ("preint", c_float_p), ("info_inertial", c_double_p), ("info_g", c_double_p), ("info_a", c_double_p),
+        ("prior_Rwb", c_double_p), ("prior_twb", c_double_p), ("prior_vel", c_double_p), ("prior_bg", c_double_p), ("prior_ba", c_double_p),
+        ("prior_H", c_double_p), ("points", c_double_p), ("edge_kind", c_uint8_p), ("edge_obs", c_double_p), ("edge_info", c_double_p),
+        ("edge_close", c_uint8_p), ("huber_mono", C.c_double), ("huber_stereo", C.c_double), ("huber_prior", C.c_double),
+        ("chi2_mono", C.c_float * 4), ("chi2_stereo", C.c_float * 4), ("iterations", C.c_int32 * 4),
+    ]
+
+
+class PoseiResult(C.Structure):
+    """``osh_posei_result`` (include/orbslam3_hip.h)."""
+
+    _fields_ = [
+        ("Rcw", C.c_double * 9), ("tcw", C.c_double * 3), ("Rwb", C.c_double * 9), ("twb", C.c_double * 3),
+        ("vel", C.c_double * 3), ("bias_g", C.c_double * 3), ("bias_a", C.c_double * 3),
+        ("outlier", c_uint8_p), ("edge_chi2", c_double_p),
+        ("n_bad", C.c_int32), ("n_inliers", C.c_int32), ("rounds", C.c_int32), ("status", C.c_int32),
+        ("H", C.c_double * 900),
+    ]
+
+
 class LibaResult(C.Structure):
     """``osh_liba_result`` (include/orbslam3_hip.h)."""
 
@@ -203,6 +232,7 @@ _SIGNATURES = {
     "osh_orb_upload": (C.c_int, [C.c_void_p, C.POINTER(OrbBatch)]),
     "osh_orb_upload_grid": (C.c_int, [C.c_void_p, C.POINTER(OrbBatch), C.POINTER(OrbGrid)]),
     "osh_orb_frustum": (C.c_int, [C.c_void_p, C.POINTER(FrustumFrame), C.POINTER(FrustumPoints), C.POINTER(FrustumResult)]),
+    "osh_posei_optimize": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(PoseiProblem), C.POINTER(PoseiResult)]),
     "osh_orb_match": (C.c_int, [C.c_void_p]),
     "osh_orb_match_local_points": (C.c_int, [C.c_void_p, C.c_float, C.c_int32, c_uint8_p, c_uint8_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p]),
     "osh_orb_download": (C.c_int, [C.c_void_p] + [c_int32_p] * 6),

@@ -420,3 +420,204 @@ def make_inertial_rig_window(seed: int = 11, right_frac: float = 0.5, right_only
     w.cam2, w.trl = cam2, trl
     w.gt["trl_qt"] = np.concatenate([q, trl_t]).astype(np.float32)      # the Sophus::SE3f a KeyFrame stores (mTrl)
     return w.normalise()
+
+
+# --------------------------------------------------------------------------- PoseInertialOptimizationLastKeyFrame / LastFrame
+@dataclass
+class PoseiFrame:
+    """Flat problem of Optimizer::PoseInertialOptimizationLastKeyFrame (mode 0) / ...LastFrame (mode 1), src/Optimizer.cc:4499-5299."""
+    mode: int
+    Rcw: np.ndarray
+    tcw: np.ndarray
+    Rwb: np.ndarray
+    twb: np.ndarray
+    vel: np.ndarray
+    bias_g: np.ndarray
+    bias_a: np.ndarray
+    prev_Rwb: np.ndarray
+    prev_twb: np.ndarray
+    prev_vel: np.ndarray
+    prev_bias_g: np.ndarray
+    prev_bias_a: np.ndarray
+    Rcb: np.ndarray
+    tcb: np.ndarray
+    tbc: np.ndarray
+    cam: np.ndarray
+    preint: np.ndarray
+    info_inertial: np.ndarray
+    info_g: np.ndarray
+    info_a: np.ndarray
+    points: np.ndarray
+    edge_kind: np.ndarray
+    edge_obs: np.ndarray
+    edge_info: np.ndarray
+    edge_close: np.ndarray
+    prior_Rwb: np.ndarray | None = None
+    prior_twb: np.ndarray | None = None
+    prior_vel: np.ndarray | None = None
+    prior_bg: np.ndarray | None = None
+    prior_ba: np.ndarray | None = None
+    prior_H: np.ndarray | None = None
+    kb8: np.ndarray | None = None
+    cam2: np.ndarray | None = None
+    trl: np.ndarray | None = None
+    rec_init: bool = False
+    huber_mono: float = synth.HUBER_MONO
+    huber_stereo: float = synth.HUBER_STEREO
+    huber_prior: float = 5.0
+    chi2_mono: tuple = (12.0, 7.5, 5.991, 5.991)
+    chi2_stereo: tuple = (15.6, 9.8, 7.815, 7.815)
+    iterations: tuple = (10, 10, 10, 10)
+    gt: dict | None = None
+
+    _F64 = ("Rcw", "tcw", "Rwb", "twb", "vel", "bias_g", "bias_a", "prev_Rwb", "prev_twb", "prev_vel", "prev_bias_g", "prev_bias_a", "Rcb", "tcb",
+            "tbc", "cam", "info_inertial", "info_g", "info_a", "points", "edge_obs", "edge_info", "prior_Rwb", "prior_twb", "prior_vel",
+            "prior_bg", "prior_ba", "prior_H", "kb8", "cam2", "trl")
+
+    @property
+    def n_edges(self):
+        return int(self.edge_kind.shape[0])
+
+    def normalise(self):
+        for k in self._F64:
+            if getattr(self, k) is not None:
+                setattr(self, k, np.ascontiguousarray(getattr(self, k), dtype=np.float64))
+        self.preint = np.ascontiguousarray(self.preint, dtype=np.float32)
+        self.edge_kind = np.ascontiguousarray(self.edge_kind, dtype=np.uint8)
+        self.edge_close = np.ascontiguousarray(self.edge_close, dtype=np.uint8)
+        return self
+
+    def as_struct(self) -> capi.PoseiProblem:
+        self.normalise()
+        p = capi.PoseiProblem()
+        p.mode, p.n_edges, p.rec_init = int(self.mode), self.n_edges, int(self.rec_init)
+        for k in self._F64:
+            setattr(p, k, capi.ptr(getattr(self, k), capi.c_double_p))
+        p.preint = capi.ptr(self.preint, capi.c_float_p)
+        p.edge_kind, p.edge_close = capi.ptr(self.edge_kind, capi.c_uint8_p), capi.ptr(self.edge_close, capi.c_uint8_p)
+        p.huber_mono, p.huber_stereo, p.huber_prior = self.huber_mono, self.huber_stereo, self.huber_prior
+        for k in range(4):
+            p.chi2_mono[k], p.chi2_stereo[k], p.iterations[k] = self.chi2_mono[k], self.chi2_stereo[k], self.iterations[k]
+        return p
+
+
+class PoseiResultArrays:
+    def __init__(self, f: PoseiFrame):
+        self.outlier = np.zeros(f.n_edges, dtype=np.uint8)
+        self.edge_chi2 = np.zeros(f.n_edges, dtype=np.float64)
+        self.struct = capi.PoseiResult()
+        self.bind(self.struct)
+
+    def bind(self, r):
+        r.outlier = capi.ptr(self.outlier, capi.c_uint8_p)
+        r.edge_chi2 = capi.ptr(self.edge_chi2, capi.c_double_p)
+
+    def read(self, r, mode):
+        for k, shape in (("Rcw", (3, 3)), ("tcw", (3,)), ("Rwb", (3, 3)), ("twb", (3,)), ("vel", (3,)), ("bias_g", (3,)), ("bias_a", (3,))):
+            setattr(self, k, np.array(getattr(r, k)[:]).reshape(shape))
+        self.n_bad, self.n_inliers, self.rounds, self.status = int(r.n_bad), int(r.n_inliers), int(r.rounds), int(r.status)
+        n = 30 if mode == 1 else 15
+        self.H = np.array(r.H[:n * n]).reshape(n, n)
+        return self
+
+
+def make_posei_frame(seed: int = 3, mode: int = 0, n_points: int = 400, stereo: bool = True, fisheye: bool = False, rig: bool = False,
+                     outlier_frac: float = 0.05, rec_init: bool = False, link_dt: float | None = None) -> PoseiFrame:
+    """A tracked frame with its IMU preintegration since the last keyframe (mode 0, 0.25 s) or since the previous frame (mode 1,
+    0.05 s), matched to ``n_points`` map points: rectified-stereo observations, monocular ones (``stereo=False``), a monocular
+    KannalaBrandt8 camera (``fisheye``) or a fisheye stereo rig whose right keypoints (index >= Nleft) are OSH_EDGE_RIGHT edges."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    fisheye = fisheye or rig
+    stereo = stereo and not fisheye
+    link_dt = link_dt if link_dt is not None else (0.25 if mode == 0 else 0.05)
+    per = int(round(link_dt * IMU_FREQ))
+    dt = 1.0 / IMU_FREQ
+    sf = np.sqrt(IMU_FREQ)
+    nga = np.array([(NG * sf) ** 2] * 3 + [(NA * sf) ** 2] * 3)
+    walk = np.array([(NGW / sf) ** 2] * 3 + [(NAW / sf) ** 2] * 3)
+    bg_true, ba_true = np.array([0.002, -0.0015, 0.003]), np.array([0.03, -0.02, 0.015])
+    Rbc, tbc = T_BC[:3, :3], T_BC[:3, 3]
+    Rcb, tcb = Rbc.T, -Rbc.T @ tbc
+    t1 = 1.0 + 0.37 * seed
+    t2 = t1 + per * dt
+    acc, gyr = [], []
+    for k in range(per):
+        t = t1 + k * dt
+        R0_, _, _, a0 = _trajectory(t)
+        R1_ = _trajectory(t + dt)[0]
+        w = log_so3(R0_.T @ R1_) / dt + rng.standard_normal(3) * NG * sf
+        f = R0_.T @ (a0 - np.array([0, 0, -GRAVITY])) + rng.standard_normal(3) * NA * sf
+        gyr.append(w + bg_true); acc.append(f + ba_true)
+    b_lin = np.concatenate([ba_true + rng.standard_normal(3) * 2e-3, bg_true + rng.standard_normal(3) * 2e-4])
+    rec, Cm = preintegrate(acc, gyr, dt, b_lin, nga, walk)
+    q = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)   # noqa: E731  float storage of frames / keyframes
+    R1, p1, v1, _ = _trajectory(t1)
+    R2, p2, v2, _ = _trajectory(t2)
+    # current frame: perturbed (the tracker's prediction), previous state: close to the truth
+    Rwb = R2 @ exp_so3(rng.standard_normal(3) * 0.01)
+    twb = p2 + rng.standard_normal(3) * 0.03
+    Rwc, twc = Rwb @ Rbc, Rwb @ tbc + twb
+    pRwb = R1 @ exp_so3(rng.standard_normal(3) * (1e-3 if mode == 1 else 0))
+    ptwb = p1 + rng.standard_normal(3) * (3e-3 if mode == 1 else 0)
+    # map points in front of the true camera
+    Rwc_t, twc_t = R2 @ Rbc, R2 @ tbc + p2
+    fx, fy, cx, cy, bf = (float(v) for v in (synth.FX, synth.FY, synth.CX, synth.CY, synth.BF))
+    Xc = np.stack([rng.uniform(-4, 4, n_points), rng.uniform(-2.5, 2.5, n_points), rng.uniform(2.0, 25.0, n_points)], axis=1)
+    Xw = Xc @ Rwc_t.T + twc_t
+    kb = synth.KB8_K
+
+    def project(cam, kbk, P):
+        if kbk is None:
+            return cam[0] * P[:, 0] / P[:, 2] + cam[2], cam[1] * P[:, 1] / P[:, 2] + cam[3]
+        th = np.arctan2(np.hypot(P[:, 0], P[:, 1]), P[:, 2])
+        ps = np.arctan2(P[:, 1], P[:, 0])
+        rr = th + kbk[0] * th**3 + kbk[1] * th**5 + kbk[2] * th**7 + kbk[3] * th**9
+        return cam[0] * rr * np.cos(ps) + cam[2], cam[1] * rr * np.sin(ps) + cam[3]
+    cam = np.array([fx, fy, cx, cy, bf])
+    u, v = project(cam, kb if fisheye else None, Xc)
+    octave = rng.integers(0, synth.N_LEVELS, n_points)
+    sig = synth.SCALE_FACTORS[octave].astype(np.float64)
+    kind = np.full(n_points, capi.OSH_EDGE_STEREO if stereo else capi.OSH_EDGE_MONO, dtype=np.uint8)
+    if stereo:
+        kind[rng.uniform(size=n_points) < 0.2] = capi.OSH_EDGE_MONO          # mvuRight < 0: no stereo match
+    obs = np.stack([u, v, u - bf / Xc[:, 2]], axis=1)
+    cam2 = trl = None
+    if rig:
+        cam2 = np.array([fx * 1.01, fy * 0.99, cx + 3.0, cy - 2.0, *(kb * np.array([1.05, 0.9, 1.1, 1.0]))]).astype(np.float32).astype(np.float64)
+        rv = np.array([0.01, -0.02, 0.005])
+        ang = np.linalg.norm(rv)
+        qq = np.concatenate([np.sin(ang / 2) * rv / ang, [np.cos(ang / 2)]])
+        Rrl = synth._quat_to_R(qq).astype(np.float32).astype(np.float64)
+        trl_t = np.array([-0.1, 0.002, 0.001], dtype=np.float32).astype(np.float64)
+        trl = np.concatenate([Rrl, trl_t[:, None]], axis=1).reshape(12)
+        right = rng.uniform(size=n_points) < 0.45                               # keypoints of the right image
+        ur, vr = project(cam2, cam2[4:], Xc @ Rrl.T + trl_t)
+        obs[right, 0], obs[right, 1] = ur[right], vr[right]
+        kind[right] = capi.OSH_EDGE_RIGHT
+    obs = obs + rng.standard_normal((n_points, 3)) * sig[:, None]
+    is_out = rng.uniform(size=n_points) < outlier_frac
+    obs += rng.standard_normal((n_points, 3)) * 25.0 * is_out[:, None]
+    obs[kind != capi.OSH_EDGE_STEREO, 2] = -1.0
+    pts = q(Xw + rng.standard_normal(Xw.shape) * 0.02)
+    f = PoseiFrame(
+        mode=mode, Rcw=q(Rwc.T), tcw=q(-Rwc.T @ twc), Rwb=q(Rwb), twb=q(twb), vel=q(v2 + rng.standard_normal(3) * 0.05),
+        bias_g=q(bg_true + rng.standard_normal(3) * 1e-4), bias_a=q(ba_true + rng.standard_normal(3) * 1e-3),
+        prev_Rwb=q(pRwb), prev_twb=q(ptwb), prev_vel=q(v1 + rng.standard_normal(3) * (5e-3 if mode == 1 else 0)),
+        prev_bias_g=q(bg_true + rng.standard_normal(3) * 1e-4), prev_bias_a=q(ba_true + rng.standard_normal(3) * 1e-3),
+        Rcb=q(Rcb), tcb=q(tcb), tbc=q(tbc), cam=q(cam), preint=rec, info_inertial=inertial_information(Cm),
+        info_g=np.linalg.inv(Cm[9:12, 9:12].astype(np.float64)), info_a=np.linalg.inv(Cm[12:15, 12:15].astype(np.float64)),
+        points=pts, edge_kind=kind, edge_obs=q(obs), edge_info=synth.INV_LEVEL_SIGMA2[octave].astype(np.float64),
+        edge_close=(Xc[:, 2] < 10.0).astype(np.uint8), kb8=kb.copy() if fisheye else None, cam2=cam2, trl=trl, rec_init=rec_init,
+        chi2_mono=(12.0, 7.5, 5.991, 5.991) if mode == 0 else (5.991, 5.991, 5.991, 5.991),
+        gt=dict(Rwb=R2, twb=p2, vel=v2, outliers=is_out))
+    if mode == 1:
+        # mpcpi of the previous frame: its state estimate at the time + a symmetric positive semi-definite information
+        Q, _ = np.linalg.qr(rng.standard_normal((15, 15)))
+        lam = 10.0 ** rng.uniform(2, 6, 15)
+        f.prior_H = (Q * lam) @ Q.T
+        f.prior_Rwb = q(R1 @ exp_so3(rng.standard_normal(3) * 1e-3))
+        f.prior_twb = q(p1 + rng.standard_normal(3) * 3e-3)
+        f.prior_vel = q(v1 + rng.standard_normal(3) * 5e-3)
+        f.prior_bg = q(bg_true + rng.standard_normal(3) * 1e-4)
+        f.prior_ba = q(ba_true + rng.standard_normal(3) * 1e-3)
+    return f.normalise()
