@@ -6,11 +6,14 @@
 #define FRAME_H
 #include <vector>
 #include "CameraModels/GeometricCamera.h"
+#include "G2oTypes.h"
+#include "ImuTypes.h"
 #include "MapPoint.h"
 #include "orbslam3_compat.h"
 #define FRAME_GRID_ROWS 48
 #define FRAME_GRID_COLS 64
 namespace ORB_SLAM3 {
+class KeyFrame;
 class Frame {
  public:
   Frame() {}
@@ -49,6 +52,22 @@ class Frame {
   Sophus::SE3f GetRelativePoseTrl() const { return mTrl; }                  // src/Frame.cc:1134-1137
   float mnMinX = 0, mnMaxX = 752, mnMinY = 0, mnMaxY = 480;   // static in the reference
   float mfGridElementWidthInv = 64.f / 752.f, mfGridElementHeightInv = 48.f / 480.f;
+  // IMU side (include/Frame.h:88-110,189-207,262-275; src/Frame.cc:447-492): what PoseInertialOptimizationLastKeyFrame / LastFrame touch
+  Eigen::Vector3f GetImuPosition() const;        // mRwc * mImuCalib.mTcb.translation() + mOw
+  Eigen::Matrix3f GetImuRotation();              // mRwc * mImuCalib.mTcb.rotationMatrix()
+  Eigen::Vector3f GetVelocity() const { return mVw; }
+  void SetVelocity(Eigen::Vector3f Vwb) { mVw = Vwb; mbHasVelocity = true; }
+  void SetImuPoseVelocity(const Eigen::Matrix3f& Rwb, const Eigen::Vector3f& twb, const Eigen::Vector3f& Vwb);
+  IMU::Calib mImuCalib;
+  IMU::Bias mImuBias;
+  IMU::Preintegrated* mpImuPreintegrated = nullptr;        // from the last keyframe
+  IMU::Preintegrated* mpImuPreintegratedFrame = nullptr;   // from the previous frame
+  KeyFrame* mpLastKeyFrame = nullptr;
+  Frame* mpPrevFrame = nullptr;
+  ConstraintPoseImu* mpcpi = nullptr;
+  Eigen::Vector3f mVw;
+  bool mbHasVelocity = false;
+  long unsigned int mnId = 0;
   Sophus::SE3f mTcw;
   Eigen::Matrix3f mRcw, mRwc;      // include/Frame.h:337-340 (private in the reference)
   Eigen::Vector3f mtcw, mOw;

@@ -18,6 +18,8 @@ class Optimizer {
   // src/Optimizer.cc:815-1114 (csrc/host/OptimizerPose.cc): pose of a tracked frame from its map-point matches, four rounds of
   // optimize(10) with outlier re-classification; returns the number of inlier correspondences and sets mvbOutlier / the pose.
   int static PoseOptimization(Frame* pFrame);
+  int static PoseInertialOptimizationLastKeyFrame(Frame* pFrame, bool bRecInit = false);   // include/Optimizer.h:60
+  int static PoseInertialOptimizationLastFrame(Frame* pFrame, bool bRecInit = false);      // include/Optimizer.h:61
   // src/Optimizer.cc:1116-1498.  num_MPs is never assigned by the reference either.
   void static LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF, int& num_OptKF,
                                     int& num_MPs, int& num_edges);

@@ -155,6 +155,20 @@ int osh_host_search_sim3(osh_host_frame* f, const float scw[8], int32_t n_mp, co
  * returns the inlier count, the optimised pose and mvbOutlier (keypoints without a match keep the value 1 they are preset to). */
 int osh_host_frame_pose_optimization(osh_host_frame* f, int32_t n_mp, const float* mp_pos, const int32_t* kp_mp,
                                      const float* inv_level_sigma2, int32_t n_levels, float pose_out[7], uint8_t* outlier_out);
+/* ---- Optimizer::PoseInertialOptimizationLastKeyFrame / LastFrame on a test frame (csrc/host/harness.cc) */
+typedef struct osh_host_posei osh_host_posei;
+osh_host_posei* osh_host_posei_create(int32_t mode, int32_t n_kp, const float* kp_xy, const int32_t* octave, const float* uright,
+                                      int32_t n_left, const float pose_qt[7], const float cam5[5], const float* kb8,
+                                      const float* cam2_8, const float* trl_qt, const float* inv_level_sigma2, int32_t n_levels,
+                                      const float* mp_pos, const uint8_t* mp_close, const float Tbc_qt[7], const float vel[3],
+                                      const float bias6[6], const float prev_pose_qt[7], const float prev_vel[3], const float prev_bias6[6],
+                                      const float* preint72, const float* cov225, const double* prior_Rwb, const double* prior_twb,
+                                      const double* prior_vel, const double* prior_bg, const double* prior_ba, const double* prior_H);
+void osh_host_posei_destroy(osh_host_posei* h);
+int osh_host_posei_pack(osh_host_posei* h, int32_t rec_init, osh_posei_problem* out, int32_t* kp_of_edge);
+int osh_host_posei_run(osh_host_posei* h, int32_t rec_init, float pose_out[7], float Rwb_out[9], float twb_out[3], float vel_out[3],
+                       float bias6_out[6], uint8_t* outlier_out, double* H225_out, int32_t* prev_cpi_deleted);
+
 #ifdef __cplusplus
 }
 #endif

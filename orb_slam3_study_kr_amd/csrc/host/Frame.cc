@@ -23,6 +23,20 @@ void Frame::UpdatePoseMatrices() {
   mtcw = mTcw.translation();
 }
 
+// src/Frame.cc:482-488 through the SE3 product Twc * Tcb (the stand-in Eigen types carry no matrix operators)
+Eigen::Vector3f Frame::GetImuPosition() const { return (mTcw.inverse() * mImuCalib.mTcb).translation(); }
+Eigen::Matrix3f Frame::GetImuRotation() { return (mTcw.inverse() * mImuCalib.mTcb).rotationMatrix(); }
+
+// src/Frame.cc:458-471
+void Frame::SetImuPoseVelocity(const Eigen::Matrix3f& Rwb, const Eigen::Vector3f& twb, const Eigen::Vector3f& Vwb) {
+  mVw = Vwb;
+  mbHasVelocity = true;
+  const Sophus::SE3f Twb(Rwb, twb);
+  mTcw = mImuCalib.mTcb * Twb.inverse();
+  ++mnPoseSets;
+  UpdatePoseMatrices();
+}
+
 int Frame::isInFrustum(const std::vector<MapPoint*>& vpMPs, float viewingCosLimit, std::vector<bool>& vbInView) {
   const int n = (int)vpMPs.size();
   vbInView.assign(n, false);

@@ -643,3 +643,131 @@ extern "C" int osh_host_frame_pose_optimization(osh_host_frame* f, int32_t n_mp,
   F.mvpMapPoints.assign(F.N, nullptr);
   return n;
 }
+
+// ------------------------------------------------------------------------------------------ PoseInertialOptimization*
+struct osh_host_posei {
+  Frame F, prevF;
+  Map map;
+  std::unique_ptr<KeyFrame> prevKF;
+  std::unique_ptr<GeometricCamera> cam, cam2;
+  std::vector<std::unique_ptr<MapPoint>> mps;
+  std::unique_ptr<IMU::Preintegrated> preint;
+  PoseiPack pack;
+  int mode = 0;
+};
+
+// A tracked frame with n_kp matched keypoints (map point k at mp_pos[k], mTrackDepth 5 or 20 by mp_close[k]) and its IMU link to the
+// last keyframe (mode 0) or to the previous frame (mode 1, with that frame's ConstraintPoseImu).  n_left < 0: monocular /
+// rectified stereo (uright >= 0: stereo keypoint); n_left >= 0: fisheye stereo rig, keypoints [0, n_left) left, the rest right.
+extern "C" osh_host_posei* osh_host_posei_create(int32_t mode, int32_t n_kp, const float* kp_xy, const int32_t* octave, const float* uright,
+                                                 int32_t n_left, const float pose_qt[7], const float cam5[5], const float* kb8,
+                                                 const float* cam2_8, const float* trl_qt, const float* inv_level_sigma2, int32_t n_levels,
+                                                 const float* mp_pos, const uint8_t* mp_close, const float Tbc_qt[7], const float vel[3],
+                                                 const float bias6[6], const float prev_pose_qt[7], const float prev_vel[3], const float prev_bias6[6],
+                                                 const float* preint72, const float* cov225, const double* prior_Rwb, const double* prior_twb,
+                                                 const double* prior_vel, const double* prior_bg, const double* prior_ba, const double* prior_H) {
+  osh_host_posei* h = new osh_host_posei();
+  h->mode = mode;
+  Frame& F = h->F;
+  if (kb8) h->cam.reset(new KannalaBrandt8(std::vector<float>{cam5[0], cam5[1], cam5[2], cam5[3], kb8[0], kb8[1], kb8[2], kb8[3]}));
+  else h->cam.reset(new Pinhole(std::vector<float>{cam5[0], cam5[1], cam5[2], cam5[3]}));
+  F.mpCamera = h->cam.get();
+  F.fx = cam5[0]; F.fy = cam5[1]; F.cx = cam5[2]; F.cy = cam5[3]; F.mbf = cam5[4];
+  F.N = n_kp;
+  F.mvInvLevelSigma2.assign(inv_level_sigma2, inv_level_sigma2 + n_levels);
+  const IMU::Calib calib(pose_from(Tbc_qt), 0.f, 0.f, 0.f, 0.f);
+  F.mImuCalib = calib;
+  F.mTcw = pose_from(pose_qt);
+  F.UpdatePoseMatrices();
+  F.SetVelocity(Eigen::Vector3f(vel[0], vel[1], vel[2]));
+  F.mImuBias = IMU::Bias(bias6[0], bias6[1], bias6[2], bias6[3], bias6[4], bias6[5]);
+  if (n_left >= 0) {
+    h->cam2.reset(new KannalaBrandt8(std::vector<float>(cam2_8, cam2_8 + 8)));
+    F.mpCamera2 = h->cam2.get();
+    F.mTrl = pose_from(trl_qt);
+    F.Nleft = n_left; F.Nright = n_kp - n_left;
+  }
+  for (int i = 0; i < n_kp; ++i) {
+    cv::KeyPoint kp;
+    kp.pt.x = kp_xy[2 * i]; kp.pt.y = kp_xy[2 * i + 1]; kp.octave = octave[i];
+    if (n_left >= 0 && i >= n_left) F.mvKeysRight.push_back(kp);
+    else { F.mvKeys.push_back(kp); F.mvKeysUn.push_back(kp); }
+    F.mvuRight.push_back(uright ? uright[i] : -1.f);
+    h->mps.emplace_back(new MapPoint((unsigned long)(1000 + i), Eigen::Vector3f(mp_pos[3 * i], mp_pos[3 * i + 1], mp_pos[3 * i + 2]), &h->map));
+    h->mps.back()->mTrackDepth = mp_close[i] ? 5.f : 20.f;
+    F.mvpMapPoints.push_back(h->mps.back().get());
+  }
+  F.mvbOutlier.assign(n_kp, true);
+  h->preint.reset(new IMU::Preintegrated(IMU::Bias(preint72[61], preint72[62], preint72[63], preint72[64], preint72[65], preint72[66]), calib));
+  IMU::Preintegrated* P = h->preint.get();
+  P->dT = preint72[0];
+  for (int a = 0; a < 9; ++a) { P->dR.v[a] = preint72[1 + a]; P->JRg.v[a] = preint72[16 + a]; P->JVg.v[a] = preint72[25 + a]; P->JVa.v[a] = preint72[34 + a]; P->JPg.v[a] = preint72[43 + a]; P->JPa.v[a] = preint72[52 + a]; }
+  for (int a = 0; a < 3; ++a) { P->dV(a) = preint72[10 + a]; P->dP(a) = preint72[13 + a]; }
+  for (int a = 0; a < 225; ++a) P->C.v[a] = cov225[a];
+  F.mpImuPreintegrated = P;          // the random-walk informations come from here in both variants
+  F.mpImuPreintegratedFrame = P;
+  if (mode == 0) {
+    h->prevKF.reset(new KeyFrame(99, &h->map));
+    KeyFrame* kf = h->prevKF.get();
+    kf->mImuCalib = calib;
+    kf->SetPose(pose_from(prev_pose_qt));
+    kf->bImu = true;
+    kf->SetVelocity(Eigen::Vector3f(prev_vel[0], prev_vel[1], prev_vel[2]));
+    kf->mImuBias = IMU::Bias(prev_bias6[0], prev_bias6[1], prev_bias6[2], prev_bias6[3], prev_bias6[4], prev_bias6[5]);
+    F.mpLastKeyFrame = kf;
+  } else {
+    Frame& Fp = h->prevF;
+    Fp.mImuCalib = calib;
+    Fp.mTcw = pose_from(prev_pose_qt);
+    Fp.UpdatePoseMatrices();
+    Fp.SetVelocity(Eigen::Vector3f(prev_vel[0], prev_vel[1], prev_vel[2]));
+    Fp.mImuBias = IMU::Bias(prev_bias6[0], prev_bias6[1], prev_bias6[2], prev_bias6[3], prev_bias6[4], prev_bias6[5]);
+    Eigen::Matrix3d R; Eigen::Vector3d t, v, bg, ba; Matrix15d H;
+    for (int a = 0; a < 9; ++a) R.v[a] = prior_Rwb[a];
+    for (int a = 0; a < 3; ++a) { t(a) = prior_twb[a]; v(a) = prior_vel[a]; bg(a) = prior_bg[a]; ba(a) = prior_ba[a]; }
+    for (int a = 0; a < 225; ++a) H.v[a] = prior_H[a];
+    Fp.mpcpi = new ConstraintPoseImu(R, t, v, bg, ba, H);
+    F.mpPrevFrame = &Fp;
+  }
+  return h;
+}
+
+extern "C" void osh_host_posei_destroy(osh_host_posei* h) {
+  if (!h) return;
+  delete h->F.mpcpi;
+  delete h->prevF.mpcpi;
+  delete h;
+}
+
+// The osh_posei_problem the host layer builds for this frame (arrays owned by the handle until the next call).
+extern "C" int osh_host_posei_pack(osh_host_posei* h, int32_t rec_init, osh_posei_problem* out, int32_t* kp_of_edge) {
+  if (!h || !out) return -1;
+  if (!PackPoseInertial(&h->F, rec_init != 0, h->mode, h->pack)) return -3;
+  h->pack.fill(*out);
+  for (size_t e = 0; e < h->pack.index.size(); ++e) kp_of_edge[e] = h->pack.index[e];
+  for (int k = 0; k < h->F.N; ++k) h->F.mvbOutlier[k] = true;
+  return 0;
+}
+
+// Optimizer::PoseInertialOptimizationLastKeyFrame / LastFrame (&frame, bRecInit): returns the function's value; outputs the frame's
+// new Tcw, IMU pose, velocity, bias, mvbOutlier, the H of its new ConstraintPoseImu and whether the previous frame's was deleted.
+extern "C" int osh_host_posei_run(osh_host_posei* h, int32_t rec_init, float pose_out[7], float Rwb_out[9], float twb_out[3], float vel_out[3],
+                                  float bias6_out[6], uint8_t* outlier_out, double* H225_out, int32_t* prev_cpi_deleted) {
+  if (!h) return -1;
+  Frame& F = h->F;
+  const int n = h->mode == 0 ? Optimizer::PoseInertialOptimizationLastKeyFrame(&F, rec_init != 0)
+                             : Optimizer::PoseInertialOptimizationLastFrame(&F, rec_init != 0);
+  const Sophus::SE3f T = F.GetPose();
+  pose_out[0] = T.unit_quaternion().x(); pose_out[1] = T.unit_quaternion().y(); pose_out[2] = T.unit_quaternion().z(); pose_out[3] = T.unit_quaternion().w();
+  pose_out[4] = T.translation()(0); pose_out[5] = T.translation()(1); pose_out[6] = T.translation()(2);
+  const Eigen::Matrix3f Rwb = F.GetImuRotation();
+  const Eigen::Vector3f twb = F.GetImuPosition(), v = F.GetVelocity();
+  for (int a = 0; a < 9; ++a) Rwb_out[a] = Rwb.v[a];
+  for (int a = 0; a < 3; ++a) { twb_out[a] = twb(a); vel_out[a] = v(a); }
+  bias6_out[0] = F.mImuBias.bax; bias6_out[1] = F.mImuBias.bay; bias6_out[2] = F.mImuBias.baz;
+  bias6_out[3] = F.mImuBias.bwx; bias6_out[4] = F.mImuBias.bwy; bias6_out[5] = F.mImuBias.bwz;
+  for (int k = 0; k < F.N; ++k) outlier_out[k] = F.mvbOutlier[k] ? 1 : 0;
+  if (F.mpcpi) for (int a = 0; a < 225; ++a) H225_out[a] = F.mpcpi->H.v[a];
+  *prev_cpi_deleted = (h->mode == 1 && h->prevF.mpcpi == nullptr) ? 1 : 0;
+  return n;
+}

@@ -1,5 +1,6 @@
 // host_pack.h -- the flattened local-BA window produced by PackLocalBA (csrc/host/Optimizer.cc).
 #pragma once
+#include <cmath>
 #include <cstdint>
 #include <list>
 #include <vector>
@@ -133,6 +134,44 @@ struct LibaPack {
     p.cam2 = has_rig ? cam2 : nullptr; p.trl = has_rig ? trl : nullptr;
   }
 };
+// Flat problem of Optimizer::PoseInertialOptimizationLastKeyFrame (mode 0) / LastFrame (mode 1), src/Optimizer.cc:4499-5299
+struct PoseiPack {
+  int mode = 0;
+  bool rec_init = false;
+  const char* unsupported = nullptr;
+  int n_mono = 0, n_stereo = 0;                 // nInitialMonoCorrespondences / nInitialStereoCorrespondences
+  std::vector<int> index;                       // keypoint of every edge
+  std::vector<double> points, edge_obs, edge_info;
+  std::vector<uint8_t> edge_kind, edge_close;
+  double Rcw[9], tcw[3], Rwb[9], twb[3], vel[3], bias_g[3], bias_a[3];
+  double prev_Rwb[9], prev_twb[3], prev_vel[3], prev_bias_g[3], prev_bias_a[3];
+  double Rcb[9], tcb[3], tbc[3], cam[5];
+  bool has_kb8 = false, has_rig = false;
+  double kb8[4] = {0, 0, 0, 0}, cam2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, trl[12] = {0};
+  float preint[OSH_PREINT_FLOATS];
+  double info_inertial[81], info_g[9], info_a[9];
+  double prior_Rwb[9], prior_twb[3], prior_vel[3], prior_bg[3], prior_ba[3], prior_H[225];
+  void fill(osh_posei_problem& p) const {
+    p.mode = mode; p.n_edges = (int32_t)index.size(); p.rec_init = rec_init ? 1 : 0;
+    p.Rcw = Rcw; p.tcw = tcw; p.Rwb = Rwb; p.twb = twb; p.vel = vel; p.bias_g = bias_g; p.bias_a = bias_a;
+    p.prev_Rwb = prev_Rwb; p.prev_twb = prev_twb; p.prev_vel = prev_vel; p.prev_bias_g = prev_bias_g; p.prev_bias_a = prev_bias_a;
+    p.Rcb = Rcb; p.tcb = tcb; p.tbc = tbc; p.cam = cam;
+    p.kb8 = has_kb8 ? kb8 : nullptr; p.cam2 = has_rig ? cam2 : nullptr; p.trl = has_rig ? trl : nullptr;
+    p.preint = preint; p.info_inertial = info_inertial; p.info_g = info_g; p.info_a = info_a;
+    const bool pr = mode == 1;
+    p.prior_Rwb = pr ? prior_Rwb : nullptr; p.prior_twb = pr ? prior_twb : nullptr; p.prior_vel = pr ? prior_vel : nullptr;
+    p.prior_bg = pr ? prior_bg : nullptr; p.prior_ba = pr ? prior_ba : nullptr; p.prior_H = pr ? prior_H : nullptr;
+    p.points = points.data(); p.edge_kind = edge_kind.data(); p.edge_obs = edge_obs.data(); p.edge_info = edge_info.data();
+    p.edge_close = edge_close.data();
+    p.huber_mono = (double)(float)std::sqrt(5.991);     // const float thHuberMono = sqrt(5.991) (:4552)
+    p.huber_stereo = (double)(float)std::sqrt(7.815);
+    p.huber_prior = 5.0;                                 // rkp->setDelta(5) (:5117)
+    const float m0[4] = {12.f, 7.5f, 5.991f, 5.991f}, m1[4] = {5.991f, 5.991f, 5.991f, 5.991f}, st[4] = {15.6f, 9.8f, 7.815f, 7.815f};
+    for (int k = 0; k < 4; ++k) { p.chi2_mono[k] = mode == 0 ? m0[k] : m1[k]; p.chi2_stereo[k] = st[k]; p.iterations[k] = 10; }   // :4714-4716 / :5121-5123
+  }
+};
+class Frame;
+bool PackPoseInertial(Frame* pFrame, bool bRecInit, int mode, PoseiPack& pk);
 bool PackLocalInertialBA(KeyFrame* pKF, Map* pMap, bool bLarge, bool bRecInit, LibaPack& pk);
 void InertialInformation(const Eigen::Matrix<float, 15, 15>& C, double* info81);
 osh_lba_ctx* HostSolverContext();   // one solver context per calling thread (Optimizer.cc)

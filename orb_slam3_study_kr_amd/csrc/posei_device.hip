@@ -1,0 +1,571 @@
+// posei_device.hip -- Optimizer::PoseInertialOptimizationLastKeyFrame / LastFrame (src/Optimizer.cc:4499-5299) on MI355X (gfx950).
+//
+// 15 unknowns (pose, velocity, gyro and accelerometer bias of the tracked frame; mode 0) or 30 (the previous frame's as well;
+// mode 1), O(10^3) unary visual edges, one EdgeInertial, two random-walk edges and, in mode 1, the EdgePriorPoseImu of the
+// previous frame.  Gauss-Newton (g2o/core/optimization_algorithm_gauss_newton.cpp:49-90): every iteration computes the errors,
+// builds the dense system, solves it (LinearSolverDense: LDL^T that must be positive, linear_solver_dense.h:60-118) and applies
+// the update; nothing is re-evaluated after the last update, so the classification after each of the four rounds sees the
+// errors of the START of the round's last iteration (an outlier is re-evaluated at the final estimate, :4763-4766).
+//
+// Like the pose-only kernel (pose_device.hip) the problem is tiny and latency-critical: ONE block per frame runs all four
+// rounds -- thread per visual edge with fixed-order block reductions, the small dense algebra of the inertial / prior edges
+// spread over the block, the 15x15 / 30x30 LDL^T in one wavefront with the pivot row broadcast by v_readlane.
+#include "common.h"
+#include "lba_math.h"
+#include "ldlt_block.h"
+#include "liba_math.h"
+#include "liba_edges.h"
+#include <cfloat>
+#include <cstring>
+#include <vector>
+
+namespace osh {
+
+constexpr int kIT = 256;   // threads per frame block
+
+struct PoseiDesc {
+  LibaDesc cam;              // camera side only: Rcb tcb tbc cam kb8 rig (the edge functions of liba_edges.h read it)
+  int mode, E, edge_off, rec_init;
+  double P[24], s[9];        // current frame: pose record Rcw tcw Rwb twb, then v bg ba
+  double pP[24], ps[9];      // previous state (Rcw / tcw unused)
+  float rec[OSH_PREINT_FLOATS];
+  double info[81], info_g[9], info_a[9];
+  double prior_R[9], prior_t[3], prior_s[9], prior_H[225];
+  double huber_mono, huber_stereo, huber_prior;
+  float chi2_mono[4], chi2_stereo[4];
+  int iters[4];
+};
+struct PoseiOut { double P[24], s[9], H[900]; int n_bad, n_inliers, rounds; };
+struct PoseiView {
+  const PoseiDesc* desc;
+  PoseiOut* out;
+  const double* X; const unsigned char* kind; const double* obs; const double* info; const unsigned char* close;
+  double* chi2; unsigned char* level; unsigned char* outlier;
+};
+
+__device__ __forceinline__ double posei_block_sum(double v, double* sh) {
+  v = dev::wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int k = 0; k < kIT / 64; ++k) t += sh[k];
+  return t;
+}
+
+// A x = b for a symmetric n x n system (n <= 32) held row-major in LDS, by ONE wavefront: lane j keeps column j, the pivot row
+// is broadcast with v_readlane; returns false unless every pivot is positive (Eigen::LDLT::isPositive).  U: 32 x 33 doubles of
+// LDS scratch for the unit upper factor; x in LDS.
+__device__ bool posei_solve_wave(const double* A, const double* b, int n, double* U, double* x) {
+  const int lane = threadIdx.x & 63;
+  const int j = lane < 32 ? lane : 0;
+  double col[32];
+#pragma unroll
+  for (int r = 0; r < 32; ++r) {
+    const bool in = r < n && j < n && r <= j;
+    const double a = A[in ? r * n + j : 0];
+    col[r] = in ? a : (r == j ? 1.0 : 0.0);
+  }
+  double zr = lane < n ? b[lane] : 0.0;
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    const double d = ldlt_readlane(col[k], k);
+    bad |= !(d > 0.0);
+    const double lk = col[k] / d;                       // l_kj in lane j (j > k)
+    const double zk = ldlt_readlane(zr, k);             // z_k is final once the steps before k have been applied
+    if (lane > k) zr -= lk * zk;
+    if (lane < 32 && lane > k) U[k * 33 + lane] = lk;
+#pragma unroll
+    for (int i = k + 1; i < 32; ++i) col[i] -= ldlt_readlane(lk, i) * col[k];
+  }
+  if (bad) return false;
+  // w = z / d, then U x = w from the last column to the first: lane r holds its running entry, the solved one is broadcast
+  double dl = 1.0;
+#pragma unroll
+  for (int r = 0; r < 32; ++r) { const double dr = ldlt_readlane(col[r], r); if (r == lane) dl = dr; }
+  double t = zr / dl;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int c = 31; c > 0; --c) {
+    const double xc = ldlt_readlane(t, c);
+    if (lane < c) t -= U[lane * 33 + c] * xc;
+  }
+  if (lane < n) x[lane] = t;
+  return true;
+}
+
+__global__ __launch_bounds__(kIT) void k_posei(PoseiView v) {
+  __shared__ double sh[kIT / 64];
+  __shared__ double shP[24], shs[9], shpP[24], shps[9];     // current / previous state
+  __shared__ double shH[900], shb[30], shx[30];
+  __shared__ double shJ[9 * 24], shWJ[15 * 30], shr[15], shJp[225];
+  __shared__ double shU[32 * 33];
+  __shared__ int sh_ok;
+  const PoseiDesc& d = v.desc[blockIdx.x];
+  PoseiOut& out = v.out[blockIdx.x];
+  const int tid = threadIdx.x;
+  const bool mode1 = d.mode == 1;
+  const int n = mode1 ? 30 : 15;
+  for (int e = tid; e < d.E; e += kIT) { const size_t ge = (size_t)d.edge_off + e; v.level[ge] = 0; v.outlier[ge] = 0; v.chi2[ge] = 0.0; }
+  if (tid < 24) { shP[tid] = d.P[tid]; shpP[tid] = d.pP[tid]; }
+  if (tid < 9) { shs[tid] = d.s[tid]; shps[tid] = d.ps[tid]; }
+  if (tid < 30) shx[tid] = 0.0;
+  __syncthreads();
+  // column of the EdgeInertial Jacobian (P1 V1 G1 A1 P2 V2) -> unknown (-1: fixed vertex)
+  auto unk_of = [&](int c) { return c >= 15 ? c - 15 : (mode1 ? 15 + c : -1); };
+  // ---- one computeActiveErrors + buildSystem: shH / shb; the errors of the active visual edges stay in v.chi2
+  auto build = [&](bool robust) {
+    for (int k = tid; k < n * n; k += kIT) shH[k] = 0.0;
+    if (tid < n) shb[tid] = 0.0;
+    double pose[24];
+#pragma unroll
+    for (int k = 0; k < 24; ++k) pose[k] = shP[k];
+    double H[21], b[6];
+#pragma unroll
+    for (int k = 0; k < 21; ++k) H[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) b[k] = 0.0;
+    for (int e = tid; e < d.E; e += kIT) {
+      const size_t ge = (size_t)d.edge_off + e;
+      if (v.level[ge]) continue;
+      const int kind = v.kind[ge];
+      const double info = v.info[ge];
+      double X[3], obs[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { X[k] = v.X[ge * 3 + k]; obs[k] = v.obs[ge * 3 + k]; }
+      VisEval ev;
+      vis_residual(d.cam, kind, pose, X, obs, info, ev);
+      v.chi2[ge] = ev.chi2;
+      double r0 = ev.chi2, r1 = 1.0, JX[9], Jp[18];
+      if (robust) dev::huber(ev.chi2, kind == OSH_EDGE_STEREO ? d.huber_stereo : d.huber_mono, r0, r1);
+      vis_jacobians(d.cam, kind, pose, ev.Xc, JX, Jp);
+      const double ww = r1 * info;
+      const double wr[3] = {-(info * ev.r[0]) * r1, -(info * ev.r[1]) * r1, -(info * ev.r[2]) * r1};
+      int m = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+#pragma unroll
+        for (int c = a; c < 6; ++c) { H[m] += (Jp[a] * ww) * Jp[c] + (Jp[6 + a] * ww) * Jp[6 + c] + (Jp[12 + a] * ww) * Jp[12 + c]; ++m; }
+        b[a] += Jp[a] * wr[0] + Jp[6 + a] * wr[1] + Jp[12 + a] * wr[2];
+      }
+    }
+    // inertial edge: residual and Jacobian by one thread, the quadratic form by the block
+    if (tid == 0) {
+      inertial_residual(d.rec, shpP, shps, shP, shs, shr);
+      inertial_jacobian(d.rec, shpP, shps, shP, shs, shJ);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 9 * 24; idx += kIT) {   // W J
+      const int k = idx / 24, c = idx - k * 24;
+      double t = 0.0;
+      for (int m = 0; m < 9; ++m) t += d.info[k * 9 + m] * shJ[m * 24 + c];
+      shWJ[idx] = t;
+    }
+    __syncthreads();
+    // visual block sums (27 fixed-order reductions), then everything else is added by the threads that own an entry
+    double red[27];
+    {
+      int m = 0;
+#pragma unroll
+      for (int k = 0; k < 21; ++k) red[m++] = posei_block_sum(H[k], sh);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) red[m++] = posei_block_sum(b[k], sh);
+    }
+    for (int idx = tid; idx < n * n; idx += kIT) {
+      const int r = idx / n, c = idx - r * n;
+      double acc = 0.0;
+      if (r < 6 && c < 6) {   // visual edges: upper-triangle sums mirrored
+        const int a = r < c ? r : c, bq = r < c ? c : r;
+        acc += red[a * 6 - a * (a - 1) / 2 + (bq - a)];
+      }
+      // EdgeInertial: J^T W J over the columns that map to unknowns r and c
+      for (int ca = 0; ca < 24; ++ca) {
+        if (unk_of(ca) != r) continue;
+        for (int cb = 0; cb < 24; ++cb) {
+          if (unk_of(cb) != c) continue;
+          double t = 0.0;
+          for (int k = 0; k < 9; ++k) t += shJ[k * 24 + ca] * shWJ[k * 24 + cb];
+          acc += t;
+        }
+      }
+      // random walks: r = b_cur - b_prev, J = [-I, I]
+      for (int which = 0; which < 2; ++which) {
+        const double* Og = which == 0 ? d.info_g : d.info_a;
+        const int o2 = 9 + 3 * which, o1 = mode1 ? 24 + 3 * which : -100;
+        const bool r2 = r >= o2 && r < o2 + 3, c2 = c >= o2 && c < o2 + 3, r1 = r >= o1 && r < o1 + 3, c1 = c >= o1 && c < o1 + 3;
+        if (r2 && c2) acc += Og[(r - o2) * 3 + (c - o2)];
+        if (r1 && c1) acc += Og[(r - o1) * 3 + (c - o1)];
+        if (r1 && c2) acc -= Og[(r - o1) * 3 + (c - o2)];
+        if (r2 && c1) acc -= Og[(c - o1) * 3 + (r - o2)];
+      }
+      shH[idx] = acc;
+    }
+    if (tid < n) {
+      double acc = tid < 6 ? red[21 + tid] : 0.0;
+      for (int ca = 0; ca < 24; ++ca) {
+        if (unk_of(ca) != tid) continue;
+        double t = 0.0;
+        for (int k = 0; k < 9; ++k) t += shWJ[k * 24 + ca] * shr[k];      // J^T (W r) = (W J)^T r, W symmetric
+        acc -= t;
+      }
+      for (int which = 0; which < 2; ++which) {
+        const double* Og = which == 0 ? d.info_g : d.info_a;
+        const int o2 = 9 + 3 * which, o1 = mode1 ? 24 + 3 * which : -100;
+        double rb[3];
+        for (int k = 0; k < 3; ++k) rb[k] = shs[3 + 3 * which + k] - shps[3 + 3 * which + k];
+        if (tid >= o2 && tid < o2 + 3) { const int i = tid - o2; acc -= Og[i * 3] * rb[0] + Og[i * 3 + 1] * rb[1] + Og[i * 3 + 2] * rb[2]; }
+        if (tid >= o1 && tid < o1 + 3) { const int i = tid - o1; acc += Og[i * 3] * rb[0] + Og[i * 3 + 1] * rb[1] + Og[i * 3 + 2] * rb[2]; }
+      }
+      shb[tid] = acc;
+    }
+    __syncthreads();
+    if (mode1) {
+      // EdgePriorPoseImu (src/G2oTypes.cc:731-763), Huber(huber_prior): residual / Jacobian by one thread, J^T W J by the block
+      if (tid == 0) {
+        double T[9], dd[3], invJr[9];
+        imu::m3_tmul(d.prior_R, shpP + 12, T);
+        imu::log_so3(T, shr);
+        for (int i = 0; i < 3; ++i) dd[i] = shpP[21 + i] - d.prior_t[i];
+        imu::m3_tvec(d.prior_R, dd, shr + 3);
+        for (int i = 0; i < 9; ++i) shr[6 + i] = shps[i] - d.prior_s[i];
+        imu::inv_right_jac(shr, invJr);
+        for (int i = 0; i < 225; ++i) shJp[i] = 0.0;
+        for (int i = 0; i < 3; ++i) for (int jq = 0; jq < 3; ++jq) { shJp[i * 15 + jq] = invJr[i * 3 + jq]; shJp[(3 + i) * 15 + 3 + jq] = T[i * 3 + jq]; }
+        for (int i = 6; i < 15; ++i) shJp[i * 15 + i] = 1.0;
+      }
+      __syncthreads();
+      double chi = 0.0;
+      if (tid < 15) { double t = 0.0; for (int m = 0; m < 15; ++m) t += d.prior_H[tid * 15 + m] * shr[m]; chi = shr[tid] * t; }
+      chi = posei_block_sum(chi, sh);
+      double r0, rho1;
+      dev::huber(chi, d.huber_prior, r0, rho1);
+      for (int idx = tid; idx < 225; idx += kIT) {   // W J with W = rho' Omega
+        const int k = idx / 15, c = idx - k * 15;
+        double t = 0.0;
+        for (int m = 0; m < 15; ++m) t += d.prior_H[k * 15 + m] * shJp[m * 15 + c];
+        shWJ[idx] = rho1 * t;
+      }
+      __syncthreads();
+      for (int idx = tid; idx < 225; idx += kIT) {
+        const int i = idx / 15, jq = idx - i * 15;
+        double t = 0.0;
+        for (int k = 0; k < 15; ++k) t += shJp[k * 15 + i] * shWJ[k * 15 + jq];
+        shH[(15 + i) * n + 15 + jq] += t;
+      }
+      if (tid < 15) { double t = 0.0; for (int k = 0; k < 15; ++k) t += shWJ[k * 15 + tid] * shr[k]; shb[15 + tid] -= t; }
+      __syncthreads();
+    }
+  };
+  // ImuCamPose::Update (src/G2oTypes.cc:187-220) of a pose record in LDS
+  auto pose_update = [&](double* P, const double* pu, bool cams) {
+    double tw[3], E[9], Rwb[9], Rbw[9], tbw[3], tc[3];
+    imu::m3_vec(P + 12, pu + 3, tw);
+    for (int i = 0; i < 3; ++i) P[21 + i] += tw[i];
+    imu::exp_so3(pu, E);
+    imu::m3_mul(P + 12, E, Rwb);
+    for (int i = 0; i < 9; ++i) P[12 + i] = Rwb[i];
+    if (!cams) return;
+    for (int i = 0; i < 3; ++i) for (int jq = 0; jq < 3; ++jq) Rbw[i * 3 + jq] = Rwb[jq * 3 + i];
+    imu::m3_vec(Rbw, P + 21, tbw);
+    tbw[0] = -tbw[0]; tbw[1] = -tbw[1]; tbw[2] = -tbw[2];
+    imu::m3_mul(d.cam.Rcb, Rbw, P);
+    imu::m3_vec(d.cam.Rcb, tbw, tc);
+    for (int i = 0; i < 3; ++i) P[9 + i] = tc[i] + d.cam.tcb[i];
+  };
+  auto depth_positive = [&](int kind, const double* R, const double* X) {
+    if (kind == OSH_EDGE_RIGHT) {
+      double r2[3], t2 = d.cam.trl[2];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) r2[c] = d.cam.Rrl[6] * R[c] + d.cam.Rrl[7] * R[3 + c] + d.cam.Rrl[8] * R[6 + c];
+      t2 += d.cam.Rrl[6] * R[9] + d.cam.Rrl[7] * R[10] + d.cam.Rrl[8] * R[11];
+      return (r2[0] * X[0] + r2[1] * X[1] + r2[2] * X[2] + t2) > 0.0;
+    }
+    return (R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + R[11]) > 0.0;
+  };
+
+  bool robust = true;
+  int n_bad = 0, n_inl = 0, rounds = 0;
+  const int n_graph_edges = d.E + (mode1 ? 4 : 3);
+  for (int round = 0; round < 4; ++round) {
+    bool ok = true;
+    for (int it = 0; it < d.iters[round] && ok; ++it) {
+      build(robust);
+      if (tid < 64) {
+        const bool good = posei_solve_wave(shH, shb, n, shU, shx);   // on failure x keeps the previous values and is still applied
+        if (tid == 0) sh_ok = good ? 1 : 0;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        pose_update(shP, shx, true);
+        for (int i = 0; i < 9; ++i) shs[i] += shx[6 + i];
+        if (mode1) {
+          pose_update(shpP, shx + 15, false);
+          for (int i = 0; i < 9; ++i) shps[i] += shx[21 + i];
+        }
+      }
+      __syncthreads();
+      ok = sh_ok != 0;
+    }
+    // ---- classification (:4747-4818 / :5139-5208)
+    double pose[24];
+#pragma unroll
+    for (int k = 0; k < 24; ++k) pose[k] = shP[k];
+    const float chi2close = 1.5 * d.chi2_mono[round];
+    int bad = 0, inl = 0;
+    for (int e = tid; e < d.E; e += kIT) {
+      const size_t ge = (size_t)d.edge_off + e;
+      const int kind = v.kind[ge];
+      double X[3], obs[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { X[k] = v.X[ge * 3 + k]; obs[k] = v.obs[ge * 3 + k]; }
+      if (v.outlier[ge]) { VisEval ev; vis_residual(d.cam, kind, pose, X, obs, v.info[ge], ev); v.chi2[ge] = ev.chi2; }
+      const float chi2 = (float)v.chi2[ge];
+      bool o;
+      if (kind != OSH_EDGE_STEREO) {
+        const bool bClose = v.close[ge] != 0;
+        o = (chi2 > d.chi2_mono[round] && !bClose) || (bClose && chi2 > chi2close) || !depth_positive(kind, pose, X);
+      } else o = chi2 > d.chi2_stereo[round];
+      v.outlier[ge] = o ? 1 : 0; v.level[ge] = o ? 1 : 0;
+      if (o) ++bad; else ++inl;
+    }
+    n_bad = (int)posei_block_sum((double)bad, sh);
+    n_inl = (int)posei_block_sum((double)inl, sh);
+    rounds = round + 1;
+    if (round == 2) robust = false;
+    __syncthreads();
+    if (n_graph_edges < 10) break;
+  }
+  double pose[24];
+#pragma unroll
+  for (int k = 0; k < 24; ++k) pose[k] = shP[k];
+  if (n_inl < 30 && !d.rec_init) {   // recovery (:4821-4848)
+    int bad = 0;
+    for (int e = tid; e < d.E; e += kIT) {
+      const size_t ge = (size_t)d.edge_off + e;
+      const int kind = v.kind[ge];
+      double X[3], obs[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { X[k] = v.X[ge * 3 + k]; obs[k] = v.obs[ge * 3 + k]; }
+      VisEval ev;
+      vis_residual(d.cam, kind, pose, X, obs, v.info[ge], ev);
+      v.chi2[ge] = ev.chi2;
+      if (ev.chi2 < (kind == OSH_EDGE_STEREO ? 24.f : 18.f)) v.outlier[ge] = 0; else ++bad;
+    }
+    n_bad = (int)posei_block_sum((double)bad, sh);
+  }
+  // ---- Hessian of the frame's ConstraintPoseImu (:4858-4893 / :5252-5293): re-linearised at the final estimate, plain information
+  {
+    const int o2 = mode1 ? 15 : 0;
+    if (tid == 0) inertial_jacobian(d.rec, shpP, shps, shP, shs, shJ);
+    double H[21];
+#pragma unroll
+    for (int k = 0; k < 21; ++k) H[k] = 0.0;
+    for (int e = tid; e < d.E; e += kIT) {
+      const size_t ge = (size_t)d.edge_off + e;
+      if (v.outlier[ge]) continue;
+      const int kind = v.kind[ge];
+      const double info = v.info[ge];
+      double X[3], obs[3], JX[9], Jp[18];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { X[k] = v.X[ge * 3 + k]; obs[k] = v.obs[ge * 3 + k]; }
+      VisEval ev;
+      vis_residual(d.cam, kind, pose, X, obs, info, ev);
+      vis_jacobians(d.cam, kind, pose, ev.Xc, JX, Jp);
+      int m = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int c = a; c < 6; ++c) { H[m] += (Jp[a] * info) * Jp[c] + (Jp[6 + a] * info) * Jp[6 + c] + (Jp[12 + a] * info) * Jp[12 + c]; ++m; }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 9 * 24; idx += kIT) {
+      const int k = idx / 24, c = idx - k * 24;
+      double t = 0.0;
+      for (int m = 0; m < 9; ++m) t += d.info[k * 9 + m] * shJ[m * 24 + c];
+      shWJ[idx] = t;
+    }
+    double red[21];
+#pragma unroll
+    for (int k = 0; k < 21; ++k) red[k] = posei_block_sum(H[k], sh);
+    if (mode1 && tid == 0) {
+      double T[9], dd[3], rr[15], invJr[9];
+      imu::m3_tmul(d.prior_R, shpP + 12, T);
+      imu::log_so3(T, rr);
+      (void)dd;
+      imu::inv_right_jac(rr, invJr);
+      for (int i = 0; i < 225; ++i) shJp[i] = 0.0;
+      for (int i = 0; i < 3; ++i) for (int jq = 0; jq < 3; ++jq) { shJp[i * 15 + jq] = invJr[i * 3 + jq]; shJp[(3 + i) * 15 + 3 + jq] = T[i * 3 + jq]; }
+      for (int i = 6; i < 15; ++i) shJp[i * 15 + i] = 1.0;
+    }
+    __syncthreads();
+    double* WJp = shH;   // 15 x 15 scratch (the solver's matrix is no longer needed)
+    if (mode1) {
+      for (int idx = tid; idx < 225; idx += kIT) {
+        const int k = idx / 15, c = idx - k * 15;
+        double t = 0.0;
+        for (int m = 0; m < 15; ++m) t += d.prior_H[k * 15 + m] * shJp[m * 15 + c];
+        WJp[idx] = t;
+      }
+      __syncthreads();
+    }
+    // reference layout: mode 0 [P V G A] of the frame; mode 1 [previous 15 | current 15]
+    auto ref_of = [&](int c) { return mode1 ? c : (c >= 15 ? c - 15 : -1); };   // EdgeInertial column -> row / column of H
+    for (int idx = tid; idx < n * n; idx += kIT) {
+      const int r = idx / n, c = idx - r * n;
+      double acc = 0.0;
+      if (r >= o2 && r < o2 + 6 && c >= o2 && c < o2 + 6) {
+        const int a0 = r - o2, c0 = c - o2;
+        const int a = a0 < c0 ? a0 : c0, bq = a0 < c0 ? c0 : a0;
+        acc += red[a * 6 - a * (a - 1) / 2 + (bq - a)];
+      }
+      for (int ca = 0; ca < 24; ++ca) {
+        if (ref_of(ca) != r) continue;
+        for (int cb = 0; cb < 24; ++cb) {
+          if (ref_of(cb) != c) continue;
+          double t = 0.0;
+          for (int k = 0; k < 9; ++k) t += shJ[k * 24 + ca] * shWJ[k * 24 + cb];
+          acc += t;
+        }
+      }
+      for (int which = 0; which < 2; ++which) {
+        const double* Og = which == 0 ? d.info_g : d.info_a;
+        const int c2 = o2 + 9 + 3 * which, c1 = mode1 ? 9 + 3 * which : -100;
+        const bool rr2 = r >= c2 && r < c2 + 3, cc2 = c >= c2 && c < c2 + 3, rr1 = r >= c1 && r < c1 + 3, cc1 = c >= c1 && c < c1 + 3;
+        if (rr2 && cc2) acc += Og[(r - c2) * 3 + (c - c2)];
+        if (rr1 && cc1) acc += Og[(r - c1) * 3 + (c - c1)];
+        if (rr1 && cc2) acc -= Og[(r - c1) * 3 + (c - c2)];
+        if (rr2 && cc1) acc -= Og[(r - c2) * 3 + (c - c1)];
+      }
+      if (mode1 && r < 15 && c < 15) {
+        double t = 0.0;
+        for (int k = 0; k < 15; ++k) t += shJp[k * 15 + r] * WJp[k * 15 + c];
+        acc += t;
+      }
+      out.H[idx] = acc;
+    }
+  }
+  if (tid < 24) out.P[tid] = shP[tid];
+  if (tid < 9) out.s[tid] = shs[tid];
+  if (tid == 0) { out.n_bad = n_bad; out.n_inliers = n_inl; out.rounds = rounds; }
+}
+
+struct PoseiBuffers { DevBuf desc, out, X, kind, obs, info, close, chi2, level, outlier; };
+PoseiBuffers& posei_buffers() { static thread_local PoseiBuffers b; return b; }
+
+}  // namespace osh
+
+using namespace osh;
+
+#define OSH_TRY(expr) do { int _rc = (expr); if (_rc != OSH_OK) return _rc; } while (0)
+
+extern "C" int osh_lba_stream(osh_lba_ctx* ctx, int* device, hipStream_t* stream);   // lba_device.hip
+
+extern "C" int osh_posei_optimize(osh_lba_ctx* ctx, int32_t n, const osh_posei_problem* pr, osh_posei_result* res) {
+  if (!ctx || n <= 0 || !pr || !res) { set_error("osh_posei_optimize: bad arguments"); return OSH_ERR_INVALID; }
+  int device = 0;
+  hipStream_t s = nullptr;
+  OSH_TRY(osh_lba_stream(ctx, &device, &s));
+  OSH_HIP(hipSetDevice(device));
+  std::vector<PoseiDesc> h_desc(n);
+  size_t NE = 0;
+  for (int f = 0; f < n; ++f) {
+    const osh_posei_problem& p = pr[f];
+    if (p.n_edges < 0 || (p.mode != 0 && p.mode != 1) || !p.Rcw || !p.tcw || !p.Rwb || !p.twb || !p.vel || !p.bias_g || !p.bias_a || !p.prev_Rwb ||
+        !p.prev_twb || !p.prev_vel || !p.prev_bias_g || !p.prev_bias_a || !p.Rcb || !p.tcb || !p.tbc || !p.cam || !p.preint || !p.info_inertial ||
+        !p.info_g || !p.info_a || (p.n_edges > 0 && (!p.points || !p.edge_kind || !p.edge_obs || !p.edge_info))) {
+      set_error("frame %d: bad mode, negative size or NULL array", f); return OSH_ERR_INVALID;
+    }
+    if (p.mode == 1 && (!p.prior_Rwb || !p.prior_twb || !p.prior_vel || !p.prior_bg || !p.prior_ba || !p.prior_H)) {
+      set_error("frame %d: PoseInertialOptimizationLastFrame needs the previous frame's ConstraintPoseImu", f); return OSH_ERR_INVALID;
+    }
+    PoseiDesc& d = h_desc[f];
+    std::memset(&d, 0, sizeof(d));
+    d.mode = p.mode; d.E = p.n_edges; d.edge_off = (int)NE; d.rec_init = p.rec_init;
+    LibaDesc& c = d.cam;
+    std::memcpy(c.Rcb, p.Rcb, 72); std::memcpy(c.tcb, p.tcb, 24); std::memcpy(c.tbc, p.tbc, 24); std::memcpy(c.cam, p.cam, 40);
+    c.kb8_on = p.kb8 ? 1 : 0;
+    for (int k = 0; k < 4; ++k) c.kb8[k] = p.kb8 ? p.kb8[k] : 0.0;
+    c.rig_on = (p.kb8 && p.cam2 && p.trl) ? 1 : 0;
+    if (c.rig_on) {
+      double tcb1[3];
+      for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) c.Rrl[i * 3 + j] = p.trl[i * 4 + j]; c.trl[i] = p.trl[i * 4 + 3]; }
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) { double a = 0.0; for (int k = 0; k < 3; ++k) a += c.Rrl[i * 3 + k] * c.Rcb[k * 3 + j]; c.Rcb1[i * 3 + j] = a; }
+      for (int i = 0; i < 3; ++i) tcb1[i] = c.Rrl[i * 3] * c.tcb[0] + c.Rrl[i * 3 + 1] * c.tcb[1] + c.Rrl[i * 3 + 2] * c.tcb[2] + c.trl[i];
+      for (int i = 0; i < 3; ++i) c.tbc1[i] = -(c.Rcb1[i] * tcb1[0] + c.Rcb1[3 + i] * tcb1[1] + c.Rcb1[6 + i] * tcb1[2]);
+      std::memcpy(c.cam2, p.cam2, 64);
+    }
+    for (int e = 0; e < p.n_edges; ++e) {
+      if (p.edge_kind[e] > OSH_EDGE_RIGHT) { set_error("frame %d edge %d: kind out of range", f, e); return OSH_ERR_INVALID; }
+      if (p.edge_kind[e] == OSH_EDGE_RIGHT && !c.rig_on) { set_error("frame %d edge %d: a right-camera edge needs kb8, cam2 and trl", f, e); return OSH_ERR_INVALID; }
+      if (p.edge_kind[e] == OSH_EDGE_STEREO && p.kb8) { set_error("frame %d: a KannalaBrandt8 frame takes monocular edges only (edge %d)", f, e); return OSH_ERR_UNSUPPORTED; }
+    }
+    std::memcpy(d.P, p.Rcw, 72); std::memcpy(d.P + 9, p.tcw, 24); std::memcpy(d.P + 12, p.Rwb, 72); std::memcpy(d.P + 21, p.twb, 24);
+    std::memcpy(d.s, p.vel, 24); std::memcpy(d.s + 3, p.bias_g, 24); std::memcpy(d.s + 6, p.bias_a, 24);
+    d.pP[0] = d.pP[4] = d.pP[8] = 1.0;
+    std::memcpy(d.pP + 12, p.prev_Rwb, 72); std::memcpy(d.pP + 21, p.prev_twb, 24);
+    std::memcpy(d.ps, p.prev_vel, 24); std::memcpy(d.ps + 3, p.prev_bias_g, 24); std::memcpy(d.ps + 6, p.prev_bias_a, 24);
+    std::memcpy(d.rec, p.preint, OSH_PREINT_FLOATS * 4);
+    std::memcpy(d.info, p.info_inertial, 81 * 8); std::memcpy(d.info_g, p.info_g, 72); std::memcpy(d.info_a, p.info_a, 72);
+    if (p.mode == 1) {
+      std::memcpy(d.prior_R, p.prior_Rwb, 72); std::memcpy(d.prior_t, p.prior_twb, 24);
+      std::memcpy(d.prior_s, p.prior_vel, 24); std::memcpy(d.prior_s + 3, p.prior_bg, 24); std::memcpy(d.prior_s + 6, p.prior_ba, 24);
+      std::memcpy(d.prior_H, p.prior_H, 225 * 8);
+    }
+    d.huber_mono = p.huber_mono; d.huber_stereo = p.huber_stereo; d.huber_prior = p.huber_prior;
+    for (int k = 0; k < 4; ++k) { d.chi2_mono[k] = p.chi2_mono[k]; d.chi2_stereo[k] = p.chi2_stereo[k]; d.iters[k] = p.iterations[k]; }
+    NE += (size_t)p.n_edges;
+  }
+  if (NE > 0x7fffff00u) { set_error("batch too large for 32-bit offsets"); return OSH_ERR_UNSUPPORTED; }
+  std::vector<double> h_X(NE * 3 + 1), h_obs(NE * 3 + 1), h_info(NE + 1);
+  std::vector<unsigned char> h_kind(NE + 1), h_close(NE + 1);
+  for (int f = 0; f < n; ++f) {
+    const osh_posei_problem& p = pr[f];
+    const size_t o = (size_t)h_desc[f].edge_off;
+    for (int e = 0; e < p.n_edges; ++e) {
+      for (int k = 0; k < 3; ++k) { h_X[(o + e) * 3 + k] = p.points[3 * (size_t)e + k]; h_obs[(o + e) * 3 + k] = p.edge_obs[3 * (size_t)e + k]; }
+      h_info[o + e] = p.edge_info[e];
+      h_kind[o + e] = p.edge_kind[e];
+      h_close[o + e] = p.edge_close ? p.edge_close[e] : 0;
+    }
+  }
+  PoseiBuffers& B = posei_buffers();
+  auto up = [&](DevBuf& b, const void* src, size_t bytes) -> int {
+    OSH_TRY(b.reserve(std::max<size_t>(bytes, 8)));
+    if (bytes) OSH_HIP(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, s));
+    return OSH_OK;
+  };
+  OSH_TRY(up(B.desc, h_desc.data(), n * sizeof(PoseiDesc)));
+  OSH_TRY(up(B.X, h_X.data(), NE * 24)); OSH_TRY(up(B.obs, h_obs.data(), NE * 24)); OSH_TRY(up(B.info, h_info.data(), NE * 8));
+  OSH_TRY(up(B.kind, h_kind.data(), NE)); OSH_TRY(up(B.close, h_close.data(), NE));
+  OSH_TRY(B.out.reserve(n * sizeof(PoseiOut))); OSH_TRY(B.chi2.reserve(std::max<size_t>(NE * 8, 8)));
+  OSH_TRY(B.level.reserve(std::max<size_t>(NE, 8))); OSH_TRY(B.outlier.reserve(std::max<size_t>(NE, 8)));
+  PoseiView v;
+  v.desc = B.desc.as<PoseiDesc>(); v.out = B.out.as<PoseiOut>();
+  v.X = B.X.as<double>(); v.kind = B.kind.as<unsigned char>(); v.obs = B.obs.as<double>(); v.info = B.info.as<double>();
+  v.close = B.close.as<unsigned char>(); v.chi2 = B.chi2.as<double>(); v.level = B.level.as<unsigned char>(); v.outlier = B.outlier.as<unsigned char>();
+  hipLaunchKernelGGL(k_posei, dim3((unsigned)n), dim3(kIT), 0, s, v);
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) { set_error("k_posei launch failed: %s", hipGetErrorString(le)); return OSH_ERR_DEVICE; }
+  std::vector<PoseiOut> h_out(n);
+  OSH_HIP(hipMemcpyAsync(h_out.data(), B.out.p, n * sizeof(PoseiOut), hipMemcpyDeviceToHost, s));
+  for (int f = 0; f < n; ++f) {
+    const PoseiDesc& d = h_desc[f];
+    if (res[f].outlier && d.E) OSH_HIP(hipMemcpyAsync(res[f].outlier, B.outlier.as<unsigned char>() + d.edge_off, d.E, hipMemcpyDeviceToHost, s));
+    if (res[f].edge_chi2 && d.E) OSH_HIP(hipMemcpyAsync(res[f].edge_chi2, B.chi2.as<double>() + d.edge_off, (size_t)d.E * 8, hipMemcpyDeviceToHost, s));
+  }
+  OSH_HIP(hipStreamSynchronize(s));
+  for (int f = 0; f < n; ++f) {
+    const PoseiOut& o = h_out[f];
+    osh_posei_result& r = res[f];
+    std::memcpy(r.Rcw, o.P, 72); std::memcpy(r.tcw, o.P + 9, 24); std::memcpy(r.Rwb, o.P + 12, 72); std::memcpy(r.twb, o.P + 21, 24);
+    std::memcpy(r.vel, o.s, 24); std::memcpy(r.bias_g, o.s + 3, 24); std::memcpy(r.bias_a, o.s + 6, 24);
+    r.n_bad = o.n_bad; r.n_inliers = o.n_inliers; r.rounds = o.rounds; r.status = OSH_OK;
+    std::memcpy(r.H, o.H, sizeof(r.H));
+  }
+  return OSH_OK;
+}

@@ -470,3 +470,91 @@ def host_inertial_information(cov):
     out = np.zeros(81)
     lib.osh_host_inertial_information(capi.ptr(_f32(cov).ravel(), capi.c_float_p), capi.ptr(out, capi.c_double_p))
     return out.reshape(9, 9)
+
+
+class HostPoseiFrame:
+    """A tracked frame + its IMU link built from a synth_inertial.PoseiFrame, for Optimizer::PoseInertialOptimizationLastKeyFrame
+    (mode 0) / LastFrame (mode 1) through the reference signatures.  Keypoint k <-> edge order[k] of the flat frame (a fisheye rig
+    frame lists its left keypoints first)."""
+
+    def __init__(self, f):
+        self.lib = capi.load_library()
+        self.f = f
+        right = f.edge_kind == capi.OSH_EDGE_RIGHT
+        rig = f.cam2 is not None
+        self.order = np.concatenate([np.nonzero(~right)[0], np.nonzero(right)[0]]) if rig else np.arange(f.n_edges)
+        o = self.order
+        n_left = int((~right).sum()) if rig else -1
+        Tbc = np.eye(4)
+        Tbc[:3, :3], Tbc[:3, 3] = f.Rcb.reshape(3, 3).T, f.tbc
+        tbc_qt = _f32(np.concatenate([_quat_from_R(Tbc[:3, :3]), Tbc[:3, 3]]))
+
+        def tcw_qt(Rwb, twb):      # Tcw = Tcb * Tbw
+            Rcb = f.Rcb.reshape(3, 3)
+            Rcw = Rcb @ Rwb.reshape(3, 3).T
+            return _f32(np.concatenate([_quat_from_R(Rcw), Rcb @ (-Rwb.reshape(3, 3).T @ twb) + f.tcb]))
+        pose = _f32(np.concatenate([_quat_from_R(f.Rcw.reshape(3, 3)), f.tcw]))
+        prev_pose = tcw_qt(f.prev_Rwb, f.prev_twb)
+        octave = _i32(np.round(np.log(1.0 / f.edge_info[o]) / np.log(1.44)).astype(np.int32))
+        uright = _f32(np.where(f.edge_kind[o] == capi.OSH_EDGE_STEREO, f.edge_obs[o, 2], -1.0))
+        cov = np.zeros((15, 15), dtype=np.float32)
+        cov[:9, :9] = np.linalg.inv(f.info_inertial.reshape(9, 9))
+        cov[9:12, 9:12] = np.linalg.inv(f.info_g.reshape(3, 3))
+        cov[12:15, 12:15] = np.linalg.inv(f.info_a.reshape(3, 3))
+        fp = lambda a: capi.ptr(_f32(a), capi.c_float_p) if a is not None else None   # noqa: E731
+        dp = lambda a: capi.ptr(np.ascontiguousarray(a, dtype=np.float64), capi.c_double_p) if a is not None else None   # noqa: E731
+        self._keep = [pose, prev_pose, octave, uright, tbc_qt, cov]
+        self.h = C.c_void_p(self.lib.osh_host_posei_create(
+            int(f.mode), f.n_edges, fp(f.edge_obs[o, :2]), capi.ptr(octave, capi.c_int32_p), capi.ptr(uright, capi.c_float_p), n_left,
+            capi.ptr(pose, capi.c_float_p), fp(f.cam), fp(f.kb8), fp(f.cam2), fp(f.gt["trl_qt"]) if rig else None, fp(synth.INV_LEVEL_SIGMA2),
+            len(synth.INV_LEVEL_SIGMA2), fp(f.points[o]), capi.ptr(np.ascontiguousarray(f.edge_close[o]), capi.c_uint8_p),
+            capi.ptr(tbc_qt, capi.c_float_p), fp(f.vel), fp(np.concatenate([f.bias_a, f.bias_g])), capi.ptr(prev_pose, capi.c_float_p), fp(f.prev_vel),
+            fp(np.concatenate([f.prev_bias_a, f.prev_bias_g])), capi.ptr(np.ascontiguousarray(f.preint), capi.c_float_p),
+            capi.ptr(np.ascontiguousarray(cov.ravel()), capi.c_float_p), dp(f.prior_Rwb), dp(f.prior_twb), dp(f.prior_vel), dp(f.prior_bg), dp(f.prior_ba),
+            dp(f.prior_H)))
+        assert self.h
+
+    def close(self):
+        if self.h:
+            self.lib.osh_host_posei_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def packed(self, rec_init=False):
+        """The osh_posei_problem the host layer builds, copied into a PoseiFrame (for the oracle) + the keypoint of every edge."""
+        from .synth_inertial import PoseiFrame
+        p = capi.PoseiProblem()
+        kp = np.zeros(self.f.n_edges, dtype=np.int32)
+        rc = self.lib.osh_host_posei_pack(self.h, int(rec_init), C.byref(p), capi.ptr(kp, capi.c_int32_p))
+        assert rc == 0, rc
+
+        def arr(ptr, n, dt=np.float64):
+            return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt).copy() if ptr else None
+        E = p.n_edges
+        g = PoseiFrame(
+            mode=p.mode, Rcw=arr(p.Rcw, 9), tcw=arr(p.tcw, 3), Rwb=arr(p.Rwb, 9), twb=arr(p.twb, 3), vel=arr(p.vel, 3), bias_g=arr(p.bias_g, 3),
+            bias_a=arr(p.bias_a, 3), prev_Rwb=arr(p.prev_Rwb, 9), prev_twb=arr(p.prev_twb, 3), prev_vel=arr(p.prev_vel, 3),
+            prev_bias_g=arr(p.prev_bias_g, 3), prev_bias_a=arr(p.prev_bias_a, 3), Rcb=arr(p.Rcb, 9), tcb=arr(p.tcb, 3), tbc=arr(p.tbc, 3), cam=arr(p.cam, 5),
+            preint=arr(p.preint, capi.OSH_PREINT_FLOATS, np.float32), info_inertial=arr(p.info_inertial, 81), info_g=arr(p.info_g, 9), info_a=arr(p.info_a, 9),
+            points=arr(p.points, E * 3).reshape(-1, 3), edge_kind=arr(p.edge_kind, E, np.uint8), edge_obs=arr(p.edge_obs, E * 3).reshape(-1, 3),
+            edge_info=arr(p.edge_info, E), edge_close=arr(p.edge_close, E, np.uint8), prior_Rwb=arr(p.prior_Rwb, 9), prior_twb=arr(p.prior_twb, 3),
+            prior_vel=arr(p.prior_vel, 3), prior_bg=arr(p.prior_bg, 3), prior_ba=arr(p.prior_ba, 3), prior_H=arr(p.prior_H, 225), kb8=arr(p.kb8, 4),
+            cam2=arr(p.cam2, 8), trl=arr(p.trl, 12), rec_init=bool(p.rec_init), huber_mono=p.huber_mono, huber_stereo=p.huber_stereo, huber_prior=p.huber_prior,
+            chi2_mono=tuple(p.chi2_mono), chi2_stereo=tuple(p.chi2_stereo), iterations=tuple(p.iterations)).normalise()
+        return g, kp[:E]
+
+    def run(self, rec_init=False):
+        pose, Rwb, twb, vel, bias = (np.zeros(k, dtype=np.float32) for k in (7, 9, 3, 3, 6))
+        outlier = np.zeros(self.f.n_edges, dtype=np.uint8)
+        H = np.zeros(225)
+        gone = C.c_int32(0)
+        n = self.lib.osh_host_posei_run(self.h, int(rec_init), capi.ptr(pose, capi.c_float_p), capi.ptr(Rwb, capi.c_float_p), capi.ptr(twb, capi.c_float_p),
+                                        capi.ptr(vel, capi.c_float_p), capi.ptr(bias, capi.c_float_p), capi.ptr(outlier, capi.c_uint8_p),
+                                        capi.ptr(H, capi.c_double_p), C.byref(gone))
+        return dict(n=n, pose_qt=pose, Rwb=Rwb.reshape(3, 3), twb=twb, vel=vel, bias_a=bias[:3], bias_g=bias[3:], outlier=outlier, H=H.reshape(15, 15),
+                    prev_cpi_deleted=bool(gone.value))

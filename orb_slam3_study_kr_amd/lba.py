@@ -136,6 +136,18 @@ class LbaSolver:
         capi.check(self.lib.osh_pose_optimize(self.ctx, n, probs, rs), "osh_pose_optimize", self.lib)
         return [a.read_scalars(r) for r, a in zip(rs, res)]
 
+    def optimize_poses_inertial(self, frames):
+        """``osh_posei_optimize``: Optimizer::PoseInertialOptimizationLastKeyFrame / LastFrame for every frame of the batch."""
+        from .synth_inertial import PoseiResultArrays
+        n = len(frames)
+        probs = (capi.PoseiProblem * n)(*[f.as_struct() for f in frames])
+        res = [PoseiResultArrays(f) for f in frames]
+        rs = (capi.PoseiResult * n)()
+        for r, a in zip(rs, res):
+            a.bind(r)
+        capi.check(self.lib.osh_posei_optimize(self.ctx, n, probs, rs), "osh_posei_optimize", self.lib)
+        return [a.read(r, f.mode) for r, a, f in zip(rs, res, frames)]
+
     def plan_stats(self) -> dict:
         st = np.zeros(6, dtype=np.int64)
         capi.check(self.lib.osh_lba_get_plan_stats(self.ctx, capi.ptr(st, capi.c_int64_p)), "osh_lba_get_plan_stats", self.lib)

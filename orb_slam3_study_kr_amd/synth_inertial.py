@@ -590,6 +590,7 @@ def make_posei_frame(seed: int = 3, mode: int = 0, n_points: int = 400, stereo: 
         Rrl = synth._quat_to_R(qq).astype(np.float32).astype(np.float64)
         trl_t = np.array([-0.1, 0.002, 0.001], dtype=np.float32).astype(np.float64)
         trl = np.concatenate([Rrl, trl_t[:, None]], axis=1).reshape(12)
+        trl_qt = np.concatenate([qq, trl_t]).astype(np.float32)
         right = rng.uniform(size=n_points) < 0.45                               # keypoints of the right image
         ur, vr = project(cam2, cam2[4:], Xc @ Rrl.T + trl_t)
         obs[right, 0], obs[right, 1] = ur[right], vr[right]
@@ -597,6 +598,7 @@ def make_posei_frame(seed: int = 3, mode: int = 0, n_points: int = 400, stereo: 
     obs = obs + rng.standard_normal((n_points, 3)) * sig[:, None]
     is_out = rng.uniform(size=n_points) < outlier_frac
     obs += rng.standard_normal((n_points, 3)) * 25.0 * is_out[:, None]
+    kind[(kind == capi.OSH_EDGE_STEREO) & (obs[:, 2] < 0)] = capi.OSH_EDGE_MONO     # a negative u_right reads as "no stereo match"
     obs[kind != capi.OSH_EDGE_STEREO, 2] = -1.0
     pts = q(Xw + rng.standard_normal(Xw.shape) * 0.02)
     f = PoseiFrame(
@@ -610,6 +612,8 @@ def make_posei_frame(seed: int = 3, mode: int = 0, n_points: int = 400, stereo: 
         edge_close=(Xc[:, 2] < 10.0).astype(np.uint8), kb8=kb.copy() if fisheye else None, cam2=cam2, trl=trl, rec_init=rec_init,
         chi2_mono=(12.0, 7.5, 5.991, 5.991) if mode == 0 else (5.991, 5.991, 5.991, 5.991),
         gt=dict(Rwb=R2, twb=p2, vel=v2, outliers=is_out))
+    if rig:
+        f.gt["trl_qt"] = trl_qt
     if mode == 1:
         # mpcpi of the previous frame: its state estimate at the time + a symmetric positive semi-definite information
         Q, _ = np.linalg.qr(rng.standard_normal((15, 15)))

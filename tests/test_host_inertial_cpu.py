@@ -87,3 +87,28 @@ def test_fisheye_rig_window_packs_right_camera_edges_with_the_left_keypoints_lev
     # a pair sits left edge first, right edge next (the reference's insertion order)
     pairs = right[1:] & ~right[:-1] & (pw.edge_pose[1:] == pw.edge_pose[:-1]) & (pw.edge_point[1:] == pw.edge_point[:-1])
     assert pairs.sum() > 50
+
+
+def test_pose_inertial_optimization_packs_the_reference_edges():
+    """src/Optimizer.cc:4555-4712 / :4957-5118: edge kinds by keypoint (mono for mvuRight < 0 or a left fisheye keypoint, stereo
+    otherwise, EdgeMonoOnlyPose(Xw, 1) for keypoints >= Nleft), the last keyframe fixed (mode 0) or the previous frame with its
+    ConstraintPoseImu (mode 1), thresholds and iteration counts of each variant."""
+    from orb_slam3_study_kr_amd import capi
+    for mode, kw in ((0, dict()), (1, dict()), (0, dict(rig=True)), (1, dict(stereo=False))):
+        f = si.make_posei_frame(31, mode=mode, n_points=120, **kw)
+        with host.HostPoseiFrame(f) as h:
+            g, kp = h.packed()
+            o = h.order
+        assert g.mode == mode and g.n_edges == f.n_edges and list(kp) == list(range(f.n_edges))
+        np.testing.assert_array_equal(g.edge_kind, f.edge_kind[o])
+        np.testing.assert_array_equal(g.edge_obs[:, :2], np.float32(f.edge_obs[o, :2]).astype(np.float64))
+        np.testing.assert_array_equal(g.edge_close, f.edge_close[o])
+        np.testing.assert_allclose(g.edge_info, f.edge_info[o], rtol=1e-6)
+        np.testing.assert_allclose(g.prev_Rwb.reshape(3, 3), f.prev_Rwb.reshape(3, 3), atol=5e-6)
+        np.testing.assert_allclose(g.prev_twb, f.prev_twb, atol=5e-6)
+        np.testing.assert_allclose(g.info_inertial.reshape(9, 9), f.info_inertial.reshape(9, 9), rtol=2e-3, atol=2e-3 * np.abs(f.info_inertial).max())
+        assert g.chi2_mono[0] == np.float32(12.0 if mode == 0 else 5.991) and g.iterations == (10, 10, 10, 10) and g.huber_prior == 5.0
+        assert (g.prior_H is not None) == (mode == 1) and (g.cam2 is not None) == bool(kw.get("rig"))
+        if mode == 1:
+            # the ConstraintPoseImu constructor symmetrised H and dropped eigenvalues below 1e-12: an SPD H passes through
+            np.testing.assert_allclose(g.prior_H.reshape(15, 15), f.prior_H.reshape(15, 15), rtol=1e-9, atol=1e-9 * np.abs(f.prior_H).max())
