@@ -178,7 +178,7 @@ def run_end_to_end(args, info, windows):
 
     import torch
     from orb_slam3_study_kr_amd import lba
-    n_ctx = 2
+    n_ctx = max(1, args.e2e_contexts)
     solvers = [lba.LbaSolver(info.local_rank) for _ in range(n_ctx)]
     prepared = [sv.prepare(windows) for sv in solvers]
     per_ctx = max(2, args.e2e_batches)
@@ -216,7 +216,7 @@ def run_end_to_end(args, info, windows):
     for s_ in solvers:
         s_.close()
     pool.shutdown()
-    return dict(elapsed=elapsed, n_batches=n_batches, serial_ms=dict(upload=(t[1] - t[0]) * 1e3, optimize=(t[2] - t[1]) * 1e3,
+    return dict(elapsed=elapsed, n_batches=n_batches, n_ctx=n_ctx, serial_ms=dict(upload=(t[1] - t[0]) * 1e3, optimize=(t[2] - t[1]) * 1e3,
                                                                        download=(t[3] - t[2]) * 1e3, upload_pack=up["pack_ms"], upload_copy=up["copy_ms"]),
                 pack_ms_mean=float(np.mean([u["pack_ms"] for u in ups])), copy_ms_mean=float(np.mean([u["copy_ms"] for u in ups])))
 
@@ -384,6 +384,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-orb", action="store_true")
     ap.add_argument("--inertial-windows", type=int, default=128, help="config-4 windows per osh_liba_solve call (0 = skip)")
+    ap.add_argument("--e2e-contexts", type=int, default=2, help="solver contexts (each with its own host thread, stream and pinned staging) of the end-to-end run")
     ap.add_argument("--e2e-batches", type=int, default=3, help="batches per solver context in the end-to-end (upload + optimize + download) run; 0 = skip")
     ap.add_argument("--stub-solver", action="store_true", help="CPU rehearsal of the rank plumbing (gloo): no GPU work, the "
                     "timed step is a fixed sleep; the JSON line is marked \"stub\" and is not a measurement")
@@ -483,8 +484,9 @@ def main():
         e2e_windows = args.windows * n_gpus * e2e_out["n_batches"]
         out["value_end_to_end"] = e2e_windows / e2e_out["elapsed"]
         out["end_to_end"] = {"what": "osh_lba_upload (host packing into pinned staging + H2D) + osh_lba_optimize + osh_lba_download of whole "
-                                     "batches of host-resident windows; two solver contexts on alternate batches (packing of batch b+1 overlaps "
-                                     "the optimisation of batch b)",
+                                     "batches of host-resident windows; several solver contexts, each driven by its own host thread, work on "
+                                     "different batches at once (packing of one batch overlaps the copies and the optimisation of the others)",
+                             "contexts": e2e_out["n_ctx"],
                              "batches": e2e_out["n_batches"], "windows_per_batch": args.windows, "ms_per_batch": e2e_out["elapsed"] / e2e_out["n_batches"] * 1e3,
                              "fraction_of_resident": (e2e_windows / e2e_out["elapsed"]) / value,
                              "one_batch_serial_ms": e2e_out["serial_ms"], "pack_ms_mean": e2e_out["pack_ms_mean"], "copy_ms_mean": e2e_out["copy_ms_mean"],

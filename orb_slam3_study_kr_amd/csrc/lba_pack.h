@@ -90,6 +90,7 @@ inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 struct WinLocal {
   std::vector<Chunk> chunks;
   std::vector<plan_detail::Build> builds;
+  std::vector<SRec> recs;            // records of all builds, Build::rec_off / n_rec
   SchurPlan plan;
   int n_sym = 0, n_cross = 0;
   size_t recs_sym = 0, recs_cross = 0;
@@ -97,13 +98,14 @@ struct WinLocal {
   char msg[320];
 };
 
-struct Scratch { std::vector<int> cnt, fill, order, second, tmp_epose, nfree, old2new; };
+struct Scratch { std::vector<int> cnt, fill, order, second, tmp_epose, nfree, old2new, old_lmo; plan_detail::PlanScratch plan; };
 
 }  // namespace pack_detail
 
 // Packs `nw` problems.  `alloc(which, bytes)` returns host memory for arena `which` (0, 1) that stays valid until the next
 // call with the same `which`.  Returns pb.err (OSH_OK on success), message in pb.msg.
-inline int pack_batch(int nw, const osh_lba_problem* pr, const std::function<void*(int, size_t)>& alloc, int n_threads, PackedBatch& pb) {
+inline int pack_batch(int nw, const osh_lba_problem* pr, const std::function<void*(int, size_t)>& alloc, int n_threads, PackedBatch& pb,
+                      bool allow_f32 = true) {
   using namespace pack_detail;
   pb = PackedBatch();
   pb.nw = nw;
@@ -142,24 +144,11 @@ inline int pack_batch(int nw, const osh_lba_problem* pr, const std::function<voi
   // the tail of a window with merged edges stays unused.
   pb.NE = NE;
   n_threads = std::max(1, std::min(n_threads, nw));
-  {
-    // are all observation records float32 values?  (parallel scan of edge_obs / edge_info; rig batches keep doubles)
-    std::atomic<int> next{0}, inexact{pb.has_rig ? 1 : 0};
-    auto worker = [&]() {
-      for (int w = next.fetch_add(1); w < nw && !inexact.load(std::memory_order_relaxed); w = next.fetch_add(1)) {
-        const osh_lba_problem& p = pr[w];
-        bool ok = true;
-        for (size_t k = 0, n = (size_t)p.n_edges * 3; k < n && ok; ++k) ok = (double)(float)p.edge_obs[k] == p.edge_obs[k];
-        for (int e = 0; e < p.n_edges && ok; ++e) ok = (double)(float)p.edge_info[e] == p.edge_info[e];
-        if (!ok) inexact.store(1, std::memory_order_relaxed);
-      }
-    };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < n_threads; ++t) pool.emplace_back(worker);
-    worker();
-    for (std::thread& t : pool) t.join();
-    pb.rec_f32 = inexact.load() == 0;
-  }
+  // Observation records travel as float32 when every value is one (what the reference stores: cv::KeyPoint::pt, mvuRight,
+  // mvInvLevelSigma2).  Optimistic: the records are written as floats and checked on the way; a batch with a value that is not
+  // a float32 (or a rig batch, which keeps doubles) is packed again with double records.
+  pb.rec_f32 = allow_f32 && !pb.has_rig;
+  std::atomic<int> inexact{0};
   {
     size_t o = 0;
     auto put = [&](int s, size_t b) { pb.off[s] = o; pb.bytes[s] = b; o += align_up(std::max<size_t>(b, 8)); };
@@ -206,31 +195,45 @@ inline int pack_batch(int nw, const osh_lba_problem* pr, const std::function<voi
       for (int k = 0; k < 5; ++k) h_cam[((size_t)d.pose_off + i) * 5 + k] = p.pose_cam[5 * i + k];
     }
     for (int i = 0; i < p.n_free; ++i) h_fpw[(size_t)d.fpose_off + i] = w;
+    // validation, landmark histogram and a sortedness check in one pass: the reference inserts its edges landmark by landmark
+    // (src/Optimizer.cc:1295-1400, observers in the order of a std::map keyed by pointer), so a caller that keeps that order
+    // needs no counting sort, only the short insertion sort of every landmark's observers
+    std::vector<int>& cnt = sc.cnt; std::vector<int>& fill = sc.fill; std::vector<int>& order = sc.order;
+    cnt.assign((size_t)p.n_points + 1, 0);
+    bool presorted = true, lm_major = true;   // poses ascending inside every landmark as well / landmarks ascending
     for (int e = 0; e < p.n_edges; ++e) {
       const int ip = p.edge_pose[e], il = p.edge_point[e], kd = p.edge_kind[e];
       if (ip < 0 || ip >= NPw || il < 0 || il >= p.n_points || kd > OSH_EDGE_BODY) return lfail(OSH_ERR_INVALID, "window %d edge %d: index or kind out of range", w, e);
       if (p.kb8 && kd == OSH_EDGE_STEREO) return lfail(OSH_ERR_UNSUPPORTED, "window %d: a KannalaBrandt8 window takes monocular and body edges only (edge %d is a rectified-stereo edge)", w, e);
       if (kd == OSH_EDGE_BODY && !d.rig_on) return lfail(OSH_ERR_INVALID, "window %d edge %d: a body edge (EdgeSE3ProjectXYZToBody) needs kb8, cam2 and trl", w, e);
+      cnt[il + 1]++;
+      if (e > 0) {
+        const int pl = p.edge_point[e - 1], pp = p.edge_pose[e - 1];
+        lm_major &= il >= pl;
+        presorted &= (il > pl) | ((il == pl) & ((ip > pp) | ((ip == pp) & (kd >= (int)p.edge_kind[e - 1]))));
+      }
     }
-    // counting sort by landmark (stable), then order poses inside each landmark
-    std::vector<int>& cnt = sc.cnt; std::vector<int>& fill = sc.fill; std::vector<int>& order = sc.order;
-    cnt.assign((size_t)p.n_points + 1, 0);
-    for (int e = 0; e < p.n_edges; ++e) cnt[p.edge_point[e] + 1]++;
     for (int j = 0; j < p.n_points; ++j) cnt[j + 1] += cnt[j];
-    fill.assign(cnt.begin(), cnt.end() - 1);
     order.resize(p.n_edges);
-    for (int e = 0; e < p.n_edges; ++e) order[fill[p.edge_point[e]]++] = e;
+    if (lm_major) {
+      for (int e = 0; e < p.n_edges; ++e) order[e] = e;
+    } else {
+      // counting sort by landmark (stable), then order poses inside each landmark
+      fill.assign(cnt.begin(), cnt.end() - 1);
+      for (int e = 0; e < p.n_edges; ++e) order[fill[p.edge_point[e]]++] = e;
+    }
     // per landmark: stable insertion sort by (pose, kind); a (pose, landmark) pair may carry a left (mono) and a right (body)
     // edge, which merge into one sorted edge; `second[x]` is the caller index of the merged right edge or -1
     std::vector<int>& second = sc.second; std::vector<int>& tmp_epose = sc.tmp_epose; std::vector<int>& nfree = sc.nfree;
     second.assign(p.n_edges, -1);
     tmp_epose.resize((size_t)p.n_edges + 1);
     nfree.assign(p.n_points, 0);
-    std::vector<int> old_lmo((size_t)p.n_points + 1);
+    std::vector<int>& old_lmo = sc.old_lmo;
+    old_lmo.resize((size_t)p.n_points + 1);
     int n_sorted = 0;
     for (int j = 0; j < p.n_points; ++j) {
       const int lo = cnt[j], hi = cnt[j + 1];
-      for (int x = lo + 1; x < hi; ++x) {
+      for (int x = lo + 1; x < hi && !presorted; ++x) {
         const int e = order[x], pe = p.edge_pose[e], ke = p.edge_kind[e];
         int y = x;
         for (; y > lo && (p.edge_pose[order[y - 1]] > pe || (p.edge_pose[order[y - 1]] == pe && p.edge_kind[order[y - 1]] > ke)); --y) order[y] = order[y - 1];
@@ -262,7 +265,8 @@ inline int pack_batch(int nw, const osh_lba_problem* pr, const std::function<voi
     tmp_epose[n_sorted] = 0;
     d.E = n_sorted;
     // Schur work plan on the old numbering (schur_plan.h)
-    if (!plan_window(w, p.n_free, p.n_points, old_lmo.data(), nfree.data(), tmp_epose.data(), L.builds, L.plan))
+    L.recs.reserve((size_t)p.n_points + p.n_points / 4);
+    if (!plan_window(w, p.n_free, p.n_points, old_lmo.data(), nfree.data(), tmp_epose.data(), L.builds, L.recs, L.plan, sc.plan))
       return lfail(OSH_ERR_UNSUPPORTED, "window %d: a landmark has more than 254 optimisable observers", w);
     // renumber the landmarks in the order of the plan's owner records (symmetric builds, in build order)
     std::vector<int>& old2new = sc.old2new;
@@ -271,7 +275,7 @@ inline int pack_batch(int nw, const osh_lba_problem* pr, const std::function<voi
     int next = 0;
     for (const plan_detail::Build& bd : L.builds) {
       if (!bd.sym) continue;
-      for (const SRec& r : bd.recs) if (r.flags & 1) { old2new[r.lm] = next; perm[next] = r.lm; ++next; }
+      for (int q = bd.rec_off; q < bd.rec_off + bd.n_rec; ++q) { const SRec& r = L.recs[q]; if (r.flags & 1) { old2new[r.lm] = next; perm[next] = r.lm; ++next; } }
     }
     if (next != p.n_points) return lfail(OSH_ERR_DEVICE, "window %d: plan owns %d of %d landmarks", w, next, p.n_points);
     int* lmo = &h_lmoff[d.lmoff_off];
@@ -279,6 +283,7 @@ inline int pack_batch(int nw, const osh_lba_problem* pr, const std::function<voi
     for (int jn = 0; jn < p.n_points; ++jn) { const int jo = perm[jn]; lmo[jn + 1] = lmo[jn] + (old_lmo[jo + 1] - old_lmo[jo]); }
     // The caller's arrays are walked in their own (old) order -- sequential reads -- and every landmark's run is written to
     // its renumbered place: scattered stores retire from the store buffer, scattered loads would each wait for memory.
+    bool exact = true;
     for (int jo = 0; jo < p.n_points; ++jo) {
       const int jn = old2new[jo];
       for (int k = 0; k < 3; ++k) h_pt[((size_t)d.pt_off + jn) * 3 + k] = p.points[3 * (size_t)jo + k];
@@ -292,8 +297,10 @@ inline int pack_batch(int nw, const osh_lba_problem* pr, const std::function<voi
         // the sign of the information carries the edge kind for the pinhole kernels (negative = monocular)
         const double inf = (kd == OSH_EDGE_STEREO) ? p.edge_info[e] : -p.edge_info[e];
         if (rec_f32) {
-          h_recf[g * 4] = (float)p.edge_obs[3 * (size_t)e]; h_recf[g * 4 + 1] = (float)p.edge_obs[3 * (size_t)e + 1];
-          h_recf[g * 4 + 2] = (float)p.edge_obs[3 * (size_t)e + 2]; h_recf[g * 4 + 3] = (float)inf;
+          const double o0 = p.edge_obs[3 * (size_t)e], o1 = p.edge_obs[3 * (size_t)e + 1], o2 = p.edge_obs[3 * (size_t)e + 2];
+          const float f0 = (float)o0, f1 = (float)o1, f2 = (float)o2, f3 = (float)inf;
+          h_recf[g * 4] = f0; h_recf[g * 4 + 1] = f1; h_recf[g * 4 + 2] = f2; h_recf[g * 4 + 3] = f3;
+          exact &= ((double)f0 == o0) & ((double)f1 == o1) & ((double)f2 == o2) & ((double)f3 == inf);
         } else {
           h_rec[g * 4] = p.edge_obs[3 * (size_t)e]; h_rec[g * 4 + 1] = p.edge_obs[3 * (size_t)e + 1]; h_rec[g * 4 + 2] = p.edge_obs[3 * (size_t)e + 2];
           h_rec[g * 4 + 3] = inf;
@@ -306,9 +313,10 @@ inline int pack_batch(int nw, const osh_lba_problem* pr, const std::function<voi
         }
       }
     }
-    for (plan_detail::Build& bd : L.builds) {
-      for (SRec& r : bd.recs) { r.lm = old2new[r.lm]; r.e_first = lmo[r.lm]; }
-      if (bd.sym) { L.n_sym++; L.recs_sym += bd.recs.size(); } else { L.n_cross++; L.recs_cross += bd.recs.size(); }
+    if (!exact) inexact.store(1, std::memory_order_relaxed);
+    for (SRec& r : L.recs) { r.lm = old2new[r.lm]; r.e_first = lmo[r.lm]; }
+    for (const plan_detail::Build& bd : L.builds) {
+      if (bd.sym) { L.n_sym++; L.recs_sym += bd.n_rec; } else { L.n_cross++; L.recs_cross += bd.n_rec; }
     }
     // chunks of the landmark-major kernels: consecutive landmarks, <= kChunkMaxEdges edges and <= kBlock landmarks (a single
     // landmark with more edges gets its own multi-pass chunk)
@@ -332,6 +340,7 @@ inline int pack_batch(int nw, const osh_lba_problem* pr, const std::function<voi
     for (std::thread& t : pool) t.join();
   }
   for (int w = 0; w < nw; ++w) if (locals[w].err != OSH_OK) return fail(locals[w].err, "%s", locals[w].msg);
+  if (pb.rec_f32 && inexact.load()) return pack_batch(nw, pr, alloc, n_threads, pb, false);
 
   // ---- phase 2: offsets of the plan sections, then a parallel merge
   struct WOff { size_t chunk, sym_item, cross_item, sym_rec, cross_rec, rblk, crange; int contrib, ccontrib; };
@@ -384,16 +393,16 @@ inline int pack_batch(int nw, const osh_lba_problem* pr, const std::function<voi
       const size_t it = bd.sym ? is++ : ic++;
       size_t& r = bd.sym ? rs : rc;
       SItem I;
-      I.win = w; I.rec_off = (int)r; I.n_lm = (int)bd.recs.size();
-      I.shape = (int)bd.X.size() | ((int)bd.Y.size() << 8) | ((bd.sym ? 1 : 0) << 16);
+      I.win = w; I.rec_off = (int)r; I.n_lm = bd.n_rec;
+      I.shape = bd.nx | (bd.ny << 8) | ((bd.sym ? 1 : 0) << 16);
       h_items[it] = I;
-      std::memcpy(h_recs + r, bd.recs.data(), bd.recs.size() * sizeof(SRec));
-      r += bd.recs.size();
+      std::memcpy(h_recs + r, L.recs.data() + bd.rec_off, (size_t)bd.n_rec * sizeof(SRec));
+      r += bd.n_rec;
       for (int k = 0; k < 64; ++k) h_spair[it * 64 + k] = bd.pair_slot[k] >= 0 ? bd.pair_slot[k] + o.contrib : -1;
       for (int k = 0; k < 8; ++k) {
         h_scslot[it * 8 + k] = bd.c_slot[k] >= 0 ? bd.c_slot[k] + o.ccontrib : -1;
-        h_posex[it * 8 + k] = k < (int)bd.X.size() ? bd.X[k] : -1;
-        h_posey[it * 8 + k] = k < (int)bd.Y.size() ? bd.Y[k] : -1;
+        h_posex[it * 8 + k] = bd.X[k];
+        h_posey[it * 8 + k] = bd.Y[k];
       }
     }
     size_t rb_i = o.rblk, cr_i = o.crange;

@@ -78,32 +78,46 @@ inline void pack_poses(const int* obs, int r0, int r1, uint64_t out[2]) {
     out[w] = (out[w] & ~(0xffffull << sh)) | ((uint64_t)(unsigned)obs[r] << sh);
   }
 }
-inline void unpack_poses(const uint64_t in[2], std::vector<int>& out) {
-  out.clear();
-  for (int s = 0; s < kItemPoses; ++s) {
-    const unsigned v = (unsigned)((in[s >> 2] >> (48 - 16 * (s & 3))) & 0xffff);
-    if (v != 0xffff) out.push_back((int)v);
-  }
-}
 
+// One item being built.  The records of all builds of a window live in one flat array (PlanScratch::recs / the caller's),
+// [rec_off, rec_off + n_rec): no per-build allocations (a window has thousands of builds and windows are planned in parallel).
 struct Build {
   bool sym = true;
-  std::vector<int> X, Y;
-  std::vector<SRec> recs;
+  int nx = 0, ny = 0;
+  int X[kItemPoses], Y[kItemPoses];
+  int rec_off = 0, n_rec = 0;
   int pair_slot[64];
   int c_slot[8];
 };
 
-inline std::vector<int> set_union(const std::vector<int>& a, const std::vector<int>& b) {
-  std::vector<int> u;
-  std::set_union(a.begin(), a.end(), b.begin(), b.end(), std::back_inserter(u));
-  return u;
+// Reusable buffers of plan_window (one per packing thread)
+struct PlanScratch {
+  std::vector<Unit> units;
+  std::vector<int> table, rep, count, gid, gorder, uorder, cnt, ccnt, fill, cfill;
+  std::vector<size_t> start;
+};
+
+// union of two ascending pose lists (<= 8 entries each) into out (<= 16); returns its length
+inline int set_union(const int* a, int na, const int* b, int nb, int* out) {
+  int i = 0, j = 0, n = 0;
+  while (i < na && j < nb) { if (a[i] < b[j]) out[n++] = a[i++]; else if (b[j] < a[i]) out[n++] = b[j++]; else { out[n++] = a[i++]; ++j; } }
+  while (i < na) out[n++] = a[i++];
+  while (j < nb) out[n++] = b[j++];
+  return n;
+}
+inline int unpack_poses(const uint64_t in[2], int* out) {
+  int n = 0;
+  for (int s = 0; s < kItemPoses; ++s) {
+    const unsigned v = (unsigned)((in[s >> 2] >> (48 - 16 * (s & 3))) & 0xffff);
+    if (v != 0xffff) out[n++] = (int)v;
+  }
+  return n;
 }
 
-inline unsigned long long pack_slots(const std::vector<int>& S, const int* obs, int r0, int r1) {
+inline unsigned long long pack_slots(const int* S, int ns, const int* obs, int r0, int r1) {
   unsigned long long v = ~0ull;
   for (int r = r0; r < r1; ++r) {
-    const int slot = (int)(std::lower_bound(S.begin(), S.end(), obs[r]) - S.begin());
+    const int slot = (int)(std::lower_bound(S, S + ns, obs[r]) - S);
     v &= ~(0xffull << (8 * slot));
     v |= (unsigned long long)(unsigned)r << (8 * slot);
   }
@@ -115,93 +129,107 @@ inline unsigned long long pack_slots(const std::vector<int>& S, const int* obs, 
 // Adds the items of window `w` to `plan` (items of all windows are re-ordered by finish_plan).
 //   P: optimisable poses; L: landmarks; lmo[L+1]: sorted-edge offsets; nfree[L]: optimisable-pose
 //   edges of each landmark (they come first, poses ascending); epose: pose of every sorted edge.
+//   out_builds / out_recs: the window's items and their records (appended); sc: reusable buffers.
 // Returns false when a landmark has more optimisable observers than a record can index.
 inline bool plan_window(int w, int P, int L, const int* lmo, const int* nfree, const int* epose,
-                        std::vector<plan_detail::Build>& out_builds, SchurPlan& plan) {
+                        std::vector<plan_detail::Build>& out_builds, std::vector<SRec>& out_recs, SchurPlan& plan,
+                        plan_detail::PlanScratch& sc) {
   using namespace plan_detail;
-  std::vector<Unit> units;
-  units.reserve((size_t)L + L / 2);
+  std::vector<Unit>& units = sc.units;
+  units.clear();
+  if (units.capacity() < (size_t)L + L / 2) units.reserve((size_t)L + L / 2);
+  if (P >= 0xffff) return false;
   for (int j = 0; j < L; ++j) {
     const int k = nfree[j];
-    if (k > 254 || P >= 0xffff) return false;
+    if (k > 254) return false;
     const int* obs = epose + lmo[j];
-    const int nparts = std::max(1, (k + kItemPoses - 1) / kItemPoses);
-    for (int a = 0; a < nparts; ++a)
-      for (int b = a; b < nparts; ++b) {
-        Unit u;
-        u.k[0] = (a == b) ? 0 : 1;
-        const int a0 = a * kItemPoses, a1 = std::min(k, a0 + kItemPoses);
-        const int b0 = b * kItemPoses, b1 = std::min(k, b0 + kItemPoses);
-        pack_poses(obs, a0, a1, &u.k[1]);
-        pack_poses(obs, b0, b1, &u.k[3]);
-        u.lm = j; u.a = a; u.b = b;
-        units.push_back(u);
-      }
+    if (k <= kItemPoses) {            // one symmetric unit (the common case)
+      Unit u;
+      u.k[0] = 0;
+      pack_poses(obs, 0, k, &u.k[1]);
+      u.k[3] = u.k[1]; u.k[4] = u.k[2];
+      u.lm = j; u.a = 0; u.b = 0;
+      units.push_back(u);
+    } else {
+      const int nparts = (k + kItemPoses - 1) / kItemPoses;
+      for (int a = 0; a < nparts; ++a)
+        for (int b = a; b < nparts; ++b) {
+          Unit u;
+          u.k[0] = (a == b) ? 0 : 1;
+          const int a0 = a * kItemPoses, a1 = std::min(k, a0 + kItemPoses);
+          const int b0 = b * kItemPoses, b1 = std::min(k, b0 + kItemPoses);
+          pack_poses(obs, a0, a1, &u.k[1]);
+          pack_poses(obs, b0, b1, &u.k[3]);
+          u.lm = j; u.a = a; u.b = b;
+          units.push_back(u);
+        }
+    }
     plan.pair_blocks += (long long)k * (k + 1) / 2;
   }
   // Order by unit_less.  A window has few distinct keys (hundreds, against tens of thousands of units), so the units are
   // bucketed by key with a small open-addressing table, only the distinct keys are sorted, and the units of a key keep their
-  // creation order (lm, a, b ascending), which is unit_less's tie-break.
+  // creation order (lm, a, b ascending), which is unit_less's tie-break.  `uorder` is the resulting permutation.
+  const size_t nu = units.size();
+  std::vector<int>& uorder = sc.uorder;
   {
     size_t cap = 64;
-    while (cap < 2 * units.size()) cap <<= 1;
-    std::vector<int> table(cap, -1);          // slot -> group
-    std::vector<int> rep, count, gid(units.size());   // group -> first unit with that key, number of units
-    for (size_t i = 0; i < units.size(); ++i) {
+    while (cap < 2 * nu) cap <<= 1;
+    sc.table.assign(cap, -1);          // slot -> group
+    sc.rep.clear(); sc.count.clear();  // group -> first unit with that key, number of units
+    sc.gid.resize(nu);
+    for (size_t i = 0; i < nu; ++i) {
       const Unit& u = units[i];
       uint64_t h = u.k[0] * 0x9e3779b97f4a7c15ull;
       for (int q = 1; q < 5; ++q) { h ^= u.k[q]; h *= 0xff51afd7ed558ccdull; h ^= h >> 32; }
       size_t slot = (size_t)h & (cap - 1);
-      while (table[slot] >= 0 && !units[rep[table[slot]]].same_key(u)) slot = (slot + 1) & (cap - 1);
-      if (table[slot] < 0) { table[slot] = (int)rep.size(); rep.push_back((int)i); count.push_back(0); }
-      gid[i] = table[slot];
-      count[gid[i]]++;
+      while (sc.table[slot] >= 0 && !units[sc.rep[sc.table[slot]]].same_key(u)) slot = (slot + 1) & (cap - 1);
+      if (sc.table[slot] < 0) { sc.table[slot] = (int)sc.rep.size(); sc.rep.push_back((int)i); sc.count.push_back(0); }
+      sc.gid[i] = sc.table[slot];
+      sc.count[sc.gid[i]]++;
     }
-    std::vector<int> gorder(rep.size());
-    for (size_t g = 0; g < rep.size(); ++g) gorder[g] = (int)g;
-    std::sort(gorder.begin(), gorder.end(), [&](int p, int q) { return unit_less(units[rep[p]], units[rep[q]]); });
-    std::vector<size_t> start(rep.size());
+    const size_t ng = sc.rep.size();
+    sc.gorder.resize(ng);
+    for (size_t g = 0; g < ng; ++g) sc.gorder[g] = (int)g;
+    std::sort(sc.gorder.begin(), sc.gorder.end(), [&](int p, int q) { return unit_less(units[sc.rep[p]], units[sc.rep[q]]); });
+    sc.start.resize(ng);
     size_t acc = 0;
-    for (int g : gorder) { start[g] = acc; acc += (size_t)count[g]; }
-    std::vector<Unit> sorted(units.size());
-    for (size_t i = 0; i < units.size(); ++i) sorted[start[gid[i]]++] = units[i];
-    units.swap(sorted);
+    for (int g : sc.gorder) { sc.start[g] = acc; acc += (size_t)sc.count[g]; }
+    uorder.resize(nu);
+    for (size_t i = 0; i < nu; ++i) uorder[sc.start[sc.gid[i]]++] = (int)i;
   }
 
   const size_t first_build = out_builds.size();
-  std::vector<int> curX, curY;
-  std::vector<const Unit*> cur;
+  int curX[2 * kItemPoses], curY[2 * kItemPoses], ncx = 0, ncy = 0;
+  size_t cur0 = 0, cur1 = 0;      // [cur0, cur1) of uorder: the units of the item(s) being collected
   bool cur_sym = true;
-  auto key_sets = [](const Unit& u, std::vector<int>& X, std::vector<int>& Y) {
-    unpack_poses(&u.k[1], X);
-    unpack_poses(&u.k[3], Y);
-  };
   auto flush = [&]() {
-    for (size_t base = 0; base < cur.size(); base += kItemMaxLm) {
-      Build bd;
-      bd.sym = cur_sym; bd.X = curX; bd.Y = curY;
+    for (size_t base = cur0; base < cur1; base += kItemMaxLm) {
+      out_builds.emplace_back();
+      Build& bd = out_builds.back();
+      bd.sym = cur_sym; bd.nx = ncx; bd.ny = ncy;
+      for (int s2 = 0; s2 < kItemPoses; ++s2) { bd.X[s2] = s2 < ncx ? curX[s2] : -1; bd.Y[s2] = s2 < ncy ? curY[s2] : -1; }
       std::fill(bd.pair_slot, bd.pair_slot + 64, -1);
       std::fill(bd.c_slot, bd.c_slot + 8, -1);
-      const size_t end = std::min(cur.size(), base + kItemMaxLm);
-      bd.recs.reserve(end - base);
+      const size_t end = std::min(cur1, base + kItemMaxLm);
+      bd.rec_off = (int)out_recs.size(); bd.n_rec = (int)(end - base);
       const Unit* prev = nullptr;
       unsigned long long xs = 0, ys = 0;
       for (size_t x = base; x < end; ++x) {
-        const Unit& u = *cur[x];
+        const Unit& u = units[uorder[x]];
         const int k = nfree[u.lm];
         const int* obs = epose + lmo[u.lm];
         const int a0 = u.a * kItemPoses, a1 = std::min(k, a0 + kItemPoses);
         const int b0 = u.b * kItemPoses, b1 = std::min(k, b0 + kItemPoses);
         // units with the same key and part pair have the same slot assignment and mark the same live pairs
         const bool same = prev && prev->same_key(u) && prev->a == u.a && prev->b == u.b;
-        if (!same) { xs = pack_slots(curX, obs, a0, a1); ys = pack_slots(curY, obs, b0, b1); }
+        if (!same) { xs = pack_slots(curX, ncx, obs, a0, a1); ys = pack_slots(curY, ncy, obs, b0, b1); }
         prev = &u;
         SRec r;
         r.lm = u.lm; r.e_first = lmo[u.lm];
         r.x_lo = (unsigned)xs; r.x_hi = (unsigned)(xs >> 32); r.y_lo = (unsigned)ys; r.y_hi = (unsigned)(ys >> 32);
         r.flags = ((u.a == 0 && u.b == 0) ? (1 | (std::min(k, kItemPoses) << 8)) : 0) | (a0 << 16) | ((a1 - a0) << 24);
         r.pad = lmo[u.lm + 1] - lmo[u.lm];
-        bd.recs.push_back(r);
+        out_recs.push_back(r);
         // live pairs (marked with -2, numbered later)
         if (same) continue;
         for (int sa = 0; sa < kItemPoses; ++sa) {
@@ -211,43 +239,46 @@ inline bool plan_window(int w, int P, int L, const int* lmo, const int* nfree, c
             if (((ys >> (8 * sb)) & 0xff) != kAbsent) bd.pair_slot[sa * 8 + sb] = -2;
         }
       }
-      const int tx = tiles_of((int)curX.size()), ty = tiles_of((int)curY.size());
+      const int tx = tiles_of(ncx), ty = tiles_of(ncy);
       const long long tiles = cur_sym ? (long long)tx * (tx + 1) / 2 : (long long)tx * ty;
       plan.tile_steps += tiles * 6 * (long long)((end - base + 7) / 8);
-      out_builds.push_back(std::move(bd));
     }
-    cur.clear();
+    cur0 = cur1;
   };
-  std::vector<int> gX, gY;
+  int gX[kItemPoses], gY[kItemPoses], ux[2 * kItemPoses], uy[2 * kItemPoses];
   size_t x = 0;
-  while (x < units.size()) {
+  while (x < nu) {
+    const Unit& u0 = units[uorder[x]];
     size_t x1 = x + 1;
-    while (x1 < units.size() && units[x1].same_key(units[x])) ++x1;
-    key_sets(units[x], gX, gY);
-    const bool g_sym = units[x].k[0] == 0;
+    while (x1 < nu && units[uorder[x1]].same_key(u0)) ++x1;
+    const int ngx = unpack_poses(&u0.k[1], gX), ngy = unpack_poses(&u0.k[3], gY);
+    const bool g_sym = u0.k[0] == 0;
     bool merged = false;
-    if (!cur.empty() && cur_sym == g_sym && cur.size() < (size_t)kItemMaxLm) {
-      std::vector<int> ux = set_union(curX, gX), uy = set_union(curY, gY);
-      if ((int)ux.size() <= kItemPoses && (int)uy.size() <= kItemPoses &&
-          tiles_of((int)ux.size()) == tiles_of((int)curX.size()) && tiles_of((int)ux.size()) == tiles_of((int)gX.size()) &&
-          tiles_of((int)uy.size()) == tiles_of((int)curY.size()) && tiles_of((int)uy.size()) == tiles_of((int)gY.size())) {
-        curX.swap(ux); curY.swap(uy);
+    if (cur1 > cur0 && cur_sym == g_sym && (cur1 - cur0) < (size_t)kItemMaxLm) {
+      const int nux = set_union(curX, ncx, gX, ngx, ux), nuy = set_union(curY, ncy, gY, ngy, uy);
+      if (nux <= kItemPoses && nuy <= kItemPoses && tiles_of(nux) == tiles_of(ncx) && tiles_of(nux) == tiles_of(ngx) &&
+          tiles_of(nuy) == tiles_of(ncy) && tiles_of(nuy) == tiles_of(ngy)) {
+        std::copy(ux, ux + nux, curX); ncx = nux;
+        std::copy(uy, uy + nuy, curY); ncy = nuy;
         merged = true;
       }
     }
     if (!merged) {
-      if (!cur.empty()) flush();
-      curX = gX; curY = gY; cur_sym = g_sym;
+      if (cur1 > cur0) flush();
+      std::copy(gX, gX + ngx, curX); ncx = ngx;
+      std::copy(gY, gY + ngy, curY); ncy = ngy;
+      cur_sym = g_sym;
     }
-    for (size_t u = x; u < x1; ++u) cur.push_back(&units[u]);
+    cur1 = x1;
     x = x1;
   }
-  if (!cur.empty()) flush();
+  if (cur1 > cur0) flush();
 
   // contribution slots: the contributions of one block of S are contiguous, in item order
   const int nblk = P * (P + 1) / 2;
   auto blk = [P](int i, int j) { return i * P - i * (i - 1) / 2 + (j - i); };
-  std::vector<int> cnt((size_t)nblk + 1, 0), ccnt((size_t)P + 1, 0);
+  std::vector<int>& cnt = sc.cnt; std::vector<int>& ccnt = sc.ccnt;
+  cnt.assign((size_t)nblk + 1, 0); ccnt.assign((size_t)P + 1, 0);
   for (size_t b = first_build; b < out_builds.size(); ++b) {
     const Build& bd = out_builds[b];
     for (int sa = 0; sa < 8; ++sa) {
@@ -258,19 +289,20 @@ inline bool plan_window(int w, int P, int L, const int* lmo, const int* nfree, c
   for (int k = 0; k < nblk; ++k) cnt[k + 1] += cnt[k];
   for (int k = 0; k < P; ++k) ccnt[k + 1] += ccnt[k];
   const size_t c0 = plan.n_contrib, cc0 = plan.n_ccontrib;
+  plan.rblk.reserve(plan.rblk.size() + (size_t)nblk + P);
   for (int i = 0; i < P; ++i)
     for (int j = i; j < P; ++j) {
       const int k = blk(i, j);
       plan.rblk.push_back(RBlk{w, i | (j << 16), (int)(c0 + cnt[k]), cnt[k + 1] - cnt[k]});
     }
   for (int i = 0; i < P; ++i) plan.rblk.push_back(RBlk{w, i | (0xffff << 16), (int)(cc0 + ccnt[i]), ccnt[i + 1] - ccnt[i]});
-  std::vector<int> fill(cnt.begin(), cnt.end() - 1), cfill(ccnt.begin(), ccnt.end() - 1);
+  sc.fill.assign(cnt.begin(), cnt.end() - 1); sc.cfill.assign(ccnt.begin(), ccnt.end() - 1);
   for (size_t b = first_build; b < out_builds.size(); ++b) {
     Build& bd = out_builds[b];
     for (int sa = 0; sa < 8; ++sa) {
-      if (bd.c_slot[sa] == -2) bd.c_slot[sa] = (int)(cc0 + cfill[bd.X[sa]]++);
+      if (bd.c_slot[sa] == -2) bd.c_slot[sa] = (int)(cc0 + sc.cfill[bd.X[sa]]++);
       for (int sb = 0; sb < 8; ++sb)
-        if (bd.pair_slot[sa * 8 + sb] == -2) bd.pair_slot[sa * 8 + sb] = (int)(c0 + fill[blk(bd.X[sa], bd.Y[sb])]++);
+        if (bd.pair_slot[sa * 8 + sb] == -2) bd.pair_slot[sa * 8 + sb] = (int)(c0 + sc.fill[blk(bd.X[sa], bd.Y[sb])]++);
     }
   }
   plan.n_contrib += (size_t)cnt[nblk];
@@ -280,7 +312,7 @@ inline bool plan_window(int w, int P, int L, const int* lmo, const int* nfree, c
 
 // Flattens the per-window builds into the device arrays: symmetric items first (they and the
 // cross items are launched as two kernels with different register budgets).
-inline void finish_plan(const std::vector<int>& build_win, std::vector<plan_detail::Build>& builds, SchurPlan& plan) {
+inline void finish_plan(const std::vector<int>& build_win, const std::vector<plan_detail::Build>& builds, const std::vector<SRec>& recs, SchurPlan& plan) {
   std::vector<size_t> order;
   for (size_t b = 0; b < builds.size(); ++b) if (builds[b].sym) order.push_back(b);
   plan.n_sym = (int)order.size();
@@ -289,16 +321,13 @@ inline void finish_plan(const std::vector<int>& build_win, std::vector<plan_deta
   for (size_t b : order) {
     const plan_detail::Build& bd = builds[b];
     SItem it;
-    it.win = build_win[b]; it.rec_off = (int)plan.recs.size(); it.n_lm = (int)bd.recs.size();
-    it.shape = (int)bd.X.size() | ((int)bd.Y.size() << 8) | ((bd.sym ? 1 : 0) << 16);
+    it.win = build_win[b]; it.rec_off = (int)plan.recs.size(); it.n_lm = bd.n_rec;
+    it.shape = bd.nx | (bd.ny << 8) | ((bd.sym ? 1 : 0) << 16);
     plan.items.push_back(it);
-    plan.recs.insert(plan.recs.end(), bd.recs.begin(), bd.recs.end());
+    plan.recs.insert(plan.recs.end(), recs.begin() + bd.rec_off, recs.begin() + bd.rec_off + bd.n_rec);
     plan.pair_slot.insert(plan.pair_slot.end(), bd.pair_slot, bd.pair_slot + 64);
     plan.c_slot.insert(plan.c_slot.end(), bd.c_slot, bd.c_slot + 8);
-    for (int s = 0; s < 8; ++s) {
-      plan.pose_x.push_back(s < (int)bd.X.size() ? bd.X[s] : -1);
-      plan.pose_y.push_back(s < (int)bd.Y.size() ? bd.Y[s] : -1);
-    }
+    for (int s = 0; s < 8; ++s) { plan.pose_x.push_back(bd.X[s]); plan.pose_y.push_back(bd.Y[s]); }
   }
 }
 

@@ -33,9 +33,11 @@ extern "C" int osh_lba_schur_plan_stats(const osh_lba_problem* p, int64_t stats[
   epose.push_back(0);
   SchurPlan plan;
   std::vector<plan_detail::Build> builds;
-  if (!plan_window(0, P, L, lmo.data(), nfree.data(), epose.data(), builds, plan)) { set_error("landmark with > 254 observers"); return OSH_ERR_UNSUPPORTED; }
+  std::vector<SRec> brecs;
+  plan_detail::PlanScratch psc;
+  if (!plan_window(0, P, L, lmo.data(), nfree.data(), epose.data(), builds, brecs, plan, psc)) { set_error("landmark with > 254 observers"); return OSH_ERR_UNSUPPORTED; }
   std::vector<int> build_win(builds.size(), 0);
-  finish_plan(build_win, builds, plan);
+  finish_plan(build_win, builds, brecs, plan);
 
   // ---- verification
   std::map<std::pair<int, int>, std::pair<int, int>> range;   // block -> [start, start+count)

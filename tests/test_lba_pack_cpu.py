@@ -99,3 +99,25 @@ def test_duplicate_pair_without_a_rig_is_refused():
     w3.edge_kind[0] = capi.OSH_EDGE_BODY
     rc, msg, _, _ = pack_check([w3])
     assert rc == capi.OSH_ERR_INVALID and "body edge" in msg
+
+
+def test_shuffled_edges_and_double_records_take_the_general_paths():
+    """Edges in any order pack to the same structure as the reference's landmark-major order (counting sort + insertion sort
+    instead of the fast path); observations that are not float32 values repack the batch with double records."""
+    w = synth.make_window(12, n_free=7, n_fixed=3, n_points=500, stereo=True)
+    rc, msg, st, _ = pack_check([w])
+    assert rc == 0, msg
+    rng = np.random.default_rng(1)
+    perm = rng.permutation(w.n_edges)
+    w2 = synth.make_window(12, n_free=7, n_fixed=3, n_points=500, stereo=True)
+    for k in ("edge_pose", "edge_point", "edge_kind", "edge_obs", "edge_info"):
+        setattr(w2, k, np.ascontiguousarray(getattr(w2, k)[perm]))
+    rc2, msg2, st2, _ = pack_check([w2])
+    assert rc2 == 0, msg2
+    assert {k: st2[k] for k in ("items", "sym", "recs", "contrib", "chunks", "staging_bytes")} == {k: st[k] for k in ("items", "sym", "recs", "contrib", "chunks", "staging_bytes")}
+    w3 = synth.make_window(12, n_free=7, n_fixed=3, n_points=500, stereo=True)
+    w3.edge_obs = w3.edge_obs + 1e-9                     # no longer float32 values
+    rc3, msg3, st3, _ = pack_check([w, w3])
+    assert rc3 == 0, msg3
+    rc4, _, st4, _ = pack_check([w, w])
+    assert st3["staging_bytes"] > st4["staging_bytes"]   # 32-byte records instead of 16-byte ones
