@@ -199,6 +199,10 @@ typedef struct osh_pose_problem {
   float chi2_mono[4], chi2_stereo[4];
   int32_t iterations[4];
   const double* kb8;          /* NULL: pinhole.  [4] k1..k4: the frame's camera is a KannalaBrandt8 (as osh_lba_problem.kb8), mono edges only */
+  /* fisheye stereo frame (Nleft != -1, src/Optimizer.cc:933-1008): OSH_EDGE_BODY edges are EdgeSE3ProjectXYZOnlyPoseToBody, the
+   * keypoints of the right camera; they need kb8, cam2 and trl (as osh_lba_problem.cam2 / trl) */
+  const double* cam2;         /* NULL or [8] fx fy cx cy k1..k4 of the right camera */
+  const double* trl;          /* NULL or [7] Trl qx qy qz qw tx ty tz */
 } osh_pose_problem;
 
 typedef struct osh_pose_result {

@@ -112,6 +112,7 @@ int osh_host_search_local_points_rig(osh_host_frame* f, int32_t n_mp, const uint
                                      const uint8_t* in_right, const float* proj_right, const int32_t* level_right,
                                      const float* viewcos_right, const int32_t* n_observations, float nnratio, float th,
                                      int32_t* assignment);
+int osh_host_frame_set_camera2(osh_host_frame* f, const float cam2[8]);
 void osh_host_frame_destroy(osh_host_frame* f);
 /* Switch the frame's camera to a KannalaBrandt8 (same fx fy cx cy, coefficients k1..k4). */
 void osh_host_frame_set_fisheye(osh_host_frame* f, const float k[4]);

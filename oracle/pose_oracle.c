@@ -35,7 +35,9 @@ static double edge_chi2(const pstate* s, int e) {
 
 static void compute_error(pstate* s, int e) {
   const osh_pose_problem* p = s->p;
-  if (p->kb8 && p->edge_kind[e] == OSH_EDGE_MONO)
+  if (p->edge_kind[e] == OSH_EDGE_BODY)   /* EdgeSE3ProjectXYZOnlyPoseToBody (include/OptimizableTypes.h:62-87): same expressions as the binary edge */
+    oracle_edge_error_body(s->qt, p->cam2, p->trl, p->points + 3 * (size_t)e, p->edge_obs + 3 * (size_t)e, s->err + 3 * (size_t)e);
+  else if (p->kb8 && p->edge_kind[e] == OSH_EDGE_MONO)
     oracle_edge_error_kb8(s->qt, p->cam, p->kb8, p->points + 3 * (size_t)e, p->edge_obs + 3 * (size_t)e, s->err + 3 * (size_t)e);
   else
     oracle_edge_error(p->edge_kind[e], s->qt, p->cam, p->points + 3 * (size_t)e, p->edge_obs + 3 * (size_t)e, s->err + 3 * (size_t)e);
@@ -52,7 +54,7 @@ static double active_robust_chi2(const pstate* s) {
     const double c = edge_chi2(s, e);
     if (s->robust) {
       double rho[3];
-      oracle_huber(c, s->p->edge_kind[e] == OSH_EDGE_MONO ? s->p->huber_mono : s->p->huber_stereo, rho);
+      oracle_huber(c, s->p->edge_kind[e] != OSH_EDGE_STEREO ? s->p->huber_mono : s->p->huber_stereo, rho);
       chi += rho[0];
     } else chi += c;
   }
@@ -66,18 +68,19 @@ static void build_system(pstate* s, double H[36], double b[6]) {
   for (int e = 0; e < p->n_edges; ++e) {
     if (s->level[e]) continue;
     double JX[9], Jp[18];
-    if (p->kb8 && p->edge_kind[e] == OSH_EDGE_MONO) oracle_edge_jacobians_kb8(s->qt, p->cam, p->kb8, p->points + 3 * (size_t)e, JX, Jp);
+    if (p->edge_kind[e] == OSH_EDGE_BODY) oracle_edge_jacobians_body(s->qt, p->cam2, p->trl, p->points + 3 * (size_t)e, JX, Jp);
+    else if (p->kb8 && p->edge_kind[e] == OSH_EDGE_MONO) oracle_edge_jacobians_kb8(s->qt, p->cam, p->kb8, p->points + 3 * (size_t)e, JX, Jp);
     else oracle_edge_jacobians(p->edge_kind[e], s->qt, p->cam, p->points + 3 * (size_t)e, JX, Jp);
     const double* r = s->err + 3 * (size_t)e;
     const double info = p->edge_info[e];
     double rho1 = 1.0;
     if (s->robust) {
       double rho[3];
-      oracle_huber(edge_chi2(s, e), p->edge_kind[e] == OSH_EDGE_MONO ? p->huber_mono : p->huber_stereo, rho);
+      oracle_huber(edge_chi2(s, e), p->edge_kind[e] != OSH_EDGE_STEREO ? p->huber_mono : p->huber_stereo, rho);
       rho1 = rho[1];
     }
     const double ww = rho1 * info;
-    const int d = p->edge_kind[e] == OSH_EDGE_MONO ? 2 : 3;
+    const int d = p->edge_kind[e] != OSH_EDGE_STEREO ? 2 : 3;
     for (int a = 0; a < 6; ++a) {
       for (int c = 0; c < 6; ++c) {
         double t = 0;
@@ -186,7 +189,7 @@ int oracle_pose_optimize(const osh_pose_problem* p, osh_pose_result* res) {
     for (int e = 0; e < p->n_edges; ++e) {
       if (outlier[e]) compute_error(&s, e);         /* level-1 edges were not evaluated by the optimiser (:1036-1039) */
       const float chi2 = (float)edge_chi2(&s, e);    /* const float chi2 = e->chi2() */
-      const float th = p->edge_kind[e] == OSH_EDGE_MONO ? p->chi2_mono[it] : p->chi2_stereo[it];
+      const float th = p->edge_kind[e] != OSH_EDGE_STEREO ? p->chi2_mono[it] : p->chi2_stereo[it];   /* right-camera edges: chi2Mono (:1053) */
       if (res->edge_chi2) res->edge_chi2[e] = edge_chi2(&s, e);
       if (chi2 > th) { outlier[e] = 1; s.level[e] = 1; nBad++; }
       else { outlier[e] = 0; s.level[e] = 0; }

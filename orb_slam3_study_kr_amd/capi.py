@@ -71,7 +71,7 @@ class PoseProblem(C.Structure):
         ("edge_kind", c_uint8_p), ("edge_obs", c_double_p), ("edge_info", c_double_p),
         ("huber_mono", C.c_double), ("huber_stereo", C.c_double),
         ("chi2_mono", C.c_float * 4), ("chi2_stereo", C.c_float * 4), ("iterations", C.c_int32 * 4),
-        ("kb8", c_double_p),
+        ("kb8", c_double_p), ("cam2", c_double_p), ("trl", c_double_p),
     ]
 
 
@@ -287,6 +287,7 @@ _HOST_SIGNATURES = {
                                                c_int32_p, C.c_float, C.c_float, c_int32_p]),
     "osh_host_search_last_frame": (C.c_int, [C.c_void_p, C.c_void_p, c_int32_p, C.c_int32, c_float_p, c_uint8_p, C.c_float, C.c_int32,
                                              C.c_int32, c_int32_p]),
+    "osh_host_frame_set_camera2": (C.c_int, [C.c_void_p, c_float_p]),
     "osh_host_frame_pose_optimization": (C.c_int, [C.c_void_p, C.c_int32, c_float_p, c_int32_p, c_float_p, C.c_int32, c_float_p, c_uint8_p]),
     "osh_host_posei_create": (C.c_void_p, [C.c_int32, C.c_int32, c_float_p, c_int32_p, c_float_p, C.c_int32, c_float_p, c_float_p, c_float_p, c_float_p,
                                            c_float_p, c_float_p, C.c_int32, c_float_p, c_uint8_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,

@@ -361,7 +361,7 @@ extern "C" int osh_host_inertial_information(const float* cov225, double* info81
 // ------------------------------------------------------------------------------------------ matcher
 struct osh_host_frame {
   Frame F;
-  std::unique_ptr<GeometricCamera> cam;
+  std::unique_ptr<GeometricCamera> cam, cam2;
   Map map;
 };
 
@@ -414,6 +414,14 @@ extern "C" int osh_host_frame_set_rig(osh_host_frame* f, int32_t n_left, const i
   F.mTrl = pose_from(trl_qt);
   F.mpCamera2 = F.mpCamera;
   F.AssignFeaturesToGrid();
+  return 0;
+}
+
+// The right camera of a fisheye stereo frame as its own KannalaBrandt8 (after osh_host_frame_set_rig, which shares the left one).
+extern "C" int osh_host_frame_set_camera2(osh_host_frame* f, const float cam2[8]) {
+  if (!f) return -1;
+  f->cam2.reset(new KannalaBrandt8(std::vector<float>(cam2, cam2 + 8)));
+  f->F.mpCamera2 = f->cam2.get();
   return 0;
 }
 

@@ -294,6 +294,53 @@ __device__ __forceinline__ void edge_jacobians_kb8(const double* R, const double
   for (int j = 0; j < 6; ++j) Jp[12 + j] = 0.0;
 }
 
+// EdgeSE3ProjectXYZOnlyPoseToBody / EdgeSE3ProjectXYZToBody (include/OptimizableTypes.h:62-87,117-144): the right camera of a
+// fisheye rig.  computeError maps through the SE3Quat product mTrl * T_lw (normalised quaternion, se3quat.h:104-110),
+// linearizeOplus through the two transforms one after the other (src/OptimizableTypes.cpp:91-107): each is restated as it is.
+// cam2: fx fy cx cy k1..k4 of the right camera, trl: qx qy qz qw tx ty tz.  Xl: point in the LEFT camera frame.
+__device__ __forceinline__ double edge_residual_body(const double* qt, const double* cam2, const double* trl, const double* X,
+                                                     const double* obs, double info, double* r, double* Xl, double* Xe) {
+  double rot[3], q[4], tr[3], rx[3];
+  quat_rotate(qt, X, rot);
+  Xl[0] = rot[0] + qt[4]; Xl[1] = rot[1] + qt[5]; Xl[2] = rot[2] + qt[6];
+  q[3] = trl[3] * qt[3] - trl[0] * qt[0] - trl[1] * qt[1] - trl[2] * qt[2];
+  q[0] = trl[3] * qt[0] + trl[0] * qt[3] + trl[1] * qt[2] - trl[2] * qt[1];
+  q[1] = trl[3] * qt[1] + trl[1] * qt[3] + trl[2] * qt[0] - trl[0] * qt[2];
+  q[2] = trl[3] * qt[2] + trl[2] * qt[3] + trl[0] * qt[1] - trl[1] * qt[0];
+  quat_normalize_rotation(q);
+  quat_rotate(trl, qt + 4, tr);
+  quat_rotate(q, X, rx);
+  Xe[0] = rx[0] + (tr[0] + trl[4]); Xe[1] = rx[1] + (tr[1] + trl[5]); Xe[2] = rx[2] + (tr[2] + trl[6]);
+  double u, v;
+  kb8_project(cam2, cam2 + 4, Xe, u, v);
+  r[0] = obs[0] - u;
+  r[1] = obs[1] - v;
+  r[2] = 0.0;
+  return r[0] * (info * r[0]) + r[1] * (info * r[1]);
+}
+// pose Jacobian only (the unary edge): Jp = -projectJac(X_r) * Rrl * SE3deriv(X_l), X_r = mTrl.map(X_l); rows 0..1, row 2 zero
+__device__ __forceinline__ void edge_jacobian_pose_body(const double* cam2, const double* trl, const double* Xl, double* Jp) {
+  double Rrl[9], Xr[3], J2[6], Pm[6];
+  quat_to_R(trl, Rrl);
+  quat_rotate(trl, Xl, Xr);
+  Xr[0] += trl[4]; Xr[1] += trl[5]; Xr[2] += trl[6];
+  kb8_project_jac(cam2, cam2 + 4, Xr, J2);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Pm[3 * i + j] = -(J2[3 * i] * Rrl[j] + J2[3 * i + 1] * Rrl[3 + j] + J2[3 * i + 2] * Rrl[6 + j]);
+  const double x = Xl[0], y = Xl[1], z = Xl[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    Jp[6 * i + 0] = Pm[3 * i + 2] * y - Pm[3 * i + 1] * z;
+    Jp[6 * i + 1] = Pm[3 * i] * z - Pm[3 * i + 2] * x;
+    Jp[6 * i + 2] = Pm[3 * i + 1] * x - Pm[3 * i] * y;
+    Jp[6 * i + 3] = Pm[3 * i]; Jp[6 * i + 4] = Pm[3 * i + 1]; Jp[6 * i + 5] = Pm[3 * i + 2];
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) Jp[12 + j] = 0.0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Compact description of a visual edge at the linearisation point.  Both reference Jacobians factor through the
 // camera-frame point Xc = R X + t:   d err / d X = Pm R,   d err / d pose = Pm [ -[Xc]x | I ]   with Pm = -projectJac(Xc)

@@ -25,6 +25,7 @@ struct PoseDesc {
   double qt[7], cam[5], huber_mono, huber_stereo;
   double kb8[4];   // KannalaBrandt8 k1..k4 (osh_pose_problem.kb8)
   int kb8_on;      // 1: the frame's mono edges project through KannalaBrandt8
+  double cam2[8], trl[7];   // fisheye stereo frame: right camera and Trl of the OSH_EDGE_BODY edges (EdgeSE3ProjectXYZOnlyPoseToBody)
   float chi2_mono[4], chi2_stereo[4];
   int iters[4];
 };
@@ -56,11 +57,13 @@ __device__ __forceinline__ double pose_block_sum(double v, double* sh) {
 template <bool KB8>
 __device__ __forceinline__ double pose_edge_residual(const PoseDesc& d, int kind, const double* qt, const double* X, const double* obs,
                                                      double info, double* r, double* Xc) {
+  if (KB8 && kind == OSH_EDGE_BODY) { double Xe[3]; return dev::edge_residual_body(qt, d.cam2, d.trl, X, obs, info, r, Xc, Xe); }   // Xc: left-camera point
   if (KB8 && d.kb8_on && kind == OSH_EDGE_MONO) return dev::edge_residual_kb8(qt, d.cam, d.kb8, X, obs, info, r, Xc);
   return dev::edge_residual(kind, qt, d.cam, X, obs, info, r, Xc);
 }
 template <bool KB8>
 __device__ __forceinline__ void pose_edge_jacobians(const PoseDesc& d, int kind, const double* R, const double* Xc, double* JX, double* Jp) {
+  if (KB8 && kind == OSH_EDGE_BODY) { dev::edge_jacobian_pose_body(d.cam2, d.trl, Xc, Jp); return; }   // unary edge: JX unused
   if (KB8 && d.kb8_on && kind == OSH_EDGE_MONO) { dev::edge_jacobians_kb8(R, d.cam, d.kb8, Xc, JX, Jp); return; }
   dev::edge_jacobians(kind, R, d.cam, Xc, JX, Jp);
 }
@@ -80,7 +83,7 @@ __device__ double pose_eval(const PoseView& v, const PoseDesc& d, const double* 
     v.chi2[ge] = c;
     if (robust) {
       double r0, r1;
-      dev::huber(c, kind == OSH_EDGE_MONO ? d.huber_mono : d.huber_stereo, r0, r1);
+      dev::huber(c, kind != OSH_EDGE_STEREO ? d.huber_mono : d.huber_stereo, r0, r1);
       acc += r0;
     } else acc += c;
   }
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(kPT) void k_pose_opt(PoseView v) {
         for (int k = 0; k < 3; ++k) { X[k] = v.X[ge * 3 + k]; obs[k] = v.obs[ge * 3 + k]; }
         const double c = pose_edge_residual<KB8>(d, kind, qt, X, obs, info, r, Xc);
         double r0 = c, r1 = 1.0;
-        if (robust) dev::huber(c, kind == OSH_EDGE_MONO ? d.huber_mono : d.huber_stereo, r0, r1);
+        if (robust) dev::huber(c, kind != OSH_EDGE_STEREO ? d.huber_mono : d.huber_stereo, r0, r1);
         double JX[9], Jp[18];
         pose_edge_jacobians<KB8>(d, kind, R, Xc, JX, Jp);
         const double ww = r1 * info;
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(kPT) void k_pose_opt(PoseView v) {
         v.chi2[ge] = pose_edge_residual<KB8>(d, kind, qf, X, obs, v.info[ge], r, Xc);
       }
       const float chi2 = (float)v.chi2[ge];
-      const float th = kind == OSH_EDGE_MONO ? d.chi2_mono[round] : d.chi2_stereo[round];
+      const float th = kind != OSH_EDGE_STEREO ? d.chi2_mono[round] : d.chi2_stereo[round];
       if (chi2 > th) { v.level[ge] = 1; ++bad; } else v.level[ge] = 0;
     }
     n_bad = (int)pose_block_sum((double)bad, sh);
@@ -296,13 +299,18 @@ extern "C" int osh_pose_optimize(osh_lba_ctx* ctx, int32_t n, const osh_pose_pro
     d.huber_mono = p.huber_mono; d.huber_stereo = p.huber_stereo;
     d.kb8_on = p.kb8 ? 1 : 0;
     for (int k = 0; k < 4; ++k) d.kb8[k] = p.kb8 ? p.kb8[k] : 0.0;
+    const bool rig = p.kb8 && p.cam2 && p.trl;
+    for (int k = 0; k < 8; ++k) d.cam2[k] = rig ? p.cam2[k] : 0.0;
+    for (int k = 0; k < 7; ++k) d.trl[k] = rig ? p.trl[k] : (k == 3 ? 1.0 : 0.0);
     if (p.kb8) {
       any_kb8 = true;
       for (int e = 0; e < p.n_edges; ++e)
-        if (p.edge_kind[e] != OSH_EDGE_MONO) { set_error("frame %d: a KannalaBrandt8 frame takes monocular edges only (edge %d)", f, e); return OSH_ERR_UNSUPPORTED; }
+        if (p.edge_kind[e] == OSH_EDGE_STEREO) { set_error("frame %d: a KannalaBrandt8 frame takes monocular and right-camera edges only (edge %d)", f, e); return OSH_ERR_UNSUPPORTED; }
     }
+    for (int e = 0; e < p.n_edges; ++e)
+      if (p.edge_kind[e] == OSH_EDGE_BODY && !rig) { set_error("frame %d edge %d: a right-camera edge needs kb8, cam2 and trl", f, e); return OSH_ERR_INVALID; }
     for (int k = 0; k < 4; ++k) { d.chi2_mono[k] = p.chi2_mono[k]; d.chi2_stereo[k] = p.chi2_stereo[k]; d.iters[k] = p.iterations[k]; }
-    for (int e = 0; e < p.n_edges; ++e) if (p.edge_kind[e] > OSH_EDGE_STEREO) { set_error("frame %d edge %d: kind out of range", f, e); return OSH_ERR_INVALID; }
+    for (int e = 0; e < p.n_edges; ++e) if (p.edge_kind[e] > OSH_EDGE_BODY) { set_error("frame %d edge %d: kind out of range", f, e); return OSH_ERR_INVALID; }
     NE += (size_t)p.n_edges;
   }
   if (NE > 0x7fffff00u) { set_error("batch too large for 32-bit offsets"); return OSH_ERR_UNSUPPORTED; }

@@ -311,6 +311,10 @@ class HostFrame:
         return n, assign
 
 
+    def set_camera2(self, cam2):
+        """Give the right camera of a fisheye stereo frame its own KannalaBrandt8 (fx fy cx cy k1..k4)."""
+        assert self.lib.osh_host_frame_set_camera2(self.f, capi.ptr(_f32(cam2), capi.c_float_p)) == 0
+
     def pose_optimization(self, kp_mp, mp_pos):
         """Optimizer::PoseOptimization(&frame) (src/Optimizer.cc:815-1114); returns (n_inliers, pose_qt, mvbOutlier)."""
         pose = np.zeros(7, dtype=np.float32)

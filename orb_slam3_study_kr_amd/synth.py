@@ -468,6 +468,8 @@ class PoseFrame:
     chi2_stereo: tuple = (7.815, 7.815, 7.815, 7.815)
     iterations: tuple = (10, 10, 10, 10)
     kb8: np.ndarray | None = None   # [4] KannalaBrandt8 k1..k4: mono edges project through the fisheye model
+    cam2: np.ndarray | None = None  # [8] right camera of a fisheye stereo frame (OSH_EDGE_BODY edges: EdgeSE3ProjectXYZOnlyPoseToBody)
+    trl: np.ndarray | None = None   # [7] Trl qx qy qz qw tx ty tz
 
     @property
     def n_edges(self) -> int:
@@ -499,6 +501,10 @@ class PoseFrame:
         if self.kb8 is not None:
             self.kb8 = np.ascontiguousarray(self.kb8, dtype=np.float64)
         p.kb8 = capi.ptr(self.kb8, capi.c_double_p)
+        if self.cam2 is not None:
+            self.cam2 = np.ascontiguousarray(self.cam2, dtype=np.float64)
+            self.trl = np.ascontiguousarray(self.trl, dtype=np.float64)
+        p.cam2, p.trl = capi.ptr(self.cam2, capi.c_double_p), capi.ptr(self.trl, capi.c_double_p)
         return p
 
 
@@ -522,10 +528,13 @@ class PoseResultArrays:
 
 
 def make_pose_frame(seed: int = 21, n_points: int = 800, stereo: bool = True, mixed_mono_frac: float = 0.3, outlier_frac: float = 0.1,
-                    pose_noise=(0.01, 0.05), fisheye: bool = False) -> PoseFrame:
+                    pose_noise=(0.01, 0.05), fisheye: bool = False, rig: bool = False) -> PoseFrame:
     """A tracked frame: map points in front of the camera, pixel noise by pyramid level, gross outliers (wrong matches),
-    the initial pose = ground truth + perturbation, everything the reference stores as float rounded to float32."""
+    the initial pose = ground truth + perturbation, everything the reference stores as float rounded to float32.
+    ``rig``: a fisheye stereo frame (Nleft != -1): about 45 % of the matched keypoints belong to the right camera (OSH_EDGE_BODY)."""
     rng = np.random.Generator(np.random.PCG64(seed))
+    if rig:
+        fisheye, stereo = True, False
     yaw = 0.1
     Rcw = _rodrigues(np.array([0.02, yaw, -0.01]))
     tcw = np.array([0.3, -0.1, 0.2])
@@ -557,6 +566,20 @@ def make_pose_frame(seed: int = 21, n_points: int = 800, stereo: bool = True, mi
     dR = _rodrigues(rng.standard_normal(3) * pose_noise[0])
     init = np.concatenate([_quat_from_R(dR @ Rcw), tcw + rng.standard_normal(3) * pose_noise[1]])
     cam = np.array([FX, FY, CX, CY, BF], dtype=np.float32).astype(np.float64)
+    cam2 = trl = None
+    if rig:
+        cam2 = np.array([float(FX) * 1.01, float(FY) * 0.99, float(CX) + 3.0, float(CY) - 2.0, *(KB8_K * np.array([1.05, 0.9, 1.1, 1.0]))]).astype(np.float32).astype(np.float64)
+        rv = np.array([0.01, -0.02, 0.005])
+        ang = np.linalg.norm(rv)
+        trl = np.concatenate([np.sin(ang / 2) * rv / ang, [np.cos(ang / 2)], [-0.1, 0.002, 0.001]]).astype(np.float32).astype(np.float64)
+        Xr = Xc @ _quat_to_R(trl[:4] / np.linalg.norm(trl[:4])).T + trl[4:]
+        th = np.arctan2(np.hypot(Xr[:, 0], Xr[:, 1]), Xr[:, 2])
+        ps = np.arctan2(Xr[:, 1], Xr[:, 0])
+        rr = th + cam2[4] * th**3 + cam2[5] * th**5 + cam2[6] * th**7 + cam2[7] * th**9
+        right = rng.uniform(0, 1, E) < 0.45
+        obs[right, 0] = (cam2[0] * rr * np.cos(ps) + cam2[2] + noise[:, 0])[right]
+        obs[right, 1] = (cam2[1] * rr * np.sin(ps) + cam2[3] + noise[:, 1])[right]
+        kind[right] = capi.OSH_EDGE_BODY
     return PoseFrame(pose_qt=_f32(init), cam=cam, points=_f32(Xw), edge_kind=kind, edge_obs=_f32(obs),
                      edge_info=INV_LEVEL_SIGMA2[octave].astype(np.float64), gt_pose_qt=gt, outlier_mask=is_out,
-                     kb8=KB8_K.copy() if fisheye else None).normalise()
+                     kb8=KB8_K.copy() if fisheye else None, cam2=cam2, trl=trl).normalise()

@@ -598,6 +598,32 @@ def test_pose_optimization_through_the_reference_signature(ob, fisheye):
     assert n_in > 0.7 * E
 
 
+def test_pose_optimization_fisheye_stereo_frame(ob):
+    """Optimizer::PoseOptimization on a frame with Nleft != -1 (src/Optimizer.cc:933-1008): keypoints [0, Nleft) through the left
+    KannalaBrandt8, the others as EdgeSE3ProjectXYZOnlyPoseToBody through Trl and mpCamera2."""
+    f = synth.make_pose_frame(53, rig=True, n_points=900, outlier_frac=0.15)
+    right = f.edge_kind == capi.OSH_EDGE_BODY
+    order = np.concatenate([np.nonzero(~right)[0], np.nonzero(right)[0]])          # left keypoints first
+    n_left = int((~right).sum())
+    xy = np.float32(f.edge_obs[order, :2])
+    octave = np.round(np.log(1.0 / f.edge_info[order]) / np.log(1.44)).astype(np.int32)
+    E = f.n_edges
+    frame = host.HostFrame(xy, octave, np.zeros((E, 32), dtype=np.uint8), pose_qt=f.pose_qt, kb8=f.kb8)
+    try:
+        frame.set_rig(n_left, -np.ones(n_left, dtype=np.int32), -np.ones(E - n_left, dtype=np.int32), trl=np.float32(f.trl))
+        frame.set_camera2(f.cam2)
+        n_in, pose, outlier = frame.pose_optimization(np.arange(E, dtype=np.int32), f.points[order])
+    finally:
+        frame.close()
+    ref = ob.pose_optimize(f)
+    th = float(np.float32(5.991))
+    near = np.abs(ref.edge_chi2 - th) < 2e-3 * th                     # float32 theta / psi staircase of the fisheye projection
+    np.testing.assert_array_equal(outlier[np.argsort(order)][~near], ref.outlier[~near])
+    assert abs(n_in - (E - ref.n_bad)) <= int(near.sum())
+    got = pose.astype(np.float64)[None]
+    assert rel_translation_error(got, ref.pose_qt[None]) < 2e-6 and rotation_error(got, ref.pose_qt[None]) < 2e-6
+
+
 @pytest.mark.parametrize("fisheye", [False, True])
 def test_local_inertial_ba_through_the_reference_signature(ob, fisheye):
     """Optimizer::LocalInertialBA(KeyFrame*, bool*, Map*, int&x4, bLarge, bRecInit) on a KeyFrame/MapPoint/IMU graph vs the

@@ -32,7 +32,7 @@ def _check(got, ref, f):
     assert rel_translation_error(got.pose_qt[None], ref.pose_qt[None]) < 1e-6
     assert rotation_error(got.pose_qt[None], ref.pose_qt[None]) < 1e-6
     np.testing.assert_allclose(got.edge_chi2, ref.edge_chi2, rtol=1e-5, atol=1e-6)
-    th = np.where(f.edge_kind == 0, np.float32(5.991), np.float32(7.815)).astype(np.float64)
+    th = np.where(f.edge_kind != 1, np.float32(5.991), np.float32(7.815)).astype(np.float64)
     near = np.abs(ref.edge_chi2 - th) < 1e-5 * th
     np.testing.assert_array_equal(got.outlier[~near], ref.outlier[~near])
     assert abs(got.n_bad - ref.n_bad) <= int(near.sum())
@@ -42,6 +42,7 @@ def _check(got, ref, f):
     dict(seed=21), dict(seed=24, stereo=False, mixed_mono_frac=0.0), dict(seed=25, mixed_mono_frac=0.5, outlier_frac=0.3),
     dict(seed=26, n_points=60, outlier_frac=0.0), dict(seed=27, n_points=3000),
     dict(seed=28, stereo=False, fisheye=True), dict(seed=29, stereo=False, fisheye=True, n_points=150, outlier_frac=0.3),
+    dict(seed=33, rig=True, n_points=900), dict(seed=34, rig=True, n_points=200, outlier_frac=0.3),
 ])
 def test_pose_optimisation_matches_oracle(solver, ob, kw):
     f = synth.make_pose_frame(**kw)

@@ -51,3 +51,23 @@ def test_fewer_than_ten_edges_stop_after_the_first_round():
     f.points, f.edge_kind, f.edge_obs, f.edge_info = f.points[keep], f.edge_kind[keep], f.edge_obs[keep], f.edge_info[keep]
     r = ob.pose_optimize(f.normalise())
     assert r.rounds == 1 and r.iterations[1:].sum() == 0
+
+
+def test_fisheye_stereo_frame_right_camera_edges():
+    """Nleft != -1 (src/Optimizer.cc:933-1008): left keypoints are EdgeSE3ProjectXYZOnlyPose through the left KannalaBrandt8, right
+    keypoints EdgeSE3ProjectXYZOnlyPoseToBody through Trl and the right camera; both are classified against chi2Mono."""
+    f = synth.make_pose_frame(35, rig=True, n_points=900, outlier_frac=0.1)
+    assert (f.edge_kind == 2).sum() > 200 and (f.edge_kind == 0).sum() > 200
+    r = ob.pose_optimize(f)
+    dt, dr = _pose_err(r.pose_qt, f.gt_pose_qt)
+    dt0, dr0 = _pose_err(f.pose_qt, f.gt_pose_qt)
+    assert r.rounds == 4 and dt < 0.1 * dt0 and dr < 0.2 * dr0
+    flagged = r.outlier.astype(bool)
+    assert flagged[f.outlier_mask].mean() > 0.9 and flagged[~f.outlier_mask].mean() < 0.12
+    # the right-camera edges alone constrain the pose as well
+    keep = f.edge_kind == 2
+    g = synth.make_pose_frame(35, rig=True, n_points=900, outlier_frac=0.1)
+    g.points, g.edge_kind, g.edge_obs, g.edge_info = g.points[keep], g.edge_kind[keep], g.edge_obs[keep], g.edge_info[keep]
+    r2 = ob.pose_optimize(g.normalise())
+    dt2, _ = _pose_err(r2.pose_qt, f.gt_pose_qt)
+    assert dt2 < 0.2 * dt0
