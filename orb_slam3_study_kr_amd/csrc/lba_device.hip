@@ -170,7 +170,7 @@ __device__ __forceinline__ void wave_sync() {
 // chi_l / chi_r are only meaningful for KB8 windows (per-edge chi2 of a merged rig edge).
 template <bool KB8>
 __device__ __forceinline__ void win_edge_core(const WinDesc& wd, const BatchView& bv, size_t ge, const double* rec, const double* qt,
-                                              const double* cam, const double* X, double* Xc, double* Q, double* g, double& rho0) {
+                                              const double* cam, const double* R, const double* X, double* Xc, double* Q, double* g, double& rho0) {
   if (KB8 && wd.kb8_on) {
     double cl, cr;
     double rec2[4] = {0.0, 0.0, 0.0, 0.0};
@@ -182,13 +182,13 @@ __device__ __forceinline__ void win_edge_core(const WinDesc& wd, const BatchView
     dev::edge_core_kb8(kind, qt, cam, wd.kb8, wd.cam2, wd.trl, X, rec, rec2, wd.huber_mono, Xc, Q, g, rho0, cl, cr);
     return;
   }
-  dev::edge_core_pinhole(qt, cam, X, rec, wd.huber_mono, wd.huber_stereo, Xc, Q, g, rho0);
+  dev::edge_core_pinhole(R, qt + 4, cam, X, rec, wd.huber_mono, wd.huber_stereo, Xc, Q, g, rho0);
 }
 
 // Robustified chi2 of sorted edge `ge` (the trial residual needs nothing else); chi_l / chi_r as above.
 template <bool KB8>
 __device__ __forceinline__ double win_edge_rho(const WinDesc& wd, const BatchView& bv, size_t ge, const double* rec, const double* qt,
-                                               const double* cam, const double* X, double& chi_l, double& chi_r) {
+                                               const double* cam, const double* R, const double* X, double& chi_l, double& chi_r) {
   if (KB8 && wd.kb8_on) {
     double Xc[3], Q[6], g[3], rho0;
     double rec2[4] = {0.0, 0.0, 0.0, 0.0};
@@ -201,10 +201,10 @@ __device__ __forceinline__ double win_edge_rho(const WinDesc& wd, const BatchVie
     return rho0;
   }
   const bool stereo = rec[3] > 0.0;
-  double r[3], Xc[3], rho0, rho1;
-  chi_l = dev::edge_residual(stereo ? OSH_EDGE_STEREO : OSH_EDGE_MONO, qt, cam, X, rec, fabs(rec[3]), r, Xc);
+  double r[3], Xc[3], rho0, rho1, iz;
+  chi_l = dev::edge_residual_pinhole(R, qt + 4, cam, X, rec, r, Xc, iz);   // the same expressions as win_edge_core: chi2 of a state is one number
   chi_r = 0.0;
-  dev::huber(chi_l, stereo ? wd.huber_stereo : wd.huber_mono, rho0, rho1);
+  dev::huber_fast(chi_l, stereo ? wd.huber_stereo : wd.huber_mono, rho0, rho1);
   return rho0;
 }
 
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(kBlock) void k_residual(BatchView bv) {
         for (int k = 0; k < 3; ++k) X[k] = sh_X[(le.il[p] - ch.lm0) * 3 + k];
         const double rec[4] = {le.ra[p].x, le.ra[p].y, le.rb[p].x, le.rb[p].y};
         double cl, cr;
-        chi_acc += win_edge_rho<KB8>(wd, bv, (size_t)wd.edge_off + e, rec, qt, cam, X, cl, cr);
+        chi_acc += win_edge_rho<KB8>(wd, bv, (size_t)wd.edge_off + e, rec, qt, cam, R, X, cl, cr);
       }
     }
   }
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(kBlock) void k_lin_lm(BatchView bv) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) X[k] = sh_X[(le.il[p] - ch.lm0) * 3 + k];
         const double rec[4] = {le.ra[p].x, le.ra[p].y, le.rb[p].x, le.rb[p].y};
-        win_edge_core<KB8>(wd, bv, (size_t)wd.edge_off + e, rec, qt, cam, X, Xc, Q, g, rho0);
+        win_edge_core<KB8>(wd, bv, (size_t)wd.edge_off + e, rec, qt, cam, R, X, Xc, Q, g, rho0);
         chi_acc += rho0;
         dev::core_landmark_side<KB8>(Q, g, R, hl);
       }
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(64, KB8 ? 1 : 2) void k_schur_fused(BatchView bv, i
     for (int k = 0; k < 9; ++k) Rm[k] = ps[12 + k];
     const double rec[4] = {er[0].x, er[0].y, er[1].x, er[1].y};
     double Xc[3], Q[6], g[3], rho0;
-    win_edge_core<KB8>(wd, bv, edge_of(ra, o), rec, qt, cam, d.X, Xc, Q, g, rho0);
+    win_edge_core<KB8>(wd, bv, edge_of(ra, o), rec, qt, cam, Rm, d.X, Xc, Q, g, rho0);
     // an empty slot computes on another edge's data: its result is discarded here (select, not multiply: it may be NaN)
 #pragma unroll
     for (int k = 0; k < 6; ++k) Q[k] = present ? Q[k] : 0.0;
@@ -922,7 +922,7 @@ __global__ __launch_bounds__(kBlock) void k_backsub(BatchView bv) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) X[k] = sh_X[(le.il[p] - ch.lm0) * 3 + k];
         const double rec[4] = {le.ra[p].x, le.ra[p].y, le.rb[p].x, le.rb[p].y};
-        win_edge_core<KB8>(wd, bv, (size_t)wd.edge_off + e, rec, qt, cam, X, Xc, Q, g, rho0);
+        win_edge_core<KB8>(wd, bv, (size_t)wd.edge_off + e, rec, qt, cam, R, X, Xc, Q, g, rho0);
         dev::core_backsub<KB8>(Xc, Q, R, x6, c);
       }
       sh_c[tid] = c[0]; sh_c[kChunkEdges + tid] = c[1]; sh_c[2 * kChunkEdges + tid] = c[2];
@@ -1100,7 +1100,9 @@ __global__ __launch_bounds__(kBlock) void k_finalize(BatchView bv) {
       for (int k = 0; k < 7; ++k) qt[k] = bv.pose_state[s][((size_t)wd.pose_off + ip) * 7 + k];
 #pragma unroll
       for (int k = 0; k < 3; ++k) X[k] = bv.pt_state[s][((size_t)wd.pt_off + il) * 3 + k];
-      (void)win_edge_rho<KB8>(wd, bv, ge, rec, qt, cam, X, chi_l, chi_r);
+      double Re[9];
+      dev::quat_to_R(qt, Re);
+      (void)win_edge_rho<KB8>(wd, bv, ge, rec, qt, cam, Re, X, chi_l, chi_r);
     }
     const int f = st.sel;
 #pragma unroll
@@ -1159,7 +1161,7 @@ __global__ __launch_bounds__(kBlock) void k_debug_hpl(BatchView bv, double* out)
       for (int k = 0; k < 3; ++k) X[k] = pts[(size_t)il * 3 + k];
 #pragma unroll
       for (int k = 0; k < 4; ++k) rec[k] = bv.e_rec[ge * 4 + k];
-      win_edge_core<KB8>(wd, bv, ge, rec, qt, cam, X, Xc, Q, g, rho0);
+      win_edge_core<KB8>(wd, bv, ge, rec, qt, cam, R, X, Xc, Q, g, rho0);
       const double ident[6] = {1.0, 0.0, 0.0, 1.0, 0.0, 1.0};
       dev::core_WF<KB8>(Xc, Q, R, ident, W);
     }

@@ -143,6 +143,34 @@ __device__ __forceinline__ void huber(double e, double delta, double& rho0, doub
   else { const double s = sqrt(e); rho0 = 2 * s * delta - dsqr; rho1 = delta / s; }
 }
 
+// 1 / z and sqrt(e), 1 / sqrt(e) from the hardware seeds (v_rcp_f64 / v_rsq_f64, ~26 bits) and two Newton steps: within an ulp or
+// two of the IEEE results at about half the instructions of the compiler's divide / square-root expansions.  Used by the
+// per-edge cores of the batch kernels, which are FP64-issue bound; never where the reference's rounding is restated on purpose.
+__device__ __forceinline__ double rcp_nr(double z) {
+  double x = __builtin_amdgcn_rcp(z);
+  x = fma(x, fma(-z, x, 1.0), x);
+  x = fma(x, fma(-z, x, 1.0), x);
+  return x;
+}
+__device__ __forceinline__ void sqrt_rsqrt_nr(double e, double& s, double& inv_s) {
+  const double y = __builtin_amdgcn_rsq(e);
+  double g = e * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  s = g; inv_s = h + h;
+}
+// RobustKernelHuber::robustify (robust_kernel_impl.cpp:78-91) with sqrt / divide replaced as above
+__device__ __forceinline__ void huber_fast(double e, double delta, double& rho0, double& rho1) {
+  const double dsqr = delta * delta;
+  double s, inv_s;
+  sqrt_rsqrt_nr(fmax(e, dsqr), s, inv_s);        // branch-free: the inlier lanes compute on dsqr and discard
+  const bool in = e <= dsqr;
+  rho0 = in ? e : 2 * s * delta - dsqr;
+  rho1 = in ? 1.0 : delta * inv_s;
+}
+
 // Residual of one visual edge; returns chi2 = r^T (info I) r.  kind: 0 mono, 1 stereo.
 __device__ __forceinline__ double edge_residual(int kind, const double* qt, const double* cam, const double* X,
                                                 const double* obs, double info, double* r, double* Xc) {
@@ -353,19 +381,47 @@ __device__ __forceinline__ void edge_jacobian_pose_body(const double* cam2, cons
 // Q is stored as 00 01 02 11 12 22.  For a pinhole camera Q01 == 0 (fx and fy rows do not mix).
 // ---------------------------------------------------------------------------------------------------------------------
 
+// Residual of a pinhole mono / rectified-stereo edge from the pose's rotation MATRIX (Xc = R X + t: 9 FMAs instead of the
+// quaternion form) and ONE reciprocal of z (rcp_nr) shared by the projection and the Jacobian entries.  The stereo residual
+// keeps the reference's float32 1/z and float bf product (types_six_dof_expmap.cpp:190-191).  rec = u v u_r +-invSigma2.
+__device__ __forceinline__ double edge_residual_pinhole(const double* R, const double* t, const double* cam, const double* X,
+                                                        const double* rec, double* r, double* Xc, double& iz) {
+  Xc[0] = fma(R[0], X[0], fma(R[1], X[1], fma(R[2], X[2], t[0])));
+  Xc[1] = fma(R[3], X[0], fma(R[4], X[1], fma(R[5], X[2], t[1])));
+  Xc[2] = fma(R[6], X[0], fma(R[7], X[1], fma(R[8], X[2], t[2])));
+  iz = rcp_nr(Xc[2]);
+  const double info = fabs(rec[3]);
+  if (!(rec[3] > 0.0)) {   // monocular
+    r[0] = rec[0] - (cam[0] * Xc[0] * iz + cam[2]);
+    r[1] = rec[1] - (cam[1] * Xc[1] * iz + cam[3]);
+    r[2] = 0.0;
+    return r[0] * (info * r[0]) + r[1] * (info * r[1]);
+  }
+  const float invz = (float)iz;              // `const float invz = 1.0f/trans_xyz[2];`
+  const float bf = (float)cam[4];            // `const float &bf`
+  const double u = Xc[0] * (double)invz * cam[0] + cam[2];
+  const double v = Xc[1] * (double)invz * cam[1] + cam[3];
+  const float bfz = __fmul_rn(bf, invz);     // float product, never fused
+  r[0] = rec[0] - u;
+  r[1] = rec[1] - v;
+  r[2] = rec[2] - (u - (double)bfz);
+  return r[0] * (info * r[0]) + r[1] * (info * r[1]) + r[2] * (info * r[2]);
+}
+
 // Pinhole mono / rectified-stereo edge.  rec = u v u_r +-invSigma2 (sign bit set: monocular).  Returns rho(chi2) in rho0.
-__device__ __forceinline__ void edge_core_pinhole(const double* qt, const double* cam, const double* X, const double* rec,
+// R, t: rotation matrix and translation of the pose.
+__device__ __forceinline__ void edge_core_pinhole(const double* R, const double* t, const double* cam, const double* X, const double* rec,
                                                   double huber_mono, double huber_stereo, double* Xc, double* Q, double* g,
                                                   double& rho0) {
   const bool stereo = rec[3] > 0.0;
   const double info = fabs(rec[3]);
-  double r[3];
-  const double chi2 = edge_residual(stereo ? OSH_EDGE_STEREO : OSH_EDGE_MONO, qt, cam, X, rec, info, r, Xc);
+  double r[3], iz;
+  const double chi2 = edge_residual_pinhole(R, t, cam, X, rec, r, Xc, iz);
   double rho1;
-  huber(chi2, stereo ? huber_stereo : huber_mono, rho0, rho1);
+  huber_fast(chi2, stereo ? huber_stereo : huber_mono, rho0, rho1);
   const double ww = rho1 * info;                       // robustInformation (first order only, base_edge.h:96-102)
   const double wr0 = -(info * r[0]) * rho1, wr1 = -(info * r[1]) * rho1, wr2 = -(info * r[2]) * rho1;   // r[2] == 0 for mono
-  const double iz = 1.0 / Xc[2], iz2 = iz * iz;
+  const double iz2 = iz * iz;
   const double pa = cam[0] * iz, pb = cam[1] * iz, pc = cam[0] * Xc[0] * iz2, pd = cam[1] * Xc[1] * iz2;
   const double pce = stereo ? pc - cam[4] * iz2 : 0.0;   // third row of Pm: (-pa, 0, pc - bf/z^2); absent for mono
   // rows of Pm: (-pa, 0, pc)  (0, -pb, pd)  [(-pa, 0, pce)]
