@@ -16,7 +16,7 @@ namespace osh {
 __host__ __device__ constexpr int ldlt_row_stride(int n) { return (n + 24 + 1) & ~1; }
 
 __host__ __device__ constexpr size_t ldlt_lds_doubles(int nb, int W, int nthreads) {
-  return (size_t)2 * nb * W + W + 2 * nb + (size_t)nb * nb + nthreads / 64 + 8;
+  return (size_t)2 * nb * W + W + 3 * nb + (size_t)nb * nb + nthreads / 64 + 8;
 }
 
 // value of `v` in lane `lane` (compile-time constant after unrolling) as a wave-uniform scalar
@@ -36,7 +36,8 @@ __device__ bool ldlt_solve_block(double* __restrict__ A, const double* __restric
   double* Lp = sh + (size_t)nb * W;  // [nb][W]  scaled panel rows    (l_jk)
   double* xs = Lp + (size_t)nb * W;  // [W]
   double* dd = xs + W;               // [nb]
-  double* part = dd + nb;            // [nb]
+  double* ddi = dd + nb;             // [nb] reciprocals of the pivots
+  double* part = ddi + nb;           // [nb]
   double* Ld = part + nb;            // [nb][nb] diagonal block: padded input, then its scaled factor rows
   double* shw = Ld + nb * nb;        // [NT/64] cross-wave scratch for the caller
   int& sh_ok = *reinterpret_cast<int*>(shw + kSolveThreads / 64);
@@ -81,14 +82,17 @@ __device__ bool ldlt_solve_block(double* __restrict__ A, const double* __restric
       for (int k = 0; k < NB; ++k) {
         const double d = ldlt_readlane(col[k], k);
         zero_pivot |= d == 0.0;
-        const double lk = col[k] / d;
+        // one reciprocal per pivot (hardware seed + two Newton steps, lba_math.h) instead of a divide per entry: the divide
+        // expansion sat on the critical path of every step here and cost 24 divides per column in the row panel below
+        const double rd = dev::rcp_nr(d);
+        const double lk = col[k] * rd;
 #pragma unroll
         for (int ii = k + 1; ii < NB; ++ii) {
           col[ii] -= ldlt_readlane(lk, ii) * col[k];
           asm volatile("" : "+v"(col[ii]));  // keeps the update here: sunk to its use, all 276 multipliers stay live in SGPRs
         }
         lout[k * NB] = tid > k ? lk : 0.0;  // scaled row k of the block (l_kj)
-        if (tid == 0) dd[k] = d;
+        if (tid == 0) { dd[k] = d; ddi[k] = rd; }
         __builtin_amdgcn_sched_barrier(0);
       }
       if (zero_pivot && tid == 0) sh_ok = 0;
@@ -107,7 +111,7 @@ __device__ bool ldlt_solve_block(double* __restrict__ A, const double* __restric
     typedef double ldlt_f64x2 __attribute__((ext_vector_type(2)));
     const ldlt_f64x2* const Ld2 = reinterpret_cast<const ldlt_f64x2*>(Ld);        // [NB][NB / 2]
     const ldlt_f64x2* const ys2 = reinterpret_cast<const ldlt_f64x2*>(xs + k0);   // rhs entries of this panel
-    const ldlt_f64x2* const dd2 = reinterpret_cast<const ldlt_f64x2*>(dd);
+    const ldlt_f64x2* const dd2 = reinterpret_cast<const ldlt_f64x2*>(ddi);   // reciprocals of the pivots
     char* const Apanel = reinterpret_cast<char*>(A + (size_t)k0 * n + k0);
     const unsigned n8p = (unsigned)n * 8u;
     for (int jj = kb + tid; jj <= m; jj += kSolveThreads) {
@@ -152,7 +156,7 @@ __device__ bool ldlt_solve_block(double* __restrict__ A, const double* __restric
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int r = 2 * r2 + h;
-          const double q = wv[r] / d2[h];
+          const double q = wv[r] * d2[h];
           const double l = is_rhs ? 0.0 : q;
           U[r * W + jj] = wv[r]; Lp[r * W + jj] = l;
           unsigned o = (r < kb && !is_rhs) ? (unsigned)r * n8p + j8 : n8p;  // n8p: entry (1, 0) of the block
