@@ -41,6 +41,7 @@ class Frame {
   std::vector<MapPoint*> mvpMapPoints;
   std::vector<bool> mvbOutlier;
   cv::Mat mDescriptors;
+  DBoW2::FeatureVector mFeatVec;   // include/Frame.h:262 (filled by ComputeBoW)
   std::vector<float> mvScaleFactors;
   int mnScaleLevels = 0;
   float mfLogScaleFactor = 0;   // log(mfScaleFactor), src/Frame.cc:75

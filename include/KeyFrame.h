@@ -46,7 +46,8 @@ class KeyFrame {
   long unsigned int mnBAGlobalForKF = 0;
   float fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0;
   int N = 0, NLeft = -1;
-  std::vector<cv::KeyPoint> mvKeysUn, mvKeysRight;
+  std::vector<cv::KeyPoint> mvKeys, mvKeysUn, mvKeysRight;
+  DBoW2::FeatureVector mFeatVec;   // include/KeyFrame.h:403 (filled by ComputeBoW)
   std::vector<float> mvuRight;
   std::vector<float> mvInvLevelSigma2;
   std::vector<float> mvScaleFactors;

@@ -14,8 +14,8 @@ class ORBmatcher {
   ORBmatcher(float nnratio = 0.6, bool checkOri = true);
   // src/ORBmatcher.cc:2058-2074 (kept on the host for single pairs; batches go through osh_orb_*)
   static int DescriptorDistance(const cv::Mat& a, const cv::Mat& b);
-  // src/ORBmatcher.cc:43-213 (TrackLocalMap): device nearest/second-nearest search + host replay of the
-  // sequential "slot already taken" rule.  Nleft == -1 layouts only (fisheye stereo pass = next).
+  // src/ORBmatcher.cc:43-213 (TrackLocalMap): device nearest/second-nearest search with the sequential "slot already taken"
+  // rule resolved on the device; fisheye stereo frames: two searches + host replay of the stereo-partner claims.
   int SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th = 3, const bool bFarPoints = false,
                          const float thFarPoints = 50.0f);
   // src/ORBmatcher.cc:1676-1887 (TrackWithMotionModel)
@@ -30,6 +30,9 @@ class ORBmatcher {
   int SearchByProjection(KeyFrame* pKF, Sophus::Sim3<float>& Scw, const std::vector<MapPoint*>& vpPoints,
                          const std::vector<KeyFrame*>& vpPointsKFs, std::vector<MapPoint*>& vpMatched,
                          std::vector<KeyFrame*>& vpMatchedKF, int th, float ratioHamming = 1.0);
+  // src/ORBmatcher.cc:223-420 (TrackReferenceKeyFrame, Relocalization): the features of the keyframe that hold a map point against
+  // the frame's features of the same vocabulary node; ratio test, rotation histogram; monocular / stereo and fisheye stereo frames
+  int SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches);
   static const int TH_LOW;
   static const int TH_HIGH;
   static const int HISTO_LENGTH;

@@ -144,6 +144,14 @@ class Sim3 {
 using Sim3f = Sim3<float>;
 }  // namespace Sophus
 
+// DBoW2::FeatureVector / BowVector (Thirdparty/DBoW2/DBoW2/FeatureVector.h:23, BowVector.h:48): vocabulary node -> indices of the
+// local features that fell into it; ORBmatcher::SearchByBoW walks two of them in step
+#include <map>
+namespace DBoW2 {
+typedef std::map<unsigned int, std::vector<unsigned int>> FeatureVector;
+typedef std::map<unsigned int, double> BowVector;
+}  // namespace DBoW2
+
 namespace cv {
 struct Point2f { float x = 0, y = 0; };
 struct KeyPoint { Point2f pt; float size = 0, angle = -1, response = 0; int octave = 0, class_id = -1; };

@@ -386,3 +386,24 @@ def constraint_pose_imu_H(H15):
     H = np.array(H15, dtype=np.float64).reshape(15, 15).copy()
     lib.oracle_constraint_pose_imu_H(_d(H))
     return H
+
+
+def orb_search_by_bow(kf_desc, f_desc, kf_has_mp, kf_fv, f_fv, kf_angle, f_angle, n_left_f=-1, nn_ratio=0.7, th_low=50, check_ori=True):
+    """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) restated sequentially (orb_oracle.c); feature vectors as (node_id, node_off, node_feat)."""
+    lib = load()
+    i32 = C.POINTER(C.c_int32)
+    lib.oracle_orb_search_by_bow.restype = C.c_int
+    lib.oracle_orb_search_by_bow.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8),
+                                             C.c_int, i32, i32, i32, C.c_int, i32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                             C.c_float, C.c_int, C.c_int, i32]
+    kf_desc, f_desc = np.ascontiguousarray(kf_desc, dtype=np.uint8), np.ascontiguousarray(f_desc, dtype=np.uint8)
+    has = np.ascontiguousarray(kf_has_mp, dtype=np.uint8)
+    kfv = [np.ascontiguousarray(a, dtype=np.int32) for a in kf_fv]
+    ffv = [np.ascontiguousarray(a, dtype=np.int32) for a in f_fv]
+    ka, fa = np.ascontiguousarray(kf_angle, dtype=np.float32), np.ascontiguousarray(f_angle, dtype=np.float32)
+    assign = -np.ones(f_desc.shape[0], dtype=np.int32)
+    n = lib.oracle_orb_search_by_bow(kf_desc.shape[0], f_desc.shape[0], int(n_left_f), _u8(kf_desc), _u8(f_desc), _u8(has),
+                                     len(kfv[0]), _i32(kfv[0]), _i32(kfv[1]), _i32(kfv[2]), len(ffv[0]), _i32(ffv[0]), _i32(ffv[1]), _i32(ffv[2]),
+                                     ka.ctypes.data_as(C.POINTER(C.c_float)), fa.ctypes.data_as(C.POINTER(C.c_float)),
+                                     C.c_float(nn_ratio), int(th_low), int(check_ori), _i32(assign))
+    return int(n), assign

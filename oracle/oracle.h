@@ -61,6 +61,11 @@ int  oracle_orb_match_local_points(int n_query, int n_train, const uint8_t* quer
                                    const uint8_t* train_desc, const int32_t* train_level,
                                    const int32_t* cand_off, const int32_t* cand_idx,
                                    float nn_ratio, int th_high, uint8_t* occupied, int32_t* assignment);
+int  oracle_orb_search_by_bow(int n_kf, int n_f, int n_left_f, const uint8_t* kf_desc, const uint8_t* f_desc, const uint8_t* kf_has_mp,
+                              int kf_nodes, const int32_t* kf_node_id, const int32_t* kf_node_off, const int32_t* kf_node_feat,
+                              int f_nodes, const int32_t* f_node_id, const int32_t* f_node_off, const int32_t* f_node_feat,
+                              const float* kf_angle, const float* f_angle, float nn_ratio, int th_low, int check_orientation,
+                              int32_t* assignment);
 int  oracle_orb_match_local_points_rig(int n_query, int n_left, int n_right, const uint8_t* query_desc, const uint8_t* desc,
                                        const int32_t* level_left, const int32_t* level_right,
                                        const uint8_t* in_l, const int32_t* candl_off, const int32_t* candl_idx,

@@ -284,3 +284,89 @@ int oracle_orb_match_last_frame_rig(int n_query, int n_left, int n_right, const 
   for (int i = 0; i < HISTO_LENGTH; ++i) free(hist[i]);
   return nmatches;
 }
+
+/* ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches), src/ORBmatcher.cc:223-420
+ * (Tracking::TrackReferenceKeyFrame, Relocalization).  The two DBoW2 feature vectors are walked in step (:242-395); inside a
+ * common vocabulary node every keyframe feature that holds a good map point is compared with the frame features of the node
+ * that are still unmatched (:266-268), best and second best by strict '<' in list order; accept bestDist1 <= TH_LOW and
+ * (float)bestDist1 < mfNNratio * (float)bestDist2 (:319-321); rotation histogram with factor 1.0f/HISTO_LENGTH, three dominant
+ * bins kept (:397-417).  Fisheye stereo frame (n_left_f >= 0): left candidates (index < Nleft) and right candidates compete
+ * separately; the right best is accepted without a ratio test ("|| true", :352) but only inside the branch of an accepted-range
+ * left best (bestDist1 <= TH_LOW, :319).
+ * Feature vectors as CSR: node ids ascending, node_off[n_nodes + 1], node_feat.  kf_has_mp[i]: keyframe feature i holds a map
+ * point that is not bad.  assignment[n_f] (out): keyframe feature whose map point ends in vpMapPointMatches[slot], or -1. */
+int oracle_orb_search_by_bow(int n_kf, int n_f, int n_left_f, const uint8_t* kf_desc, const uint8_t* f_desc, const uint8_t* kf_has_mp,
+                             int kf_nodes, const int32_t* kf_node_id, const int32_t* kf_node_off, const int32_t* kf_node_feat,
+                             int f_nodes, const int32_t* f_node_id, const int32_t* f_node_off, const int32_t* f_node_feat,
+                             const float* kf_angle, const float* f_angle, float nn_ratio, int th_low, int check_orientation,
+                             int32_t* assignment) {
+  enum { HISTO_LENGTH = 30 };
+  (void)n_kf;
+  int nmatches = 0;
+  int* hist[HISTO_LENGTH];
+  int hsize[HISTO_LENGTH];
+  for (int i = 0; i < HISTO_LENGTH; ++i) { hist[i] = (int*)malloc(sizeof(int) * (size_t)(2 * n_f + 2)); hsize[i] = 0; }
+  for (int i = 0; i < n_f; ++i) assignment[i] = -1;
+  const float factor = 1.0f / HISTO_LENGTH;
+  int a = 0, b = 0;
+  while (a < kf_nodes && b < f_nodes) {
+    if (kf_node_id[a] == f_node_id[b]) {
+      for (int x = kf_node_off[a]; x < kf_node_off[a + 1]; ++x) {
+        const int iKF = kf_node_feat[x];
+        if (!kf_has_mp[iKF]) continue;
+        int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256, bestDist1R = 256, bestIdxFR = -1, bestDist2R = 256;
+        for (int y = f_node_off[b]; y < f_node_off[b + 1]; ++y) {
+          const int iF = f_node_feat[y];
+          if (assignment[iF] >= 0) continue;
+          const int dist = oracle_descriptor_distance(kf_desc + 32 * (size_t)iKF, f_desc + 32 * (size_t)iF);
+          if (n_left_f < 0 || iF < n_left_f) {
+            if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = iF; }
+            else if (dist < bestDist2) bestDist2 = dist;
+          } else {
+            if (dist < bestDist1R) { bestDist2R = bestDist1R; bestDist1R = dist; bestIdxFR = iF; }
+            else if (dist < bestDist2R) bestDist2R = dist;
+          }
+        }
+        if (bestDist1 <= th_low) {
+          if ((float)bestDist1 < nn_ratio * (float)bestDist2) {
+            assignment[bestIdxF] = iKF;
+            if (check_orientation) {
+              float rot = kf_angle[iKF] - f_angle[bestIdxF];
+              if (rot < 0.0) rot += 360.0f;
+              int bin = (int)roundf(rot * factor);
+              if (bin == HISTO_LENGTH) bin = 0;
+              hist[bin][hsize[bin]++] = bestIdxF;
+            }
+            nmatches++;
+          }
+          if (bestDist1R <= th_low) {
+            assignment[bestIdxFR] = iKF;
+            if (check_orientation) {
+              float rot = kf_angle[iKF] - f_angle[bestIdxFR];
+              if (rot < 0.0) rot += 360.0f;
+              int bin = (int)roundf(rot * factor);
+              if (bin == HISTO_LENGTH) bin = 0;
+              hist[bin][hsize[bin]++] = bestIdxFR;
+            }
+            nmatches++;
+          }
+        }
+      }
+      ++a; ++b;
+    } else if (kf_node_id[a] < f_node_id[b]) {
+      while (a < kf_nodes && kf_node_id[a] < f_node_id[b]) ++a;   /* vFeatVecKF.lower_bound(Fit->first) */
+    } else {
+      while (b < f_nodes && f_node_id[b] < kf_node_id[a]) ++b;
+    }
+  }
+  if (check_orientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(hsize, HISTO_LENGTH, &ind1, &ind2, &ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int j = 0; j < hsize[i]; j++) { assignment[hist[i][j]] = -1; nmatches--; }
+    }
+  }
+  for (int i = 0; i < HISTO_LENGTH; ++i) free(hist[i]);
+  return nmatches;
+}

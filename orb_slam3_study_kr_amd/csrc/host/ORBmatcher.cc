@@ -669,4 +669,141 @@ int ORBmatcher::SearchByProjection(KeyFrame* pKF, Sophus::Sim3<float>& Scw, cons
   return search_by_sim3(pKF, Scw, vpPoints, &vpPointsKFs, vpMatched, &vpMatchedKF, th, ratioHamming, TH_LOW);
 }
 
+namespace {
+
+// one batched device search over explicit candidate lists (osh_orb_upload with cand_off / cand_idx): best / second-best distance of
+// every query among its list, positions in list order
+bool device_search_lists(const std::vector<uint8_t>& qdesc, const cv::Mat& train, int n_train, const std::vector<int32_t>& off,
+                         const std::vector<int32_t>& idx, std::vector<int32_t>& best_idx, std::vector<int32_t>& best_dist,
+                         std::vector<int32_t>& second_dist, std::vector<int32_t>& second_idx) {
+  const int nq = (int)off.size() - 1;
+  best_idx.assign(nq, -1); best_dist.assign(nq, 256); second_dist.assign(nq, 256); second_idx.assign(nq, -1);
+  if (nq <= 0) return true;
+  osh_orb_ctx* ctx = thread_ctx();
+  if (!ctx) return false;
+  const int64_t base = 0;
+  const int32_t none = 0;
+  osh_orb_batch b;
+  b.n_pairs = 1; b.n_query = nq; b.n_train = n_train;
+  b.query_desc = qdesc.data(); b.train_desc = train.ptr<uint8_t>(0); b.train_level = nullptr;
+  b.cand_off = off.data(); b.cand_idx = idx.empty() ? &none : idx.data(); b.pair_cand_base = &base;
+  std::vector<int32_t> lv1(nq), lv2(nq);
+  if (osh_orb_upload(ctx, &b) != OSH_OK || osh_orb_match(ctx) != OSH_OK ||
+      osh_orb_download(ctx, best_idx.data(), best_dist.data(), second_dist.data(), lv1.data(), lv2.data(), second_idx.data()) != OSH_OK) {
+    std::fprintf(stderr, "ORBmatcher: device search failed: %s\n", osh_last_error());
+    return false;
+  }
+  return true;
+}
+
+}  // namespace
+
+// src/ORBmatcher.cc:223-420.  The candidate loops of every keyframe feature run as batched device searches over the feature
+// lists of its vocabulary node (one search for the left / only camera, one for the right camera of a fisheye stereo frame); the
+// "frame feature already matched" rule (:266-268) makes the loop sequential, so the queries are replayed in the reference's
+// order and a query whose best or second-best candidate has been taken in the meantime is scanned again with the current matches.
+int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches) {
+  const std::vector<MapPoint*> vpMapPointsKF = pKF->GetMapPointMatches();
+  vpMapPointMatches = std::vector<MapPoint*>(F.N, static_cast<MapPoint*>(nullptr));
+  const DBoW2::FeatureVector& vFeatVecKF = pKF->mFeatVec;
+  const bool rig = F.Nleft != -1;
+  // queries in visiting order, each with the frame-feature list of its node
+  std::vector<int> qKF;
+  std::vector<const std::vector<unsigned int>*> qList;
+  DBoW2::FeatureVector::const_iterator KFit = vFeatVecKF.begin(), KFend = vFeatVecKF.end();
+  DBoW2::FeatureVector::const_iterator Fit = F.mFeatVec.begin(), Fend = F.mFeatVec.end();
+  while (KFit != KFend && Fit != Fend) {
+    if (KFit->first == Fit->first) {
+      for (const unsigned int realIdxKF : KFit->second) {
+        MapPoint* pMP = vpMapPointsKF[realIdxKF];
+        if (!pMP || pMP->isBad()) continue;
+        qKF.push_back((int)realIdxKF);
+        qList.push_back(&Fit->second);
+      }
+      KFit++; Fit++;
+    } else if (KFit->first < Fit->first) {
+      KFit = vFeatVecKF.lower_bound(Fit->first);
+    } else {
+      Fit = F.mFeatVec.lower_bound(KFit->first);
+    }
+  }
+  const int nq = (int)qKF.size();
+  if (nq == 0) return 0;
+  std::vector<uint8_t> qdesc((size_t)nq * 32);
+  std::vector<int32_t> offL(1, 0), idxL, offR(1, 0), idxR;
+  for (int q = 0; q < nq; ++q) {
+    std::memcpy(&qdesc[(size_t)q * 32], pKF->mDescriptors.ptr<uint8_t>(qKF[q]), 32);
+    for (const unsigned int iF : *qList[q]) {
+      if (!rig || (int)iF < F.Nleft) idxL.push_back((int32_t)iF); else idxR.push_back((int32_t)iF);
+    }
+    offL.push_back((int32_t)idxL.size()); offR.push_back((int32_t)idxR.size());
+  }
+  std::vector<int32_t> bL, dL, sL, siL, bR, dR, sR, siR;
+  if (!device_search_lists(qdesc, F.mDescriptors, F.N, offL, idxL, bL, dL, sL, siL)) return 0;
+  if (rig && !device_search_lists(qdesc, F.mDescriptors, F.N, offR, idxR, bR, dR, sR, siR)) return 0;
+
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  for (int i = 0; i < HISTO_LENGTH; i++) rotHist[i].reserve(500);
+  const float factor = 1.0f / HISTO_LENGTH;
+  // the reference's candidate loop over one side of the node's list with the current matches (for contested queries only)
+  auto rescan = [&](int q, bool right, int& bestDist1, int& bestIdxF, int& bestDist2) {
+    bestDist1 = 256; bestIdxF = -1; bestDist2 = 256;
+    const uint32_t* qd = reinterpret_cast<const uint32_t*>(&qdesc[(size_t)q * 32]);
+    for (const unsigned int realIdxF : *qList[q]) {
+      if (rig && (((int)realIdxF >= F.Nleft) != right)) continue;
+      if (vpMapPointMatches[realIdxF]) continue;
+      const uint32_t* td = F.mDescriptors.ptr<uint32_t>((int)realIdxF);
+      int dist = 0;
+      for (int k = 0; k < 8; ++k) dist += __builtin_popcount(qd[k] ^ td[k]);
+      if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = (int)realIdxF; }
+      else if (dist < bestDist2) bestDist2 = dist;
+    }
+  };
+  auto histo = [&](int realIdxKF, int idxF) {
+    const cv::KeyPoint& kp = (!pKF->mpCamera2) ? pKF->mvKeysUn[realIdxKF]
+                             : (realIdxKF >= pKF->NLeft) ? pKF->mvKeysRight[realIdxKF - pKF->NLeft] : pKF->mvKeys[realIdxKF];
+    const cv::KeyPoint& Fkp = (!rig) ? F.mvKeys[idxF] : (idxF >= F.Nleft) ? F.mvKeysRight[idxF - F.Nleft] : F.mvKeys[idxF];
+    float rot = kp.angle - Fkp.angle;
+    if (rot < 0.0) rot += 360.0f;
+    int bin = (int)std::round(rot * factor);
+    if (bin == HISTO_LENGTH) bin = 0;
+    rotHist[bin].push_back(idxF);
+  };
+  for (int q = 0; q < nq; ++q) {
+    MapPoint* pMP = vpMapPointsKF[qKF[q]];
+    int bestDist1 = dL[q], bestIdxF = bL[q], bestDist2 = sL[q];
+    if ((bestIdxF >= 0 && vpMapPointMatches[bestIdxF]) || (siL[q] >= 0 && vpMapPointMatches[siL[q]])) rescan(q, false, bestDist1, bestIdxF, bestDist2);
+    int bestDist1R = 256, bestIdxFR = -1, bestDist2R = 256;
+    if (rig) {
+      bestDist1R = dR[q]; bestIdxFR = bR[q]; bestDist2R = sR[q];
+      if ((bestIdxFR >= 0 && vpMapPointMatches[bestIdxFR]) || (siR[q] >= 0 && vpMapPointMatches[siR[q]])) rescan(q, true, bestDist1R, bestIdxFR, bestDist2R);
+    }
+    if (bestDist1 <= TH_LOW) {
+      if (static_cast<float>(bestDist1) < mfNNratio * static_cast<float>(bestDist2)) {
+        vpMapPointMatches[bestIdxF] = pMP;
+        if (mbCheckOrientation) histo(qKF[q], bestIdxF);
+        nmatches++;
+      }
+      if (bestDist1R <= TH_LOW) {   // the right-camera best is taken without a ratio test ("|| true", :352)
+        vpMapPointMatches[bestIdxFR] = pMP;
+        if (mbCheckOrientation) histo(qKF[q], bestIdxFR);
+        nmatches++;
+      }
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+        vpMapPointMatches[rotHist[i][j]] = static_cast<MapPoint*>(nullptr);
+        nmatches--;
+      }
+    }
+  }
+  return nmatches;
+}
+
 }  // namespace ORB_SLAM3

@@ -652,6 +652,45 @@ extern "C" int osh_host_frame_pose_optimization(osh_host_frame* f, int32_t n_mp,
   return n;
 }
 
+// ORBmatcher(nnratio, check_ori).SearchByBoW(&keyframe, frame, matches): the keyframe is built from n_kf features (descriptor, angle,
+// has_mp[i]: the feature holds a good map point); the DBoW2 feature vectors of keyframe and frame come as CSR (node ids ascending).
+// assignment[k] (k < F.N): keyframe feature whose map point landed in vpMapPointMatches[k], or -1.
+extern "C" int osh_host_search_by_bow(osh_host_frame* f, int32_t n_kf, const uint8_t* kf_desc, const float* kf_angle, const uint8_t* kf_has_mp,
+                                      int32_t kf_nodes, const int32_t* kf_node_id, const int32_t* kf_node_off, const int32_t* kf_node_feat,
+                                      int32_t f_nodes, const int32_t* f_node_id, const int32_t* f_node_off, const int32_t* f_node_feat,
+                                      float nnratio, int32_t check_ori, int32_t* assignment) {
+  if (!f) return -1;
+  Frame& F = f->F;
+  KeyFrame kf(7, &f->map);
+  kf.N = n_kf;
+  kf.mDescriptors = cv::Mat(n_kf, 32);
+  std::vector<std::unique_ptr<MapPoint>> mps;
+  kf.mvpMapPoints.assign(n_kf, nullptr);
+  for (int i = 0; i < n_kf; ++i) {
+    cv::KeyPoint kp;
+    kp.angle = kf_angle[i];
+    kf.mvKeysUn.push_back(kp); kf.mvKeys.push_back(kp);
+    std::memcpy(kf.mDescriptors.ptr<uint8_t>(i), kf_desc + 32 * (size_t)i, 32);
+    if (kf_has_mp[i]) {
+      mps.emplace_back(new MapPoint((unsigned long)i, Eigen::Vector3f(0.f, 0.f, 1.f), &f->map));
+      kf.mvpMapPoints[i] = mps.back().get();
+    }
+  }
+  for (int a = 0; a < kf_nodes; ++a)
+    kf.mFeatVec[(unsigned)kf_node_id[a]] = std::vector<unsigned int>(kf_node_feat + kf_node_off[a], kf_node_feat + kf_node_off[a + 1]);
+  F.mFeatVec.clear();
+  for (int b = 0; b < f_nodes; ++b)
+    F.mFeatVec[(unsigned)f_node_id[b]] = std::vector<unsigned int>(f_node_feat + f_node_off[b], f_node_feat + f_node_off[b + 1]);
+  std::vector<MapPoint*> matches;
+  ORBmatcher matcher(nnratio, check_ori != 0);
+  const int n = matcher.SearchByBoW(&kf, F, matches);
+  for (int k = 0; k < F.N; ++k) {
+    assignment[k] = -1;
+    if (k < (int)matches.size() && matches[k]) assignment[k] = (int32_t)matches[k]->mnId;
+  }
+  return n;
+}
+
 // ------------------------------------------------------------------------------------------ PoseInertialOptimization*
 struct osh_host_posei {
   Frame F, prevF;

@@ -311,6 +311,19 @@ class HostFrame:
         return n, assign
 
 
+    def search_by_bow(self, kf_desc, kf_angle, kf_has_mp, kf_fv, f_fv, nnratio=0.7, check_ori=True):
+        """ORBmatcher(nnratio, check_ori).SearchByBoW(pKF, F, vpMapPointMatches) (src/ORBmatcher.cc:223-420).  kf_fv / f_fv: feature
+        vectors as (node_id[n], node_off[n + 1], node_feat) with ascending node ids.  Returns (nmatches, assignment[F.N])."""
+        kf_desc = np.ascontiguousarray(kf_desc, dtype=np.uint8)
+        keep = [kf_desc, _f32(kf_angle), np.ascontiguousarray(kf_has_mp, dtype=np.uint8)] + [_i32(a) for a in kf_fv] + [_i32(a) for a in f_fv]
+        assign = np.zeros(self.n, dtype=np.int32)
+        n = self.lib.osh_host_search_by_bow(self.f, len(kf_desc), capi.ptr(keep[0], capi.c_uint8_p), capi.ptr(keep[1], capi.c_float_p),
+                                            capi.ptr(keep[2], capi.c_uint8_p), len(keep[3]), capi.ptr(keep[3], capi.c_int32_p),
+                                            capi.ptr(keep[4], capi.c_int32_p), capi.ptr(keep[5], capi.c_int32_p), len(keep[6]),
+                                            capi.ptr(keep[6], capi.c_int32_p), capi.ptr(keep[7], capi.c_int32_p), capi.ptr(keep[8], capi.c_int32_p),
+                                            float(nnratio), int(check_ori), capi.ptr(assign, capi.c_int32_p))
+        return n, assign
+
     def set_camera2(self, cam2):
         """Give the right camera of a fisheye stereo frame its own KannalaBrandt8 (fx fy cx cy k1..k4)."""
         assert self.lib.osh_host_frame_set_camera2(self.f, capi.ptr(_f32(cam2), capi.c_float_p)) == 0

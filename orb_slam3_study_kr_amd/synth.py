@@ -583,3 +583,34 @@ def make_pose_frame(seed: int = 21, n_points: int = 800, stereo: bool = True, mi
     return PoseFrame(pose_qt=_f32(init), cam=cam, points=_f32(Xw), edge_kind=kind, edge_obs=_f32(obs),
                      edge_info=INV_LEVEL_SIGMA2[octave].astype(np.float64), gt_pose_qt=gt, outlier_mask=is_out,
                      kb8=KB8_K.copy() if fisheye else None, cam2=cam2, trl=trl).normalise()
+
+
+def make_bow_pair(seed: int = 5, n_kf: int = 900, n_f: int = 1000, n_nodes: int = 120, match_frac: float = 0.6, flip: float = 0.04, n_left_f: int = -1):
+    """A keyframe and a frame described by DBoW2-style feature vectors (vocabulary node -> feature indices, ids ascending) for
+    ORBmatcher::SearchByBoW: ``match_frac`` of the frame features are noisy copies of keyframe features in the SAME node (so they
+    can match), several keyframe features share near-identical descriptors (ratio-test failures and contested frame features),
+    some nodes exist on one side only.  Returns a dict of arrays; feature vectors as (node_id, node_off, node_feat)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    kf_desc = rng.integers(0, 256, (n_kf, 32), dtype=np.uint8)
+    dup = rng.permutation(n_kf)[:n_kf // 6]                        # near-duplicates: a source of ties and contested slots
+    kf_desc[dup] = kf_desc[(dup + 1) % n_kf] ^ np.packbits(rng.uniform(0, 1, (len(dup), 256)) < 0.01, axis=1)
+    kf_node = rng.integers(0, n_nodes, n_kf)
+    kf_node[dup] = kf_node[(dup + 1) % n_kf]
+    f_desc = rng.integers(0, 256, (n_f, 32), dtype=np.uint8)
+    f_node = rng.integers(0, n_nodes + 15, n_f)                     # nodes n_nodes .. n_nodes+14 exist in the frame only
+    src = rng.permutation(n_kf)[:int(match_frac * n_f)]
+    tgt = rng.permutation(n_f)[:len(src)]
+    f_desc[tgt] = kf_desc[src] ^ np.packbits(rng.uniform(0, 1, (len(src), 256)) < flip, axis=1)
+    f_node[tgt] = kf_node[src]
+    kf_node[kf_node % 11 == 3] += 1000                              # nodes that exist in the keyframe only
+    kf_angle = rng.uniform(0, 360, n_kf).astype(np.float32)
+    f_angle = rng.uniform(0, 360, n_f).astype(np.float32)
+    f_angle[tgt] = (kf_angle[src] - 20.0 + rng.normal(0, 3.0, len(src))).astype(np.float32) % np.float32(360.0)   # a dominant rotation
+
+    def fv(node):
+        ids = np.unique(node)
+        feats = [np.nonzero(node == i)[0] for i in ids]
+        off = np.concatenate([[0], np.cumsum([len(f) for f in feats])])
+        return ids.astype(np.int32), off.astype(np.int32), np.concatenate(feats).astype(np.int32)
+    return dict(kf_desc=kf_desc, f_desc=f_desc, kf_has_mp=(rng.uniform(size=n_kf) < 0.8).astype(np.uint8), kf_fv=fv(kf_node), f_fv=fv(f_node),
+                kf_angle=kf_angle, f_angle=f_angle, n_left_f=n_left_f, src=src, tgt=tgt)

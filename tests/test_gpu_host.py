@@ -598,6 +598,27 @@ def test_pose_optimization_through_the_reference_signature(ob, fisheye):
     assert n_in > 0.7 * E
 
 
+@pytest.mark.parametrize("rig", [False, True])
+@pytest.mark.parametrize("check_ori", [True, False])
+def test_search_by_bow_equals_sequential_reference(ob, rig, check_ori):
+    """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) (src/ORBmatcher.cc:223-420): device searches over the node lists
+    + host replay of the "frame feature already matched" rule, slot by slot against the sequential oracle."""
+    d = synth.make_bow_pair(7 + int(rig), n_left_f=600 if rig else -1)
+    n_f = len(d["f_desc"])
+    xy = np.zeros((n_f, 2), dtype=np.float32)
+    f = host.HostFrame(xy, np.zeros(n_f, dtype=np.int32), d["f_desc"], angle=d["f_angle"])
+    try:
+        if rig:
+            f.set_rig(600, -np.ones(600, dtype=np.int32), -np.ones(n_f - 600, dtype=np.int32))
+        n, assign = f.search_by_bow(d["kf_desc"], d["kf_angle"], d["kf_has_mp"], d["kf_fv"], d["f_fv"], nnratio=0.7, check_ori=check_ori)
+    finally:
+        f.close()
+    n_ref, assign_ref = ob.orb_search_by_bow(d["kf_desc"], d["f_desc"], d["kf_has_mp"], d["kf_fv"], d["f_fv"], d["kf_angle"], d["f_angle"],
+                                             n_left_f=d["n_left_f"], nn_ratio=0.7, check_ori=check_ori)
+    assert n == n_ref and n > 200
+    np.testing.assert_array_equal(assign, assign_ref)
+
+
 def test_pose_optimization_fisheye_stereo_frame(ob):
     """Optimizer::PoseOptimization on a frame with Nleft != -1 (src/Optimizer.cc:933-1008): keypoints [0, Nleft) through the left
     KannalaBrandt8, the others as EdgeSE3ProjectXYZOnlyPoseToBody through Trl and mpCamera2."""
