@@ -33,6 +33,8 @@ class ORBmatcher {
   // src/ORBmatcher.cc:223-420 (TrackReferenceKeyFrame, Relocalization): the features of the keyframe that hold a map point against
   // the frame's features of the same vocabulary node; ratio test, rotation histogram; monocular / stereo and fisheye stereo frames
   int SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches);
+  // src/ORBmatcher.cc:765-905 (loop closing / map merging): map points of keyframe 1 against the map points of keyframe 2 of the same node
+  int SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12);
   static const int TH_LOW;
   static const int TH_HIGH;
   static const int HISTO_LENGTH;

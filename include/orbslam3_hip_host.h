@@ -113,6 +113,10 @@ int osh_host_search_local_points_rig(osh_host_frame* f, int32_t n_mp, const uint
                                      const float* viewcos_right, const int32_t* n_observations, float nnratio, float th,
                                      int32_t* assignment);
 int osh_host_frame_set_camera2(osh_host_frame* f, const float cam2[8]);
+int osh_host_search_by_bow_kf(int32_t n1, const uint8_t* desc1, const float* angle1, const uint8_t* has_mp1, int32_t nodes1,
+                              const int32_t* node_id1, const int32_t* node_off1, const int32_t* node_feat1, int32_t n2,
+                              const uint8_t* desc2, const float* angle2, const uint8_t* has_mp2, int32_t nodes2, const int32_t* node_id2,
+                              const int32_t* node_off2, const int32_t* node_feat2, float nnratio, int32_t check_ori, int32_t* match12);
 int osh_host_search_by_bow(osh_host_frame* f, int32_t n_kf, const uint8_t* kf_desc, const float* kf_angle, const uint8_t* kf_has_mp,
                            int32_t kf_nodes, const int32_t* kf_node_id, const int32_t* kf_node_off, const int32_t* kf_node_feat,
                            int32_t f_nodes, const int32_t* f_node_id, const int32_t* f_node_off, const int32_t* f_node_feat,

@@ -407,3 +407,24 @@ def orb_search_by_bow(kf_desc, f_desc, kf_has_mp, kf_fv, f_fv, kf_angle, f_angle
                                      ka.ctypes.data_as(C.POINTER(C.c_float)), fa.ctypes.data_as(C.POINTER(C.c_float)),
                                      C.c_float(nn_ratio), int(th_low), int(check_ori), _i32(assign))
     return int(n), assign
+
+
+def orb_search_by_bow_kf(desc1, desc2, has_mp1, has_mp2, fv1, fv2, angle1, angle2, lim1=-1, lim2=-1, nn_ratio=0.7, th_low=50, check_ori=True):
+    """ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, ...) restated sequentially (orb_oracle.c)."""
+    lib = load()
+    i32 = C.POINTER(C.c_int32)
+    u8 = C.POINTER(C.c_uint8)
+    lib.oracle_orb_search_by_bow_kf.restype = C.c_int
+    lib.oracle_orb_search_by_bow_kf.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, u8, u8, u8, u8, C.c_int, i32, i32, i32, C.c_int, i32, i32, i32,
+                                                C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_int, C.c_int, i32]
+    d1, d2 = np.ascontiguousarray(desc1, dtype=np.uint8), np.ascontiguousarray(desc2, dtype=np.uint8)
+    h1, h2 = np.ascontiguousarray(has_mp1, dtype=np.uint8), np.ascontiguousarray(has_mp2, dtype=np.uint8)
+    f1 = [np.ascontiguousarray(a, dtype=np.int32) for a in fv1]
+    f2 = [np.ascontiguousarray(a, dtype=np.int32) for a in fv2]
+    a1, a2 = np.ascontiguousarray(angle1, dtype=np.float32), np.ascontiguousarray(angle2, dtype=np.float32)
+    m = -np.ones(d1.shape[0], dtype=np.int32)
+    n = lib.oracle_orb_search_by_bow_kf(d1.shape[0], d2.shape[0], int(lim1), int(lim2), _u8(d1), _u8(d2), _u8(h1), _u8(h2), len(f1[0]), _i32(f1[0]),
+                                        _i32(f1[1]), _i32(f1[2]), len(f2[0]), _i32(f2[0]), _i32(f2[1]), _i32(f2[2]),
+                                        a1.ctypes.data_as(C.POINTER(C.c_float)), a2.ctypes.data_as(C.POINTER(C.c_float)), C.c_float(nn_ratio),
+                                        int(th_low), int(check_ori), _i32(m))
+    return int(n), m

@@ -66,6 +66,12 @@ int  oracle_orb_search_by_bow(int n_kf, int n_f, int n_left_f, const uint8_t* kf
                               int f_nodes, const int32_t* f_node_id, const int32_t* f_node_off, const int32_t* f_node_feat,
                               const float* kf_angle, const float* f_angle, float nn_ratio, int th_low, int check_orientation,
                               int32_t* assignment);
+int  oracle_orb_search_by_bow_kf(int n1, int n2, int lim1, int lim2, const uint8_t* desc1, const uint8_t* desc2,
+                                 const uint8_t* has_mp1, const uint8_t* has_mp2,
+                                 int nodes1, const int32_t* node_id1, const int32_t* node_off1, const int32_t* node_feat1,
+                                 int nodes2, const int32_t* node_id2, const int32_t* node_off2, const int32_t* node_feat2,
+                                 const float* angle1, const float* angle2, float nn_ratio, int th_low, int check_orientation,
+                                 int32_t* match12);
 int  oracle_orb_match_local_points_rig(int n_query, int n_left, int n_right, const uint8_t* query_desc, const uint8_t* desc,
                                        const int32_t* level_left, const int32_t* level_right,
                                        const uint8_t* in_l, const int32_t* candl_off, const int32_t* candl_idx,

@@ -370,3 +370,71 @@ int oracle_orb_search_by_bow(int n_kf, int n_f, int n_left_f, const uint8_t* kf_
   for (int i = 0; i < HISTO_LENGTH; ++i) free(hist[i]);
   return nmatches;
 }
+
+/* ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12), src/ORBmatcher.cc:765-905 (loop closing,
+ * map merging).  Like the keyframe / frame variant, but: a candidate of keyframe 2 must hold a good map point and must not have
+ * been matched yet (vbMatched2, :822-826); features with index >= lim (mvKeysUn.size() of a fisheye rig keyframe, :801,817) are
+ * skipped on both sides (lim < 0: no limit); accept bestDist1 < TH_LOW (strict, :841) and the float ratio test; the histogram
+ * holds keyframe-1 indices and pruning a match leaves vbMatched2 set.  match12[n1] (out): feature of keyframe 2 or -1. */
+int oracle_orb_search_by_bow_kf(int n1, int n2, int lim1, int lim2, const uint8_t* desc1, const uint8_t* desc2,
+                                const uint8_t* has_mp1, const uint8_t* has_mp2,
+                                int nodes1, const int32_t* node_id1, const int32_t* node_off1, const int32_t* node_feat1,
+                                int nodes2, const int32_t* node_id2, const int32_t* node_off2, const int32_t* node_feat2,
+                                const float* angle1, const float* angle2, float nn_ratio, int th_low, int check_orientation,
+                                int32_t* match12) {
+  enum { HISTO_LENGTH = 30 };
+  int nmatches = 0;
+  int* hist[HISTO_LENGTH];
+  int hsize[HISTO_LENGTH];
+  for (int i = 0; i < HISTO_LENGTH; ++i) { hist[i] = (int*)malloc(sizeof(int) * (size_t)(n1 + 1)); hsize[i] = 0; }
+  uint8_t* matched2 = (uint8_t*)calloc((size_t)(n2 ? n2 : 1), 1);
+  for (int i = 0; i < n1; ++i) match12[i] = -1;
+  const float factor = 1.0f / HISTO_LENGTH;
+  int a = 0, b = 0;
+  while (a < nodes1 && b < nodes2) {
+    if (node_id1[a] == node_id2[b]) {
+      for (int x = node_off1[a]; x < node_off1[a + 1]; ++x) {
+        const int idx1 = node_feat1[x];
+        if (lim1 >= 0 && idx1 >= lim1) continue;
+        if (!has_mp1[idx1]) continue;
+        int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+        for (int y = node_off2[b]; y < node_off2[b + 1]; ++y) {
+          const int idx2 = node_feat2[y];
+          if (lim2 >= 0 && idx2 >= lim2) continue;
+          if (matched2[idx2] || !has_mp2[idx2]) continue;
+          const int dist = oracle_descriptor_distance(desc1 + 32 * (size_t)idx1, desc2 + 32 * (size_t)idx2);
+          if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = idx2; }
+          else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist1 < th_low && (float)bestDist1 < nn_ratio * (float)bestDist2) {
+          match12[idx1] = bestIdx2;
+          matched2[bestIdx2] = 1;
+          if (check_orientation) {
+            float rot = angle1[idx1] - angle2[bestIdx2];
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            hist[bin][hsize[bin]++] = idx1;
+          }
+          nmatches++;
+        }
+      }
+      ++a; ++b;
+    } else if (node_id1[a] < node_id2[b]) {
+      while (a < nodes1 && node_id1[a] < node_id2[b]) ++a;
+    } else {
+      while (b < nodes2 && node_id2[b] < node_id1[a]) ++b;
+    }
+  }
+  if (check_orientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(hsize, HISTO_LENGTH, &ind1, &ind2, &ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int j = 0; j < hsize[i]; j++) { match12[hist[i][j]] = -1; nmatches--; }
+    }
+  }
+  for (int i = 0; i < HISTO_LENGTH; ++i) free(hist[i]);
+  free(matched2);
+  return nmatches;
+}

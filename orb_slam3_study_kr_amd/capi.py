@@ -288,6 +288,9 @@ _HOST_SIGNATURES = {
     "osh_host_search_last_frame": (C.c_int, [C.c_void_p, C.c_void_p, c_int32_p, C.c_int32, c_float_p, c_uint8_p, C.c_float, C.c_int32,
                                              C.c_int32, c_int32_p]),
     "osh_host_frame_set_camera2": (C.c_int, [C.c_void_p, c_float_p]),
+    "osh_host_search_by_bow_kf": (C.c_int, [C.c_int32, c_uint8_p, c_float_p, c_uint8_p, C.c_int32, c_int32_p, c_int32_p, c_int32_p,
+                                            C.c_int32, c_uint8_p, c_float_p, c_uint8_p, C.c_int32, c_int32_p, c_int32_p, c_int32_p,
+                                            C.c_float, C.c_int32, c_int32_p]),
     "osh_host_search_by_bow": (C.c_int, [C.c_void_p, C.c_int32, c_uint8_p, c_float_p, c_uint8_p, C.c_int32, c_int32_p, c_int32_p, c_int32_p,
                                          C.c_int32, c_int32_p, c_int32_p, c_int32_p, C.c_float, C.c_int32, c_int32_p]),
     "osh_host_frame_pose_optimization": (C.c_int, [C.c_void_p, C.c_int32, c_float_p, c_int32_p, c_float_p, C.c_int32, c_float_p, c_uint8_p]),

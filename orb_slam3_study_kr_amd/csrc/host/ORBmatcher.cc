@@ -806,4 +806,97 @@ int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpM
   return nmatches;
 }
 
+// src/ORBmatcher.cc:765-905: same scheme as the keyframe / frame variant.  The static candidate filters (keyframe 2's feature holds a
+// good map point, index below mvKeysUn.size() on a fisheye rig keyframe) are applied when the lists are built; vbMatched2 is the
+// sequential part that the ordered replay reproduces.
+int ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12) {
+  const std::vector<cv::KeyPoint>& vKeysUn1 = pKF1->mvKeysUn;
+  const DBoW2::FeatureVector& vFeatVec1 = pKF1->mFeatVec;
+  const std::vector<MapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches();
+  const std::vector<cv::KeyPoint>& vKeysUn2 = pKF2->mvKeysUn;
+  const DBoW2::FeatureVector& vFeatVec2 = pKF2->mFeatVec;
+  const std::vector<MapPoint*> vpMapPoints2 = pKF2->GetMapPointMatches();
+  vpMatches12 = std::vector<MapPoint*>(vpMapPoints1.size(), static_cast<MapPoint*>(nullptr));
+  std::vector<bool> vbMatched2(vpMapPoints2.size(), false);
+  std::vector<int> q1;
+  std::vector<int32_t> off(1, 0), idx;
+  DBoW2::FeatureVector::const_iterator f1it = vFeatVec1.begin(), f1end = vFeatVec1.end();
+  DBoW2::FeatureVector::const_iterator f2it = vFeatVec2.begin(), f2end = vFeatVec2.end();
+  while (f1it != f1end && f2it != f2end) {
+    if (f1it->first == f2it->first) {
+      for (const unsigned int idx1 : f1it->second) {
+        if (pKF1->NLeft != -1 && idx1 >= pKF1->mvKeysUn.size()) continue;
+        MapPoint* pMP1 = vpMapPoints1[idx1];
+        if (!pMP1 || pMP1->isBad()) continue;
+        q1.push_back((int)idx1);
+        for (const unsigned int idx2 : f2it->second) {
+          if (pKF2->NLeft != -1 && idx2 >= pKF2->mvKeysUn.size()) continue;
+          MapPoint* pMP2 = vpMapPoints2[idx2];
+          if (!pMP2 || pMP2->isBad()) continue;
+          idx.push_back((int32_t)idx2);
+        }
+        off.push_back((int32_t)idx.size());
+      }
+      f1it++; f2it++;
+    } else if (f1it->first < f2it->first) {
+      f1it = vFeatVec1.lower_bound(f2it->first);
+    } else {
+      f2it = vFeatVec2.lower_bound(f1it->first);
+    }
+  }
+  const int nq = (int)q1.size();
+  if (nq == 0) return 0;
+  std::vector<uint8_t> qdesc((size_t)nq * 32);
+  for (int q = 0; q < nq; ++q) std::memcpy(&qdesc[(size_t)q * 32], pKF1->mDescriptors.ptr<uint8_t>(q1[q]), 32);
+  std::vector<int32_t> b2, d1, d2, si;
+  if (!device_search_lists(qdesc, pKF2->mDescriptors, (int)vpMapPoints2.size(), off, idx, b2, d1, d2, si)) return 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  for (int i = 0; i < HISTO_LENGTH; i++) rotHist[i].reserve(500);
+  const float factor = 1.0f / HISTO_LENGTH;
+  int nmatches = 0;
+  for (int q = 0; q < nq; ++q) {
+    const int idx1 = q1[q];
+    int bestDist1 = d1[q], bestIdx2 = b2[q], bestDist2 = d2[q];
+    if ((bestIdx2 >= 0 && vbMatched2[bestIdx2]) || (si[q] >= 0 && vbMatched2[si[q]])) {
+      bestDist1 = 256; bestIdx2 = -1; bestDist2 = 256;
+      const uint32_t* qd = reinterpret_cast<const uint32_t*>(&qdesc[(size_t)q * 32]);
+      for (int c = off[q]; c < off[q + 1]; ++c) {
+        const int i2 = idx[c];
+        if (vbMatched2[i2]) continue;
+        const uint32_t* td = pKF2->mDescriptors.ptr<uint32_t>(i2);
+        int dist = 0;
+        for (int k = 0; k < 8; ++k) dist += __builtin_popcount(qd[k] ^ td[k]);
+        if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = i2; }
+        else if (dist < bestDist2) bestDist2 = dist;
+      }
+    }
+    if (bestDist1 < TH_LOW) {
+      if (static_cast<float>(bestDist1) < mfNNratio * static_cast<float>(bestDist2)) {
+        vpMatches12[idx1] = vpMapPoints2[bestIdx2];
+        vbMatched2[bestIdx2] = true;
+        if (mbCheckOrientation) {
+          float rot = vKeysUn1[idx1].angle - vKeysUn2[bestIdx2].angle;
+          if (rot < 0.0) rot += 360.0f;
+          int bin = (int)std::round(rot * factor);
+          if (bin == HISTO_LENGTH) bin = 0;
+          rotHist[bin].push_back(idx1);
+        }
+        nmatches++;
+      }
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+        vpMatches12[rotHist[i][j]] = static_cast<MapPoint*>(nullptr);
+        nmatches--;
+      }
+    }
+  }
+  return nmatches;
+}
+
 }  // namespace ORB_SLAM3

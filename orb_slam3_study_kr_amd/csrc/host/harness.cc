@@ -691,6 +691,44 @@ extern "C" int osh_host_search_by_bow(osh_host_frame* f, int32_t n_kf, const uin
   return n;
 }
 
+// ORBmatcher(nnratio, check_ori).SearchByBoW(&kf1, &kf2, matches12): two keyframes built from flat features (descriptor, angle, has_mp)
+// and CSR feature vectors; map point of feature i of keyframe 2 has id i.  match12[i] (i < n1): feature of keyframe 2 or -1.
+extern "C" int osh_host_search_by_bow_kf(int32_t n1, const uint8_t* desc1, const float* angle1, const uint8_t* has_mp1, int32_t nodes1,
+                                         const int32_t* node_id1, const int32_t* node_off1, const int32_t* node_feat1, int32_t n2,
+                                         const uint8_t* desc2, const float* angle2, const uint8_t* has_mp2, int32_t nodes2, const int32_t* node_id2,
+                                         const int32_t* node_off2, const int32_t* node_feat2, float nnratio, int32_t check_ori, int32_t* match12) {
+  Map map;
+  std::vector<std::unique_ptr<MapPoint>> mps;
+  auto build = [&](KeyFrame& kf, int n, const uint8_t* desc, const float* angle, const uint8_t* has_mp, int nodes, const int32_t* nid,
+                   const int32_t* noff, const int32_t* nfeat) {
+    kf.N = n;
+    kf.mDescriptors = cv::Mat(n, 32);
+    kf.mvpMapPoints.assign(n, nullptr);
+    for (int i = 0; i < n; ++i) {
+      cv::KeyPoint kp;
+      kp.angle = angle[i];
+      kf.mvKeysUn.push_back(kp); kf.mvKeys.push_back(kp);
+      std::memcpy(kf.mDescriptors.ptr<uint8_t>(i), desc + 32 * (size_t)i, 32);
+      if (has_mp[i]) {
+        mps.emplace_back(new MapPoint((unsigned long)i, Eigen::Vector3f(0.f, 0.f, 1.f), &map));
+        kf.mvpMapPoints[i] = mps.back().get();
+      }
+    }
+    for (int a = 0; a < nodes; ++a) kf.mFeatVec[(unsigned)nid[a]] = std::vector<unsigned int>(nfeat + noff[a], nfeat + noff[a + 1]);
+  };
+  KeyFrame kf1(7, &map), kf2(8, &map);
+  build(kf1, n1, desc1, angle1, has_mp1, nodes1, node_id1, node_off1, node_feat1);
+  build(kf2, n2, desc2, angle2, has_mp2, nodes2, node_id2, node_off2, node_feat2);
+  std::vector<MapPoint*> matches;
+  ORBmatcher matcher(nnratio, check_ori != 0);
+  const int n = matcher.SearchByBoW(&kf1, &kf2, matches);
+  for (int i = 0; i < n1; ++i) {
+    match12[i] = -1;
+    if (i < (int)matches.size() && matches[i]) match12[i] = (int32_t)matches[i]->mnId;
+  }
+  return n;
+}
+
 // ------------------------------------------------------------------------------------------ PoseInertialOptimization*
 struct osh_host_posei {
   Frame F, prevF;

@@ -575,3 +575,19 @@ class HostPoseiFrame:
                                         capi.ptr(H, capi.c_double_p), C.byref(gone))
         return dict(n=n, pose_qt=pose, Rwb=Rwb.reshape(3, 3), twb=twb, vel=vel, bias_a=bias[:3], bias_g=bias[3:], outlier=outlier, H=H.reshape(15, 15),
                     prev_cpi_deleted=bool(gone.value))
+
+
+def search_by_bow_keyframes(desc1, angle1, has_mp1, fv1, desc2, angle2, has_mp2, fv2, nnratio=0.7, check_ori=True):
+    """ORBmatcher(nnratio, check_ori).SearchByBoW(pKF1, pKF2, vpMatches12) (src/ORBmatcher.cc:765-905) on two keyframes built from flat
+    features; returns (nmatches, match12[n1]) with match12[i] = feature of keyframe 2 whose map point was matched to feature i."""
+    lib = capi.load_library()
+    d1, d2 = np.ascontiguousarray(desc1, dtype=np.uint8), np.ascontiguousarray(desc2, dtype=np.uint8)
+    keep = [d1, _f32(angle1), np.ascontiguousarray(has_mp1, dtype=np.uint8)] + [_i32(a) for a in fv1] + \
+           [d2, _f32(angle2), np.ascontiguousarray(has_mp2, dtype=np.uint8)] + [_i32(a) for a in fv2]
+    m = np.zeros(len(d1), dtype=np.int32)
+    n = lib.osh_host_search_by_bow_kf(len(d1), capi.ptr(keep[0], capi.c_uint8_p), capi.ptr(keep[1], capi.c_float_p), capi.ptr(keep[2], capi.c_uint8_p),
+                                      len(keep[3]), capi.ptr(keep[3], capi.c_int32_p), capi.ptr(keep[4], capi.c_int32_p), capi.ptr(keep[5], capi.c_int32_p),
+                                      len(d2), capi.ptr(keep[6], capi.c_uint8_p), capi.ptr(keep[7], capi.c_float_p), capi.ptr(keep[8], capi.c_uint8_p),
+                                      len(keep[9]), capi.ptr(keep[9], capi.c_int32_p), capi.ptr(keep[10], capi.c_int32_p), capi.ptr(keep[11], capi.c_int32_p),
+                                      float(nnratio), int(check_ori), capi.ptr(m, capi.c_int32_p))
+    return n, m

@@ -619,6 +619,21 @@ def test_search_by_bow_equals_sequential_reference(ob, rig, check_ori):
     np.testing.assert_array_equal(assign, assign_ref)
 
 
+@pytest.mark.parametrize("check_ori", [True, False])
+def test_search_by_bow_between_keyframes_equals_sequential_reference(ob, check_ori):
+    """ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&) (src/ORBmatcher.cc:765-905): candidates of keyframe 2 need a
+    map point, vbMatched2 replayed in order, strict bestDist1 < TH_LOW."""
+    d = synth.make_bow_pair(17, n_kf=800, n_f=850)
+    rng = np.random.Generator(np.random.PCG64(18))
+    has2 = (rng.uniform(size=len(d["f_desc"])) < 0.75).astype(np.uint8)
+    n, m = host.search_by_bow_keyframes(d["kf_desc"], d["kf_angle"], d["kf_has_mp"], d["kf_fv"], d["f_desc"], d["f_angle"], has2, d["f_fv"],
+                                        nnratio=0.75, check_ori=check_ori)
+    n_ref, m_ref = ob.orb_search_by_bow_kf(d["kf_desc"], d["f_desc"], d["kf_has_mp"], has2, d["kf_fv"], d["f_fv"], d["kf_angle"], d["f_angle"],
+                                           nn_ratio=0.75, check_ori=check_ori)
+    assert n == n_ref and n > 150
+    np.testing.assert_array_equal(m, m_ref)
+
+
 def test_pose_optimization_fisheye_stereo_frame(ob):
     """Optimizer::PoseOptimization on a frame with Nleft != -1 (src/Optimizer.cc:933-1008): keypoints [0, Nleft) through the left
     KannalaBrandt8, the others as EdgeSE3ProjectXYZOnlyPoseToBody through Trl and mpCamera2."""
