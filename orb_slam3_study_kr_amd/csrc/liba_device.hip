@@ -50,6 +50,7 @@ struct LibaView {
   const int* link_prev; const int* link_cur; const float* link_preint; const double* link_info; const double* link_info_g;
   const double* link_info_a; const unsigned char* link_robust;
   double* Hpl; double* Hll; double* bl; double* dinv;   // [E*18] [L*6] [L*3] [L*9]
+  double* BD;                 // [E*18] B Dinv of every optimisable-pose edge (Schur step)
   double* H; double* b; double* S; double* bs; double* x;   // [n*n] [n] [n*n] [n] [n]
   double* linkJ;              // [NL*(216+81+9)] J(9x24), W(9x9), -W r (9)
   double* out_chi2; unsigned char* out_depth;
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(kLT) void k_liba(LibaView v, int W) {
   double* H = v.H + d.H_off; double* S = v.S + d.H_off;
   double* b = v.b + d.b_off; double* bs = v.bs + d.b_off; double* xg = v.x + d.b_off;
   double* Hpl = v.Hpl + (size_t)d.edge_off * 18;
+  double* BD = v.BD + (size_t)d.edge_off * 18;
   double* Hll = v.Hll + (size_t)d.pt_off * 6; double* bl = v.bl + (size_t)d.pt_off * 3; double* dinv = v.dinv + (size_t)d.pt_off * 9;
   const int* lmo = v.lm_off + d.lmoff_off;
   const int* po = v.pel_off + d.peloff_off;
@@ -347,72 +349,72 @@ __global__ __launch_bounds__(kLT) void k_liba(LibaView v, int W) {
       for (int k = tid; k < n * n; k += kLT) { const int r = k / n, c = k - r * n; S[k] = H[k] + ((r == c) ? lambda : 0.0); }
       for (int k = tid; k < n; k += kLT) bs[k] = b[k];
       __syncthreads();
-      // Schur rows (block_solver.hpp:381-432): one wavefront per pose row i; lane (t, col) owns column col of the blocks
-      // S(i, i + 10 g + t), g = 0..2.  The row's edges are taken 32 at a time: lane k of the pass loads edge k (its landmark's
-      // Dinv, its Hpl block, the landmark's partner-edge list), forms BD = B Dinv once and parks it in the wave's LDS slice;
-      // all lanes then walk the 32 staged edges out of LDS, so the only global load left in the inner loop is the partner
-      // block (independent across edges -> several in flight).  Before: every edge cost three dependent global loads, ~1 us.
-      for (int i = wave; i < N; i += kLT / 64) {
-        const int t = lane / 6, col = lane - t * 6;
-        double* stBD = sh + (size_t)wave * kStageDoublesPerWave;
-        int* stq = reinterpret_cast<int*>(stBD + kStageEdges * 18);
-        double ci[6] = {0, 0, 0, 0, 0, 0};
-        double acc[3][6];
+      // Schur complement (block_solver.hpp:381-432), landmark-parallel.  (a) BD = B Dinv of every optimisable-pose edge, one thread
+      // per edge; (b) one wavefront per pose PAIR (i <= i2): the lanes stride the landmarks, a landmark seen by both poses adds
+      // BD_i B_i2^T to the lane's 6x6 partial, the 36 partials are summed by a fixed butterfly and subtracted from S(i, i2);
+      // (c) the rhs terms B (Dinv b_l), one wavefront per pose over its edges.  (The first version walked the edges of one pose
+      // row per wavefront and looked every partner block up on the way: 48 % of the kernel, with 8 of 10 rows on the first pass
+      // and two wavefronts on the second.)
+      for (int i = 0; i < N; ++i)
+        for (int idx = po[i] + tid; idx < po[i + 1]; idx += kLT) {
+          const int e = v.pel_edge[(size_t)d.pel_off + idx];
+          const int j = v.e_point[(size_t)d.edge_off + e];
+          const double* Dj = dinv + (size_t)j * 9;
+          const double* Be = Hpl + (size_t)e * 18;
+          double* o = BD + (size_t)e * 18;
 #pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-          for (int r = 0; r < 6; ++r) acc[g][r] = 0.0;
-        const int ngroups = (N - i + 9) / 10;   // <= 3 for N <= 25 + the guard below
-        for (int c0 = po[i]; c0 < po[i + 1]; c0 += kStageEdges) {
-          const int cnt = min(kStageEdges, po[i + 1] - c0);
-          if (lane < cnt) {
-            const int e = v.pel_edge[(size_t)d.pel_off + c0 + lane];
-            const int j = v.e_point[(size_t)d.edge_off + e];
-            const double* Dj = dinv + (size_t)j * 9;
-            const double* Be = Hpl + (size_t)e * 18;
-            // second edge of a (keyframe, landmark) pair: its block lives in the first edge's slot, this entry contributes nothing
-            const bool second = e > lmo[j] && v.e_pose[(size_t)d.edge_off + e - 1] == i;
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-              const double x0 = second ? 0.0 : Be[r * 3], x1 = second ? 0.0 : Be[r * 3 + 1], x2 = second ? 0.0 : Be[r * 3 + 2];
-              stBD[lane * 18 + r * 3 + 0] = x0 * Dj[0] + x1 * Dj[1] + x2 * Dj[2];
-              stBD[lane * 18 + r * 3 + 1] = x0 * Dj[1] + x1 * Dj[3] + x2 * Dj[4];
-              stBD[lane * 18 + r * 3 + 2] = x0 * Dj[2] + x1 * Dj[4] + x2 * Dj[5];
-              ci[r] += x0 * Dj[6] + x1 * Dj[7] + x2 * Dj[8];
-            }
-            for (int p2 = 0; p2 < N; ++p2) stq[lane * kStageMaxN + p2] = second ? -1 : lmpe[(size_t)j * N + p2];
+          for (int r = 0; r < 6; ++r) {
+            const double x0 = Be[r * 3], x1 = Be[r * 3 + 1], x2 = Be[r * 3 + 2];
+            o[r * 3 + 0] = x0 * Dj[0] + x1 * Dj[1] + x2 * Dj[2];
+            o[r * 3 + 1] = x0 * Dj[1] + x1 * Dj[3] + x2 * Dj[4];
+            o[r * 3 + 2] = x0 * Dj[2] + x1 * Dj[4] + x2 * Dj[5];
           }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll 4
-          for (int k = 0; k < cnt; ++k) {
-            double BD[18];
+        }
+      __syncthreads();
+      const int npairs = N * (N + 1) / 2;
+      for (int pr = wave; pr < npairs; pr += kLT / 64) {
+        int i = 0, rem = pr;
+        while (rem >= N - i) { rem -= N - i; ++i; }
+        const int i2 = i + rem;
+        double acc[36];
 #pragma unroll
-            for (int m = 0; m < 18; ++m) BD[m] = stBD[k * 18 + m];
+        for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+        for (int j = lane; j < L; j += 64) {
+          const int e1 = lmpe[(size_t)j * N + i], e2 = lmpe[(size_t)j * N + i2];
+          if (e1 < 0 || e2 < 0) continue;
+          const double* A1 = BD + (size_t)e1 * 18;
+          const double* B2 = Hpl + (size_t)e2 * 18;
+          double b2[18];
 #pragma unroll
-            for (int g = 0; g < 3; ++g) {
-              const int i2 = i + 10 * g + t;
-              if (g < ngroups && t < 10 && i2 < N) {
-                const int q = stq[k * kStageMaxN + i2];
-                if (q >= 0) {
-                  const double* Bq = Hpl + (size_t)q * 18 + col * 3;
-                  const double y0 = Bq[0], y1 = Bq[1], y2 = Bq[2];
+          for (int k = 0; k < 18; ++k) b2[k] = B2[k];
 #pragma unroll
-                  for (int r = 0; r < 6; ++r) acc[g][r] += BD[r * 3] * y0 + BD[r * 3 + 1] * y1 + BD[r * 3 + 2] * y2;
-                }
-              }
-            }
+          for (int r = 0; r < 6; ++r) {
+            const double a0 = A1[r * 3], a1 = A1[r * 3 + 1], a2 = A1[r * 3 + 2];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) acc[r * 6 + c] += a0 * b2[c * 3] + a1 * b2[c * 3 + 1] + a2 * b2[c * 3 + 2];
           }
-          __builtin_amdgcn_wave_barrier();
         }
 #pragma unroll
-        for (int g = 0; g < 3; ++g) {
-          const int i2 = i + 10 * g + t;
-          if (g < ngroups && t < 10 && i2 < N) {
+        for (int k = 0; k < 36; ++k) acc[k] = dev::wave_sum(acc[k]);
+        if (lane < 36) {
+          double val = acc[0];
 #pragma unroll
-            for (int r = 0; r < 6; ++r) S[(size_t)(6 * i + r) * n + 6 * i2 + col] -= acc[g][r];
-          }
+          for (int k = 1; k < 36; ++k) val = (lane == k) ? acc[k] : val;
+          const int r = lane / 6, c = lane - r * 6;
+          S[(size_t)(6 * i + r) * n + 6 * i2 + c] -= val;
+        }
+      }
+      for (int i = wave; i < N; i += kLT / 64) {
+        double ci[6] = {0, 0, 0, 0, 0, 0};
+        for (int idx = po[i] + lane; idx < po[i + 1]; idx += 64) {
+          const int e = v.pel_edge[(size_t)d.pel_off + idx];
+          const int j = v.e_point[(size_t)d.edge_off + e];
+          // second edge of a (keyframe, landmark) pair: its block lives in the first edge's slot
+          if (e > lmo[j] && v.e_pose[(size_t)d.edge_off + e - 1] == i) continue;
+          const double* Dj = dinv + (size_t)j * 9;
+          const double* Be = Hpl + (size_t)e * 18;
+#pragma unroll
+          for (int r = 0; r < 6; ++r) ci[r] += Be[r * 3] * Dj[6] + Be[r * 3 + 1] * Dj[7] + Be[r * 3 + 2] * Dj[8];
         }
 #pragma unroll
         for (int r = 0; r < 6; ++r) ci[r] = dev::wave_sum(ci[r]);
@@ -546,7 +548,7 @@ using namespace osh;
 namespace {
 struct LibaBuffers {
   DevBuf desc, out, pose[2], vba[2], pts[2], e_pose, e_point, e_kind, e_obs, e_info, e_orig, lm_off, pel_off, pel_edge, lmpe,
-      l_prev, l_cur, l_pre, l_info, l_ig, l_ia, l_rob, Hpl, Hll, bl, dinv, H, b, S, bs, x, linkJ, o_chi2, o_depth;
+      l_prev, l_cur, l_pre, l_info, l_ig, l_ia, l_rob, Hpl, BD, Hll, bl, dinv, H, b, S, bs, x, linkJ, o_chi2, o_depth;
 };
 LibaBuffers& liba_buffers() { static thread_local LibaBuffers b; return b; }
 template <class T>
@@ -699,7 +701,7 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
   OSH_TRY(up(B.l_pre, h_pre, s)); OSH_TRY(up(B.l_info, h_li, s)); OSH_TRY(up(B.l_ig, h_lg, s)); OSH_TRY(up(B.l_ia, h_la, s));
   OSH_TRY(up(B.l_rob, h_rob, s));
   auto R = [](DevBuf& b, size_t bytes) { return b.reserve(std::max<size_t>(bytes, 8)); };
-  OSH_TRY(R(B.out, nw * sizeof(LibaOut))); OSH_TRY(R(B.Hpl, E * 18 * 8)); OSH_TRY(R(B.Hll, L * 6 * 8)); OSH_TRY(R(B.bl, L * 3 * 8));
+  OSH_TRY(R(B.out, nw * sizeof(LibaOut))); OSH_TRY(R(B.Hpl, E * 18 * 8)); OSH_TRY(R(B.BD, E * 18 * 8)); OSH_TRY(R(B.Hll, L * 6 * 8)); OSH_TRY(R(B.bl, L * 3 * 8));
   OSH_TRY(R(B.dinv, L * 9 * 8)); OSH_TRY(R(B.H, Htot * 8)); OSH_TRY(R(B.S, Htot * 8)); OSH_TRY(R(B.b, btot * 8)); OSH_TRY(R(B.bs, btot * 8));
   OSH_TRY(R(B.x, btot * 8)); OSH_TRY(R(B.linkJ, NL * 306 * 8)); OSH_TRY(R(B.o_chi2, E * 8)); OSH_TRY(R(B.o_depth, E));
   OSH_HIP(hipMemsetAsync(B.Hpl.p, 0, std::max<size_t>(E * 18 * 8, 8), s));
@@ -710,7 +712,7 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
   v.e_info = B.e_info.as<double>(); v.e_orig = B.e_orig.as<int>(); v.lm_off = B.lm_off.as<int>(); v.pel_off = B.pel_off.as<int>();
   v.pel_edge = B.pel_edge.as<int>(); v.lm_pose_edge = B.lmpe.as<int>(); v.link_prev = B.l_prev.as<int>(); v.link_cur = B.l_cur.as<int>();
   v.link_preint = B.l_pre.as<float>(); v.link_info = B.l_info.as<double>(); v.link_info_g = B.l_ig.as<double>(); v.link_info_a = B.l_ia.as<double>();
-  v.link_robust = B.l_rob.as<unsigned char>(); v.Hpl = B.Hpl.as<double>(); v.Hll = B.Hll.as<double>(); v.bl = B.bl.as<double>();
+  v.link_robust = B.l_rob.as<unsigned char>(); v.Hpl = B.Hpl.as<double>(); v.BD = B.BD.as<double>(); v.Hll = B.Hll.as<double>(); v.bl = B.bl.as<double>();
   v.dinv = B.dinv.as<double>(); v.H = B.H.as<double>(); v.b = B.b.as<double>(); v.S = B.S.as<double>(); v.bs = B.bs.as<double>();
   v.x = B.x.as<double>(); v.linkJ = B.linkJ.as<double>(); v.out_chi2 = B.o_chi2.as<double>(); v.out_depth = B.o_depth.as<unsigned char>();
   static bool attr_done = false;
