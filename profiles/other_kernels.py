@@ -28,6 +28,13 @@ def main():
         m.match()
     launches, ms = m.profile()
     out["orb_bruteforce_ms_per_launch_64_pairs"] = ms / max(launches, 1)
+    # the whole matching loop with the sequential slot occupancy resolved on the device (k_orb_claim / k_orb_research rounds)
+    m.match_local_points()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        n_m, _, _, rounds = m.match_local_points()
+    out["orb_match_local_points_ms_64_pairs"] = (time.perf_counter() - t0) / 5 * 1e3
+    out["orb_occupancy_rounds"] = rounds
     m.close()
     ws = [si.make_inertial_window(11 + k) for k in range(8)]
     sv = lba.LbaSolver(0)
@@ -52,6 +59,25 @@ def main():
         t0 = time.perf_counter()
         sv.optimize_poses(frames)
         out["pose_64_frames_ms"] = (time.perf_counter() - t0) * 1e3
+    # PoseInertialOptimizationLastKeyFrame / LastFrame (k_posei): one frame (the tracker's call) and a batch
+    pf = [si.make_posei_frame(70 + k, mode=k % 2, n_points=800) for k in range(64)]
+    sv.optimize_poses_inertial(pf[:1])
+    t0 = time.perf_counter()
+    for _ in range(5):
+        sv.optimize_poses_inertial(pf[:1])
+    out["posei_single_frame_ms"] = (time.perf_counter() - t0) / 5 * 1e3
+    sv.optimize_poses_inertial(pf)
+    t0 = time.perf_counter()
+    sv.optimize_poses_inertial(pf)
+    out["posei_64_frames_ms"] = (time.perf_counter() - t0) * 1e3
+    # global BA of a 600-keyframe map: the reduced system (n = 3594) goes through csrc/big_solve.h
+    big = synth.make_window(900, n_free=599, n_fixed=1, n_points=18000, stereo=True, max_iterations=5)
+    sv.upload([big])
+    t0 = time.perf_counter()
+    sv.optimize()
+    out["gba_600_keyframes_optimize_ms"] = (time.perf_counter() - t0) * 1e3
+    r = sv.download()[0]
+    out["gba_600_keyframes_iterations"] = int(r.iterations)
     sv.close()
     print(json.dumps(out))
 
