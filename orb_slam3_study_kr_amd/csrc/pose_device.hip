@@ -94,6 +94,7 @@ template <bool KB8>
 __global__ __launch_bounds__(kPT) void k_pose_opt(PoseView v) {
   __shared__ double sh[kPT / 64];
   __shared__ double shH[28];          // upper(Hpp) (21), b (6), spare
+  __shared__ double shn[(kPT / 64) * 27];   // per-wavefront partials of the 27 sums
   __shared__ double sh_qt[2][7];      // current / trial estimate
   __shared__ double sh_x[6];
   __shared__ int sh_ok;
@@ -161,9 +162,26 @@ __global__ __launch_bounds__(kPT) void k_pose_opt(PoseView v) {
           b[a] += Jp[a] * wr[0] + Jp[6 + a] * wr[1] + Jp[12 + a] * wr[2];
         }
       }
-      for (int k = 0; k < 27; ++k) {
-        const double t = pose_block_sum(k < 21 ? H[k < 21 ? k : 0] : b[(k - 21) < 0 ? 0 : (k - 21)], sh);
-        if (tid == 0) shH[k] = t;
+      {
+        // 27 block sums with two barriers: wavefront butterflies, partials parked in LDS, added in wavefront order (deterministic);
+        // one barrier pair per value cost 54 barriers per LM iteration
+        double red[27];
+#pragma unroll
+        for (int k = 0; k < 21; ++k) red[k] = dev::wave_sum(H[k]);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) red[21 + k] = dev::wave_sum(b[k]);
+        __syncthreads();
+        if ((tid & 63) == 0) {
+#pragma unroll
+          for (int k = 0; k < 27; ++k) shn[(tid >> 6) * 27 + k] = red[k];
+        }
+        __syncthreads();
+        if (tid < 27) {
+          double t = 0.0;
+#pragma unroll
+          for (int w = 0; w < kPT / 64; ++w) t += shn[w * 27 + tid];
+          shH[tid] = t;
+        }
       }
       __syncthreads();
       if (it == 0) {

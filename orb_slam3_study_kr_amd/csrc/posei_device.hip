@@ -54,6 +54,27 @@ __device__ __forceinline__ double posei_block_sum(double v, double* sh) {
   return t;
 }
 
+// N block sums with TWO barriers: butterfly inside each wavefront, the wavefront partials parked in LDS ([kIT/64][N]) and added in
+// wavefront order by every thread (deterministic).  27 single sums cost 54 barriers per Gauss-Newton iteration before.
+template <int N>
+__device__ __forceinline__ void posei_block_sum_n(double* v, double* shn) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = dev::wave_sum(v[k]);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) shn[(threadIdx.x >> 6) * N + k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < kIT / 64; ++w) t += shn[w * N + k];
+    v[k] = t;
+  }
+}
+
 // A x = b for a symmetric n x n system (n <= 32) held row-major in LDS, by ONE wavefront: lane j keeps column j, the pivot row
 // is broadcast with v_readlane; returns false unless every pivot is positive (Eigen::LDLT::isPositive).  U: 32 x 33 doubles of
 // LDS scratch for the unit upper factor; x in LDS.
@@ -100,6 +121,7 @@ __device__ bool posei_solve_wave(const double* A, const double* b, int n, double
 
 __global__ __launch_bounds__(kIT) void k_posei(PoseiView v) {
   __shared__ double sh[kIT / 64];
+  __shared__ double shn[(kIT / 64) * 27];
   __shared__ double shP[24], shs[9], shpP[24], shps[9];     // current / previous state
   __shared__ double shH[900], shb[30], shx[30];
   __shared__ double shJ[9 * 24], shWJ[15 * 30], shr[15], shJp[225];
@@ -168,13 +190,11 @@ __global__ __launch_bounds__(kIT) void k_posei(PoseiView v) {
     __syncthreads();
     // visual block sums (27 fixed-order reductions), then everything else is added by the threads that own an entry
     double red[27];
-    {
-      int m = 0;
 #pragma unroll
-      for (int k = 0; k < 21; ++k) red[m++] = posei_block_sum(H[k], sh);
+    for (int k = 0; k < 21; ++k) red[k] = H[k];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) red[m++] = posei_block_sum(b[k], sh);
-    }
+    for (int k = 0; k < 6; ++k) red[21 + k] = b[k];
+    posei_block_sum_n<27>(red, shn);
     for (int idx = tid; idx < n * n; idx += kIT) {
       const int r = idx / n, c = idx - r * n;
       double acc = 0.0;
@@ -390,7 +410,8 @@ __global__ __launch_bounds__(kIT) void k_posei(PoseiView v) {
     }
     double red[21];
 #pragma unroll
-    for (int k = 0; k < 21; ++k) red[k] = posei_block_sum(H[k], sh);
+    for (int k = 0; k < 21; ++k) red[k] = H[k];
+    posei_block_sum_n<21>(red, shn);
     if (mode1 && tid == 0) {
       double T[9], dd[3], rr[15], invJr[9];
       imu::m3_tmul(d.prior_R, shpP + 12, T);
