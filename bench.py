@@ -316,6 +316,21 @@ def run_inertial(args, info, windows):
     out = dict(metric="LocalInertialBA windows/sec (10 temporal KF + 21 fixed, ~1.1k landmarks, ~16.7k stereo edges, IMU preintegration edges)",
                windows_per_s=len(windows) / batch_s, windows_per_batch=len(windows), single_window_latency_ms=single_ms,
                lm_iterations_mean=float(np.mean([r.iterations for r in res])), includes="H2D upload + D2H download", dtype="f64 (+f32 preintegration getters)")
+    # SURVEY.md 8(d) byte model applied to the visual part of the inertial window (d = 3, P = the temporal keyframes): per iteration and
+    # trial (lin + resid) + (schur + back + update + resid).  k_liba is ONE block per window and bound by global-memory latency
+    # (DESIGN.md 4b), so the fraction is tiny by construction; it is reported so that the next round's multi-CU kernel has a yardstick.
+    alg = 0.0
+    for w, r in zip(windows, res):
+        E, L, P, F = w.n_edges, w.n_points, w.n_opt, w.n_fixed + w.n_fixed_imu
+        Ef = int((w.edge_pose < w.n_opt).sum())
+        resid = E * (8 * 3 + 16) + L * 24 + (P + F) * 56
+        lin = resid + Ef * 144 + L * 72 + P * 216
+        schur = Ef * 144 + L * 72 + (6 * P) * (6 * P + 1) * 8
+        back = Ef * 144 + L * 96 + 6 * P * 8
+        upd = 2 * (P * 56 + L * 24)
+        alg += r.iterations * (lin + resid) + r.trials * (schur + back + upd + resid)
+    out["roofline"] = dict(bound="hbm", kernel="k_liba", achieved=alg / batch_s / 1e9, peak=8000.0, unit="GB/s", frac=alg / batch_s / 8e12,
+                           traffic=None, note="whole call incl. upload / download; one persistent block per window, latency bound")
     if info.rank == 0 and info.world == 1 and not args.no_cpu_baseline:
         from oracle import binding as ob
         n, t0 = 0, time.perf_counter()
