@@ -110,7 +110,11 @@ inline int pack_batch(int nw, const osh_lba_problem* pr, const std::function<voi
   pb = PackedBatch();
   pb.nw = nw;
   pb.win.assign(nw, WinDesc{});
-  auto fail = [&](int code, const char* fmt, auto... a) { pb.err = code; std::snprintf(pb.msg, sizeof(pb.msg), fmt, a...); return code; };
+  auto fail = [&](int code, const char* fmt, auto... a) {
+    pb.err = code;
+    if constexpr (sizeof...(a) == 0) std::snprintf(pb.msg, sizeof(pb.msg), "%s", fmt); else std::snprintf(pb.msg, sizeof(pb.msg), fmt, a...);
+    return code;
+  };
   // ---- pass 1: validate + offsets of the fixed-size sections
   size_t NP = 0, NFP = 0, NL = 0, NE = 0, NLO = 0, NOUT = 0, S_total = 0;
   for (int w = 0; w < nw; ++w) {
