@@ -303,3 +303,109 @@ def posei_numeric_system(st, delta_pose=1e-6, delta_bias=2e-3):
         H += Ji.T @ (rho1 * Om) @ Ji
         b += -Ji.T @ (rho1 * Om @ r)
     return H, b
+
+
+def posei_optimize(f, delta_pose=1e-6, delta_bias=2e-3):
+    """The whole of PoseInertialOptimizationLastKeyFrame / LastFrame (src/Optimizer.cc:4499-5299) in numpy, independent of the C
+    restatement: Gauss-Newton with CENTRAL-DIFFERENCE Jacobians of every residual block (smooth fisheye angles for the differences),
+    numpy.linalg.solve for the step, four classify rounds with g2o's stale-error rule, the recovery pass, and the Hessian of the
+    frame's ConstraintPoseImu (mode 1: over [previous, current], before Marginalize).  Returns a dict."""
+    st = PoseiState(f)
+    E = f.n_edges
+    n = 30 if f.mode == 1 else 15
+    level = np.zeros(E, dtype=bool)
+    outlier = np.zeros(E, dtype=bool)
+    chi2 = np.zeros(E)
+    robust = True
+    n_extra = 4 if f.mode == 1 else 3
+
+    def depth_ok(s, e):
+        X = f.points[e]
+        R, t = s.Rcw, s.tcw
+        if f.edge_kind[e] == 2:
+            T = np.asarray(f.trl).reshape(3, 4)
+            R, t = T[:, :3] @ R, T[:, :3] @ t + T[:, 3]
+        return (R[2] @ X + t[2]) > 0.0
+
+    def jac(s, block_fn):
+        r0 = block_fn(s)
+        J = np.zeros((len(r0), n))
+        for j in range(n):
+            d = delta_bias if (j % 15) >= 9 else delta_pose
+            e = np.zeros(n); e[j] = d
+            sp, sm = s.copy(), s.copy()
+            sp.oplus(e); sm.oplus(-e)
+            J[:, j] = (block_fn(sp) - block_fn(sm)) / (2 * d)
+        return J
+
+    def all_jacobians(s, skip):
+        """Central-difference Jacobian of every residual block that is not skipped, one state perturbation per column."""
+        base = posei_residual_blocks(s, smooth=True)
+        J = [None if skip(i) else np.zeros((len(r), n)) for i, (r, _, _) in enumerate(base)]
+        for j in range(n):
+            d = delta_bias if (j % 15) >= 9 else delta_pose
+            e = np.zeros(n); e[j] = d
+            sp, sm = s.copy(), s.copy()
+            sp.oplus(e); sm.oplus(-e)
+            bp, bm = posei_residual_blocks(sp, smooth=True), posei_residual_blocks(sm, smooth=True)
+            for i in range(len(base)):
+                if J[i] is not None:
+                    J[i][:, j] = (bp[i][0] - bm[i][0]) / (2 * d)
+        return J
+    rounds = n_bad = n_inl = 0
+    for rnd in range(4):
+        for _ in range(f.iterations[rnd]):
+            H, b = np.zeros((n, n)), np.zeros(n)
+            blocks = posei_residual_blocks(st)                       # reference residuals (float32 fisheye angles)
+            J = all_jacobians(st, lambda i: i < E and level[i])
+            for i, (r, Om, delta) in enumerate(blocks):
+                if i < E:
+                    if level[i]:
+                        continue
+                    chi2[i] = float(r @ Om @ r)
+                    rho1 = huber(chi2[i], delta)[1] if robust else 1.0
+                else:
+                    rho1 = huber(float(r @ Om @ r), delta)[1] if delta is not None else 1.0
+                H += J[i].T @ (rho1 * Om) @ J[i]
+                b += -J[i].T @ (rho1 * Om @ r)
+            st.oplus(np.linalg.solve(H, b))
+        bad = inl = 0
+        chi2close = np.float32(1.5 * np.float32(f.chi2_mono[rnd]))
+        for e in range(E):
+            if outlier[e]:
+                r = posei_visual_residual(st, e)
+                chi2[e] = float(r @ r) * f.edge_info[e]
+            c = np.float32(chi2[e])
+            if f.edge_kind[e] != 1:
+                close = bool(f.edge_close[e])
+                o = (c > np.float32(f.chi2_mono[rnd]) and not close) or (close and c > chi2close) or not depth_ok(st, e)
+            else:
+                o = c > np.float32(f.chi2_stereo[rnd])
+            outlier[e] = level[e] = o
+            bad += int(o); inl += int(not o)
+        n_bad, n_inl, rounds = bad, inl, rnd + 1
+        if rnd == 2:
+            robust = False
+        if E + n_extra < 10:
+            break
+    if n_inl < 30 and not f.rec_init:
+        n_bad = 0
+        for e in range(E):
+            r = posei_visual_residual(st, e)
+            chi2[e] = float(r @ r) * f.edge_info[e]
+            if chi2[e] < (24.0 if f.edge_kind[e] == 1 else 18.0):
+                outlier[e] = False
+            else:
+                n_bad += 1
+    # Hessian for ConstraintPoseImu: plain information, every block re-linearised at the final state; reference order [prev | cur]
+    Hc = np.zeros((n, n))
+    blocks = posei_residual_blocks(st)
+    J = all_jacobians(st, lambda i: i < E and outlier[i])
+    for i, (r, Om, delta) in enumerate(blocks):
+        if J[i] is not None:
+            Hc += J[i].T @ Om @ J[i]
+    if f.mode == 1:
+        perm = np.concatenate([np.arange(15, 30), np.arange(0, 15)])
+        Hc = Hc[np.ix_(perm, perm)]
+    return dict(Rwb=st.Rwb, twb=st.twb, Rcw=st.Rcw, tcw=st.tcw, vel=st.v, bias_g=st.bg, bias_a=st.ba, outlier=outlier.astype(np.uint8),
+                edge_chi2=chi2, n_bad=n_bad, n_inliers=n_inl, rounds=rounds, H=Hc)

@@ -16,6 +16,8 @@ sys.path.insert(0, str(ROOT))
 
 from orb_slam3_study_kr_amd import synth  # noqa: E402
 from oracle import lm_numpy  # noqa: E402
+from oracle import liba_numpy  # noqa: E402
+from orb_slam3_study_kr_amd import synth_inertial  # noqa: E402
 
 OUT = Path(__file__).resolve().parent
 
@@ -58,7 +60,27 @@ def orb_fixture():
     print("orb_64x64", dist.min(), dist.max())
 
 
-if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "rig":
+POSEI_INPUTS = ("Rcw", "tcw", "Rwb", "twb", "vel", "bias_g", "bias_a", "prev_Rwb", "prev_twb", "prev_vel", "prev_bias_g", "prev_bias_a", "Rcb", "tcb",
+                "tbc", "cam", "preint", "info_inertial", "info_g", "info_a", "points", "edge_kind", "edge_obs", "edge_info", "edge_close", "prior_Rwb",
+                "prior_twb", "prior_vel", "prior_bg", "prior_ba", "prior_H", "kb8", "cam2", "trl")
+
+
+def posei_fixture(name, f):
+    """PoseInertialOptimizationLastKeyFrame / LastFrame: inputs + the outputs of the independent numpy model (oracle/liba_numpy.py:
+    central-difference Jacobians, numpy.linalg.solve, its own classification loop)."""
+    g = liba_numpy.posei_optimize(f)
+    arrays = {k: (getattr(f, k) if getattr(f, k) is not None else np.zeros(0)) for k in POSEI_INPUTS}
+    np.savez_compressed(OUT / f"{name}.npz", mode=f.mode, rec_init=int(f.rec_init), chi2_mono=np.array(f.chi2_mono), chi2_stereo=np.array(f.chi2_stereo),
+                        iterations=np.array(f.iterations), huber=np.array([f.huber_mono, f.huber_stereo, f.huber_prior]), **arrays,
+                        **{"exp_" + k: np.asarray(v) for k, v in g.items()})
+    print(name, "mode", f.mode, "edges", f.n_edges, "rounds", g["rounds"], "n_bad", g["n_bad"])
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "posei":
+    posei_fixture("posei_tiny_keyframe", synth_inertial.make_posei_frame(9, mode=0, n_points=60))
+    posei_fixture("posei_tiny_frame", synth_inertial.make_posei_frame(9, mode=1, n_points=60))
+    posei_fixture("posei_tiny_rig", synth_inertial.make_posei_frame(10, mode=1, n_points=60, rig=True))
+elif __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "rig":
     lba_fixture("lba_tiny_rig", synth.make_rig_window(71, n_free=3, n_fixed=2, n_points=40, track_len=(2, 5)))
 elif __name__ == "__main__":
     lba_fixture("lba_tiny_mono", synth.make_window(11, n_free=3, n_fixed=2, n_points=40, stereo=False, track_len=(2, 5)))
@@ -74,3 +96,6 @@ elif __name__ == "__main__":
     # fisheye STEREO rig: left KannalaBrandt8 edges + right-camera body edges (EdgeSE3ProjectXYZToBody) sharing Hessian blocks
     lba_fixture("lba_tiny_rig", synth.make_rig_window(71, n_free=3, n_fixed=2, n_points=40, track_len=(2, 5)))
     orb_fixture()
+    posei_fixture("posei_tiny_keyframe", synth_inertial.make_posei_frame(9, mode=0, n_points=60))
+    posei_fixture("posei_tiny_frame", synth_inertial.make_posei_frame(9, mode=1, n_points=60))
+    posei_fixture("posei_tiny_rig", synth_inertial.make_posei_frame(10, mode=1, n_points=60, rig=True))

@@ -51,3 +51,24 @@ def dense_blocks_from_H(H, b, w):
         if ip < P:
             Hpl[e] = H[6 * ip:6 * ip + 6, 6 * P + 3 * il:6 * P + 3 * il + 3]
     return Hpp, b[:6 * P].reshape(P, 6), Hll, b[6 * P:].reshape(L, 3), Hpl
+
+
+POSEI_FIXTURES = ["posei_tiny_keyframe", "posei_tiny_frame", "posei_tiny_rig"]
+
+
+def load_posei_fixture(name):
+    """A committed PoseInertialOptimization fixture (tests/golden/make_golden.py posei): the flat frame and the numpy model's outputs."""
+    from orb_slam3_study_kr_amd import synth_inertial as si
+    z = np.load(GOLDEN / f"{name}.npz")
+    opt = lambda k: (z[k] if z[k].size else None)   # noqa: E731
+    f = si.PoseiFrame(
+        mode=int(z["mode"]), Rcw=z["Rcw"], tcw=z["tcw"], Rwb=z["Rwb"], twb=z["twb"], vel=z["vel"], bias_g=z["bias_g"], bias_a=z["bias_a"],
+        prev_Rwb=z["prev_Rwb"], prev_twb=z["prev_twb"], prev_vel=z["prev_vel"], prev_bias_g=z["prev_bias_g"], prev_bias_a=z["prev_bias_a"],
+        Rcb=z["Rcb"], tcb=z["tcb"], tbc=z["tbc"], cam=z["cam"], preint=z["preint"], info_inertial=z["info_inertial"], info_g=z["info_g"],
+        info_a=z["info_a"], points=z["points"], edge_kind=z["edge_kind"], edge_obs=z["edge_obs"], edge_info=z["edge_info"],
+        edge_close=z["edge_close"], prior_Rwb=opt("prior_Rwb"), prior_twb=opt("prior_twb"), prior_vel=opt("prior_vel"), prior_bg=opt("prior_bg"),
+        prior_ba=opt("prior_ba"), prior_H=opt("prior_H"), kb8=opt("kb8"), cam2=opt("cam2"), trl=opt("trl"), rec_init=bool(int(z["rec_init"])),
+        huber_mono=float(z["huber"][0]), huber_stereo=float(z["huber"][1]), huber_prior=float(z["huber"][2]),
+        chi2_mono=tuple(float(x) for x in z["chi2_mono"]), chi2_stereo=tuple(float(x) for x in z["chi2_stereo"]),
+        iterations=tuple(int(x) for x in z["iterations"])).normalise()
+    return f, z

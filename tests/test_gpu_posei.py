@@ -6,6 +6,9 @@ import pytest
 from orb_slam3_study_kr_amd import lba
 from orb_slam3_study_kr_amd import synth_inertial as si
 
+from helpers import POSEI_FIXTURES, load_posei_fixture
+from test_oracle_posei import check_against_posei_fixture
+
 pytestmark = pytest.mark.gpu
 
 
@@ -64,3 +67,11 @@ def test_mixed_batch_mono_fisheye_rig_and_small_frames(solver, ob):
     for g, a in zip(got, again):
         np.testing.assert_array_equal(g.twb, a.twb)      # fixed reduction orders: bitwise reproducible
         np.testing.assert_array_equal(g.H, a.H)
+
+
+@pytest.mark.parametrize("name", POSEI_FIXTURES)
+def test_device_matches_the_numpy_models_golden_outputs(solver, name):
+    """The committed fixtures of tests/golden/make_golden.py (independent numpy model of the whole function): no oracle in the loop."""
+    f, z = load_posei_fixture(name)
+    fish = f.kb8 is not None
+    check_against_posei_fixture(solver.optimize_poses_inertial([f])[0], z, f, state_tol=2e-6 if fish else 1e-7, chi_tol=2e-3 if fish else 2e-5)

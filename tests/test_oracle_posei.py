@@ -7,6 +7,7 @@ import pytest
 from oracle import binding as ob
 from oracle import liba_numpy as ln
 from orb_slam3_study_kr_amd import synth_inertial as si
+from helpers import POSEI_FIXTURES, load_posei_fixture
 
 
 @pytest.mark.parametrize("mode", [0, 1])
@@ -68,3 +69,28 @@ def test_few_inliers_recovery_pass_and_rec_init():
     # fewer than 10 graph edges: one round only (:4814-4817)
     f3 = si.make_posei_frame(7, mode=0, n_points=5, outlier_frac=0.0)
     assert ob.posei_optimize(f3).rounds == 1
+
+
+def check_against_posei_fixture(got, z, f, state_tol=1e-7, chi_tol=2e-5):
+    """Outputs of a PoseInertialOptimization run against the committed outputs of the independent numpy model (numeric Jacobians,
+    numpy.linalg.solve): final state, per-edge chi2, identical classification and the ConstraintPoseImu Hessian."""
+    assert got.rounds == int(z["exp_rounds"])
+    np.testing.assert_allclose(got.Rwb, z["exp_Rwb"], atol=state_tol)
+    np.testing.assert_allclose(got.twb, z["exp_twb"], atol=state_tol * max(1.0, np.abs(z["exp_twb"]).max()))
+    np.testing.assert_allclose(got.vel, z["exp_vel"], atol=state_tol * 10)
+    np.testing.assert_allclose(got.bias_g, z["exp_bias_g"], atol=state_tol / 10)
+    np.testing.assert_allclose(got.bias_a, z["exp_bias_a"], atol=state_tol)
+    np.testing.assert_allclose(got.edge_chi2, z["exp_edge_chi2"], rtol=chi_tol, atol=chi_tol)
+    thr = np.where(f.edge_kind == 1, f.chi2_stereo[3], np.where(f.edge_close == 1, 1.5 * f.chi2_mono[3], f.chi2_mono[3]))
+    near = np.abs(z["exp_edge_chi2"] - thr) < 10 * chi_tol * thr
+    np.testing.assert_array_equal(got.outlier[~near], z["exp_outlier"][~near])
+    if not near.any():
+        assert (got.n_bad, got.n_inliers) == (int(z["exp_n_bad"]), int(z["exp_n_inliers"]))
+    np.testing.assert_allclose(got.H, z["exp_H"], rtol=0, atol=2e-6 * np.abs(z["exp_H"]).max())
+
+
+@pytest.mark.parametrize("name", POSEI_FIXTURES)
+def test_oracle_matches_the_numpy_models_golden_outputs(name):
+    f, z = load_posei_fixture(name)
+    fish = f.kb8 is not None      # float32 theta / psi staircase: the numpy Jacobians differentiate the smooth projection
+    check_against_posei_fixture(ob.posei_optimize(f), z, f, state_tol=2e-6 if fish else 1e-7, chi_tol=2e-3 if fish else 2e-5)
