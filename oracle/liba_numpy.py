@@ -409,3 +409,54 @@ def posei_optimize(f, delta_pose=1e-6, delta_bias=2e-3):
         Hc = Hc[np.ix_(perm, perm)]
     return dict(Rwb=st.Rwb, twb=st.twb, Rcw=st.Rcw, tcw=st.tcw, vel=st.v, bias_g=st.bg, bias_a=st.ba, outlier=outlier.astype(np.uint8),
                 edge_chi2=chi2, n_bad=n_bad, n_inliers=n_inl, rounds=rounds, H=Hc)
+
+
+def lm_optimize(w, max_iterations=None):
+    """Optimizer::LocalInertialBA's optimizer.optimize(opt_it) in numpy, independent of the C restatement: the full (not Schur-reduced)
+    system over poses, velocities, biases and landmarks from central-difference Jacobians, numpy.linalg.solve, and g2o's
+    Levenberg-Marquardt controller (optimization_algorithm_levenberg.cpp:61-169: user lambda, rho with the +1e-3 scale, lambda
+    update by alpha / the ni doubling, at most 10 trials, Raul's three-bad-iterations stop).  Returns (state, trace dict)."""
+    st = State(w)
+    n = 15 * w.n_opt + 3 * w.n_points
+    lam = w.lambda_init if w.lambda_init > 0 else None
+    ni, n_bad = 2.0, 0
+    trace = dict(chi2=[], lam=[], trials=[], chi2_initial=robust_chi2(st))
+    its = w.max_iterations if max_iterations is None else max_iterations
+    for it in range(its):
+        current = robust_chi2(st)
+        ini = current
+        H, b = numeric_dense_system(st)
+        if it == 0 and lam is None:
+            lam = 1e-5 * np.max(np.abs(np.diag(H)))
+        rho, q = 0.0, 0
+        while True:
+            try:
+                x = np.linalg.solve(H + lam * np.eye(n), b)
+                ok = True
+            except np.linalg.LinAlgError:
+                x, ok = np.zeros(n), False
+            trial = st.copy()
+            trial.oplus(x)
+            temp = robust_chi2(trial) if ok else np.inf
+            scale = float(x @ (lam * x + b)) + 1e-3
+            rho = (current - temp) / scale
+            if rho > 0 and np.isfinite(temp):
+                alpha = min(1.0 - (2 * rho - 1) ** 3, 2.0 / 3.0)
+                lam *= max(1.0 / 3.0, alpha)
+                ni = 2.0
+                current = temp
+                st = trial
+            else:
+                lam *= ni
+                ni *= 2
+            q += 1
+            if not (rho < 0 and q < 10):
+                break
+        trace["chi2"].append(current); trace["lam"].append(lam); trace["trials"].append(q)
+        if q == 10 or rho == 0:
+            break
+        n_bad = n_bad + 1 if (ini - current) * 1e3 < ini else 0
+        if n_bad >= 3:
+            break
+    trace["iterations"] = len(trace["chi2"])
+    return st, trace

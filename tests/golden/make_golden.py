@@ -76,7 +76,29 @@ def posei_fixture(name, f):
     print(name, "mode", f.mode, "edges", f.n_edges, "rounds", g["rounds"], "n_bad", g["n_bad"])
 
 
-if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "posei":
+LIBA_INPUTS = ("pose_Rcw", "pose_tcw", "pose_Rwb", "pose_twb", "Rcb", "tcb", "tbc", "cam", "vel", "bias_g", "bias_a", "points", "edge_pose",
+               "edge_point", "edge_kind", "edge_obs", "edge_info", "link_prev", "link_cur", "link_preint", "link_info", "link_info_g",
+               "link_info_a", "link_robust", "kb8", "cam2", "trl")
+
+
+def liba_fixture(name, w):
+    """LocalInertialBA: inputs + the outputs of the independent numpy Levenberg-Marquardt (oracle/liba_numpy.py:lm_optimize: full dense
+    system from central-difference Jacobians, numpy.linalg.solve, g2o's controller)."""
+    st, tr = liba_numpy.lm_optimize(w)
+    N = w.n_opt
+    arrays = {k: (getattr(w, k) if getattr(w, k) is not None else np.zeros(0)) for k in LIBA_INPUTS}
+    np.savez_compressed(OUT / f"{name}.npz", n_opt=w.n_opt, n_fixed_imu=w.n_fixed_imu, n_fixed=w.n_fixed, lambda_init=w.lambda_init,
+                        max_iterations=w.max_iterations, huber=np.array([w.huber_mono, w.huber_stereo, w.huber_inertial]), **arrays,
+                        exp_chi2_initial=tr["chi2_initial"], exp_chi2_trace=np.array(tr["chi2"]), exp_lambda_trace=np.array(tr["lam"]),
+                        exp_trials_trace=np.array(tr["trials"]), exp_iterations=tr["iterations"], exp_Rwb=st.Rwb[:N], exp_twb=st.twb[:N],
+                        exp_Rcw=st.Rcw[:N], exp_tcw=st.tcw[:N], exp_vel=st.vel[:N], exp_bg=st.bg[:N], exp_ba=st.ba[:N], exp_points=st.X)
+    print(name, "edges", w.n_edges, "iters", tr["iterations"], "trials", tr["trials"], "chi2", tr["chi2_initial"], "->", tr["chi2"][-1])
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "liba":
+    liba_fixture("liba_tiny", synth_inertial.make_inertial_window(5, n_opt=3, n_fixed=2, n_points=40))
+    liba_fixture("liba_tiny_rig", synth_inertial.make_inertial_rig_window(7, n_opt=3, n_fixed=2, n_points=40))
+elif __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "posei":
     posei_fixture("posei_tiny_keyframe", synth_inertial.make_posei_frame(9, mode=0, n_points=60))
     posei_fixture("posei_tiny_frame", synth_inertial.make_posei_frame(9, mode=1, n_points=60))
     posei_fixture("posei_tiny_rig", synth_inertial.make_posei_frame(10, mode=1, n_points=60, rig=True))
@@ -96,6 +118,8 @@ elif __name__ == "__main__":
     # fisheye STEREO rig: left KannalaBrandt8 edges + right-camera body edges (EdgeSE3ProjectXYZToBody) sharing Hessian blocks
     lba_fixture("lba_tiny_rig", synth.make_rig_window(71, n_free=3, n_fixed=2, n_points=40, track_len=(2, 5)))
     orb_fixture()
+    liba_fixture("liba_tiny", synth_inertial.make_inertial_window(5, n_opt=3, n_fixed=2, n_points=40))
+    liba_fixture("liba_tiny_rig", synth_inertial.make_inertial_rig_window(7, n_opt=3, n_fixed=2, n_points=40))
     posei_fixture("posei_tiny_keyframe", synth_inertial.make_posei_frame(9, mode=0, n_points=60))
     posei_fixture("posei_tiny_frame", synth_inertial.make_posei_frame(9, mode=1, n_points=60))
     posei_fixture("posei_tiny_rig", synth_inertial.make_posei_frame(10, mode=1, n_points=60, rig=True))

@@ -72,3 +72,41 @@ def load_posei_fixture(name):
         chi2_mono=tuple(float(x) for x in z["chi2_mono"]), chi2_stereo=tuple(float(x) for x in z["chi2_stereo"]),
         iterations=tuple(int(x) for x in z["iterations"])).normalise()
     return f, z
+
+
+LIBA_FIXTURES = ["liba_tiny", "liba_tiny_rig"]
+
+
+def load_liba_fixture(name):
+    """A committed LocalInertialBA fixture (tests/golden/make_golden.py liba): the flat window and the numpy LM's outputs."""
+    from orb_slam3_study_kr_amd import synth_inertial as si
+    z = np.load(GOLDEN / f"{name}.npz")
+    opt = lambda k: (z[k] if z[k].size else None)   # noqa: E731
+    w = si.LibaWindow(
+        n_opt=int(z["n_opt"]), n_fixed_imu=int(z["n_fixed_imu"]), n_fixed=int(z["n_fixed"]), pose_Rcw=z["pose_Rcw"], pose_tcw=z["pose_tcw"],
+        pose_Rwb=z["pose_Rwb"], pose_twb=z["pose_twb"], Rcb=z["Rcb"], tcb=z["tcb"], tbc=z["tbc"], cam=z["cam"], vel=z["vel"], bias_g=z["bias_g"],
+        bias_a=z["bias_a"], points=z["points"], edge_pose=z["edge_pose"], edge_point=z["edge_point"], edge_kind=z["edge_kind"], edge_obs=z["edge_obs"],
+        edge_info=z["edge_info"], link_prev=z["link_prev"], link_cur=z["link_cur"], link_preint=z["link_preint"], link_info=z["link_info"],
+        link_info_g=z["link_info_g"], link_info_a=z["link_info_a"], link_robust=z["link_robust"], huber_mono=float(z["huber"][0]),
+        huber_stereo=float(z["huber"][1]), huber_inertial=float(z["huber"][2]), lambda_init=float(z["lambda_init"]),
+        max_iterations=int(z["max_iterations"]), kb8=opt("kb8"), cam2=opt("cam2"), trl=opt("trl")).normalise()
+    return w, z
+
+
+def check_against_liba_fixture(got, z, fisheye):
+    """A LocalInertialBA result against the numpy LM's committed outputs: LM trace, poses, velocities, biases, landmarks."""
+    assert got.iterations == int(z["exp_iterations"])
+    np.testing.assert_array_equal(got.trials_trace, z["exp_trials_trace"])
+    np.testing.assert_allclose(got.chi2_initial, z["exp_chi2_initial"], rtol=1e-6)
+    np.testing.assert_allclose(got.chi2_trace, z["exp_chi2_trace"], rtol=5e-6)
+    # the lambda left behind by the LAST iteration is never used, and at convergence its gain ratio is a quotient of two 1e-6-relative
+    # cost differences: compare the lambdas that steer an iteration
+    np.testing.assert_allclose(got.lambda_trace[:-1], z["exp_lambda_trace"][:-1], rtol=1e-4)
+    np.testing.assert_allclose(got.pose_Rwb, z["exp_Rwb"], atol=2e-7)
+    np.testing.assert_allclose(got.pose_twb, z["exp_twb"], atol=2e-7 * max(1.0, np.abs(z["exp_twb"]).max()))
+    np.testing.assert_allclose(got.pose_Rcw, z["exp_Rcw"], atol=2e-7)
+    np.testing.assert_allclose(got.vel, z["exp_vel"], atol=5e-7)
+    np.testing.assert_allclose(got.bias_g, z["exp_bg"], atol=1e-7)
+    np.testing.assert_allclose(got.bias_a, z["exp_ba"], atol=1e-6)
+    # weakly observed depths of a monocular / fisheye window move with the 1e-8 differences of the float32 preintegration getters
+    np.testing.assert_allclose(got.points, z["exp_points"], atol=2e-4 if fisheye else 1e-5)

@@ -107,3 +107,11 @@ def test_fisheye_stereo_rig_right_camera_edges(solver, ob):
     w2.edge_kind[3] = 2                                            # a right-camera edge without cam2 / trl
     with pytest.raises(RuntimeError, match="right-camera"):
         solver.solve_inertial([w2])
+
+
+@pytest.mark.parametrize("name", ["liba_tiny", "liba_tiny_rig"])
+def test_device_matches_the_numpy_lm_golden_outputs(solver, name):
+    """The committed fixtures of the independent numpy LM (tests/golden/make_golden.py liba): no oracle in the loop."""
+    from helpers import check_against_liba_fixture, load_liba_fixture
+    w, z = load_liba_fixture(name)
+    check_against_liba_fixture(solver.solve_inertial([w])[0], z, fisheye=w.kb8 is not None)

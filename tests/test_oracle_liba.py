@@ -142,3 +142,12 @@ def test_fisheye_rig_right_camera_edges_vs_numeric_dense_system():
     r = ob.liba_solve(wf)
     assert 0 < r.iterations <= 10 and r.chi2_final < 0.05 * r.chi2_initial
     assert np.abs(r.pose_twb - wf.gt["twb"][:wf.n_opt]).max() < 0.01
+
+
+@pytest.mark.parametrize("name", ["liba_tiny", "liba_tiny_rig"])
+def test_oracle_matches_the_numpy_lm_golden_outputs(name):
+    """tests/golden/liba_tiny*.npz: the whole optimize() of LocalInertialBA by the independent numpy Levenberg-Marquardt (full dense
+    system, central-difference Jacobians).  Same iteration / trial trace, cost trace to 5e-6, states to 2e-7."""
+    from helpers import check_against_liba_fixture, load_liba_fixture
+    w, z = load_liba_fixture(name)
+    check_against_liba_fixture(ob.liba_solve(w), z, fisheye=w.kb8 is not None)
