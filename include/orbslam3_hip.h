@@ -361,6 +361,11 @@ typedef struct osh_liba_result {
 /* Solve one batch of inertial windows on the device (upload + optimize + download). */
 int osh_liba_solve(osh_lba_ctx* ctx, int32_t n_windows, const osh_liba_problem* problems, osh_liba_result* results);
 
+/* Diagnostics of the calling thread's last osh_liba_solve: the number of thread blocks that worked on each window (8 for the
+ * tracker's single window, 1 for a large batch) and, for window 0, shader-clock cycles per phase of the optimisation
+ * (linearise, assembly, Dinv, Schur, LDL^T, back-substitution, errors, outputs). */
+int osh_liba_get_profile(int32_t* group, int64_t cycles[8]);
+
 /* --------------------------------------------------------- ORB matching API */
 /*
  * Nearest / second-nearest 256-bit Hamming search (the candidate loops of

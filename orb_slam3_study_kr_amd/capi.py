@@ -238,6 +238,7 @@ _SIGNATURES = {
     "osh_orb_download": (C.c_int, [C.c_void_p] + [c_int32_p] * 6),
     "osh_orb_get_profile": (C.c_int, [C.c_void_p, c_int64_p, c_double_p]),
     "osh_orb_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "osh_liba_get_profile": (C.c_int, [C.POINTER(C.c_int32), c_int64_p]),
     "osh_orb_get_resolve_profile": (C.c_int, [C.c_void_p, c_int64_p, c_double_p]),
     "osh_orb_distance_matrix": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_uint8_p, c_uint8_p, c_int32_p]),
 }

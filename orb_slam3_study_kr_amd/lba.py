@@ -99,6 +99,14 @@ class LbaSolver:
         capi.check(self.lib.osh_liba_solve(self.ctx, n, probs, arr), "osh_liba_solve", self.lib)
         return [o.read_scalars(arr[i]) for i, o in enumerate(outs)]
 
+    def inertial_profile(self):
+        """(blocks per window, shader-clock cycles per phase of window 0) of the last solve_inertial on this thread."""
+        grp = C.c_int32(0)
+        cyc = np.zeros(8, dtype=np.int64)
+        capi.check(self.lib.osh_liba_get_profile(C.byref(grp), capi.ptr(cyc, capi.c_int64_p)), "osh_liba_get_profile", self.lib)
+        names = ("linearise", "assembly", "dinv", "schur", "ldlt", "backsub", "errors", "outputs")
+        return int(grp.value), dict(zip(names, (int(c) for c in cyc)))
+
     # -- parity / debug aids ------------------------------------------------------------------
     def linearize(self, window: int = 0) -> dict:
         w = self._windows[window]
