@@ -640,6 +640,28 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
+// Sum over the wavefront without the LDS crossbar: four DPP steps leave every lane with the sum of its row of 16, the four row
+// sums are then read as scalars and added in row order.  (wave_sum's xor butterfly is 12 ds_bpermute per value.)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);   // row_half_mirror
+  v += dpp_f64<0x140>(v);   // row_mirror
+  double r[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 16 * k);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 16 * k);
+    r[k] = __hiloint2double(hi, lo);
+  }
+  return ((r[0] + r[1]) + r[2]) + r[3];
+}
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));

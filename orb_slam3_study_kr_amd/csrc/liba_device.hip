@@ -1,14 +1,19 @@
 // liba_device.hip -- Optimizer::LocalInertialBA's optimisation (src/Optimizer.cc:2843-2848) on MI355X.
 //
-// An inertial window is small (N <= 10/25 keyframes x 15 dof, O(10^3) landmarks, O(10^4) edges) and the
-// reference runs exactly one at a time, so the whole Levenberg-Marquardt loop of a window is ONE persistent
-// thread block: no host round trip, every reduction in a fixed order (bitwise reproducible), many windows =
-// many blocks.  Phases inside the block (all separated by __syncthreads):
-//   errors      computeActiveErrors + activeRobustChi2      thread per landmark over its edges + thread per link
-//   linearise   buildSystem: visual blocks (Hll, b_l, Hpl per landmark; Hpp, b_p by one wavefront per pose),
-//               EdgeInertial / EdgeGyroRW / EdgeAccRW blocks (BaseMultiEdge::constructQuadraticForm) link by link
-//   trial       setLambda, Dinv, Schur rows (wavefront per pose row, register accumulators), blocked LDL^T
-//               (ldlt_block.h), landmark back-substitution, ImuCamPose::Update, trial errors, gain ratio
+// An inertial window is small (N <= 10/25 keyframes x 15 dof, O(10^3) landmarks, O(10^4) edges) and the reference runs exactly
+// one at a time, so the whole Levenberg-Marquardt loop of a window runs inside ONE launch with no host round trip: a GROUP of
+// up to 16 thread blocks on one XCD works on the window (the tracker's single window: 16 blocks; a large batch: one block per
+// window fills the chip).  The phases are separated by a barrier of the group (arrival counter in global memory); every sum is
+// taken in a fixed order (lanes, wavefronts, blocks), so a run is bitwise reproducible and every block takes the same controller
+// decisions from the same numbers.  Phases (each a function of its own, see the note above liba_landmark_pass):
+//   errors      computeActiveErrors + activeRobustChi2: an edge per thread and round, the links on the blocks' last wavefronts
+//   linearise   buildSystem: an edge per thread, walked pose by pose: its Hpl block and its terms of Hll, b_l (a row of `eh`) and
+//               of Hpp, b_p (a column of `ep`); EdgeInertial Jacobians one lane per link, J^T W J by the link's block
+//   sums        per landmark (a team of 1/2/4 lanes): Hll, b_l, Dinv = (Hll + lambda I)^-1, B Dinv; per pose: Hpp, b_p in chunks;
+//               the links' blocks into H, links of one colour (no shared keyframe) at a time
+//   Schur       S = H + lambda I - sum_l (B Dinv)_i B_i2^T, one wavefront per pose pair; rhs
+//   solve       blocked LDL^T (ldlt_block.h) by block 0
+//   update      landmark back-substitution (teams), ImuCamPose::Update, computeScale; then the trial's errors and the gain ratio
 // Vertex order of the reduced system = g2o's: the 6-dof poses of the N temporal keyframes, then (v, bg, ba).
 #include "common.h"
 #include "lba_math.h"
@@ -22,23 +27,18 @@
 
 namespace osh {
 
-constexpr int kLT = 256;      // threads of the persistent block
+constexpr int kLT = 256;      // threads of a block: one wavefront per SIMD, so a phase may use all 512 registers (with 512 threads the
+                              // per-edge code spilled: 1.2 KB of scratch per lane)
 constexpr int kLNB = 24;      // LDL^T panel width
 constexpr int kLG = 16;       // blocks per window at most (one XCD's worth of a group)
 constexpr int kPoseChunks = 8;   // a pose row's edges are summed in at most this many chunks
 constexpr int kLinkQ = 832;   // per link: J^T W J (24x24), -J^T W r (24), then J (9x24), -W r (9), rho'
-constexpr int kStageEdges = 32;                                   // edges of a pose row staged in LDS per pass of the Schur loop
-constexpr int kStageMaxN = 32;                                    // partner-edge list entries per staged edge (N <= 25 optimisable keyframes)
-constexpr size_t kStageDoublesPerWave = kStageEdges * 18 + (kStageEdges * kStageMaxN + 1) / 2;
-__host__ __device__ constexpr size_t liba_scratch_doubles(int W) {
-  return ldlt_lds_doubles(kLNB, W, kLT) > (kLT / 64) * kStageDoublesPerWave ? ldlt_lds_doubles(kLNB, W, kLT) : (kLT / 64) * kStageDoublesPerWave;
-}
+__host__ __device__ constexpr size_t liba_scratch_doubles(int W) { return ldlt_lds_doubles(kLNB, W, kLT) > 512 ? ldlt_lds_doubles(kLNB, W, kLT) : 512; }
 struct LibaOut {
   double chi2_initial, chi2_final;
   int iterations, trials, n_trace, sel;
   double chi2_trace[OSH_LBA_MAX_TRACE], lambda_trace[OSH_LBA_MAX_TRACE];
   int trials_trace[OSH_LBA_MAX_TRACE];
-  long long prof2[8];
   long long prof[8];   // shader-clock cycles of block 0 per phase: linearise, assembly, Dinv, Schur, LDL^T, back-substitution, errors, outputs
 };
 
@@ -50,24 +50,29 @@ struct LibaView {
   double* pts[2];             // [L*3]
   const int* e_pose; const int* e_point; const unsigned char* e_kind; const double* e_obs; const double* e_info; const int* e_orig;
   const int* lm_off;          // L+1 per window (sorted edges)
-  const int* pel_off; const int* pel_edge;   // per optimisable pose: its edges in landmark order
+  const int* pel_off; const int* pel_edge;   // pel_off [N+1]: the optimisable poses' ranges in pel_edge [E]: their edges pose by pose (landmark order inside), then the fixed keyframes' edges
   const int* lm_pose_edge;    // [L*N] sorted edge index of (landmark, optimisable pose) or -1
   const int* link_prev; const int* link_cur; const float* link_preint; const double* link_info; const double* link_info_g;
   const double* link_info_a; const unsigned char* link_robust;
   double* Hpl; double* Hll; double* bl; double* dinv;   // [E*18] [L*6] [L*3] [L*9]
   double* BD;                 // [E*18] B Dinv of every optimisable-pose edge (Schur step)
+  double* eh; double* ep;     // [9][E_total], [27][EF_total] per-edge terms of the landmark rows / pose rows (linearisation)
+  size_t E_total, EF_total;
+  const int* link_colour;     // [NL] links of one colour share no keyframe
+  double* bfull;              // [n] b with the pose rows' visual part
   double* H; double* b; double* S; double* bs; double* x;   // [n*n] [n] [n*n] [n] [n]
   double* linkQ;              // [NL*kLinkQ]
   double* ppart;              // [sum N][kPoseChunks][27] pose-row chunk sums: Hpp upper (21), b_p (6)
   unsigned* bar; int* abort_flag; double* red; double* ctrl;   // group barrier counters [nw], abort word, published sums [nw*4*kLG*2], [nw*4]
   int nw;
+  int force_heavy;            // diagnostic: keep the agent-scope fences even when a group shares an XCD (OSH_LIBA_HEAVY_BARRIER=1)
   double* out_chi2; unsigned char* out_depth;   // result arena: per edge, caller's order
   int* res_abort; double* res_pose; double* res_vba; double* res_pts;   // result arena: abort word, final [sum N][24], [sum N][9], [sum L][3]
 };
 
 // deterministic block reductions over kLT threads
 __device__ __forceinline__ double blk_sum(double v, double* shw) {
-  v = dev::wave_sum(v);
+  v = dev::wave_sum_dpp(v);
   if ((threadIdx.x & 63) == 0) shw[threadIdx.x >> 6] = v;
   __syncthreads();
   double t = 0.0;
@@ -108,16 +113,21 @@ struct Grp {
   int* res_abort;       // the copy of it that travels back with the results
   double* red;          // [4][kLG][2] published partial sums
   int G, m;             // blocks in the group, this block's rank
+  int light;            // 1: every block of the group runs on the same XCD (checked at start), so they share one L2: a barrier then only
+                        // has to drain this block's stores to L2 and drop this CU's L1, not write back and invalidate the L2
   unsigned gen, nred;
 };
 constexpr unsigned kSpinLimit = 1u << 22;   // polls (about a microsecond each) before a barrier gives up
 
 __device__ __forceinline__ bool grp_sync(Grp& g, int* lds_flag) {
+  // every wavefront drains its own stores to L2 first (the counter is per wavefront): the arrival below must not overtake them
+  if (g.G > 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
   if (g.G == 1) return true;
   ++g.gen;
   if (threadIdx.x == 0) {
-    __threadfence();
+    if (g.light) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else __threadfence();
     atomicAdd(g.bar, 1u);
     const unsigned target = g.gen * (unsigned)g.G;
     int good = 1;
@@ -127,7 +137,8 @@ __device__ __forceinline__ bool grp_sync(Grp& g, int* lds_flag) {
       if ((++spins & 255u) == 0 && (spins > kSpinLimit || __hip_atomic_load(g.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { good = 0; break; }
     }
     if (!good) { __hip_atomic_store(g.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *g.res_abort = 1; }
-    __threadfence();
+    if (g.light) asm volatile("buffer_inv sc1" ::: "memory");
+    else __threadfence();
     *lds_flag = good;
   }
   __syncthreads();
@@ -148,9 +159,36 @@ __device__ __forceinline__ bool grp_sum2(Grp& g, double& a, double& b, double* s
   return true;
 }
 
+// Inputs of NE visual edges (clamped to the last edge when past the end) read with every load in flight at once: first the
+// indices, then the camera rows of the poses, the landmarks, the observations.  (Left to itself the scheduler of this large
+// kernel waits for each load before it issues the next one.)
+template <int NE>
+struct EdgeIn { int kind[NE], ip[NE], j[NE]; double pose[NE][12], X[NE][3], obs[NE][3], info[NE]; };
+template <int NE>
+__device__ __forceinline__ void load_edges(const LibaView& v, const LibaDesc& d, const int* e, const double* poses, const double* pts, EdgeIn<NE>& o) {
+  size_t ge[NE];
+#pragma unroll
+  for (int u = 0; u < NE; ++u) {
+    ge[u] = (size_t)d.edge_off + min(e[u], d.E - 1);
+    o.kind[u] = v.e_kind[ge[u]]; o.ip[u] = v.e_pose[ge[u]]; o.j[u] = v.e_point[ge[u]];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < NE; ++u) {
+    const double* P = poses + 24 * (size_t)o.ip[u];
+    const double* X = pts + 3 * (size_t)o.j[u];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) o.pose[u][k] = P[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { o.X[u][k] = X[k]; o.obs[u][k] = v.e_obs[ge[u] * 3 + k]; }
+    o.info[u] = v.e_info[ge[u]];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // this thread's share of the robust chi2 of the state in buffer `sel` (computeActiveErrors + activeRobustChi2): one edge per
 // thread and round, the inertial links on the last wavefront of the blocks
-__device__ double eval_partial(const LibaView& v, const LibaDesc& d, int sel, const Grp& g) {
+__device__ __noinline__ double eval_partial(const LibaView& v, const LibaDesc& d, int sel, const Grp& g) {
   const int tid = threadIdx.x;
   const double* poses = v.pose[sel] + (size_t)d.pose_off * 24;
   const double* vba = v.vba[sel] + (size_t)d.vel_off * 9;
@@ -176,14 +214,19 @@ __device__ double eval_partial(const LibaView& v, const LibaDesc& d, int sel, co
     }
   }
   const int GT = g.G * kLT;
-  for (int e = g.m * kLT + tid; e < d.E; e += GT) {
-    const size_t ge = (size_t)d.edge_off + e;
-    const int kind = v.e_kind[ge];
-    VisEval ev;
-    vis_residual(d, kind, poses + 24 * (size_t)v.e_pose[ge], pts + 3 * (size_t)v.e_point[ge], v.e_obs + ge * 3, v.e_info[ge], ev);
-    double r0, r1;
-    dev::huber(ev.chi2, kind == OSH_EDGE_STEREO ? d.huber_stereo : d.huber_mono, r0, r1);
-    acc += r0;
+  for (int e0 = g.m * kLT + tid; e0 < d.E; e0 += 2 * GT) {   // two edges per thread and step
+    const int e[2] = {e0, e0 + GT};
+    EdgeIn<2> in;
+    load_edges<2>(v, d, e, poses, pts, in);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (e[u] >= d.E) continue;
+      VisEval ev;
+      vis_residual(d, in.kind[u], in.pose[u], in.X[u], in.obs[u], in.info[u], ev);
+      double r0, r1;
+      dev::huber(ev.chi2, in.kind[u] == OSH_EDGE_STEREO ? d.huber_stereo : d.huber_mono, r0, r1);
+      acc += r0;
+    }
   }
   return acc;
 }
@@ -191,67 +234,239 @@ __device__ double eval_partial(const LibaView& v, const LibaDesc& d, int sel, co
 #define OSH_GSYNC() do { if (!grp_sync(g, lds_flag)) return; } while (0)
 #define OSH_PROF(i) do { if (prof_on) { const long long _n = clock64(); prof[i] += _n - prof_last; prof_last = _n; } } while (0)
 
-__global__ __launch_bounds__(kLT) void k_liba(LibaView v, int W, int G) {
-  extern __shared__ __attribute__((aligned(16))) double sh[];
-  // consecutive workgroups go to the 8 XCDs in turn: the G blocks of a window are 8 apart, so they share one XCD and its L2
-  const int bid = blockIdx.x;
-  const int win = (bid / (8 * G)) * 8 + (bid & 7);
-  if (win >= v.nw) return;
-  const LibaDesc& d = v.desc[win];
-  LibaOut& out = v.out[win];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  Grp g;
-  g.bar = v.bar + win; g.abort_flag = v.abort_flag; g.res_abort = v.res_abort; g.red = v.red + (size_t)win * 4 * kLG * 2; g.G = G; g.m = (bid >> 3) % G; g.gen = 0; g.nred = 0;
-  const int m = g.m, GT = G * kLT, gt = m * kLT + tid, GW = G * (kLT / 64);
-  const int N = d.N, n = d.n, L = d.L;
-  // LDS carve: [0, ldlt) the LDL^T scratch (reused as general scratch between solves), then control words
-  double* shw = sh + liba_scratch_doubles(W);             // [kLT/64] reductions
-  int* lds_flag = reinterpret_cast<int*>(shw + kLT / 64 + 1);
-  double* H = v.H + d.H_off; double* S = v.S + d.H_off;
-  double* b = v.b + d.b_off; double* bs = v.bs + d.b_off; double* xg = v.x + d.b_off;
-  double* Hpl = v.Hpl + (size_t)d.edge_off * 18;
-  double* BD = v.BD + (size_t)d.edge_off * 18;
-  double* Hll = v.Hll + (size_t)d.pt_off * 6; double* bl = v.bl + (size_t)d.pt_off * 3; double* dinv = v.dinv + (size_t)d.pt_off * 9;
-  const int* lmo = v.lm_off + d.lmoff_off;
-  const int* po = v.pel_off + d.peloff_off;
-  const int* lmpe = v.lm_pose_edge + d.lmpose_off;
-  double* linkQ = v.linkQ + (size_t)d.link_off * kLinkQ;
-  double* ppart = v.ppart + (size_t)(d.b_off / 15) * kPoseChunks * 27;
-  double* ctrl = v.ctrl + (size_t)win * 4;
-  const bool prof_on = (m == 0 && tid == 0);
-  long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  long long prof_last = clock64();
-  // pose rows are summed in chunks so that a window's few keyframes still spread over the group's wavefronts
-  int C = (GW - GW / 4) / (N > 0 ? N : 1);
-  C = C < 1 ? 1 : (C > kPoseChunks ? kPoseChunks : C);
+// linearisation of one visual edge: robust weight, weighted residual, JX (3x3), Jp (3x6)
+struct EdgeLin { double ww, wr[3], JX[9], Jp[18]; };
+__device__ __forceinline__ void lin_edge(const LibaDesc& d, int kind, const double* pose, const double* X, const double* obs, double info, EdgeLin& o) {
+  VisEval ev;
+  vis_residual(d, kind, pose, X, obs, info, ev);
+  double r0, r1;
+  dev::huber(ev.chi2, kind == OSH_EDGE_STEREO ? d.huber_stereo : d.huber_mono, r0, r1);
+  vis_jacobians(d, kind, pose, ev.Xc, o.JX, o.Jp);
+  o.ww = r1 * info;
+  o.wr[0] = -(info * ev.r[0]) * r1; o.wr[1] = -(info * ev.r[1]) * r1; o.wr[2] = -(info * ev.r[2]) * r1;
+}
 
-  if (m == 0 && tid < 8) out.prof2[tid] = 0;
-  if (bid == 0 && tid == 0) *v.res_abort = 0;
-  // the trial buffers start as copies of the estimates (the fixed keyframes and the fixed IMU state are only ever read)
-  for (int k = gt; k < d.K * 24; k += GT) v.pose[1][(size_t)d.pose_off * 24 + k] = v.pose[0][(size_t)d.pose_off * 24 + k];
-  for (int k = gt; k < d.NV * 9; k += GT) v.vba[1][(size_t)d.vel_off * 9 + k] = v.vba[0][(size_t)d.vel_off * 9 + k];
-  int sel = 0, eval_sel = 0;
-  double lambda = -1.0, ni = 2.0;
-  int nBad = 0, cj = 0, trials_total = 0, n_trace = 0;
-  bool ok = true;
-  double chi_init = eval_partial(v, d, 0, g), zero = 0.0;
-  if (!grp_sum2(g, chi_init, zero, shw, lds_flag)) return;
-  if (m == 0 && tid == 0) out.chi2_initial = chi_init;
-  double last_chi = chi_init;      // activeRobustChi2() of the errors evaluated last (err_end)
-  double currentChi = chi_init;    // of buffer `sel`: the accepted trial's value (the same sum over the same buffer the reference recomputes)
-  OSH_PROF(6);
+// sum over the T = 1, 2 or 4 neighbouring lanes of a landmark's team
+__device__ __forceinline__ double team_sum(double v, int T) {
+  if (T >= 2) v += __shfl_xor(v, 1, 64);
+  if (T >= 4) v += __shfl_xor(v, 2, 64);
+  return v;
+}
 
-  for (int it = 0; it < d.max_iter && ok; ++it) {
-    const double* poses = v.pose[sel] + (size_t)d.pose_off * 24;
-    const double* vba = v.vba[sel] + (size_t)d.vel_off * 9;
-    const double* pts = v.pts[sel] + (size_t)d.pt_off * 3;
-    const double iniChi = currentChi;
-    // ---------------------------------------------------------------- linearise (buildSystem)
+struct LibaCtx { const LibaView* v; const LibaDesc* d; double* sh; double* shw; int G, m, C, win, W; };
+// eh [E][9]: per-edge terms of Hll (6) and b_l (3), a row per edge (writer and reader both take whole rows);
+// ep [27][EF_total]: per-edge terms of Hpp (21, upper) and b_p (6), a column per edge at its place in its pose's list (written by
+// consecutive lanes: the linearisation walks the optimisable edges in that order; read the same way)
+#define OSH_LIBA_LOCALS \
+  [[maybe_unused]] const LibaView& v = *c.v; [[maybe_unused]] const LibaDesc& d = *c.d; \
+  [[maybe_unused]] const int G = c.G, m = c.m, tid = threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6; \
+  [[maybe_unused]] const int GT = G * kLT, gt = m * kLT + tid, GW = G * (kLT / 64); \
+  [[maybe_unused]] const int N = d.N, n = d.n, L = d.L, E = d.E, n6 = 6 * d.N, C = c.C; \
+  [[maybe_unused]] double* const sh = c.sh; [[maybe_unused]] double* const shw = c.shw; \
+  [[maybe_unused]] double* const H = v.H + d.H_off; [[maybe_unused]] double* const S = v.S + d.H_off; \
+  [[maybe_unused]] double* const b = v.b + d.b_off; [[maybe_unused]] double* const bs = v.bs + d.b_off; \
+  [[maybe_unused]] double* const xg = v.x + d.b_off; [[maybe_unused]] double* const bfull = v.bfull + d.b_off; \
+  [[maybe_unused]] double* const Hpl = v.Hpl + (size_t)d.edge_off * 18; [[maybe_unused]] double* const BD = v.BD + (size_t)d.edge_off * 18; \
+  [[maybe_unused]] double* const Hll = v.Hll + (size_t)d.pt_off * 6; [[maybe_unused]] double* const bl = v.bl + (size_t)d.pt_off * 3; \
+  [[maybe_unused]] double* const dinv = v.dinv + (size_t)d.pt_off * 9; \
+  [[maybe_unused]] double* const eh = v.eh + (size_t)d.edge_off * 9; [[maybe_unused]] double* const ep = v.ep + d.pel_off; \
+  [[maybe_unused]] const size_t ES = v.E_total, PS = v.EF_total; \
+  [[maybe_unused]] const int* const lmo = v.lm_off + d.lmoff_off; [[maybe_unused]] const int* const po = v.pel_off + d.peloff_off; \
+  [[maybe_unused]] const int* const lmpe = v.lm_pose_edge + d.lmpose_off; \
+  [[maybe_unused]] double* const linkQ = v.linkQ + (size_t)d.link_off * kLinkQ; \
+  [[maybe_unused]] double* const ppart = v.ppart + (size_t)(d.b_off / 15) * kPoseChunks * 27; \
+  [[maybe_unused]] double* const ctrl = v.ctrl + (size_t)c.win * 4; \
+  (void)0;
+__device__ __forceinline__ int up21(int r, int c) { const int lo = r < c ? r : c, hi = r < c ? c : r; return lo * 6 - lo * (lo - 1) / 2 + (hi - lo); }
+
+// Each phase is a function of its own (not inlined): the register allocation and the instruction scheduling of a phase are then its
+// own business.  Inlined into one kernel body, the pressure of the widest phase put the scheduler into its register-saving mode
+// everywhere, which waits for every load before it issues the next one.
+
+// ---- landmark pass: each landmark is worked on by a team of T neighbouring lanes of the blocks [first, first + nblk).
+// from_edges: Hll, b_l = sums of the per-edge terms (else read back); with_dinv: Dinv = (Hll + lambda I)^-1, Dinv b_l and
+// B Dinv of the landmark's optimisable-pose edges (setLambda on Hll + the first product of block_solver.hpp:381-432)
+__device__ __noinline__ void liba_landmark_pass(const LibaCtx& c, bool from_edges, bool with_dinv, double lambda, int first, int nblk) {
+  OSH_LIBA_LOCALS
+    if (m < first || m >= first + nblk) return;
+    const int lanes = nblk * kLT;
+    const int T = (4 * L <= lanes) ? 4 : ((2 * L <= lanes) ? 2 : 1);
+    const int q = tid & (T - 1);
+    for (int j = ((m - first) * kLT + tid) / T; j < L; j += lanes / T) {
+      double h[9];
+      if (from_edges) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) h[k] = 0.0;
+        const int e_end = lmo[j + 1];
+        for (int e = lmo[j] + q; e < e_end; e += 4 * T) {   // four edges in flight: the loads of one are a full L2 round trip
+          double t[4][9];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int eu = min(e + u * T, e_end - 1);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) t[u][k] = eh[(size_t)eu * 9 + k];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const bool in = e + u * T < e_end;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) h[k] += in ? t[u][k] : 0.0;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) h[k] = team_sum(h[k], T);
+        if (q == 0) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) Hll[(size_t)j * 6 + k] = h[k];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) bl[(size_t)j * 3 + k] = h[6 + k];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) h[k] = Hll[(size_t)j * 6 + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) h[6 + k] = bl[(size_t)j * 3 + k];
+      }
+      if (!with_dinv) continue;
+      double Di[9];
+      dev::inv3_sym(h[0] + lambda, h[1], h[2], h[3] + lambda, h[4], h[5] + lambda, Di);
+      if (q == 0) {
+        double* o = dinv + (size_t)j * 9;
+        o[0] = Di[0]; o[1] = Di[1]; o[2] = Di[2]; o[3] = Di[4]; o[4] = Di[5]; o[5] = Di[8];
+        o[6] = Di[0] * h[6] + Di[1] * h[7] + Di[2] * h[8]; o[7] = Di[3] * h[6] + Di[4] * h[7] + Di[5] * h[8]; o[8] = Di[6] * h[6] + Di[7] * h[7] + Di[8] * h[8];
+      }
+      for (int i0 = q; i0 < N; i0 += 2 * T) {   // two blocks in flight
+        int eu[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) eu[u] = (i0 + u * T < N) ? lmpe[(size_t)j * N + i0 + u * T] : -1;
+        __builtin_amdgcn_sched_barrier(0);
+        double Bu[2][18];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const double* Be = Hpl + (size_t)(eu[u] < 0 ? 0 : eu[u]) * 18;
+#pragma unroll
+          for (int k = 0; k < 18; ++k) Bu[u][k] = Be[k];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (eu[u] < 0) continue;
+          double* od = BD + (size_t)eu[u] * 18;
+#pragma unroll
+          for (int r = 0; r < 6; ++r) {
+            const double x0 = Bu[u][r * 3], x1 = Bu[u][r * 3 + 1], x2 = Bu[u][r * 3 + 2];
+            od[r * 3 + 0] = x0 * Di[0] + x1 * Di[1] + x2 * Di[2];
+            od[r * 3 + 1] = x0 * Di[1] + x1 * Di[4] + x2 * Di[5];
+            od[r * 3 + 2] = x0 * Di[2] + x1 * Di[5] + x2 * Di[8];
+          }
+        }
+      }
+    }
+}
+
+// ---- pose rows: Hpp (upper) and b_p of pose i = sum of its edges' terms, one wavefront per (pose, chunk) on blocks [first, first + nblk)
+__device__ __noinline__ void liba_pose_pass(const LibaCtx& c, int first, int nblk) {
+  OSH_LIBA_LOCALS
+    if (m < first || m >= first + nblk) return;
+    for (int item = (kLT / 64 - 1 - wave) * nblk + (m - first); item < N * C; item += nblk * (kLT / 64)) {
+      const int i = item / C, ch = item - i * C;
+      const int cnt = po[i + 1] - po[i];
+      const int per = ((cnt + C - 1) / C + 63) / 64 * 64;
+      const int lo = po[i] + ch * per, hi = min(po[i + 1], lo + per);
+      double a[27];
+#pragma unroll
+      for (int k = 0; k < 27; ++k) a[k] = 0.0;
+      for (int idx = lo + lane; idx < hi; idx += 64) {
+        // all 27 loads are issued before the first add (left alone, the scheduler waits for each load in turn)
+        double t[27];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) t[k] = ep[k * PS + idx];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 27; ++k) a[k] += t[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 27; ++k) a[k] = dev::wave_sum_dpp(a[k]);
+      if (lane == 0) {
+        double* o = ppart + ((size_t)i * kPoseChunks + ch) * 27;
+#pragma unroll
+        for (int k = 0; k < 27; ++k) o[k] = a[k];
+      }
+    }
+}
+
+// ---- the inertial links into H and b (which the linearisation zeroed): links of one colour share no keyframe and are added
+// together by the whole group, one colour per phase; EdgeGyroRW / EdgeAccRW (r = b2 - b1, J = [-I, I], plain information) ride along
+__device__ __noinline__ void liba_assemble_links(const LibaCtx& c, int sel, int col) {
+  OSH_LIBA_LOCALS
+  const double* vba = v.vba[sel] + (size_t)d.vel_off * 9;
+    auto vert_of = [](int col) { return col < 6 ? 0 : col < 9 ? 1 : col < 12 ? 2 : col < 15 ? 3 : col < 21 ? 4 : 5; };
+    const int vbase[6] = {0, 6, 9, 12, 15, 21};
+    {
+      for (int idx = gt; idx < d.NL * 648; idx += GT) {
+        const int l = idx / 648, sl = idx - l * 648;
+        const int gl = d.link_off + l;
+        if (v.link_colour[gl] != col) continue;
+        const int a = v.link_prev[gl], c = v.link_cur[gl];
+        const double* Q = linkQ + (size_t)l * kLinkQ;
+        if (sl < 576) {
+          const int ca = sl / 24, cb = sl - ca * 24;
+          const int va = vert_of(ca), vb = vert_of(cb);
+          if (vb < va) continue;   // upper blocks + mirrored below
+          const int oa = link_vertex_offset(va, a, c, N), ob = link_vertex_offset(vb, a, c, N);
+          if (oa < 0 || ob < 0) continue;
+          double val = Q[sl];
+          if (va == vb && (va == 2 || va == 3)) val += (va == 2 ? v.link_info_g : v.link_info_a)[(size_t)gl * 9 + (ca - vbase[va]) * 3 + (cb - vbase[vb])];
+          const int ra = oa + (ca - vbase[va]), rb = ob + (cb - vbase[vb]);
+          H[(size_t)ra * n + rb] += val;
+          if (va != vb) H[(size_t)rb * n + ra] += val;
+        } else if (sl < 600) {
+          const int ca = sl - 576;
+          const int va = vert_of(ca);
+          const int oa = link_vertex_offset(va, a, c, N);
+          if (oa < 0) continue;
+          double val = Q[sl];
+          if (va == 2 || va == 3) {
+            const int which = va - 2, i = ca - vbase[va];
+            const double* Og = (which == 0 ? v.link_info_g : v.link_info_a) + (size_t)gl * 9;
+            double rb[3];
+            for (int k = 0; k < 3; ++k) rb[k] = vba[9 * c + 3 + 3 * which + k] - vba[9 * a + 3 + 3 * which + k];
+            val += Og[i * 3] * rb[0] + Og[i * 3 + 1] * rb[1] + Og[i * 3 + 2] * rb[2];
+          }
+          b[oa + (ca - vbase[va])] += val;
+        } else if (sl < 642) {
+          const int t = sl - 600, which = t / 21, u = t - which * 21;
+          const double* Og = (which == 0 ? v.link_info_g : v.link_info_a) + (size_t)gl * 9;
+          const int o1 = (a < N) ? n6 + 9 * a + 3 + 3 * which : -1;
+          const int o2 = n6 + 9 * c + 3 + 3 * which;
+          if (u < 9) {
+            const int i = u / 3, j = u - i * 3;
+            if (o1 >= 0) { H[(size_t)(o1 + i) * n + o2 + j] += -Og[u]; H[(size_t)(o2 + j) * n + o1 + i] += -Og[u]; }
+          } else if (u < 18) {
+            const int i = (u - 9) / 3, j = (u - 9) - i * 3;
+            H[(size_t)(o2 + i) * n + o2 + j] += Og[u - 9];
+          } else {
+            const int i = u - 18;
+            double rb[3];
+            for (int k = 0; k < 3; ++k) rb[k] = vba[9 * c + 3 + 3 * which + k] - vba[9 * a + 3 + 3 * which + k];
+            b[o2 + i] += -(Og[i * 3] * rb[0] + Og[i * 3 + 1] * rb[1] + Og[i * 3 + 2] * rb[2]);
+          }
+        }
+      }
+    }
+}
+
+// ---- linearise (buildSystem): zero H and b, Jacobians and quadratic forms of the inertial links, per-edge terms of the visual edges
+__device__ __noinline__ void liba_linearise(const LibaCtx& c, int sel) {
+  OSH_LIBA_LOCALS
+  const double* poses = v.pose[sel] + (size_t)d.pose_off * 24;
+  const double* vba = v.vba[sel] + (size_t)d.vel_off * 9;
+  const double* pts = v.pts[sel] + (size_t)d.pt_off * 3;
     for (int k = gt; k < n * n; k += GT) H[k] = 0.0;
     for (int k = gt; k < n; k += GT) b[k] = 0.0;
-    // inertial links, Jacobians: link l belongs to block l mod G, one lane of that block's wavefront 3 each
-    const long long tl0 = clock64();
-    if (wave == 3 % (kLT / 64)) {
+    // inertial links, Jacobians: link l belongs to block l mod G, one lane of that block's last wavefront each
+    if (wave == kLT / 64 - 1) {
       for (int l = lane * G + m; l < d.NL; l += 64 * G) {
         const int gl = d.link_off + l;
         const int a = v.link_prev[gl], c = v.link_cur[gl];
@@ -273,99 +488,70 @@ __global__ __launch_bounds__(kLT) void k_liba(LibaView v, int W, int G) {
         for (int i = 0; i < 9; ++i) { double t = 0; for (int j = 0; j < 9; ++j) t += Om[i * 9 + j] * r[j]; wr[i] = -t * rho1; }
       }
     }
-    if (m == 0 && tid == kLT - 64) out.prof2[0] += clock64() - tl0;
-    const long long tl1 = clock64();
-    // landmark side: thread per landmark (landmark j on block j mod G), its edges in order
-    for (int j = tid * G + m; j < L; j += GT) {
-      const double* X = pts + 3 * (size_t)j;
-      double hl[6] = {0, 0, 0, 0, 0, 0}, bj[3] = {0, 0, 0};
-      for (int e = lmo[j]; e < lmo[j + 1]; ++e) {
-        const size_t ge = (size_t)d.edge_off + e;
-        const int kind = v.e_kind[ge], ip = v.e_pose[ge];
-        const double info = v.e_info[ge];
-        VisEval ev;
-        vis_residual(d, kind, poses + 24 * (size_t)ip, X, v.e_obs + ge * 3, info, ev);
-        double r0, r1, JX[9], Jp[18];
-        dev::huber(ev.chi2, kind == OSH_EDGE_STEREO ? d.huber_stereo : d.huber_mono, r0, r1);
-        vis_jacobians(d, kind, poses + 24 * (size_t)ip, ev.Xc, JX, Jp);
-        const double ww = r1 * info;
-        const double wr[3] = {-(info * ev.r[0]) * r1, -(info * ev.r[1]) * r1, -(info * ev.r[2]) * r1};
-        hl[0] += (JX[0] * ww) * JX[0] + (JX[3] * ww) * JX[3] + (JX[6] * ww) * JX[6];
-        hl[1] += (JX[0] * ww) * JX[1] + (JX[3] * ww) * JX[4] + (JX[6] * ww) * JX[7];
-        hl[2] += (JX[0] * ww) * JX[2] + (JX[3] * ww) * JX[5] + (JX[6] * ww) * JX[8];
-        hl[3] += (JX[1] * ww) * JX[1] + (JX[4] * ww) * JX[4] + (JX[7] * ww) * JX[7];
-        hl[4] += (JX[1] * ww) * JX[2] + (JX[4] * ww) * JX[5] + (JX[7] * ww) * JX[8];
-        hl[5] += (JX[2] * ww) * JX[2] + (JX[5] * ww) * JX[5] + (JX[8] * ww) * JX[8];
+    // visual edges, one per thread and round: the edge's terms of Hll, b_l (summed per landmark in the next phase), of Hpp, b_p
+    // (summed per pose there), and its Hpl block
+    // (in a group the wavefronts that hold a link's Jacobian take no edges: the Jacobian is as long as four edge rounds)
+    const int nlw = G > 1 ? min(G, d.NL) : 0;                                  // blocks 0 .. nlw-1: their last wavefront is a link wavefront
+    const int wpb = kLT / 64;
+    const int nfree = nlw * (wpb - 1) + (G - nlw) * wpb;
+    const bool link_wave = m < nlw && wave == wpb - 1;
+    const int frank = m < nlw ? m * (wpb - 1) + wave : nlw * (wpb - 1) + (m - nlw) * wpb + wave;
+    for (int idx = link_wave ? E : frank * 64 + lane; idx < E; idx += nfree * 64) {
+      // the optimisable keyframes' edges first, pose by pose (so the columns of ep are written by consecutive lanes), then the rest
+      const int e = v.pel_edge[(size_t)d.edge_off + idx];
+      const size_t ge = (size_t)d.edge_off + e;
+      EdgeIn<1> in;
+      load_edges<1>(v, d, &e, poses, pts, in);
+      const int kind = in.kind[0], ip = in.ip[0], j = in.j[0];
+      const double* X = in.X[0];
+      const double* pose = in.pose[0];
+      EdgeLin ln;
+      lin_edge(d, kind, pose, X, in.obs[0], in.info[0], ln);
+      const double* JX = ln.JX; const double* Jp = ln.Jp;
+      const double ww = ln.ww;
+      eh[(size_t)e * 9 + 0] = (JX[0] * ww) * JX[0] + (JX[3] * ww) * JX[3] + (JX[6] * ww) * JX[6];
+      eh[(size_t)e * 9 + 1] = (JX[0] * ww) * JX[1] + (JX[3] * ww) * JX[4] + (JX[6] * ww) * JX[7];
+      eh[(size_t)e * 9 + 2] = (JX[0] * ww) * JX[2] + (JX[3] * ww) * JX[5] + (JX[6] * ww) * JX[8];
+      eh[(size_t)e * 9 + 3] = (JX[1] * ww) * JX[1] + (JX[4] * ww) * JX[4] + (JX[7] * ww) * JX[7];
+      eh[(size_t)e * 9 + 4] = (JX[1] * ww) * JX[2] + (JX[4] * ww) * JX[5] + (JX[7] * ww) * JX[8];
+      eh[(size_t)e * 9 + 5] = (JX[2] * ww) * JX[2] + (JX[5] * ww) * JX[5] + (JX[8] * ww) * JX[8];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) bj[i] += JX[i] * wr[0] + JX[3 + i] * wr[1] + JX[6 + i] * wr[2];
-        if (ip < N) {
-          // the right-camera edge of a (keyframe, landmark) pair adds to the block of the left edge sorted just before it
-          const bool second = e > lmo[j] && v.e_pose[ge - 1] == ip;
-          double* Hb = Hpl + (size_t)(second ? e - 1 : e) * 18;
-#pragma unroll
-          for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int jj = 0; jj < 3; ++jj) {
-              const double hv = (Jp[i] * ww) * JX[jj] + (Jp[6 + i] * ww) * JX[3 + jj] + (Jp[12 + i] * ww) * JX[6 + jj];
-              Hb[i * 3 + jj] = second ? Hb[i * 3 + jj] + hv : hv;
-            }
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 6; ++k) Hll[(size_t)j * 6 + k] = hl[k];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) bl[(size_t)j * 3 + k] = bj[k];
-    }
-    if (m == 0 && tid == 0) out.prof2[1] += clock64() - tl1;
-    const long long tl2 = clock64();
-    // pose side: one wavefront per (optimisable pose, chunk of its edges), taken from the last wavefronts of the blocks
-    for (int item = (kLT / 64 - 1 - wave) * G + m; item < N * C; item += GW) {
-      const int i = item / C, ch = item - i * C;
-      const int cnt = po[i + 1] - po[i];
-      const int per = ((cnt + C - 1) / C + 63) / 64 * 64;
-      const int lo = po[i] + ch * per, hi = min(po[i + 1], lo + per);
-      double Hp[21], bp[6];
-#pragma unroll
-      for (int k = 0; k < 21; ++k) Hp[k] = 0.0;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) bp[k] = 0.0;
-      const double* pose = poses + 24 * (size_t)i;
-      for (int idx = lo + lane; idx < hi; idx += 64) {
-        const int e = v.pel_edge[(size_t)d.pel_off + idx];
-        const size_t ge = (size_t)d.edge_off + e;
-        const int kind = v.e_kind[ge];
-        const double info = v.e_info[ge];
-        VisEval ev;
-        vis_residual(d, kind, pose, pts + 3 * (size_t)v.e_point[ge], v.e_obs + ge * 3, info, ev);
-        double r0, r1, JX[9], Jp[18];
-        dev::huber(ev.chi2, kind == OSH_EDGE_STEREO ? d.huber_stereo : d.huber_mono, r0, r1);
-        vis_jacobians(d, kind, pose, ev.Xc, JX, Jp);
-        const double ww = r1 * info;
-        const double wr[3] = {-(info * ev.r[0]) * r1, -(info * ev.r[1]) * r1, -(info * ev.r[2]) * r1};
+      for (int i = 0; i < 3; ++i) eh[(size_t)e * 9 + 6 + i] = JX[i] * ln.wr[0] + JX[3 + i] * ln.wr[1] + JX[6 + i] * ln.wr[2];
+      if (ip < N) {
+        const int pp = idx;   // = the edge's place in its pose's list
         int q = 0;
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
 #pragma unroll
-          for (int c = a; c < 6; ++c) { Hp[q] += (Jp[a] * ww) * Jp[c] + (Jp[6 + a] * ww) * Jp[6 + c] + (Jp[12 + a] * ww) * Jp[12 + c]; ++q; }
-          bp[a] += Jp[a] * wr[0] + Jp[6 + a] * wr[1] + Jp[12 + a] * wr[2];
+          for (int c = a; c < 6; ++c) { ep[q * PS + pp] = (Jp[a] * ww) * Jp[c] + (Jp[6 + a] * ww) * Jp[6 + c] + (Jp[12 + a] * ww) * Jp[12 + c]; ++q; }
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) ep[(21 + a) * PS + pp] = Jp[a] * ln.wr[0] + Jp[6 + a] * ln.wr[1] + Jp[12 + a] * ln.wr[2];
+        // Hpl: the right-camera edge of a (keyframe, landmark) pair shares the block of the left edge sorted just before it;
+        // the left edge's thread forms both terms
+        const bool second = e > 0 && v.e_point[ge - 1] == j && v.e_pose[ge - 1] == ip;
+        if (!second) {
+          double hv[18];
+#pragma unroll
+          for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) hv[i * 3 + jj] = (Jp[i] * ww) * JX[jj] + (Jp[6 + i] * ww) * JX[3 + jj] + (Jp[12 + i] * ww) * JX[6 + jj];
+          if (d.rig_on && e + 1 < E && v.e_point[ge + 1] == j && v.e_pose[ge + 1] == ip) {
+            EdgeLin l2;
+            lin_edge(d, v.e_kind[ge + 1], pose, X, v.e_obs + (ge + 1) * 3, v.e_info[ge + 1], l2);
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+              for (int jj = 0; jj < 3; ++jj)
+                hv[i * 3 + jj] += (l2.Jp[i] * l2.ww) * l2.JX[jj] + (l2.Jp[6 + i] * l2.ww) * l2.JX[3 + jj] + (l2.Jp[12 + i] * l2.ww) * l2.JX[6 + jj];
+          }
+          double* Hb = Hpl + (size_t)e * 18;
+#pragma unroll
+          for (int k = 0; k < 18; ++k) Hb[k] = hv[k];
         }
       }
-#pragma unroll
-      for (int k = 0; k < 21; ++k) Hp[k] = dev::wave_sum(Hp[k]);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) bp[k] = dev::wave_sum(bp[k]);
-      if (lane == 0) {
-        double* o = ppart + ((size_t)i * kPoseChunks + ch) * 27;
-#pragma unroll
-        for (int k = 0; k < 21; ++k) o[k] = Hp[k];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) o[21 + k] = bp[k];
-      }
     }
-    if (m == 0 && tid == kLT - 64) out.prof2[2] += clock64() - tl2;
     __syncthreads();
-    const long long tl3 = clock64();
-    if (m == 0 && tid == 0) out.prof2[3] += tl3 - tl0;
     // quadratic forms of this block's links (BaseMultiEdge::constructQuadraticForm): W J first, then J^T (W J)
     for (int l = m; l < d.NL; l += G) {
       const int gl = d.link_off + l;
@@ -373,8 +559,9 @@ __global__ __launch_bounds__(kLT) void k_liba(LibaView v, int W, int G) {
       const double* J = Q + 600;
       const double rho1 = J[216 + 9];
       const double* Om = v.link_info + (size_t)gl * 81;
-      double* WJ = sh;            // [9][24]
-      double* Js = sh + 216;      // [9][24]
+      extern __shared__ __attribute__((aligned(16))) double lds_lin[];   // the block's dynamic LDS (the LDL^T scratch, free here)
+      double* WJ = lds_lin;       // [9][24]
+      double* Js = lds_lin + 216; // [9][24]
       for (int idx = tid; idx < 216; idx += kLT) {
         const int k = idx / 24, cb = idx - k * 24;
         double t = 0.0;
@@ -396,126 +583,21 @@ __global__ __launch_bounds__(kLT) void k_liba(LibaView v, int W, int G) {
       }
       __syncthreads();
     }
-    if (m == 0 && tid == 0) out.prof2[4] += clock64() - tl3;
-    const long long tl4 = clock64();
-    OSH_GSYNC();
-    if (m == 0 && tid == 0) out.prof2[5] += clock64() - tl4;
-    OSH_PROF(0);
-    // ---- assembly by block 0: pose diagonal blocks from the chunk sums, then the links one after another (fixed order)
-    if (m == 0) {
-      for (int idx = tid; idx < N * 27; idx += kLT) {
-        const int i = idx / 27, k = idx - i * 27;
-        double s = 0.0;
-        for (int ch = 0; ch < C; ++ch) s += ppart[((size_t)i * kPoseChunks + ch) * 27 + k];
-        if (k < 21) {
-          int a = 0, rem = k;
-          while (rem >= 6 - a) { rem -= 6 - a; ++a; }
-          const int c = a + rem;
-          H[(size_t)(6 * i + a) * n + 6 * i + c] = s;
-          H[(size_t)(6 * i + c) * n + 6 * i + a] = s;
-        } else {
-          b[6 * i + (k - 21)] = s;
-        }
+}
+
+// ---- S = H + lambda I, Schur complement of the landmarks, right-hand side
+__device__ __noinline__ void liba_schur(const LibaCtx& c, double lambda) {
+  OSH_LIBA_LOCALS
+      // S = H + lambda I and the rhs outside the pose-pose blocks (upper triangle)
+      for (int k = gt; k < n * n; k += GT) {
+        const int r = k / n, c = k - r * n;
+        if (c >= r && c >= n6) S[k] = H[k] + ((r == c) ? lambda : 0.0);
       }
-      __syncthreads();
-      for (int l = 0; l < d.NL; ++l) {
-        const int gl = d.link_off + l;
-        const int a = v.link_prev[gl], c = v.link_cur[gl];
-        const double* Q = linkQ + (size_t)l * kLinkQ;
-        auto vert_of = [](int col) { return col < 6 ? 0 : col < 9 ? 1 : col < 12 ? 2 : col < 15 ? 3 : col < 21 ? 4 : 5; };
-        const int vbase[6] = {0, 6, 9, 12, 15, 21};
-        for (int idx = tid; idx < 600; idx += kLT) {
-          if (idx < 576) {
-            const int ca = idx / 24, cb = idx - ca * 24;
-            const int va = vert_of(ca), vb = vert_of(cb);
-            if (vb < va) continue;   // upper blocks + mirrored below
-            const int oa = link_vertex_offset(va, a, c, N), ob = link_vertex_offset(vb, a, c, N);
-            if (oa < 0 || ob < 0) continue;
-            const int ra = oa + (ca - vbase[va]), rb = ob + (cb - vbase[vb]);
-            H[(size_t)ra * n + rb] += Q[idx];
-            if (va != vb) H[(size_t)rb * n + ra] += Q[idx];
-          } else {
-            const int ca = idx - 576;
-            const int va = vert_of(ca);
-            const int oa = link_vertex_offset(va, a, c, N);
-            if (oa >= 0) b[oa + (ca - vbase[va])] += Q[idx];
-          }
-        }
-        __syncthreads();
-        // EdgeGyroRW / EdgeAccRW: r = b2 - b1, J = [-I, I], plain information
-        if (tid < 18) {
-          const int which = tid / 9, i = (tid % 9) / 3, j = tid % 3;
-          const double* Og = (which == 0 ? v.link_info_g : v.link_info_a) + (size_t)gl * 9;
-          const int o1 = (a < N) ? 6 * N + 9 * a + 3 + 3 * which : -1;
-          const int o2 = 6 * N + 9 * c + 3 + 3 * which;
-          const double gg = Og[i * 3 + j];
-          if (o1 >= 0) {
-            H[(size_t)(o1 + i) * n + o1 + j] += gg;
-            H[(size_t)(o1 + i) * n + o2 + j] += -gg;
-            H[(size_t)(o2 + j) * n + o1 + i] += -gg;
-          }
-          H[(size_t)(o2 + i) * n + o2 + j] += gg;
-          if (j == 0) {
-            double rb[3];
-            for (int k = 0; k < 3; ++k) rb[k] = vba[9 * c + 3 + 3 * which + k] - vba[9 * a + 3 + 3 * which + k];
-            const double Or = -(Og[i * 3] * rb[0] + Og[i * 3 + 1] * rb[1] + Og[i * 3 + 2] * rb[2]);
-            if (o1 >= 0) b[o1 + i] += -Or;
-            b[o2 + i] += Or;
-          }
-        }
-        __syncthreads();
-      }
-      if (it == 0) {
-        double l0 = d.lambda_init;
-        if (!(d.lambda_init > 0)) {
-          double mx = 0.0;
-          for (int k = tid; k < n; k += kLT) mx = fmax(mx, fabs(H[(size_t)k * n + k]));
-          for (int j = tid; j < L; j += kLT) mx = fmax(mx, fmax(fabs(Hll[(size_t)j * 6]), fmax(fabs(Hll[(size_t)j * 6 + 3]), fabs(Hll[(size_t)j * 6 + 5]))));
-          l0 = 1e-5 * blk_max(mx, shw);
-        }
-        if (tid == 0) ctrl[0] = l0;
-      }
-    }
-    OSH_GSYNC();
-    if (it == 0) { lambda = ctrl[0]; ni = 2.0; nBad = 0; }
-    OSH_PROF(1);
-    // ---------------------------------------------------------------- LM trials
-    double rho = 0.0;
-    int qmax = 0;
-    do {
-      const int trs = sel ^ 1;
-      // Dinv and Dinv b_l per landmark (setLambda on Hll, block_solver.hpp:389,582-587), and B Dinv of its optimisable-pose edges
-      for (int j = tid * G + m; j < L; j += GT) {
-        const double* hl = Hll + (size_t)j * 6;
-        double Di[9];
-        dev::inv3_sym(hl[0] + lambda, hl[1], hl[2], hl[3] + lambda, hl[4], hl[5] + lambda, Di);
-        const double b0 = bl[(size_t)j * 3], b1 = bl[(size_t)j * 3 + 1], b2 = bl[(size_t)j * 3 + 2];
-        double* o = dinv + (size_t)j * 9;
-        o[0] = Di[0]; o[1] = Di[1]; o[2] = Di[2]; o[3] = Di[4]; o[4] = Di[5]; o[5] = Di[8];
-        o[6] = Di[0] * b0 + Di[1] * b1 + Di[2] * b2; o[7] = Di[3] * b0 + Di[4] * b1 + Di[5] * b2; o[8] = Di[6] * b0 + Di[7] * b1 + Di[8] * b2;
-        for (int e = lmo[j]; e < lmo[j + 1]; ++e) {
-          const int ip = v.e_pose[(size_t)d.edge_off + e];
-          if (ip >= N) continue;
-          if (e > lmo[j] && v.e_pose[(size_t)d.edge_off + e - 1] == ip) continue;   // the pair's block lives in the first edge's slot
-          const double* Be = Hpl + (size_t)e * 18;
-          double* od = BD + (size_t)e * 18;
-#pragma unroll
-          for (int r = 0; r < 6; ++r) {
-            const double x0 = Be[r * 3], x1 = Be[r * 3 + 1], x2 = Be[r * 3 + 2];
-            od[r * 3 + 0] = x0 * Di[0] + x1 * Di[1] + x2 * Di[2];
-            od[r * 3 + 1] = x0 * Di[1] + x1 * Di[4] + x2 * Di[5];
-            od[r * 3 + 2] = x0 * Di[2] + x1 * Di[5] + x2 * Di[8];
-          }
-        }
-      }
-      // S = H + lambda I (upper), rhs = b
-      for (int k = gt; k < n * n; k += GT) { const int r = k / n, c = k - r * n; S[k] = H[k] + ((r == c) ? lambda : 0.0); }
-      for (int k = gt; k < n; k += GT) bs[k] = b[k];
-      OSH_GSYNC();
-      OSH_PROF(2);
+      for (int k = n6 + gt; k < n; k += GT) { bfull[k] = b[k]; bs[k] = b[k]; }
       // Schur complement (block_solver.hpp:381-432), landmark-parallel: one wavefront per pose PAIR (i <= i2), the lanes stride
       // the landmarks, a landmark seen by both poses adds (B Dinv)_i B_i2^T to the lane's 6x6 partial, the 36 partials are summed
-      // by a fixed butterfly and subtracted from S(i, i2); the diagonal pairs also take the rhs term B (Dinv b_l) of their pose.
+      // by a fixed butterfly; S(i, i2) = H(i, i2) [links] + Hpp_i + lambda I [i = i2] - that sum.  The diagonal pairs also form
+      // their pose's rhs  b_p - B (Dinv b_l).
       const int npairs = N * (N + 1) / 2;
       for (int pr = wave * G + m; pr < npairs; pr += GW) {
         int i = 0, rem = pr;
@@ -524,84 +606,137 @@ __global__ __launch_bounds__(kLT) void k_liba(LibaView v, int W, int G) {
         double acc[36], ci[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int k = 0; k < 36; ++k) acc[k] = 0.0;
-        for (int j = lane; j < L; j += 64) {
-          const int e1 = lmpe[(size_t)j * N + i], e2 = lmpe[(size_t)j * N + i2];
-          if (e1 < 0 || e2 < 0) continue;
-          const double* A1 = BD + (size_t)e1 * 18;
-          const double* B2 = Hpl + (size_t)e2 * 18;
-          double b2[18];
+        for (int j0 = lane; j0 < L; j0 += 64) {   // every load of a step issued before its first use
+          int e1[1], e2[1];
 #pragma unroll
-          for (int k = 0; k < 18; ++k) b2[k] = B2[k];
-#pragma unroll
-          for (int r = 0; r < 6; ++r) {
-            const double a0 = A1[r * 3], a1 = A1[r * 3 + 1], a2 = A1[r * 3 + 2];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) acc[r * 6 + c] += a0 * b2[c * 3] + a1 * b2[c * 3 + 1] + a2 * b2[c * 3 + 2];
+          for (int u = 0; u < 1; ++u) {
+            const int j = min(j0 + 64 * u, L - 1);
+            e1[u] = lmpe[(size_t)j * N + i]; e2[u] = lmpe[(size_t)j * N + i2];
+            if (j0 + 64 * u >= L) e1[u] = -1;
           }
-          if (i == i2) {
-            const double* Dj = dinv + (size_t)j * 9;
+          __builtin_amdgcn_sched_barrier(0);
+          double a1[1][18], b2[1][18], dj[1][3];
 #pragma unroll
-            for (int r = 0; r < 6; ++r) ci[r] += b2[r * 3] * Dj[6] + b2[r * 3 + 1] * Dj[7] + b2[r * 3 + 2] * Dj[8];
+          for (int u = 0; u < 1; ++u) {
+            const bool on = e1[u] >= 0 && e2[u] >= 0;
+            const double* A1 = BD + (size_t)(on ? e1[u] : 0) * 18;
+            const double* B2 = Hpl + (size_t)(on ? e2[u] : 0) * 18;
+            const double* Dj = dinv + (size_t)min(j0 + 64 * u, L - 1) * 9;
+#pragma unroll
+            for (int k = 0; k < 18; ++k) { a1[u][k] = A1[k]; b2[u][k] = B2[k]; }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dj[u][k] = Dj[6 + k];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < 1; ++u) {
+            if (e1[u] < 0 || e2[u] < 0) continue;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+              const double a0 = a1[u][r * 3], a1v = a1[u][r * 3 + 1], a2 = a1[u][r * 3 + 2];
+#pragma unroll
+              for (int c = 0; c < 6; ++c) acc[r * 6 + c] += a0 * b2[u][c * 3] + a1v * b2[u][c * 3 + 1] + a2 * b2[u][c * 3 + 2];
+            }
+            if (i == i2) {
+#pragma unroll
+              for (int r = 0; r < 6; ++r) ci[r] += b2[u][r * 3] * dj[u][0] + b2[u][r * 3 + 1] * dj[u][1] + b2[u][r * 3 + 2] * dj[u][2];
+            }
           }
         }
 #pragma unroll
-        for (int k = 0; k < 36; ++k) acc[k] = dev::wave_sum(acc[k]);
+        for (int k = 0; k < 36; ++k) acc[k] = dev::wave_sum_dpp(acc[k]);
         if (lane < 36) {
           double val = acc[0];
 #pragma unroll
           for (int k = 1; k < 36; ++k) val = (lane == k) ? acc[k] : val;
           const int r = lane / 6, c = lane - r * 6;
-          S[(size_t)(6 * i + r) * n + 6 * i2 + c] -= val;
+          double base = H[(size_t)(6 * i + r) * n + 6 * i2 + c];
+          if (i == i2) {
+            const int qq = up21(r, c);
+            for (int ch = 0; ch < C; ++ch) base += ppart[((size_t)i * kPoseChunks + ch) * 27 + qq];
+            if (r == c) base += lambda;
+          }
+          S[(size_t)(6 * i + r) * n + 6 * i2 + c] = base - val;
         }
         if (i == i2) {
 #pragma unroll
-          for (int r = 0; r < 6; ++r) ci[r] = dev::wave_sum(ci[r]);
+          for (int r = 0; r < 6; ++r) ci[r] = dev::wave_sum_dpp(ci[r]);
           if (lane < 6) {
             double c = ci[0];
             if (lane == 1) c = ci[1]; else if (lane == 2) c = ci[2]; else if (lane == 3) c = ci[3];
             else if (lane == 4) c = ci[4]; else if (lane == 5) c = ci[5];
-            bs[6 * i + lane] -= c;
+            double bf = b[6 * i + lane];
+            for (int ch = 0; ch < C; ++ch) bf += ppart[((size_t)i * kPoseChunks + ch) * 27 + 21 + lane];
+            bfull[6 * i + lane] = bf;
+            bs[6 * i + lane] = bf - c;
           }
         }
       }
-      OSH_GSYNC();
-      OSH_PROF(3);
-      if (m == 0) {
-        double *xs, *shw2;
-        const bool okb = ldlt_solve_block<kLNB, kLT>(S, bs, n, W, sh, xs, shw2);
-        for (int k = tid; k < n; k += kLT) xg[k] = xs[k];
-        if (tid == 0) ctrl[1] = okb ? 1.0 : 0.0;
-      }
-      OSH_GSYNC();
-      const bool ok2 = ctrl[1] != 0.0;
-      OSH_PROF(4);
-      // landmark back-substitution, point update, landmark part of computeScale
+}
+
+// ---- LDL^T + solve of the reduced system by block 0 of the group (inlined: its panels live in LDS, and only inside the kernel does the
+// compiler know that pointer for what it is)
+__device__ __forceinline__ void liba_solve(const LibaCtx& c, double* sh_lds) {
+  OSH_LIBA_LOCALS
+  double *xs, *shw2;
+  const bool okb = ldlt_solve_block<kLNB, kLT>(S, bs, n, c.W, sh_lds, xs, shw2);
+  for (int k = tid; k < n; k += kLT) xg[k] = xs[k];
+  if (tid == 0) ctrl[1] = okb ? 1.0 : 0.0;
+}
+
+// ---- landmark back-substitution and the update of every vertex into the trial buffers; returns this thread's share of computeScale
+__device__ __noinline__ double liba_backsub(const LibaCtx& c, int sel, double lambda, bool ok2) {
+  OSH_LIBA_LOCALS
+  const double* poses = v.pose[sel] + (size_t)d.pose_off * 24;
+  const double* vba = v.vba[sel] + (size_t)d.vel_off * 9;
+  const double* pts = v.pts[sel] + (size_t)d.pt_off * 3;
+  const int trs = sel ^ 1;
+      // landmark back-substitution (team per landmark), point update, landmark part of computeScale
       double sc = 0.0;
       double* pts_t = v.pts[trs] + (size_t)d.pt_off * 3;
-      for (int j = tid * G + m; j < L; j += GT) {
-        const double* Dj = dinv + (size_t)j * 9;
-        const double b0 = bl[(size_t)j * 3], b1 = bl[(size_t)j * 3 + 1], b2 = bl[(size_t)j * 3 + 2];
-        double c0 = b0, c1 = b1, c2 = b2;
-        for (int e = lmo[j]; e < lmo[j + 1]; ++e) {
-          const int ip = v.e_pose[(size_t)d.edge_off + e];
-          if (ip >= N) continue;
-          if (e > lmo[j] && v.e_pose[(size_t)d.edge_off + e - 1] == ip) continue;   // block already taken with the pair's first edge
-          const double* B = Hpl + (size_t)e * 18;
-          const double* xp = xg + 6 * ip;
-          double a0 = 0, a1 = 0, a2 = 0;
+      {
+        const int T = (4 * L <= GT) ? 4 : ((2 * L <= GT) ? 2 : 1);
+        const int q = tid & (T - 1);
+        for (int j = gt / T; j < L; j += GT / T) {
+          double c0 = 0, c1 = 0, c2 = 0;
+          for (int i0 = q; i0 < N; i0 += 2 * T) {   // two blocks in flight
+            int eu[2];
 #pragma unroll
-          for (int r = 0; r < 6; ++r) { const double mx = -xp[r]; a0 += B[r * 3] * mx; a1 += B[r * 3 + 1] * mx; a2 += B[r * 3 + 2] * mx; }
-          c0 += a0; c1 += a1; c2 += a2;
+            for (int u = 0; u < 2; ++u) eu[u] = (i0 + u * T < N) ? lmpe[(size_t)j * N + i0 + u * T] : -1;
+            __builtin_amdgcn_sched_barrier(0);
+            double Bu[2][18], xu[2][6];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const double* B = Hpl + (size_t)(eu[u] < 0 ? 0 : eu[u]) * 18;
+              const double* xp = xg + 6 * min(i0 + u * T, N - 1);
+#pragma unroll
+              for (int k = 0; k < 18; ++k) Bu[u][k] = B[k];
+#pragma unroll
+              for (int k = 0; k < 6; ++k) xu[u][k] = xp[k];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              if (eu[u] < 0) continue;
+#pragma unroll
+              for (int r = 0; r < 6; ++r) { const double mx = -xu[u][r]; c0 += Bu[u][r * 3] * mx; c1 += Bu[u][r * 3 + 1] * mx; c2 += Bu[u][r * 3 + 2] * mx; }
+            }
+          }
+          c0 = team_sum(c0, T); c1 = team_sum(c1, T); c2 = team_sum(c2, T);
+          if (q != 0) continue;
+          const double* Dj = dinv + (size_t)j * 9;
+          const double b0 = bl[(size_t)j * 3], b1 = bl[(size_t)j * 3 + 1], b2 = bl[(size_t)j * 3 + 2];
+          c0 += b0; c1 += b1; c2 += b2;
+          double xl[3] = {0, 0, 0};
+          if (ok2) {
+            xl[0] = Dj[0] * c0 + Dj[1] * c1 + Dj[2] * c2;
+            xl[1] = Dj[1] * c0 + Dj[3] * c1 + Dj[4] * c2;
+            xl[2] = Dj[2] * c0 + Dj[4] * c1 + Dj[5] * c2;
+          }
+          pts_t[3 * (size_t)j] = pts[3 * (size_t)j] + xl[0]; pts_t[3 * (size_t)j + 1] = pts[3 * (size_t)j + 1] + xl[1];
+          pts_t[3 * (size_t)j + 2] = pts[3 * (size_t)j + 2] + xl[2];
+          sc += xl[0] * (lambda * xl[0] + b0) + xl[1] * (lambda * xl[1] + b1) + xl[2] * (lambda * xl[2] + b2);
         }
-        double xl[3] = {0, 0, 0};
-        if (ok2) {
-          xl[0] = Dj[0] * c0 + Dj[1] * c1 + Dj[2] * c2;
-          xl[1] = Dj[1] * c0 + Dj[3] * c1 + Dj[4] * c2;
-          xl[2] = Dj[2] * c0 + Dj[4] * c1 + Dj[5] * c2;
-        }
-        pts_t[3 * (size_t)j] = pts[3 * (size_t)j] + xl[0]; pts_t[3 * (size_t)j + 1] = pts[3 * (size_t)j + 1] + xl[1];
-        pts_t[3 * (size_t)j + 2] = pts[3 * (size_t)j + 2] + xl[2];
-        sc += xl[0] * (lambda * xl[0] + b0) + xl[1] * (lambda * xl[1] + b1) + xl[2] * (lambda * xl[2] + b2);
       }
       // pose / velocity / bias update into the trial buffers (ImuCamPose::Update, src/G2oTypes.cc:187-220): last block of the group
       double* poses_t = v.pose[trs] + (size_t)d.pose_off * 24;
@@ -611,11 +746,11 @@ __global__ __launch_bounds__(kLT) void k_liba(LibaView v, int W, int G) {
           const double* pu = xg + 6 * k;
           const double* P = poses + 24 * (size_t)k;
           double* Q = poses_t + 24 * (size_t)k;
-          double tw[3], E[9], Rwb[9], Rbw[9], tbw[3], tc[3];
+          double tw[3], Ex[9], Rwb[9], Rbw[9], tbw[3], tc[3];
           imu::m3_vec(P + 12, pu + 3, tw);
           for (int i = 0; i < 3; ++i) Q[21 + i] = P[21 + i] + tw[i];
-          imu::exp_so3(pu, E);
-          imu::m3_mul(P + 12, E, Rwb);
+          imu::exp_so3(pu, Ex);
+          imu::m3_mul(P + 12, Ex, Rwb);
           for (int i = 0; i < 9; ++i) Q[12 + i] = Rwb[i];
           for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rbw[i * 3 + j] = Rwb[j * 3 + i];
           imu::m3_vec(Rbw, Q + 21, tbw);
@@ -623,43 +758,16 @@ __global__ __launch_bounds__(kLT) void k_liba(LibaView v, int W, int G) {
           imu::m3_mul(d.Rcb, Rbw, Q);
           imu::m3_vec(d.Rcb, tbw, tc);
           for (int i = 0; i < 3; ++i) Q[9 + i] = tc[i] + d.tcb[i];
-          for (int i = 0; i < 9; ++i) vba_t[9 * k + i] = vba[9 * k + i] + xg[6 * N + 9 * k + i];
+          for (int i = 0; i < 9; ++i) vba_t[9 * k + i] = vba[9 * k + i] + xg[n6 + 9 * k + i];
         }
-        for (int k = tid; k < n; k += kLT) sc += xg[k] * (lambda * xg[k] + b[k]);
+        for (int k = tid; k < n; k += kLT) sc += xg[k] * (lambda * xg[k] + bfull[k]);
       }
-      OSH_GSYNC();
-      OSH_PROF(5);
-      double tempChi = eval_partial(v, d, trs, g);
-      if (!grp_sum2(g, tempChi, sc, shw, lds_flag)) return;
-      const double scale_sum = sc;
-      last_chi = tempChi;
-      eval_sel = trs;
-      if (!ok2) tempChi = DBL_MAX;
-      // controller: identical decisions in every thread of every block (all inputs are group-uniform)
-      rho = (currentChi - tempChi);
-      const double scale = scale_sum + 1e-3;
-      rho /= scale;
-      if (rho > 0 && isfinite(tempChi)) {
-        double alpha = 1. - pow((2 * rho - 1), 3);
-        alpha = fmin(alpha, 2. / 3.);
-        lambda *= fmax(1. / 3., alpha);
-        ni = 2; currentChi = tempChi;
-        sel = trs;   // discardTop
-        poses = v.pose[sel] + (size_t)d.pose_off * 24; vba = v.vba[sel] + (size_t)d.vel_off * 9; pts = v.pts[sel] + (size_t)d.pt_off * 3;
-      } else {
-        lambda *= ni; ni *= 2;   // pop
-      }
-      qmax++; trials_total++;
-      OSH_PROF(6);
-    } while (rho < 0 && qmax < 10);
-    ++cj;
-    if (m == 0 && tid == 0 && n_trace < OSH_LBA_MAX_TRACE) { out.chi2_trace[n_trace] = currentChi; out.lambda_trace[n_trace] = lambda; out.trials_trace[n_trace] = qmax; }
-    if (n_trace < OSH_LBA_MAX_TRACE) ++n_trace;
-    if (qmax == 10 || rho == 0) { ok = false; continue; }
-    if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
-    if (nBad >= 3) { ok = false; continue; }
-  }
-  if (m == 0 && tid == 0) { out.iterations = cj; out.trials = trials_total; out.n_trace = n_trace; out.sel = sel; out.chi2_final = last_chi; }
+  return sc;
+}
+
+// ---- per-edge chi2 and depth flags, final estimates into the result arena
+__device__ __noinline__ void liba_outputs(const LibaCtx& c, int sel, int eval_sel) {
+  OSH_LIBA_LOCALS
   // e->chi2() of the errors computeActiveErrors saw last (buffer eval_sel: stale after a rejected final trial) and
   // isDepthPositive() of the final estimates (src/Optimizer.cc:2861-2888; ImuCamPose::isDepthPositive, G2oTypes.cc:185-188)
   {
@@ -696,6 +804,152 @@ __global__ __launch_bounds__(kLT) void k_liba(LibaView v, int W, int G) {
     for (int k = gt; k < N * 9; k += GT) v.res_vba[kf0 * 9 + k] = sf[k];
     for (int k = gt; k < L * 3; k += GT) v.res_pts[(size_t)d.pt_off * 3 + k] = xf[k];
   }
+}
+
+__global__ __launch_bounds__(kLT) void k_liba(LibaView v, int W, int G) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  // consecutive workgroups go to the 8 XCDs in turn: the G blocks of a window are 8 apart, so they share one XCD and its L2
+  const int bid = blockIdx.x;
+  const int win = (bid / (8 * G)) * 8 + (bid & 7);
+  if (win >= v.nw) return;
+  const LibaDesc& d = v.desc[win];
+  LibaOut& out = v.out[win];
+  const int tid = threadIdx.x;
+  Grp g;
+  g.bar = v.bar + win; g.abort_flag = v.abort_flag; g.res_abort = v.res_abort; g.red = v.red + (size_t)win * 4 * kLG * 2; g.G = G; g.m = (bid >> 3) % G;
+  g.gen = 0; g.nred = 0; g.light = 0;
+  const int m = g.m, GT = G * kLT, gt = m * kLT + tid, GW = G * (kLT / 64);
+  const int N = d.N, n = d.n, L = d.L, n6 = 6 * d.N;
+  // LDS carve: [0, ldlt) the LDL^T scratch (reused as general scratch between solves), then control words
+  double* shw = sh + liba_scratch_doubles(W);             // [kLT/64] reductions
+  int* lds_flag = reinterpret_cast<int*>(shw + kLT / 64 + 1);
+  const double* H = v.H + d.H_off;
+  const double* Hll = v.Hll + (size_t)d.pt_off * 6;
+  const double* ppart = v.ppart + (size_t)(d.b_off / 15) * kPoseChunks * 27;
+  double* ctrl = v.ctrl + (size_t)win * 4;
+  const bool prof_on = (m == 0 && tid == 0);
+  long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long prof_last = clock64();
+  if (bid == 0 && tid == 0) *v.res_abort = 0;
+  // the trial buffers start as copies of the estimates (the fixed keyframes and the fixed IMU state are only ever read)
+  for (int k = gt; k < d.K * 24; k += GT) v.pose[1][(size_t)d.pose_off * 24 + k] = v.pose[0][(size_t)d.pose_off * 24 + k];
+  for (int k = gt; k < d.NV * 9; k += GT) v.vba[1][(size_t)d.vel_off * 9 + k] = v.vba[0][(size_t)d.vel_off * 9 + k];
+
+  int C = (GW - GW / 4) / (N > 0 ? N : 1);     // pose rows are summed in C chunks each so that a few keyframes still spread over the group
+  C = C < 1 ? 1 : (C > kPoseChunks ? kPoseChunks : C);
+  LibaCtx c;
+  c.v = &v; c.d = &d; c.sh = sh; c.shw = shw; c.G = G; c.m = m; c.C = C; c.win = win; c.W = W;
+
+  if (G > 1) {
+    // which XCD is this block on?  (the first barrier is the full agent-scope one)
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (tid == 0) g.red[3 * kLG * 2 + m] = (double)(xcc & 0xfu);
+    OSH_GSYNC();
+    bool same = true;
+    for (int k = 1; k < G; ++k) same = same && g.red[3 * kLG * 2 + k] == g.red[3 * kLG * 2];
+    g.light = (same && !v.force_heavy) ? 1 : 0;
+    __syncthreads();
+  }
+  int sel = 0, eval_sel = 0;
+  double lambda = -1.0, ni = 2.0;
+  int nBad = 0, cj = 0, trials_total = 0, n_trace = 0;
+  bool ok = true;
+  double chi_init = eval_partial(v, d, 0, g), zero = 0.0;
+  if (!grp_sum2(g, chi_init, zero, shw, lds_flag)) return;
+  if (m == 0 && tid == 0) out.chi2_initial = chi_init;
+  double last_chi = chi_init;      // activeRobustChi2() of the errors evaluated last (err_end)
+  double currentChi = chi_init;    // of buffer `sel`: the accepted trial's value (the same sum over the same buffer the reference recomputes)
+  OSH_PROF(6);
+
+  for (int it = 0; it < d.max_iter && ok; ++it) {
+    const double iniChi = currentChi;
+    // ---------------------------------------------------------------- linearise (buildSystem)
+    liba_linearise(c, sel);
+    OSH_GSYNC();
+    OSH_PROF(0);
+    // ---- the links of the first colour into H; landmark and pose rows summed; (lambda known) Dinv, B Dinv
+    const bool lambda_known = it > 0 || d.lambda_init > 0;
+    if (it == 0 && lambda_known) lambda = d.lambda_init;
+    liba_assemble_links(c, sel, 0);
+    liba_landmark_pass(c, true, lambda_known, lambda, 0, G);
+    liba_pose_pass(c, 0, G);
+    OSH_GSYNC();
+    for (int col = 1; col < d.n_colours; ++col) {
+      liba_assemble_links(c, sel, col);
+      OSH_GSYNC();
+    }
+    if (!lambda_known) {
+      // setLambda's default: 1e-5 x the largest diagonal entry of the full Hessian (computeLambdaInit)
+      if (m == 0) {
+        double mx = 0.0;
+        for (int k = tid; k < n; k += kLT) {
+          double hd = H[(size_t)k * n + k];
+          if (k < n6) { const int i = k / 6, r = k - i * 6; for (int ch = 0; ch < C; ++ch) hd += ppart[((size_t)i * kPoseChunks + ch) * 27 + up21(r, r)]; }
+          mx = fmax(mx, fabs(hd));
+        }
+        for (int j = tid; j < L; j += kLT) mx = fmax(mx, fmax(fabs(Hll[(size_t)j * 6]), fmax(fabs(Hll[(size_t)j * 6 + 3]), fabs(Hll[(size_t)j * 6 + 5]))));
+        mx = blk_max(mx, shw);
+        if (tid == 0) ctrl[0] = 1e-5 * mx;
+      }
+      OSH_GSYNC();
+      lambda = ctrl[0];
+      liba_landmark_pass(c, false, true, lambda, 0, G);
+      OSH_GSYNC();
+    }
+    if (it == 0) { ni = 2.0; nBad = 0; }
+    OSH_PROF(1);
+    // ---------------------------------------------------------------- LM trials
+    double rho = 0.0;
+    int qmax = 0;
+    do {
+      const int trs = sel ^ 1;
+      if (qmax > 0) {   // a rejected trial changed lambda: Dinv, B Dinv again
+        liba_landmark_pass(c, false, true, lambda, 0, G);
+        OSH_GSYNC();
+      }
+      OSH_PROF(2);
+      liba_schur(c, lambda);
+      OSH_GSYNC();
+      OSH_PROF(3);
+      if (m == 0) liba_solve(c, sh);
+      OSH_GSYNC();
+      const bool ok2 = ctrl[1] != 0.0;
+      OSH_PROF(4);
+      double sc = liba_backsub(c, sel, lambda, ok2);
+      OSH_GSYNC();
+      OSH_PROF(5);
+      double tempChi = eval_partial(v, d, trs, g);
+      if (!grp_sum2(g, tempChi, sc, shw, lds_flag)) return;
+      const double scale_sum = sc;
+      last_chi = tempChi;
+      eval_sel = trs;
+      if (!ok2) tempChi = DBL_MAX;
+      // controller: identical decisions in every thread of every block (all inputs are group-uniform)
+      rho = (currentChi - tempChi);
+      const double scale = scale_sum + 1e-3;
+      rho /= scale;
+      if (rho > 0 && isfinite(tempChi)) {
+        double alpha = 1. - pow((2 * rho - 1), 3);
+        alpha = fmin(alpha, 2. / 3.);
+        lambda *= fmax(1. / 3., alpha);
+        ni = 2; currentChi = tempChi;
+        sel = trs;   // discardTop
+      } else {
+        lambda *= ni; ni *= 2;   // pop
+      }
+      qmax++; trials_total++;
+      OSH_PROF(6);
+    } while (rho < 0 && qmax < 10);
+    ++cj;
+    if (m == 0 && tid == 0 && n_trace < OSH_LBA_MAX_TRACE) { out.chi2_trace[n_trace] = currentChi; out.lambda_trace[n_trace] = lambda; out.trials_trace[n_trace] = qmax; }
+    if (n_trace < OSH_LBA_MAX_TRACE) ++n_trace;
+    if (qmax == 10 || rho == 0) { ok = false; continue; }
+    if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+    if (nBad >= 3) { ok = false; continue; }
+  }
+  if (m == 0 && tid == 0) { out.iterations = cj; out.trials = trials_total; out.n_trace = n_trace; out.sel = sel; out.chi2_final = last_chi; }
+  liba_outputs(c, sel, eval_sel);
   OSH_PROF(7);
   if (prof_on) for (int k = 0; k < 8; ++k) out.prof[k] = prof[k];
 }
@@ -725,7 +979,7 @@ struct PinnedBuf {
 };
 struct LibaBuffers {
   PinnedBuf h_in, h_out;
-  DevBuf in, res, pose1, vba1, pts1, Hpl, BD, Hll, bl, dinv, H, b, S, bs, x, linkQ, ppart, red, ctrl;
+  DevBuf in, res, pose1, vba1, pts1, eh, ep, bfull, Hpl, BD, Hll, bl, dinv, H, b, S, bs, x, linkQ, ppart, red, ctrl;
 };
 LibaBuffers& liba_buffers() { static thread_local LibaBuffers b; return b; }
 thread_local int g_liba_last_group = 0;
@@ -751,7 +1005,7 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
         p.max_iterations > OSH_LBA_MAX_TRACE) { set_error("window %d: bad sizes", w); return OSH_ERR_INVALID; }
     LibaDesc& d = h_desc[w];
     d.N = p.n_opt; d.NV = p.n_opt + p.n_fixed_imu; d.K = d.NV + p.n_fixed; d.L = p.n_points; d.E = p.n_edges; d.NL = p.n_links;
-    d.n = 15 * d.N; d.max_iter = p.max_iterations;
+    d.n = 15 * d.N; d.max_iter = p.max_iterations; d.n_colours = 0; d.pad_ = 0;
     d.pose_off = (int)K; d.vel_off = (int)NV; d.pt_off = (int)L; d.edge_off = (int)E; d.link_off = (int)NL; d.lmoff_off = (int)LO;
     d.peloff_off = (int)PO; d.pel_off = (int)EF; d.lmpose_off = (int)LP; d.H_off = (long long)Htot; d.b_off = (int)btot;
     std::memcpy(d.Rcb, p.Rcb, 72); std::memcpy(d.tcb, p.tcb, 24); std::memcpy(d.tbc, p.tbc, 24); std::memcpy(d.cam, p.cam, 40);
@@ -803,9 +1057,9 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
   auto take = [&](size_t bytes) { const size_t o = in_bytes; in_bytes = (in_bytes + bytes + 255) & ~(size_t)255; return o; };
   const size_t o_desc = take(nw * sizeof(LibaDesc)), o_pose = take(K * 24 * 8), o_vba = take(NV * 9 * 8), o_pts = take(L * 3 * 8), o_obs = take(E * 3 * 8),
                o_info = take(E * 8), o_ep = take(E * 4), o_el = take(E * 4), o_eo = take(E * 4), o_lmo = take(LO * 4), o_po = take(PO * 4),
-               o_pel = take(EF * 4), o_lmpe = take(LP * 4), o_lp = take(NL * 4), o_lc = take(NL * 4), o_kind = take(E), o_rob = take(NL),
+               o_pel = take(E * 4), o_lmpe = take(LP * 4), o_lp = take(NL * 4), o_lc = take(NL * 4), o_kind = take(E), o_rob = take(NL),
                o_pre = take(NL * OSH_PREINT_FLOATS * 4), o_li = take(NL * 81 * 8), o_lg = take(NL * 9 * 8), o_la = take(NL * 9 * 8),
-               o_bar = take(nw * sizeof(unsigned)), o_abort = take(sizeof(int));
+               o_bar = take(nw * sizeof(unsigned)), o_abort = take(sizeof(int)), o_col = take(NL * 4);
   char* hs = static_cast<char*>(B.h_in.reserve(in_bytes));
   if (!hs) { set_error("osh_liba_solve: pinned staging allocation of %zu bytes failed", in_bytes); return OSH_ERR_DEVICE; }
   LibaDesc* h_descp = reinterpret_cast<LibaDesc*>(hs + o_desc);
@@ -817,8 +1071,8 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
   int* h_lmpe = reinterpret_cast<int*>(hs + o_lmpe); int* h_lp = reinterpret_cast<int*>(hs + o_lp); int* h_lc = reinterpret_cast<int*>(hs + o_lc);
   unsigned char* h_kind = reinterpret_cast<unsigned char*>(hs + o_kind); unsigned char* h_rob = reinterpret_cast<unsigned char*>(hs + o_rob);
   float* h_pre = reinterpret_cast<float*>(hs + o_pre);
+  int* h_col = reinterpret_cast<int*>(hs + o_col);
   double* h_li = reinterpret_cast<double*>(hs + o_li); double* h_lg = reinterpret_cast<double*>(hs + o_lg); double* h_la = reinterpret_cast<double*>(hs + o_la);
-  std::memcpy(h_descp, h_desc.data(), nw * sizeof(LibaDesc));
   std::memset(h_lmpe, 0xff, LP * 4);
   std::memset(hs + o_bar, 0, nw * sizeof(unsigned));
   std::memset(hs + o_abort, 0, sizeof(int));
@@ -872,15 +1126,31 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
     }
     for (int i = 0; i < d.N; ++i) po[i + 1] += po[i];
     fill.assign(po, po + d.N);
-    for (int x = 0; x < d.E; ++x) { const int ip = h_ep[(size_t)d.edge_off + x]; if (ip < d.N) h_pel[(size_t)d.pel_off + fill[ip]++] = x; }
+    int nfix = po[d.N];   // the fixed keyframes' edges follow the optimisable ones in the walk order of the linearisation
+    for (int x = 0; x < d.E; ++x) {
+      const int ip = h_ep[(size_t)d.edge_off + x];
+      h_pel[(size_t)d.edge_off + (ip < d.N ? fill[ip]++ : nfix++)] = x;
+    }
     for (int l = 0; l < d.NL; ++l) {
       const size_t g = (size_t)d.link_off + l;
       h_lp[g] = p.link_prev[l]; h_lc[g] = p.link_cur[l]; h_rob[g] = p.link_robust[l];
       std::memcpy(&h_pre[g * OSH_PREINT_FLOATS], p.link_preint + (size_t)l * OSH_PREINT_FLOATS, OSH_PREINT_FLOATS * 4);
       std::memcpy(&h_li[g * 81], p.link_info + (size_t)l * 81, 81 * 8);
       std::memcpy(&h_lg[g * 9], p.link_info_g + (size_t)l * 9, 72); std::memcpy(&h_la[g * 9], p.link_info_a + (size_t)l * 9, 72);
+      // greedy colouring: the first colour none of the earlier links sharing a keyframe with this one has (a chain takes two)
+      int col = 0;
+      for (bool clash = true; clash; ) {
+        clash = false;
+        for (int l2 = 0; l2 < l && !clash; ++l2)
+          clash = h_col[(size_t)d.link_off + l2] == col && (p.link_prev[l2] == p.link_prev[l] || p.link_prev[l2] == p.link_cur[l] ||
+                                                           p.link_cur[l2] == p.link_prev[l] || p.link_cur[l2] == p.link_cur[l]);
+        if (clash) ++col;
+      }
+      h_col[g] = col;
+      h_desc[w].n_colours = std::max(h_desc[w].n_colours, col + 1);
     }
   }
+  std::memcpy(h_descp, h_desc.data(), nw * sizeof(LibaDesc));
   // ---- result arena (one copy back): LibaOut per window, abort word, final poses / velocities+biases / points, edge chi2 and depth flags
   size_t out_bytes = 0;
   auto take_out = [&](size_t bytes) { const size_t o = out_bytes; out_bytes = (out_bytes + bytes + 255) & ~(size_t)255; return o; };
@@ -891,6 +1161,7 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
   auto R = [](DevBuf& b, size_t bytes) { return b.reserve(std::max<size_t>(bytes, 8)); };
   OSH_TRY(R(B.in, in_bytes)); OSH_TRY(R(B.res, out_bytes));
   OSH_TRY(R(B.pose1, K * 24 * 8)); OSH_TRY(R(B.vba1, NV * 9 * 8)); OSH_TRY(R(B.pts1, L * 3 * 8));
+  OSH_TRY(R(B.eh, E * 9 * 8)); OSH_TRY(R(B.ep, EF * 27 * 8)); OSH_TRY(R(B.bfull, btot * 8));
   OSH_TRY(R(B.Hpl, E * 18 * 8)); OSH_TRY(R(B.BD, E * 18 * 8)); OSH_TRY(R(B.Hll, L * 6 * 8)); OSH_TRY(R(B.bl, L * 3 * 8));
   OSH_TRY(R(B.dinv, L * 9 * 8)); OSH_TRY(R(B.H, Htot * 8)); OSH_TRY(R(B.S, Htot * 8)); OSH_TRY(R(B.b, btot * 8)); OSH_TRY(R(B.bs, btot * 8));
   OSH_TRY(R(B.x, btot * 8)); OSH_TRY(R(B.linkQ, NL * kLinkQ * 8)); OSH_TRY(R(B.ppart, (btot / 15) * kPoseChunks * 27 * 8));
@@ -916,6 +1187,9 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
   v.x = B.x.as<double>(); v.linkQ = B.linkQ.as<double>(); v.ppart = B.ppart.as<double>();
   v.bar = reinterpret_cast<unsigned*>(din + o_bar); v.abort_flag = reinterpret_cast<int*>(din + o_abort);
   v.red = B.red.as<double>(); v.ctrl = B.ctrl.as<double>(); v.nw = nw;
+  v.force_heavy = getenv("OSH_LIBA_HEAVY_BARRIER") ? 1 : 0;
+  v.eh = B.eh.as<double>(); v.ep = B.ep.as<double>(); v.bfull = B.bfull.as<double>(); v.E_total = E; v.EF_total = EF;
+  v.link_colour = reinterpret_cast<const int*>(din + o_col);
   v.res_abort = reinterpret_cast<int*>(dres + r_abort); v.res_pose = reinterpret_cast<double*>(dres + r_pose); v.res_vba = reinterpret_cast<double*>(dres + r_vba);
   v.res_pts = reinterpret_cast<double*>(dres + r_pts); v.out_chi2 = reinterpret_cast<double*>(dres + r_chi2);
   v.out_depth = reinterpret_cast<unsigned char*>(dres + r_depth);
@@ -943,7 +1217,6 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
   const LibaOut* h_out = reinterpret_cast<const LibaOut*>(hr + r_out);
   g_liba_last_group = G;
   std::memcpy(g_liba_last_prof, h_out[0].prof, sizeof(g_liba_last_prof));
-  if (getenv("OSH_LIBA_PROF2")) for (int k = 0; k < 6; ++k) fprintf(stderr, "prof2[%d] = %lld\n", k, h_out[0].prof2[k]);
   for (int w = 0; w < nw; ++w) {
     const LibaDesc& d = h_desc[w];
     const LibaOut& o = h_out[w];

@@ -21,6 +21,7 @@ struct LibaDesc {
   int rig_on;      // 1: fisheye stereo rig, OSH_EDGE_RIGHT edges are EdgeMono(1) on camera 1 of ImuCamPose (src/G2oTypes.cc:56-66)
   double Rrl[9], trl[3], Rcb1[9], tbc1[3], cam2[8];   // Trl; Rcb[1] = Rrl Rcb[0]; tbc[1] = -Rbc[1] tcb[1]; right camera fx fy cx cy k1..k4
   double huber_mono, huber_stereo, huber_inertial, lambda_init;
+  int n_colours, pad_;   // inertial links are coloured so that the links of one colour share no keyframe (liba_device.hip)
 };
 
 struct VisEval { double r[3], chi2, Xc[3]; };

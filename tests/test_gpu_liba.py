@@ -115,3 +115,27 @@ def test_device_matches_the_numpy_lm_golden_outputs(solver, name):
     from helpers import check_against_liba_fixture, load_liba_fixture
     w, z = load_liba_fixture(name)
     check_against_liba_fixture(solver.solve_inertial([w])[0], z, fisheye=w.kb8 is not None)
+
+
+@pytest.mark.parametrize("group", ["1", "2", "4", "8", "16"])
+def test_every_group_size_takes_the_same_path(solver, ob, monkeypatch, group):
+    """A window is optimised by a group of 1..16 thread blocks (OSH_LIBA_GROUP; default: 16 for a single window, 1 for a large
+    batch).  The group size only changes how the sums are split, so the Levenberg-Marquardt trace is the oracle's for each."""
+    monkeypatch.setenv("OSH_LIBA_GROUP", group)
+    ws = [si.make_inertial_window(41), si.make_inertial_rig_window(43, n_opt=4, n_fixed=3, n_points=150)]
+    got = solver.solve_inertial(ws)
+    assert solver.inertial_profile()[0] == int(group)
+    for w, g in zip(ws, got):
+        rig = w.kb8 is not None
+        _check(g, ob.liba_solve(w), w, **(dict(pts_tol=2e-4, edge_tol=2e-3) if rig else {}))   # fisheye tolerances as above
+
+
+def test_agent_scope_barrier_path_agrees(solver, monkeypatch):
+    """OSH_LIBA_HEAVY_BARRIER=1 keeps the agent-scope fences (L2 write-back) a group uses when its blocks are not all on one XCD."""
+    w = si.make_inertial_window(45)
+    a = solver.solve_inertial([w])[0]
+    monkeypatch.setenv("OSH_LIBA_HEAVY_BARRIER", "1")
+    b = solver.solve_inertial([w])[0]
+    np.testing.assert_array_equal(a.chi2_trace, b.chi2_trace)
+    np.testing.assert_array_equal(a.pose_twb, b.pose_twb)
+    np.testing.assert_array_equal(a.points, b.points)
