@@ -51,11 +51,11 @@ struct LibaView {
   const int* e_pose; const int* e_point; const unsigned char* e_kind; const double* e_obs; const double* e_info; const int* e_orig;
   const int* lm_off;          // L+1 per window (sorted edges)
   const int* pel_off; const int* pel_edge;   // pel_off [N+1]: the optimisable poses' ranges in pel_edge [E]: their edges pose by pose (landmark order inside), then the fixed keyframes' edges
-  const int* lm_pose_edge;    // [L*N] sorted edge index of (landmark, optimisable pose) or -1
+  const int* lm_pose_edge;    // [L*N] place of the block of (landmark, optimisable pose) in the pose-by-pose order (pel_edge), or -1
   const int* link_prev; const int* link_cur; const float* link_preint; const double* link_info; const double* link_info_g;
   const double* link_info_a; const unsigned char* link_robust;
-  double* Hpl; double* Hll; double* bl; double* dinv;   // [E*18] [L*6] [L*3] [L*9]
-  double* BD;                 // [E*18] B Dinv of every optimisable-pose edge (Schur step)
+  double* Hpl; double* Hll; double* bl; double* dinv;   // [18][EF_total] (a column per block, pose-by-pose order) [L*6] [L*3] [L*9]
+  double* BD;                 // [18][EF_total] B Dinv of every optimisable-pose block (Schur step), same layout as Hpl
   double* eh; double* ep;     // [9][E_total], [27][EF_total] per-edge terms of the landmark rows / pose rows (linearisation)
   size_t E_total, EF_total;
   const int* link_colour;     // [NL] links of one colour share no keyframe
@@ -214,12 +214,12 @@ __device__ __noinline__ double eval_partial(const LibaView& v, const LibaDesc& d
     }
   }
   const int GT = g.G * kLT;
-  for (int e0 = g.m * kLT + tid; e0 < d.E; e0 += 2 * GT) {   // two edges per thread and step
-    const int e[2] = {e0, e0 + GT};
-    EdgeIn<2> in;
-    load_edges<2>(v, d, e, poses, pts, in);
+  for (int e0 = g.m * kLT + tid; e0 < d.E; e0 += 3 * GT) {   // three edges per thread and step
+    const int e[3] = {e0, e0 + GT, e0 + 2 * GT};
+    EdgeIn<3> in;
+    load_edges<3>(v, d, e, poses, pts, in);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < 3; ++u) {
       if (e[u] >= d.E) continue;
       VisEval ev;
       vis_residual(d, in.kind[u], in.pose[u], in.X[u], in.obs[u], in.info[u], ev);
@@ -266,7 +266,7 @@ struct LibaCtx { const LibaView* v; const LibaDesc* d; double* sh; double* shw; 
   [[maybe_unused]] double* const H = v.H + d.H_off; [[maybe_unused]] double* const S = v.S + d.H_off; \
   [[maybe_unused]] double* const b = v.b + d.b_off; [[maybe_unused]] double* const bs = v.bs + d.b_off; \
   [[maybe_unused]] double* const xg = v.x + d.b_off; [[maybe_unused]] double* const bfull = v.bfull + d.b_off; \
-  [[maybe_unused]] double* const Hpl = v.Hpl + (size_t)d.edge_off * 18; [[maybe_unused]] double* const BD = v.BD + (size_t)d.edge_off * 18; \
+  [[maybe_unused]] double* const Hpl = v.Hpl + d.pel_off; [[maybe_unused]] double* const BD = v.BD + d.pel_off; \
   [[maybe_unused]] double* const Hll = v.Hll + (size_t)d.pt_off * 6; [[maybe_unused]] double* const bl = v.bl + (size_t)d.pt_off * 3; \
   [[maybe_unused]] double* const dinv = v.dinv + (size_t)d.pt_off * 9; \
   [[maybe_unused]] double* const eh = v.eh + (size_t)d.edge_off * 9; [[maybe_unused]] double* const ep = v.ep + d.pel_off; \
@@ -344,21 +344,21 @@ __device__ __noinline__ void liba_landmark_pass(const LibaCtx& c, bool from_edge
         double Bu[2][18];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          const double* Be = Hpl + (size_t)(eu[u] < 0 ? 0 : eu[u]) * 18;
+          const double* Be = Hpl + (eu[u] < 0 ? 0 : eu[u]);
 #pragma unroll
-          for (int k = 0; k < 18; ++k) Bu[u][k] = Be[k];
+          for (int k = 0; k < 18; ++k) Bu[u][k] = Be[k * PS];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           if (eu[u] < 0) continue;
-          double* od = BD + (size_t)eu[u] * 18;
+          double* od = BD + eu[u];
 #pragma unroll
           for (int r = 0; r < 6; ++r) {
             const double x0 = Bu[u][r * 3], x1 = Bu[u][r * 3 + 1], x2 = Bu[u][r * 3 + 2];
-            od[r * 3 + 0] = x0 * Di[0] + x1 * Di[1] + x2 * Di[2];
-            od[r * 3 + 1] = x0 * Di[1] + x1 * Di[4] + x2 * Di[5];
-            od[r * 3 + 2] = x0 * Di[2] + x1 * Di[5] + x2 * Di[8];
+            od[(r * 3 + 0) * PS] = x0 * Di[0] + x1 * Di[1] + x2 * Di[2];
+            od[(r * 3 + 1) * PS] = x0 * Di[1] + x1 * Di[4] + x2 * Di[5];
+            od[(r * 3 + 2) * PS] = x0 * Di[2] + x1 * Di[5] + x2 * Di[8];
           }
         }
       }
@@ -545,9 +545,8 @@ __device__ __noinline__ void liba_linearise(const LibaCtx& c, int sel) {
               for (int jj = 0; jj < 3; ++jj)
                 hv[i * 3 + jj] += (l2.Jp[i] * l2.ww) * l2.JX[jj] + (l2.Jp[6 + i] * l2.ww) * l2.JX[3 + jj] + (l2.Jp[12 + i] * l2.ww) * l2.JX[6 + jj];
           }
-          double* Hb = Hpl + (size_t)e * 18;
 #pragma unroll
-          for (int k = 0; k < 18; ++k) Hb[k] = hv[k];
+          for (int k = 0; k < 18; ++k) Hpl[k * PS + idx] = hv[k];
         }
       }
     }
@@ -606,30 +605,30 @@ __device__ __noinline__ void liba_schur(const LibaCtx& c, double lambda) {
         double acc[36], ci[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int k = 0; k < 36; ++k) acc[k] = 0.0;
-        for (int j0 = lane; j0 < L; j0 += 64) {   // every load of a step issued before its first use
-          int e1[1], e2[1];
+        for (int j0 = lane; j0 < L; j0 += 128) {   // two landmarks per lane and step, every load of a step issued before its first use
+          int e1[2], e2[2];
 #pragma unroll
-          for (int u = 0; u < 1; ++u) {
+          for (int u = 0; u < 2; ++u) {
             const int j = min(j0 + 64 * u, L - 1);
             e1[u] = lmpe[(size_t)j * N + i]; e2[u] = lmpe[(size_t)j * N + i2];
             if (j0 + 64 * u >= L) e1[u] = -1;
           }
           __builtin_amdgcn_sched_barrier(0);
-          double a1[1][18], b2[1][18], dj[1][3];
+          double a1[2][18], b2[2][18], dj[2][3];
 #pragma unroll
-          for (int u = 0; u < 1; ++u) {
+          for (int u = 0; u < 2; ++u) {
             const bool on = e1[u] >= 0 && e2[u] >= 0;
-            const double* A1 = BD + (size_t)(on ? e1[u] : 0) * 18;
-            const double* B2 = Hpl + (size_t)(on ? e2[u] : 0) * 18;
+            const double* A1 = BD + (on ? e1[u] : 0);
+            const double* B2 = Hpl + (on ? e2[u] : 0);
             const double* Dj = dinv + (size_t)min(j0 + 64 * u, L - 1) * 9;
 #pragma unroll
-            for (int k = 0; k < 18; ++k) { a1[u][k] = A1[k]; b2[u][k] = B2[k]; }
+            for (int k = 0; k < 18; ++k) { a1[u][k] = A1[k * PS]; b2[u][k] = B2[k * PS]; }
 #pragma unroll
             for (int k = 0; k < 3; ++k) dj[u][k] = Dj[6 + k];
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int u = 0; u < 1; ++u) {
+          for (int u = 0; u < 2; ++u) {
             if (e1[u] < 0 || e2[u] < 0) continue;
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
@@ -707,10 +706,10 @@ __device__ __noinline__ double liba_backsub(const LibaCtx& c, int sel, double la
             double Bu[2][18], xu[2][6];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-              const double* B = Hpl + (size_t)(eu[u] < 0 ? 0 : eu[u]) * 18;
+              const double* B = Hpl + (eu[u] < 0 ? 0 : eu[u]);
               const double* xp = xg + 6 * min(i0 + u * T, N - 1);
 #pragma unroll
-              for (int k = 0; k < 18; ++k) Bu[u][k] = B[k];
+              for (int k = 0; k < 18; ++k) Bu[u][k] = B[k * PS];
 #pragma unroll
               for (int k = 0; k < 6; ++k) xu[u][k] = xp[k];
             }
@@ -979,7 +978,7 @@ struct PinnedBuf {
 };
 struct LibaBuffers {
   PinnedBuf h_in, h_out;
-  DevBuf in, res, pose1, vba1, pts1, eh, ep, bfull, Hpl, BD, Hll, bl, dinv, H, b, S, bs, x, linkQ, ppart, red, ctrl;
+  DevBuf arena;
 };
 LibaBuffers& liba_buffers() { static thread_local LibaBuffers b; return b; }
 thread_local int g_liba_last_group = 0;
@@ -1127,10 +1126,14 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
     for (int i = 0; i < d.N; ++i) po[i + 1] += po[i];
     fill.assign(po, po + d.N);
     int nfix = po[d.N];   // the fixed keyframes' edges follow the optimisable ones in the walk order of the linearisation
+    cnt.assign((size_t)d.E, -1);   // place of each optimisable-pose edge in that order
     for (int x = 0; x < d.E; ++x) {
       const int ip = h_ep[(size_t)d.edge_off + x];
+      if (ip < d.N) cnt[x] = fill[ip];
       h_pel[(size_t)d.edge_off + (ip < d.N ? fill[ip]++ : nfix++)] = x;
     }
+    // (landmark, pose) -> place of the pair's block: Hpl and B Dinv are stored pose by pose, a landmark's neighbours next to it
+    for (size_t k = 0; k < (size_t)d.L * d.N; ++k) { int& x = h_lmpe[(size_t)d.lmpose_off + k]; if (x >= 0) x = cnt[x]; }
     for (int l = 0; l < d.NL; ++l) {
       const size_t g = (size_t)d.link_off + l;
       h_lp[g] = p.link_prev[l]; h_lc[g] = p.link_cur[l]; h_rob[g] = p.link_robust[l];
@@ -1158,21 +1161,25 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
                r_pts = take_out(L * 3 * 8), r_chi2 = take_out(E * 8), r_depth = take_out(E);
   char* hr = static_cast<char*>(B.h_out.reserve(out_bytes));
   if (!hr) { set_error("osh_liba_solve: pinned result allocation of %zu bytes failed", out_bytes); return OSH_ERR_DEVICE; }
-  auto R = [](DevBuf& b, size_t bytes) { return b.reserve(std::max<size_t>(bytes, 8)); };
-  OSH_TRY(R(B.in, in_bytes)); OSH_TRY(R(B.res, out_bytes));
-  OSH_TRY(R(B.pose1, K * 24 * 8)); OSH_TRY(R(B.vba1, NV * 9 * 8)); OSH_TRY(R(B.pts1, L * 3 * 8));
-  OSH_TRY(R(B.eh, E * 9 * 8)); OSH_TRY(R(B.ep, EF * 27 * 8)); OSH_TRY(R(B.bfull, btot * 8));
-  OSH_TRY(R(B.Hpl, E * 18 * 8)); OSH_TRY(R(B.BD, E * 18 * 8)); OSH_TRY(R(B.Hll, L * 6 * 8)); OSH_TRY(R(B.bl, L * 3 * 8));
-  OSH_TRY(R(B.dinv, L * 9 * 8)); OSH_TRY(R(B.H, Htot * 8)); OSH_TRY(R(B.S, Htot * 8)); OSH_TRY(R(B.b, btot * 8)); OSH_TRY(R(B.bs, btot * 8));
-  OSH_TRY(R(B.x, btot * 8)); OSH_TRY(R(B.linkQ, NL * kLinkQ * 8)); OSH_TRY(R(B.ppart, (btot / 15) * kPoseChunks * 27 * 8));
-  OSH_TRY(R(B.red, (size_t)nw * 4 * kLG * 2 * 8)); OSH_TRY(R(B.ctrl, (size_t)nw * 4 * 8));
-  OSH_HIP(hipMemcpyAsync(B.in.p, hs, in_bytes, hipMemcpyHostToDevice, s));
-  char* din = B.in.as<char>();
-  char* dres = B.res.as<char>();
+  auto R = [](DevBuf& b, size_t bytes) { return b.reserve(std::max<size_t>(bytes, (size_t)64 << 20)); };   // at least 64 MiB: large page fragments
+  // ONE device arena: inputs (uploaded in one copy), results (downloaded in one copy), then the work buffers
+  size_t dev_bytes = 0;
+  auto take_dev = [&](size_t bytes) { const size_t o = dev_bytes; dev_bytes = (dev_bytes + std::max<size_t>(bytes, 8) + 255) & ~(size_t)255; return o; };
+  const size_t a_in = take_dev(in_bytes), a_res = take_dev(out_bytes), a_pose1 = take_dev(K * 24 * 8), a_vba1 = take_dev(NV * 9 * 8), a_pts1 = take_dev(L * 3 * 8),
+               a_eh = take_dev(E * 9 * 8), a_ep = take_dev(EF * 27 * 8), a_bfull = take_dev(btot * 8), a_Hpl = take_dev(EF * 18 * 8), a_BD = take_dev(EF * 18 * 8),
+               a_Hll = take_dev(L * 6 * 8), a_bl = take_dev(L * 3 * 8), a_dinv = take_dev(L * 9 * 8), a_H = take_dev(Htot * 8), a_S = take_dev(Htot * 8),
+               a_b = take_dev(btot * 8), a_bs = take_dev(btot * 8), a_x = take_dev(btot * 8), a_linkQ = take_dev(NL * kLinkQ * 8),
+               a_ppart = take_dev((btot / 15) * kPoseChunks * 27 * 8), a_red = take_dev((size_t)nw * 4 * kLG * 2 * 8), a_ctrl = take_dev((size_t)nw * 4 * 8);
+  OSH_TRY(R(B.arena, dev_bytes));
+  char* const dbase = B.arena.as<char>();
+  auto dptr = [&](size_t off) { return reinterpret_cast<double*>(dbase + off); };
+  char* din = dbase + a_in;
+  char* dres = dbase + a_res;
+  OSH_HIP(hipMemcpyAsync(din, hs, in_bytes, hipMemcpyHostToDevice, s));
   LibaView v{};
   v.desc = reinterpret_cast<const LibaDesc*>(din + o_desc); v.out = reinterpret_cast<LibaOut*>(dres + r_out);
   v.pose[0] = reinterpret_cast<double*>(din + o_pose); v.vba[0] = reinterpret_cast<double*>(din + o_vba); v.pts[0] = reinterpret_cast<double*>(din + o_pts);
-  v.pose[1] = B.pose1.as<double>(); v.vba[1] = B.vba1.as<double>(); v.pts[1] = B.pts1.as<double>();
+  v.pose[1] = dptr(a_pose1); v.vba[1] = dptr(a_vba1); v.pts[1] = dptr(a_pts1);
   v.e_pose = reinterpret_cast<const int*>(din + o_ep); v.e_point = reinterpret_cast<const int*>(din + o_el);
   v.e_kind = reinterpret_cast<const unsigned char*>(din + o_kind); v.e_obs = reinterpret_cast<const double*>(din + o_obs);
   v.e_info = reinterpret_cast<const double*>(din + o_info); v.e_orig = reinterpret_cast<const int*>(din + o_eo);
@@ -1182,13 +1189,13 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
   v.link_preint = reinterpret_cast<const float*>(din + o_pre); v.link_info = reinterpret_cast<const double*>(din + o_li);
   v.link_info_g = reinterpret_cast<const double*>(din + o_lg); v.link_info_a = reinterpret_cast<const double*>(din + o_la);
   v.link_robust = reinterpret_cast<const unsigned char*>(din + o_rob);
-  v.Hpl = B.Hpl.as<double>(); v.BD = B.BD.as<double>(); v.Hll = B.Hll.as<double>(); v.bl = B.bl.as<double>();
-  v.dinv = B.dinv.as<double>(); v.H = B.H.as<double>(); v.b = B.b.as<double>(); v.S = B.S.as<double>(); v.bs = B.bs.as<double>();
-  v.x = B.x.as<double>(); v.linkQ = B.linkQ.as<double>(); v.ppart = B.ppart.as<double>();
+  v.Hpl = dptr(a_Hpl); v.BD = dptr(a_BD); v.Hll = dptr(a_Hll); v.bl = dptr(a_bl);
+  v.dinv = dptr(a_dinv); v.H = dptr(a_H); v.b = dptr(a_b); v.S = dptr(a_S); v.bs = dptr(a_bs);
+  v.x = dptr(a_x); v.linkQ = dptr(a_linkQ); v.ppart = dptr(a_ppart);
   v.bar = reinterpret_cast<unsigned*>(din + o_bar); v.abort_flag = reinterpret_cast<int*>(din + o_abort);
-  v.red = B.red.as<double>(); v.ctrl = B.ctrl.as<double>(); v.nw = nw;
+  v.red = dptr(a_red); v.ctrl = dptr(a_ctrl); v.nw = nw;
   v.force_heavy = getenv("OSH_LIBA_HEAVY_BARRIER") ? 1 : 0;
-  v.eh = B.eh.as<double>(); v.ep = B.ep.as<double>(); v.bfull = B.bfull.as<double>(); v.E_total = E; v.EF_total = EF;
+  v.eh = dptr(a_eh); v.ep = dptr(a_ep); v.bfull = dptr(a_bfull); v.E_total = E; v.EF_total = EF;
   v.link_colour = reinterpret_cast<const int*>(din + o_col);
   v.res_abort = reinterpret_cast<int*>(dres + r_abort); v.res_pose = reinterpret_cast<double*>(dres + r_pose); v.res_vba = reinterpret_cast<double*>(dres + r_vba);
   v.res_pts = reinterpret_cast<double*>(dres + r_pts); v.out_chi2 = reinterpret_cast<double*>(dres + r_chi2);
