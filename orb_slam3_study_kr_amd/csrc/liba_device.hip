@@ -2,7 +2,7 @@
 //
 // An inertial window is small (N <= 10/25 keyframes x 15 dof, O(10^3) landmarks, O(10^4) edges) and the reference runs exactly
 // one at a time, so the whole Levenberg-Marquardt loop of a window runs inside ONE launch with no host round trip: a GROUP of
-// up to 16 thread blocks on one XCD works on the window (the tracker's single window: 16 blocks; a large batch: one block per
+// up to 32 thread blocks -- one XCD -- works on the window (the tracker's single window: 32 blocks; a large batch: one block per
 // window fills the chip).  The phases are separated by a barrier of the group (arrival counter in global memory); every sum is
 // taken in a fixed order (lanes, wavefronts, blocks), so a run is bitwise reproducible and every block takes the same controller
 // decisions from the same numbers.  Phases (each a function of its own, see the note above liba_landmark_pass):
@@ -30,7 +30,7 @@ namespace osh {
 constexpr int kLT = 256;      // threads of a block: one wavefront per SIMD, so a phase may use all 512 registers (with 512 threads the
                               // per-edge code spilled: 1.2 KB of scratch per lane)
 constexpr int kLNB = 24;      // LDL^T panel width
-constexpr int kLG = 16;       // blocks per window at most (one XCD's worth of a group)
+constexpr int kLG = 32;       // blocks per window at most (one XCD's worth of a group)
 constexpr int kPoseChunks = 8;   // a pose row's edges are summed in at most this many chunks
 constexpr int kLinkQ = 832;   // per link: J^T W J (24x24), -J^T W r (24), then J (9x24), -W r (9), rho'
 __host__ __device__ constexpr size_t liba_scratch_doubles(int W) { return ldlt_lds_doubles(kLNB, W, kLT) > 512 ? ldlt_lds_doubles(kLNB, W, kLT) : 512; }
@@ -1202,10 +1202,10 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
   v.out_depth = reinterpret_cast<unsigned char*>(dres + r_depth);
   static bool attr_done = false;
   if (!attr_done) { OSH_HIP(hipFuncSetAttribute((const void*)k_liba, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)); attr_done = true; }
-  // blocks per window: the tracker's single window (and small batches) get a group of 16 on one XCD; a large batch fills the chip
+  // blocks per window: the tracker's single window (and small batches) get a group of 32 = one whole XCD; a large batch fills the chip
   // with one block per window.  A group needs all its blocks resident (they meet at barriers): cooperative launch checks that.
-  int G = nw <= 16 ? kLG : (nw <= 32 ? 8 : (nw <= 64 ? 4 : (nw <= 128 ? 2 : 1)));
-  if (const char* gs = getenv("OSH_LIBA_GROUP")) { const int gv = atoi(gs); if (gv == 1 || gv == 2 || gv == 4 || gv == 8 || gv == 16) G = gv; }
+  int G = nw <= 8 ? kLG : (nw <= 16 ? 16 : (nw <= 32 ? 8 : (nw <= 64 ? 4 : (nw <= 128 ? 2 : 1))));
+  if (const char* gs = getenv("OSH_LIBA_GROUP")) { const int gv = atoi(gs); if (gv == 1 || gv == 2 || gv == 4 || gv == 8 || gv == 16 || gv == 32) G = gv; }
   int W_arg = W;
   hipError_t le = hipSuccess;
   if (G > 1) {

@@ -117,9 +117,9 @@ def test_device_matches_the_numpy_lm_golden_outputs(solver, name):
     check_against_liba_fixture(solver.solve_inertial([w])[0], z, fisheye=w.kb8 is not None)
 
 
-@pytest.mark.parametrize("group", ["1", "2", "4", "8", "16"])
+@pytest.mark.parametrize("group", ["1", "2", "4", "8", "16", "32"])
 def test_every_group_size_takes_the_same_path(solver, ob, monkeypatch, group):
-    """A window is optimised by a group of 1..16 thread blocks (OSH_LIBA_GROUP; default: 16 for a single window, 1 for a large
+    """A window is optimised by a group of 1..32 thread blocks (OSH_LIBA_GROUP; default: 32 for a single window, 1 for a large
     batch).  The group size only changes how the sums are split, so the Levenberg-Marquardt trace is the oracle's for each."""
     monkeypatch.setenv("OSH_LIBA_GROUP", group)
     ws = [si.make_inertial_window(41), si.make_inertial_rig_window(43, n_opt=4, n_fixed=3, n_points=150)]
