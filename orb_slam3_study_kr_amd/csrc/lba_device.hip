@@ -1238,6 +1238,8 @@ struct PinBuf {
 struct osh_lba_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  void* attach[4] = {nullptr, nullptr, nullptr, nullptr};
+  void (*attach_free[4])(void*) = {nullptr, nullptr, nullptr, nullptr};
   KernelTimer timer;
   // host-side batch description
   int n_windows = 0;
@@ -1300,10 +1302,19 @@ extern "C" int osh_lba_stream(osh_lba_ctx* c, int* device, hipStream_t* stream) 
   return OSH_OK;
 }
 
+// State another translation unit keeps with the context (liba_device.hip: its staging and work buffers): created on first use,
+// released by osh_lba_destroy -- not by a thread_local destructor at process exit, when the HIP runtime may already be gone.
+extern "C" void** osh_lba_attachment(osh_lba_ctx* c, int slot, void (*free_fn)(void*)) {
+  if (!c || slot < 0 || slot >= 4) return nullptr;
+  c->attach_free[slot] = free_fn;
+  return &c->attach[slot];
+}
+
 extern "C" void osh_lba_destroy(osh_lba_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (int k = 0; k < 4; ++k) if (c->attach[k] && c->attach_free[k]) { c->attach_free[k](c->attach[k]); c->attach[k] = nullptr; }
   c->timer.destroy();
   if (c->h_nactive) (void)hipHostFree(c->h_nactive);
   if (c->h_stop) (void)hipHostFree(c->h_stop);

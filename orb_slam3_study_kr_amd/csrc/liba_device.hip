@@ -980,7 +980,7 @@ struct LibaBuffers {
   PinnedBuf h_in, h_out;
   DevBuf arena;
 };
-LibaBuffers& liba_buffers() { static thread_local LibaBuffers b; return b; }
+
 thread_local int g_liba_last_group = 0;
 thread_local long long g_liba_last_prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 }  // namespace
@@ -988,6 +988,7 @@ thread_local long long g_liba_last_prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define OSH_TRY(expr) do { int _rc = (expr); if (_rc != OSH_OK) return _rc; } while (0)
 
 extern "C" int osh_lba_stream(osh_lba_ctx* ctx, int* device, hipStream_t* stream);   // lba_device.hip
+extern "C" void** osh_lba_attachment(osh_lba_ctx* ctx, int slot, void (*free_fn)(void*));   // lba_device.hip
 
 extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_problem* pr, osh_liba_result* res) {
   if (!ctx || nw <= 0 || !pr || !res) { set_error("osh_liba_solve: bad arguments"); return OSH_ERR_INVALID; }
@@ -1051,7 +1052,11 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
   if (lds > 160 * 1024 - 64) { set_error("inertial window with %d keyframes exceeds the LDS budget", n_max / 15); return OSH_ERR_UNSUPPORTED; }
   // ---- pack: every input array goes into ONE pinned staging buffer and travels in ONE copy (an upload per array cost more than
   // the optimisation of a single window); the device pointers are offsets into the arena.
-  LibaBuffers& B = liba_buffers();
+  // staging and work buffers live with the context (one solver at a time per context, as for the visual path)
+  void** slot = osh_lba_attachment(ctx, 0, [](void* q) { delete static_cast<LibaBuffers*>(q); });
+  if (!slot) { set_error("osh_liba_solve: no context"); return OSH_ERR_INVALID; }
+  if (!*slot) *slot = new LibaBuffers();
+  LibaBuffers& B = *static_cast<LibaBuffers*>(*slot);
   size_t in_bytes = 0;
   auto take = [&](size_t bytes) { const size_t o = in_bytes; in_bytes = (in_bytes + bytes + 255) & ~(size_t)255; return o; };
   const size_t o_desc = take(nw * sizeof(LibaDesc)), o_pose = take(K * 24 * 8), o_vba = take(NV * 9 * 8), o_pts = take(L * 3 * 8), o_obs = take(E * 3 * 8),
