@@ -474,8 +474,7 @@ __device__ __noinline__ void liba_linearise(const LibaCtx& c, int sel) {
         double* J = Q + 600;
         double r[9];
         const float* rec = v.link_preint + (size_t)gl * OSH_PREINT_FLOATS;
-        inertial_residual(rec, poses + 24 * a, vba + 9 * a, poses + 24 * c, vba + 9 * c, r);
-        inertial_jacobian(rec, poses + 24 * a, vba + 9 * a, poses + 24 * c, vba + 9 * c, J);
+        inertial_residual_jacobian(rec, poses + 24 * a, vba + 9 * a, poses + 24 * c, vba + 9 * c, r, J);
         const double* Om = v.link_info + (size_t)gl * 81;
         double rho1 = 1.0;
         if (v.link_robust[gl]) {

@@ -154,4 +154,48 @@ __device__ inline void inertial_jacobian(const float* rec, const double* P1, con
 #undef OSH_PUT
 }
 
+// computeError + linearizeOplus of EdgeInertial in one pass: the bias-corrected deltas, Rbw1 and the rotation error (and its log)
+// are formed once for both (the residual and the Jacobian are always wanted together on the device)
+__device__ inline void inertial_residual_jacobian(const float* rec, const double* P1, const double* s1, const double* P2, const double* s2, double* r, double* J) {
+  const double dt = (double)rec[0];
+  double dR[9], dV[3], dP[3], dbg[3], Rbw1[9], T[9], eR[9], er[3], invJr[9], M[9], v[3], W[9], t[3];
+  imu::preint_deltas(rec, s1 + 3, s1 + 6, dR, dV, dP, dbg);
+  const double* Rwb1 = P1 + 12; const double* Rwb2 = P2 + 12;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rbw1[i * 3 + j] = Rwb1[j * 3 + i];
+  imu::m3_tmul(dR, Rbw1, T); imu::m3_mul(T, Rwb2, eR);
+  imu::log_so3(eR, er);
+  // residual (src/G2oTypes.cc:513-533)
+  for (int i = 0; i < 3; ++i) r[i] = er[i];
+  for (int i = 0; i < 3; ++i) t[i] = s2[i] - s1[i] - (i == 2 ? -kGrav : 0.0) * dt;
+  imu::m3_tvec(Rwb1, t, t);
+  for (int i = 0; i < 3; ++i) r[3 + i] = t[i] - dV[i];
+  for (int i = 0; i < 3; ++i) t[i] = P2[21 + i] - P1[21 + i] - s1[i] * dt - (i == 2 ? -kGrav : 0.0) * dt * dt / 2;
+  imu::m3_tvec(Rwb1, t, t);
+  for (int i = 0; i < 3; ++i) r[6 + i] = t[i] - dP[i];
+  // Jacobian (src/G2oTypes.cc:535-594), columns P1(6) V1(3) G1(3) A1(3) P2(6) V2(3)
+  imu::inv_right_jac(er, invJr);
+  for (int i = 0; i < 9 * 24; ++i) J[i] = 0.0;
+#define OSH_PUT(r0, c0, Mx, sgn) for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) J[((r0) + i) * 24 + (c0) + j] = (sgn) * (Mx)[i * 3 + j]
+  imu::m3_tmul(Rwb2, Rwb1, M); imu::m3_mul(invJr, M, M); OSH_PUT(0, 0, M, -1.0);
+  for (int i = 0; i < 3; ++i) v[i] = s2[i] - s1[i] - (i == 2 ? -kGrav : 0.0) * dt;
+  imu::m3_vec(Rbw1, v, v); imu::m3_hat(v, W); OSH_PUT(3, 0, W, 1.0);
+  for (int i = 0; i < 3; ++i) v[i] = P2[21 + i] - P1[21 + i] - s1[i] * dt - 0.5 * (i == 2 ? -kGrav : 0.0) * dt * dt;
+  imu::m3_vec(Rbw1, v, v); imu::m3_hat(v, W); OSH_PUT(6, 0, W, 1.0);
+  { const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; OSH_PUT(6, 3, I, -1.0); }
+  OSH_PUT(3, 6, Rbw1, -1.0);
+  for (int i = 0; i < 9; ++i) M[i] = Rbw1[i] * dt;
+  OSH_PUT(6, 6, M, -1.0);
+  double JRg[9], JVg[9], JVa[9], JPg[9], JPa[9], rj[9], w[3], eRt[9];
+  for (int i = 0; i < 9; ++i) { JRg[i] = rec[16 + i]; JVg[i] = rec[25 + i]; JVa[i] = rec[34 + i]; JPg[i] = rec[43 + i]; JPa[i] = rec[52 + i]; }
+  imu::m3_vec(JRg, dbg, w); imu::right_jac(w, rj);
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) eRt[i * 3 + j] = eR[j * 3 + i];
+  imu::m3_mul(invJr, eRt, M); imu::m3_mul(M, rj, M); imu::m3_mul(M, JRg, M); OSH_PUT(0, 9, M, -1.0);
+  OSH_PUT(3, 9, JVg, -1.0); OSH_PUT(6, 9, JPg, -1.0);
+  OSH_PUT(3, 12, JVa, -1.0); OSH_PUT(6, 12, JPa, -1.0);
+  OSH_PUT(0, 15, invJr, 1.0);
+  imu::m3_mul(Rbw1, Rwb2, M); OSH_PUT(6, 18, M, 1.0);
+  OSH_PUT(3, 21, Rbw1, 1.0);
+#undef OSH_PUT
+}
+
 }  // namespace osh

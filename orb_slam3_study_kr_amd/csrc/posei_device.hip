@@ -126,6 +126,7 @@ __global__ __launch_bounds__(kIT) void k_posei(PoseiView v) {
   __shared__ double shH[900], shb[30], shx[30];
   __shared__ double shJ[9 * 24], shWJ[15 * 30], shr[15], shJp[225];
   __shared__ double shU[32 * 33];
+  __shared__ float shrec[OSH_PREINT_FLOATS];   // the preintegration record: read a dozen times per iteration by one thread
   __shared__ int sh_ok;
   const PoseiDesc& d = v.desc[blockIdx.x];
   PoseiOut& out = v.out[blockIdx.x];
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(kIT) void k_posei(PoseiView v) {
   if (tid < 24) { shP[tid] = d.P[tid]; shpP[tid] = d.pP[tid]; }
   if (tid < 9) { shs[tid] = d.s[tid]; shps[tid] = d.ps[tid]; }
   if (tid < 30) shx[tid] = 0.0;
+  if (tid < OSH_PREINT_FLOATS) shrec[tid] = d.rec[tid];
   __syncthreads();
   // column of the EdgeInertial Jacobian (P1 V1 G1 A1 P2 V2) -> unknown (-1: fixed vertex)
   auto unk_of = [&](int c) { return c >= 15 ? c - 15 : (mode1 ? 15 + c : -1); };
@@ -151,7 +153,10 @@ __global__ __launch_bounds__(kIT) void k_posei(PoseiView v) {
     for (int k = 0; k < 21; ++k) H[k] = 0.0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) b[k] = 0.0;
-    for (int e = tid; e < d.E; e += kIT) {
+    // the visual edges run on the first wavefronts while lane 0 of the last one forms the inertial edge (one long chain of
+    // small matrix products): the two take about the same time
+    constexpr int kVis = kIT - 64;
+    for (int e = tid < kVis ? tid : d.E; e < d.E; e += kVis) {
       const size_t ge = (size_t)d.edge_off + e;
       if (v.level[ge]) continue;
       const int kind = v.kind[ge];
@@ -176,9 +181,8 @@ __global__ __launch_bounds__(kIT) void k_posei(PoseiView v) {
       }
     }
     // inertial edge: residual and Jacobian by one thread, the quadratic form by the block
-    if (tid == 0) {
-      inertial_residual(d.rec, shpP, shps, shP, shs, shr);
-      inertial_jacobian(d.rec, shpP, shps, shP, shs, shJ);
+    if (tid == kVis) {
+      inertial_residual_jacobian(shrec, shpP, shps, shP, shs, shr, shJ);
     }
     __syncthreads();
     for (int idx = tid; idx < 9 * 24; idx += kIT) {   // W J
@@ -202,16 +206,6 @@ __global__ __launch_bounds__(kIT) void k_posei(PoseiView v) {
         const int a = r < c ? r : c, bq = r < c ? c : r;
         acc += red[a * 6 - a * (a - 1) / 2 + (bq - a)];
       }
-      // EdgeInertial: J^T W J over the columns that map to unknowns r and c
-      for (int ca = 0; ca < 24; ++ca) {
-        if (unk_of(ca) != r) continue;
-        for (int cb = 0; cb < 24; ++cb) {
-          if (unk_of(cb) != c) continue;
-          double t = 0.0;
-          for (int k = 0; k < 9; ++k) t += shJ[k * 24 + ca] * shWJ[k * 24 + cb];
-          acc += t;
-        }
-      }
       // random walks: r = b_cur - b_prev, J = [-I, I]
       for (int which = 0; which < 2; ++which) {
         const double* Og = which == 0 ? d.info_g : d.info_a;
@@ -223,6 +217,16 @@ __global__ __launch_bounds__(kIT) void k_posei(PoseiView v) {
         if (r2 && c1) acc -= Og[(c - o1) * 3 + (r - o2)];
       }
       shH[idx] = acc;
+    }
+    __syncthreads();
+    // EdgeInertial: J^T W J, a thread per pair of Jacobian columns (a column maps to at most one unknown, so no two pairs meet)
+    for (int idx = tid; idx < 24 * 24; idx += kIT) {
+      const int ca = idx / 24, cb = idx - ca * 24;
+      const int r = unk_of(ca), c = unk_of(cb);
+      if (r < 0 || c < 0) continue;
+      double t = 0.0;
+      for (int k = 0; k < 9; ++k) t += shJ[k * 24 + ca] * shWJ[k * 24 + cb];
+      shH[r * n + c] += t;
     }
     if (tid < n) {
       double acc = tid < 6 ? red[21 + tid] : 0.0;
@@ -380,7 +384,7 @@ __global__ __launch_bounds__(kIT) void k_posei(PoseiView v) {
   // ---- Hessian of the frame's ConstraintPoseImu (:4858-4893 / :5252-5293): re-linearised at the final estimate, plain information
   {
     const int o2 = mode1 ? 15 : 0;
-    if (tid == 0) inertial_jacobian(d.rec, shpP, shps, shP, shs, shJ);
+    if (tid == 0) inertial_jacobian(shrec, shpP, shps, shP, shs, shJ);
     double H[21];
 #pragma unroll
     for (int k = 0; k < 21; ++k) H[k] = 0.0;
