@@ -540,7 +540,7 @@ __global__ __launch_bounds__(64, KB8 ? 1 : 2) void k_schur_fused(BatchView bv, i
     }
   };
   // rows of W F of the lane's edge on one side of the item (side 0: row poses, 1: column poses) -> the side's LDS image
-  auto side_rows = [&](int side, bool present, const int4& ra, unsigned o, const double2* er, const Dat& d, double* img) {
+  auto side_rows = [&](int side, bool present, const int4& ra, unsigned o, const double2* er, const Dat& d, double* img) __attribute__((always_inline)) {
     const double* ps = shPose + (side * 8 + s) * kPoseRec;
     double qt[7], cam[5], Rm[9];
 #pragma unroll
@@ -569,7 +569,8 @@ __global__ __launch_bounds__(64, KB8 ? 1 : 2) void k_schur_fused(BatchView bv, i
       }
     }
   };
-  auto park = [&](int c0, const int4& ra, const int4& rb, const Dat& d) {
+  // (always inlined: as a call, in the fisheye instantiation, every accumulator it touches by reference would live in scratch memory)
+  auto park = [&](int c0, const int4& ra, const int4& rb, const Dat& d) __attribute__((always_inline)) {
     const bool valid = (c0 + l) < it.n_lm;
     const unsigned xo = valid ? slot_of((unsigned)ra.z, (unsigned)ra.w) : kAbsent;
     wave_sync();   // the previous chunk's MFMA reads are done

@@ -481,7 +481,9 @@ __device__ __forceinline__ void edge_core_kb8(int kind, const double* qt, const 
     edge_core_add_rows2(Pm, rh1 * info, -(info * r0) * rh1, -(info * r1) * rh1, Q, g);
   }
   if (kind >= 2) {   // right edge: EdgeSE3ProjectXYZToBody (include/OptimizableTypes.h:125-130, src/OptimizableTypes.cpp:192-213)
-    const double* ro = (kind == 2) ? rec : rec2;
+    // (values, not a pointer, are selected: a pointer into either record would park both in scratch memory)
+    const bool solo = kind == 2;
+    const double ro[4] = {solo ? rec[0] : rec2[0], solo ? rec[1] : rec2[1], 0.0, solo ? rec[3] : rec2[3]};
     const double info = fabs(ro[3]);
     double Rrl[9], Xr[3], Xe[3];
     quat_to_R(trl, Rrl);

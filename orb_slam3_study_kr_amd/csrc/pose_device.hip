@@ -128,7 +128,9 @@ __global__ __launch_bounds__(kPT) void k_pose_opt(PoseView v) {
       double qt[7];
 #pragma unroll
       for (int k = 0; k < 7; ++k) qt[k] = sh_qt[sel][k];
-      double currentChi = pose_eval<KB8>(v, d, qt, robust, sh);
+      // activeRobustChi2 of the current estimate: after the first iteration of a round it is the accepted trial's value (the same
+      // sum over the same edges of the same buffer; an iteration that accepts nothing ends the round)
+      double currentChi = it == 0 ? pose_eval<KB8>(v, d, qt, robust, sh) : last_chi;
       const double iniChi = currentChi;
       // ---- buildSystem: Hpp += Jp^T W Jp, b += Jp^T (-rho' Omega r) over the active edges
       double H[21], b[6];
@@ -195,32 +197,54 @@ __global__ __launch_bounds__(kPT) void k_pose_opt(PoseView v) {
         const int trs = sel ^ 1;
         if (tid == 0) {
           // (Hpp + lambda I) x = b by LDL^T; the solver reports failure unless every pivot is positive
+          // (every loop unrolled: with run-time indices the 6x6 array lives in scratch memory and this one-thread section was
+          // most of an iteration; a non-positive pivot no longer leaves the loop early, its results are simply not used)
           double A[36], x[6];
-          int m = 0;
-          for (int a = 0; a < 6; ++a)
-            for (int c2 = a; c2 < 6; ++c2) { A[a * 6 + c2] = shH[m] + ((a == c2) ? lambda : 0.0); A[c2 * 6 + a] = A[a * 6 + c2]; ++m; }
-          int good = 1;
+          {
+            int m = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+              for (int c2 = a; c2 < 6; ++c2) { A[a * 6 + c2] = shH[m] + ((a == c2) ? lambda : 0.0); ++m; }
+          }
+          bool good = true;
+#pragma unroll
           for (int k = 0; k < 6; ++k) {
             const double dk = A[k * 6 + k];
-            if (!(dk > 0.0)) { good = 0; break; }
+            good = good && (dk > 0.0);
             double l[6];
+#pragma unroll
             for (int i = k + 1; i < 6; ++i) l[i] = A[k * 6 + i] / dk;
+#pragma unroll
             for (int i = k + 1; i < 6; ++i)
+#pragma unroll
               for (int j = i; j < 6; ++j) A[i * 6 + j] -= l[i] * A[k * 6 + j];
+#pragma unroll
             for (int i = k + 1; i < 6; ++i) A[k * 6 + i] = l[i];
           }
-          for (int k = 0; k < 6; ++k) x[k] = good ? shH[21 + k] : 0.0;
-          if (good) {
-            for (int k = 0; k < 6; ++k) for (int i = k + 1; i < 6; ++i) x[i] -= A[k * 6 + i] * x[k];
-            for (int k = 0; k < 6; ++k) x[k] /= A[k * 6 + k];
-            for (int k = 5; k >= 0; --k) { double s2 = x[k]; for (int i = k + 1; i < 6; ++i) s2 -= A[k * 6 + i] * x[i]; x[k] = s2; }
+#pragma unroll
+          for (int k = 0; k < 6; ++k) x[k] = shH[21 + k];
+#pragma unroll
+          for (int k = 0; k < 6; ++k)
+#pragma unroll
+            for (int i = k + 1; i < 6; ++i) x[i] -= A[k * 6 + i] * x[k];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) x[k] /= A[k * 6 + k];
+#pragma unroll
+          for (int k = 5; k >= 0; --k) {
+            double s2 = x[k];
+#pragma unroll
+            for (int i = k + 1; i < 6; ++i) s2 -= A[k * 6 + i] * x[i];
+            x[k] = s2;
           }
+#pragma unroll
+          for (int k = 0; k < 6; ++k) x[k] = good ? x[k] : 0.0;
           double qin[7], qout[7];
           for (int k = 0; k < 7; ++k) qin[k] = sh_qt[sel][k];
           dev::pose_oplus(x, qin, qout);
           for (int k = 0; k < 7; ++k) sh_qt[trs][k] = qout[k];
           for (int k = 0; k < 6; ++k) sh_x[k] = x[k];
-          sh_ok = good;
+          sh_ok = good ? 1 : 0;
         }
         __syncthreads();
         double qtr[7];

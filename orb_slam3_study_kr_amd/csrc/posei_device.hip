@@ -75,15 +75,16 @@ __device__ __forceinline__ void posei_block_sum_n(double* v, double* shn) {
   }
 }
 
-// A x = b for a symmetric n x n system (n <= 32) held row-major in LDS, by ONE wavefront: lane j keeps column j, the pivot row
+// A x = b for a symmetric n x n system (n <= NMAX = 16 or 32: 15 unknowns of the frame, 30 with the previous frame free) held row-major in LDS, by ONE wavefront: lane j keeps column j, the pivot row
 // is broadcast with v_readlane; returns false unless every pivot is positive (Eigen::LDLT::isPositive).  U: 32 x 33 doubles of
 // LDS scratch for the unit upper factor; x in LDS.
+template <int NMAX>
 __device__ bool posei_solve_wave(const double* A, const double* b, int n, double* U, double* x) {
   const int lane = threadIdx.x & 63;
-  const int j = lane < 32 ? lane : 0;
-  double col[32];
+  const int j = lane < NMAX ? lane : 0;
+  double col[NMAX];
 #pragma unroll
-  for (int r = 0; r < 32; ++r) {
+  for (int r = 0; r < NMAX; ++r) {
     const bool in = r < n && j < n && r <= j;
     const double a = A[in ? r * n + j : 0];
     col[r] = in ? a : (r == j ? 1.0 : 0.0);
@@ -91,27 +92,27 @@ __device__ bool posei_solve_wave(const double* A, const double* b, int n, double
   double zr = lane < n ? b[lane] : 0.0;
   bool bad = false;
 #pragma unroll
-  for (int k = 0; k < 32; ++k) {
+  for (int k = 0; k < NMAX; ++k) {
     const double d = ldlt_readlane(col[k], k);
     bad |= !(d > 0.0);
     const double lk = col[k] / d;                       // l_kj in lane j (j > k)
     const double zk = ldlt_readlane(zr, k);             // z_k is final once the steps before k have been applied
     if (lane > k) zr -= lk * zk;
-    if (lane < 32 && lane > k) U[k * 33 + lane] = lk;
+    if (lane < NMAX && lane > k) U[k * 33 + lane] = lk;
 #pragma unroll
-    for (int i = k + 1; i < 32; ++i) col[i] -= ldlt_readlane(lk, i) * col[k];
+    for (int i = k + 1; i < NMAX; ++i) col[i] -= ldlt_readlane(lk, i) * col[k];
   }
   if (bad) return false;
   // w = z / d, then U x = w from the last column to the first: lane r holds its running entry, the solved one is broadcast
   double dl = 1.0;
 #pragma unroll
-  for (int r = 0; r < 32; ++r) { const double dr = ldlt_readlane(col[r], r); if (r == lane) dl = dr; }
+  for (int r = 0; r < NMAX; ++r) { const double dr = ldlt_readlane(col[r], r); if (r == lane) dl = dr; }
   double t = zr / dl;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-  for (int c = 31; c > 0; --c) {
+  for (int c = NMAX - 1; c > 0; --c) {
     const double xc = ldlt_readlane(t, c);
     if (lane < c) t -= U[lane * 33 + c] * xc;
   }
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(kIT) void k_posei(PoseiView v) {
     for (int it = 0; it < d.iters[round] && ok; ++it) {
       build(robust);
       if (tid < 64) {
-        const bool good = posei_solve_wave(shH, shb, n, shU, shx);   // on failure x keeps the previous values and is still applied
+        const bool good = mode1 ? posei_solve_wave<32>(shH, shb, n, shU, shx) : posei_solve_wave<16>(shH, shb, n, shU, shx);   // on failure x keeps the previous values and is still applied
         if (tid == 0) sh_ok = good ? 1 : 0;
       }
       __syncthreads();
