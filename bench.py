@@ -257,9 +257,10 @@ def run_orb(args, info):
     tot = osh_dist.all_reduce_sum(info, [float(accepted), float(len(pairs))])
     per_step_s = elapsed / steps
     sbp = search_by_projection_end_to_end() if info.rank == 0 else None
+    fuse = fuse_end_to_end() if info.rank == 0 else None
     return dict(matches_per_s=tot[0] / per_step_s, pair_evals_per_s=tot[1] * 4.0e6 / per_step_s,
                 frame_pairs_per_s=tot[1] / per_step_s, accepted_per_pair=tot[0] / max(tot[1], 1),
-                kernel_ms=ms / max(launches, 1), resolve_ms=rms / max(rl, 1), rounds=rounds, pairs_per_gpu=len(pairs), pair0=pairs[0], res=res, sbp=sbp)
+                kernel_ms=ms / max(launches, 1), resolve_ms=rms / max(rl, 1), rounds=rounds, pairs_per_gpu=len(pairs), pair0=pairs[0], res=res, sbp=sbp, fuse=fuse)
 
 
 def search_by_projection_end_to_end(n_kp=2000, n_mp=2000, reps=20):
@@ -290,6 +291,46 @@ def search_by_projection_end_to_end(n_kp=2000, n_mp=2000, reps=20):
                 includes="host gather + H2D + windowed device search + D2H + host replay of the slot occupancy; python harness call overhead too")
 
 
+def fuse_end_to_end(n_kp=2000, n_mp=2000, reps=10):
+    """ORBmatcher::Fuse(pKF, vpMapPoints, th) as LocalMapping::SearchInNeighbors calls it, through the drop-in ORBmatcher.cc:
+    projection gates and candidate lists on the host, one batched device search, the ordered replace / add replay -- wall clock."""
+    from orb_slam3_study_kr_amd import host
+    rng = np.random.Generator(np.random.PCG64(6))
+    f32 = np.float32
+    xy = np.stack([rng.uniform(5, synth.IMG_W - 5, n_kp), rng.uniform(5, synth.IMG_H - 5, n_kp)], axis=1).astype(f32)
+    octave = rng.integers(0, synth.N_LEVELS, n_kp).astype(np.int32)
+    desc = rng.integers(0, 256, (n_kp, 32), dtype=np.uint8)
+    depth_kp = rng.uniform(4, 10, n_kp)
+    uright = np.where(rng.uniform(0, 1, n_kp) < 0.6, xy[:, 0] - float(synth.BF) / depth_kp, -1.0).astype(f32)
+    src = rng.integers(0, n_kp, n_mp)
+    noisy = xy[src] + rng.normal(0, 0.8, (n_mp, 2))
+    depth = depth_kp[src]
+    pos = np.stack([(noisy[:, 0] - float(synth.CX)) / float(synth.FX) * depth, (noisy[:, 1] - float(synth.CY)) / float(synth.FY) * depth, depth], axis=1).astype(f32)
+    mp_desc = desc[src] ^ np.packbits(rng.uniform(0, 1, (n_mp, 256)) < 0.05, axis=1)
+    maxd = (depth * synth.SCALE_FACTORS[octave[src]].astype(np.float64)).astype(f32)
+    mind = (maxd / f32(synth.SCALE_FACTORS[-1]) * f32(0.5)).astype(f32)
+    normal = (pos / np.linalg.norm(pos, axis=1, keepdims=True)).astype(f32)
+    nobs = rng.integers(1, 8, n_mp).astype(np.int32)
+    n_res = n_kp // 2
+    slot_res = -np.ones(n_kp, dtype=np.int32)
+    slot_res[rng.permutation(n_kp)[:n_res]] = np.arange(n_res)
+    res_nobs = rng.integers(0, 8, n_res).astype(np.int32)
+    f = host.HostFrame(xy, octave, desc, uright=uright)
+    try:
+        args = (pos, mp_desc, np.stack([mind, maxd], axis=1), normal, nobs, slot_res, res_nobs)
+        n, _ = f.fuse(*args)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            f.fuse(*args)
+        ms = (time.perf_counter() - t0) / reps * 1e3
+    finally:
+        f.close()
+    return dict(call="ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th=3) through the drop-in ORBmatcher.cc", keypoints=n_kp, map_points=n_mp,
+                fused=int(n), ms_per_call=ms,
+                includes="test harness (builds the keyframe, 2000 + 1000 map points and their observations: most of the time) + projection gates + "
+                         "candidate lists + H2D + device search + D2H + ordered replay")
+
+
 def make_inertial_inputs(args):
     from orb_slam3_study_kr_amd import synth_inertial as si
     base = [si.make_inertial_window(11 + k) for k in range(8)]       # BASELINE.json configs[3] shape
@@ -297,8 +338,9 @@ def make_inertial_inputs(args):
 
 
 def run_inertial(args, info, windows):
-    """BASELINE.json configs[3]: LocalInertialBA windows through osh_liba_solve (one persistent block per window).
-    The call includes the H2D upload and the D2H download (the reference calls it one window at a time)."""
+    """BASELINE.json configs[3]: LocalInertialBA windows through osh_liba_solve (one launch; a group of thread blocks per window: 32
+    for a single window, fewer as the batch grows).  The call includes the H2D upload and the D2H download (the reference calls it
+    one window at a time)."""
     from orb_slam3_study_kr_amd import lba
     solver = lba.LbaSolver(info.local_rank)
     solver.solve_inertial(windows[:1])
@@ -317,8 +359,9 @@ def run_inertial(args, info, windows):
                windows_per_s=len(windows) / batch_s, windows_per_batch=len(windows), single_window_latency_ms=single_ms,
                lm_iterations_mean=float(np.mean([r.iterations for r in res])), includes="H2D upload + D2H download", dtype="f64 (+f32 preintegration getters)")
     # SURVEY.md 8(d) byte model applied to the visual part of the inertial window (d = 3, P = the temporal keyframes): per iteration and
-    # trial (lin + resid) + (schur + back + update + resid).  k_liba is ONE block per window and bound by global-memory latency
-    # (DESIGN.md 4b), so the fraction is tiny by construction; it is reported so that the next round's multi-CU kernel has a yardstick.
+    # trial (lin + resid) + (schur + back + update + resid).  A window is a few MB and its optimisation a chain of barrier-separated
+    # phases on at most one XCD, half of the time in a 150x150 LDL^T on one CU: it is latency bound and the
+    # fraction of the HBM peak is tiny by construction; it is reported as a yardstick.
     alg = 0.0
     for w, r in zip(windows, res):
         E, L, P, F = w.n_edges, w.n_points, w.n_opt, w.n_fixed + w.n_fixed_imu
@@ -330,7 +373,7 @@ def run_inertial(args, info, windows):
         upd = 2 * (P * 56 + L * 24)
         alg += r.iterations * (lin + resid) + r.trials * (schur + back + upd + resid)
     out["roofline"] = dict(bound="hbm", kernel="k_liba", achieved=alg / batch_s / 1e9, peak=8000.0, unit="GB/s", frac=alg / batch_s / 8e12,
-                           traffic=None, note="whole call incl. upload / download; one persistent block per window, latency bound")
+                           traffic=None, note="whole call incl. upload / download; a group of thread blocks per window, latency bound (DESIGN.md 4b)")
     if info.rank == 0 and info.world == 1 and not args.no_cpu_baseline:
         from oracle import binding as ob
         n, t0 = 0, time.perf_counter()
@@ -524,6 +567,8 @@ def main():
                                   "pair_evals_per_s_kernel": pe, "traffic": None}
         if orb_out.get("sbp"):
             out["orb"]["search_by_projection_end_to_end"] = orb_out["sbp"]
+        if orb_out.get("fuse"):
+            out["orb"]["fuse_end_to_end"] = orb_out["fuse"]
     if inertial_out is not None:
         out["inertial"] = inertial_out
     if info.rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:

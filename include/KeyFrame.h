@@ -31,6 +31,12 @@ class KeyFrame {
   std::set<MapPoint*> GetMapPoints();                        // src/KeyFrame.cc:336-349: the non-bad matches
   MapPoint* GetMapPoint(const size_t& idx) { return mvpMapPoints[idx]; }   // src/KeyFrame.cc:373-377
   void EraseMapPointMatch(MapPoint* pMP);
+  void EraseMapPointMatch(const int& idx) { mvpMapPoints[idx] = nullptr; }                  // src/KeyFrame.cc:303-307
+  void AddMapPoint(MapPoint* pMP, const size_t& idx) { mvpMapPoints[idx] = pMP; }           // src/KeyFrame.cc:297-301
+  void ReplaceMapPointMatch(const int& idx, MapPoint* pMP) { mvpMapPoints[idx] = pMP; }     // src/KeyFrame.cc:320-323
+  Eigen::Vector3f GetCameraCenter() { return mTwc.translation(); }                          // src/KeyFrame.cc:143-146
+  Sophus::SE3f GetRightPose() { return mTrl * mTcw; }                                       // src/KeyFrame.cc:1120-1124
+  Eigen::Vector3f GetRightCameraCenter() { return (mTwc * mTrl.inverse()).translation(); }  // src/KeyFrame.cc:1132-1136 (mTlr = mTrl^-1)
   Sophus::SE3f GetRelativePoseTrl() { return mTrl; }
   bool isBad() { return mbBad; }
   Map* GetMap() { return mpMap; }

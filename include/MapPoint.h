@@ -21,6 +21,12 @@ class MapPoint {
   void AddObservation(KeyFrame* pKF, int idx);
   void EraseObservation(KeyFrame* pKF);
   bool isBad() { return mbBad; }
+  bool IsInKeyFrame(KeyFrame* pKF) { return mObservations.count(pKF) != 0; }   // src/MapPoint.cc:420-424
+  void Replace(MapPoint* pMP);                                                  // src/MapPoint.cc:248-297
+  MapPoint* GetReplaced() { return mpReplaced; }
+  void IncreaseVisible(int n = 1) { mnVisible += n; }
+  void IncreaseFound(int n = 1) { mnFound += n; }
+  void ComputeDistinctiveDescriptors() { ++mnDescriptorUpdates; }
   Map* GetMap() { return mpMap; }
   void UpdateNormalAndDepth() { ++mnNormalUpdates; }
   cv::Mat GetDescriptor() { return mDescriptor.clone(); }
@@ -52,6 +58,8 @@ class MapPoint {
   Map* mpMap;
   cv::Mat mDescriptor;
   int mnNormalUpdates = 0;
+  MapPoint* mpReplaced = nullptr;
+  int mnVisible = 1, mnFound = 1, mnDescriptorUpdates = 0;
 };
 }  // namespace ORB_SLAM3
 #endif

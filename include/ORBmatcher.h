@@ -35,6 +35,8 @@ class ORBmatcher {
   int SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches);
   // src/ORBmatcher.cc:765-905 (loop closing / map merging): map points of keyframe 1 against the map points of keyframe 2 of the same node
   int SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12);
+  // Project MapPoints into KeyFrame and search for duplicated MapPoints (include/ORBmatcher.h:87, src/ORBmatcher.cc:1148-1338)
+  int Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const float th = 3.0, const bool bRight = false);
   static const int TH_LOW;
   static const int TH_HIGH;
   static const int HISTO_LENGTH;

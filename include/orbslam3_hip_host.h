@@ -160,6 +160,16 @@ int osh_host_search_sim3(osh_host_frame* f, const float scw[8], int32_t n_mp, co
                          const float* mp_min_max_dist, const float* mp_normal, const uint8_t* mp_bad,
                          const int32_t* matched_in, int32_t th, float ratio_hamming, int32_t with_keyframes,
                          int32_t* matched_out, int32_t* matched_kf_out);
+/* ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:1148-1338): the keyframe is made from `f` (its pose,
+ * keypoints, grid, mvuRight).  Candidate map points j (null_mask[j]: a null entry) with world position, descriptor, {mfMinDistance,
+ * mfMaxDistance}, normal, isBad(), Observations(); resident map points r already sitting in keypoint slots (slot_res[k] = r or -1).
+ * Ids in the outputs: candidate j -> j, resident r -> 100000 + r, none -> -1.  slot_out[k]: the keyframe's match at keypoint k
+ * afterwards; *_replaced_out: GetReplaced(); *_nobs_out: Observations() afterwards.  Returns nFused. */
+int osh_host_fuse(osh_host_frame* f, int32_t n_mp, const float* mp_pos, const uint8_t* mp_desc, const float* mp_min_max_dist,
+                  const float* mp_normal, const uint8_t* mp_bad, const uint8_t* null_mask, const int32_t* mp_nobs,
+                  int32_t n_res, const int32_t* slot_res, const int32_t* res_nobs, const uint8_t* res_bad, float th,
+                  int32_t* slot_out, uint8_t* cand_bad_out, int32_t* cand_replaced_out, int32_t* cand_nobs_out,
+                  uint8_t* res_bad_out, int32_t* res_replaced_out, int32_t* res_nobs_out);
 /* Optimizer::PoseOptimization(&frame) (src/Optimizer.cc:815-1114): kp_mp[k] = map point matched to keypoint k (-1 none);
  * returns the inlier count, the optimised pose and mvbOutlier (keypoints without a match keep the value 1 they are preset to). */
 int osh_host_frame_pose_optimization(osh_host_frame* f, int32_t n_mp, const float* mp_pos, const int32_t* kp_mp,

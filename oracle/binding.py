@@ -428,3 +428,29 @@ def orb_search_by_bow_kf(desc1, desc2, has_mp1, has_mp2, fv1, fv2, angle1, angle
                                         a1.ctypes.data_as(C.POINTER(C.c_float)), a2.ctypes.data_as(C.POINTER(C.c_float)), C.c_float(nn_ratio),
                                         int(th_low), int(check_ori), _i32(m))
     return int(n), m
+
+
+def orb_fuse(q_desc, feat_desc, skip, cand_off, cand_idx, stereo, slot, nobs, bad, th_low=50):
+    """ORBmatcher::Fuse after its projection gates, restated sequentially (orb_oracle.c:oracle_orb_fuse).  skip: 0 candidate passes
+    the gates, 1 fails one, 2 null entry.  slot[k] = id at feature k (-1 none); nobs / bad indexed [candidates..., residents...]
+    (resident r has id 100000 + r).  Returns nFused and the final slot, nobs, bad, replaced arrays."""
+    lib = load()
+    i32, u8 = C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+    lib.oracle_orb_fuse.restype = C.c_int
+    lib.oracle_orb_fuse.argtypes = [C.c_int, C.c_int, C.c_int, u8, u8, u8, i32, i32, u8, C.c_int, i32, i32, u8, i32, u8]
+    qd, fd = np.ascontiguousarray(q_desc, dtype=np.uint8), np.ascontiguousarray(feat_desc, dtype=np.uint8)
+    sk, st = np.ascontiguousarray(skip, dtype=np.uint8), np.ascontiguousarray(stereo, dtype=np.uint8)
+    off, idx = np.ascontiguousarray(cand_off, dtype=np.int32), np.ascontiguousarray(cand_idx if len(cand_idx) else [0], dtype=np.int32)
+    slot = np.array(slot, dtype=np.int32)
+    nobs = np.array(nobs, dtype=np.int32)
+    bad = np.array(bad, dtype=np.uint8)
+    n_q = qd.shape[0]
+    n_res = len(nobs) - n_q
+    replaced = -np.ones(len(nobs), dtype=np.int32)
+    in_kf = np.zeros(len(nobs), dtype=np.uint8)
+    for k in range(len(slot)):
+        if slot[k] >= 100000:
+            in_kf[n_q + slot[k] - 100000] = 1
+    n = lib.oracle_orb_fuse(n_q, n_res, fd.shape[0], _u8(qd), _u8(fd), _u8(sk), _i32(off), _i32(idx), _u8(st), int(th_low), _i32(slot), _i32(nobs),
+                            _u8(bad), _i32(replaced), _u8(in_kf))
+    return int(n), slot, nobs, bad, replaced

@@ -438,3 +438,55 @@ int oracle_orb_search_by_bow_kf(int n1, int n2, int lim1, int lim2, const uint8_
   free(matched2);
   return nmatches;
 }
+
+
+/* ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th, bRight) -- src/ORBmatcher.cc:1148-1338, the part after the projection
+ * gates: candidate point q (in vpMapPoints order; skip[q]: null, or fails a gate of :1198-1253) has the feature list
+ * cand_idx[cand_off[q] .. cand_off[q+1]) (GetFeaturesInArea order, level and chi2 gates of :1263-1300 applied).  Best = first
+ * strictly smaller distance (:1307-1311); bestDist <= th_low: the slot's resident is replaced by / replaces the candidate
+ * according to Observations() (:1316-1326, MapPoint::Replace src/MapPoint.cc:248-297), or the candidate is added (:1328-1332).
+ * State: slot[k] = id of the keyframe's match at feature k (-1 none); points by id: candidates [0, n_q), residents 100000 + r.
+ * nobs / bad / replaced / in_kf are indexed by "point index" = id for candidates, n_q + r for residents.  Every observation of a
+ * point outside this keyframe is in a monocular keyframe no other point is seen in (so Replace moves each of them: +1), an
+ * observation in this keyframe counts 2 when stereo[k] (mvuRight[k] >= 0, src/MapPoint.cc:140-165) else 1.  Returns nFused. */
+int oracle_orb_fuse(int n_q, int n_res, int n_feat, const uint8_t* q_desc, const uint8_t* feat_desc, const uint8_t* skip,
+                    const int32_t* cand_off, const int32_t* cand_idx, const uint8_t* stereo, int th_low,
+                    int32_t* slot, int32_t* nobs, uint8_t* bad, int32_t* replaced, uint8_t* in_kf) {
+  (void)n_feat;
+  int n_fused = 0;
+#define PIDX(id) ((id) >= 100000 ? n_q + ((id) - 100000) : (id))
+  for (int q = 0; q < n_q; ++q) {
+    if (skip[q] == 2) continue;                    /* null entry */
+    if (bad[q]) continue;
+    if (in_kf[q]) continue;
+    if (skip[q]) continue;
+    int best_dist = 256, best_idx = -1;
+    for (int c = cand_off[q]; c < cand_off[q + 1]; ++c) {
+      const int d = oracle_descriptor_distance(q_desc + 32 * (size_t)q, feat_desc + 32 * (size_t)cand_idx[c]);
+      if (d < best_dist) { best_dist = d; best_idx = cand_idx[c]; }
+    }
+    if (best_dist > th_low) continue;
+    const int w = stereo[best_idx] ? 2 : 1;
+    const int res_id = slot[best_idx];
+    if (res_id >= 0) {
+      const int r = PIDX(res_id);
+      if (!bad[r]) {
+        if (nobs[r] > nobs[q]) {
+          /* pMP->Replace(pMPinKF): the candidate's observations (none in this keyframe) move to the resident */
+          nobs[r] += nobs[q]; nobs[q] = nobs[q];   /* Observations() of a replaced point keeps its count (nObs is not reset) */
+          bad[q] = 1; replaced[q] = res_id;
+        } else {
+          /* pMPinKF->Replace(pMP): the resident's observations move to the candidate; the one in this keyframe re-points the slot */
+          nobs[q] += (nobs[r] - w) + w;
+          bad[r] = 1; replaced[r] = q; in_kf[r] = 0;
+          slot[best_idx] = q; in_kf[q] = 1;
+        }
+      }
+    } else {
+      nobs[q] += w; in_kf[q] = 1; slot[best_idx] = q;
+    }
+    ++n_fused;
+  }
+#undef PIDX
+  return n_fused;
+}

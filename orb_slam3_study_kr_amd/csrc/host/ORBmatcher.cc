@@ -698,6 +698,92 @@ bool device_search_lists(const std::vector<uint8_t>& qdesc, const cv::Mat& train
 
 }  // namespace
 
+// src/ORBmatcher.cc:1148-1338.  Every map point is projected into the keyframe and its candidate list (the features in the search
+// radius that pass the level and the reprojection-chi2 gates, in GetFeaturesInArea's order) is formed up front: none of that depends
+// on what the loop does to earlier points.  ONE batched device search gives the best candidate of every point; the part that is
+// order dependent -- "already in the keyframe", Replace in either direction, AddObservation / AddMapPoint -- is replayed in the
+// reference's order on the map itself.
+int ORBmatcher::Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const float th, const bool bRight) {
+  GeometricCamera* pCamera;
+  Sophus::SE3f Tcw;
+  Eigen::Vector3f Ow;
+  if (bRight) { Tcw = pKF->GetRightPose(); Ow = pKF->GetRightCameraCenter(); pCamera = pKF->mpCamera2; }
+  else { Tcw = pKF->GetPose(); Ow = pKF->GetCameraCenter(); pCamera = pKF->mpCamera; }
+  const float& bf = pKF->mbf;
+  const int nMPs = (int)vpMapPoints.size();
+  std::vector<int> qOf(nMPs, -1);            // map point -> query of the device search (-1: fails a gate that does not depend on the loop)
+  std::vector<uint8_t> qdesc;
+  std::vector<int32_t> off(1, 0), idx;
+  int nq = 0;
+  for (int i = 0; i < nMPs; i++) {
+    MapPoint* pMP = vpMapPoints[i];
+    if (!pMP) continue;
+    const Eigen::Vector3f p3Dw = pMP->GetWorldPos();
+    const Eigen::Vector3f p3Dc = Tcw * p3Dw;
+    if (p3Dc(2) < 0.0f) continue;                                   // depth must be positive
+    const float invz = 1 / p3Dc(2);
+    const Eigen::Vector2f uv = pCamera->project(p3Dc);
+    if (!pKF->IsInImage(uv(0), uv(1))) continue;                    // point must be inside the image
+    const float ur = uv(0) - bf * invz;
+    const float maxDistance = pMP->GetMaxDistanceInvariance();
+    const float minDistance = pMP->GetMinDistanceInvariance();
+    const float px = p3Dw(0) - Ow(0), py = p3Dw(1) - Ow(1), pz = p3Dw(2) - Ow(2);
+    const float dist3D = std::sqrt(px * px + py * py + pz * pz);
+    if (dist3D < minDistance || dist3D > maxDistance) continue;     // inside the scale pyramid of the image
+    const Eigen::Vector3f Pn = pMP->GetNormal();
+    if (px * Pn(0) + py * Pn(1) + pz * Pn(2) < 0.5 * dist3D) continue;   // viewing angle below 60 degrees
+    const int nPredictedLevel = pMP->PredictScale(dist3D, pKF);
+    const float radius = th * pKF->mvScaleFactors[nPredictedLevel];
+    const std::vector<size_t> vIndices = pKF->GetFeaturesInArea(uv(0), uv(1), radius, bRight);
+    if (vIndices.empty()) continue;
+    for (size_t k : vIndices) {
+      const cv::KeyPoint& kp = (pKF->NLeft == -1) ? pKF->mvKeysUn[k] : (!bRight) ? pKF->mvKeys[k] : pKF->mvKeysRight[k];
+      const int& kpLevel = kp.octave;
+      if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+      const float ex = uv(0) - kp.pt.x, ey = uv(1) - kp.pt.y;
+      if (pKF->mvuRight[k] >= 0) {                                  // reprojection error in stereo
+        const float er = ur - pKF->mvuRight[k];
+        const float e2 = ex * ex + ey * ey + er * er;
+        if (e2 * pKF->mvInvLevelSigma2[kpLevel] > 7.8) continue;
+      } else {
+        const float e2 = ex * ex + ey * ey;
+        if (e2 * pKF->mvInvLevelSigma2[kpLevel] > 5.99) continue;
+      }
+      idx.push_back((int32_t)(bRight ? k + pKF->NLeft : k));
+    }
+    off.push_back((int32_t)idx.size());
+    const cv::Mat dMP = pMP->GetDescriptor();
+    qdesc.insert(qdesc.end(), dMP.ptr<uint8_t>(0), dMP.ptr<uint8_t>(0) + 32);
+    qOf[i] = nq++;
+  }
+  std::vector<int32_t> best, bestD, secondD, secondI;
+  if (nq > 0 && !device_search_lists(qdesc, pKF->mDescriptors, pKF->mDescriptors.rows, off, idx, best, bestD, secondD, secondI)) return 0;
+
+  int nFused = 0;
+  for (int i = 0; i < nMPs; i++) {
+    MapPoint* pMP = vpMapPoints[i];
+    if (!pMP) continue;
+    if (pMP->isBad()) continue;
+    else if (pMP->IsInKeyFrame(pKF)) continue;
+    if (qOf[i] < 0) continue;
+    const int bestDist = bestD[qOf[i]], bestIdx = best[qOf[i]];
+    if (bestIdx >= 0 && bestDist <= TH_LOW) {                       // already a MapPoint there: replace, otherwise add the measurement
+      MapPoint* pMPinKF = pKF->GetMapPoint(bestIdx);
+      if (pMPinKF) {
+        if (!pMPinKF->isBad()) {
+          if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+          else pMPinKF->Replace(pMP);
+        }
+      } else {
+        pMP->AddObservation(pKF, bestIdx);
+        pKF->AddMapPoint(pMP, bestIdx);
+      }
+      nFused++;
+    }
+  }
+  return nFused;
+}
+
 // src/ORBmatcher.cc:223-420.  The candidate loops of every keyframe feature run as batched device searches over the feature
 // lists of its vocabulary node (one search for the left / only camera, one for the right camera of a fisheye stereo frame); the
 // "frame feature already matched" rule (:266-268) makes the loop sequential, so the queries are replayed in the reference's

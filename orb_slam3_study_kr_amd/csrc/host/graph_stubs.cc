@@ -45,6 +45,30 @@ void MapPoint::AddObservation(KeyFrame* pKF, int idx) {
   else nObs++;
 }
 
+// src/MapPoint.cc:248-297: this point hands its observations to pMP and goes bad
+void MapPoint::Replace(MapPoint* pMP) {
+  if (pMP->mnId == this->mnId) return;
+  std::map<KeyFrame*, std::tuple<int, int>> obs = mObservations;
+  mObservations.clear();
+  mbBad = true;
+  const int nvisible = mnVisible, nfound = mnFound;
+  mpReplaced = pMP;
+  for (auto& ob : obs) {
+    KeyFrame* pKF = ob.first;
+    const int leftIndex = std::get<0>(ob.second), rightIndex = std::get<1>(ob.second);
+    if (!pMP->IsInKeyFrame(pKF)) {
+      if (leftIndex != -1) { pKF->ReplaceMapPointMatch(leftIndex, pMP); pMP->AddObservation(pKF, leftIndex); }
+      if (rightIndex != -1) { pKF->ReplaceMapPointMatch(rightIndex, pMP); pMP->AddObservation(pKF, rightIndex); }
+    } else {
+      if (leftIndex != -1) pKF->EraseMapPointMatch(leftIndex);
+      if (rightIndex != -1) pKF->EraseMapPointMatch(rightIndex);
+    }
+  }
+  pMP->IncreaseFound(nfound);
+  pMP->IncreaseVisible(nvisible);
+  pMP->ComputeDistinctiveDescriptors();
+}
+
 // src/MapPoint.cc:168-201: drop the observation; a point left with <= 2 observations goes bad
 // src/MapPoint.cc:531-546 (float ratio, float log: `log(ratio)` resolves to the float overload there)
 int MapPoint::PredictScale(const float& currentDist, Frame* pF) {

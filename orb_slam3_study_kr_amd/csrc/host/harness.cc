@@ -633,6 +633,78 @@ extern "C" int osh_host_search_sim3(osh_host_frame* f, const float scw[8], int32
   return n;
 }
 
+// ORBmatcher::Fuse(pKF, vpMapPoints, th) with the frame standing in for the keyframe (pose = the frame's).  Candidates j in
+// [0, n_mp) (null_mask[j]: a null entry of vpMapPoints), residents r in [0, n_res) sitting in keypoint slots (slot_res[k] = r or
+// -1).  Every point starts with n_obs observations in keyframes of its own (monocular dummies), residents in this keyframe too.
+// Outputs use ids: candidate j -> j, resident r -> 100000 + r, none -> -1.
+extern "C" int osh_host_fuse(osh_host_frame* f, int32_t n_mp, const float* mp_pos, const uint8_t* mp_desc, const float* mp_min_max_dist,
+                             const float* mp_normal, const uint8_t* mp_bad, const uint8_t* null_mask, const int32_t* mp_nobs,
+                             int32_t n_res, const int32_t* slot_res, const int32_t* res_nobs, const uint8_t* res_bad, float th,
+                             int32_t* slot_out, uint8_t* cand_bad_out, int32_t* cand_replaced_out, int32_t* cand_nobs_out,
+                             uint8_t* res_bad_out, int32_t* res_replaced_out, int32_t* res_nobs_out) {
+  if (!f) return -1;
+  Frame& F = f->F;
+  KeyFrame kf(1, &f->map);
+  kf.N = F.N;
+  kf.mvKeys = F.mvKeys; kf.mvKeysUn = F.mvKeysUn; kf.mvuRight = F.mvuRight;
+  kf.mDescriptors = F.mDescriptors;
+  kf.mvScaleFactors = F.mvScaleFactors; kf.mnScaleLevels = F.mnScaleLevels; kf.mfLogScaleFactor = F.mfLogScaleFactor;
+  kf.mvInvLevelSigma2.assign(F.mnScaleLevels, 1.0f);
+  for (int l = 0; l < F.mnScaleLevels; ++l) kf.mvInvLevelSigma2[l] = 1.0f / (F.mvScaleFactors[l] * F.mvScaleFactors[l]);   // src/ORBextractor.cc:414-422
+  kf.mpCamera = F.mpCamera;
+  kf.fx = F.fx; kf.fy = F.fy; kf.cx = F.cx; kf.cy = F.cy; kf.mbf = F.mbf;
+  kf.mnGridCols = FRAME_GRID_COLS; kf.mnGridRows = FRAME_GRID_ROWS;
+  kf.mfGridElementWidthInv = F.mfGridElementWidthInv; kf.mfGridElementHeightInv = F.mfGridElementHeightInv;
+  kf.mnMinX = (int)F.mnMinX; kf.mnMinY = (int)F.mnMinY; kf.mnMaxX = (int)F.mnMaxX; kf.mnMaxY = (int)F.mnMaxY;
+  kf.mGrid.assign(FRAME_GRID_COLS, std::vector<std::vector<size_t>>(FRAME_GRID_ROWS));
+  for (int i = 0; i < FRAME_GRID_COLS; ++i)
+    for (int j = 0; j < FRAME_GRID_ROWS; ++j) kf.mGrid[i][j] = F.mGrid[i][j];
+  kf.mvpMapPoints.assign(F.N, nullptr);
+  kf.SetPose(F.GetPose());
+  auto cands = make_points(&f->map, n_mp, mp_desc, mp_pos, nullptr);
+  std::vector<uint8_t> zero_desc((size_t)std::max(n_res, 1) * 32, 0);
+  auto residents = make_points(&f->map, n_res, zero_desc.data(), nullptr, nullptr);
+  std::vector<std::unique_ptr<KeyFrame>> others;
+  auto give_observations = [&](MapPoint* p, int n) {   // n observations in monocular keyframes nobody else sees
+    p->nObs = 0;
+    for (int k = 0; k < n; ++k) {
+      others.emplace_back(new KeyFrame((unsigned long)(10 + others.size()), &f->map));
+      KeyFrame* o = others.back().get();
+      o->N = 1; o->mvuRight.assign(1, -1.f); o->mvpMapPoints.assign(1, p);
+      p->AddObservation(o, 0);
+    }
+  };
+  for (int j = 0; j < n_mp; ++j) {
+    cands[j]->mfMinDistance = mp_min_max_dist[2 * j]; cands[j]->mfMaxDistance = mp_min_max_dist[2 * j + 1];
+    cands[j]->mNormalVector = Eigen::Vector3f(mp_normal[3 * j], mp_normal[3 * j + 1], mp_normal[3 * j + 2]);
+    give_observations(cands[j].get(), mp_nobs[j]);
+    if (mp_bad && mp_bad[j]) cands[j]->mbBad = true;
+  }
+  for (int r = 0; r < n_res; ++r) {
+    residents[r]->mnId = 100000 + (unsigned long)r;
+    give_observations(residents[r].get(), res_nobs[r]);
+    if (res_bad && res_bad[r]) residents[r]->mbBad = true;
+  }
+  for (int k = 0; k < F.N; ++k)
+    if (slot_res[k] >= 0) { kf.mvpMapPoints[k] = residents[slot_res[k]].get(); residents[slot_res[k]]->AddObservation(&kf, k); }
+  std::vector<MapPoint*> vpMapPoints;
+  for (int j = 0; j < n_mp; ++j) vpMapPoints.push_back((null_mask && null_mask[j]) ? nullptr : cands[j].get());
+  ORBmatcher matcher(0.6f, true);
+  const int n = matcher.Fuse(&kf, vpMapPoints, th);
+  for (int k = 0; k < F.N; ++k) slot_out[k] = kf.mvpMapPoints[k] ? (int32_t)kf.mvpMapPoints[k]->mnId : -1;
+  for (int j = 0; j < n_mp; ++j) {
+    cand_bad_out[j] = cands[j]->isBad() ? 1 : 0;
+    cand_replaced_out[j] = cands[j]->GetReplaced() ? (int32_t)cands[j]->GetReplaced()->mnId : -1;
+    cand_nobs_out[j] = cands[j]->Observations();
+  }
+  for (int r = 0; r < n_res; ++r) {
+    res_bad_out[r] = residents[r]->isBad() ? 1 : 0;
+    res_replaced_out[r] = residents[r]->GetReplaced() ? (int32_t)residents[r]->GetReplaced()->mnId : -1;
+    res_nobs_out[r] = residents[r]->Observations();
+  }
+  return n;
+}
+
 // Optimizer::PoseOptimization(&frame): kp_mp[k] = map point matched to keypoint k (-1 none), map points by position.
 extern "C" int osh_host_frame_pose_optimization(osh_host_frame* f, int32_t n_mp, const float* mp_pos, const int32_t* kp_mp,
                                                 const float* inv_level_sigma2, int32_t n_levels, float pose_out[7], uint8_t* outlier_out) {

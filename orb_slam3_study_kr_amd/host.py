@@ -354,6 +354,30 @@ class HostFrame:
         return n, out, out_kf
 
 
+    def fuse(self, mp_pos, mp_desc, mp_min_max_dist, mp_normal, mp_nobs, slot_res, res_nobs, mp_bad=None, null_mask=None, res_bad=None, th=3.0):
+        """ORBmatcher::Fuse(pKF, vpMapPoints, th) (src/ORBmatcher.cc:1148-1338) with this frame turned into the keyframe.  Returns
+        nFused and a dict: slot (the keyframe's matches afterwards), cand_bad / cand_replaced / cand_nobs, res_bad / res_replaced /
+        res_nobs (ids: candidate j -> j, resident r -> 100000 + r, none -> -1)."""
+        u8 = lambda a: np.ascontiguousarray(a, dtype=np.uint8)
+        n_mp, n_res = len(mp_pos), len(res_nobs)
+        zeros = np.zeros(max(n_mp, n_res, 1))
+        keep = [_f32(mp_pos), u8(mp_desc), _f32(mp_min_max_dist), _f32(mp_normal), u8(mp_bad if mp_bad is not None else zeros[:n_mp]),
+                u8(null_mask if null_mask is not None else zeros[:n_mp]), _i32(mp_nobs), _i32(slot_res), _i32(res_nobs),
+                u8(res_bad if res_bad is not None else zeros[:n_res])]
+        out = dict(slot=-np.ones(self.n, dtype=np.int32), cand_bad=np.zeros(n_mp, dtype=np.uint8), cand_replaced=-np.ones(n_mp, dtype=np.int32),
+                   cand_nobs=np.zeros(n_mp, dtype=np.int32), res_bad=np.zeros(max(n_res, 1), dtype=np.uint8),
+                   res_replaced=-np.ones(max(n_res, 1), dtype=np.int32), res_nobs=np.zeros(max(n_res, 1), dtype=np.int32))
+        fp, ip, bp = capi.c_float_p, capi.c_int32_p, capi.c_uint8_p
+        n = self.lib.osh_host_fuse(self.f, n_mp, capi.ptr(keep[0], fp), capi.ptr(keep[1], bp), capi.ptr(keep[2], fp), capi.ptr(keep[3], fp),
+                                   capi.ptr(keep[4], bp), capi.ptr(keep[5], bp), capi.ptr(keep[6], ip), n_res, capi.ptr(keep[7], ip),
+                                   capi.ptr(keep[8], ip), capi.ptr(keep[9], bp), float(th), capi.ptr(out["slot"], ip), capi.ptr(out["cand_bad"], bp),
+                                   capi.ptr(out["cand_replaced"], ip), capi.ptr(out["cand_nobs"], ip), capi.ptr(out["res_bad"], bp),
+                                   capi.ptr(out["res_replaced"], ip), capi.ptr(out["res_nobs"], ip))
+        for k in ("res_bad", "res_replaced", "res_nobs"):
+            out[k] = out[k][:n_res]
+        return n, out
+
+
 def _quat_from_R(R):
     return synth._quat_from_R(np.asarray(R, dtype=np.float64))
 

@@ -561,6 +561,111 @@ def test_search_by_projection_sim3_equals_sequential_reference(ob, with_keyframe
     assert side.any() and bad.any()
 
 
+def test_fuse_equals_sequential_reference(ob):
+    """ORBmatcher::Fuse(pKF, vpMapPoints, th) (src/ORBmatcher.cc:1148-1338) on a stereo keyframe: projection gates (depth, image,
+    scale-pyramid distance, 60 degree viewing angle), candidates by GetFeaturesInArea with the level and the reprojection-chi2 gates
+    (5.99 mono / 7.8 stereo), best Hamming distance <= TH_LOW, then -- in order -- Replace in either direction by Observations() or
+    AddObservation + AddMapPoint.  The candidate lists are formed here in float32 numpy, the order-dependent part is the oracle's."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    f32 = np.float32
+    n_kp, n_mp = 700, 900
+    xy, octave, desc, _, _, _, _ = _frame_and_points(31, n_kp=n_kp, n_mp=10)
+    fx, fy, cx, cy = (f32(v) for v in (synth.FX, synth.FY, synth.CX, synth.CY))
+    bf = f32(synth.BF)
+    t = np.array([0.1, -0.05, 0.2], dtype=f32)                          # Tcw = (I, t)
+    depth_kp = rng.uniform(4, 10, n_kp)
+    uright = np.where(rng.uniform(0, 1, n_kp) < 0.6, xy[:, 0] - float(bf) / depth_kp, -1.0).astype(f32)   # 60 % stereo keypoints
+    # candidates: most are noisy copies of a keypoint's landmark (several per keypoint: later ones meet an occupied slot), some random
+    src = rng.integers(0, n_kp, n_mp)
+    noisy = xy[src] + rng.normal(0, 0.8, (n_mp, 2))
+    depth = depth_kp[src] * rng.uniform(0.98, 1.02, n_mp)
+    Xc = np.stack([(noisy[:, 0] - float(cx)) / float(fx) * depth, (noisy[:, 1] - float(cy)) / float(fy) * depth, depth], axis=1)
+    behind = rng.uniform(0, 1, n_mp) < 0.03
+    Xc[behind, 2] *= -1
+    pos = (Xc - t.astype(np.float64)).astype(f32)
+    mp_desc = desc[src] ^ np.packbits(rng.uniform(0, 1, (n_mp, 256)) < 0.05, axis=1)
+    far = rng.uniform(0, 1, n_mp) < 0.1
+    mp_desc[far] = rng.integers(0, 256, (int(far.sum()), 32), dtype=np.uint8)                              # no match within TH_LOW
+    maxd = (depth * synth.SCALE_FACTORS[octave[src]].astype(np.float64) * rng.uniform(0.9, 1.05, n_mp)).astype(f32)
+    mind = (maxd / f32(synth.SCALE_FACTORS[-1]) * f32(0.5)).astype(f32)
+    Ow = (-t).astype(f32)
+    PO = (pos - Ow).astype(f32)
+    normal = (PO / np.linalg.norm(PO, axis=1, keepdims=True)).astype(f32)
+    side = rng.uniform(0, 1, n_mp) < 0.04
+    normal[side] = np.array([1.0, 0.0, 0.0], dtype=f32)
+    bad = rng.uniform(0, 1, n_mp) < 0.03
+    null = rng.uniform(0, 1, n_mp) < 0.02
+    nobs = rng.integers(1, 8, n_mp).astype(np.int32)
+    # residents in 40 % of the slots, a few of them bad
+    n_res = int(0.4 * n_kp)
+    slot_res = -np.ones(n_kp, dtype=np.int32)
+    slot_res[rng.permutation(n_kp)[:n_res]] = np.arange(n_res)
+    res_nobs = rng.integers(0, 8, n_res).astype(np.int32)
+    res_bad = rng.uniform(0, 1, n_res) < 0.05
+    th = 3.0
+    kf = host.HostFrame(xy, octave, desc, uright=uright, pose_qt=np.array([0, 0, 0, 1, *t], dtype=np.float64))
+    try:
+        n, out = kf.fuse(pos, mp_desc, np.stack([mind, maxd], axis=1), normal, nobs, slot_res, res_nobs, mp_bad=bad, null_mask=null, res_bad=res_bad, th=th)
+    finally:
+        kf.close()
+    # ---- projection gates and candidate lists in float32 (the expressions of :1196-1300)
+    pc = (pos + t).astype(f32)
+    invz = (f32(1) / pc[:, 2]).astype(f32)
+    u = (fx * pc[:, 0] / pc[:, 2] + cx).astype(f32)                      # Pinhole::project (src/CameraModels/Pinhole.cpp:47-53)
+    v = (fy * pc[:, 1] / pc[:, 2] + cy).astype(f32)
+    ur = (u - (bf * invz).astype(f32)).astype(f32)
+    dist = np.sqrt((PO[:, 0] * PO[:, 0] + PO[:, 1] * PO[:, 1]).astype(f32) + (PO[:, 2] * PO[:, 2]).astype(f32)).astype(f32)
+    dot = ((PO[:, 0] * normal[:, 0] + PO[:, 1] * normal[:, 1]).astype(f32) + (PO[:, 2] * normal[:, 2]).astype(f32)).astype(f32)
+    ok = (pc[:, 2] >= 0) & (u >= 0) & (u < synth.IMG_W) & (v >= 0) & (v < synth.IMG_H)
+    ok &= ~((dist < f32(0.8) * mind) | (dist > f32(1.2) * maxd))
+    ok &= ~(dot.astype(np.float64) < 0.5 * dist.astype(np.float64))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        lvl = np.clip(np.ceil(np.log((maxd / dist).astype(f32)) / np.log(f32(synth.SCALE_FACTOR))).astype(np.int64), 0, synth.N_LEVELS - 1).astype(np.int32)
+    radius = (f32(th) * synth.SCALE_FACTORS[lvl]).astype(f32)
+    qsel = np.nonzero(ok)[0]
+    off0, idx0 = synth.features_in_area_lists(xy[:, 0], xy[:, 1], octave, u[qsel], v[qsel], radius[qsel], None, None)
+    inv_sigma2 = (f32(1) / (synth.SCALE_FACTORS.astype(f32) * synth.SCALE_FACTORS.astype(f32))).astype(f32)
+    skip = np.ones(n_mp, dtype=np.uint8)
+    off, idx = [0], []
+    for a, q in enumerate(qsel):
+        c = idx0[off0[a]:off0[a + 1]]
+        if len(c):                                                       # an empty window skips the point (:1256-1260)
+            skip[q] = 0
+            keep = (octave[c] >= lvl[q] - 1) & (octave[c] <= lvl[q])
+            ex, ey = (u[q] - xy[c, 0]).astype(f32), (v[q] - xy[c, 1]).astype(f32)
+            e2m = ((ex * ex).astype(f32) + (ey * ey).astype(f32)).astype(f32)
+            er = (ur[q] - uright[c]).astype(f32)
+            e2s = (e2m + (er * er).astype(f32)).astype(f32)
+            st = uright[c] >= 0
+            chi = np.where(st, (e2s * inv_sigma2[octave[c]]).astype(f32), (e2m * inv_sigma2[octave[c]]).astype(f32)).astype(np.float64)
+            keep &= ~(chi > np.where(st, 7.8, 5.99))
+            idx.extend(c[keep].tolist())
+        off.append(len(idx))
+    skip[null] = 2
+    full_off = np.zeros(n_mp + 1, dtype=np.int32)                        # lists for every candidate (empty for the skipped ones)
+    lens = np.zeros(n_mp, dtype=np.int32)
+    lens[qsel] = np.diff(np.array(off, dtype=np.int32))
+    full_off[1:] = np.cumsum(lens)
+    stereo = (uright >= 0).astype(np.uint8)
+    slot0 = np.where(slot_res >= 0, 100000 + slot_res, -1).astype(np.int32)
+    w_res = np.zeros(n_res, dtype=np.int32)
+    w_res[slot_res[slot_res >= 0]] = np.where(stereo[slot_res >= 0] > 0, 2, 1)
+    n_ref, slot_ref, nobs_ref, bad_ref, repl_ref = ob.orb_fuse(mp_desc, desc, skip, full_off, np.array(idx, dtype=np.int32), stereo, slot0,
+                                                              np.concatenate([nobs, res_nobs + w_res]), np.concatenate([bad, res_bad]).astype(np.uint8))
+    assert n == n_ref and n > 300
+    np.testing.assert_array_equal(out["slot"], slot_ref)
+    np.testing.assert_array_equal(out["cand_bad"], bad_ref[:n_mp])
+    np.testing.assert_array_equal(out["res_bad"], bad_ref[n_mp:])
+    np.testing.assert_array_equal(out["cand_replaced"], repl_ref[:n_mp])
+    np.testing.assert_array_equal(out["res_replaced"], repl_ref[n_mp:])
+    np.testing.assert_array_equal(out["cand_nobs"], nobs_ref[:n_mp])
+    np.testing.assert_array_equal(out["res_nobs"], nobs_ref[n_mp:])
+    # every branch was taken: added to an empty slot, candidate replaced by the resident, resident replaced by the candidate
+    assert ((slot_ref >= 0) & (slot_ref < 100000) & (slot0 < 0)).sum() > 50
+    assert (repl_ref[:n_mp] >= 100000).sum() > 20 and (repl_ref[n_mp:] >= 0).sum() > 20
+    assert side.any() and bad.any() and null.any() and behind.any()
+
+
 @pytest.mark.parametrize("fisheye", [False, True])
 def test_pose_optimization_through_the_reference_signature(ob, fisheye):
     """Optimizer::PoseOptimization(Frame*) (src/Optimizer.cc:815-1114) on a Frame whose keypoints hold map points: the returned

@@ -136,3 +136,28 @@ def test_search_by_bow_restatement_properties():
         s = int(assign3[t])
         lefts = [u for u in np.nonzero(f_node[:600] == kf_node[s])[0]]
         assert min(ob.descriptor_distance(d["kf_desc"][s], d["f_desc"][u]) for u in lefts) <= 50
+
+
+def test_fuse_replay_by_hand():
+    """oracle_orb_fuse on a case small enough to follow: 4 features, residents in slots 0 and 1, five candidates."""
+    from oracle import binding as ob
+    feat = np.zeros((4, 32), dtype=np.uint8)
+    feat[1, 0] = 0xFF; feat[2, 1] = 0xFF; feat[3, 2] = 0xFF
+    q = np.stack([feat[0], feat[1], feat[2], feat[2], feat[3] ^ 0xFF]).astype(np.uint8)   # the last one: 248 bits away from everything near
+    off = np.array([0, 1, 2, 3, 4, 5], dtype=np.int32)
+    idx = np.array([0, 1, 2, 2, 3], dtype=np.int32)
+    stereo = np.array([1, 0, 0, 0], dtype=np.uint8)
+    slot = np.array([100000, 100001, -1, -1], dtype=np.int32)
+    #              candidates 0..4        residents 0, 1 (their counts include this keyframe: 2 for the stereo slot, 1 for the mono one)
+    nobs = np.array([3, 5, 2, 4, 1,       6, 2], dtype=np.int32)
+    bad = np.zeros(7, dtype=np.uint8)
+    n, slot_o, nobs_o, bad_o, repl = ob.orb_fuse(q, feat, np.zeros(5, np.uint8), off, idx, stereo, slot, nobs, bad)
+    # candidate 0 (3 obs) meets resident 0 (6 obs): the candidate is replaced, the resident takes its 3 observations
+    # candidate 1 (5 obs) meets resident 1 (2 obs): the resident is replaced, the candidate takes the slot and its 2 observations
+    # candidate 2 takes the empty slot 2 (+1, mono); candidate 3 then meets candidate 2 there (3 obs vs 4): candidate 2 is replaced
+    # candidate 4 is too far from its only candidate feature
+    assert n == 4
+    np.testing.assert_array_equal(slot_o, [100000, 1, 3, -1])
+    np.testing.assert_array_equal(bad_o, [1, 0, 1, 0, 0, 0, 1])
+    np.testing.assert_array_equal(repl, [100000, -1, 3, -1, -1, -1, 1])
+    np.testing.assert_array_equal(nobs_o, [3, 7, 3, 7, 1, 9, 2])
