@@ -37,6 +37,8 @@ class ORBmatcher {
   int SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12);
   // Project MapPoints into KeyFrame and search for duplicated MapPoints (include/ORBmatcher.h:87, src/ORBmatcher.cc:1148-1338)
   int Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const float th = 3.0, const bool bRight = false);
+  // Project MapPoints into KeyFrame using a given Sim3 and search for duplicated MapPoints (include/ORBmatcher.h:90, src/ORBmatcher.cc:1340-1455)
+  int Fuse(KeyFrame* pKF, Sophus::Sim3f& Scw, const std::vector<MapPoint*>& vpPoints, float th, std::vector<MapPoint*>& vpReplacePoint);
   static const int TH_LOW;
   static const int TH_HIGH;
   static const int HISTO_LENGTH;

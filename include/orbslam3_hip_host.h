@@ -170,6 +170,13 @@ int osh_host_fuse(osh_host_frame* f, int32_t n_mp, const float* mp_pos, const ui
                   int32_t n_res, const int32_t* slot_res, const int32_t* res_nobs, const uint8_t* res_bad, float th,
                   int32_t* slot_out, uint8_t* cand_bad_out, int32_t* cand_replaced_out, int32_t* cand_nobs_out,
                   uint8_t* res_bad_out, int32_t* res_replaced_out, int32_t* res_nobs_out);
+/* ORBmatcher::Fuse(KeyFrame*, Sim3f&, const vector<MapPoint*>&, th, vpReplacePoint) (src/ORBmatcher.cc:1340-1455): as osh_host_fuse;
+ * found_slot[j] >= 0: candidate j already sits in the keyframe at that keypoint (spAlreadyFound); replace_out[j]: id of
+ * vpReplacePoint[j] (-1 null). */
+int osh_host_fuse_sim3(osh_host_frame* f, const float scw[8], int32_t n_mp, const float* mp_pos, const uint8_t* mp_desc,
+                       const float* mp_min_max_dist, const float* mp_normal, const uint8_t* mp_bad, const int32_t* mp_nobs,
+                       const int32_t* found_slot, int32_t n_res, const int32_t* slot_res, const uint8_t* res_bad, float th,
+                       int32_t* slot_out, int32_t* replace_out, int32_t* cand_nobs_out);
 /* Optimizer::PoseOptimization(&frame) (src/Optimizer.cc:815-1114): kp_mp[k] = map point matched to keypoint k (-1 none);
  * returns the inlier count, the optimised pose and mvbOutlier (keypoints without a match keep the value 1 they are preset to). */
 int osh_host_frame_pose_optimization(osh_host_frame* f, int32_t n_mp, const float* mp_pos, const int32_t* kp_mp,

@@ -454,3 +454,19 @@ def orb_fuse(q_desc, feat_desc, skip, cand_off, cand_idx, stereo, slot, nobs, ba
     n = lib.oracle_orb_fuse(n_q, n_res, fd.shape[0], _u8(qd), _u8(fd), _u8(sk), _i32(off), _i32(idx), _u8(st), int(th_low), _i32(slot), _i32(nobs),
                             _u8(bad), _i32(replaced), _u8(in_kf))
     return int(n), slot, nobs, bad, replaced
+
+
+def orb_fuse_sim3(q_desc, feat_desc, skip, cand_off, cand_idx, stereo, slot, slot_bad, nobs, th_low=50):
+    """The Sim3 overload of ORBmatcher::Fuse after its gates (orb_oracle.c:oracle_orb_fuse_sim3).  Returns nFused, slot, nobs, replace."""
+    lib = load()
+    i32, u8 = C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+    lib.oracle_orb_fuse_sim3.restype = C.c_int
+    lib.oracle_orb_fuse_sim3.argtypes = [C.c_int, u8, u8, u8, i32, i32, u8, u8, C.c_int, i32, i32, i32]
+    qd, fd = np.ascontiguousarray(q_desc, dtype=np.uint8), np.ascontiguousarray(feat_desc, dtype=np.uint8)
+    sk, st, sb = (np.ascontiguousarray(a, dtype=np.uint8) for a in (skip, stereo, slot_bad))
+    off, idx = np.ascontiguousarray(cand_off, dtype=np.int32), np.ascontiguousarray(cand_idx if len(cand_idx) else [0], dtype=np.int32)
+    slot, nobs = np.array(slot, dtype=np.int32), np.array(nobs, dtype=np.int32)
+    replace = -np.ones(qd.shape[0], dtype=np.int32)
+    n = lib.oracle_orb_fuse_sim3(qd.shape[0], _u8(qd), _u8(fd), _u8(sk), _i32(off), _i32(idx), _u8(st), _u8(sb), int(th_low), _i32(slot), _i32(nobs),
+                                 _i32(replace))
+    return int(n), slot, nobs, replace

@@ -75,6 +75,9 @@ int  oracle_orb_search_by_bow_kf(int n1, int n2, int lim1, int lim2, const uint8
 int  oracle_orb_fuse(int n_q, int n_res, int n_feat, const uint8_t* q_desc, const uint8_t* feat_desc, const uint8_t* skip,
                      const int32_t* cand_off, const int32_t* cand_idx, const uint8_t* stereo, int th_low,
                      int32_t* slot, int32_t* nobs, uint8_t* bad, int32_t* replaced, uint8_t* in_kf);
+int  oracle_orb_fuse_sim3(int n_q, const uint8_t* q_desc, const uint8_t* feat_desc, const uint8_t* skip, const int32_t* cand_off,
+                          const int32_t* cand_idx, const uint8_t* stereo, const uint8_t* slot_bad, int th_low, int32_t* slot, int32_t* nobs,
+                          int32_t* replace);
 int  oracle_orb_match_local_points_rig(int n_query, int n_left, int n_right, const uint8_t* query_desc, const uint8_t* desc,
                                        const int32_t* level_left, const int32_t* level_right,
                                        const uint8_t* in_l, const int32_t* candl_off, const int32_t* candl_idx,

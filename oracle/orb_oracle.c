@@ -490,3 +490,33 @@ int oracle_orb_fuse(int n_q, int n_res, int n_feat, const uint8_t* q_desc, const
 #undef PIDX
   return n_fused;
 }
+
+
+/* ORBmatcher::Fuse(KeyFrame*, Sim3f&, const vector<MapPoint*>&, th, vpReplacePoint) -- src/ORBmatcher.cc:1340-1455 after its gates
+ * (skip[q]: bad, already found at entry, or fails a projection gate; lists: GetFeaturesInArea order with the level gate).  A best
+ * feature within th_low that holds a (non-bad: slot_bad[k] == 0) map point reports it in replace[q]; an empty one takes the
+ * candidate (AddObservation + AddMapPoint: nobs[q] += 2 when stereo[k] else 1, and later candidates find it there).
+ * slot[k]: id at feature k (-1 none; candidates are ids [0, n_q)).  Returns nFused. */
+int oracle_orb_fuse_sim3(int n_q, const uint8_t* q_desc, const uint8_t* feat_desc, const uint8_t* skip, const int32_t* cand_off,
+                         const int32_t* cand_idx, const uint8_t* stereo, const uint8_t* slot_bad, int th_low, int32_t* slot, int32_t* nobs,
+                         int32_t* replace) {
+  int n_fused = 0;
+  for (int q = 0; q < n_q; ++q) {
+    replace[q] = -1;
+    if (skip[q]) continue;
+    int best_dist = 0x7fffffff, best_idx = -1;
+    for (int c = cand_off[q]; c < cand_off[q + 1]; ++c) {
+      const int d = oracle_descriptor_distance(q_desc + 32 * (size_t)q, feat_desc + 32 * (size_t)cand_idx[c]);
+      if (d < best_dist) { best_dist = d; best_idx = cand_idx[c]; }
+    }
+    if (best_dist > th_low) continue;
+    if (slot[best_idx] >= 0) {
+      if (!(slot[best_idx] >= 100000 && slot_bad[best_idx])) replace[q] = slot[best_idx];
+    } else {
+      nobs[q] += stereo[best_idx] ? 2 : 1;
+      slot[best_idx] = q;
+    }
+    ++n_fused;
+  }
+  return n_fused;
+}

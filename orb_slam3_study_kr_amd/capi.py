@@ -305,6 +305,8 @@ _HOST_SIGNATURES = {
                                        C.c_int32, C.c_float, C.c_int32, c_int32_p, c_int32_p]),
     "osh_host_fuse": (C.c_int, [C.c_void_p, C.c_int32, c_float_p, c_uint8_p, c_float_p, c_float_p, c_uint8_p, c_uint8_p, c_int32_p, C.c_int32,
                                 c_int32_p, c_int32_p, c_uint8_p, C.c_float, c_int32_p, c_uint8_p, c_int32_p, c_int32_p, c_uint8_p, c_int32_p, c_int32_p]),
+    "osh_host_fuse_sim3": (C.c_int, [C.c_void_p, c_float_p, C.c_int32, c_float_p, c_uint8_p, c_float_p, c_float_p, c_uint8_p, c_int32_p, c_int32_p,
+                                     C.c_int32, c_int32_p, c_uint8_p, C.c_float, c_int32_p, c_int32_p, c_int32_p]),
     "osh_host_pack_gba": (C.c_int, [C.c_void_p, c_int32_p, c_double_p, c_double_p, c_double_p, c_int32_p, c_int32_p, c_uint8_p, c_double_p,
                                     c_double_p, c_int64_p, c_int64_p]),
     "osh_host_pack_welding": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_int32_p, C.c_int32, c_int32_p, c_int32_p, c_double_p, c_double_p,

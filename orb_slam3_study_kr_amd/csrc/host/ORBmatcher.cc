@@ -703,15 +703,17 @@ bool device_search_lists(const std::vector<uint8_t>& qdesc, const cv::Mat& train
 // on what the loop does to earlier points.  ONE batched device search gives the best candidate of every point; the part that is
 // order dependent -- "already in the keyframe", Replace in either direction, AddObservation / AddMapPoint -- is replayed in the
 // reference's order on the map itself.
-int ORBmatcher::Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const float th, const bool bRight) {
-  GeometricCamera* pCamera;
-  Sophus::SE3f Tcw;
-  Eigen::Vector3f Ow;
-  if (bRight) { Tcw = pKF->GetRightPose(); Ow = pKF->GetRightCameraCenter(); pCamera = pKF->mpCamera2; }
-  else { Tcw = pKF->GetPose(); Ow = pKF->GetCameraCenter(); pCamera = pKF->mpCamera; }
+namespace {
+
+// The part of both Fuse overloads that does not depend on what their loops do to the map: per map point the projection gates
+// (src/ORBmatcher.cc:1196-1260 / 1372-1412) and the candidate list -- the features of GetFeaturesInArea, in its order, that pass the
+// level gate and (first overload, chi2_gate) the reprojection-error gate -- then ONE batched device search over the lists.
+// qOf[i] = query of point i or -1; best / bestD by query.
+bool fuse_search(KeyFrame* pKF, const Sophus::SE3f& Tcw, const Eigen::Vector3f& Ow, GeometricCamera* pCamera, const std::vector<MapPoint*>& vpMapPoints,
+                 const float th, const bool bRight, const bool chi2_gate, std::vector<int>& qOf, std::vector<int32_t>& best, std::vector<int32_t>& bestD) {
   const float& bf = pKF->mbf;
   const int nMPs = (int)vpMapPoints.size();
-  std::vector<int> qOf(nMPs, -1);            // map point -> query of the device search (-1: fails a gate that does not depend on the loop)
+  qOf.assign(nMPs, -1);
   std::vector<uint8_t> qdesc;
   std::vector<int32_t> off(1, 0), idx;
   int nq = 0;
@@ -737,17 +739,19 @@ int ORBmatcher::Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, c
     const std::vector<size_t> vIndices = pKF->GetFeaturesInArea(uv(0), uv(1), radius, bRight);
     if (vIndices.empty()) continue;
     for (size_t k : vIndices) {
-      const cv::KeyPoint& kp = (pKF->NLeft == -1) ? pKF->mvKeysUn[k] : (!bRight) ? pKF->mvKeys[k] : pKF->mvKeysRight[k];
+      const cv::KeyPoint& kp = (!chi2_gate || pKF->NLeft == -1) ? pKF->mvKeysUn[k] : (!bRight) ? pKF->mvKeys[k] : pKF->mvKeysRight[k];
       const int& kpLevel = kp.octave;
       if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
-      const float ex = uv(0) - kp.pt.x, ey = uv(1) - kp.pt.y;
-      if (pKF->mvuRight[k] >= 0) {                                  // reprojection error in stereo
-        const float er = ur - pKF->mvuRight[k];
-        const float e2 = ex * ex + ey * ey + er * er;
-        if (e2 * pKF->mvInvLevelSigma2[kpLevel] > 7.8) continue;
-      } else {
-        const float e2 = ex * ex + ey * ey;
-        if (e2 * pKF->mvInvLevelSigma2[kpLevel] > 5.99) continue;
+      if (chi2_gate) {
+        const float ex = uv(0) - kp.pt.x, ey = uv(1) - kp.pt.y;
+        if (pKF->mvuRight[k] >= 0) {                                // reprojection error in stereo
+          const float er = ur - pKF->mvuRight[k];
+          const float e2 = ex * ex + ey * ey + er * er;
+          if (e2 * pKF->mvInvLevelSigma2[kpLevel] > 7.8) continue;
+        } else {
+          const float e2 = ex * ex + ey * ey;
+          if (e2 * pKF->mvInvLevelSigma2[kpLevel] > 5.99) continue;
+        }
       }
       idx.push_back((int32_t)(bRight ? k + pKF->NLeft : k));
     }
@@ -756,8 +760,23 @@ int ORBmatcher::Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, c
     qdesc.insert(qdesc.end(), dMP.ptr<uint8_t>(0), dMP.ptr<uint8_t>(0) + 32);
     qOf[i] = nq++;
   }
-  std::vector<int32_t> best, bestD, secondD, secondI;
-  if (nq > 0 && !device_search_lists(qdesc, pKF->mDescriptors, pKF->mDescriptors.rows, off, idx, best, bestD, secondD, secondI)) return 0;
+  std::vector<int32_t> secondD, secondI;
+  best.clear(); bestD.clear();
+  return nq == 0 || device_search_lists(qdesc, pKF->mDescriptors, pKF->mDescriptors.rows, off, idx, best, bestD, secondD, secondI);
+}
+
+}  // namespace
+
+int ORBmatcher::Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const float th, const bool bRight) {
+  GeometricCamera* pCamera;
+  Sophus::SE3f Tcw;
+  Eigen::Vector3f Ow;
+  if (bRight) { Tcw = pKF->GetRightPose(); Ow = pKF->GetRightCameraCenter(); pCamera = pKF->mpCamera2; }
+  else { Tcw = pKF->GetPose(); Ow = pKF->GetCameraCenter(); pCamera = pKF->mpCamera; }
+  const int nMPs = (int)vpMapPoints.size();
+  std::vector<int> qOf;
+  std::vector<int32_t> best, bestD;
+  if (!fuse_search(pKF, Tcw, Ow, pCamera, vpMapPoints, th, bRight, true, qOf, best, bestD)) return 0;
 
   int nFused = 0;
   for (int i = 0; i < nMPs; i++) {
@@ -774,6 +793,38 @@ int ORBmatcher::Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, c
           if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
           else pMPinKF->Replace(pMP);
         }
+      } else {
+        pMP->AddObservation(pKF, bestIdx);
+        pKF->AddMapPoint(pMP, bestIdx);
+      }
+      nFused++;
+    }
+  }
+  return nFused;
+}
+
+// src/ORBmatcher.cc:1340-1455 (loop closing / map merging): the same search through a Sim3 pose, no reprojection-error gate; a point
+// whose best feature already holds a map point is reported in vpReplacePoint instead of being replaced.
+int ORBmatcher::Fuse(KeyFrame* pKF, Sophus::Sim3f& Scw, const std::vector<MapPoint*>& vpPoints, float th, std::vector<MapPoint*>& vpReplacePoint) {
+  const Eigen::Vector3f ts = Scw.translation();
+  const float sc = Scw.scale();
+  const Sophus::SE3f Tcw(Scw.rotationMatrix(), Eigen::Vector3f(ts(0) / sc, ts(1) / sc, ts(2) / sc));
+  const Eigen::Vector3f Ow = Tcw.inverse().translation();
+  const std::set<MapPoint*> spAlreadyFound = pKF->GetMapPoints();    // as found at entry: the loop does not update it
+  const int nPoints = (int)vpPoints.size();
+  std::vector<int> qOf;
+  std::vector<int32_t> best, bestD;
+  if (!fuse_search(pKF, Tcw, Ow, pKF->mpCamera, vpPoints, th, false, false, qOf, best, bestD)) return 0;
+  int nFused = 0;
+  for (int iMP = 0; iMP < nPoints; iMP++) {
+    MapPoint* pMP = vpPoints[iMP];
+    if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+    if (qOf[iMP] < 0) continue;
+    const int bestDist = bestD[qOf[iMP]], bestIdx = best[qOf[iMP]];
+    if (bestIdx >= 0 && bestDist <= TH_LOW) {
+      MapPoint* pMPinKF = pKF->GetMapPoint(bestIdx);
+      if (pMPinKF) {
+        if (!pMPinKF->isBad()) vpReplacePoint[iMP] = pMPinKF;
       } else {
         pMP->AddObservation(pKF, bestIdx);
         pKF->AddMapPoint(pMP, bestIdx);

@@ -705,6 +705,49 @@ extern "C" int osh_host_fuse(osh_host_frame* f, int32_t n_mp, const float* mp_po
   return n;
 }
 
+// ORBmatcher::Fuse(pKF, Scw, vpPoints, th, vpReplacePoint): same set-up as osh_host_fuse; already_found[j]: candidate j sits in the
+// keyframe at entry (slot found_slot[j]).  replace_out[j]: id of vpReplacePoint[j] (-1 null).
+extern "C" int osh_host_fuse_sim3(osh_host_frame* f, const float scw[8], int32_t n_mp, const float* mp_pos, const uint8_t* mp_desc,
+                                  const float* mp_min_max_dist, const float* mp_normal, const uint8_t* mp_bad, const int32_t* mp_nobs,
+                                  const int32_t* found_slot, int32_t n_res, const int32_t* slot_res, const uint8_t* res_bad, float th,
+                                  int32_t* slot_out, int32_t* replace_out, int32_t* cand_nobs_out) {
+  if (!f) return -1;
+  Frame& F = f->F;
+  KeyFrame kf(1, &f->map);
+  kf.N = F.N;
+  kf.mvKeys = F.mvKeys; kf.mvKeysUn = F.mvKeysUn; kf.mvuRight = F.mvuRight;
+  kf.mDescriptors = F.mDescriptors;
+  kf.mvScaleFactors = F.mvScaleFactors; kf.mnScaleLevels = F.mnScaleLevels; kf.mfLogScaleFactor = F.mfLogScaleFactor;
+  kf.mpCamera = F.mpCamera;
+  kf.fx = F.fx; kf.fy = F.fy; kf.cx = F.cx; kf.cy = F.cy; kf.mbf = F.mbf;
+  kf.mnGridCols = FRAME_GRID_COLS; kf.mnGridRows = FRAME_GRID_ROWS;
+  kf.mfGridElementWidthInv = F.mfGridElementWidthInv; kf.mfGridElementHeightInv = F.mfGridElementHeightInv;
+  kf.mnMinX = (int)F.mnMinX; kf.mnMinY = (int)F.mnMinY; kf.mnMaxX = (int)F.mnMaxX; kf.mnMaxY = (int)F.mnMaxY;
+  kf.mGrid.assign(FRAME_GRID_COLS, std::vector<std::vector<size_t>>(FRAME_GRID_ROWS));
+  for (int i = 0; i < FRAME_GRID_COLS; ++i)
+    for (int j = 0; j < FRAME_GRID_ROWS; ++j) kf.mGrid[i][j] = F.mGrid[i][j];
+  kf.mvpMapPoints.assign(F.N, nullptr);
+  auto cands = make_points(&f->map, n_mp, mp_desc, mp_pos, mp_nobs);
+  std::vector<uint8_t> zero_desc((size_t)std::max(n_res, 1) * 32, 0);
+  auto residents = make_points(&f->map, n_res, zero_desc.data(), nullptr, nullptr);
+  for (int j = 0; j < n_mp; ++j) {
+    cands[j]->mfMinDistance = mp_min_max_dist[2 * j]; cands[j]->mfMaxDistance = mp_min_max_dist[2 * j + 1];
+    cands[j]->mNormalVector = Eigen::Vector3f(mp_normal[3 * j], mp_normal[3 * j + 1], mp_normal[3 * j + 2]);
+    if (mp_bad && mp_bad[j]) cands[j]->mbBad = true;
+    if (found_slot && found_slot[j] >= 0) kf.mvpMapPoints[found_slot[j]] = cands[j].get();
+  }
+  for (int r = 0; r < n_res; ++r) { residents[r]->mnId = 100000 + (unsigned long)r; if (res_bad && res_bad[r]) residents[r]->mbBad = true; }
+  for (int k = 0; k < F.N; ++k) if (slot_res[k] >= 0) kf.mvpMapPoints[k] = residents[slot_res[k]].get();
+  std::vector<MapPoint*> vpPoints, vpReplace(n_mp, nullptr);
+  for (int j = 0; j < n_mp; ++j) vpPoints.push_back(cands[j].get());
+  Sophus::Sim3f Scw(Eigen::Quaternionf(scw[3], scw[0], scw[1], scw[2]), Eigen::Vector3f(scw[4], scw[5], scw[6]), scw[7]);
+  ORBmatcher matcher(0.8f, true);
+  const int n = matcher.Fuse(&kf, Scw, vpPoints, th, vpReplace);
+  for (int k = 0; k < F.N; ++k) slot_out[k] = kf.mvpMapPoints[k] ? (int32_t)kf.mvpMapPoints[k]->mnId : -1;
+  for (int j = 0; j < n_mp; ++j) { replace_out[j] = vpReplace[j] ? (int32_t)vpReplace[j]->mnId : -1; cand_nobs_out[j] = cands[j]->Observations(); }
+  return n;
+}
+
 // Optimizer::PoseOptimization(&frame): kp_mp[k] = map point matched to keypoint k (-1 none), map points by position.
 extern "C" int osh_host_frame_pose_optimization(osh_host_frame* f, int32_t n_mp, const float* mp_pos, const int32_t* kp_mp,
                                                 const float* inv_level_sigma2, int32_t n_levels, float pose_out[7], uint8_t* outlier_out) {

@@ -378,6 +378,22 @@ class HostFrame:
         return n, out
 
 
+    def fuse_sim3(self, scw, mp_pos, mp_desc, mp_min_max_dist, mp_normal, mp_nobs, slot_res, n_res, mp_bad=None, found_slot=None, res_bad=None, th=3.0):
+        """ORBmatcher::Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (src/ORBmatcher.cc:1340-1455) with this frame turned into the
+        keyframe.  Returns nFused, the keyframe's matches afterwards, vpReplacePoint as ids, Observations() of the candidates."""
+        u8 = lambda a: np.ascontiguousarray(a, dtype=np.uint8)
+        n_mp = len(mp_pos)
+        keep = [_f32(scw), _f32(mp_pos), u8(mp_desc), _f32(mp_min_max_dist), _f32(mp_normal), u8(mp_bad if mp_bad is not None else np.zeros(n_mp)),
+                _i32(mp_nobs), _i32(found_slot if found_slot is not None else -np.ones(n_mp)), _i32(slot_res),
+                u8(res_bad if res_bad is not None else np.zeros(max(n_res, 1)))]
+        slot, repl, nobs = -np.ones(self.n, dtype=np.int32), -np.ones(n_mp, dtype=np.int32), np.zeros(n_mp, dtype=np.int32)
+        fp, ip, bp = capi.c_float_p, capi.c_int32_p, capi.c_uint8_p
+        n = self.lib.osh_host_fuse_sim3(self.f, capi.ptr(keep[0], fp), n_mp, capi.ptr(keep[1], fp), capi.ptr(keep[2], bp), capi.ptr(keep[3], fp),
+                                        capi.ptr(keep[4], fp), capi.ptr(keep[5], bp), capi.ptr(keep[6], ip), capi.ptr(keep[7], ip), int(n_res),
+                                        capi.ptr(keep[8], ip), capi.ptr(keep[9], bp), float(th), capi.ptr(slot, ip), capi.ptr(repl, ip), capi.ptr(nobs, ip))
+        return n, slot, repl, nobs
+
+
 def _quat_from_R(R):
     return synth._quat_from_R(np.asarray(R, dtype=np.float64))
 

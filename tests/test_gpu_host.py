@@ -666,6 +666,92 @@ def test_fuse_equals_sequential_reference(ob):
     assert side.any() and bad.any() and null.any() and behind.any()
 
 
+def test_fuse_sim3_equals_sequential_reference(ob):
+    """ORBmatcher::Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (src/ORBmatcher.cc:1340-1455): the Sim3 pose, the points already in the
+    keyframe at entry skipped, no reprojection gate, occupied slots reported in vpReplacePoint (later candidates meet the ones added
+    earlier), empty ones taken."""
+    rng = np.random.Generator(np.random.PCG64(78))
+    f32 = np.float32
+    n_kp, n_mp = 700, 900
+    xy, octave, desc, _, _, _, _ = _frame_and_points(32, n_kp=n_kp, n_mp=10)
+    fx, fy, cx, cy = (f32(v) for v in (synth.FX, synth.FY, synth.CX, synth.CY))
+    scale = f32(0.8)
+    ts = np.array([-0.2, 0.1, 0.3], dtype=f32)
+    t = (ts / scale).astype(f32)
+    depth_kp = rng.uniform(4, 10, n_kp)
+    uright = np.where(rng.uniform(0, 1, n_kp) < 0.5, xy[:, 0] - float(synth.BF) / depth_kp, -1.0).astype(f32)
+    src = rng.integers(0, n_kp, n_mp)
+    noisy = xy[src] + rng.normal(0, 0.8, (n_mp, 2))
+    depth = depth_kp[src] * rng.uniform(0.98, 1.02, n_mp)
+    Xc = np.stack([(noisy[:, 0] - float(cx)) / float(fx) * depth, (noisy[:, 1] - float(cy)) / float(fy) * depth, depth], axis=1)
+    pos = (Xc - t.astype(np.float64)).astype(f32)
+    mp_desc = desc[src] ^ np.packbits(rng.uniform(0, 1, (n_mp, 256)) < 0.05, axis=1)
+    maxd = (depth * synth.SCALE_FACTORS[octave[src]].astype(np.float64) * rng.uniform(0.9, 1.05, n_mp)).astype(f32)
+    mind = (maxd / f32(synth.SCALE_FACTORS[-1]) * f32(0.5)).astype(f32)
+    Ow = (-t).astype(f32)
+    PO = (pos - Ow).astype(f32)
+    normal = (PO / np.linalg.norm(PO, axis=1, keepdims=True)).astype(f32)
+    bad = rng.uniform(0, 1, n_mp) < 0.03
+    nobs = rng.integers(1, 8, n_mp).astype(np.int32)
+    n_res = int(0.3 * n_kp)
+    perm = rng.permutation(n_kp)
+    slot_res = -np.ones(n_kp, dtype=np.int32)
+    slot_res[perm[:n_res]] = np.arange(n_res)
+    res_bad = rng.uniform(0, 1, n_res) < 0.1
+    found_slot = -np.ones(n_mp, dtype=np.int32)                         # 30 candidates already sit in (other) slots of the keyframe
+    found = np.nonzero(~bad)[0][:30]
+    found_slot[found] = perm[n_res:n_res + 30]
+    th = 4.0
+    kf = host.HostFrame(xy, octave, desc, uright=uright)
+    try:
+        n, slot, repl, nobs_out = kf.fuse_sim3(np.concatenate([[0, 0, 0, 1], ts, [scale]]), pos, mp_desc, np.stack([mind, maxd], axis=1), normal, nobs,
+                                               slot_res, n_res, mp_bad=bad, found_slot=found_slot, res_bad=res_bad, th=th)
+    finally:
+        kf.close()
+    pc = (pos + t).astype(f32)
+    u = (fx * pc[:, 0] / pc[:, 2] + cx).astype(f32)
+    v = (fy * pc[:, 1] / pc[:, 2] + cy).astype(f32)
+    dist = np.sqrt((PO[:, 0] * PO[:, 0] + PO[:, 1] * PO[:, 1]).astype(f32) + (PO[:, 2] * PO[:, 2]).astype(f32)).astype(f32)
+    dot = ((PO[:, 0] * normal[:, 0] + PO[:, 1] * normal[:, 1]).astype(f32) + (PO[:, 2] * normal[:, 2]).astype(f32)).astype(f32)
+    ok = (pc[:, 2] >= 0) & (u >= 0) & (u < synth.IMG_W) & (v >= 0) & (v < synth.IMG_H)
+    ok &= ~((dist < f32(0.8) * mind) | (dist > f32(1.2) * maxd))
+    ok &= ~(dot.astype(np.float64) < 0.5 * dist.astype(np.float64))
+    lvl = np.clip(np.ceil(np.log((maxd / dist).astype(f32)) / np.log(f32(synth.SCALE_FACTOR))).astype(np.int64), 0, synth.N_LEVELS - 1).astype(np.int32)
+    radius = (f32(th) * synth.SCALE_FACTORS[lvl]).astype(f32)
+    qsel = np.nonzero(ok)[0]
+    off0, idx0 = synth.features_in_area_lists(xy[:, 0], xy[:, 1], octave, u[qsel], v[qsel], radius[qsel], None, None)
+    skip = np.ones(n_mp, dtype=np.uint8)
+    lens = np.zeros(n_mp, dtype=np.int32)
+    idx = []
+    for a, q in enumerate(qsel):
+        c = idx0[off0[a]:off0[a + 1]]
+        if len(c):
+            skip[q] = 0
+            c = c[(octave[c] >= lvl[q] - 1) & (octave[c] <= lvl[q])]
+            lens[q] = len(c)
+            idx.extend(c.tolist())
+    skip[bad | (found_slot >= 0)] = 1
+    # lists are laid out in candidate order; a skipped candidate's list is never read
+    order_idx, full_off = [], np.zeros(n_mp + 1, dtype=np.int32)
+    pos_in = np.concatenate([[0], np.cumsum(lens[qsel])])
+    per_q = {int(q): idx[pos_in[a]:pos_in[a + 1]] for a, q in enumerate(qsel)}
+    for q in range(n_mp):
+        order_idx.extend(per_q.get(q, []))
+        full_off[q + 1] = len(order_idx)
+    slot0 = np.where(slot_res >= 0, 100000 + slot_res, -1).astype(np.int32)
+    slot0[found_slot[found]] = found
+    slot_bad = np.zeros(n_kp, dtype=np.uint8)
+    slot_bad[slot_res >= 0] = res_bad[slot_res[slot_res >= 0]]
+    n_ref, slot_ref, nobs_ref, repl_ref = ob.orb_fuse_sim3(mp_desc, desc, skip, full_off, np.array(order_idx, dtype=np.int32), (uright >= 0).astype(np.uint8),
+                                                          slot0, slot_bad, nobs)
+    assert n == n_ref and n > 300
+    np.testing.assert_array_equal(slot, slot_ref)
+    np.testing.assert_array_equal(repl, repl_ref)
+    np.testing.assert_array_equal(nobs_out, nobs_ref)
+    assert (repl_ref >= 100000).sum() > 50 and ((repl_ref >= 0) & (repl_ref < 100000)).sum() > 20      # residents and earlier candidates
+    assert ((slot_ref >= 0) & (slot_ref < 100000) & (slot0 < 0)).sum() > 50
+
+
 @pytest.mark.parametrize("fisheye", [False, True])
 def test_pose_optimization_through_the_reference_signature(ob, fisheye):
     """Optimizer::PoseOptimization(Frame*) (src/Optimizer.cc:815-1114) on a Frame whose keypoints hold map points: the returned
