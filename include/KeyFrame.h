@@ -35,6 +35,8 @@ class KeyFrame {
   void AddMapPoint(MapPoint* pMP, const size_t& idx) { mvpMapPoints[idx] = pMP; }           // src/KeyFrame.cc:297-301
   void ReplaceMapPointMatch(const int& idx, MapPoint* pMP) { mvpMapPoints[idx] = pMP; }     // src/KeyFrame.cc:320-323
   Eigen::Vector3f GetCameraCenter() { return mTwc.translation(); }                          // src/KeyFrame.cc:143-146
+  Sophus::SE3f GetPoseInverse() { return mTwc; }                                            // src/KeyFrame.cc:133-136
+  Sophus::SE3f GetRightPoseInverse() { return mTwc * mTrl.inverse(); }                      // src/KeyFrame.cc:1126-1130
   Sophus::SE3f GetRightPose() { return mTrl * mTcw; }                                       // src/KeyFrame.cc:1120-1124
   Eigen::Vector3f GetRightCameraCenter() { return (mTwc * mTrl.inverse()).translation(); }  // src/KeyFrame.cc:1132-1136 (mTlr = mTrl^-1)
   Sophus::SE3f GetRelativePoseTrl() { return mTrl; }
@@ -56,6 +58,7 @@ class KeyFrame {
   DBoW2::FeatureVector mFeatVec;   // include/KeyFrame.h:403 (filled by ComputeBoW)
   std::vector<float> mvuRight;
   std::vector<float> mvInvLevelSigma2;
+  std::vector<float> mvLevelSigma2;
   std::vector<float> mvScaleFactors;
   int mnScaleLevels = 0;
   float mfLogScaleFactor = 0;

@@ -35,6 +35,9 @@ class ORBmatcher {
   int SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches);
   // src/ORBmatcher.cc:765-905 (loop closing / map merging): map points of keyframe 1 against the map points of keyframe 2 of the same node
   int SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12);
+  // Matching to triangulate new MapPoints. Check Epipolar Constraint. (include/ORBmatcher.h:75-76, src/ORBmatcher.cc:907-1146)
+  int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<std::pair<size_t, size_t>>& vMatchedPairs, const bool bOnlyStereo,
+                             const bool bCoarse = false);
   // Project MapPoints into KeyFrame and search for duplicated MapPoints (include/ORBmatcher.h:87, src/ORBmatcher.cc:1148-1338)
   int Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const float th = 3.0, const bool bRight = false);
   // Project MapPoints into KeyFrame using a given Sim3 and search for duplicated MapPoints (include/ORBmatcher.h:90, src/ORBmatcher.cc:1340-1455)

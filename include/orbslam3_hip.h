@@ -440,6 +440,11 @@ int osh_orb_match(osh_orb_ctx* ctx);
  *   rounds        out (may be NULL): fixed-point rounds run */
 int osh_orb_match_local_points(osh_orb_ctx* ctx, float nn_ratio, int32_t th_high, const uint8_t* occupied, const uint8_t* query_blocks,
                                int32_t* assignment, int32_t* n_matches, int32_t* query_slot, int32_t* rounds);
+/* After osh_orb_upload with candidate lists: the Hamming distance of every (query, candidate) entry, dist_out[pair_cand_base[p] + e]
+ * for entry e of pair p (total = sum of the list lengths).  For searches whose choice among the candidates depends on a per-pair test
+ * made on the host (ORBmatcher::SearchForTriangulation's epipolar constraint, src/ORBmatcher.cc:1009-1075). */
+int osh_orb_list_distances(osh_orb_ctx* ctx, int32_t* dist_out);
+
 /* Copy the per-query results back. Each array has n_pairs*n_query entries. */
 int osh_orb_download(osh_orb_ctx* ctx, int32_t* best_idx, int32_t* best_dist,
                      int32_t* second_dist, int32_t* best_level, int32_t* second_level,

@@ -160,6 +160,15 @@ int osh_host_search_sim3(osh_host_frame* f, const float scw[8], int32_t n_mp, co
                          const float* mp_min_max_dist, const float* mp_normal, const uint8_t* mp_bad,
                          const int32_t* matched_in, int32_t th, float ratio_hamming, int32_t with_keyframes,
                          int32_t* matched_out, int32_t* matched_kf_out);
+/* ORBmatcher::SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse) (src/ORBmatcher.cc:907-1146) on two pinhole
+ * keyframes: kp[n][4] = x, y, angle, uright (< 0: monocular), vocabulary nodes as (id, offsets, features), poses as unit quaternion
+ * (x y z w) + translation of Tcw.  match12[i] = feature of keyframe 2 paired with feature i of keyframe 1 (-1 none). */
+int osh_host_search_for_triangulation(const float cam4[4], int32_t n_levels, float scale_factor, int32_t n1, const float* kp1,
+                                      const int32_t* octave1, const uint8_t* desc1, const uint8_t* has_mp1, const float pose1_qt[7],
+                                      int32_t nodes1, const int32_t* node_id1, const int32_t* node_off1, const int32_t* node_feat1,
+                                      int32_t n2, const float* kp2, const int32_t* octave2, const uint8_t* desc2, const uint8_t* has_mp2,
+                                      const float pose2_qt[7], int32_t nodes2, const int32_t* node_id2, const int32_t* node_off2,
+                                      const int32_t* node_feat2, int32_t only_stereo, int32_t coarse, int32_t check_ori, int32_t* match12);
 /* ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:1148-1338): the keyframe is made from `f` (its pose,
  * keypoints, grid, mvuRight).  Candidate map points j (null_mask[j]: a null entry) with world position, descriptor, {mfMinDistance,
  * mfMaxDistance}, normal, isBad(), Observations(); resident map points r already sitting in keypoint slots (slot_res[k] = r or -1).

@@ -470,3 +470,25 @@ def orb_fuse_sim3(q_desc, feat_desc, skip, cand_off, cand_idx, stereo, slot, slo
     n = lib.oracle_orb_fuse_sim3(qd.shape[0], _u8(qd), _u8(fd), _u8(sk), _i32(off), _i32(idx), _u8(st), _u8(sb), int(th_low), _i32(slot), _i32(nobs),
                                  _i32(replace))
     return int(n), slot, nobs, replace
+
+
+def orb_search_for_triangulation(desc1, desc2, has_mp1, has_mp2, fv1, fv2, kp1, kp2, octave2, F12, ep, scale_factors, level_sigma2, only_stereo=False,
+                                 coarse=False, th_low=50, check_ori=True):
+    """ORBmatcher::SearchForTriangulation on two pinhole keyframes, restated (orb_oracle.c).  kp = x y angle uright per feature."""
+    lib = load()
+    i32, u8, f32p = C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.POINTER(C.c_float)
+    lib.oracle_orb_search_for_triangulation.restype = C.c_int
+    lib.oracle_orb_search_for_triangulation.argtypes = [C.c_int, C.c_int, u8, u8, u8, u8, C.c_int, i32, i32, i32, C.c_int, i32, i32, i32, f32p, f32p, i32,
+                                                        f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, i32]
+    d1, d2 = np.ascontiguousarray(desc1, dtype=np.uint8), np.ascontiguousarray(desc2, dtype=np.uint8)
+    h1, h2 = np.ascontiguousarray(has_mp1, dtype=np.uint8), np.ascontiguousarray(has_mp2, dtype=np.uint8)
+    f1 = [np.ascontiguousarray(a, dtype=np.int32) for a in fv1]
+    f2 = [np.ascontiguousarray(a, dtype=np.int32) for a in fv2]
+    fl = [np.ascontiguousarray(a, dtype=np.float32) for a in (kp1, kp2, np.asarray(F12).reshape(9), ep, scale_factors, level_sigma2)]
+    o2 = np.ascontiguousarray(octave2, dtype=np.int32)
+    fp = lambda a: a.ctypes.data_as(f32p)
+    m = -np.ones(d1.shape[0], dtype=np.int32)
+    n = lib.oracle_orb_search_for_triangulation(d1.shape[0], d2.shape[0], _u8(d1), _u8(d2), _u8(h1), _u8(h2), len(f1[0]), _i32(f1[0]), _i32(f1[1]),
+                                                _i32(f1[2]), len(f2[0]), _i32(f2[0]), _i32(f2[1]), _i32(f2[2]), fp(fl[0]), fp(fl[1]), _i32(o2), fp(fl[2]),
+                                                fp(fl[3]), fp(fl[4]), fp(fl[5]), int(only_stereo), int(coarse), int(th_low), int(check_ori), _i32(m))
+    return int(n), m

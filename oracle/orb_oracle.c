@@ -520,3 +520,88 @@ int oracle_orb_fuse_sim3(int n_q, const uint8_t* q_desc, const uint8_t* feat_des
   }
   return n_fused;
 }
+
+
+/* ORBmatcher::SearchForTriangulation -- src/ORBmatcher.cc:907-1146, two pinhole keyframes (no mpCamera2).  kp = x y angle uright per
+ * feature (uright < 0: monocular), F12 = K1^-T [t12]x R12 K2^-1 row-major (src/CameraModels/Pinhole.cpp:107-112), ep = the epipole in
+ * image 2, level_sigma2_2 / scale_factor_2 by octave of keyframe 2.  Per unmatched feature of keyframe 1, in the order of the
+ * vocabulary walk: candidates = unmatched features of keyframe 2 in the same node; `dist > TH_LOW || dist > bestDist` skips, so a
+ * later candidate at the same distance replaces the earlier one (:1020); a monocular pair must lie farther than 10 px (scaled) from
+ * the epipole (:1033-1044); accepted when coarse or dsqr < 3.84 sigma2 of the second keypoint's level (Pinhole.cpp:114-128). */
+int oracle_orb_search_for_triangulation(int n1, int n2, const uint8_t* desc1, const uint8_t* desc2, const uint8_t* has_mp1, const uint8_t* has_mp2,
+                                        int nodes1, const int32_t* node_id1, const int32_t* node_off1, const int32_t* node_feat1,
+                                        int nodes2, const int32_t* node_id2, const int32_t* node_off2, const int32_t* node_feat2,
+                                        const float* kp1, const float* kp2, const int32_t* octave2, const float* F12, const float* ep,
+                                        const float* scale_factor_2, const float* level_sigma2_2, int only_stereo, int coarse, int th_low,
+                                        int check_orientation, int32_t* match12) {
+  enum { HISTO_LENGTH = 30 };
+  (void)n2;
+  int nmatches = 0;
+  int* hist[HISTO_LENGTH];
+  int hsize[HISTO_LENGTH];
+  for (int i = 0; i < HISTO_LENGTH; ++i) { hist[i] = (int*)malloc(sizeof(int) * (size_t)(n1 + 1)); hsize[i] = 0; }
+  for (int i = 0; i < n1; ++i) match12[i] = -1;
+  const float factor = 1.0f / HISTO_LENGTH;
+  int a = 0, b = 0;
+  while (a < nodes1 && b < nodes2) {
+    if (node_id1[a] == node_id2[b]) {
+      for (int x = node_off1[a]; x < node_off1[a + 1]; ++x) {
+        const int idx1 = node_feat1[x];
+        if (has_mp1[idx1]) continue;
+        const int stereo1 = kp1[4 * idx1 + 3] >= 0;
+        if (only_stereo && !stereo1) continue;
+        int bestDist = th_low, bestIdx2 = -1;
+        for (int y = node_off2[b]; y < node_off2[b + 1]; ++y) {
+          const int idx2 = node_feat2[y];
+          if (has_mp2[idx2]) continue;
+          const int stereo2 = kp2[4 * idx2 + 3] >= 0;
+          if (only_stereo && !stereo2) continue;
+          const int dist = oracle_descriptor_distance(desc1 + 32 * (size_t)idx1, desc2 + 32 * (size_t)idx2);
+          if (dist > th_low || dist > bestDist) continue;
+          const float x2 = kp2[4 * idx2], y2 = kp2[4 * idx2 + 1];
+          if (!stereo1 && !stereo2) {
+            const float distex = ep[0] - x2, distey = ep[1] - y2;
+            if (distex * distex + distey * distey < 100 * scale_factor_2[octave2[idx2]]) continue;
+          }
+          int ok = coarse;
+          if (!ok) {
+            const float x1 = kp1[4 * idx1], y1 = kp1[4 * idx1 + 1];
+            const float la = x1 * F12[0] + y1 * F12[3] + F12[6];
+            const float lb = x1 * F12[1] + y1 * F12[4] + F12[7];
+            const float lc = x1 * F12[2] + y1 * F12[5] + F12[8];
+            const float num = la * x2 + lb * y2 + lc;
+            const float den = la * la + lb * lb;
+            if (den != 0) { const float dsqr = num * num / den; ok = dsqr < 3.84 * level_sigma2_2[octave2[idx2]]; }
+          }
+          if (ok) { bestIdx2 = idx2; bestDist = dist; }
+        }
+        if (bestIdx2 >= 0) {
+          match12[idx1] = bestIdx2;
+          nmatches++;
+          if (check_orientation) {
+            float rot = kp1[4 * idx1 + 2] - kp2[4 * bestIdx2 + 2];
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            hist[bin][hsize[bin]++] = idx1;
+          }
+        }
+      }
+      ++a; ++b;
+    } else if (node_id1[a] < node_id2[b]) {
+      while (a < nodes1 && node_id1[a] < node_id2[b]) ++a;
+    } else {
+      while (b < nodes2 && node_id2[b] < node_id1[a]) ++b;
+    }
+  }
+  if (check_orientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(hsize, HISTO_LENGTH, &ind1, &ind2, &ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int j = 0; j < hsize[i]; j++) { match12[hist[i][j]] = -1; nmatches--; }
+    }
+  }
+  for (int i = 0; i < HISTO_LENGTH; ++i) free(hist[i]);
+  return nmatches;
+}

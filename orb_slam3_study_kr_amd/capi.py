@@ -239,6 +239,7 @@ _SIGNATURES = {
     "osh_orb_get_profile": (C.c_int, [C.c_void_p, c_int64_p, c_double_p]),
     "osh_orb_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "osh_liba_get_profile": (C.c_int, [C.POINTER(C.c_int32), c_int64_p]),
+    "osh_orb_list_distances": (C.c_int, [C.c_void_p, c_int32_p]),
     "osh_orb_get_resolve_profile": (C.c_int, [C.c_void_p, c_int64_p, c_double_p]),
     "osh_orb_distance_matrix": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_uint8_p, c_uint8_p, c_int32_p]),
 }
@@ -307,6 +308,9 @@ _HOST_SIGNATURES = {
                                 c_int32_p, c_int32_p, c_uint8_p, C.c_float, c_int32_p, c_uint8_p, c_int32_p, c_int32_p, c_uint8_p, c_int32_p, c_int32_p]),
     "osh_host_fuse_sim3": (C.c_int, [C.c_void_p, c_float_p, C.c_int32, c_float_p, c_uint8_p, c_float_p, c_float_p, c_uint8_p, c_int32_p, c_int32_p,
                                      C.c_int32, c_int32_p, c_uint8_p, C.c_float, c_int32_p, c_int32_p, c_int32_p]),
+    "osh_host_search_for_triangulation": (C.c_int, [c_float_p, C.c_int32, C.c_float, C.c_int32, c_float_p, c_int32_p, c_uint8_p, c_uint8_p, c_float_p,
+                                                    C.c_int32, c_int32_p, c_int32_p, c_int32_p, C.c_int32, c_float_p, c_int32_p, c_uint8_p, c_uint8_p,
+                                                    c_float_p, C.c_int32, c_int32_p, c_int32_p, c_int32_p, C.c_int32, C.c_int32, C.c_int32, c_int32_p]),
     "osh_host_pack_gba": (C.c_int, [C.c_void_p, c_int32_p, c_double_p, c_double_p, c_double_p, c_int32_p, c_int32_p, c_uint8_p, c_double_p,
                                     c_double_p, c_int64_p, c_int64_p]),
     "osh_host_pack_welding": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_int32_p, C.c_int32, c_int32_p, c_int32_p, c_double_p, c_double_p,

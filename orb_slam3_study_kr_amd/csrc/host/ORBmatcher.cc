@@ -705,6 +705,165 @@ bool device_search_lists(const std::vector<uint8_t>& qdesc, const cv::Mat& train
 // reference's order on the map itself.
 namespace {
 
+// osh_orb_list_distances over explicit candidate lists: the Hamming distance of every (query, candidate) entry, in list order
+bool device_list_distances(const std::vector<uint8_t>& qdesc, const cv::Mat& train, int n_train, const std::vector<int32_t>& off,
+                           const std::vector<int32_t>& idx, std::vector<int32_t>& dist) {
+  const int nq = (int)off.size() - 1;
+  dist.assign(idx.size(), 256);
+  if (nq <= 0 || idx.empty()) return true;
+  osh_orb_ctx* ctx = thread_ctx();
+  if (!ctx) return false;
+  const int64_t base = 0;
+  osh_orb_batch b;
+  b.n_pairs = 1; b.n_query = nq; b.n_train = n_train;
+  b.query_desc = qdesc.data(); b.train_desc = train.ptr<uint8_t>(0); b.train_level = nullptr;
+  b.cand_off = off.data(); b.cand_idx = idx.data(); b.pair_cand_base = &base;
+  if (osh_orb_upload(ctx, &b) != OSH_OK || osh_orb_list_distances(ctx, dist.data()) != OSH_OK) {
+    std::fprintf(stderr, "ORBmatcher: device distances failed: %s\n", osh_last_error());
+    return false;
+  }
+  return true;
+}
+
+}  // namespace
+
+// src/ORBmatcher.cc:907-1146.  No step of this search depends on an earlier one (vbMatched2 is read but never set), so every
+// unmatched feature of keyframe 1 is a query whose candidates are the unmatched features of keyframe 2 in the same vocabulary
+// node.  The device returns the distance of every (query, candidate) entry in one launch; the choice among the candidates --
+// the reference's loop with its `dist > bestDist` rule (a later candidate at the same distance wins), the epipole test and the
+// epipolar constraint, which is a virtual call on the camera object -- runs on the host over the entries within TH_LOW only.
+int ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<std::pair<size_t, size_t>>& vMatchedPairs,
+                                       const bool bOnlyStereo, const bool bCoarse) {
+  const DBoW2::FeatureVector& vFeatVec1 = pKF1->mFeatVec;
+  const DBoW2::FeatureVector& vFeatVec2 = pKF2->mFeatVec;
+  // Compute epipole in second image
+  Sophus::SE3f T1w = pKF1->GetPose();
+  Sophus::SE3f T2w = pKF2->GetPose();
+  Sophus::SE3f Tw2 = pKF2->GetPoseInverse();
+  Eigen::Vector3f Cw = pKF1->GetCameraCenter();
+  Eigen::Vector3f C2 = T2w * Cw;
+  Eigen::Vector2f ep = pKF2->mpCamera->project(C2);
+  Sophus::SE3f T12;
+  Sophus::SE3f Tll, Tlr, Trl, Trr;
+  Eigen::Matrix3f R12;
+  Eigen::Vector3f t12;
+  GeometricCamera *pCamera1 = pKF1->mpCamera, *pCamera2 = pKF2->mpCamera;
+  if (!pKF1->mpCamera2 && !pKF2->mpCamera2) {
+    T12 = T1w * Tw2;
+    R12 = T12.rotationMatrix();
+    t12 = T12.translation();
+  } else {
+    Sophus::SE3f Tr1w = pKF1->GetRightPose();
+    Sophus::SE3f Twr2 = pKF2->GetRightPoseInverse();
+    Tll = T1w * Tw2; Tlr = T1w * Twr2; Trl = Tr1w * Tw2; Trr = Tr1w * Twr2;
+  }
+  Eigen::Matrix3f Rll = Tll.rotationMatrix(), Rlr = Tlr.rotationMatrix(), Rrl = Trl.rotationMatrix(), Rrr = Trr.rotationMatrix();
+  Eigen::Vector3f tll = Tll.translation(), tlr = Tlr.translation(), trl = Trl.translation(), trr = Trr.translation();
+
+  // ---- queries and candidate lists in the order of the vocabulary walk
+  std::vector<int> q1;
+  std::vector<uint8_t> qdesc;
+  std::vector<int32_t> off(1, 0), idx;
+  DBoW2::FeatureVector::const_iterator f1it = vFeatVec1.begin(), f1end = vFeatVec1.end();
+  DBoW2::FeatureVector::const_iterator f2it = vFeatVec2.begin(), f2end = vFeatVec2.end();
+  while (f1it != f1end && f2it != f2end) {
+    if (f1it->first == f2it->first) {
+      for (size_t i1 = 0, iend1 = f1it->second.size(); i1 < iend1; i1++) {
+        const size_t idx1 = f1it->second[i1];
+        if (pKF1->GetMapPoint(idx1)) continue;                       // already a MapPoint: skip
+        const bool bStereo1 = (!pKF1->mpCamera2 && pKF1->mvuRight[idx1] >= 0);
+        if (bOnlyStereo && !bStereo1) continue;
+        for (size_t i2 = 0, iend2 = f2it->second.size(); i2 < iend2; i2++) {
+          const size_t idx2 = f2it->second[i2];
+          if (pKF2->GetMapPoint(idx2)) continue;                     // already matched / already a MapPoint
+          const bool bStereo2 = (!pKF2->mpCamera2 && pKF2->mvuRight[idx2] >= 0);
+          if (bOnlyStereo && !bStereo2) continue;
+          idx.push_back((int32_t)idx2);
+        }
+        off.push_back((int32_t)idx.size());
+        q1.push_back((int)idx1);
+        qdesc.insert(qdesc.end(), pKF1->mDescriptors.ptr<uint8_t>((int)idx1), pKF1->mDescriptors.ptr<uint8_t>((int)idx1) + 32);
+      }
+      f1it++; f2it++;
+    } else if (f1it->first < f2it->first) {
+      f1it = vFeatVec1.lower_bound(f2it->first);
+    } else {
+      f2it = vFeatVec2.lower_bound(f1it->first);
+    }
+  }
+  std::vector<int32_t> dist;
+  if (!device_list_distances(qdesc, pKF2->mDescriptors, pKF2->mDescriptors.rows, off, idx, dist)) return 0;
+
+  int nmatches = 0;
+  std::vector<int> vMatches12(pKF1->N, -1);
+  std::vector<int> rotHist[HISTO_LENGTH];
+  for (int i = 0; i < HISTO_LENGTH; i++) rotHist[i].reserve(500);
+  const float factor = 1.0f / HISTO_LENGTH;
+  for (size_t q = 0; q < q1.size(); ++q) {
+    const size_t idx1 = (size_t)q1[q];
+    const bool bStereo1 = (!pKF1->mpCamera2 && pKF1->mvuRight[idx1] >= 0);
+    const cv::KeyPoint& kp1 = (pKF1->NLeft == -1) ? pKF1->mvKeysUn[idx1]
+                              : ((int)idx1 < pKF1->NLeft) ? pKF1->mvKeys[idx1] : pKF1->mvKeysRight[idx1 - pKF1->NLeft];
+    const bool bRight1 = (pKF1->NLeft == -1 || (int)idx1 < pKF1->NLeft) ? false : true;
+    int bestDist = TH_LOW;
+    int bestIdx2 = -1;
+    for (int e = off[q]; e < off[q + 1]; ++e) {
+      const size_t idx2 = (size_t)idx[e];
+      const int d = dist[e];
+      if (d > TH_LOW || d > bestDist) continue;
+      const bool bStereo2 = (!pKF2->mpCamera2 && pKF2->mvuRight[idx2] >= 0);
+      const cv::KeyPoint& kp2 = (pKF2->NLeft == -1) ? pKF2->mvKeysUn[idx2]
+                                : ((int)idx2 < pKF2->NLeft) ? pKF2->mvKeys[idx2] : pKF2->mvKeysRight[idx2 - pKF2->NLeft];
+      const bool bRight2 = (pKF2->NLeft == -1 || (int)idx2 < pKF2->NLeft) ? false : true;
+      if (!bStereo1 && !bStereo2 && !pKF1->mpCamera2) {
+        const float distex = ep(0) - kp2.pt.x;
+        const float distey = ep(1) - kp2.pt.y;
+        if (distex * distex + distey * distey < 100 * pKF2->mvScaleFactors[kp2.octave]) continue;
+      }
+      if (pKF1->mpCamera2 && pKF2->mpCamera2) {
+        if (bRight1 && bRight2) { R12 = Rrr; t12 = trr; T12 = Trr; pCamera1 = pKF1->mpCamera2; pCamera2 = pKF2->mpCamera2; }
+        else if (bRight1 && !bRight2) { R12 = Rrl; t12 = trl; T12 = Trl; pCamera1 = pKF1->mpCamera2; pCamera2 = pKF2->mpCamera; }
+        else if (!bRight1 && bRight2) { R12 = Rlr; t12 = tlr; T12 = Tlr; pCamera1 = pKF1->mpCamera; pCamera2 = pKF2->mpCamera2; }
+        else { R12 = Rll; t12 = tll; T12 = Tll; pCamera1 = pKF1->mpCamera; pCamera2 = pKF2->mpCamera; }
+      }
+      if (bCoarse || pCamera1->epipolarConstrain(pCamera2, kp1, kp2, R12, t12, pKF1->mvLevelSigma2[kp1.octave], pKF2->mvLevelSigma2[kp2.octave])) {
+        bestIdx2 = (int)idx2;
+        bestDist = d;
+      }
+    }
+    if (bestIdx2 >= 0) {
+      const cv::KeyPoint& kp2 = (pKF2->NLeft == -1) ? pKF2->mvKeysUn[bestIdx2]
+                                : (bestIdx2 < pKF2->NLeft) ? pKF2->mvKeys[bestIdx2] : pKF2->mvKeysRight[bestIdx2 - pKF2->NLeft];
+      vMatches12[idx1] = bestIdx2;
+      nmatches++;
+      if (mbCheckOrientation) {
+        float rot = kp1.angle - kp2.angle;
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)std::round(rot * factor);
+        if (bin == HISTO_LENGTH) bin = 0;
+        rotHist[bin].push_back((int)idx1);
+      }
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) { vMatches12[rotHist[i][j]] = -1; nmatches--; }
+    }
+  }
+  vMatchedPairs.clear();
+  vMatchedPairs.reserve(nmatches);
+  for (size_t i = 0, iend = vMatches12.size(); i < iend; i++) {
+    if (vMatches12[i] < 0) continue;
+    vMatchedPairs.push_back(std::make_pair(i, (size_t)vMatches12[i]));
+  }
+  return nmatches;
+}
+
+namespace {
+
 // The part of both Fuse overloads that does not depend on what their loops do to the map: per map point the projection gates
 // (src/ORBmatcher.cc:1196-1260 / 1372-1412) and the candidate list -- the features of GetFeaturesInArea, in its order, that pass the
 // level gate and (first overload, chi2_gate) the reprojection-error gate -- then ONE batched device search over the lists.

@@ -844,6 +844,51 @@ extern "C" int osh_host_search_by_bow_kf(int32_t n1, const uint8_t* desc1, const
   return n;
 }
 
+// ORBmatcher::SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse) on two pinhole keyframes built from flat
+// features: kp[n][4] = x, y, angle, uright (< 0: monocular keypoint); match12[i] = feature of keyframe 2 paired with feature i or -1.
+extern "C" int osh_host_search_for_triangulation(const float cam4[4], int32_t n_levels, float scale_factor, int32_t n1, const float* kp1,
+                                                 const int32_t* octave1, const uint8_t* desc1, const uint8_t* has_mp1, const float pose1_qt[7],
+                                                 int32_t nodes1, const int32_t* node_id1, const int32_t* node_off1, const int32_t* node_feat1,
+                                                 int32_t n2, const float* kp2, const int32_t* octave2, const uint8_t* desc2, const uint8_t* has_mp2,
+                                                 const float pose2_qt[7], int32_t nodes2, const int32_t* node_id2, const int32_t* node_off2,
+                                                 const int32_t* node_feat2, int32_t only_stereo, int32_t coarse, int32_t check_ori, int32_t* match12) {
+  Map map;
+  Pinhole cam(std::vector<float>{cam4[0], cam4[1], cam4[2], cam4[3]});
+  std::vector<std::unique_ptr<MapPoint>> mps;
+  auto build = [&](KeyFrame& kf, int n, const float* kp, const int32_t* octave, const uint8_t* desc, const uint8_t* has_mp, const float* pose_qt,
+                   int nodes, const int32_t* nid, const int32_t* noff, const int32_t* nfeat) {
+    kf.N = n;
+    kf.mpCamera = &cam;
+    kf.mDescriptors = cv::Mat(n, 32);
+    kf.mvpMapPoints.assign(n, nullptr);
+    kf.mvScaleFactors.assign(n_levels, 1.0f);
+    kf.mvLevelSigma2.assign(n_levels, 1.0f);
+    for (int l = 1; l < n_levels; ++l) { kf.mvScaleFactors[l] = kf.mvScaleFactors[l - 1] * scale_factor; kf.mvLevelSigma2[l] = kf.mvScaleFactors[l] * kf.mvScaleFactors[l]; }
+    for (int i = 0; i < n; ++i) {
+      cv::KeyPoint k;
+      k.pt.x = kp[4 * i]; k.pt.y = kp[4 * i + 1]; k.angle = kp[4 * i + 2]; k.octave = octave[i];
+      kf.mvKeysUn.push_back(k); kf.mvKeys.push_back(k);
+      kf.mvuRight.push_back(kp[4 * i + 3]);
+      std::memcpy(kf.mDescriptors.ptr<uint8_t>(i), desc + 32 * (size_t)i, 32);
+      if (has_mp[i]) {
+        mps.emplace_back(new MapPoint((unsigned long)i, Eigen::Vector3f(0.f, 0.f, 1.f), &map));
+        kf.mvpMapPoints[i] = mps.back().get();
+      }
+    }
+    for (int a = 0; a < nodes; ++a) kf.mFeatVec[(unsigned)nid[a]] = std::vector<unsigned int>(nfeat + noff[a], nfeat + noff[a + 1]);
+    kf.SetPose(pose_from(pose_qt));
+  };
+  KeyFrame kf1(7, &map), kf2(8, &map);
+  build(kf1, n1, kp1, octave1, desc1, has_mp1, pose1_qt, nodes1, node_id1, node_off1, node_feat1);
+  build(kf2, n2, kp2, octave2, desc2, has_mp2, pose2_qt, nodes2, node_id2, node_off2, node_feat2);
+  std::vector<std::pair<size_t, size_t>> pairs;
+  ORBmatcher matcher(0.6f, check_ori != 0);
+  const int n = matcher.SearchForTriangulation(&kf1, &kf2, pairs, only_stereo != 0, coarse != 0);
+  for (int i = 0; i < n1; ++i) match12[i] = -1;
+  for (const auto& pr : pairs) match12[pr.first] = (int32_t)pr.second;
+  return n;
+}
+
 // ------------------------------------------------------------------------------------------ PoseInertialOptimization*
 struct osh_host_posei {
   Frame F, prevF;

@@ -512,13 +512,34 @@ __global__ __launch_bounds__(256) void k_frustum(FrustumFrame f, int n, const fl
   out[2 * i + 1] = make_float4(pc_dist, vcos_out, __int_as_float(level), 0.f);
 }
 
+// Distance of every (query, candidate) entry of the uploaded candidate lists: out[pair_cand_base[p] + e] for entry e of pair p.
+// For callers whose choice among the candidates needs a per-pair test the search kernels cannot make (the epipolar constraint of
+// ORBmatcher::SearchForTriangulation is a virtual call on the reference's camera object): the host walks only the entries
+// within its distance threshold.
+__global__ __launch_bounds__(256) void k_orb_list_dist(OrbView v, int* __restrict__ out) {
+  const int p = blockIdx.y;
+  const int* off = v.cand_off + (size_t)p * (v.n_query + 1);
+  const int total = off[v.n_query];
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  int lo = 0, hi = v.n_query;            // the query whose list holds entry e: largest q with off[q] <= e
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= e) lo = mid; else hi = mid; }
+  const long long base = v.pair_cand_base[p];
+  const int t = v.cand_idx[base + e];
+  const uint4* q = v.query + ((size_t)p * v.n_query + lo) * 2;
+  const uint4* tr = v.train + ((size_t)p * v.n_train + t) * 2;
+  out[base + e] = (int)hamming256(q[0], q[1], tr[0], tr[1]);
+}
+
 struct osh_orb_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   KernelTimer timer;
   DevBuf d_query, d_train, d_level, d_off, d_idx, d_base, d_part, d_out[6], d_a, d_b, d_dm;
   DevBuf d_txy, d_tur, d_tskip, d_coff, d_cidx, d_qwin, d_qlev, d_qur;
-  DevBuf d_fin, d_fout;
+  DevBuf d_fin, d_fout, d_ldist;
+  long long list_total = 0;
+  int list_longest_pair = 0;
   DevBuf d_claim, d_owner[2], d_pre, d_blocks, d_cur[5], d_state, d_assign, d_nmatch;   // osh_orb_match_local_points
   std::vector<float> h_fin, h_fout;
   OrbView v{};
@@ -609,6 +630,9 @@ extern "C" int osh_orb_upload(osh_orb_ctx* c, const osh_orb_batch* b) {
     OSH_HIP(hipMemcpyAsync(c->d_base.p, b->pair_cand_base, (size_t)b->n_pairs * 8, hipMemcpyHostToDevice, s));
     v.cand_off = c->d_off.as<int>(); v.cand_idx = c->d_idx.as<int>(); v.pair_cand_base = c->d_base.as<long long>();
     v.n_split = 1;
+    c->list_total = total;
+    c->list_longest_pair = 0;
+    for (int p = 0; p < b->n_pairs; ++p) c->list_longest_pair = std::max(c->list_longest_pair, (int)b->cand_off[(size_t)p * (b->n_query + 1) + b->n_query]);
   } else {
     const int qblocks = (b->n_query + kQBlock - 1) / kQBlock;
     const long blocks = (long)b->n_pairs * std::max(qblocks, 1);
@@ -798,6 +822,20 @@ extern "C" int osh_orb_match_local_points(osh_orb_ctx* c, float nn_ratio, int32_
   if (c->timer.enabled) c->timer.collect();
   if (rounds) *rounds = state[2];
   c->matched = true;
+  return OSH_OK;
+}
+
+extern "C" int osh_orb_list_distances(osh_orb_ctx* c, int32_t* dist_out) {
+  if (!c || !c->uploaded || !c->windowed || c->grid || !dist_out) { set_error("osh_orb_list_distances: upload candidate lists first (osh_orb_upload with cand_off)"); return OSH_ERR_INVALID; }
+  if (c->list_total == 0) return OSH_OK;
+  OSH_HIP(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  OSH_TRY(c->d_ldist.reserve((size_t)c->list_total * 4));
+  hipLaunchKernelGGL(k_orb_list_dist, dim3((unsigned)((c->list_longest_pair + 255) / 256), (unsigned)c->v.n_pairs), dim3(256), 0, s, c->v, c->d_ldist.as<int>());
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) { set_error("k_orb_list_dist launch failed: %s", hipGetErrorString(le)); return OSH_ERR_DEVICE; }
+  OSH_HIP(hipMemcpyAsync(dist_out, c->d_ldist.p, (size_t)c->list_total * 4, hipMemcpyDeviceToHost, s));
+  OSH_HIP(hipStreamSynchronize(s));
   return OSH_OK;
 }
 

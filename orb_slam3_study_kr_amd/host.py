@@ -631,3 +631,23 @@ def search_by_bow_keyframes(desc1, angle1, has_mp1, fv1, desc2, angle2, has_mp2,
                                       len(keep[9]), capi.ptr(keep[9], capi.c_int32_p), capi.ptr(keep[10], capi.c_int32_p), capi.ptr(keep[11], capi.c_int32_p),
                                       float(nnratio), int(check_ori), capi.ptr(m, capi.c_int32_p))
     return n, m
+
+
+def search_for_triangulation(kp1, octave1, desc1, has_mp1, pose1_qt, fv1, kp2, octave2, desc2, has_mp2, pose2_qt, fv2, only_stereo=False, coarse=False,
+                             check_ori=True):
+    """ORBmatcher(0.6, check_ori).SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse) (src/ORBmatcher.cc:907-1146) on
+    two pinhole keyframes built from flat features (kp = x, y, angle, uright); returns (nmatches, match12[n1])."""
+    lib = capi.load_library()
+    u8 = lambda a: np.ascontiguousarray(a, dtype=np.uint8)
+    cam4 = _f32([synth.FX, synth.FY, synth.CX, synth.CY])
+    keep = [cam4, _f32(kp1), _i32(octave1), u8(desc1), u8(has_mp1), _f32(pose1_qt)] + [_i32(a) for a in fv1] + \
+           [_f32(kp2), _i32(octave2), u8(desc2), u8(has_mp2), _f32(pose2_qt)] + [_i32(a) for a in fv2]
+    m = -np.ones(len(octave1), dtype=np.int32)
+    fp, ip, bp = capi.c_float_p, capi.c_int32_p, capi.c_uint8_p
+    n = lib.osh_host_search_for_triangulation(capi.ptr(keep[0], fp), int(synth.N_LEVELS), float(synth.SCALE_FACTOR), len(octave1), capi.ptr(keep[1], fp),
+                                              capi.ptr(keep[2], ip), capi.ptr(keep[3], bp), capi.ptr(keep[4], bp), capi.ptr(keep[5], fp), len(keep[6]),
+                                              capi.ptr(keep[6], ip), capi.ptr(keep[7], ip), capi.ptr(keep[8], ip), len(octave2), capi.ptr(keep[9], fp),
+                                              capi.ptr(keep[10], ip), capi.ptr(keep[11], bp), capi.ptr(keep[12], bp), capi.ptr(keep[13], fp), len(keep[14]),
+                                              capi.ptr(keep[14], ip), capi.ptr(keep[15], ip), capi.ptr(keep[16], ip), int(only_stereo), int(coarse),
+                                              int(check_ori), capi.ptr(m, ip))
+    return n, m

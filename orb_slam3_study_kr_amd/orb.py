@@ -49,6 +49,7 @@ class OrbMatcher:
             b.cand_off, b.cand_idx = capi.ptr(off, capi.c_int32_p), capi.ptr(idx, capi.c_int32_p)
             b.pair_cand_base = capi.ptr(base, capi.c_int64_p)
             keep += [off, idx, base]
+            self._list_total = int(lens.sum())
         self._keep = keep
         self._shape = (n_pairs, nq)
         self._n_train = nt
@@ -89,6 +90,12 @@ class OrbMatcher:
         args, res, outs = frustum_args(pos, normal, min_dist, max_dist)
         capi.check(self.lib.osh_orb_frustum(self.ctx, C.byref(frame), C.byref(args[0]), C.byref(res)), "osh_orb_frustum", self.lib)
         return outs
+
+    def list_distances(self):
+        """osh_orb_list_distances: the Hamming distance of every (query, candidate) entry of the uploaded lists, pairs concatenated."""
+        out = np.zeros(max(self._list_total, 1), dtype=np.int32)
+        capi.check(self.lib.osh_orb_list_distances(self.ctx, capi.ptr(out, capi.c_int32_p)), "osh_orb_list_distances", self.lib)
+        return out[:self._list_total]
 
     def match(self):
         capi.check(self.lib.osh_orb_match(self.ctx), "osh_orb_match", self.lib)

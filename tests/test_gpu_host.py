@@ -561,6 +561,100 @@ def test_search_by_projection_sim3_equals_sequential_reference(ob, with_keyframe
     assert side.any() and bad.any()
 
 
+@pytest.mark.parametrize("only_stereo,coarse", [(False, False), (True, False), (False, True)])
+def test_search_for_triangulation_equals_reference(ob, only_stereo, coarse):
+    """ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:907-1146) on two pinhole keyframes seeing the same points: candidates of
+    the same vocabulary node, the `dist > bestDist` rule (the later of two equally distant candidates wins), the epipole gate for
+    monocular pairs, Pinhole::epipolarConstrain, bOnlyStereo / bCoarse, the orientation histogram.  Decoys with the true match's
+    descriptor sit off the epipolar line before and after it in the node's list."""
+    rng = np.random.Generator(np.random.PCG64(91 + 2 * int(only_stereo) + int(coarse)))
+    f32 = np.float32
+    n_true, n_rand, n_nodes = 520, 260, 90
+    fx, fy, cx, cy = (float(v) for v in (synth.FX, synth.FY, synth.CX, synth.CY))
+    # keyframe 1 at the origin, keyframe 2 half a metre to the right and 0.3 m forward with a small yaw
+    yaw = 0.05
+    R2 = np.array([[np.cos(yaw), 0, np.sin(yaw)], [0, 1, 0], [-np.sin(yaw), 0, np.cos(yaw)]])
+    t2 = np.array([-0.5, 0.02, -0.3])
+    X = np.stack([rng.uniform(-6, 6, n_true), rng.uniform(-3, 3, n_true), rng.uniform(5, 14, n_true)], axis=1)
+    def proj(Xc):
+        return np.stack([fx * Xc[:, 0] / Xc[:, 2] + cx, fy * Xc[:, 1] / Xc[:, 2] + cy], axis=1)
+    p1 = proj(X) + rng.normal(0, 0.4, (n_true, 2))
+    X2 = X @ R2.T + t2
+    p2 = proj(X2) + rng.normal(0, 0.4, (n_true, 2))
+    inside = (p1[:, 0] > 5) & (p1[:, 0] < synth.IMG_W - 5) & (p1[:, 1] > 5) & (p1[:, 1] < synth.IMG_H - 5) & \
+             (p2[:, 0] > 5) & (p2[:, 0] < synth.IMG_W - 5) & (p2[:, 1] > 5) & (p2[:, 1] < synth.IMG_H - 5)
+    p1, p2, X, X2 = p1[inside], p2[inside], X[inside], X2[inside]
+    nt = len(p1)
+    n_dec = nt // 5                                                    # decoys in keyframe 2: same descriptor, wrong place
+    n1, n2 = nt + n_rand, nt + n_dec + n_rand
+    def rand_xy(n):
+        return np.stack([rng.uniform(5, synth.IMG_W - 5, n), rng.uniform(5, synth.IMG_H - 5, n)], axis=1)
+    xy1 = np.concatenate([p1, rand_xy(n_rand)])
+    dec_of = rng.permutation(nt)[:n_dec]
+    xy2 = np.concatenate([p2, p2[dec_of] + rng.choice([-1.0, 1.0], (n_dec, 2)) * rng.uniform(25, 60, (n_dec, 2)), rand_xy(n_rand)])
+    desc1 = rng.integers(0, 256, (n1, 32), dtype=np.uint8)
+    desc2 = rng.integers(0, 256, (n2, 32), dtype=np.uint8)
+    desc2[:nt] = desc1[:nt] ^ np.packbits(rng.uniform(0, 1, (nt, 256)) < 0.05, axis=1)
+    desc2[nt:nt + n_dec] = desc2[dec_of]                               # exactly the true match's descriptor: a tie in distance
+    node1 = rng.integers(0, n_nodes, n1)
+    node2 = rng.integers(0, n_nodes + 10, n2)
+    node2[:nt] = node1[:nt]
+    node2[nt:nt + n_dec] = node1[dec_of]
+    octave1 = rng.integers(0, synth.N_LEVELS, n1).astype(np.int32)
+    octave2 = rng.integers(0, synth.N_LEVELS, n2).astype(np.int32)
+    octave2[:nt] = octave1[:nt]
+    angle1 = rng.uniform(0, 360, n1).astype(f32)
+    angle2 = rng.uniform(0, 360, n2).astype(f32)
+    angle2[:nt] = (angle1[:nt] - 15.0 + rng.normal(0, 3.0, nt)).astype(f32) % f32(360.0)
+    ur1 = np.where(rng.uniform(0, 1, n1) < 0.5, xy1[:, 0] - 40.0 / 8.0, -1.0).astype(f32)
+    ur2 = np.where(rng.uniform(0, 1, n2) < 0.5, xy2[:, 0] - 40.0 / 8.0, -1.0).astype(f32)
+    has1 = (rng.uniform(0, 1, n1) < 0.3).astype(np.uint8)
+    has2 = (rng.uniform(0, 1, n2) < 0.3).astype(np.uint8)
+    # shuffle the feature order of keyframe 2 so that decoys come before and after their true match inside a node's list
+    perm2 = rng.permutation(n2)
+    inv2 = np.argsort(perm2)
+    xy2, desc2, node2, octave2, angle2, ur2, has2 = xy2[perm2], desc2[perm2], node2[perm2], octave2[perm2], angle2[perm2], ur2[perm2], has2[perm2]
+
+    def fv(node):
+        ids = np.unique(node)
+        feats = [np.nonzero(node == i)[0] for i in ids]
+        off = np.concatenate([[0], np.cumsum([len(f) for f in feats])])
+        return ids.astype(np.int32), off.astype(np.int32), np.concatenate(feats).astype(np.int32)
+    fv1, fv2 = fv(node1), fv(node2)
+    kp1 = np.concatenate([xy1, angle1[:, None], ur1[:, None]], axis=1).astype(f32)
+    kp2 = np.concatenate([xy2, angle2[:, None], ur2[:, None]], axis=1).astype(f32)
+    q2 = synth._quat_from_R(R2)
+    pose1 = np.array([0, 0, 0, 1, 0, 0, 0], dtype=f32)
+    pose2 = np.concatenate([q2, t2]).astype(f32)
+    n, m = host.search_for_triangulation(kp1, octave1, desc1, has1, pose1, fv1, kp2, octave2, desc2, has2, pose2, fv2, only_stereo=only_stereo, coarse=coarse)
+    # ---- reference quantities: T12 = T1w Tw2 = T2w^-1 here, F12 = K1^-T [t12]x R12 K2^-1, the epipole of camera 1 in image 2
+    R12 = R2.T
+    t12 = -R2.T @ t2
+    tx = np.array([[0, -t12[2], t12[1]], [t12[2], 0, -t12[0]], [-t12[1], t12[0], 0]])
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+    F12 = np.linalg.inv(K).T @ tx @ R12 @ np.linalg.inv(K)
+    C2 = t2                                                             # T2w * Cw with Cw = 0
+    ep = np.array([fx * C2[0] / C2[2] + cx, fy * C2[1] / C2[2] + cy], dtype=f32)
+    sf = synth.SCALE_FACTORS.astype(f32)
+    sigma2 = (sf * sf).astype(f32)
+    # no candidate pair may sit on the decision boundary of the float32 epipolar test (float64 here, 0.5 % margin)
+    l = np.concatenate([xy1, np.ones((n1, 1))], axis=1) @ F12
+    for i in range(n1):
+        c = np.nonzero(node2 == node1[i])[0]
+        c = c[np.unpackbits(desc2[c] ^ desc1[i], axis=1).sum(axis=1) <= 50]     # the pairs the search evaluates
+        num = l[i, 0] * xy2[c, 0] + l[i, 1] * xy2[c, 1] + l[i, 2]
+        dsqr = num * num / (l[i, 0] ** 2 + l[i, 1] ** 2)
+        thr = 3.84 * sigma2[octave2[c]].astype(np.float64)
+        assert (np.abs(dsqr - thr) > 5e-3 * thr).all()
+    n_ref, m_ref = ob.orb_search_for_triangulation(desc1, desc2, has1, has2, fv1, fv2, kp1, kp2, octave2, F12.astype(f32), ep, sf, sigma2,
+                                                   only_stereo=only_stereo, coarse=coarse)
+    assert n == n_ref and n > (40 if only_stereo else 120)
+    np.testing.assert_array_equal(m, m_ref)
+    if not coarse:                                                      # the epipolar constraint rejected the decoys
+        dec_new = inv2[nt:nt + n_dec]
+        assert not np.isin(m_ref[m_ref >= 0], dec_new).any()
+
+
 def test_fuse_equals_sequential_reference(ob):
     """ORBmatcher::Fuse(pKF, vpMapPoints, th) (src/ORBmatcher.cc:1148-1338) on a stereo keyframe: projection gates (depth, image,
     scale-pyramid distance, 60 degree viewing angle), candidates by GetFeaturesInArea with the level and the reprojection-chi2 gates

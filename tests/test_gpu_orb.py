@@ -269,3 +269,18 @@ def test_frustum_projection_fisheye_frame_bit_exact(matcher, ob):
     pin = ob.frustum(_frustum_scene(5, 20000)[0], P, normal, min_d, max_d)
     both = (ref["stage"] >= 1) & (pin["stage"] >= 1)
     assert both.sum() > 2000 and np.abs(ref["proj_x"][both] - pin["proj_x"][both]).max() > 5.0      # a different camera model indeed
+
+
+def test_list_distances_bit_exact(matcher, ob):
+    """osh_orb_list_distances: every (query, candidate) entry of the uploaded lists against the oracle's DescriptorDistance."""
+    pairs = [synth.make_orb_pair(70 + i, 300, 500, windowed=True, same_level=False) for i in range(3)]
+    matcher.upload(pairs, windowed=True)
+    got = matcher.list_distances()
+    exp = []
+    for p in pairs:
+        q_of = np.repeat(np.arange(len(p.cand_off) - 1), np.diff(p.cand_off))
+        x = np.unpackbits(p.query_desc[q_of] ^ p.train_desc[p.cand_idx], axis=1).sum(axis=1)
+        exp.append(x.astype(np.int32))
+        assert ob.descriptor_distance(p.query_desc[q_of[0]], p.train_desc[p.cand_idx[0]]) == x[0]
+    np.testing.assert_array_equal(got, np.concatenate(exp))
+    assert len(got) > 1000
