@@ -35,6 +35,8 @@ class ORBmatcher {
   int SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches);
   // src/ORBmatcher.cc:765-905 (loop closing / map merging): map points of keyframe 1 against the map points of keyframe 2 of the same node
   int SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12);
+  // Matching for the Map Initialization (only used in the monocular case) (include/ORBmatcher.h:72, src/ORBmatcher.cc:648-763)
+  int SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12, int windowSize = 10);
   // Matching to triangulate new MapPoints. Check Epipolar Constraint. (include/ORBmatcher.h:75-76, src/ORBmatcher.cc:907-1146)
   int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<std::pair<size_t, size_t>>& vMatchedPairs, const bool bOnlyStereo,
                              const bool bCoarse = false);

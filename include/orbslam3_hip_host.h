@@ -160,6 +160,10 @@ int osh_host_search_sim3(osh_host_frame* f, const float scw[8], int32_t n_mp, co
                          const float* mp_min_max_dist, const float* mp_normal, const uint8_t* mp_bad,
                          const int32_t* matched_in, int32_t th, float ratio_hamming, int32_t with_keyframes,
                          int32_t* matched_out, int32_t* matched_kf_out);
+/* ORBmatcher(nnratio, check_ori).SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (src/ORBmatcher.cc:648-763):
+ * prev_xy[n1][2] is vbPrevMatched (updated in place), matches12[n1] = vnMatches12. */
+int osh_host_search_for_initialization(osh_host_frame* f1, osh_host_frame* f2, float* prev_xy, int32_t window, float nnratio, int32_t check_ori,
+                                       int32_t* matches12);
 /* ORBmatcher::SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse) (src/ORBmatcher.cc:907-1146) on two pinhole
  * keyframes: kp[n][4] = x, y, angle, uright (< 0: monocular), vocabulary nodes as (id, offsets, features), poses as unit quaternion
  * (x y z w) + translation of Tcw.  match12[i] = feature of keyframe 2 paired with feature i of keyframe 1 (-1 none). */

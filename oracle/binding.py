@@ -492,3 +492,20 @@ def orb_search_for_triangulation(desc1, desc2, has_mp1, has_mp2, fv1, fv2, kp1, 
                                                 _i32(f1[2]), len(f2[0]), _i32(f2[0]), _i32(f2[1]), _i32(f2[2]), fp(fl[0]), fp(fl[1]), _i32(o2), fp(fl[2]),
                                                 fp(fl[3]), fp(fl[4]), fp(fl[5]), int(only_stereo), int(coarse), int(th_low), int(check_ori), _i32(m))
     return int(n), m
+
+
+def orb_search_for_initialization(desc1, desc2, skip, cand_off, cand_idx, angle1, angle2, xy2, prev_xy, nn_ratio=0.9, th_low=50, check_ori=True):
+    """ORBmatcher::SearchForInitialization after its candidate generation, restated sequentially (orb_oracle.c)."""
+    lib = load()
+    i32, u8, f32p = C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.POINTER(C.c_float)
+    lib.oracle_orb_search_for_initialization.restype = C.c_int
+    lib.oracle_orb_search_for_initialization.argtypes = [C.c_int, C.c_int, u8, u8, u8, i32, i32, f32p, f32p, f32p, C.c_float, C.c_int, C.c_int, i32, f32p]
+    d1, d2, sk = (np.ascontiguousarray(a, dtype=np.uint8) for a in (desc1, desc2, skip))
+    off, idx = np.ascontiguousarray(cand_off, dtype=np.int32), np.ascontiguousarray(cand_idx if len(cand_idx) else [0], dtype=np.int32)
+    a1, a2, x2 = (np.ascontiguousarray(a, dtype=np.float32) for a in (angle1, angle2, xy2))
+    prev = np.array(prev_xy, dtype=np.float32)
+    fp = lambda a: a.ctypes.data_as(f32p)
+    m = -np.ones(d1.shape[0], dtype=np.int32)
+    n = lib.oracle_orb_search_for_initialization(d1.shape[0], d2.shape[0], _u8(d1), _u8(d2), _u8(sk), _i32(off), _i32(idx), fp(a1), fp(a2), fp(x2),
+                                                 C.c_float(nn_ratio), int(th_low), int(check_ori), _i32(m), fp(prev))
+    return int(n), m, prev

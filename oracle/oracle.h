@@ -78,6 +78,9 @@ int  oracle_orb_search_for_triangulation(int n1, int n2, const uint8_t* desc1, c
                                          const float* kp1, const float* kp2, const int32_t* octave2, const float* F12, const float* ep,
                                          const float* scale_factor_2, const float* level_sigma2_2, int only_stereo, int coarse, int th_low,
                                          int check_orientation, int32_t* match12);
+int  oracle_orb_search_for_initialization(int n1, int n2, const uint8_t* desc1, const uint8_t* desc2, const uint8_t* skip, const int32_t* cand_off,
+                                          const int32_t* cand_idx, const float* angle1, const float* angle2, const float* xy2, float nn_ratio,
+                                          int th_low, int check_orientation, int32_t* match12, float* prev_xy);
 int  oracle_orb_fuse(int n_q, int n_res, int n_feat, const uint8_t* q_desc, const uint8_t* feat_desc, const uint8_t* skip,
                      const int32_t* cand_off, const int32_t* cand_idx, const uint8_t* stereo, int th_low,
                      int32_t* slot, int32_t* nobs, uint8_t* bad, int32_t* replaced, uint8_t* in_kf);

@@ -605,3 +605,63 @@ int oracle_orb_search_for_triangulation(int n1, int n2, const uint8_t* desc1, co
   for (int i = 0; i < HISTO_LENGTH; ++i) free(hist[i]);
   return nmatches;
 }
+
+
+/* ORBmatcher::SearchForInitialization -- src/ORBmatcher.cc:648-763 after the candidate generation: keypoint q of frame 1 (skip[q]:
+ * level > 0 or an empty window) has the candidate list cand_idx[cand_off[q] .. cand_off[q+1]) (Frame::GetFeaturesInArea order, level
+ * 0).  A candidate is passed over while the distance it is currently matched with is <= this one (:680-681); best / second best;
+ * bestDist <= th_low and bestDist < nn_ratio * bestDist2 (float): the match replaces an earlier match of the same feature (:698-702).
+ * Orientation histogram on angle1 - angle2.  prev_xy (vbPrevMatched) is updated with the matched positions (:755-757). */
+int oracle_orb_search_for_initialization(int n1, int n2, const uint8_t* desc1, const uint8_t* desc2, const uint8_t* skip, const int32_t* cand_off,
+                                         const int32_t* cand_idx, const float* angle1, const float* angle2, const float* xy2, float nn_ratio,
+                                         int th_low, int check_orientation, int32_t* match12, float* prev_xy) {
+  enum { HISTO_LENGTH = 30 };
+  int nmatches = 0;
+  int* hist[HISTO_LENGTH];
+  int hsize[HISTO_LENGTH];
+  for (int i = 0; i < HISTO_LENGTH; ++i) { hist[i] = (int*)malloc(sizeof(int) * (size_t)(n1 + 1)); hsize[i] = 0; }
+  int* matched_dist = (int*)malloc(sizeof(int) * (size_t)(n2 ? n2 : 1));
+  int* match21 = (int*)malloc(sizeof(int) * (size_t)(n2 ? n2 : 1));
+  for (int i = 0; i < n2; ++i) { matched_dist[i] = 0x7fffffff; match21[i] = -1; }
+  for (int i = 0; i < n1; ++i) match12[i] = -1;
+  const float factor = 1.0f / HISTO_LENGTH;
+  for (int i1 = 0; i1 < n1; ++i1) {
+    if (skip[i1]) continue;
+    int bestDist = 0x7fffffff, bestDist2 = 0x7fffffff, bestIdx2 = -1;
+    for (int c = cand_off[i1]; c < cand_off[i1 + 1]; ++c) {
+      const int i2 = cand_idx[c];
+      const int dist = oracle_descriptor_distance(desc1 + 32 * (size_t)i1, desc2 + 32 * (size_t)i2);
+      if (matched_dist[i2] <= dist) continue;
+      if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+      else if (dist < bestDist2) bestDist2 = dist;
+    }
+    if (bestDist <= th_low && (float)bestDist < (float)bestDist2 * nn_ratio) {
+      if (match21[bestIdx2] >= 0) { match12[match21[bestIdx2]] = -1; nmatches--; }
+      match12[i1] = bestIdx2;
+      match21[bestIdx2] = i1;
+      matched_dist[bestIdx2] = bestDist;
+      nmatches++;
+      if (check_orientation) {
+        float rot = angle1[i1] - angle2[bestIdx2];
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)roundf(rot * factor);
+        if (bin == HISTO_LENGTH) bin = 0;
+        hist[bin][hsize[bin]++] = i1;
+      }
+    }
+  }
+  if (check_orientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(hsize, HISTO_LENGTH, &ind1, &ind2, &ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int j = 0; j < hsize[i]; j++)
+        if (match12[hist[i][j]] >= 0) { match12[hist[i][j]] = -1; nmatches--; }
+    }
+  }
+  for (int i1 = 0; i1 < n1; ++i1)
+    if (match12[i1] >= 0) { prev_xy[2 * i1] = xy2[2 * match12[i1]]; prev_xy[2 * i1 + 1] = xy2[2 * match12[i1] + 1]; }
+  for (int i = 0; i < HISTO_LENGTH; ++i) free(hist[i]);
+  free(matched_dist); free(match21);
+  return nmatches;
+}

@@ -311,6 +311,7 @@ _HOST_SIGNATURES = {
     "osh_host_search_for_triangulation": (C.c_int, [c_float_p, C.c_int32, C.c_float, C.c_int32, c_float_p, c_int32_p, c_uint8_p, c_uint8_p, c_float_p,
                                                     C.c_int32, c_int32_p, c_int32_p, c_int32_p, C.c_int32, c_float_p, c_int32_p, c_uint8_p, c_uint8_p,
                                                     c_float_p, C.c_int32, c_int32_p, c_int32_p, c_int32_p, C.c_int32, C.c_int32, C.c_int32, c_int32_p]),
+    "osh_host_search_for_initialization": (C.c_int, [C.c_void_p, C.c_void_p, c_float_p, C.c_int32, C.c_float, C.c_int32, c_int32_p]),
     "osh_host_pack_gba": (C.c_int, [C.c_void_p, c_int32_p, c_double_p, c_double_p, c_double_p, c_int32_p, c_int32_p, c_uint8_p, c_double_p,
                                     c_double_p, c_int64_p, c_int64_p]),
     "osh_host_pack_welding": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_int32_p, C.c_int32, c_int32_p, c_int32_p, c_double_p, c_double_p,

@@ -10,6 +10,7 @@
 // (its candidate list is then rebuilt by the frame's own GetFeaturesInArea).
 #include "ORBmatcher.h"
 
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -726,6 +727,76 @@ bool device_list_distances(const std::vector<uint8_t>& qdesc, const cv::Mat& tra
 }
 
 }  // namespace
+
+// src/ORBmatcher.cc:648-763 (monocular map initialisation).  The candidates of every level-0 keypoint of F1 are the level-0 features
+// of F2 in the window around its previous match; the device returns the distance of every (keypoint, candidate) entry in one launch.
+// The loop itself is order dependent -- a candidate is skipped while the distance it was last matched with is not larger
+// (vMatchedDistance), and a new match displaces the old one of the same feature -- and is replayed as written.
+int ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12, int windowSize) {
+  int nmatches = 0;
+  vnMatches12 = std::vector<int>(F1.mvKeysUn.size(), -1);
+  std::vector<int> rotHist[HISTO_LENGTH];
+  for (int i = 0; i < HISTO_LENGTH; i++) rotHist[i].reserve(500);
+  const float factor = 1.0f / HISTO_LENGTH;
+  std::vector<int> vMatchedDistance(F2.mvKeysUn.size(), INT_MAX);
+  std::vector<int> vnMatches21(F2.mvKeysUn.size(), -1);
+  // queries: the level-0 keypoints with a non-empty window, in order
+  std::vector<int> q1;
+  std::vector<uint8_t> qdesc;
+  std::vector<int32_t> off(1, 0), idx;
+  for (size_t i1 = 0, iend1 = F1.mvKeysUn.size(); i1 < iend1; i1++) {
+    const int level1 = F1.mvKeysUn[i1].octave;
+    if (level1 > 0) continue;
+    const std::vector<size_t> vIndices2 = F2.GetFeaturesInArea(vbPrevMatched[i1].x, vbPrevMatched[i1].y, (float)windowSize, level1, level1);
+    if (vIndices2.empty()) continue;
+    for (size_t i2 : vIndices2) idx.push_back((int32_t)i2);
+    off.push_back((int32_t)idx.size());
+    q1.push_back((int)i1);
+    qdesc.insert(qdesc.end(), F1.mDescriptors.ptr<uint8_t>((int)i1), F1.mDescriptors.ptr<uint8_t>((int)i1) + 32);
+  }
+  std::vector<int32_t> dist;
+  if (!device_list_distances(qdesc, F2.mDescriptors, F2.mDescriptors.rows, off, idx, dist)) return 0;
+  for (size_t q = 0; q < q1.size(); ++q) {
+    const int i1 = q1[q];
+    int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+    for (int e = off[q]; e < off[q + 1]; ++e) {
+      const int i2 = idx[e], d = dist[e];
+      if (vMatchedDistance[i2] <= d) continue;
+      if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestIdx2 = i2; }
+      else if (d < bestDist2) bestDist2 = d;
+    }
+    if (bestDist <= TH_LOW) {
+      if (bestDist < (float)bestDist2 * mfNNratio) {
+        if (vnMatches21[bestIdx2] >= 0) { vnMatches12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+        vnMatches12[i1] = bestIdx2;
+        vnMatches21[bestIdx2] = i1;
+        vMatchedDistance[bestIdx2] = bestDist;
+        nmatches++;
+        if (mbCheckOrientation) {
+          float rot = F1.mvKeysUn[i1].angle - F2.mvKeysUn[bestIdx2].angle;
+          if (rot < 0.0) rot += 360.0f;
+          int bin = (int)std::round(rot * factor);
+          if (bin == HISTO_LENGTH) bin = 0;
+          rotHist[bin].push_back(i1);
+        }
+      }
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+        const int idx1 = rotHist[i][j];
+        if (vnMatches12[idx1] >= 0) { vnMatches12[idx1] = -1; nmatches--; }
+      }
+    }
+  }
+  for (size_t i1 = 0, iend1 = vnMatches12.size(); i1 < iend1; i1++)      // update prev matched
+    if (vnMatches12[i1] >= 0) vbPrevMatched[i1] = F2.mvKeysUn[vnMatches12[i1]].pt;
+  return nmatches;
+}
 
 // src/ORBmatcher.cc:907-1146.  No step of this search depends on an earlier one (vbMatched2 is read but never set), so every
 // unmatched feature of keyframe 1 is a query whose candidates are the unmatched features of keyframe 2 in the same vocabulary

@@ -844,6 +844,19 @@ extern "C" int osh_host_search_by_bow_kf(int32_t n1, const uint8_t* desc1, const
   return n;
 }
 
+// ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize): prev_xy[n1][2] in / out.
+extern "C" int osh_host_search_for_initialization(osh_host_frame* f1, osh_host_frame* f2, float* prev_xy, int32_t window, float nnratio, int32_t check_ori,
+                                                  int32_t* matches12) {
+  if (!f1 || !f2) return -1;
+  std::vector<cv::Point2f> prev(f1->F.mvKeysUn.size());
+  for (size_t i = 0; i < prev.size(); ++i) { prev[i].x = prev_xy[2 * i]; prev[i].y = prev_xy[2 * i + 1]; }
+  std::vector<int> m;
+  ORBmatcher matcher(nnratio, check_ori != 0);
+  const int n = matcher.SearchForInitialization(f1->F, f2->F, prev, m, window);
+  for (size_t i = 0; i < prev.size(); ++i) { prev_xy[2 * i] = prev[i].x; prev_xy[2 * i + 1] = prev[i].y; matches12[i] = m[i]; }
+  return n;
+}
+
 // ORBmatcher::SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse) on two pinhole keyframes built from flat
 // features: kp[n][4] = x, y, angle, uright (< 0: monocular keypoint); match12[i] = feature of keyframe 2 paired with feature i or -1.
 extern "C" int osh_host_search_for_triangulation(const float cam4[4], int32_t n_levels, float scale_factor, int32_t n1, const float* kp1,

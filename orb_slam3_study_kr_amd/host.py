@@ -651,3 +651,14 @@ def search_for_triangulation(kp1, octave1, desc1, has_mp1, pose1_qt, fv1, kp2, o
                                               capi.ptr(keep[14], ip), capi.ptr(keep[15], ip), capi.ptr(keep[16], ip), int(only_stereo), int(coarse),
                                               int(check_ori), capi.ptr(m, ip))
     return n, m
+
+
+def search_for_initialization(f1, f2, prev_xy, window=100, nnratio=0.9, check_ori=True):
+    """ORBmatcher(nnratio, check_ori).SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (src/ORBmatcher.cc:648-763)
+    on two HostFrames; returns (nmatches, vnMatches12, the updated vbPrevMatched)."""
+    lib = capi.load_library()
+    prev = np.array(prev_xy, dtype=np.float32)
+    m = -np.ones(f1.n, dtype=np.int32)
+    n = lib.osh_host_search_for_initialization(f1.f, f2.f, capi.ptr(prev, capi.c_float_p), int(window), float(nnratio), int(check_ori),
+                                               capi.ptr(m, capi.c_int32_p))
+    return n, m, prev

@@ -561,6 +561,55 @@ def test_search_by_projection_sim3_equals_sequential_reference(ob, with_keyframe
     assert side.any() and bad.any()
 
 
+def test_search_for_initialization_equals_sequential_reference(ob):
+    """ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:648-763): level-0 keypoints only, windows around vbPrevMatched, a candidate
+    passed over while its current match is at least as close, displaced matches, ratio test, orientation histogram, vbPrevMatched
+    updated.  Several keypoints of frame 1 compete for the same feature of frame 2 (near-duplicate descriptors)."""
+    rng = np.random.Generator(np.random.PCG64(123))
+    f32 = np.float32
+    n1, n2 = 900, 1000
+    xy1 = np.stack([rng.uniform(20, synth.IMG_W - 20, n1), rng.uniform(20, synth.IMG_H - 20, n1)], axis=1).astype(f32)
+    oct1 = np.where(rng.uniform(0, 1, n1) < 0.7, 0, rng.integers(1, synth.N_LEVELS, n1)).astype(np.int32)
+    desc1 = rng.integers(0, 256, (n1, 32), dtype=np.uint8)
+    dup = rng.permutation(n1)[:150]                                     # competitors: same place, nearly the same descriptor
+    xy1[dup] = xy1[(dup + 1) % n1] + rng.normal(0, 1.0, (150, 2)).astype(f32)
+    desc1[dup] = desc1[(dup + 1) % n1] ^ np.packbits(rng.uniform(0, 1, (150, 256)) < 0.01, axis=1)
+    oct1[dup] = oct1[(dup + 1) % n1]
+    xy2 = np.stack([rng.uniform(20, synth.IMG_W - 20, n2), rng.uniform(20, synth.IMG_H - 20, n2)], axis=1).astype(f32)
+    oct2 = np.where(rng.uniform(0, 1, n2) < 0.7, 0, rng.integers(1, synth.N_LEVELS, n2)).astype(np.int32)
+    desc2 = rng.integers(0, 256, (n2, 32), dtype=np.uint8)
+    src = rng.permutation(n1)[:700]
+    tgt = rng.permutation(n2)[:700]
+    xy2[tgt] = xy1[src] + rng.normal(0, 15.0, (700, 2)).astype(f32)       # the scene moved a little between the two frames
+    desc2[tgt] = desc1[src] ^ np.packbits(rng.uniform(0, 1, (700, 256)) < 0.05, axis=1)
+    oct2[tgt] = oct1[src]
+    ang1 = rng.uniform(0, 360, n1).astype(f32)
+    ang2 = rng.uniform(0, 360, n2).astype(f32)
+    ang2[tgt] = (ang1[src] - 10.0 + rng.normal(0, 3.0, 700)).astype(f32) % f32(360.0)
+    prev = xy1.copy()                                                    # Tracking::MonocularInitialization: vbPrevMatched = the keypoints of F1
+    window = 100
+    f1 = host.HostFrame(xy1, oct1, desc1, angle=ang1)
+    f2 = host.HostFrame(xy2, oct2, desc2, angle=ang2)
+    try:
+        n, m, prev_out = host.search_for_initialization(f1, f2, prev, window=window, nnratio=0.9)
+    finally:
+        f1.close(); f2.close()
+    sel = np.nonzero(oct1 == 0)[0]
+    off0, idx0 = synth.features_in_area_lists(xy2[:, 0], xy2[:, 1], oct2, prev[sel, 0], prev[sel, 1], np.full(len(sel), f32(window)), np.zeros(len(sel), np.int32),
+                                              np.zeros(len(sel), np.int32))
+    skip = np.ones(n1, dtype=np.uint8)
+    lens = np.zeros(n1, dtype=np.int32)
+    lens[sel] = np.diff(off0)
+    skip[sel[np.diff(off0) > 0]] = 0
+    full_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    n_ref, m_ref, prev_ref = ob.orb_search_for_initialization(desc1, desc2, skip, full_off, idx0, ang1, ang2, xy2, prev, nn_ratio=0.9)
+    assert n == n_ref and n > 250
+    np.testing.assert_array_equal(m, m_ref)
+    np.testing.assert_array_equal(prev_out, prev_ref)
+    taken = m_ref[m_ref >= 0]
+    assert len(np.unique(taken)) == len(taken)                           # a feature of frame 2 ends up with one match
+
+
 @pytest.mark.parametrize("only_stereo,coarse", [(False, False), (True, False), (False, True)])
 def test_search_for_triangulation_equals_reference(ob, only_stereo, coarse):
     """ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:907-1146) on two pinhole keyframes seeing the same points: candidates of
