@@ -169,9 +169,9 @@ def run_lba(args, info, windows):
 
 
 def run_end_to_end(args, info, windows):
-    """Upload + optimize + download of whole batches, the call pattern of a caller that hands over HOST buffers: two solver
-    contexts (own stream, own pinned staging) driven by two host threads work on alternate batches, so the host packing /
-    H2D copy of batch b+1 overlaps the optimisation of batch b on the device.  Every batch is packed from scratch (sort,
+    """Upload + optimize + download of whole batches, the call pattern of a caller that hands over HOST buffers: several solver
+    contexts (own stream, own pinned staging), each driven by its own host thread, work on different batches, so the host packing /
+    H2D copy of one batch overlaps the optimisation of another on the device.  Every batch is packed from scratch (sort,
     Schur plan, landmark renumbering) -- the work SparseOptimizer::initializeOptimization + BlockSolver::buildStructure do
     inside the call this replaces.  Only C-ABI calls are inside the timed region."""
     from concurrent.futures import ThreadPoolExecutor
@@ -196,6 +196,11 @@ def run_end_to_end(args, info, windows):
             sv.download_prepared(res)
         return ups
 
+    # packing threads per context: the contexts pack at the same time, so together they should not oversubscribe the cores by much
+    # (measured on the 16-core GPU box, profiles/e2e_sweep.sh: 2 x 16 threads 0.42-0.46 of the resident rate, 4 x 8 threads 0.48-0.55)
+    user_threads = os.environ.get("ORBSLAM3_HIP_UPLOAD_THREADS")
+    e2e_threads = int(user_threads) if user_threads else max(4, min(16, os.cpu_count() or 1) * 2 // n_ctx)
+    os.environ["ORBSLAM3_HIP_UPLOAD_THREADS"] = str(e2e_threads)
     pool = ThreadPoolExecutor(n_ctx)
     list(pool.map(lambda k: drive(k, 1), range(n_ctx)))            # warm-up: staging buffers, device buffers
     torch.cuda.synchronize()
@@ -205,7 +210,9 @@ def run_end_to_end(args, info, windows):
     torch.cuda.synchronize()
     osh_dist.barrier(info)
     elapsed = osh_dist.all_reduce_max(info, time.perf_counter() - t0)
-    # one batch alone, phases timed one after the other (no overlap): where an end-to-end batch spends its time
+    # one batch alone, phases timed one after the other (no overlap, all packing threads): where an end-to-end batch spends its time
+    if user_threads is None:
+        del os.environ["ORBSLAM3_HIP_UPLOAD_THREADS"]
     sv = solvers[0]
     probs, res, outs = prepared[0]
     t = [time.perf_counter()]
@@ -216,7 +223,7 @@ def run_end_to_end(args, info, windows):
     for s_ in solvers:
         s_.close()
     pool.shutdown()
-    return dict(elapsed=elapsed, n_batches=n_batches, n_ctx=n_ctx, serial_ms=dict(upload=(t[1] - t[0]) * 1e3, optimize=(t[2] - t[1]) * 1e3,
+    return dict(elapsed=elapsed, n_batches=n_batches, n_ctx=n_ctx, upload_threads=e2e_threads, serial_ms=dict(upload=(t[1] - t[0]) * 1e3, optimize=(t[2] - t[1]) * 1e3,
                                                                        download=(t[3] - t[2]) * 1e3, upload_pack=up["pack_ms"], upload_copy=up["copy_ms"]),
                 pack_ms_mean=float(np.mean([u["pack_ms"] for u in ups])), copy_ms_mean=float(np.mean([u["copy_ms"] for u in ups])))
 
@@ -442,7 +449,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-orb", action="store_true")
     ap.add_argument("--inertial-windows", type=int, default=128, help="config-4 windows per osh_liba_solve call (0 = skip)")
-    ap.add_argument("--e2e-contexts", type=int, default=2, help="solver contexts (each with its own host thread, stream and pinned staging) of the end-to-end run")
+    ap.add_argument("--e2e-contexts", type=int, default=4, help="solver contexts (each with its own host thread, stream and pinned staging) of the end-to-end run")
     ap.add_argument("--e2e-batches", type=int, default=3, help="batches per solver context in the end-to-end (upload + optimize + download) run; 0 = skip")
     ap.add_argument("--stub-solver", action="store_true", help="CPU rehearsal of the rank plumbing (gloo): no GPU work, the "
                     "timed step is a fixed sleep; the JSON line is marked \"stub\" and is not a measurement")
@@ -548,7 +555,7 @@ def main():
                              "batches": e2e_out["n_batches"], "windows_per_batch": args.windows, "ms_per_batch": e2e_out["elapsed"] / e2e_out["n_batches"] * 1e3,
                              "fraction_of_resident": (e2e_windows / e2e_out["elapsed"]) / value,
                              "one_batch_serial_ms": e2e_out["serial_ms"], "pack_ms_mean": e2e_out["pack_ms_mean"], "copy_ms_mean": e2e_out["copy_ms_mean"],
-                             "upload_threads": int(os.environ.get("ORBSLAM3_HIP_UPLOAD_THREADS", min(16, os.cpu_count() or 1)))}
+                             "upload_threads_per_context": e2e_out["upload_threads"]}
     if orb_out is not None:
         out["orb"] = {"metric": "ORB matches/sec (SearchByProjection 256-bit Hamming, 2000x2000 per frame pair)",
                       "matches_per_s": orb_out["matches_per_s"], "pair_evals_per_s": orb_out["pair_evals_per_s"],
