@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 namespace osh {
@@ -1204,8 +1205,16 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
   v.res_abort = reinterpret_cast<int*>(dres + r_abort); v.res_pose = reinterpret_cast<double*>(dres + r_pose); v.res_vba = reinterpret_cast<double*>(dres + r_vba);
   v.res_pts = reinterpret_cast<double*>(dres + r_pts); v.out_chi2 = reinterpret_cast<double*>(dres + r_chi2);
   v.out_depth = reinterpret_cast<unsigned char*>(dres + r_depth);
-  static bool attr_done = false;
-  if (!attr_done) { OSH_HIP(hipFuncSetAttribute((const void*)k_liba, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)); attr_done = true; }
+  {
+    // opt in to large dynamic LDS: the attribute is per device, so once per device of the process
+    static std::mutex attr_mu;
+    static std::vector<int> attr_devices;
+    std::lock_guard<std::mutex> attr_lock(attr_mu);
+    if (std::find(attr_devices.begin(), attr_devices.end(), device) == attr_devices.end()) {
+      OSH_HIP(hipFuncSetAttribute((const void*)k_liba, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+      attr_devices.push_back(device);
+    }
+  }
   // blocks per window: the tracker's single window (and small batches) get a group of 32 = one whole XCD; a large batch fills the chip
   // with one block per window.  A group needs all its blocks resident (they meet at barriers): cooperative launch checks that.
   int G = nw <= 8 ? kLG : (nw <= 16 ? 16 : (nw <= 32 ? 8 : (nw <= 64 ? 4 : (nw <= 128 ? 2 : 1))));
