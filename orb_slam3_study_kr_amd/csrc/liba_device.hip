@@ -1046,7 +1046,7 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
     EF += ef; LP += (size_t)d.L * d.N;
     n_max = std::max(n_max, d.n);
   }
-  if (n_max / 15 > 30) { set_error("inertial window with %d optimisable keyframes: the device path handles up to 30 (the reference uses 10 or 25)", n_max / 15); return OSH_ERR_UNSUPPORTED; }
+  if (n_max / 15 > 25) { set_error("inertial window with %d optimisable keyframes: the device path handles up to 25 (the reference uses 10 or 25; the panels of the reduced system's LDL^T live in LDS)", n_max / 15); return OSH_ERR_UNSUPPORTED; }
   const int W = ldlt_row_stride(n_max);
   const size_t lds = (liba_scratch_doubles(W) + kLT / 64 + 8) * sizeof(double);
   if (lds > 160 * 1024 - 64) { set_error("inertial window with %d keyframes exceeds the LDS budget", n_max / 15); return OSH_ERR_UNSUPPORTED; }

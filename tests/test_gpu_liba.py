@@ -139,3 +139,11 @@ def test_agent_scope_barrier_path_agrees(solver, monkeypatch):
     np.testing.assert_array_equal(a.chi2_trace, b.chi2_trace)
     np.testing.assert_array_equal(a.pose_twb, b.pose_twb)
     np.testing.assert_array_equal(a.points, b.points)
+
+
+def test_large_window_of_25_keyframes(solver, ob):
+    """LocalInertialBA's bLarge case: 25 temporal keyframes (src/Optimizer.cc:2394-2400), a 375 x 375 reduced system."""
+    w = si.make_inertial_window(61, n_opt=25, n_fixed=10, n_points=1500, large=True)
+    _check(solver.solve_inertial([w])[0], ob.liba_solve(w), w)
+    with pytest.raises(RuntimeError, match="up to 25"):
+        solver.solve_inertial([si.make_inertial_window(62, n_opt=26, n_fixed=5, n_points=600, large=True)])
