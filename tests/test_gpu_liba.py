@@ -21,7 +21,7 @@ def ob():
     return binding
 
 
-def _check(got, ref, w, tol=1e-6, pts_tol=1e-6, edge_tol=1e-4):
+def _check(got, ref, w, tol=1e-6, pts_tol=1e-6, edge_tol=1e-4, lam_tol=1e-5):
     assert got.iterations == ref.iterations
     np.testing.assert_array_equal(got.trials_trace, ref.trials_trace)
     # float32 sinf/cosf of the preintegration getters differ by an ulp between device and host libm; the
@@ -29,7 +29,7 @@ def _check(got, ref, w, tol=1e-6, pts_tol=1e-6, edge_tol=1e-4):
     np.testing.assert_allclose(got.chi2_initial, ref.chi2_initial, rtol=1e-7)
     np.testing.assert_allclose(got.chi2_trace, ref.chi2_trace, rtol=1e-6)
     np.testing.assert_allclose(got.chi2_final, ref.chi2_final, rtol=1e-6)
-    np.testing.assert_allclose(got.lambda_trace, ref.lambda_trace, rtol=1e-5)
+    np.testing.assert_allclose(got.lambda_trace, ref.lambda_trace, rtol=lam_tol)
     t_rel = np.max(np.linalg.norm(got.pose_tcw - ref.pose_tcw, axis=1) / np.linalg.norm(ref.pose_tcw, axis=1))
     assert t_rel < tol, t_rel                                  # north star: SE3 translations <= 1e-6 relative
     assert np.abs(got.pose_Rcw - ref.pose_Rcw).max() < tol
@@ -147,3 +147,22 @@ def test_large_window_of_25_keyframes(solver, ob):
     _check(solver.solve_inertial([w])[0], ob.liba_solve(w), w)
     with pytest.raises(RuntimeError, match="up to 25"):
         solver.solve_inertial([si.make_inertial_window(62, n_opt=26, n_fixed=5, n_points=600, large=True)])
+
+
+def test_many_window_shapes_through_the_block_groups(solver, ob, monkeypatch):
+    """Windows of many shapes (3..12 keyframes, 60..1300 landmarks, with and without fixed observers), one at a time (a group of 32
+    blocks each) and as one batch (groups of 16): the barriers, the lane teams and the chunked sums see every remainder case."""
+    rng = np.random.Generator(np.random.PCG64(2024))
+    ws = []
+    for k in range(14):
+        ws.append(si.make_inertial_window(200 + k, n_opt=int(rng.integers(3, 13)), n_fixed=int(rng.integers(0, 12)), n_points=int(rng.integers(60, 1300)),
+                                          large=bool(k % 3 == 0), rec_init=bool(k % 4 == 1)))
+    refs = [ob.liba_solve(w) for w in ws]
+    # near convergence the gain ratio is a quotient of two 1e-6-relative cost differences, and lambda follows its cube: 1e-3 there;
+    # landmarks seen from two or three nearby keyframes only (the small windows) have a depth the float32 preintegration noise moves
+    for w, r in zip(ws, refs):
+        _check(solver.solve_inertial([w])[0], r, w, lam_tol=1e-3, pts_tol=2e-4, edge_tol=1e-3)
+    assert solver.inertial_profile()[0] == 32
+    for g, w, r in zip(solver.solve_inertial(ws), ws, refs):
+        _check(g, r, w, lam_tol=1e-3, pts_tol=2e-4, edge_tol=1e-3)
+    assert solver.inertial_profile()[0] == 16
