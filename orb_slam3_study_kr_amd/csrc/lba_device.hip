@@ -1359,6 +1359,8 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
     auto need = [&](int b) { return ldlt_lds_doubles(b, ldlt_row_stride(pb.n_max), c->solve_threads) * sizeof(double); };
     int nb = 24;
     while (nb > 6 && need(nb) > (size_t)150 * 1024) nb /= 2;  // 24 -> 12 -> 6 (template instantiations of k_solve)
+    if (const char* e = std::getenv("OSH_LBA_SOLVE_THREADS")) { const int t = std::atoi(e); if (t == kSolveThreadsBatch || t == kSolveThreadsLatency) c->solve_threads = t; }
+    if (const char* e = std::getenv("OSH_LBA_SOLVE_NB")) { const int b = std::atoi(e); if ((b == 24 || b == 12 || b == 6) && b <= nb) nb = b; }
     c->solve_big = need(nb) > (size_t)150 * 1024;
     if (c->solve_big) {
       // beyond ~240 optimisable poses (global BA of a long session) the system is factored in global memory, one window at a time
