@@ -127,6 +127,7 @@ __global__ __launch_bounds__(kIT) void k_posei(PoseiView v) {
   __shared__ double shH[900], shb[30], shx[30];
   __shared__ double shJ[9 * 24], shWJ[15 * 30], shr[15], shJp[225];
   __shared__ double shU[32 * 33];
+  __shared__ double shred[27];                 // the 27 visual sums, looked up by entry (a register array indexed at run time lives in scratch)
   __shared__ float shrec[OSH_PREINT_FLOATS];   // the preintegration record: read a dozen times per iteration by one thread
   __shared__ int sh_ok;
   const PoseiDesc& d = v.desc[blockIdx.x];
@@ -200,12 +201,17 @@ __global__ __launch_bounds__(kIT) void k_posei(PoseiView v) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) red[21 + k] = b[k];
     posei_block_sum_n<27>(red, shn);
+    if (tid == 0) {
+#pragma unroll
+      for (int k = 0; k < 27; ++k) shred[k] = red[k];
+    }
+    __syncthreads();
     for (int idx = tid; idx < n * n; idx += kIT) {
       const int r = idx / n, c = idx - r * n;
       double acc = 0.0;
       if (r < 6 && c < 6) {   // visual edges: upper-triangle sums mirrored
         const int a = r < c ? r : c, bq = r < c ? c : r;
-        acc += red[a * 6 - a * (a - 1) / 2 + (bq - a)];
+        acc += shred[a * 6 - a * (a - 1) / 2 + (bq - a)];
       }
       // random walks: r = b_cur - b_prev, J = [-I, I]
       for (int which = 0; which < 2; ++which) {
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(kIT) void k_posei(PoseiView v) {
       shH[r * n + c] += t;
     }
     if (tid < n) {
-      double acc = tid < 6 ? red[21 + tid] : 0.0;
+      double acc = tid < 6 ? shred[21 + tid] : 0.0;
       for (int ca = 0; ca < 24; ++ca) {
         if (unk_of(ca) != tid) continue;
         double t = 0.0;
@@ -417,6 +423,10 @@ __global__ __launch_bounds__(kIT) void k_posei(PoseiView v) {
 #pragma unroll
     for (int k = 0; k < 21; ++k) red[k] = H[k];
     posei_block_sum_n<21>(red, shn);
+    if (tid == 0) {
+#pragma unroll
+      for (int k = 0; k < 21; ++k) shred[k] = red[k];
+    }
     if (mode1 && tid == 0) {
       double T[9], dd[3], rr[15], invJr[9];
       imu::m3_tmul(d.prior_R, shpP + 12, T);
@@ -446,7 +456,7 @@ __global__ __launch_bounds__(kIT) void k_posei(PoseiView v) {
       if (r >= o2 && r < o2 + 6 && c >= o2 && c < o2 + 6) {
         const int a0 = r - o2, c0 = c - o2;
         const int a = a0 < c0 ? a0 : c0, bq = a0 < c0 ? c0 : a0;
-        acc += red[a * 6 - a * (a - 1) / 2 + (bq - a)];
+        acc += shred[a * 6 - a * (a - 1) / 2 + (bq - a)];
       }
       for (int ca = 0; ca < 24; ++ca) {
         if (ref_of(ca) != r) continue;
