@@ -1224,7 +1224,8 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
   if (G > 1) {
     void* args[] = {(void*)&v, (void*)&W_arg, (void*)&G};
     le = hipLaunchCooperativeKernel((const void*)k_liba, dim3((unsigned)((nw + 7) / 8 * 8 * G)), dim3(kLT), args, (unsigned)lds, s);
-    if (le == hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); G = 1; le = hipSuccess; }
+    // not enough free CUs for every group to be resident, or no cooperative launches on this device: one block per window needs neither
+    if (le != hipSuccess) { (void)hipGetLastError(); G = 1; le = hipSuccess; }
   }
   if (G == 1) {
     hipLaunchKernelGGL(k_liba, dim3((unsigned)((nw + 7) / 8 * 8)), dim3(kLT), lds, s, v, W, 1);
