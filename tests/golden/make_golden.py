@@ -17,6 +17,7 @@ sys.path.insert(0, str(ROOT))
 from orb_slam3_study_kr_amd import synth  # noqa: E402
 from oracle import lm_numpy  # noqa: E402
 from oracle import liba_numpy  # noqa: E402
+from oracle import pose_numpy  # noqa: E402
 from orb_slam3_study_kr_amd import synth_inertial  # noqa: E402
 
 OUT = Path(__file__).resolve().parent
@@ -65,6 +66,17 @@ POSEI_INPUTS = ("Rcw", "tcw", "Rwb", "twb", "vel", "bias_g", "bias_a", "prev_Rwb
                 "prior_twb", "prior_vel", "prior_bg", "prior_ba", "prior_H", "kb8", "cam2", "trl")
 
 
+def pose_fixture(name, f):
+    """PoseOptimization: the flat frame + the outputs of the independent numpy model (oracle/pose_numpy.py: numeric Jacobians, own
+    Levenberg-Marquardt loop and classification rounds)."""
+    r = pose_numpy.pose_optimize(f)
+    np.savez_compressed(OUT / f"{name}.npz", pose_qt=f.pose_qt, cam=f.cam, points=f.points, edge_kind=f.edge_kind, edge_obs=f.edge_obs, edge_info=f.edge_info,
+                        huber=np.array([f.huber_mono, f.huber_stereo]), chi2_mono=np.array(f.chi2_mono), chi2_stereo=np.array(f.chi2_stereo),
+                        iterations=np.array(f.iterations), exp_T=r["T"], exp_outlier=r["outlier"], exp_n_bad=r["n_bad"], exp_chi2_final=r["chi2_final"],
+                        exp_edge_chi2=r["edge_chi2"], exp_rounds=r["rounds"])
+    print(name, "edges", f.n_edges, "iterations", r["iterations"], "bad", r["n_bad"], "chi2", r["chi2_final"])
+
+
 def posei_fixture(name, f):
     """PoseInertialOptimizationLastKeyFrame / LastFrame: inputs + the outputs of the independent numpy model (oracle/liba_numpy.py:
     central-difference Jacobians, numpy.linalg.solve, its own classification loop)."""
@@ -95,7 +107,10 @@ def liba_fixture(name, w):
     print(name, "edges", w.n_edges, "iters", tr["iterations"], "trials", tr["trials"], "chi2", tr["chi2_initial"], "->", tr["chi2"][-1])
 
 
-if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "liba":
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "pose":
+    pose_fixture("pose_tiny", synth.make_pose_frame(401, n_points=70, mixed_mono_frac=0.4, outlier_frac=0.15))
+    pose_fixture("pose_tiny_mono", synth.make_pose_frame(402, n_points=60, stereo=False, outlier_frac=0.1))
+elif __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "liba":
     liba_fixture("liba_tiny", synth_inertial.make_inertial_window(5, n_opt=3, n_fixed=2, n_points=40))
     liba_fixture("liba_tiny_rig", synth_inertial.make_inertial_rig_window(7, n_opt=3, n_fixed=2, n_points=40))
 elif __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "posei":
@@ -118,6 +133,8 @@ elif __name__ == "__main__":
     # fisheye STEREO rig: left KannalaBrandt8 edges + right-camera body edges (EdgeSE3ProjectXYZToBody) sharing Hessian blocks
     lba_fixture("lba_tiny_rig", synth.make_rig_window(71, n_free=3, n_fixed=2, n_points=40, track_len=(2, 5)))
     orb_fixture()
+    pose_fixture("pose_tiny", synth.make_pose_frame(401, n_points=70, mixed_mono_frac=0.4, outlier_frac=0.15))
+    pose_fixture("pose_tiny_mono", synth.make_pose_frame(402, n_points=60, stereo=False, outlier_frac=0.1))
     liba_fixture("liba_tiny", synth_inertial.make_inertial_window(5, n_opt=3, n_fixed=2, n_points=40))
     liba_fixture("liba_tiny_rig", synth_inertial.make_inertial_rig_window(7, n_opt=3, n_fixed=2, n_points=40))
     posei_fixture("posei_tiny_keyframe", synth_inertial.make_posei_frame(9, mode=0, n_points=60))

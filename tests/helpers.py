@@ -110,3 +110,30 @@ def check_against_liba_fixture(got, z, fisheye):
     np.testing.assert_allclose(got.bias_a, z["exp_ba"], atol=1e-6)
     # weakly observed depths of a monocular / fisheye window move with the 1e-8 differences of the float32 preintegration getters
     np.testing.assert_allclose(got.points, z["exp_points"], atol=2e-4 if fisheye else 1e-5)
+
+
+POSE_FIXTURES = ["pose_tiny", "pose_tiny_mono"]
+
+
+def load_pose_fixture(name):
+    """A committed PoseOptimization fixture (tests/golden/make_golden.py pose): the flat frame and the numpy model's outputs."""
+    from orb_slam3_study_kr_amd import synth
+    z = np.load(GOLDEN / f"{name}.npz")
+    f = synth.PoseFrame(pose_qt=z["pose_qt"], cam=z["cam"], points=z["points"], edge_kind=z["edge_kind"], edge_obs=z["edge_obs"], edge_info=z["edge_info"],
+                        huber_mono=float(z["huber"][0]), huber_stereo=float(z["huber"][1]), chi2_mono=tuple(z["chi2_mono"]), chi2_stereo=tuple(z["chi2_stereo"]),
+                        iterations=tuple(int(k) for k in z["iterations"])).normalise()
+    return f, z
+
+
+def check_against_pose_fixture(got, z):
+    """A PoseOptimization result (pose_qt, outlier, n_bad, chi2_final, edge_chi2) against the numpy model's committed outputs."""
+    from oracle import lm_numpy as lm
+    T = np.eye(4)
+    T[:3, :3] = lm.quat_to_R(np.asarray(got.pose_qt[:4], dtype=np.float64))
+    T[:3, 3] = got.pose_qt[4:]
+    np.testing.assert_allclose(T, z["exp_T"], atol=5e-8)
+    np.testing.assert_array_equal(got.outlier, z["exp_outlier"])
+    assert got.n_bad == int(z["exp_n_bad"]) and got.rounds == int(z["exp_rounds"])
+    np.testing.assert_allclose(got.chi2_final, z["exp_chi2_final"], rtol=1e-6)
+    inl = z["exp_outlier"] == 0
+    np.testing.assert_allclose(got.edge_chi2[inl], z["exp_edge_chi2"][inl], rtol=1e-5, atol=1e-7)

@@ -74,3 +74,11 @@ def test_fisheye_and_pinhole_frames_in_one_batch(solver, ob):
     bad.edge_kind[0] = 1
     with pytest.raises(RuntimeError, match="KannalaBrandt8"):
         solver.optimize_poses([bad])
+
+
+@pytest.mark.parametrize("name", ["pose_tiny", "pose_tiny_mono"])
+def test_device_matches_the_numpy_model_golden_outputs(solver, name):
+    """The committed fixtures of the independent numpy model of PoseOptimization (tests/golden/make_golden.py pose): no oracle in the loop."""
+    from helpers import check_against_pose_fixture, load_pose_fixture
+    f, z = load_pose_fixture(name)
+    check_against_pose_fixture(solver.optimize_poses([f])[0], z)

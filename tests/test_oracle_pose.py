@@ -1,6 +1,8 @@
 """CPU oracle of the pose-only optimisation (oracle/pose_oracle.c <-> src/Optimizer.cc:815-1114): property tests.
-PARITY UNPINNED against a reference binary (see DESIGN.md section 5); the edge functions it uses are the ones
-tests/test_oracle_lba.py pins against numpy and central differences."""
+PARITY UNPINNED against a reference binary (see DESIGN.md section 6); the edge functions it uses are the ones
+tests/test_oracle_lba.py pins against numpy and central differences, and the whole function is pinned by the independent numpy model
+oracle/pose_numpy.py (fixtures tests/golden/pose_tiny*.npz)."""
+import pytest
 import numpy as np
 
 from helpers import quat_to_R
@@ -71,3 +73,12 @@ def test_fisheye_stereo_frame_right_camera_edges():
     r2 = ob.pose_optimize(g.normalise())
     dt2, _ = _pose_err(r2.pose_qt, f.gt_pose_qt)
     assert dt2 < 0.2 * dt0
+
+
+@pytest.mark.parametrize("name", ["pose_tiny", "pose_tiny_mono"])
+def test_oracle_matches_the_numpy_model_golden_outputs(name):
+    """tests/golden/pose_tiny*.npz: the whole PoseOptimization by the independent numpy model (oracle/pose_numpy.py: 4x4 poses, numeric
+    Jacobians, own Levenberg-Marquardt and classification rounds): same outliers, pose to 5e-8, costs to 1e-6."""
+    from helpers import check_against_pose_fixture, load_pose_fixture
+    f, z = load_pose_fixture(name)
+    check_against_pose_fixture(ob.pose_optimize(f), z)
