@@ -726,7 +726,16 @@ __global__ __launch_bounds__(256) void k_schur_reduce(BatchView bv) {
     const size_t gp = (size_t)wd.fpose_off + i;
     double v = bv.bp[gp * 6 + el];
     const double* c = bv.ccontrib + (size_t)rb.start * 6 + el;
-    for (int k = 0; k < rb.count; ++k) v -= c[(size_t)k * 6];
+    int k = 0;
+    for (; k + 8 <= rb.count; k += 8) {   // eight contributions in flight, subtracted in plan order
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = c[(size_t)(k + u) * 6];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v -= t[u];
+    }
+    for (; k < rb.count; ++k) v -= c[(size_t)k * 6];
     bv.bs[gp * 6 + el] = v;
     return;
   }
@@ -734,7 +743,16 @@ __global__ __launch_bounds__(256) void k_schur_reduce(BatchView bv) {
   double v = 0.0;
   if (i == j) v = bv.Hpp[((size_t)wd.fpose_off + i) * 36 + el] + ((r == cc) ? st.lambda : 0.0);
   const double* c = bv.contrib + (size_t)rb.start * 36 + el;
-  for (int k = 0; k < rb.count; ++k) v -= c[(size_t)k * 36];
+  int k = 0;
+  for (; k + 8 <= rb.count; k += 8) {   // eight contributions in flight (one load per iteration left every memory round trip exposed),
+    double t[8];                        // subtracted in plan order: the sum is the same number as before
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = c[(size_t)(k + u) * 36];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v -= t[u];
+  }
+  for (; k < rb.count; ++k) v -= c[(size_t)k * 36];
   bv.S[wd.S_off + (size_t)(6 * i + r) * wd.n + 6 * j + cc] = v;
 }
 
