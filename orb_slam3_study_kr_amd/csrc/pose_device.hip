@@ -14,6 +14,7 @@
 #include "common.h"
 #include "lba_math.h"
 #include <cfloat>
+#include <cstring>
 #include <vector>
 
 namespace osh {
@@ -68,25 +69,50 @@ __device__ __forceinline__ void pose_edge_jacobians(const PoseDesc& d, int kind,
   dev::edge_jacobians(kind, R, d.cam, Xc, JX, Jp);
 }
 
-// computeActiveErrors + activeRobustChi2 at pose `qt` over the active edges; stores every edge's chi2
-template <bool KB8>
-__device__ double pose_eval(const PoseView& v, const PoseDesc& d, const double* qt, bool robust, double* sh) {
-  double acc = 0.0;
-  for (int e = threadIdx.x; e < d.E; e += kPT) {
+// The frame's edges never change during the optimisation: every thread keeps the inputs of its first kPC edges (edge tid + q kPT),
+// their level and the chi2 last computed in registers -- 40 Levenberg-Marquardt iterations otherwise pay two memory round trips
+// per pass over the edges.  Edges beyond kPC kPT of a frame (more than 1024 matches) go through global memory as before.
+constexpr int kPC = 4;
+struct EdgeCache {
+  double X[kPC][3], obs[kPC][3], info[kPC], chi2[kPC];
+  int kind[kPC];
+  unsigned char level[kPC];
+};
+// f(kind, X, obs, info, level&, chi2&) on every edge of the frame owned by this thread
+template <class F>
+__device__ __forceinline__ void for_edges(const PoseView& v, const PoseDesc& d, EdgeCache& c, F&& f) {
+#pragma unroll
+  for (int q = 0; q < kPC; ++q) {
+    const int e = threadIdx.x + q * kPT;
+    if (e < d.E) f(c.kind[q], c.X[q], c.obs[q], c.info[q], c.level[q], c.chi2[q]);
+  }
+  for (int e = threadIdx.x + kPC * kPT; e < d.E; e += kPT) {
     const size_t ge = (size_t)d.edge_off + e;
-    if (v.level[ge]) continue;
-    const int kind = v.kind[ge];
-    double X[3], obs[3], r[3], Xc[3];
+    double X[3], obs[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) { X[k] = v.X[ge * 3 + k]; obs[k] = v.obs[ge * 3 + k]; }
-    const double c = pose_edge_residual<KB8>(d, kind, qt, X, obs, v.info[ge], r, Xc);
-    v.chi2[ge] = c;
+    unsigned char lv = v.level[ge];
+    double ch = v.chi2[ge];
+    f((int)v.kind[ge], X, obs, v.info[ge], lv, ch);
+    v.level[ge] = lv; v.chi2[ge] = ch;
+  }
+}
+
+// computeActiveErrors + activeRobustChi2 at pose `qt` over the active edges; stores every edge's chi2
+template <bool KB8>
+__device__ double pose_eval(const PoseView& v, const PoseDesc& d, EdgeCache& ec, const double* qt, bool robust, double* sh) {
+  double acc = 0.0;
+  for_edges(v, d, ec, [&](int kind, const double* X, const double* obs, double info, unsigned char& level, double& chi2) {
+    if (level) return;
+    double r[3], Xc[3];
+    const double c = pose_edge_residual<KB8>(d, kind, qt, X, obs, info, r, Xc);
+    chi2 = c;
     if (robust) {
       double r0, r1;
       dev::huber(c, kind != OSH_EDGE_STEREO ? d.huber_mono : d.huber_stereo, r0, r1);
       acc += r0;
     } else acc += c;
-  }
+  });
   return pose_block_sum(acc, sh);
 }
 
@@ -101,7 +127,15 @@ __global__ __launch_bounds__(kPT) void k_pose_opt(PoseView v) {
   const PoseDesc& d = v.desc[blockIdx.x];
   PoseOut& out = v.out[blockIdx.x];
   const int tid = threadIdx.x;
-  for (int e = tid; e < d.E; e += kPT) { v.level[(size_t)d.edge_off + e] = 0; v.chi2[(size_t)d.edge_off + e] = 0.0; }
+  for (int e = tid + kPC * kPT; e < d.E; e += kPT) { v.level[(size_t)d.edge_off + e] = 0; v.chi2[(size_t)d.edge_off + e] = 0.0; }
+  EdgeCache ec;
+#pragma unroll
+  for (int q = 0; q < kPC; ++q) {
+    const size_t ge = (size_t)d.edge_off + min(tid + q * kPT, max(d.E - 1, 0));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { ec.X[q][k] = v.X[ge * 3 + k]; ec.obs[q][k] = v.obs[ge * 3 + k]; }
+    ec.info[q] = v.info[ge]; ec.kind[q] = v.kind[ge]; ec.level[q] = 0; ec.chi2[q] = 0.0;
+  }
   bool robust = true;
   int n_bad = 0, rounds = 0;
   __syncthreads();
@@ -122,7 +156,7 @@ __global__ __launch_bounds__(kPT) void k_pose_opt(PoseView v) {
     int nBad = 0;
     // initializeOptimization(0): nothing to do without active edges
     int active = 0;
-    for (int e = tid; e < d.E; e += kPT) active += v.level[(size_t)d.edge_off + e] ? 0 : 1;
+    for_edges(v, d, ec, [&](int, const double*, const double*, double, unsigned char& level, double&) { active += level ? 0 : 1; });
     const bool any = pose_block_sum((double)active, sh) > 0.0;
     for (int it = 0; it < d.iters[round] && ok && any; ++it) {
       double qt[7];
@@ -130,7 +164,7 @@ __global__ __launch_bounds__(kPT) void k_pose_opt(PoseView v) {
       for (int k = 0; k < 7; ++k) qt[k] = sh_qt[sel][k];
       // activeRobustChi2 of the current estimate: after the first iteration of a round it is the accepted trial's value (the same
       // sum over the same edges of the same buffer; an iteration that accepts nothing ends the round)
-      double currentChi = it == 0 ? pose_eval<KB8>(v, d, qt, robust, sh) : last_chi;
+      double currentChi = it == 0 ? pose_eval<KB8>(v, d, ec, qt, robust, sh) : last_chi;
       const double iniChi = currentChi;
       // ---- buildSystem: Hpp += Jp^T W Jp, b += Jp^T (-rho' Omega r) over the active edges
       double H[21], b[6];
@@ -140,14 +174,9 @@ __global__ __launch_bounds__(kPT) void k_pose_opt(PoseView v) {
       for (int k = 0; k < 6; ++k) b[k] = 0.0;
       double R[9];
       dev::quat_to_R(qt, R);
-      for (int e = tid; e < d.E; e += kPT) {
-        const size_t ge = (size_t)d.edge_off + e;
-        if (v.level[ge]) continue;
-        const int kind = v.kind[ge];
-        const double info = v.info[ge];
-        double X[3], obs[3], r[3], Xc[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { X[k] = v.X[ge * 3 + k]; obs[k] = v.obs[ge * 3 + k]; }
+      for_edges(v, d, ec, [&](int kind, const double* X, const double* obs, double info, unsigned char& level, double&) {
+        if (level) return;
+        double r[3], Xc[3];
         const double c = pose_edge_residual<KB8>(d, kind, qt, X, obs, info, r, Xc);
         double r0 = c, r1 = 1.0;
         if (robust) dev::huber(c, kind != OSH_EDGE_STEREO ? d.huber_mono : d.huber_stereo, r0, r1);
@@ -163,7 +192,7 @@ __global__ __launch_bounds__(kPT) void k_pose_opt(PoseView v) {
           for (int c2 = a; c2 < 6; ++c2) { H[m] += b0 * Jp[c2] + b1 * Jp[6 + c2] + b2 * Jp[12 + c2]; ++m; }
           b[a] += Jp[a] * wr[0] + Jp[6 + a] * wr[1] + Jp[12 + a] * wr[2];
         }
-      }
+      });
       {
         // 27 block sums with two barriers: wavefront butterflies, partials parked in LDS, added in wavefront order (deterministic);
         // one barrier pair per value cost 54 barriers per LM iteration
@@ -250,7 +279,7 @@ __global__ __launch_bounds__(kPT) void k_pose_opt(PoseView v) {
         double qtr[7];
 #pragma unroll
         for (int k = 0; k < 7; ++k) qtr[k] = sh_qt[trs][k];
-        double tempChi = pose_eval<KB8>(v, d, qtr, robust, sh);
+        double tempChi = pose_eval<KB8>(v, d, ec, qtr, robust, sh);
         if (!sh_ok) tempChi = DBL_MAX;
         rho = currentChi - tempChi;
         double scale = 0.0;
@@ -282,19 +311,15 @@ __global__ __launch_bounds__(kPT) void k_pose_opt(PoseView v) {
 #pragma unroll
     for (int k = 0; k < 7; ++k) qf[k] = sh_qt[sel][k];
     int bad = 0;
-    for (int e = tid; e < d.E; e += kPT) {
-      const size_t ge = (size_t)d.edge_off + e;
-      const int kind = v.kind[ge];
-      if (v.level[ge]) {
-        double X[3], obs[3], r[3], Xc[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { X[k] = v.X[ge * 3 + k]; obs[k] = v.obs[ge * 3 + k]; }
-        v.chi2[ge] = pose_edge_residual<KB8>(d, kind, qf, X, obs, v.info[ge], r, Xc);
+    for_edges(v, d, ec, [&](int kind, const double* X, const double* obs, double info, unsigned char& level, double& chi2e) {
+      if (level) {
+        double r[3], Xc[3];
+        chi2e = pose_edge_residual<KB8>(d, kind, qf, X, obs, info, r, Xc);
       }
-      const float chi2 = (float)v.chi2[ge];
+      const float chi2 = (float)chi2e;
       const float th = kind != OSH_EDGE_STEREO ? d.chi2_mono[round] : d.chi2_stereo[round];
-      if (chi2 > th) { v.level[ge] = 1; ++bad; } else v.level[ge] = 0;
-    }
+      if (chi2 > th) { level = 1; ++bad; } else level = 0;
+    });
     n_bad = (int)pose_block_sum((double)bad, sh);
     rounds = round + 1;
     if (tid == 0) { out.iterations[round] = cj; out.chi2_final[round] = last_chi; }
@@ -307,10 +332,29 @@ __global__ __launch_bounds__(kPT) void k_pose_opt(PoseView v) {
     if (d.E < 10) break;
   }
   if (tid == 0) { out.n_bad = n_bad; out.rounds = rounds; }
+  // the cached edges' outlier flags and chi2 for the caller
+#pragma unroll
+  for (int q = 0; q < kPC; ++q) {
+    const int e = tid + q * kPT;
+    if (e < d.E) { v.level[(size_t)d.edge_off + e] = ec.level[q]; v.chi2[(size_t)d.edge_off + e] = ec.chi2[q]; }
+  }
 }
 
-struct PoseBuffers { DevBuf desc, out, X, kind, obs, info, chi2, level; };
-PoseBuffers& pose_buffers() { static thread_local PoseBuffers b; return b; }
+struct PosePinned {
+  void* p = nullptr;
+  size_t cap = 0;
+  ~PosePinned() { if (p) (void)hipHostFree(p); }
+  void* reserve(size_t bytes) {
+    if (bytes <= cap) return p;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    const size_t want = bytes + bytes / 4 + 4096;
+    if (hipHostMalloc(&p, want) != hipSuccess) { p = nullptr; return nullptr; }
+    cap = want;
+    return p;
+  }
+};
+// staging and device arena of osh_pose_optimize: kept with the context (released by osh_lba_destroy)
+struct PoseBuffers { PosePinned h_in, h_out; DevBuf arena; };
 
 }  // namespace osh
 
@@ -319,6 +363,7 @@ using namespace osh;
 #define OSH_TRY(expr) do { int _rc = (expr); if (_rc != OSH_OK) return _rc; } while (0)
 
 extern "C" int osh_lba_stream(osh_lba_ctx* ctx, int* device, hipStream_t* stream);   // lba_device.hip
+extern "C" void** osh_lba_attachment(osh_lba_ctx* ctx, int slot, void (*free_fn)(void*));   // lba_device.hip
 
 extern "C" int osh_pose_optimize(osh_lba_ctx* ctx, int32_t n, const osh_pose_problem* pr, osh_pose_result* res) {
   if (!ctx || n <= 0 || !pr || !res) { set_error("osh_pose_optimize: bad arguments"); return OSH_ERR_INVALID; }
@@ -356,42 +401,49 @@ extern "C" int osh_pose_optimize(osh_lba_ctx* ctx, int32_t n, const osh_pose_pro
     NE += (size_t)p.n_edges;
   }
   if (NE > 0x7fffff00u) { set_error("batch too large for 32-bit offsets"); return OSH_ERR_UNSUPPORTED; }
-  std::vector<double> h_X(NE * 3 + 1), h_obs(NE * 3 + 1), h_info(NE + 1);
-  std::vector<unsigned char> h_kind(NE + 1);
+  // one pinned staging buffer, one device arena, one copy each way (eight separate copies cost a third of a single frame's call)
+  void** slot = osh_lba_attachment(ctx, 1, [](void* q) { delete static_cast<PoseBuffers*>(q); });
+  if (!slot) { set_error("osh_pose_optimize: no context"); return OSH_ERR_INVALID; }
+  if (!*slot) *slot = new PoseBuffers();
+  PoseBuffers& B = *static_cast<PoseBuffers*>(*slot);
+  size_t in_bytes = 0, out_bytes = 0;
+  auto take = [](size_t& total, size_t bytes) { const size_t o = total; total = (total + std::max<size_t>(bytes, 8) + 255) & ~(size_t)255; return o; };
+  const size_t i_desc = take(in_bytes, n * sizeof(PoseDesc)), i_X = take(in_bytes, NE * 24), i_obs = take(in_bytes, NE * 24), i_info = take(in_bytes, NE * 8),
+               i_kind = take(in_bytes, NE);
+  const size_t o_out = take(out_bytes, n * sizeof(PoseOut)), o_level = take(out_bytes, NE), o_chi2 = take(out_bytes, NE * 8);
+  char* hs = static_cast<char*>(B.h_in.reserve(in_bytes));
+  char* hr = static_cast<char*>(B.h_out.reserve(out_bytes));
+  if (!hs || !hr) { set_error("osh_pose_optimize: pinned staging allocation failed"); return OSH_ERR_DEVICE; }
+  std::memcpy(hs + i_desc, h_desc.data(), n * sizeof(PoseDesc));
+  double* h_X = reinterpret_cast<double*>(hs + i_X); double* h_obs = reinterpret_cast<double*>(hs + i_obs); double* h_info = reinterpret_cast<double*>(hs + i_info);
+  unsigned char* h_kind = reinterpret_cast<unsigned char*>(hs + i_kind);
   for (int f = 0; f < n; ++f) {
     const osh_pose_problem& p = pr[f];
     const size_t o = (size_t)h_desc[f].edge_off;
-    for (int e = 0; e < p.n_edges; ++e) {
-      for (int k = 0; k < 3; ++k) { h_X[(o + e) * 3 + k] = p.points[3 * (size_t)e + k]; h_obs[(o + e) * 3 + k] = p.edge_obs[3 * (size_t)e + k]; }
-      h_info[o + e] = p.edge_info[e];
-      h_kind[o + e] = p.edge_kind[e];
+    if (p.n_edges > 0) {
+      std::memcpy(h_X + o * 3, p.points, (size_t)p.n_edges * 24);
+      std::memcpy(h_obs + o * 3, p.edge_obs, (size_t)p.n_edges * 24);
+      std::memcpy(h_info + o, p.edge_info, (size_t)p.n_edges * 8);
+      std::memcpy(h_kind + o, p.edge_kind, (size_t)p.n_edges);
     }
   }
-  PoseBuffers& B = pose_buffers();
-  auto up = [&](DevBuf& b, const void* src, size_t bytes) -> int {
-    OSH_TRY(b.reserve(std::max<size_t>(bytes, 8)));
-    if (bytes) OSH_HIP(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, s));
-    return OSH_OK;
-  };
-  OSH_TRY(up(B.desc, h_desc.data(), n * sizeof(PoseDesc)));
-  OSH_TRY(up(B.X, h_X.data(), NE * 24)); OSH_TRY(up(B.obs, h_obs.data(), NE * 24)); OSH_TRY(up(B.info, h_info.data(), NE * 8));
-  OSH_TRY(up(B.kind, h_kind.data(), NE));
-  OSH_TRY(B.out.reserve(n * sizeof(PoseOut))); OSH_TRY(B.chi2.reserve(std::max<size_t>(NE * 8, 8))); OSH_TRY(B.level.reserve(std::max<size_t>(NE, 8)));
+  OSH_TRY(B.arena.reserve(in_bytes + out_bytes));
+  char* din = B.arena.as<char>();
+  char* dout = din + in_bytes;
+  OSH_HIP(hipMemcpyAsync(din, hs, in_bytes, hipMemcpyHostToDevice, s));
   PoseView v;
-  v.desc = B.desc.as<PoseDesc>(); v.out = B.out.as<PoseOut>(); v.X = B.X.as<double>(); v.kind = B.kind.as<unsigned char>();
-  v.obs = B.obs.as<double>(); v.info = B.info.as<double>(); v.chi2 = B.chi2.as<double>(); v.level = B.level.as<unsigned char>();
+  v.desc = reinterpret_cast<const PoseDesc*>(din + i_desc); v.out = reinterpret_cast<PoseOut*>(dout + o_out);
+  v.X = reinterpret_cast<const double*>(din + i_X); v.kind = reinterpret_cast<const unsigned char*>(din + i_kind);
+  v.obs = reinterpret_cast<const double*>(din + i_obs); v.info = reinterpret_cast<const double*>(din + i_info);
+  v.chi2 = reinterpret_cast<double*>(dout + o_chi2); v.level = reinterpret_cast<unsigned char*>(dout + o_level);
   if (any_kb8) hipLaunchKernelGGL(k_pose_opt<true>, dim3((unsigned)n), dim3(kPT), 0, s, v);
   else hipLaunchKernelGGL(k_pose_opt<false>, dim3((unsigned)n), dim3(kPT), 0, s, v);
   { hipError_t e = hipGetLastError(); if (e != hipSuccess) { set_error("kernel launch k_pose_opt failed: %s", hipGetErrorString(e)); return OSH_ERR_DEVICE; } }
-  std::vector<PoseOut> h_out(n);
-  std::vector<unsigned char> h_level(NE + 1);
-  std::vector<double> h_chi2(NE + 1);
-  OSH_HIP(hipMemcpyAsync(h_out.data(), B.out.p, n * sizeof(PoseOut), hipMemcpyDeviceToHost, s));
-  if (NE) {
-    OSH_HIP(hipMemcpyAsync(h_level.data(), B.level.p, NE, hipMemcpyDeviceToHost, s));
-    OSH_HIP(hipMemcpyAsync(h_chi2.data(), B.chi2.p, NE * 8, hipMemcpyDeviceToHost, s));
-  }
+  OSH_HIP(hipMemcpyAsync(hr, dout, out_bytes, hipMemcpyDeviceToHost, s));
   OSH_HIP(hipStreamSynchronize(s));
+  const PoseOut* h_out = reinterpret_cast<const PoseOut*>(hr + o_out);
+  const unsigned char* h_level = reinterpret_cast<const unsigned char*>(hr + o_level);
+  const double* h_chi2 = reinterpret_cast<const double*>(hr + o_chi2);
   for (int f = 0; f < n; ++f) {
     osh_pose_result& r = res[f];
     const PoseOut& o = h_out[f];
