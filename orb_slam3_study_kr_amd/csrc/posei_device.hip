@@ -489,8 +489,21 @@ __global__ __launch_bounds__(kIT) void k_posei(PoseiView v) {
   if (tid == 0) { out.n_bad = n_bad; out.n_inliers = n_inl; out.rounds = rounds; }
 }
 
-struct PoseiBuffers { DevBuf desc, out, X, kind, obs, info, close, chi2, level, outlier; };
-PoseiBuffers& posei_buffers() { static thread_local PoseiBuffers b; return b; }
+struct PoseiPinned {
+  void* p = nullptr;
+  size_t cap = 0;
+  ~PoseiPinned() { if (p) (void)hipHostFree(p); }
+  void* reserve(size_t bytes) {
+    if (bytes <= cap) return p;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    const size_t want = bytes + bytes / 4 + 4096;
+    if (hipHostMalloc(&p, want) != hipSuccess) { p = nullptr; return nullptr; }
+    cap = want;
+    return p;
+  }
+};
+// staging and device arena of osh_posei_optimize: kept with the context (released by osh_lba_destroy)
+struct PoseiBuffers { PoseiPinned h_in, h_out; DevBuf arena; };
 
 }  // namespace osh
 
@@ -499,6 +512,7 @@ using namespace osh;
 #define OSH_TRY(expr) do { int _rc = (expr); if (_rc != OSH_OK) return _rc; } while (0)
 
 extern "C" int osh_lba_stream(osh_lba_ctx* ctx, int* device, hipStream_t* stream);   // lba_device.hip
+extern "C" void** osh_lba_attachment(osh_lba_ctx* ctx, int slot, void (*free_fn)(void*));   // lba_device.hip
 
 extern "C" int osh_posei_optimize(osh_lba_ctx* ctx, int32_t n, const osh_posei_problem* pr, osh_posei_result* res) {
   if (!ctx || n <= 0 || !pr || !res) { set_error("osh_posei_optimize: bad arguments"); return OSH_ERR_INVALID; }
@@ -557,44 +571,52 @@ extern "C" int osh_posei_optimize(osh_lba_ctx* ctx, int32_t n, const osh_posei_p
     NE += (size_t)p.n_edges;
   }
   if (NE > 0x7fffff00u) { set_error("batch too large for 32-bit offsets"); return OSH_ERR_UNSUPPORTED; }
-  std::vector<double> h_X(NE * 3 + 1), h_obs(NE * 3 + 1), h_info(NE + 1);
-  std::vector<unsigned char> h_kind(NE + 1), h_close(NE + 1);
+  // one pinned staging buffer, one device arena, one copy each way (the call of a single frame was a dozen copies)
+  void** slot = osh_lba_attachment(ctx, 2, [](void* q) { delete static_cast<PoseiBuffers*>(q); });
+  if (!slot) { set_error("osh_posei_optimize: no context"); return OSH_ERR_INVALID; }
+  if (!*slot) *slot = new PoseiBuffers();
+  PoseiBuffers& B = *static_cast<PoseiBuffers*>(*slot);
+  size_t in_bytes = 0, out_bytes = 0;
+  auto take = [](size_t& total, size_t bytes) { const size_t o = total; total = (total + std::max<size_t>(bytes, 8) + 255) & ~(size_t)255; return o; };
+  const size_t i_desc = take(in_bytes, n * sizeof(PoseiDesc)), i_X = take(in_bytes, NE * 24), i_obs = take(in_bytes, NE * 24), i_info = take(in_bytes, NE * 8),
+               i_kind = take(in_bytes, NE), i_close = take(in_bytes, NE);
+  const size_t o_out = take(out_bytes, n * sizeof(PoseiOut)), o_outlier = take(out_bytes, NE), o_chi2 = take(out_bytes, NE * 8), o_level = take(out_bytes, NE);
+  char* hs = static_cast<char*>(B.h_in.reserve(in_bytes));
+  char* hr = static_cast<char*>(B.h_out.reserve(out_bytes));
+  if (!hs || !hr) { set_error("osh_posei_optimize: pinned staging allocation failed"); return OSH_ERR_DEVICE; }
+  std::memcpy(hs + i_desc, h_desc.data(), n * sizeof(PoseiDesc));
   for (int f = 0; f < n; ++f) {
     const osh_posei_problem& p = pr[f];
     const size_t o = (size_t)h_desc[f].edge_off;
-    for (int e = 0; e < p.n_edges; ++e) {
-      for (int k = 0; k < 3; ++k) { h_X[(o + e) * 3 + k] = p.points[3 * (size_t)e + k]; h_obs[(o + e) * 3 + k] = p.edge_obs[3 * (size_t)e + k]; }
-      h_info[o + e] = p.edge_info[e];
-      h_kind[o + e] = p.edge_kind[e];
-      h_close[o + e] = p.edge_close ? p.edge_close[e] : 0;
+    if (p.n_edges > 0) {
+      std::memcpy(hs + i_X + o * 24, p.points, (size_t)p.n_edges * 24);
+      std::memcpy(hs + i_obs + o * 24, p.edge_obs, (size_t)p.n_edges * 24);
+      std::memcpy(hs + i_info + o * 8, p.edge_info, (size_t)p.n_edges * 8);
+      std::memcpy(hs + i_kind + o, p.edge_kind, (size_t)p.n_edges);
+      if (p.edge_close) std::memcpy(hs + i_close + o, p.edge_close, (size_t)p.n_edges); else std::memset(hs + i_close + o, 0, (size_t)p.n_edges);
     }
   }
-  PoseiBuffers& B = posei_buffers();
-  auto up = [&](DevBuf& b, const void* src, size_t bytes) -> int {
-    OSH_TRY(b.reserve(std::max<size_t>(bytes, 8)));
-    if (bytes) OSH_HIP(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, s));
-    return OSH_OK;
-  };
-  OSH_TRY(up(B.desc, h_desc.data(), n * sizeof(PoseiDesc)));
-  OSH_TRY(up(B.X, h_X.data(), NE * 24)); OSH_TRY(up(B.obs, h_obs.data(), NE * 24)); OSH_TRY(up(B.info, h_info.data(), NE * 8));
-  OSH_TRY(up(B.kind, h_kind.data(), NE)); OSH_TRY(up(B.close, h_close.data(), NE));
-  OSH_TRY(B.out.reserve(n * sizeof(PoseiOut))); OSH_TRY(B.chi2.reserve(std::max<size_t>(NE * 8, 8)));
-  OSH_TRY(B.level.reserve(std::max<size_t>(NE, 8))); OSH_TRY(B.outlier.reserve(std::max<size_t>(NE, 8)));
+  OSH_TRY(B.arena.reserve(in_bytes + out_bytes));
+  char* din = B.arena.as<char>();
+  char* dout = din + in_bytes;
+  OSH_HIP(hipMemcpyAsync(din, hs, in_bytes, hipMemcpyHostToDevice, s));
   PoseiView v;
-  v.desc = B.desc.as<PoseiDesc>(); v.out = B.out.as<PoseiOut>();
-  v.X = B.X.as<double>(); v.kind = B.kind.as<unsigned char>(); v.obs = B.obs.as<double>(); v.info = B.info.as<double>();
-  v.close = B.close.as<unsigned char>(); v.chi2 = B.chi2.as<double>(); v.level = B.level.as<unsigned char>(); v.outlier = B.outlier.as<unsigned char>();
+  v.desc = reinterpret_cast<const PoseiDesc*>(din + i_desc); v.out = reinterpret_cast<PoseiOut*>(dout + o_out);
+  v.X = reinterpret_cast<const double*>(din + i_X); v.kind = reinterpret_cast<const unsigned char*>(din + i_kind);
+  v.obs = reinterpret_cast<const double*>(din + i_obs); v.info = reinterpret_cast<const double*>(din + i_info);
+  v.close = reinterpret_cast<const unsigned char*>(din + i_close); v.chi2 = reinterpret_cast<double*>(dout + o_chi2);
+  v.level = reinterpret_cast<unsigned char*>(dout + o_level); v.outlier = reinterpret_cast<unsigned char*>(dout + o_outlier);
   hipLaunchKernelGGL(k_posei, dim3((unsigned)n), dim3(kIT), 0, s, v);
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) { set_error("k_posei launch failed: %s", hipGetErrorString(le)); return OSH_ERR_DEVICE; }
-  std::vector<PoseiOut> h_out(n);
-  OSH_HIP(hipMemcpyAsync(h_out.data(), B.out.p, n * sizeof(PoseiOut), hipMemcpyDeviceToHost, s));
+  OSH_HIP(hipMemcpyAsync(hr, dout, out_bytes, hipMemcpyDeviceToHost, s));
+  OSH_HIP(hipStreamSynchronize(s));
+  const PoseiOut* h_out = reinterpret_cast<const PoseiOut*>(hr + o_out);
   for (int f = 0; f < n; ++f) {
     const PoseiDesc& d = h_desc[f];
-    if (res[f].outlier && d.E) OSH_HIP(hipMemcpyAsync(res[f].outlier, B.outlier.as<unsigned char>() + d.edge_off, d.E, hipMemcpyDeviceToHost, s));
-    if (res[f].edge_chi2 && d.E) OSH_HIP(hipMemcpyAsync(res[f].edge_chi2, B.chi2.as<double>() + d.edge_off, (size_t)d.E * 8, hipMemcpyDeviceToHost, s));
+    if (res[f].outlier && d.E) std::memcpy(res[f].outlier, hr + o_outlier + d.edge_off, (size_t)d.E);
+    if (res[f].edge_chi2 && d.E) std::memcpy(res[f].edge_chi2, hr + o_chi2 + (size_t)d.edge_off * 8, (size_t)d.E * 8);
   }
-  OSH_HIP(hipStreamSynchronize(s));
   for (int f = 0; f < n; ++f) {
     const PoseiOut& o = h_out[f];
     osh_posei_result& r = res[f];
