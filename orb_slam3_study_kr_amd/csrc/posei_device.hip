@@ -17,6 +17,8 @@
 #include "liba_edges.h"
 #include <cfloat>
 #include <cstring>
+#include <mutex>
+#include <algorithm>
 #include <vector>
 
 namespace osh {
@@ -41,6 +43,7 @@ struct PoseiView {
   PoseiOut* out;
   const double* X; const unsigned char* kind; const double* obs; const double* info; const unsigned char* close;
   double* chi2; unsigned char* level; unsigned char* outlier;
+  int ecap;                   // edges per frame the block's dynamic LDS can hold (0: every access goes to global memory)
 };
 
 __device__ __forceinline__ double posei_block_sum(double v, double* sh) {
@@ -135,7 +138,34 @@ __global__ __launch_bounds__(kIT) void k_posei(PoseiView v) {
   const int tid = threadIdx.x;
   const bool mode1 = d.mode == 1;
   const int n = mode1 ? 30 : 15;
-  for (int e = tid; e < d.E; e += kIT) { const size_t ge = (size_t)d.edge_off + e; v.level[ge] = 0; v.outlier[ge] = 0; v.chi2[ge] = 0.0; }
+  // The frame's edges (inputs, level, outlier flag, the chi2 computed last) live in LDS for the whole optimisation when they fit: the
+  // 40 Gauss-Newton iterations otherwise pay global-memory round trips for data that never change.  Layout: a plane per field.
+  extern __shared__ __attribute__((aligned(16))) double dyn[];
+  const int cap = v.ecap;
+  const bool cached = cap > 0 && d.E <= cap;
+  double* const sX = dyn; double* const sObs = dyn + 3 * (size_t)cap; double* const sInfo = dyn + 6 * (size_t)cap; double* const sChi = dyn + 7 * (size_t)cap;
+  unsigned char* const sKind = reinterpret_cast<unsigned char*>(dyn + 8 * (size_t)cap);
+  unsigned char* const sClose = sKind + cap; unsigned char* const sLevel = sClose + cap; unsigned char* const sOutlier = sLevel + cap;
+  const size_t e0 = (size_t)d.edge_off;
+  auto eX = [&](int e, int k) { return cached ? sX[k * cap + e] : v.X[(e0 + e) * 3 + k]; };
+  auto eObs = [&](int e, int k) { return cached ? sObs[k * cap + e] : v.obs[(e0 + e) * 3 + k]; };
+  auto eInfo = [&](int e) { return cached ? sInfo[e] : v.info[e0 + e]; };
+  auto eKind = [&](int e) { return (int)(cached ? sKind[e] : v.kind[e0 + e]); };
+  auto eClose = [&](int e) { return (cached ? sClose[e] : v.close[e0 + e]) != 0; };
+  auto eLevel = [&](int e) { return (cached ? sLevel[e] : v.level[e0 + e]) != 0; };
+  auto eOutlier = [&](int e) { return (cached ? sOutlier[e] : v.outlier[e0 + e]) != 0; };
+  auto eChi = [&](int e) { return cached ? sChi[e] : v.chi2[e0 + e]; };
+  auto setChi = [&](int e, double c) { if (cached) sChi[e] = c; else v.chi2[e0 + e] = c; };
+  auto setLevel = [&](int e, bool l) { if (cached) sLevel[e] = l ? 1 : 0; else v.level[e0 + e] = l ? 1 : 0; };
+  auto setOutlier = [&](int e, bool o) { if (cached) sOutlier[e] = o ? 1 : 0; else v.outlier[e0 + e] = o ? 1 : 0; };
+  for (int e = tid; e < d.E; e += kIT) {
+    if (cached) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { sX[k * cap + e] = v.X[(e0 + e) * 3 + k]; sObs[k * cap + e] = v.obs[(e0 + e) * 3 + k]; }
+      sInfo[e] = v.info[e0 + e]; sKind[e] = v.kind[e0 + e]; sClose[e] = v.close[e0 + e];
+    }
+    setLevel(e, false); setOutlier(e, false); setChi(e, 0.0);
+  }
   if (tid < 24) { shP[tid] = d.P[tid]; shpP[tid] = d.pP[tid]; }
   if (tid < 9) { shs[tid] = d.s[tid]; shps[tid] = d.ps[tid]; }
   if (tid < 30) shx[tid] = 0.0;
@@ -159,16 +189,15 @@ __global__ __launch_bounds__(kIT) void k_posei(PoseiView v) {
     // small matrix products): the two take about the same time
     constexpr int kVis = kIT - 64;
     for (int e = tid < kVis ? tid : d.E; e < d.E; e += kVis) {
-      const size_t ge = (size_t)d.edge_off + e;
-      if (v.level[ge]) continue;
-      const int kind = v.kind[ge];
-      const double info = v.info[ge];
+      if (eLevel(e)) continue;
+      const int kind = eKind(e);
+      const double info = eInfo(e);
       double X[3], obs[3];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { X[k] = v.X[ge * 3 + k]; obs[k] = v.obs[ge * 3 + k]; }
+      for (int k = 0; k < 3; ++k) { X[k] = eX(e, k); obs[k] = eObs(e, k); }
       VisEval ev;
       vis_residual(d.cam, kind, pose, X, obs, info, ev);
-      v.chi2[ge] = ev.chi2;
+      setChi(e, ev.chi2);
       double r0 = ev.chi2, r1 = 1.0, JX[9], Jp[18];
       if (robust) dev::huber(ev.chi2, kind == OSH_EDGE_STEREO ? d.huber_stereo : d.huber_mono, r0, r1);
       vis_jacobians(d.cam, kind, pose, ev.Xc, JX, Jp);
@@ -348,19 +377,18 @@ __global__ __launch_bounds__(kIT) void k_posei(PoseiView v) {
     const float chi2close = 1.5 * d.chi2_mono[round];
     int bad = 0, inl = 0;
     for (int e = tid; e < d.E; e += kIT) {
-      const size_t ge = (size_t)d.edge_off + e;
-      const int kind = v.kind[ge];
+      const int kind = eKind(e);
       double X[3], obs[3];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { X[k] = v.X[ge * 3 + k]; obs[k] = v.obs[ge * 3 + k]; }
-      if (v.outlier[ge]) { VisEval ev; vis_residual(d.cam, kind, pose, X, obs, v.info[ge], ev); v.chi2[ge] = ev.chi2; }
-      const float chi2 = (float)v.chi2[ge];
+      for (int k = 0; k < 3; ++k) { X[k] = eX(e, k); obs[k] = eObs(e, k); }
+      if (eOutlier(e)) { VisEval ev; vis_residual(d.cam, kind, pose, X, obs, eInfo(e), ev); setChi(e, ev.chi2); }
+      const float chi2 = (float)eChi(e);
       bool o;
       if (kind != OSH_EDGE_STEREO) {
-        const bool bClose = v.close[ge] != 0;
+        const bool bClose = eClose(e);
         o = (chi2 > d.chi2_mono[round] && !bClose) || (bClose && chi2 > chi2close) || !depth_positive(kind, pose, X);
       } else o = chi2 > d.chi2_stereo[round];
-      v.outlier[ge] = o ? 1 : 0; v.level[ge] = o ? 1 : 0;
+      setOutlier(e, o); setLevel(e, o);
       if (o) ++bad; else ++inl;
     }
     n_bad = (int)posei_block_sum((double)bad, sh);
@@ -376,15 +404,14 @@ __global__ __launch_bounds__(kIT) void k_posei(PoseiView v) {
   if (n_inl < 30 && !d.rec_init) {   // recovery (:4821-4848)
     int bad = 0;
     for (int e = tid; e < d.E; e += kIT) {
-      const size_t ge = (size_t)d.edge_off + e;
-      const int kind = v.kind[ge];
+      const int kind = eKind(e);
       double X[3], obs[3];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { X[k] = v.X[ge * 3 + k]; obs[k] = v.obs[ge * 3 + k]; }
+      for (int k = 0; k < 3; ++k) { X[k] = eX(e, k); obs[k] = eObs(e, k); }
       VisEval ev;
-      vis_residual(d.cam, kind, pose, X, obs, v.info[ge], ev);
-      v.chi2[ge] = ev.chi2;
-      if (ev.chi2 < (kind == OSH_EDGE_STEREO ? 24.f : 18.f)) v.outlier[ge] = 0; else ++bad;
+      vis_residual(d.cam, kind, pose, X, obs, eInfo(e), ev);
+      setChi(e, ev.chi2);
+      if (ev.chi2 < (kind == OSH_EDGE_STEREO ? 24.f : 18.f)) setOutlier(e, false); else ++bad;
     }
     n_bad = (int)posei_block_sum((double)bad, sh);
   }
@@ -396,13 +423,12 @@ __global__ __launch_bounds__(kIT) void k_posei(PoseiView v) {
 #pragma unroll
     for (int k = 0; k < 21; ++k) H[k] = 0.0;
     for (int e = tid; e < d.E; e += kIT) {
-      const size_t ge = (size_t)d.edge_off + e;
-      if (v.outlier[ge]) continue;
-      const int kind = v.kind[ge];
-      const double info = v.info[ge];
+      if (eOutlier(e)) continue;
+      const int kind = eKind(e);
+      const double info = eInfo(e);
       double X[3], obs[3], JX[9], Jp[18];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { X[k] = v.X[ge * 3 + k]; obs[k] = v.obs[ge * 3 + k]; }
+      for (int k = 0; k < 3; ++k) { X[k] = eX(e, k); obs[k] = eObs(e, k); }
       VisEval ev;
       vis_residual(d.cam, kind, pose, X, obs, info, ev);
       vis_jacobians(d.cam, kind, pose, ev.Xc, JX, Jp);
@@ -487,6 +513,10 @@ __global__ __launch_bounds__(kIT) void k_posei(PoseiView v) {
   if (tid < 24) out.P[tid] = shP[tid];
   if (tid < 9) out.s[tid] = shs[tid];
   if (tid == 0) { out.n_bad = n_bad; out.n_inliers = n_inl; out.rounds = rounds; }
+  if (cached) {   // the caller's per-edge results
+    __syncthreads();
+    for (int e = tid; e < d.E; e += kIT) { v.outlier[e0 + e] = sOutlier[e]; v.chi2[e0 + e] = sChi[e]; v.level[e0 + e] = sLevel[e]; }
+  }
 }
 
 struct PoseiPinned {
@@ -606,7 +636,22 @@ extern "C" int osh_posei_optimize(osh_lba_ctx* ctx, int32_t n, const osh_posei_p
   v.obs = reinterpret_cast<const double*>(din + i_obs); v.info = reinterpret_cast<const double*>(din + i_info);
   v.close = reinterpret_cast<const unsigned char*>(din + i_close); v.chi2 = reinterpret_cast<double*>(dout + o_chi2);
   v.level = reinterpret_cast<unsigned char*>(dout + o_level); v.outlier = reinterpret_cast<unsigned char*>(dout + o_outlier);
-  hipLaunchKernelGGL(k_posei, dim3((unsigned)n), dim3(kIT), 0, s, v);
+  // dynamic LDS for the edges of a frame: 8 doubles + 4 bytes each; frames of more than kPoseiMaxCached edges read global memory instead
+  int e_max = 0;
+  for (int f = 0; f < n; ++f) e_max = std::max(e_max, h_desc[f].E);
+  constexpr int kPoseiMaxCached = 1400;
+  v.ecap = (e_max > 0 && e_max <= kPoseiMaxCached) ? ((e_max + 63) & ~63) : 0;
+  const size_t dyn_bytes = (size_t)v.ecap * (8 * 8 + 4) + 16;
+  {
+    static std::mutex attr_mu;
+    static std::vector<int> attr_devices;
+    std::lock_guard<std::mutex> attr_lock(attr_mu);
+    if (std::find(attr_devices.begin(), attr_devices.end(), device) == attr_devices.end()) {
+      OSH_HIP(hipFuncSetAttribute((const void*)k_posei, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      attr_devices.push_back(device);
+    }
+  }
+  hipLaunchKernelGGL(k_posei, dim3((unsigned)n), dim3(kIT), dyn_bytes, s, v);
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) { set_error("k_posei launch failed: %s", hipGetErrorString(le)); return OSH_ERR_DEVICE; }
   OSH_HIP(hipMemcpyAsync(hr, dout, out_bytes, hipMemcpyDeviceToHost, s));
