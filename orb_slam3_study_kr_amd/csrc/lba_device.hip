@@ -1372,8 +1372,10 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
     c->resid_lds = (size_t)(4 + 3 * kBlock + staged * kPoseRec) * sizeof(double);
     const int pmax = pb.n_max / 6;
     c->backsub_lds = (size_t)(3 * kChunkEdges + 4 + 3 * kBlock + (pmax <= kLdsPoses ? pb.n_max + pmax * kPoseRec : 0)) * sizeof(double);
-    // One 512-thread block per window with the widest panel that fits (one block per CU).
-    c->solve_threads = kSolveThreadsLatency;
+    // One block per window with the widest panel that fits.  A batch takes 256-thread blocks: the one LDS panel of ldlt_block.h
+    // (70 KB for 50 keyframes) lets two windows share a CU, and the factorisation is latency bound, so they overlap (measured:
+    // 5.5 ms of solve per 512-window step against 6.0 with 512-thread blocks, profiles/solve_sweep.sh); a few windows take 512 threads.
+    c->solve_threads = nw >= 128 ? kSolveThreadsBatch : kSolveThreadsLatency;
     auto need = [&](int b) { return ldlt_lds_doubles(b, ldlt_row_stride(pb.n_max), c->solve_threads) * sizeof(double); };
     int nb = 24;
     while (nb > 6 && need(nb) > (size_t)150 * 1024) nb /= 2;  // 24 -> 12 -> 6 (template instantiations of k_solve)

@@ -16,7 +16,7 @@ namespace osh {
 __host__ __device__ constexpr int ldlt_row_stride(int n) { return (n + 24 + 1) & ~1; }
 
 __host__ __device__ constexpr size_t ldlt_lds_doubles(int nb, int W, int nthreads) {
-  return (size_t)2 * nb * W + W + 3 * nb + (size_t)nb * nb + nthreads / 64 + 8;
+  return (size_t)nb * W + W + 3 * nb + (size_t)nb * nb + nthreads / 64 + 8;
 }
 
 // value of `v` in lane `lane` (compile-time constant after unrolling) as a wave-uniform scalar
@@ -32,9 +32,10 @@ __device__ bool ldlt_solve_block(double* __restrict__ A, const double* __restric
   constexpr int nb = NB;
   constexpr int kSolveThreads = NT;
   const int tid = threadIdx.x;
-  double* U = sh;                    // [nb][W]  unscaled panel rows  (d_k * l_jk)
-  double* Lp = sh + (size_t)nb * W;  // [nb][W]  scaled panel rows    (l_jk)
-  double* xs = Lp + (size_t)nb * W;  // [W]
+  double* U = sh;                    // [nb][W]  unscaled panel rows  (d_k * l_jk); the scaled rows l_jk = u_jk / d_k are formed from them
+                                     // on the way into the matrix cores (one multiply per operand): ONE panel in LDS, so two windows of
+                                     // a batch can share a CU
+  double* xs = U + (size_t)nb * W;   // [W]
   double* dd = xs + W;               // [nb]
   double* ddi = dd + nb;             // [nb] reciprocals of the pivots
   double* part = ddi + nb;           // [nb]
@@ -158,7 +159,7 @@ __device__ bool ldlt_solve_block(double* __restrict__ A, const double* __restric
           const int r = 2 * r2 + h;
           const double q = wv[r] * d2[h];
           const double l = is_rhs ? 0.0 : q;
-          U[r * W + jj] = wv[r]; Lp[r * W + jj] = l;
+          U[r * W + jj] = wv[r];
           unsigned o = (r < kb && !is_rhs) ? (unsigned)r * n8p + j8 : n8p;  // n8p: entry (1, 0) of the block
           asm volatile("" : "+v"(o));
           *reinterpret_cast<double*>(Apanel + o) = l;
@@ -177,13 +178,13 @@ __device__ bool ldlt_solve_block(double* __restrict__ A, const double* __restric
     // zero padding so the 16-wide tiles below may over-read (W >= n + 17, see ldlt_row_stride)
     for (int idx = tid; idx < kb * 16; idx += kSolveThreads) {
       const int r = idx >> 4, jj = m + 1 + (idx & 15);
-      U[r * W + jj] = 0.0; Lp[r * W + jj] = 0.0;
+      U[r * W + jj] = 0.0;
     }
     __syncthreads();
     OSH_TR(2);
     // ---- 3. trailing update of rows k0+kb .. n-1 (upper part) on the FP64 matrix cores: one wavefront per 16x16 tile of
     // the trailing block, C -= L[16 x NB] U[NB x 16] as NB/4 v_mfma_f64_16x16x4_f64 (a partial panel is the last one and has
-    // no trailing block).  Operand lanes read straight from the panels in LDS: A[i = lane & 15][k = lane >> 4] = Lp[k][i0 + i],
+    // no trailing block).  Operand lanes read straight from the panel in LDS: A[i = lane & 15][k = lane >> 4] = U[k][i0 + i] / d_k,
     // B[k][j] = U[k][j0 + j]; lane holds D[row = (lane >> 4) + 4 reg][col = lane & 15].  (A 4x4 register-tiled VALU version
     // spent 3 of 4 issue slots on operand traffic: 44 k cycles per panel on one CU against ~10 k for the first MFMA version.)
     const int tr = m - kb;  // trailing rows
@@ -192,7 +193,7 @@ __device__ bool ldlt_solve_block(double* __restrict__ A, const double* __restric
       for (int ii = kb + tid; ii < m; ii += kSolveThreads) {
         double acc = 0.0;
 #pragma unroll
-        for (int k = 0; k < NB; ++k) acc += Lp[k * W + ii] * U[k * W + m];
+        for (int k = 0; k < NB; ++k) acc += (U[k * W + ii] * ddi[k]) * U[k * W + m];
         xs[k0 + ii] -= acc;
       }
       typedef double ldlt_f64x4 __attribute__((ext_vector_type(4)));
@@ -234,22 +235,26 @@ __device__ bool ldlt_solve_block(double* __restrict__ A, const double* __restric
       };
       // two tiles per step: their MFMA chains are independent, so the matrix core issues back to back instead of waiting
       // for each accumulator; all operand reads of a step are issued before its first MFMA
+      constexpr int KSq = (NB + 3) / 4;
+      double dq[KSq];   // 1 / d_k of the lane's operand rows k = 4 q + lrow: the A operand is l_ki = u_ki / d_k
+#pragma unroll
+      for (int q = 0; q < KSq; ++q) dq[q] = (4 * q + lrow < NB) ? ddi[4 * q + lrow] : 0.0;
       auto run2 = [&](const Tile& T0, const Tile& T1) {
         constexpr int KS = (NB + 3) / 4;
         double a0[KS], b0[KS], a1[KS], b1[KS];
-        const double* pa0 = Lp + cA + T0.i0; const double* pb0 = U + cA + T0.j0;
-        const double* pa1 = Lp + cA + T1.i0; const double* pb1 = U + cA + T1.j0;
+        const double* pa0 = U + cA + T0.i0; const double* pb0 = U + cA + T0.j0;
+        const double* pa1 = U + cA + T1.i0; const double* pb1 = U + cA + T1.j0;
 #pragma unroll
         for (int q = 0; q < KS; ++q) {
           if (4 * q + 3 < NB) {
-            a0[q] = pa0[4 * q * W]; b0[q] = pb0[4 * q * W];
-            a1[q] = pa1[4 * q * W]; b1[q] = pb1[4 * q * W];
+            a0[q] = pa0[4 * q * W] * dq[q]; b0[q] = pb0[4 * q * W];
+            a1[q] = pa1[4 * q * W] * dq[q]; b1[q] = pb1[4 * q * W];
           } else {
             // last k step of a panel whose width is not a multiple of 4: rows >= NB do not exist, their lanes multiply zeros
             const bool kin = 4 * q + lrow < NB;
             const int back = kin ? 0 : lrow * W;
-            a0[q] = pa0[4 * q * W - back]; b0[q] = pb0[4 * q * W - back];
-            a1[q] = pa1[4 * q * W - back]; b1[q] = pb1[4 * q * W - back];
+            a0[q] = pa0[4 * q * W - back] * dq[q]; b0[q] = pb0[4 * q * W - back];
+            a1[q] = pa1[4 * q * W - back] * dq[q]; b1[q] = pb1[4 * q * W - back];
             if (!kin) { a0[q] = 0.0; b0[q] = 0.0; a1[q] = 0.0; b1[q] = 0.0; }
           }
         }
