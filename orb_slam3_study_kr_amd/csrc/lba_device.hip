@@ -89,6 +89,8 @@ struct BatchView {
   const int* e_point;        // [NE] window-local landmark index
   const unsigned char* e_kind;   // [NE] sorted-edge kind (kKind*); the pinhole kernels read the sign of e_rec[.][3] instead
   const double* e_rec;       // [NE*4] u v u_right +-invSigma2 of every sorted edge: one 32-byte record (sign bit set = mono)
+  const float4* e_rec32;     // the same records as the float32 values they were uploaded as (null unless every record is exact in
+                             // float32): the landmark-major kernels are bandwidth bound and read these, 16 bytes an edge
   const double* e_rec2;      // [NE*4] right-camera observation of a fisheye-rig edge (u v - invSigma2), rig batches only
   const int* e_orig;         // [NE] index in the caller's edge order
   const int* e_orig2;        // [NE] caller index of the merged right-camera edge or -1, rig batches only
@@ -255,6 +257,10 @@ constexpr int kPasses = kChunkMaxEdges / kChunkEdges;
 struct LaneEdges { int ip[kPasses], il[kPasses]; double2 ra[kPasses], rb[kPasses]; };
 
 // edges base + p * 256 + tid, p = 0..kPasses-1, clamped to the last edge of the chunk (validity is applied at use)
+// F32: the records are read as the float32 values they were uploaded as (exact: the packer checked) -- 16 bytes an edge instead of
+// 32 in the three bandwidth-bound landmark-major kernels.  A compile-time choice: a run-time test in this loop splits the block of
+// loads the kernels issue up front (measured: k_lin_lm 0.68 -> 1.09 ms with the branch, 0.56 ms without).
+template <bool F32>
 __device__ __forceinline__ void load_lane_edges(const BatchView& bv, const WinDesc& wd, int base, int e1, int tid, LaneEdges& le) {
   const int last = max(e1 - 1, 0);
 #pragma unroll
@@ -262,8 +268,13 @@ __device__ __forceinline__ void load_lane_edges(const BatchView& bv, const WinDe
     const size_t ge = (size_t)wd.edge_off + min(base + p * kChunkEdges + tid, last);
     le.ip[p] = bv.e_pose[ge];
     le.il[p] = bv.e_point[ge];
-    const double2* r = reinterpret_cast<const double2*>(bv.e_rec + ge * 4);
-    le.ra[p] = r[0]; le.rb[p] = r[1];
+    if (F32) {
+      const float4 r = bv.e_rec32[ge];
+      le.ra[p] = make_double2((double)r.x, (double)r.y); le.rb[p] = make_double2((double)r.z, (double)r.w);
+    } else {
+      const double2* r = reinterpret_cast<const double2*>(bv.e_rec + ge * 4);
+      le.ra[p] = r[0]; le.rb[p] = r[1];
+    }
   }
 }
 
@@ -276,7 +287,7 @@ __device__ __forceinline__ void stage_points(double* sh_X, const double* pts, in
 // k_residual: computeActiveErrors + activeRobustChi2 at the TRIAL estimates (every active window); chunk partial sums in
 // fixed order.
 // --------------------------------------------------------------------------------------------
-template <bool KB8>
+template <bool KB8, bool F32>
 __global__ __launch_bounds__(kBlock) void k_residual(BatchView bv) {
   extern __shared__ __attribute__((aligned(16))) double sh_rs[];   // [4] reduce, [256*3] landmarks, staged poses
   const Chunk ch = bv.chunks[blockIdx.x];
@@ -298,7 +309,7 @@ __global__ __launch_bounds__(kBlock) void k_residual(BatchView bv) {
   double chi_acc = 0.0;
   for (int base = e0; base < e1; base += kChunkMaxEdges) {
     LaneEdges le;
-    load_lane_edges(bv, wd, base, e1, tid, le);
+    load_lane_edges<F32>(bv, wd, base, e1, tid, le);
     if (base == e0) {
       stage_points(sh_X, pts, ch.lm0, nl, tid);
       if (staged) stage_poses(sh_pose, poses, cams, wd.P + wd.F, tid, kBlock);
@@ -331,7 +342,7 @@ __global__ __launch_bounds__(kBlock) void k_residual(BatchView bv) {
 // A window that is not linearising this round but whose lambda changed (first lambda of optimize(), rejected trial) only
 // re-forms its factors from the stored Hll / b_l.
 // --------------------------------------------------------------------------------------------
-template <bool KB8>
+template <bool KB8, bool F32>
 __global__ __launch_bounds__(kBlock) void k_lin_lm(BatchView bv) {
   extern __shared__ __attribute__((aligned(16))) double sh_lm[];   // [9*256] partials, [4] reduce, [256*3] landmarks, staged poses
   const Chunk ch = bv.chunks[blockIdx.x];
@@ -373,7 +384,7 @@ __global__ __launch_bounds__(kBlock) void k_lin_lm(BatchView bv) {
   double chi_acc = 0.0;
   for (int base = e0; base < e1; base += kChunkMaxEdges) {
     LaneEdges le;
-    load_lane_edges(bv, wd, base, e1, tid, le);
+    load_lane_edges<F32>(bv, wd, base, e1, tid, le);
     if (base == e0) {
       stage_points(sh_X, pts, ch.lm0, nl, tid);
       if (staged) stage_poses(sh_pose, poses, cams, wd.P + wd.F, tid, kBlock);
@@ -877,7 +888,7 @@ __global__ __launch_bounds__(256) void k_big_finish(BatchView bv, int w, const i
 // -Hpl^T x_p = -R^T Q (D x_p) formed from the edge description (lba_math.h), lane per landmark for the ordered sum; the
 // optimisable poses of the window and x_p sit in LDS.
 // --------------------------------------------------------------------------------------------
-template <bool KB8>
+template <bool KB8, bool F32>
 __global__ __launch_bounds__(kBlock) void k_backsub(BatchView bv) {
   extern __shared__ __attribute__((aligned(16))) double sh_bs[];  // [3*256] partials, [4] reduce, [256*3] landmarks, [n] x_p, [P*21] poses
   double* sh_c = sh_bs;
@@ -917,7 +928,7 @@ __global__ __launch_bounds__(kBlock) void k_backsub(BatchView bv) {
   }
   for (int base = e0; base < e1; base += kChunkMaxEdges) {
     LaneEdges le;
-    load_lane_edges(bv, wd, base, e1, tid, le);
+    load_lane_edges<F32>(bv, wd, base, e1, tid, le);
     if (base == e0) {
       stage_points(sh_X, pts, ch.lm0, nl, tid);
       if (staged) {
@@ -1441,6 +1452,7 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
     }
     bv.e_rec = c->d_erec.as<double>();
   }
+  bv.e_rec32 = (pb.rec_f32 && !std::getenv("OSH_LBA_NO_F32_RECORDS")) ? c->dsec<float4>(PackedBatch::EREC) : nullptr;
   bv.e_orig = c->dsec<int>(PackedBatch::EORIG); bv.e_orig2 = c->dsec<int>(PackedBatch::EORIG2);
   bv.lm_off = c->dsec<int>(PackedBatch::LMOFF);
   bv.sitems = c->dsec<SItem>(PackedBatch::ITEMS); bv.srecs = c->dsec<SRec>(PackedBatch::RECS);
@@ -1462,12 +1474,15 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   c->upload_pack_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
   c->upload_copy_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
 
+  const bool f32 = bv.e_rec32 != nullptr;
   if (pb.has_kb8) {
-    c->kp_lin_lm = k_lin_lm<true>; c->kp_schur_sym = k_schur_fused<true, true>; c->kp_schur_cross = k_schur_fused<false, true>;
-    c->kp_residual = k_residual<true>; c->kp_finalize = k_finalize<true>; c->kp_backsub = k_backsub<true>; c->kp_debug_hpl = k_debug_hpl<true>;
+    c->kp_lin_lm = f32 ? k_lin_lm<true, true> : k_lin_lm<true, false>; c->kp_schur_sym = k_schur_fused<true, true>; c->kp_schur_cross = k_schur_fused<false, true>;
+    c->kp_residual = f32 ? k_residual<true, true> : k_residual<true, false>; c->kp_finalize = k_finalize<true>;
+    c->kp_backsub = f32 ? k_backsub<true, true> : k_backsub<true, false>; c->kp_debug_hpl = k_debug_hpl<true>;
   } else {
-    c->kp_lin_lm = k_lin_lm<false>; c->kp_schur_sym = k_schur_fused<true, false>; c->kp_schur_cross = k_schur_fused<false, false>;
-    c->kp_residual = k_residual<false>; c->kp_finalize = k_finalize<false>; c->kp_backsub = k_backsub<false>; c->kp_debug_hpl = k_debug_hpl<false>;
+    c->kp_lin_lm = f32 ? k_lin_lm<false, true> : k_lin_lm<false, false>; c->kp_schur_sym = k_schur_fused<true, false>; c->kp_schur_cross = k_schur_fused<false, false>;
+    c->kp_residual = f32 ? k_residual<false, true> : k_residual<false, false>; c->kp_finalize = k_finalize<false>;
+    c->kp_backsub = f32 ? k_backsub<false, true> : k_backsub<false, false>; c->kp_debug_hpl = k_debug_hpl<false>;
   }
 
   // opt in to large dynamic LDS: the attribute is per device, so once per device of the process
@@ -1479,12 +1494,13 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
     OSH_SOLVE_ATTR(24, kSolveThreadsBatch); OSH_SOLVE_ATTR(12, kSolveThreadsBatch); OSH_SOLVE_ATTR(6, kSolveThreadsBatch);
     OSH_SOLVE_ATTR(24, kSolveThreadsLatency); OSH_SOLVE_ATTR(12, kSolveThreadsLatency); OSH_SOLVE_ATTR(6, kSolveThreadsLatency);
 #undef OSH_SOLVE_ATTR
-    OSH_HIP(hipFuncSetAttribute((const void*)k_backsub<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-    OSH_HIP(hipFuncSetAttribute((const void*)k_backsub<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-    OSH_HIP(hipFuncSetAttribute((const void*)k_lin_lm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-    OSH_HIP(hipFuncSetAttribute((const void*)k_lin_lm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-    OSH_HIP(hipFuncSetAttribute((const void*)k_residual<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-    OSH_HIP(hipFuncSetAttribute((const void*)k_residual<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+#define OSH_LM_ATTR(K) \
+    OSH_HIP(hipFuncSetAttribute((const void*)K<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)); \
+    OSH_HIP(hipFuncSetAttribute((const void*)K<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)); \
+    OSH_HIP(hipFuncSetAttribute((const void*)K<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)); \
+    OSH_HIP(hipFuncSetAttribute((const void*)K<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    OSH_LM_ATTR(k_backsub) OSH_LM_ATTR(k_lin_lm) OSH_LM_ATTR(k_residual)
+#undef OSH_LM_ATTR
     attr_devices.push_back(c->device);
   }
   c->n_windows = nw;
@@ -1840,9 +1856,9 @@ extern "C" int osh_lba_get_upload_times(osh_lba_ctx* c, double ms[2]) {
 }
 
 extern "C" const char* osh_lba_kernel_name(int k) {
-  // pinhole instantiations (<.., true> for a fisheye batch)
-  static const char* names[OSH_K_COUNT] = {"k_lin_lm<false>", "k_pose_reduce", "k_schur_fused<true, false> (mode 1)", "k_solve", "k_backsub<false>",
-                                           "k_residual<false>", "k_control", "k_schur_reduce", "k_schur_fused<false, false>",
-                                           "k_lin_lm<false> (factors only)", "k_schur_fused<true, false> (mode 0)"};
+  // pinhole instantiations reading float32 records (<true, ..> for a fisheye batch, <.., false> when a record is not exact in float32)
+  static const char* names[OSH_K_COUNT] = {"k_lin_lm<false, true>", "k_pose_reduce", "k_schur_fused<true, false> (mode 1)", "k_solve", "k_backsub<false, true>",
+                                           "k_residual<false, true>", "k_control", "k_schur_reduce", "k_schur_fused<false, false>",
+                                           "k_lin_lm<false, true> (factors only)", "k_schur_fused<true, false> (mode 0)"};
   return (k >= 0 && k < OSH_K_COUNT) ? names[k] : "?";
 }

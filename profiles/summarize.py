@@ -35,7 +35,11 @@ if rows:
     piv = d.pivot_table(index="Counter_Name", columns="Kernel_Name", values="Counter_Value")
     piv.to_csv(dst / f"{tag}_pmc_summary.csv", float_format="%.6g")
     # rocprofv3 kernel name -> short name of capi.KERNEL_NAMES
-    names = {"void k_lin_lm<false>": "linearize", "void k_lin_lm<true>": "linearize", "void k_schur_fused<true, false>": "schur",
+    names = {"void k_lin_lm<false>": "linearize", "void k_lin_lm<true>": "linearize",
+             "void k_lin_lm<false, true>": "linearize", "void k_lin_lm<false, false>": "linearize", "void k_lin_lm<true, true>": "linearize",
+             "void k_lin_lm<true, false>": "linearize", "void k_residual<false, true>": "residual", "void k_residual<false, false>": "residual",
+             "void k_residual<true, true>": "residual", "void k_residual<true, false>": "residual", "void k_backsub<false, true>": "backsub",
+             "void k_backsub<false, false>": "backsub", "void k_backsub<true, true>": "backsub", "void k_backsub<true, false>": "backsub", "void k_schur_fused<true, false>": "schur",
              "void k_schur_fused<false, false>": "schur_cross", "void k_schur_fused<true, true>": "schur", "void k_schur_fused<false, true>": "schur_cross",
              "void k_lin_items<0, false>": "linearize", "void k_lin_items<1, false>": "lin_pose", "void k_lin_aux<false>": "lin_aux",
              "void k_lin_items<0, true>": "linearize", "void k_lin_items<1, true>": "lin_pose", "void k_lin_aux<true>": "lin_aux",
