@@ -52,6 +52,8 @@ class KeyFrame {
   // global BA results kept beside the live pose until the loop-closing thread applies them (include/KeyFrame.h:369-372)
   Sophus::SE3f mTcwGBA;
   long unsigned int mnBAGlobalForKF = 0;
+  Eigen::Vector3f mVwbGBA;                   // include/KeyFrame.h:373-375: what FullInertialBA leaves for the loop closer
+  IMU::Bias mBiasGBA;
   float fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0;
   int N = 0, NLeft = -1;
   std::vector<cv::KeyPoint> mvKeys, mvKeysUn, mvKeysRight;
@@ -70,6 +72,7 @@ class KeyFrame {
   GeometricCamera* mpCamera = nullptr;
   GeometricCamera* mpCamera2 = nullptr;
   KeyFrame* mPrevKF = nullptr;
+  KeyFrame* mNextKF = nullptr;               // include/KeyFrame.h:419-420
   bool bImu = false;
   IMU::Preintegrated* mpImuPreintegrated = nullptr;
   IMU::Calib mImuCalib;

@@ -15,6 +15,7 @@ class Map {
   long unsigned int KeyFramesInMap() { return mnKeyFrames; }   // src/Map.cc:165
   std::vector<KeyFrame*> GetAllKeyFrames() { return mvpKeyFrames; }   // src/Map.cc:153-163 (copies of the sets)
   std::vector<MapPoint*> GetAllMapPoints() { return mvpMapPoints; }
+  long unsigned int GetMaxKFid() { return mnMaxKFid; }               // src/Map.cc:177-181
   KeyFrame* GetOriginKF() { return mpKFinitial; }                     // src/Map.cc:186-189
   void IncreaseChangeIndex() { ++mnMapChange; }
   int GetMapChangeIndex() { return mnMapChange; }
@@ -23,6 +24,7 @@ class Map {
   std::set<long unsigned int> msFixedKFs;
   // test-double state (the real class keeps these private)
   long unsigned int mnInitKFid = 0;
+  long unsigned int mnMaxKFid = 0;
   bool mbIsInertial = false;
   int mnMapChange = 0;
   long unsigned int mnKeyFrames = 0;

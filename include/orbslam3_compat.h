@@ -115,6 +115,10 @@ class SE3 {
   }
   const Eigen::Quaternion<T>& unit_quaternion() const { return q_; }
   const Eigen::Matrix<T, 3>& translation() const { return t_; }
+  template <class U> SE3<U> cast() const {   // member-wise cast, no renormalisation (Sophus: SE3<U>(so3.cast<U>(), t.cast<U>()))
+    SE3<U> o; o.set_raw(q_.template cast<U>(), t_.template cast<U>()); return o;
+  }
+  void set_raw(const Eigen::Quaternion<T>& q, const Eigen::Matrix<T, 3>& t) { q_ = q; t_ = t; }
   // p_out = R p + t
   Eigen::Matrix<T, 3> operator*(const Eigen::Matrix<T, 3>& p) const {
     const T x = q_.x(), y = q_.y(), z = q_.z(), w = q_.w();
@@ -127,6 +131,7 @@ class SE3 {
   Eigen::Matrix<T, 3> t_;
 };
 using SE3f = SE3<float>;
+using SE3d = SE3<double>;
 // Sim3 as rotation + translation + scale; only the accessors ORBmatcher::SearchByProjection(KeyFrame*, Sim3f&, ...) uses.
 template <class T>
 class Sim3 {
@@ -143,6 +148,26 @@ class Sim3 {
 };
 using Sim3f = Sim3<float>;
 }  // namespace Sophus
+
+// g2o::Sim3 (Thirdparty/g2o/g2o/types/sim3.h:45-80): what Optimizer::MergeInertialBA leaves in LoopClosing::KeyFrameAndPose
+namespace g2o {
+class Sim3 {
+ public:
+  Sim3() : s_(1.0) {}
+  Sim3(const Eigen::Quaterniond& r, const Eigen::Vector3d& t, double s) : r_(r), t_(t), s_(s) {}
+  const Eigen::Quaterniond& rotation() const { return r_; }
+  const Eigen::Vector3d& translation() const { return t_; }
+  const double& scale() const { return s_; }
+ private:
+  Eigen::Quaterniond r_;
+  Eigen::Vector3d t_;
+  double s_;
+};
+}  // namespace g2o
+namespace Eigen {
+template <class T> using aligned_allocator = std::allocator<T>;
+struct VectorXd { std::vector<double> v; };   // only named by Optimizer::FullInertialBA's unused vSingVal parameter
+}  // namespace Eigen
 
 // DBoW2::FeatureVector / BowVector (Thirdparty/DBoW2/DBoW2/FeatureVector.h:23, BowVector.h:48): vocabulary node -> indices of the
 // local features that fell into it; ORBmatcher::SearchByBoW walks two of them in step

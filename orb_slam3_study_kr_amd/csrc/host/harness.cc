@@ -66,6 +66,7 @@ extern "C" osh_host_graph* osh_host_graph_create(int32_t n_kf, const int64_t* kf
   // Map::GetAllKeyFrames / GetOriginKF: the origin keyframe is the one with the map's initial id (else the first one)
   for (auto& kf : g->kfs) {
     g->map.mvpKeyFrames.push_back(kf.get());
+    g->map.mnMaxKFid = std::max(g->map.mnMaxKFid, kf->mnId);
     if (kf->mnId == g->map.mnInitKFid) g->map.mpKFinitial = kf.get();
   }
   if (!g->map.mpKFinitial && !g->kfs.empty()) g->map.mpKFinitial = g->kfs[0].get();
@@ -285,6 +286,7 @@ extern "C" int osh_host_graph_set_inertial(osh_host_graph* g, int32_t n, const i
     KeyFrame* kf = g->kfs[kf_index[i]].get();
     kf->bImu = true;
     kf->mPrevKF = prev_index[i] >= 0 ? g->kfs[prev_index[i]].get() : nullptr;
+    if (kf->mPrevKF) kf->mPrevKF->mNextKF = kf;
     kf->SetVelocity(Eigen::Vector3f(vel[3 * i], vel[3 * i + 1], vel[3 * i + 2]));
     kf->mImuBias = IMU::Bias(bias6[6 * i], bias6[6 * i + 1], bias6[6 * i + 2], bias6[6 * i + 3], bias6[6 * i + 4], bias6[6 * i + 5]);
     const float* r = preint + (size_t)i * OSH_PREINT_FLOATS;
@@ -324,6 +326,79 @@ extern "C" int osh_host_run_liba(osh_host_graph* g, int32_t kf_index, int32_t b_
   int a = -1, b = -1, c = -1, d = -1;
   Optimizer::LocalInertialBA(g->kfs[kf_index].get(), nullptr, &g->map, a, b, c, d, b_large != 0, b_rec_init != 0);
   return (a == -1 && b == -1 && c == -1 && d == -1) ? 0 : 2;   // the reference never assigns the num_* outputs
+}
+
+// ------------------------------------------------------------------------------------------ FullInertialBA / MergeInertialBA
+static void export_pack(osh_host_graph* g, osh_liba_problem* out, int64_t* pose_kf_id, int64_t* point_mp_id) {
+  g->liba.fill(*out);
+  out->max_iterations = g->liba.opt_it;
+  if (pose_kf_id) for (size_t i = 0; i < g->liba.vPoseKFs.size(); ++i) pose_kf_id[i] = (int64_t)g->liba.vPoseKFs[i]->mnId;
+  if (point_mp_id) for (size_t j = 0; j < g->liba.vPointMPs.size(); ++j) point_mp_id[j] = (int64_t)g->liba.vPointMPs[j]->mnId;
+}
+
+// the problem Optimizer::FullInertialBA(&map, its, bFixLocal, ., ., bInit) solves; *n_idle = keyframes no edge touches
+extern "C" int osh_host_pack_full_inertial(osh_host_graph* g, int32_t its, int32_t fix_local, int32_t b_init, osh_liba_problem* out,
+                                           int64_t* pose_kf_id, int64_t* point_mp_id, int32_t* n_idle) {
+  if (!g || !out) return -1;
+  std::vector<KeyFrame*> idle;
+  std::vector<MapPoint*> all;
+  const bool ok = PackFullInertialBA(&g->map, its, fix_local != 0, b_init != 0, g->liba, idle, all);
+  if (g->liba.unsupported) return -3;
+  if (!ok) return 1;
+  export_pack(g, out, pose_kf_id, point_mp_id);
+  if (n_idle) *n_idle = (int32_t)idle.size();
+  return 0;
+}
+
+extern "C" int osh_host_run_full_inertial(osh_host_graph* g, int32_t its, int32_t fix_local, int64_t loop_id, int32_t b_init) {
+  if (!g) return -1;
+  Optimizer::FullInertialBA(&g->map, its, fix_local != 0, (unsigned long)loop_id, nullptr, b_init != 0);
+  return 0;
+}
+
+// what FullInertialBA leaves beside the live state when nLoopId != 0: returns mnBAGlobalForKF
+extern "C" int64_t osh_host_get_kf_inertial_gba(osh_host_graph* g, int32_t i, float vel[3], float bias6[6]) {
+  const KeyFrame* k = g->kfs[i].get();
+  for (int a = 0; a < 3; ++a) vel[a] = k->mVwbGBA(a);
+  bias6[0] = k->mBiasGBA.bax; bias6[1] = k->mBiasGBA.bay; bias6[2] = k->mBiasGBA.baz; bias6[3] = k->mBiasGBA.bwx; bias6[4] = k->mBiasGBA.bwy; bias6[5] = k->mBiasGBA.bwz;
+  return (int64_t)k->mnBAGlobalForKF;
+}
+
+// the problem Optimizer::MergeInertialBA(curr, merge, ...) solves; n_sets = {temporal keyframes, covisible keyframes}
+extern "C" int osh_host_pack_merge_inertial(osh_host_graph* g, int32_t curr, int32_t merge, osh_liba_problem* out, int64_t* pose_kf_id,
+                                            int64_t* point_mp_id, int32_t n_sets[2], int64_t* temporal_kf_id, int64_t* cov_kf_id) {
+  if (!g || !out || curr < 0 || curr >= (int)g->kfs.size() || merge < 0 || merge >= (int)g->kfs.size()) return -1;
+  std::vector<KeyFrame*> cov;
+  const bool ok = PackMergeInertialBA(g->kfs[curr].get(), g->kfs[merge].get(), g->liba, cov);
+  reset_marks(g);
+  if (g->liba.unsupported) return -3;
+  if (!ok) return 1;
+  export_pack(g, out, pose_kf_id, point_mp_id);
+  out->lambda_init = 1e3;
+  if (n_sets) { n_sets[0] = (int32_t)g->liba.vpOptimizableKFs.size(); n_sets[1] = (int32_t)cov.size(); }
+  if (temporal_kf_id) for (size_t i = 0; i < g->liba.vpOptimizableKFs.size(); ++i) temporal_kf_id[i] = (int64_t)g->liba.vpOptimizableKFs[i]->mnId;
+  if (cov_kf_id) for (size_t i = 0; i < cov.size(); ++i) cov_kf_id[i] = (int64_t)cov[i]->mnId;
+  return 0;
+}
+
+// Optimizer::MergeInertialBA; returns the size of corrPoses and copies up to max_corr entries {keyframe id; qx qy qz qw tx ty tz s}
+extern "C" int osh_host_run_merge_inertial(osh_host_graph* g, int32_t curr, int32_t merge, int32_t max_corr, int64_t* corr_kf_id, double* corr_sim3) {
+  if (!g || curr < 0 || curr >= (int)g->kfs.size() || merge < 0 || merge >= (int)g->kfs.size()) return -1;
+  LoopClosing::KeyFrameAndPose corr;
+  Optimizer::MergeInertialBA(g->kfs[curr].get(), g->kfs[merge].get(), nullptr, &g->map, corr);
+  reset_marks(g);
+  int n = 0;
+  for (const auto& kv : corr) {
+    if (n < max_corr) {
+      corr_kf_id[n] = (int64_t)kv.first->mnId;
+      double* o = corr_sim3 + 8 * (size_t)n;
+      o[0] = kv.second.rotation().x(); o[1] = kv.second.rotation().y(); o[2] = kv.second.rotation().z(); o[3] = kv.second.rotation().w();
+      for (int a = 0; a < 3; ++a) o[4 + a] = kv.second.translation()(a);
+      o[7] = kv.second.scale();
+    }
+    ++n;
+  }
+  return n;
 }
 
 extern "C" void osh_host_get_kf_velocity(osh_host_graph* g, int32_t i, float o[3]) {

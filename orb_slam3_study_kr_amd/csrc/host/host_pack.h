@@ -173,6 +173,10 @@ struct PoseiPack {
 class Frame;
 bool PackPoseInertial(Frame* pFrame, bool bRecInit, int mode, PoseiPack& pk);
 bool PackLocalInertialBA(KeyFrame* pKF, Map* pMap, bool bLarge, bool bRecInit, LibaPack& pk);
+// Optimizer::FullInertialBA / MergeInertialBA as the same flat problem (OptimizerInertialMap.cc).  vpIdle: keyframes no edge touches;
+// vpCovKFs: the merge's covisible keyframes in the reference's order
+bool PackFullInertialBA(Map* pMap, int its, bool bFixLocal, bool bInit, LibaPack& pk, std::vector<KeyFrame*>& vpIdle, std::vector<MapPoint*>& vpAllMPs);
+bool PackMergeInertialBA(KeyFrame* pCurrKF, KeyFrame* pMergeKF, LibaPack& pk, std::vector<KeyFrame*>& vpCovKFs);
 void InertialInformation(const Eigen::Matrix<float, 15, 15>& C, double* info81);
 osh_lba_ctx* HostSolverContext();   // one solver context per calling thread (Optimizer.cc)
 

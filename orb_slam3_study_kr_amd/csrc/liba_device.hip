@@ -34,6 +34,7 @@ constexpr int kLNB = 24;      // LDL^T panel width
 constexpr int kLG = 32;       // blocks per window at most (one XCD's worth of a group)
 constexpr int kPoseChunks = 8;   // a pose row's edges are summed in at most this many chunks
 constexpr int kLinkQ = 832;   // per link: J^T W J (24x24), -J^T W r (24), then J (9x24), -W r (9), rho'
+constexpr int kLibaMaxKeyframes = 51;   // (liba_scratch_doubles(ldlt_row_stride(15 N)) + kLT/64 + 8) doubles must fit 160 KB of LDS
 __host__ __device__ constexpr size_t liba_scratch_doubles(int W) { return ldlt_lds_doubles(kLNB, W, kLT) > 512 ? ldlt_lds_doubles(kLNB, W, kLT) : 512; }
 struct LibaOut {
   double chi2_initial, chi2_final;
@@ -1046,10 +1047,12 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
     EF += ef; LP += (size_t)d.L * d.N;
     n_max = std::max(n_max, d.n);
   }
-  if (n_max / 15 > 25) { set_error("inertial window with %d optimisable keyframes: the device path handles up to 25 (the reference uses 10 or 25; the panels of the reduced system's LDL^T live in LDS)", n_max / 15); return OSH_ERR_UNSUPPORTED; }
   const int W = ldlt_row_stride(n_max);
   const size_t lds = (liba_scratch_doubles(W) + kLT / 64 + 8) * sizeof(double);
-  if (lds > 160 * 1024 - 64) { set_error("inertial window with %d keyframes exceeds the LDS budget", n_max / 15); return OSH_ERR_UNSUPPORTED; }
+  if (lds > 160 * 1024 - 64) {   // the panels of the reduced system's LDL^T live in LDS: 51 keyframes x 15 dof at most
+    set_error("inertial window with %d optimisable keyframes: the device path handles up to %d (LocalInertialBA uses 10 or 25)", n_max / 15, kLibaMaxKeyframes);
+    return OSH_ERR_UNSUPPORTED;
+  }
   // ---- pack: every input array goes into ONE pinned staging buffer and travels in ONE copy (an upload per array cost more than
   // the optimisation of a single window); the device pointers are offsets into the arena.
   // staging and work buffers live with the context (one solver at a time per context, as for the visual path)

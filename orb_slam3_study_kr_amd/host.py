@@ -402,9 +402,12 @@ class HostInertialGraph:
     """A map with IMU state built from a synth_inertial.LibaWindow: keyframe k <-> pose index k of the window
     (temporal keyframes ids 100+i, the fixed predecessor id 99, fixed observers ids 10+i)."""
 
-    def __init__(self, w):
+    def __init__(self, w, no_prev=()):
+        """``no_prev``: pose indices of temporal keyframes whose mPrevKF stays null (the chain of keyframes breaks before them;
+        the window must not hold an inertial link that ends there)."""
         self.lib = capi.load_library()
         self.w = w
+        assert not np.isin(w.link_cur, list(no_prev)).any()
         N, K = w.n_opt, w.n_opt + w.n_fixed_imu + w.n_fixed
         self.kf_id = np.array([100 + i for i in range(N)] + [99] * w.n_fixed_imu + [10 + i for i in range(w.n_fixed)], dtype=np.int64)
         self.mp_id = np.arange(w.n_points, dtype=np.int64) + 1000
@@ -426,7 +429,7 @@ class HostInertialGraph:
             capi.ptr(obs, capi.c_float_p), capi.ptr(octave, capi.c_int32_p), -1 & 0x7FFFFFFF, 1))
         n_imu = N + w.n_fixed_imu
         kf_index = _i32(np.arange(n_imu))
-        prev = _i32([N if (i == 0 and w.n_fixed_imu) else i - 1 for i in range(N)] + [-1] * w.n_fixed_imu)
+        prev = _i32([-1 if i in no_prev else N if (i == 0 and w.n_fixed_imu) else i - 1 for i in range(N)] + [-1] * w.n_fixed_imu)
         vel = _f32(w.vel.reshape(-1, 3)[:n_imu])
         bias6 = _f32(np.concatenate([w.bias_a.reshape(-1, 3)[:n_imu], w.bias_g.reshape(-1, 3)[:n_imu]], axis=1))
         pre = np.zeros((n_imu, capi.OSH_PREINT_FLOATS), dtype=np.float32)
@@ -471,6 +474,14 @@ class HostInertialGraph:
                                          capi.ptr(mid, capi.c_int64_p))
         assert rc == 0, rc
 
+        w = self._window_of(p, lambda_init=1e-2 if large else 1.0, max_iterations=4 if large else 10)
+        Kp = p.n_opt + p.n_fixed_imu + p.n_fixed
+        return w, kid[:Kp], mid[:p.n_points]
+
+    @staticmethod
+    def _window_of(p, lambda_init, max_iterations):
+        from .synth_inertial import LibaWindow
+
         def arr(ptr, n, dt=np.float64):
             return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt).copy() if n else np.zeros(0, dtype=dt)
         Kp, NV, L, E, NL = p.n_opt + p.n_fixed_imu + p.n_fixed, p.n_opt + p.n_fixed_imu, p.n_points, p.n_edges, p.n_links
@@ -484,12 +495,55 @@ class HostInertialGraph:
             link_preint=arr(p.link_preint, NL * capi.OSH_PREINT_FLOATS, np.float32).reshape(NL, -1),
             link_info=arr(p.link_info, NL * 81).reshape(NL, 81), link_info_g=arr(p.link_info_g, NL * 9).reshape(NL, 9),
             link_info_a=arr(p.link_info_a, NL * 9).reshape(NL, 9), link_robust=arr(p.link_robust, NL, np.uint8),
-            lambda_init=1e-2 if large else 1.0, max_iterations=4 if large else 10,
+            lambda_init=lambda_init, max_iterations=max_iterations,
             kb8=arr(p.kb8, 4) if p.kb8 else None, cam2=arr(p.cam2, 8) if p.cam2 else None, trl=arr(p.trl, 12) if p.trl else None).normalise()
-        return w, kid[:Kp], mid[:L]
+        return w
 
     def run(self, large=False, rec_init=False):
         return self.lib.osh_host_run_liba(self.g, self.cur, int(large), int(rec_init))
+
+    def packed_full(self, its, fix_local=False, init=False):
+        """The problem Optimizer::FullInertialBA(map, its, bFixLocal, ., ., bInit) solves, as (LibaWindow, keyframe ids, map point ids,
+        number of keyframes no edge touches); the host layer's return code instead when it declines the case."""
+        p = capi.LibaProblem()
+        kid, mid = np.zeros(len(self.kf_id), dtype=np.int64), np.zeros(self.w.n_points, dtype=np.int64)
+        idle = np.zeros(1, dtype=np.int32)
+        rc = self.lib.osh_host_pack_full_inertial(self.g, int(its), int(fix_local), int(init), C.byref(p), capi.ptr(kid, capi.c_int64_p),
+                                                  capi.ptr(mid, capi.c_int64_p), capi.ptr(idle, capi.c_int32_p))
+        if rc != 0:
+            return rc
+        return self._window_of(p, 1e-5, int(its)), kid[:p.n_opt + p.n_fixed_imu + p.n_fixed], mid[:p.n_points], int(idle[0])
+
+    def run_full(self, its, loop_id=0, fix_local=False, init=False):
+        return self.lib.osh_host_run_full_inertial(self.g, int(its), int(fix_local), int(loop_id), int(init))
+
+    def packed_merge(self, curr, merge):
+        """The problem Optimizer::MergeInertialBA(kf[curr], kf[merge], ...) solves + (temporal keyframe ids, covisible keyframe ids) in
+        the reference's order."""
+        p = capi.LibaProblem()
+        K = len(self.kf_id)
+        kid, mid = np.zeros(K, dtype=np.int64), np.zeros(self.w.n_points, dtype=np.int64)
+        sets, tid, cid = np.zeros(2, dtype=np.int32), np.zeros(K, dtype=np.int64), np.zeros(K, dtype=np.int64)
+        rc = self.lib.osh_host_pack_merge_inertial(self.g, int(curr), int(merge), C.byref(p), capi.ptr(kid, capi.c_int64_p), capi.ptr(mid, capi.c_int64_p),
+                                                   capi.ptr(sets, capi.c_int32_p), capi.ptr(tid, capi.c_int64_p), capi.ptr(cid, capi.c_int64_p))
+        if rc != 0:
+            return rc
+        return (self._window_of(p, 1e3, 8), kid[:p.n_opt + p.n_fixed_imu + p.n_fixed], mid[:p.n_points], tid[:sets[0]], cid[:sets[1]])
+
+    def run_merge(self, curr, merge):
+        """Optimizer::MergeInertialBA; returns corrPoses as {keyframe id: [qx qy qz qw tx ty tz s]}."""
+        K = len(self.kf_id)
+        ids, sim = np.zeros(K, dtype=np.int64), np.zeros((K, 8))
+        n = self.lib.osh_host_run_merge_inertial(self.g, int(curr), int(merge), K, capi.ptr(ids, capi.c_int64_p), capi.ptr(sim, capi.c_double_p))
+        assert 0 <= n <= K, n
+        return {int(ids[i]): sim[i].copy() for i in range(n)}
+
+    def kf_inertial_gba(self, i):
+        """(mnBAGlobalForKF, mTcwGBA [qx qy qz qw tx ty tz], mVwbGBA, mBiasGBA [ba, bg]) of keyframe i."""
+        pose, vel, bias = np.zeros(7, dtype=np.float32), np.zeros(3, dtype=np.float32), np.zeros(6, dtype=np.float32)
+        self.lib.osh_host_get_kf_pose_gba(self.g, i, capi.ptr(pose, capi.c_float_p))
+        lid = self.lib.osh_host_get_kf_inertial_gba(self.g, i, capi.ptr(vel, capi.c_float_p), capi.ptr(bias, capi.c_float_p))
+        return int(lid), pose, vel, bias
 
     def kf_pose(self, i):
         o = np.zeros(7, dtype=np.float32)

@@ -994,6 +994,145 @@ def test_pose_optimization_fisheye_stereo_frame(ob):
     assert rel_translation_error(got, ref.pose_qt[None]) < 2e-6 and rotation_error(got, ref.pose_qt[None]) < 2e-6
 
 
+def _broken_chain_window(seed=83, n_opt=20, n_fixed=3, n_points=1500, at=9):
+    """An inertial map whose chain of keyframes breaks before temporal keyframe `at` (two sessions that a map merge welds)."""
+    import dataclasses
+    from orb_slam3_study_kr_amd import synth_inertial as si
+    w = si.make_inertial_window(seed, n_opt=n_opt, n_fixed=n_fixed, n_points=n_points)
+    keep = w.link_cur != at
+    w = dataclasses.replace(w, **{f: getattr(w, f)[keep] for f in ("link_prev", "link_cur", "link_preint", "link_info", "link_info_g", "link_info_a", "link_robust")})
+    w.gt["link_cov"] = w.gt["link_cov"][keep]
+    return w
+
+
+def _check_inertial_keyframe(qt, vel, bias, ref, n, linked=True):
+    qt = qt.astype(np.float64)
+    np.testing.assert_allclose(qt[4:], ref.pose_tcw[n], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(quat_R(qt[:4]), ref.pose_Rcw[n], atol=2e-6)
+    if linked:
+        np.testing.assert_allclose(vel, ref.vel[n], rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(bias[:3], ref.bias_a[n], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(bias[3:], ref.bias_g[n], rtol=1e-4, atol=1e-7)
+
+
+def _anchored(Rcw, tcw, vel, pts, a):
+    """Poses, velocities and points expressed in the camera frame of keyframe `a`: what a problem without a fixed keyframe determines
+    (a rigid change of the world frame -- for a visual-inertial map a yaw and a translation -- leaves every residual unchanged)."""
+    R0, t0 = Rcw[a], tcw[a]
+    relR = np.einsum("nij,kj->nik", Rcw, R0)
+    relt = tcw - np.einsum("nij,j->ni", relR, t0)
+    return relR, relt, vel @ R0.T, pts @ R0.T + t0
+
+
+@pytest.mark.parametrize("loop_id", [0, 7])
+def test_full_inertial_ba_through_the_reference_signature(ob, loop_id):
+    """Optimizer::FullInertialBA(Map*, its, bFixLocal=false, nLoopId, NULL, bInit=false) (src/Optimizer.cc:393-814) on a map of 15 inertial
+    keyframes + 4 keyframes without IMU (pose vertices only): one optimize(its) at lambda 1e-5, every keyframe optimisable, no outlier pass.
+    Against the inertial oracle on the problem the host layer packed; written into the live map (nLoopId 0) or beside it (mTcwGBA,
+    mVwbGBA, mBiasGBA, mPosGBA with the loop id).
+    Nothing is fixed, so position and yaw of the whole map are held by the damping term alone (1e-5, 5e-9 after seven accepted steps): the
+    increment along those four directions is rounding noise over lambda, and it feeds back into the next linearisation -- the CPU
+    restatement itself moves its intermediate costs by 3e-4 relative when the edges are merely summed in another order (the order of
+    std::map<KeyFrame*, ...>, src/Optimizer.cc:618, differs from run to run in the reference too).  What the problem determines is the
+    minimum it converges to, expressed in the frame of one keyframe: that is what is compared, after 25 iterations."""
+    from orb_slam3_study_kr_amd import lba, synth_inertial as si
+    w = si.make_inertial_window(81, n_opt=14, n_fixed=4, n_points=900)
+    with host.HostInertialGraph(w) as g:
+        pw, kid, mid, idle = g.packed_full(25)
+        assert (pw.n_opt, pw.n_fixed_imu, pw.n_fixed, idle) == (19, 0, 0, 0)
+        ref = ob.liba_solve(pw)
+        with lba.LbaSolver(0) as s:
+            dev = s.solve_inertial([pw])[0]
+        np.testing.assert_allclose(dev.chi2_initial, ref.chi2_initial, rtol=1e-7)
+        np.testing.assert_allclose(dev.chi2_trace[:2], ref.chi2_trace[:2], rtol=1e-4)
+        np.testing.assert_allclose(dev.chi2_final, ref.chi2_final, rtol=1e-6)
+        assert dev.iterations == ref.iterations < 25       # both end on Levenberg's own stop rule, at the minimum
+        before = [(g.kf_pose(k).copy(), g.kf_velocity(k).copy(), g.kf_bias(k).copy()) for k in range(len(g.kf_id))]
+        assert g.run_full(25, loop_id) == 0
+        assert g.lib.osh_host_map_change_index(g.g) == 1
+        kf_index = {int(i): k for k, i in enumerate(g.kf_id)}
+        linked = sorted(set(pw.link_prev.tolist()) | set(pw.link_cur.tolist()))
+        assert len(linked) == 15
+        N = len(kid)
+        Rcw, tcw, vel, bias = np.zeros((N, 3, 3)), np.zeros((N, 3)), np.zeros((N, 3)), np.zeros((N, 6))
+        for n, kf in enumerate(kid):
+            k = kf_index[int(kf)]
+            if loop_id == 0:
+                qt, vel[n], bias[n] = g.kf_pose(k).astype(np.float64), g.kf_velocity(k), g.kf_bias(k)
+                assert g.lib.osh_host_kf_pose_sets(g.g, k) == 1
+                if n not in linked:   # a keyframe without IMU: only its pose is a vertex
+                    np.testing.assert_array_equal(g.kf_velocity(k), before[k][1])
+            else:
+                lid, qt, vel[n], bias[n] = g.kf_inertial_gba(k)
+                assert lid == loop_id
+                np.testing.assert_array_equal(g.kf_pose(k), before[k][0])
+                assert g.lib.osh_host_kf_pose_sets(g.g, k) == 0
+            Rcw[n], tcw[n] = quat_R(qt[:4].astype(np.float64)), qt[4:]
+        mp_index = {int(i): k for k, i in enumerate(g.mp_id)}
+        pts = np.zeros((len(mid), 3))
+        for r, i in enumerate(mid):
+            if loop_id == 0:
+                pts[r] = g.mp_pos(mp_index[int(i)])
+            else:
+                o = np.zeros(3, dtype=np.float32)
+                assert g.lib.osh_host_get_mp_pos_gba(g.g, mp_index[int(i)], capi.ptr(o, capi.c_float_p)) == loop_id
+                pts[r] = o
+        a = linked[-1]
+        gR, gt, gv, gp = _anchored(Rcw, tcw, vel, pts, a)
+        rR, rt, rv, rp = _anchored(ref.pose_Rcw.reshape(-1, 3, 3), ref.pose_tcw, np.pad(ref.vel, ((0, 0), (0, 0))), ref.points, a)
+        np.testing.assert_allclose(gR, rR, atol=5e-6)
+        np.testing.assert_allclose(gt, rt, atol=2e-5)
+        np.testing.assert_allclose(gp, rp, atol=5e-4)       # the depth of a few low-parallax landmarks is flat at the minimum
+        assert np.mean(np.abs(gp - rp) > 5e-5) < 5e-3
+        np.testing.assert_allclose(gv[linked], rv[linked], atol=2e-5)
+        np.testing.assert_allclose(bias[linked, :3], ref.bias_a[linked], rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(bias[linked, 3:], ref.bias_g[linked], rtol=1e-4, atol=2e-7)
+
+
+def test_full_inertial_ba_declines_what_it_does_not_cover(ob):
+    """bInit (one shared bias pair with priors) and bFixLocal are not on the device path: message on stderr, map untouched."""
+    from orb_slam3_study_kr_amd import synth_inertial as si
+    w = si.make_inertial_window(82, n_opt=5, n_fixed=2, n_points=200)
+    with host.HostInertialGraph(w) as g:
+        assert g.packed_full(5, init=True) == -3 and g.packed_full(5, fix_local=True) == -3
+        assert g.run_full(5, init=True) == 0 and g.lib.osh_host_map_change_index(g.g) == 0
+        assert all(g.lib.osh_host_kf_pose_sets(g.g, k) == 0 for k in range(len(g.kf_id)))
+
+
+def test_merge_inertial_ba_through_the_reference_signature(ob):
+    """Optimizer::MergeInertialBA(pCurrKF, pMergeKF, NULL, pMap, corrPoses) (src/Optimizer.cc:3956-4498) on a map of two sessions: the
+    temporal keyframes of both chains (15 dof), one fixed keyframe, covisible keyframes with pose vertices only; optimize(8) at lambda 1e3,
+    outliers by chi2 alone, every optimised pose also returned as a Sim3 of scale 1."""
+    w = _broken_chain_window()
+    with host.HostInertialGraph(w, no_prev=(9,)) as g:
+        pw, kid, mid, tid, cid = g.packed_merge(19, 4)
+        ref = ob.liba_solve(pw)
+        before_v = {int(g.kf_id[k]): g.kf_velocity(k).copy() for k in range(len(g.kf_id))}
+        corr = g.run_merge(19, 4)
+        assert g.lib.osh_host_map_change_index(g.g) == 1
+        assert sorted(corr) == sorted(tid.tolist() + cid.tolist())
+        kf_index = {int(i): k for k, i in enumerate(g.kf_id)}
+        linked = set(pw.link_prev.tolist()) | set(pw.link_cur.tolist())
+        for n, kf in enumerate(kid[:pw.n_opt]):
+            k = kf_index[int(kf)]
+            _check_inertial_keyframe(g.kf_pose(k), g.kf_velocity(k), g.kf_bias(k), ref, n, n in linked)
+            if n not in linked:
+                np.testing.assert_array_equal(g.kf_velocity(k), before_v[int(kf)])
+            qt = g.kf_pose(k).astype(np.float64)       # corrPoses: the float pose just set, widened (Tiw = GetPose().cast<double>())
+            np.testing.assert_array_equal(corr[int(kf)][:7], qt)
+            assert corr[int(kf)][7] == 1.0
+        assert g.lib.osh_host_kf_pose_sets(g.g, kf_index[int(kid[-1])]) == 0      # the fixed keyframe
+        mp_index = {int(i): k for k, i in enumerate(g.mp_id)}
+        got_pts = np.stack([g.mp_pos(mp_index[int(i)]) for i in mid]).astype(np.float64)
+        np.testing.assert_allclose(got_pts, ref.points, rtol=2e-6, atol=2e-6)
+        out = ref.edge_chi2 > np.float32(7.815)                                  # stereo map: chi2 > 7.815f, no depth test (:4412-4426)
+        near = np.abs(ref.edge_chi2 - 7.815) < 1e-3
+        assert out.sum() > 10
+        for e in np.nonzero(~near)[0]:
+            k, j = kf_index[int(kid[pw.edge_pose[e]])], mp_index[int(mid[pw.edge_point[e]])]
+            assert g.lib.osh_host_kf_observes(g.g, k, j) == (0 if out[e] else 1)
+
+
 @pytest.mark.parametrize("fisheye", [False, True])
 def test_local_inertial_ba_through_the_reference_signature(ob, fisheye):
     """Optimizer::LocalInertialBA(KeyFrame*, bool*, Map*, int&x4, bLarge, bRecInit) on a KeyFrame/MapPoint/IMU graph vs the

@@ -145,8 +145,34 @@ def test_large_window_of_25_keyframes(solver, ob):
     """LocalInertialBA's bLarge case: 25 temporal keyframes (src/Optimizer.cc:2394-2400), a 375 x 375 reduced system."""
     w = si.make_inertial_window(61, n_opt=25, n_fixed=10, n_points=1500, large=True)
     _check(solver.solve_inertial([w])[0], ob.liba_solve(w), w)
-    with pytest.raises(RuntimeError, match="up to 25"):
-        solver.solve_inertial([si.make_inertial_window(62, n_opt=26, n_fixed=5, n_points=600, large=True)])
+    with pytest.raises(RuntimeError, match="up to 51"):
+        solver.solve_inertial([si.make_inertial_window(62, n_opt=52, n_fixed=5, n_points=600, large=True)])
+
+
+def _without_links_at(w, kfs):
+    """The window with every inertial link that touches one of the keyframes `kfs` removed: those keyframes keep their 15-dof
+    state, but nothing constrains its velocity / bias part (the pose-only optimisable keyframes of MergeInertialBA and of
+    FullInertialBA with !bImu keyframes, whose velocity / bias vertices have no active edge, src/Optimizer.cc:4077-4100)."""
+    import dataclasses
+    keep = ~(np.isin(w.link_prev, kfs) | np.isin(w.link_cur, kfs))
+    return dataclasses.replace(w, link_prev=w.link_prev[keep], link_cur=w.link_cur[keep], link_preint=w.link_preint[keep], link_info=w.link_info[keep],
+                               link_info_g=w.link_info_g[keep], link_info_a=w.link_info_a[keep], link_robust=w.link_robust[keep])
+
+
+@pytest.mark.parametrize("n_opt,lam,its", [(40, 1e-5, 7), (51, 1e3, 8)])
+def test_map_sized_windows_and_keyframes_without_links(solver, ob, n_opt, lam, its):
+    """Windows beyond LocalInertialBA's 25 keyframes (FullInertialBA over a small map: lambda 1e-5, src/Optimizer.cc:408; MergeInertialBA:
+    lambda 1e3, optimize(8), :4121,4388): up to 51 keyframes (a 765 x 765 reduced system), no fixed observers, some keyframes without
+    inertial links (their velocity / bias columns carry lambda only and stay where they are)."""
+    import dataclasses
+    w = si.make_inertial_window(70 + n_opt, n_opt=n_opt, n_fixed=0, n_points=2500, large=True)
+    w = _without_links_at(w, [5, 17, 18])
+    w = dataclasses.replace(w, lambda_init=lam, max_iterations=its, link_robust=np.ones_like(w.link_robust))
+    got, ref = solver.solve_inertial([w])[0], ob.liba_solve(w)
+    _check(got, ref, w, lam_tol=1e-3, pts_tol=2e-4, edge_tol=1e-3)
+    for k in (5, 17, 18):
+        np.testing.assert_array_equal(got.vel[k], w.vel[k])
+        np.testing.assert_array_equal(got.bias_g[k], w.bias_g[k])
 
 
 def test_many_window_shapes_through_the_block_groups(solver, ob, monkeypatch):
