@@ -342,6 +342,13 @@ typedef struct osh_liba_problem {
    * A (keyframe, landmark) pair may carry one OSH_EDGE_MONO and one OSH_EDGE_RIGHT edge.  Needs kb8; both NULL otherwise. */
   const double* cam2;       /* [8] right camera fx fy cx cy k1 k2 k3 k4 */
   const double* trl;        /* [12] rows of the 3x4 matrix [Rrl | trl] = KeyFrame::GetRelativePoseTrl().matrix().cast<double>() (float32 values) */
+  /* NULL, or [n_links]: the keyframe whose (gyro, acc) bias vertices are vertices 2 and 3 of link l's EdgeInertial (< n_opt+n_fixed_imu);
+   * NULL = link_prev[l], the keyframe's own.  FullInertialBA with bInit (src/Optimizer.cc:452-462,514-518) hangs every inertial edge on
+   * ONE pair of bias vertices: all entries name the keyframe that stores it (any keyframe that is not the later one of a link: a link
+   * with link_bias != link_prev must have link_bias != link_cur and zero link_info_g / link_info_a).  EdgeGyroRW / EdgeAccRW stay between
+   * link_prev and link_cur; a link whose link_info is all zero is that pair of edges alone -- from a fixed keyframe that holds a prior
+   * value it is EdgePriorGyro / EdgePriorAcc (residual prior - b, include/G2oTypes.h:706-760). */
+  const int32_t* link_bias;
 } osh_liba_problem;
 
 typedef struct osh_liba_result {

@@ -96,7 +96,8 @@ def inertial_residual(st, l):
     dR, dV, dP = rec[1:10].reshape(3, 3), rec[10:13], rec[13:16]
     JRg, JVg, JVa, JPg, JPa = (rec[o:o + 9].reshape(3, 3) for o in (16, 25, 34, 43, 52))
     b = rec[61:67]
-    bg1, ba1 = st.bg[a].astype(f32), st.ba[a].astype(f32)     # IMU::Bias holds floats
+    ab = a if getattr(w, "link_bias", None) is None else int(w.link_bias[l])   # the keyframe whose bias vertices the edge hangs on
+    bg1, ba1 = st.bg[ab].astype(f32), st.ba[ab].astype(f32)   # IMU::Bias holds floats
     dbg, dba = (bg1 - b[3:6]).astype(f32), (ba1 - b[0:3]).astype(f32)
     u, _, vt = np.linalg.svd((dR @ so3f_exp(JRg @ dbg)).astype(f32))
     dRb = (u @ vt).astype(np.float64)

@@ -364,13 +364,15 @@ static void inertial_jac_core(const float* rec, const double* Rwb1, const double
 static void inertial_error(const istate* s, int l, double* r) {
   const osh_liba_problem* p = s->pr;
   const int a = p->link_prev[l], c = p->link_cur[l];
-  inertial_error_core(p->link_preint + (size_t)l * OSH_PREINT_FLOATS, s->Rwb + 9 * a, s->twb + 3 * a, s->vel + 3 * a, s->bg + 3 * a, s->ba + 3 * a,
+  const int ab = p->link_bias ? p->link_bias[l] : a;   /* the keyframe that stores the edge's bias vertices (bInit: one shared pair, src/Optimizer.cc:514-518) */
+  inertial_error_core(p->link_preint + (size_t)l * OSH_PREINT_FLOATS, s->Rwb + 9 * a, s->twb + 3 * a, s->vel + 3 * a, s->bg + 3 * ab, s->ba + 3 * ab,
                       s->Rwb + 9 * c, s->twb + 3 * c, s->vel + 3 * c, r);
 }
 static void inertial_jac(const istate* s, int l, double* J) {
   const osh_liba_problem* p = s->pr;
   const int a = p->link_prev[l], c = p->link_cur[l];
-  inertial_jac_core(p->link_preint + (size_t)l * OSH_PREINT_FLOATS, s->Rwb + 9 * a, s->twb + 3 * a, s->vel + 3 * a, s->bg + 3 * a, s->ba + 3 * a,
+  const int ab = p->link_bias ? p->link_bias[l] : a;
+  inertial_jac_core(p->link_preint + (size_t)l * OSH_PREINT_FLOATS, s->Rwb + 9 * a, s->twb + 3 * a, s->vel + 3 * a, s->bg + 3 * ab, s->ba + 3 * ab,
                     s->Rwb + 9 * c, s->twb + 3 * c, s->vel + 3 * c, J);
 }
 
@@ -380,7 +382,7 @@ static int lnk_off(const istate* s, int v /*0..5 vertex of the inertial edge*/, 
   const int a = p->link_prev[l], c = p->link_cur[l], N = s->N;
   static const int dims[6] = {6, 3, 3, 3, 6, 3};
   *dim = dims[v];
-  const int kf = (v < 4) ? a : c;
+  const int kf = (v == 2 || v == 3) ? (p->link_bias ? p->link_bias[l] : a) : (v < 4) ? a : c;
   if (kf >= N) return -1;
   switch (v) {
     case 0: case 4: return 6 * kf;

@@ -103,7 +103,7 @@ class LibaProblem(C.Structure):
         ("link_info", c_double_p), ("link_info_g", c_double_p), ("link_info_a", c_double_p), ("link_robust", c_uint8_p),
         ("huber_mono", C.c_double), ("huber_stereo", C.c_double), ("huber_inertial", C.c_double),
         ("lambda_init", C.c_double), ("max_iterations", C.c_int32), ("kb8", c_double_p),
-        ("cam2", c_double_p), ("trl", c_double_p),
+        ("cam2", c_double_p), ("trl", c_double_p), ("link_bias", c_int32_p),
     ]
 
 

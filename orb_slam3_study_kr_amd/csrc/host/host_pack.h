@@ -118,6 +118,7 @@ struct LibaPack {
   bool has_rig = false;       // fisheye stereo rig: OSH_EDGE_RIGHT edges (EdgeMono(1)) through cam2 / trl
   double cam2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, trl[12] = {0};
   std::vector<int32_t> edge_pose, edge_point, link_prev, link_cur;
+  std::vector<int32_t> link_bias;   // empty, or per link the keyframe that stores the edge's bias vertices (FullInertialBA with bInit)
   std::vector<uint8_t> edge_kind, link_robust;
   std::vector<float> link_preint;
   void fill(osh_liba_problem& p) const {
@@ -132,6 +133,7 @@ struct LibaPack {
     p.huber_mono = p.huber_stereo = p.huber_inertial = 0; p.lambda_init = 1.0; p.max_iterations = opt_it;
     p.kb8 = has_kb8 ? kb8 : nullptr;
     p.cam2 = has_rig ? cam2 : nullptr; p.trl = has_rig ? trl : nullptr;
+    p.link_bias = link_bias.empty() ? nullptr : link_bias.data();
   }
 };
 // Flat problem of Optimizer::PoseInertialOptimizationLastKeyFrame (mode 0) / LastFrame (mode 1), src/Optimizer.cc:4499-5299

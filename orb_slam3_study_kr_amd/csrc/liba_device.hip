@@ -54,7 +54,7 @@ struct LibaView {
   const int* lm_off;          // L+1 per window (sorted edges)
   const int* pel_off; const int* pel_edge;   // pel_off [N+1]: the optimisable poses' ranges in pel_edge [E]: their edges pose by pose (landmark order inside), then the fixed keyframes' edges
   const int* lm_pose_edge;    // [L*N] place of the block of (landmark, optimisable pose) in the pose-by-pose order (pel_edge), or -1
-  const int* link_prev; const int* link_cur; const float* link_preint; const double* link_info; const double* link_info_g;
+  const int* link_prev; const int* link_cur; const int* link_bias; const float* link_preint; const double* link_info; const double* link_info_g;
   const double* link_info_a; const unsigned char* link_robust;
   double* Hpl; double* Hll; double* bl; double* dinv;   // [18][EF_total] (a column per block, pose-by-pose order) [L*6] [L*3] [L*9]
   double* BD;                 // [18][EF_total] B Dinv of every optimisable-pose block (Schur step), same layout as Hpl
@@ -95,8 +95,8 @@ __device__ __forceinline__ double blk_max(double v, double* shw) {
 }
 
 // reduced-state offset of vertex v (0..5) of link (a -> c), or -1 when the vertex is fixed
-__device__ __forceinline__ int link_vertex_offset(int v, int a, int c, int N) {
-  const int kf = (v < 4) ? a : c;
+__device__ __forceinline__ int link_vertex_offset(int v, int a, int c, int ab, int N) {
+  const int kf = (v == 2 || v == 3) ? ab : (v < 4) ? a : c;   // ab: the keyframe that stores the edge's bias vertices (osh_liba_problem.link_bias)
   if (kf >= N) return -1;
   if (v == 0 || v == 4) return 6 * kf;
   const int base = 6 * N + 9 * kf;
@@ -199,9 +199,11 @@ __device__ __noinline__ double eval_partial(const LibaView& v, const LibaDesc& d
   if ((tid >> 6) == kLT / 64 - 1) {
     for (int l = (tid & 63) * g.G + g.m; l < d.NL; l += 64 * g.G) {
       const int gl = d.link_off + l;
-      const int a = v.link_prev[gl], c = v.link_cur[gl];
-      double r[9];
-      inertial_residual(v.link_preint + (size_t)gl * OSH_PREINT_FLOATS, poses + 24 * a, vba + 9 * a, poses + 24 * c, vba + 9 * c, r);
+      const int a = v.link_prev[gl], c = v.link_cur[gl], ab = v.link_bias[gl];
+      double r[9], s1[9];   // (v, bg, ba) of vertices 1..3: the earlier keyframe's velocity, the biases of keyframe ab
+      for (int i = 0; i < 3; ++i) s1[i] = vba[9 * a + i];
+      for (int i = 3; i < 9; ++i) s1[i] = vba[9 * ab + i];
+      inertial_residual(v.link_preint + (size_t)gl * OSH_PREINT_FLOATS, poses + 24 * a, s1, poses + 24 * c, vba + 9 * c, r);
       const double* Om = v.link_info + (size_t)gl * 81;
       double chi = 0.0;
       for (int i = 0; i < 9; ++i) { double t = 0; for (int j = 0; j < 9; ++j) t += Om[i * 9 + j] * r[j]; chi += r[i] * t; }
@@ -410,13 +412,13 @@ __device__ __noinline__ void liba_assemble_links(const LibaCtx& c, int sel, int 
         const int l = idx / 648, sl = idx - l * 648;
         const int gl = d.link_off + l;
         if (v.link_colour[gl] != col) continue;
-        const int a = v.link_prev[gl], c = v.link_cur[gl];
+        const int a = v.link_prev[gl], c = v.link_cur[gl], ab = v.link_bias[gl];
         const double* Q = linkQ + (size_t)l * kLinkQ;
         if (sl < 576) {
           const int ca = sl / 24, cb = sl - ca * 24;
           const int va = vert_of(ca), vb = vert_of(cb);
           if (vb < va) continue;   // upper blocks + mirrored below
-          const int oa = link_vertex_offset(va, a, c, N), ob = link_vertex_offset(vb, a, c, N);
+          const int oa = link_vertex_offset(va, a, c, ab, N), ob = link_vertex_offset(vb, a, c, ab, N);
           if (oa < 0 || ob < 0) continue;
           double val = Q[sl];
           if (va == vb && (va == 2 || va == 3)) val += (va == 2 ? v.link_info_g : v.link_info_a)[(size_t)gl * 9 + (ca - vbase[va]) * 3 + (cb - vbase[vb])];
@@ -426,7 +428,7 @@ __device__ __noinline__ void liba_assemble_links(const LibaCtx& c, int sel, int 
         } else if (sl < 600) {
           const int ca = sl - 576;
           const int va = vert_of(ca);
-          const int oa = link_vertex_offset(va, a, c, N);
+          const int oa = link_vertex_offset(va, a, c, ab, N);
           if (oa < 0) continue;
           double val = Q[sl];
           if (va == 2 || va == 3) {
@@ -471,12 +473,14 @@ __device__ __noinline__ void liba_linearise(const LibaCtx& c, int sel) {
     if (wave == kLT / 64 - 1) {
       for (int l = lane * G + m; l < d.NL; l += 64 * G) {
         const int gl = d.link_off + l;
-        const int a = v.link_prev[gl], c = v.link_cur[gl];
+        const int a = v.link_prev[gl], c = v.link_cur[gl], ab = v.link_bias[gl];
         double* Q = linkQ + (size_t)l * kLinkQ;
         double* J = Q + 600;
-        double r[9];
+        double r[9], s1[9];
+        for (int i = 0; i < 3; ++i) s1[i] = vba[9 * a + i];
+        for (int i = 3; i < 9; ++i) s1[i] = vba[9 * ab + i];
         const float* rec = v.link_preint + (size_t)gl * OSH_PREINT_FLOATS;
-        inertial_residual_jacobian(rec, poses + 24 * a, vba + 9 * a, poses + 24 * c, vba + 9 * c, r, J);
+        inertial_residual_jacobian(rec, poses + 24 * a, s1, poses + 24 * c, vba + 9 * c, r, J);
         const double* Om = v.link_info + (size_t)gl * 81;
         double rho1 = 1.0;
         if (v.link_robust[gl]) {
@@ -1043,6 +1047,18 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
       if (p.link_prev[l] < 0 || p.link_prev[l] >= d.NV || p.link_cur[l] < 0 || p.link_cur[l] >= d.N) {
         set_error("window %d link %d: keyframe index out of range", w, l); return OSH_ERR_INVALID;
       }
+    if (p.link_bias)
+      for (int l = 0; l < p.n_links; ++l) {
+        if (p.link_bias[l] < 0 || p.link_bias[l] >= d.NV) { set_error("window %d link %d: bias keyframe out of range", w, l); return OSH_ERR_INVALID; }
+        if (p.link_bias[l] == p.link_prev[l]) continue;
+        // the random-walk terms of the later keyframe are added beside the edge's own terms, by other threads of the same phase
+        if (p.link_bias[l] == p.link_cur[l]) { set_error("window %d link %d: the bias vertices of a link cannot be those of its later keyframe", w, l); return OSH_ERR_UNSUPPORTED; }
+        // the random-walk terms of a link's earlier keyframe are summed into the blocks of the edge's own bias vertices
+        for (int k = 0; k < 9; ++k)
+          if (p.link_info_g[(size_t)l * 9 + k] != 0.0 || p.link_info_a[(size_t)l * 9 + k] != 0.0) {
+            set_error("window %d link %d: a link whose bias vertices belong to another keyframe carries no random-walk edges", w, l); return OSH_ERR_UNSUPPORTED;
+          }
+      }
     K += d.K; NV += d.NV; L += d.L; E += d.E; NL += d.NL; Htot += (size_t)d.n * d.n; btot += d.n; LO += (size_t)d.L + 1; PO += (size_t)d.N + 1;
     EF += ef; LP += (size_t)d.L * d.N;
     n_max = std::max(n_max, d.n);
@@ -1066,7 +1082,7 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
                o_info = take(E * 8), o_ep = take(E * 4), o_el = take(E * 4), o_eo = take(E * 4), o_lmo = take(LO * 4), o_po = take(PO * 4),
                o_pel = take(E * 4), o_lmpe = take(LP * 4), o_lp = take(NL * 4), o_lc = take(NL * 4), o_kind = take(E), o_rob = take(NL),
                o_pre = take(NL * OSH_PREINT_FLOATS * 4), o_li = take(NL * 81 * 8), o_lg = take(NL * 9 * 8), o_la = take(NL * 9 * 8),
-               o_bar = take(nw * sizeof(unsigned)), o_abort = take(sizeof(int)), o_col = take(NL * 4);
+               o_bar = take(nw * sizeof(unsigned)), o_abort = take(sizeof(int)), o_col = take(NL * 4), o_lb = take(NL * 4);
   char* hs = static_cast<char*>(B.h_in.reserve(in_bytes));
   if (!hs) { set_error("osh_liba_solve: pinned staging allocation of %zu bytes failed", in_bytes); return OSH_ERR_DEVICE; }
   LibaDesc* h_descp = reinterpret_cast<LibaDesc*>(hs + o_desc);
@@ -1075,7 +1091,7 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
   double* h_info = reinterpret_cast<double*>(hs + o_info);
   int* h_ep = reinterpret_cast<int*>(hs + o_ep); int* h_el = reinterpret_cast<int*>(hs + o_el); int* h_eo = reinterpret_cast<int*>(hs + o_eo);
   int* h_lmo = reinterpret_cast<int*>(hs + o_lmo); int* h_po = reinterpret_cast<int*>(hs + o_po); int* h_pel = reinterpret_cast<int*>(hs + o_pel);
-  int* h_lmpe = reinterpret_cast<int*>(hs + o_lmpe); int* h_lp = reinterpret_cast<int*>(hs + o_lp); int* h_lc = reinterpret_cast<int*>(hs + o_lc);
+  int* h_lmpe = reinterpret_cast<int*>(hs + o_lmpe); int* h_lp = reinterpret_cast<int*>(hs + o_lp); int* h_lc = reinterpret_cast<int*>(hs + o_lc); int* h_lb = reinterpret_cast<int*>(hs + o_lb);
   unsigned char* h_kind = reinterpret_cast<unsigned char*>(hs + o_kind); unsigned char* h_rob = reinterpret_cast<unsigned char*>(hs + o_rob);
   float* h_pre = reinterpret_cast<float*>(hs + o_pre);
   int* h_col = reinterpret_cast<int*>(hs + o_col);
@@ -1145,6 +1161,7 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
     for (int l = 0; l < d.NL; ++l) {
       const size_t g = (size_t)d.link_off + l;
       h_lp[g] = p.link_prev[l]; h_lc[g] = p.link_cur[l]; h_rob[g] = p.link_robust[l];
+      h_lb[g] = p.link_bias ? p.link_bias[l] : p.link_prev[l];
       std::memcpy(&h_pre[g * OSH_PREINT_FLOATS], p.link_preint + (size_t)l * OSH_PREINT_FLOATS, OSH_PREINT_FLOATS * 4);
       std::memcpy(&h_li[g * 81], p.link_info + (size_t)l * 81, 81 * 8);
       std::memcpy(&h_lg[g * 9], p.link_info_g + (size_t)l * 9, 72); std::memcpy(&h_la[g * 9], p.link_info_a + (size_t)l * 9, 72);
@@ -1152,9 +1169,11 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
       int col = 0;
       for (bool clash = true; clash; ) {
         clash = false;
-        for (int l2 = 0; l2 < l && !clash; ++l2)
-          clash = h_col[(size_t)d.link_off + l2] == col && (p.link_prev[l2] == p.link_prev[l] || p.link_prev[l2] == p.link_cur[l] ||
-                                                           p.link_cur[l2] == p.link_prev[l] || p.link_cur[l2] == p.link_cur[l]);
+        for (int l2 = 0; l2 < l && !clash; ++l2) {
+          if (h_col[(size_t)d.link_off + l2] != col) continue;
+          const int k1[3] = {p.link_prev[l], p.link_cur[l], h_lb[g]}, k2[3] = {p.link_prev[l2], p.link_cur[l2], h_lb[(size_t)d.link_off + l2]};
+          for (int x = 0; x < 3; ++x) for (int y = 0; y < 3; ++y) clash = clash || k1[x] == k2[y];
+        }
         if (clash) ++col;
       }
       h_col[g] = col;
@@ -1193,7 +1212,7 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
   v.e_info = reinterpret_cast<const double*>(din + o_info); v.e_orig = reinterpret_cast<const int*>(din + o_eo);
   v.lm_off = reinterpret_cast<const int*>(din + o_lmo); v.pel_off = reinterpret_cast<const int*>(din + o_po);
   v.pel_edge = reinterpret_cast<const int*>(din + o_pel); v.lm_pose_edge = reinterpret_cast<const int*>(din + o_lmpe);
-  v.link_prev = reinterpret_cast<const int*>(din + o_lp); v.link_cur = reinterpret_cast<const int*>(din + o_lc);
+  v.link_prev = reinterpret_cast<const int*>(din + o_lp); v.link_cur = reinterpret_cast<const int*>(din + o_lc); v.link_bias = reinterpret_cast<const int*>(din + o_lb);
   v.link_preint = reinterpret_cast<const float*>(din + o_pre); v.link_info = reinterpret_cast<const double*>(din + o_li);
   v.link_info_g = reinterpret_cast<const double*>(din + o_lg); v.link_info_a = reinterpret_cast<const double*>(din + o_la);
   v.link_robust = reinterpret_cast<const unsigned char*>(din + o_rob);

@@ -496,7 +496,8 @@ class HostInertialGraph:
             link_info=arr(p.link_info, NL * 81).reshape(NL, 81), link_info_g=arr(p.link_info_g, NL * 9).reshape(NL, 9),
             link_info_a=arr(p.link_info_a, NL * 9).reshape(NL, 9), link_robust=arr(p.link_robust, NL, np.uint8),
             lambda_init=lambda_init, max_iterations=max_iterations,
-            kb8=arr(p.kb8, 4) if p.kb8 else None, cam2=arr(p.cam2, 8) if p.cam2 else None, trl=arr(p.trl, 12) if p.trl else None).normalise()
+            kb8=arr(p.kb8, 4) if p.kb8 else None, cam2=arr(p.cam2, 8) if p.cam2 else None, trl=arr(p.trl, 12) if p.trl else None,
+            link_bias=arr(p.link_bias, NL, np.int32) if p.link_bias else None).normalise()
         return w
 
     def run(self, large=False, rec_init=False):

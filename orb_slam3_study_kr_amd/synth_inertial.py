@@ -148,6 +148,7 @@ class LibaWindow:
     kb8: np.ndarray | None = None   # [4] KannalaBrandt8 k1..k4 (monocular fisheye window)
     cam2: np.ndarray | None = None  # [8] right camera of a fisheye stereo rig: fx fy cx cy k1..k4 (edges of kind OSH_EDGE_RIGHT)
     trl: np.ndarray | None = None   # [12] rows of [Rrl | trl] (float32 values)
+    link_bias: np.ndarray | None = None   # [n_links] keyframe that stores the bias vertices of each inertial edge (None: link_prev)
     gt: dict | None = None
 
     _F64 = ("pose_Rcw", "pose_tcw", "pose_Rwb", "pose_twb", "Rcb", "tcb", "tbc", "cam", "vel", "bias_g", "bias_a", "points",
@@ -196,6 +197,9 @@ class LibaWindow:
             self.cam2 = np.ascontiguousarray(self.cam2, dtype=np.float64)
             self.trl = np.ascontiguousarray(self.trl, dtype=np.float64)
         p.cam2, p.trl = capi.ptr(self.cam2, capi.c_double_p), capi.ptr(self.trl, capi.c_double_p)
+        if self.link_bias is not None:
+            self.link_bias = np.ascontiguousarray(self.link_bias, dtype=np.int32)
+        p.link_bias = capi.ptr(self.link_bias, capi.c_int32_p)
         return p
 
 
@@ -235,6 +239,35 @@ def _trajectory(t):
     v = np.array([0.9 + 0.13 * np.cos(1.3 * t), 0.28 * np.cos(0.8 * t), 0.204 * np.cos(1.7 * t)])
     a = np.array([-0.169 * np.sin(1.3 * t), -0.224 * np.sin(0.8 * t), -0.3468 * np.sin(1.7 * t)])
     return R, p, v, a
+
+
+def with_shared_bias(w: "LibaWindow", prior_g: float = 1e2, prior_a: float = 1e6) -> "LibaWindow":
+    """The window in the form Optimizer::FullInertialBA takes with bInit (src/Optimizer.cc:452-462, 514-518, 551, 581-601): every
+    EdgeInertial hangs on ONE (gyro, acc) bias pair -- stored with the oldest keyframe, which no link ends at --, there are no random-walk edges, and
+    EdgePriorGyro / EdgePriorAcc (prior value 0, information prior_g I / prior_a I) hold that pair.  The priors are written as the
+    random-walk edges of one extra link with zero inertial information, from the fixed predecessor (made to hold the prior value, and
+    cut loose from the window) to the keyframe that stores the pair."""
+    import dataclasses
+    assert w.n_fixed_imu == 1
+    N = w.n_opt
+    keep = w.link_prev != N
+    nl = int(keep.sum())
+    rec = np.zeros(w.link_preint.shape[1], dtype=np.float32)
+    rec[1:10] = np.eye(3, dtype=np.float32).ravel()              # dR = I, dT = 0: a finite residual that the zero information drops
+    vel, bg, ba = (np.array(x, dtype=np.float64).reshape(-1, 3).copy() for x in (w.vel, w.bias_g, w.bias_a))
+    vel[N] = 0.0; bg[N] = 0.0; ba[N] = 0.0                        # the prior value (bprior = 0, :586)
+    cat = lambda a, b: np.concatenate([np.asarray(a)[keep], np.asarray(b)[None]], axis=0)
+    out = dataclasses.replace(
+        w, vel=vel, bias_g=bg, bias_a=ba,
+        link_prev=cat(w.link_prev, np.int32(N)), link_cur=cat(w.link_cur, np.int32(0)), link_preint=cat(w.link_preint, rec),
+        link_info=cat(np.asarray(w.link_info).reshape(len(keep), -1), np.zeros(81)),
+        link_info_g=cat(np.zeros((len(keep), 9)), prior_g * np.eye(3).ravel()), link_info_a=cat(np.zeros((len(keep), 9)), prior_a * np.eye(3).ravel()),
+        link_robust=cat(np.ones(len(keep), dtype=np.uint8), np.uint8(0)),
+        link_bias=np.concatenate([np.full(nl, 0), [N]]).astype(np.int32))
+    if out.gt is not None and "link_cov" in out.gt:
+        out.gt = dict(out.gt)
+        out.gt["link_cov"] = np.concatenate([np.asarray(w.gt["link_cov"])[keep], np.zeros((1, 15, 15))], axis=0)
+    return out.normalise()
 
 
 def make_inertial_window(seed: int = 11, n_opt: int = 10, n_fixed: int = 20, n_points: int = 2000, kf_dt: float = 0.25,

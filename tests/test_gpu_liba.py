@@ -175,6 +175,28 @@ def test_map_sized_windows_and_keyframes_without_links(solver, ob, n_opt, lam, i
         np.testing.assert_array_equal(got.bias_g[k], w.bias_g[k])
 
 
+@pytest.mark.parametrize("n_opt", [4, 12, 30])
+def test_one_bias_pair_for_every_inertial_edge_with_priors(solver, ob, n_opt):
+    """FullInertialBA with bInit (src/Optimizer.cc:452-462,514-518,581-601) as a flat problem: link_bias names one keyframe for all links
+    (every link then shares a keyframe with every other: one colour each), no random walks, the two priors as one link without
+    inertial information.  The bias slots of the other keyframes stay where they are."""
+    import dataclasses
+    w = si.with_shared_bias(si.make_inertial_window(300 + n_opt, n_opt=n_opt, n_fixed=6, n_points=60 * n_opt + 200))
+    w = dataclasses.replace(w, lambda_init=1e-5, max_iterations=3)   # at the minimum the gain ratio, and lambda with it, is rounding noise
+    got, ref = solver.solve_inertial([w])[0], ob.liba_solve(w)
+    _check(got, ref, w, lam_tol=1e-3, pts_tol=2e-4, edge_tol=1e-3)
+    np.testing.assert_array_equal(got.bias_g[1:], np.asarray(w.bias_g).reshape(-1, 3)[1:n_opt])
+    np.testing.assert_array_equal(got.bias_a[1:], np.asarray(w.bias_a).reshape(-1, 3)[1:n_opt])
+    assert np.linalg.norm(got.bias_a[0]) < 0.6 * np.linalg.norm(np.asarray(w.bias_a).reshape(-1, 3)[0])   # information 1e6 pulls it towards the prior
+    bad = dataclasses.replace(w, link_info_g=np.tile(np.eye(3).ravel(), (w.n_links, 1)))
+    with pytest.raises(RuntimeError, match="no random-walk edges"):
+        solver.solve_inertial([bad])
+    lb = w.link_bias.copy()
+    lb[0] = w.link_cur[0]
+    with pytest.raises(RuntimeError, match="later keyframe"):
+        solver.solve_inertial([dataclasses.replace(w, link_bias=lb)])
+
+
 def test_many_window_shapes_through_the_block_groups(solver, ob, monkeypatch):
     """Windows of many shapes (3..12 keyframes, 60..1300 landmarks, with and without fixed observers), one at a time (a group of 32
     blocks each) and as one batch (groups of 16): the barriers, the lane teams and the chunked sums see every remainder case."""

@@ -94,6 +94,32 @@ def test_linearisation_matches_numeric_dense_system(tiny):
     assert np.abs(lin["b"] - bn).max() < 2e-4 * np.abs(bn).max()
 
 
+def test_shared_bias_pair_and_its_priors_vs_numeric_dense_system():
+    """FullInertialBA with bInit (src/Optimizer.cc:452-462,514-518,581-601): every EdgeInertial on one (gyro, acc) bias pair, no random
+    walks, EdgePriorGyro / EdgePriorAcc written as the random-walk edges of a link without inertial information from a fixed keyframe that
+    holds the prior value (osh_liba_problem.link_bias).  The C restatement against the numpy model's cost and numeric Jacobians."""
+    from orb_slam3_study_kr_amd import synth_inertial as si
+    w = si.with_shared_bias(si.make_inertial_window(5, n_opt=3, n_fixed=2, n_points=25, outlier_frac=0.0), prior_g=1e2, prior_a=1e6)
+    lin, st = ob.liba_linearize(w), ln.State(w)
+    np.testing.assert_allclose(lin["chi2"], ln.robust_chi2(st), rtol=1e-6)
+    prior = float(1e2 * st.bg[0] @ st.bg[0] + 1e6 * st.ba[0] @ st.ba[0])          # (bprior - b)^T info (bprior - b), bprior = 0
+    plain = si.make_inertial_window(5, n_opt=3, n_fixed=2, n_points=25, outlier_frac=0.0)
+    assert prior > 100.0 and lin["chi2"] > prior
+    Hn, bn = ln.numeric_dense_system(st)
+    n = 15 * w.n_opt
+    assert np.abs(lin["H"] - Hn[:n, :n]).max() < 2e-4 * np.abs(Hn).max()
+    assert np.abs(lin["b"][:n] - bn[:n]).max() < 2e-4 * np.abs(bn).max()
+    o = 6 * w.n_opt + 9 * 0 + 3                                                   # the shared pair sits with the oldest keyframe
+    for k in (1, 2):                                                              # the other keyframes' bias slots take part in nothing
+        oo = 6 * w.n_opt + 9 * k + 3
+        assert not lin["H"][oo:oo + 6].any() and not lin["b"][oo:oo + 6].any()
+    assert np.abs(lin["H"][o:o + 6, :6 * w.n_opt]).max() > 0                      # the pair couples with the poses of every link
+    r = ob.liba_solve(w)
+    assert r.chi2_final < 0.05 * r.chi2_initial and np.abs(r.bias_a[0]).max() < 1e-4      # information 1e6 pulls the acc bias to the prior
+    np.testing.assert_array_equal(r.bias_g[1:], np.asarray(w.bias_g).reshape(-1, 3)[1:3])
+    assert plain.n_links == w.n_links
+
+
 def test_full_inertial_lm_converges_and_is_consistent():
     w = si.make_inertial_window(11)
     r = ob.liba_solve(w)
