@@ -70,9 +70,9 @@ int osh_host_pack_liba(osh_host_graph* g, int32_t kf_index, int32_t b_large, int
 int osh_host_run_liba(osh_host_graph* g, int32_t kf_index, int32_t b_large, int32_t b_rec_init);
 /* Optimizer::FullInertialBA(&map, its, bFixLocal, nLoopId, NULL, bInit) (src/Optimizer.cc:393-814): the flat problem it solves
  * (pack; *n_idle = keyframes no edge touches) and the call itself.  -3: a case the device path does not take (message on stderr). */
-int osh_host_pack_full_inertial(osh_host_graph* g, int32_t its, int32_t fix_local, int32_t b_init, struct osh_liba_problem* out,
-                                int64_t* pose_kf_id, int64_t* point_mp_id, int32_t* n_idle);
-int osh_host_run_full_inertial(osh_host_graph* g, int32_t its, int32_t fix_local, int64_t loop_id, int32_t b_init);
+int osh_host_pack_full_inertial(osh_host_graph* g, int32_t its, int32_t fix_local, int32_t b_init, float prior_g, float prior_a,
+                                struct osh_liba_problem* out, int64_t* pose_kf_id, int64_t* point_mp_id, int32_t* n_idle);
+int osh_host_run_full_inertial(osh_host_graph* g, int32_t its, int32_t fix_local, int64_t loop_id, int32_t b_init, float prior_g, float prior_a);
 int64_t osh_host_get_kf_inertial_gba(osh_host_graph* g, int32_t i, float vel[3], float bias6[6]);   /* mVwbGBA, mBiasGBA; returns mnBAGlobalForKF */
 /* Optimizer::MergeInertialBA(curr, merge, NULL, &map, corrPoses) (src/Optimizer.cc:3956-4498).  n_sets = {temporal, covisible}
  * keyframe counts with their ids in the reference's order; run returns corrPoses.size() and copies {id; qx qy qz qw tx ty tz s}. */

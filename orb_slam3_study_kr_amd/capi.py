@@ -271,8 +271,8 @@ _HOST_SIGNATURES = {
     "osh_host_graph_set_inertial": (C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_int32_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p]),
     "osh_host_pack_liba": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(LibaProblem), c_int64_p, c_int64_p]),
     "osh_host_run_liba": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
-    "osh_host_pack_full_inertial": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(LibaProblem), c_int64_p, c_int64_p, c_int32_p]),
-    "osh_host_run_full_inertial": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32]),
+    "osh_host_pack_full_inertial": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.POINTER(LibaProblem), c_int64_p, c_int64_p, c_int32_p]),
+    "osh_host_run_full_inertial": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_float]),
     "osh_host_get_kf_inertial_gba": (C.c_int64, [C.c_void_p, C.c_int32, c_float_p, c_float_p]),
     "osh_host_pack_merge_inertial": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(LibaProblem), c_int64_p, c_int64_p, c_int32_p, c_int64_p, c_int64_p]),
     "osh_host_run_merge_inertial": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_int64_p, c_double_p]),

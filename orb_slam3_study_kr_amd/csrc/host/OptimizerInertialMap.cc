@@ -152,10 +152,11 @@ struct LibaOutput {
 // ------------------------------------------------------------------------------------------------
 // FullInertialBA: vertices :417-470, inertial links :480-579, points and visual edges :604-727
 // ------------------------------------------------------------------------------------------------
-bool PackFullInertialBA(Map* pMap, int its, bool bFixLocal, bool bInit, LibaPack& pk, std::vector<KeyFrame*>& vpIdle, std::vector<MapPoint*>& vpAllMPs) {
+bool PackFullInertialBA(Map* pMap, int its, bool bFixLocal, bool bInit, float priorG, float priorA, LibaPack& pk, std::vector<KeyFrame*>& vpIdle,
+                        std::vector<MapPoint*>& vpAllMPs, int* sharedBiasSlot) {
   pk = LibaPack();
   vpIdle.clear();
-  if (bInit) { pk.unsupported = "bInit (one gyro / accelerometer bias shared by every keyframe, with priors) is not on the device path"; return false; }
+  if (sharedBiasSlot) *sharedBiasSlot = -1;
   if (bFixLocal) { pk.unsupported = "bFixLocal (keyframes of the local window fixed) is not on the device path; the reference never passes it"; return false; }
   const long unsigned int maxKFid = pMap->GetMaxKFid();
   const std::vector<KeyFrame*> vpKFs = pMap->GetAllKeyFrames();
@@ -189,6 +190,39 @@ bool PackFullInertialBA(Map* pMap, int its, bool bFixLocal, bool bInit, LibaPack
     if (!pKFi->mpImuPreintegrated || !sKF.count(pKFi->mPrevKF)) continue;
     pKFi->mpImuPreintegrated->SetNewBias(pKFi->mPrevKF->GetImuBias());   // :504
     PackLink(pk, pKFi, poseIndex.at(pKFi->mPrevKF), poseIndex.at(pKFi));
+  }
+  if (bInit) {
+    // ONE gyro and ONE accelerometer bias vertex for the whole map, created from the last keyframe of the map's list (:452-462); every
+    // EdgeInertial hangs on them (:514-518), there are no random-walk edges (:551), EdgePriorAcc / EdgePriorGyro with prior value 0 hold
+    // them (:581-601).  The pair lives in the bias slot of a keyframe no link ends at (osh_liba_problem.link_bias); the priors are the
+    // random-walk edges of a link without inertial information from a fixed, virtual keyframe whose biases are the prior value.
+    KeyFrame* pIncKF = nullptr;
+    for (KeyFrame* k : vpKFs) if (k->mnId <= maxKFid) pIncKF = k;
+    int slot = -1;
+    for (int i = 0; i < pk.n_opt && slot < 0; ++i)
+      if (std::find(pk.link_cur.begin(), pk.link_cur.end(), i) == pk.link_cur.end()) slot = i;
+    if (slot < 0) { pk.unsupported = "bInit: every keyframe ends an inertial link (a closed chain of mPrevKF)"; return true; }
+    const Eigen::Vector3f bg = pIncKF->GetGyroBias(), ba = pIncKF->GetAccBias();
+    for (int a = 0; a < 3; ++a) { pk.bias_g[(size_t)slot * 3 + a] = (double)bg(a); pk.bias_a[(size_t)slot * 3 + a] = (double)ba(a); }
+    const size_t NLr = pk.link_prev.size();
+    std::fill(pk.link_info_g.begin(), pk.link_info_g.end(), 0.0);
+    std::fill(pk.link_info_a.begin(), pk.link_info_a.end(), 0.0);
+    pk.link_bias.assign(NLr, slot);
+    const int N = pk.n_opt;
+    pk.n_fixed_imu = 1;   // the virtual keyframe: the slot keyframe's pose (any would do), zero velocity, biases = bprior = 0 (:586)
+    for (int a = 0; a < 9; ++a) { pk.pose_Rcw.push_back(pk.pose_Rcw[(size_t)slot * 9 + a]); pk.pose_Rwb.push_back(pk.pose_Rwb[(size_t)slot * 9 + a]); }
+    for (int a = 0; a < 3; ++a) { pk.pose_tcw.push_back(pk.pose_tcw[(size_t)slot * 3 + a]); pk.pose_twb.push_back(pk.pose_twb[(size_t)slot * 3 + a]); }
+    for (int a = 0; a < 3; ++a) { pk.vel.push_back(0.0); pk.bias_g.push_back(0.0); pk.bias_a.push_back(0.0); }
+    pk.link_prev.push_back(N); pk.link_cur.push_back(slot); pk.link_bias.push_back(N);
+    float rec[OSH_PREINT_FLOATS];
+    std::memset(rec, 0, sizeof(rec));
+    rec[1] = rec[5] = rec[9] = 1.f;   // dR = I, dT = 0: a finite residual, dropped by the zero information
+    pk.link_preint.insert(pk.link_preint.end(), rec, rec + OSH_PREINT_FLOATS);
+    pk.link_info.insert(pk.link_info.end(), 81, 0.0);
+    pk.link_robust.push_back(0);
+    const double infoPriorG = priorG, infoPriorA = priorA;   // :589,595
+    for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) { pk.link_info_g.push_back(a == c ? infoPriorG : 0.0); pk.link_info_a.push_back(a == c ? infoPriorA : 0.0); }
+    if (sharedBiasSlot) *sharedBiasSlot = slot;
   }
   // points in map order; vertex id = mnId + 5 maxKFid + 1, so the Hessian order is ascending mnId
   std::vector<MapPoint*> vMP(vpAllMPs);
@@ -231,11 +265,12 @@ bool PackFullInertialBA(Map* pMap, int its, bool bFixLocal, bool bInit, LibaPack
 
 void Optimizer::FullInertialBA(Map* pMap, int its, const bool bFixLocal, const unsigned long nLoopId, bool* pbStopFlag, bool bInit, float priorG,
                                float priorA, Eigen::VectorXd* vSingVal, bool* bHess) {
-  (void)priorG; (void)priorA; (void)vSingVal; (void)bHess;
+  (void)vSingVal; (void)bHess;
   LibaPack pk;
   std::vector<KeyFrame*> vpIdle;
   std::vector<MapPoint*> vpAllMPs;
-  const bool packed = PackFullInertialBA(pMap, its, bFixLocal, bInit, pk, vpIdle, vpAllMPs);
+  int slot = -1;
+  const bool packed = PackFullInertialBA(pMap, its, bFixLocal, bInit, priorG, priorA, pk, vpIdle, vpAllMPs, &slot);
   if (!packed || pk.unsupported) {
     std::fprintf(stderr, "FullInertialBA: %s; map left untouched\n", pk.unsupported ? pk.unsupported : "nothing to optimise");
     return;
@@ -269,10 +304,11 @@ void Optimizer::FullInertialBA(Map* pMap, int its, const bool bFixLocal, const u
     KeyFrame* pKFi = pk.vPoseKFs[i];
     const bool linked = std::find(pk.link_prev.begin(), pk.link_prev.end(), i) != pk.link_prev.end() || std::find(pk.link_cur.begin(), pk.link_cur.end(), i) != pk.link_cur.end();
     // velocity / bias vertices without an edge keep their float values (the device's increment there is exactly zero as well)
-    write_kf(pKFi, out.pose(i), linked ? out.velocity(i) : pKFi->GetVelocity(), linked ? out.bias(i) : pKFi->GetImuBias());
+    // with bInit every keyframe is handed the one optimised bias pair (:779-789)
+    write_kf(pKFi, out.pose(i), linked ? out.velocity(i) : pKFi->GetVelocity(), slot >= 0 ? out.bias(slot) : linked ? out.bias(i) : pKFi->GetImuBias());
   }
   for (KeyFrame* pKFi : vpIdle)   // vertices no edge touches: the estimate the vertex was created with
-    write_kf(pKFi, Sophus::SE3f(pKFi->GetRotation(), pKFi->GetTranslation()), pKFi->GetVelocity(), pKFi->GetImuBias());
+    write_kf(pKFi, Sophus::SE3f(pKFi->GetRotation(), pKFi->GetTranslation()), pKFi->GetVelocity(), slot >= 0 ? out.bias(slot) : pKFi->GetImuBias());
   for (int j = 0; j < L; ++j) {
     MapPoint* pMP = pk.vPointMPs[j];
     if (nLoopId == 0) { pMP->SetWorldPos(out.point(j)); pMP->UpdateNormalAndDepth(); }

@@ -332,17 +332,18 @@ extern "C" int osh_host_run_liba(osh_host_graph* g, int32_t kf_index, int32_t b_
 static void export_pack(osh_host_graph* g, osh_liba_problem* out, int64_t* pose_kf_id, int64_t* point_mp_id) {
   g->liba.fill(*out);
   out->max_iterations = g->liba.opt_it;
+  if (pose_kf_id) for (int i = 0; i < out->n_opt + out->n_fixed_imu + out->n_fixed; ++i) pose_kf_id[i] = -1;   // -1: a virtual keyframe (bInit)
   if (pose_kf_id) for (size_t i = 0; i < g->liba.vPoseKFs.size(); ++i) pose_kf_id[i] = (int64_t)g->liba.vPoseKFs[i]->mnId;
   if (point_mp_id) for (size_t j = 0; j < g->liba.vPointMPs.size(); ++j) point_mp_id[j] = (int64_t)g->liba.vPointMPs[j]->mnId;
 }
 
 // the problem Optimizer::FullInertialBA(&map, its, bFixLocal, ., ., bInit) solves; *n_idle = keyframes no edge touches
-extern "C" int osh_host_pack_full_inertial(osh_host_graph* g, int32_t its, int32_t fix_local, int32_t b_init, osh_liba_problem* out,
-                                           int64_t* pose_kf_id, int64_t* point_mp_id, int32_t* n_idle) {
+extern "C" int osh_host_pack_full_inertial(osh_host_graph* g, int32_t its, int32_t fix_local, int32_t b_init, float prior_g, float prior_a,
+                                           osh_liba_problem* out, int64_t* pose_kf_id, int64_t* point_mp_id, int32_t* n_idle) {
   if (!g || !out) return -1;
   std::vector<KeyFrame*> idle;
   std::vector<MapPoint*> all;
-  const bool ok = PackFullInertialBA(&g->map, its, fix_local != 0, b_init != 0, g->liba, idle, all);
+  const bool ok = PackFullInertialBA(&g->map, its, fix_local != 0, b_init != 0, prior_g, prior_a, g->liba, idle, all, nullptr);
   if (g->liba.unsupported) return -3;
   if (!ok) return 1;
   export_pack(g, out, pose_kf_id, point_mp_id);
@@ -350,9 +351,9 @@ extern "C" int osh_host_pack_full_inertial(osh_host_graph* g, int32_t its, int32
   return 0;
 }
 
-extern "C" int osh_host_run_full_inertial(osh_host_graph* g, int32_t its, int32_t fix_local, int64_t loop_id, int32_t b_init) {
+extern "C" int osh_host_run_full_inertial(osh_host_graph* g, int32_t its, int32_t fix_local, int64_t loop_id, int32_t b_init, float prior_g, float prior_a) {
   if (!g) return -1;
-  Optimizer::FullInertialBA(&g->map, its, fix_local != 0, (unsigned long)loop_id, nullptr, b_init != 0);
+  Optimizer::FullInertialBA(&g->map, its, fix_local != 0, (unsigned long)loop_id, nullptr, b_init != 0, prior_g, prior_a);
   return 0;
 }
 

@@ -177,7 +177,9 @@ bool PackPoseInertial(Frame* pFrame, bool bRecInit, int mode, PoseiPack& pk);
 bool PackLocalInertialBA(KeyFrame* pKF, Map* pMap, bool bLarge, bool bRecInit, LibaPack& pk);
 // Optimizer::FullInertialBA / MergeInertialBA as the same flat problem (OptimizerInertialMap.cc).  vpIdle: keyframes no edge touches;
 // vpCovKFs: the merge's covisible keyframes in the reference's order
-bool PackFullInertialBA(Map* pMap, int its, bool bFixLocal, bool bInit, LibaPack& pk, std::vector<KeyFrame*>& vpIdle, std::vector<MapPoint*>& vpAllMPs);
+// *sharedBiasSlot: with bInit the keyframe (pose index) whose bias slot holds the one optimised bias pair, else -1
+bool PackFullInertialBA(Map* pMap, int its, bool bFixLocal, bool bInit, float priorG, float priorA, LibaPack& pk, std::vector<KeyFrame*>& vpIdle,
+                        std::vector<MapPoint*>& vpAllMPs, int* sharedBiasSlot);
 bool PackMergeInertialBA(KeyFrame* pCurrKF, KeyFrame* pMergeKF, LibaPack& pk, std::vector<KeyFrame*>& vpCovKFs);
 void InertialInformation(const Eigen::Matrix<float, 15, 15>& C, double* info81);
 osh_lba_ctx* HostSolverContext();   // one solver context per calling thread (Optimizer.cc)

@@ -503,20 +503,20 @@ class HostInertialGraph:
     def run(self, large=False, rec_init=False):
         return self.lib.osh_host_run_liba(self.g, self.cur, int(large), int(rec_init))
 
-    def packed_full(self, its, fix_local=False, init=False):
+    def packed_full(self, its, fix_local=False, init=False, prior_g=1e2, prior_a=1e6):
         """The problem Optimizer::FullInertialBA(map, its, bFixLocal, ., ., bInit) solves, as (LibaWindow, keyframe ids, map point ids,
         number of keyframes no edge touches); the host layer's return code instead when it declines the case."""
         p = capi.LibaProblem()
-        kid, mid = np.zeros(len(self.kf_id), dtype=np.int64), np.zeros(self.w.n_points, dtype=np.int64)
+        kid, mid = np.zeros(len(self.kf_id) + 1, dtype=np.int64), np.zeros(self.w.n_points, dtype=np.int64)
         idle = np.zeros(1, dtype=np.int32)
-        rc = self.lib.osh_host_pack_full_inertial(self.g, int(its), int(fix_local), int(init), C.byref(p), capi.ptr(kid, capi.c_int64_p),
+        rc = self.lib.osh_host_pack_full_inertial(self.g, int(its), int(fix_local), int(init), prior_g, prior_a, C.byref(p), capi.ptr(kid, capi.c_int64_p),
                                                   capi.ptr(mid, capi.c_int64_p), capi.ptr(idle, capi.c_int32_p))
         if rc != 0:
             return rc
         return self._window_of(p, 1e-5, int(its)), kid[:p.n_opt + p.n_fixed_imu + p.n_fixed], mid[:p.n_points], int(idle[0])
 
-    def run_full(self, its, loop_id=0, fix_local=False, init=False):
-        return self.lib.osh_host_run_full_inertial(self.g, int(its), int(fix_local), int(loop_id), int(init))
+    def run_full(self, its, loop_id=0, fix_local=False, init=False, prior_g=1e2, prior_a=1e6):
+        return self.lib.osh_host_run_full_inertial(self.g, int(its), int(fix_local), int(loop_id), int(init), prior_g, prior_a)
 
     def packed_merge(self, curr, merge):
         """The problem Optimizer::MergeInertialBA(kf[curr], kf[merge], ...) solves + (temporal keyframe ids, covisible keyframe ids) in

@@ -36,7 +36,22 @@ def test_full_inertial_ba_packs_every_keyframe_of_the_map(ob):
         np.testing.assert_allclose(pw.link_info[l_old].ravel(), w.link_info[int(np.nonzero(w.link_cur == 0)[0][0])].ravel() * 100.0, rtol=1e-6, atol=1e-3)
         ref = ob.liba_solve(pw)
         assert ref.iterations == 7 and ref.chi2_final < 0.2 * ref.chi2_initial
-        assert g.packed_full(7, init=True) == -3 and g.packed_full(7, fix_local=True) == -3
+        assert g.packed_full(7, fix_local=True) == -3
+        # bInit (:452-462,514-518,551,581-601): one bias pair in the slot of a keyframe no link ends at, started from the biases of the
+        # last keyframe of the map's list; no random walks; the priors as the random-walk pair of a link from a virtual fixed keyframe
+        pi, kidi, _, _ = g.packed_full(7, init=True, prior_g=3.0, prior_a=5.0)
+        slot = int(pi.link_bias[0])
+        assert (pi.n_opt, pi.n_fixed_imu, pi.n_links) == (19, 1, 15) and kidi[19] == -1
+        assert (pi.link_bias[:-1] == slot).all() and slot not in pi.link_cur[:-1].tolist() and pi.link_bias[-1] == 19
+        assert not pi.link_info_g[:-1].any() and not pi.link_info_a[:-1].any() and not pi.link_info[-1].any() and pi.link_robust[:-1].all()
+        np.testing.assert_array_equal(pi.link_info_g[-1].reshape(3, 3), 3.0 * np.eye(3))
+        np.testing.assert_array_equal(pi.link_info_a[-1].reshape(3, 3), 5.0 * np.eye(3))
+        np.testing.assert_array_equal(pi.link_info[:-1], pw.link_info)
+        last = len(g.kf_id) - 1                                        # Map::GetAllKeyFrames order of the test double = creation order
+        np.testing.assert_array_equal(pi.bias_a.reshape(-1, 3)[slot], g.kf_bias(last)[:3].astype(np.float64))
+        assert not pi.bias_a.reshape(-1, 3)[19].any() and not pi.vel.reshape(-1, 3)[19].any()
+        ri = ob.liba_solve(pi)
+        assert ri.chi2_final < 0.2 * ri.chi2_initial
 
 
 def test_merge_inertial_ba_selects_both_chains_and_the_covisible_keyframes(ob):
