@@ -30,12 +30,14 @@ namespace osh {
 
 constexpr int kLT = 256;      // threads of a block: one wavefront per SIMD, so a phase may use all 512 registers (with 512 threads the
                               // per-edge code spilled: 1.2 KB of scratch per lane)
-constexpr int kLNB = 24;      // LDL^T panel width
+constexpr int kLNB = 24;      // LDL^T panel width (12 or 6 for windows whose 24-wide panels do not fit LDS: k_liba<NB>)
 constexpr int kLG = 32;       // blocks per window at most (one XCD's worth of a group)
 constexpr int kPoseChunks = 8;   // a pose row's edges are summed in at most this many chunks
 constexpr int kLinkQ = 832;   // per link: J^T W J (24x24), -J^T W r (24), then J (9x24), -W r (9), rho'
-constexpr int kLibaMaxKeyframes = 51;   // (liba_scratch_doubles(ldlt_row_stride(15 N)) + kLT/64 + 8) doubles must fit 160 KB of LDS
-__host__ __device__ constexpr size_t liba_scratch_doubles(int W) { return ldlt_lds_doubles(kLNB, W, kLT) > 512 ? ldlt_lds_doubles(kLNB, W, kLT) : 512; }
+// (liba_scratch_doubles(NB, ldlt_row_stride(15 N)) + kLT/64 + 8) doubles must fit 160 KB of LDS: 51 keyframes with 24-wide panels
+// (every LocalInertialBA / MergeInertialBA window), 102 with 12-wide, 192 with 6-wide ones (FullInertialBA over a map)
+constexpr int kLibaMaxKeyframes = 192;
+__host__ __device__ constexpr size_t liba_scratch_doubles(int NB, int W) { return ldlt_lds_doubles(NB, W, kLT) > 512 ? ldlt_lds_doubles(NB, W, kLT) : 512; }
 struct LibaOut {
   double chi2_initial, chi2_final;
   int iterations, trials, n_trace, sel;
@@ -680,10 +682,11 @@ __device__ __noinline__ void liba_schur(const LibaCtx& c, double lambda) {
 
 // ---- LDL^T + solve of the reduced system by block 0 of the group (inlined: its panels live in LDS, and only inside the kernel does the
 // compiler know that pointer for what it is)
+template <int NB>
 __device__ __forceinline__ void liba_solve(const LibaCtx& c, double* sh_lds) {
   OSH_LIBA_LOCALS
   double *xs, *shw2;
-  const bool okb = ldlt_solve_block<kLNB, kLT>(S, bs, n, c.W, sh_lds, xs, shw2);
+  const bool okb = ldlt_solve_block<NB, kLT>(S, bs, n, c.W, sh_lds, xs, shw2);
   for (int k = tid; k < n; k += kLT) xg[k] = xs[k];
   if (tid == 0) ctrl[1] = okb ? 1.0 : 0.0;
 }
@@ -810,6 +813,7 @@ __device__ __noinline__ void liba_outputs(const LibaCtx& c, int sel, int eval_se
   }
 }
 
+template <int NB>
 __global__ __launch_bounds__(kLT) void k_liba(LibaView v, int W, int G) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   // consecutive workgroups go to the 8 XCDs in turn: the G blocks of a window are 8 apart, so they share one XCD and its L2
@@ -825,7 +829,7 @@ __global__ __launch_bounds__(kLT) void k_liba(LibaView v, int W, int G) {
   const int m = g.m, GT = G * kLT, gt = m * kLT + tid, GW = G * (kLT / 64);
   const int N = d.N, n = d.n, L = d.L, n6 = 6 * d.N;
   // LDS carve: [0, ldlt) the LDL^T scratch (reused as general scratch between solves), then control words
-  double* shw = sh + liba_scratch_doubles(W);             // [kLT/64] reductions
+  double* shw = sh + liba_scratch_doubles(NB, W);             // [kLT/64] reductions
   int* lds_flag = reinterpret_cast<int*>(shw + kLT / 64 + 1);
   const double* H = v.H + d.H_off;
   const double* Hll = v.Hll + (size_t)d.pt_off * 6;
@@ -916,7 +920,7 @@ __global__ __launch_bounds__(kLT) void k_liba(LibaView v, int W, int G) {
       liba_schur(c, lambda);
       OSH_GSYNC();
       OSH_PROF(3);
-      if (m == 0) liba_solve(c, sh);
+      if (m == 0) liba_solve<NB>(c, sh);
       OSH_GSYNC();
       const bool ok2 = ctrl[1] != 0.0;
       OSH_PROF(4);
@@ -1064,8 +1068,10 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
     n_max = std::max(n_max, d.n);
   }
   const int W = ldlt_row_stride(n_max);
-  const size_t lds = (liba_scratch_doubles(W) + kLT / 64 + 8) * sizeof(double);
-  if (lds > 160 * 1024 - 64) {   // the panels of the reduced system's LDL^T live in LDS: 51 keyframes x 15 dof at most
+  int NB = kLNB;   // the widest panel whose LDL^T working set fits LDS
+  while (NB > 6 && (liba_scratch_doubles(NB, W) + kLT / 64 + 8) * sizeof(double) > 160 * 1024 - 64) NB /= 2;
+  const size_t lds = (liba_scratch_doubles(NB, W) + kLT / 64 + 8) * sizeof(double);
+  if (lds > 160 * 1024 - 64) {   // the panels of the reduced system's LDL^T live in LDS
     set_error("inertial window with %d optimisable keyframes: the device path handles up to %d (LocalInertialBA uses 10 or 25)", n_max / 15, kLibaMaxKeyframes);
     return OSH_ERR_UNSUPPORTED;
   }
@@ -1233,7 +1239,9 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
     static std::vector<int> attr_devices;
     std::lock_guard<std::mutex> attr_lock(attr_mu);
     if (std::find(attr_devices.begin(), attr_devices.end(), device) == attr_devices.end()) {
-      OSH_HIP(hipFuncSetAttribute((const void*)k_liba, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+      OSH_HIP(hipFuncSetAttribute((const void*)k_liba<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+      OSH_HIP(hipFuncSetAttribute((const void*)k_liba<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+      OSH_HIP(hipFuncSetAttribute((const void*)k_liba<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
       attr_devices.push_back(device);
     }
   }
@@ -1243,15 +1251,17 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
   if (const char* gs = getenv("OSH_LIBA_GROUP")) { const int gv = atoi(gs); if (gv == 1 || gv == 2 || gv == 4 || gv == 8 || gv == 16 || gv == 32) G = gv; }
   int W_arg = W;
   hipError_t le = hipSuccess;
+  const void* kfn = NB == 24 ? (const void*)k_liba<24> : NB == 12 ? (const void*)k_liba<12> : (const void*)k_liba<6>;
   if (G > 1) {
     void* args[] = {(void*)&v, (void*)&W_arg, (void*)&G};
-    le = hipLaunchCooperativeKernel((const void*)k_liba, dim3((unsigned)((nw + 7) / 8 * 8 * G)), dim3(kLT), args, (unsigned)lds, s);
+    le = hipLaunchCooperativeKernel(kfn, dim3((unsigned)((nw + 7) / 8 * 8 * G)), dim3(kLT), args, (unsigned)lds, s);
     // not enough free CUs for every group to be resident, or no cooperative launches on this device: one block per window needs neither
     if (le != hipSuccess) { (void)hipGetLastError(); G = 1; le = hipSuccess; }
   }
   if (G == 1) {
-    hipLaunchKernelGGL(k_liba, dim3((unsigned)((nw + 7) / 8 * 8)), dim3(kLT), lds, s, v, W, 1);
-    le = hipGetLastError();
+    int one = 1;
+    void* args[] = {(void*)&v, (void*)&W_arg, (void*)&one};
+    le = hipLaunchKernel(kfn, dim3((unsigned)((nw + 7) / 8 * 8)), dim3(kLT), args, lds, s);
   }
   if (le != hipSuccess) { set_error("k_liba launch failed: %s", hipGetErrorString(le)); return OSH_ERR_DEVICE; }
   OSH_HIP(hipMemcpyAsync(hr, dres, out_bytes, hipMemcpyDeviceToHost, s));
