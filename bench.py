@@ -361,8 +361,21 @@ def run_inertial(args, info, windows):
     for _ in range(reps):
         res = solver.solve_inertial(windows)
     batch_s = (time.perf_counter() - t0) / reps
+    # the same kernel on the problems of Optimizer::FullInertialBA (every keyframe of a small map optimisable, lambda 1e-5, optimize(7) as the
+    # loop closer calls it, src/LoopClosing.cc:2291) and MergeInertialBA (12 temporal + 31 pose-only keyframes, lambda 1e3, optimize(8))
+    import dataclasses
+    from orb_slam3_study_kr_amd import synth_inertial as si
+    map_ba = {}
+    for name, n_opt, lam, its in (("full_inertial_ba_100_keyframes", 100, 1e-5, 7), ("merge_inertial_ba_43_keyframes", 43, 1e3, 8)):
+        w = si.make_inertial_window(900 + n_opt, n_opt=n_opt, n_fixed=0, n_points=40 * n_opt, large=True)
+        w = dataclasses.replace(w, lambda_init=lam, max_iterations=its, link_robust=np.ones_like(w.link_robust))
+        solver.solve_inertial([w])
+        t0 = time.perf_counter()
+        r = solver.solve_inertial([w])[0]
+        map_ba[name] = dict(ms=(time.perf_counter() - t0) * 1e3, keyframes=n_opt, landmarks=w.n_points, edges=w.n_edges, lm_iterations=int(r.iterations))
     solver.close()
     out = dict(metric="LocalInertialBA windows/sec (10 temporal KF + 21 fixed, ~1.1k landmarks, ~16.7k stereo edges, IMU preintegration edges)",
+               map_sized=map_ba,
                windows_per_s=len(windows) / batch_s, windows_per_batch=len(windows), single_window_latency_ms=single_ms,
                lm_iterations_mean=float(np.mean([r.iterations for r in res])), includes="H2D upload + D2H download", dtype="f64 (+f32 preintegration getters)")
     # SURVEY.md 8(d) byte model applied to the visual part of the inertial window (d = 3, P = the temporal keyframes): per iteration and
@@ -379,7 +392,7 @@ def run_inertial(args, info, windows):
         back = Ef * 144 + L * 96 + 6 * P * 8
         upd = 2 * (P * 56 + L * 24)
         alg += r.iterations * (lin + resid) + r.trials * (schur + back + upd + resid)
-    out["roofline"] = dict(bound="hbm", kernel="k_liba", achieved=alg / batch_s / 1e9, peak=8000.0, unit="GB/s", frac=alg / batch_s / 8e12,
+    out["roofline"] = dict(bound="hbm", kernel="k_liba<24>", achieved=alg / batch_s / 1e9, peak=8000.0, unit="GB/s", frac=alg / batch_s / 8e12,
                            traffic=None, note="whole call incl. upload / download; a group of thread blocks per window, latency bound (DESIGN.md 4b)")
     if info.rank == 0 and info.world == 1 and not args.no_cpu_baseline:
         from oracle import binding as ob
@@ -450,7 +463,7 @@ def main():
     ap.add_argument("--no-orb", action="store_true")
     ap.add_argument("--inertial-windows", type=int, default=128, help="config-4 windows per osh_liba_solve call (0 = skip)")
     ap.add_argument("--e2e-contexts", type=int, default=4, help="solver contexts (each with its own host thread, stream and pinned staging) of the end-to-end run")
-    ap.add_argument("--e2e-batches", type=int, default=3, help="batches per solver context in the end-to-end (upload + optimize + download) run; 0 = skip")
+    ap.add_argument("--e2e-batches", type=int, default=6, help="batches per solver context in the end-to-end (upload + optimize + download) run; 0 = skip")
     ap.add_argument("--stub-solver", action="store_true", help="CPU rehearsal of the rank plumbing (gloo): no GPU work, the "
                     "timed step is a fixed sleep; the JSON line is marked \"stub\" and is not a measurement")
     args = ap.parse_args()
