@@ -35,7 +35,7 @@ constexpr int kLG = 32;       // blocks per window at most (one XCD's worth of a
 constexpr int kPoseChunks = 8;   // a pose row's edges are summed in at most this many chunks
 constexpr int kLinkQ = 832;   // per link: J^T W J (24x24), -J^T W r (24), then J (9x24), -W r (9), rho'
 // (liba_scratch_doubles(NB, ldlt_row_stride(15 N)) + kLT/64 + 8) doubles must fit 160 KB of LDS: 51 keyframes with 24-wide panels
-// (every LocalInertialBA / MergeInertialBA window), 102 with 12-wide, 192 with 6-wide ones (FullInertialBA over a map)
+// (every LocalInertialBA / MergeInertialBA window, liba_solve); up to 192 keyframes the group factorises in global memory (liba_solve_group)
 constexpr int kLibaMaxKeyframes = 192;
 __host__ __device__ constexpr size_t liba_scratch_doubles(int NB, int W) { return ldlt_lds_doubles(NB, W, kLT) > 512 ? ldlt_lds_doubles(NB, W, kLT) : 512; }
 struct LibaOut {
@@ -691,6 +691,161 @@ __device__ __forceinline__ void liba_solve(const LibaCtx& c, double* sh_lds) {
   if (tid == 0) ctrl[1] = okb ? 1.0 : 0.0;
 }
 
+// ---- LDL^T + solve of a reduced system too wide for the LDS panels above (FullInertialBA over a map: up to 2880 unknowns), by the WHOLE
+// group: right-looking, 16 pivots per step, the matrix stays in global memory (upper storage; A = U^T D^-1 U with the unscaled rows
+// u_pj = d_p l_jp kept in place of A, as in ldlt_block.h).  Per step: every block factors the 16 x 16 diagonal block for itself (one
+// wavefront, the columns in registers, pivots and multipliers passed by lane shuffles), the row panel is divided among all threads of
+// the group, a group barrier, the trailing update A_ij -= sum_p u_pi u_pj / d_p in tiles of 16 rows x 64 columns divided among all
+// wavefronts of the group, a group barrier.  Forward and back substitution by block 0, 16 rows at a time, the vectors in LDS.
+constexpr int kPB = 16;
+__device__ __noinline__ bool liba_solve_group(const LibaCtx& c, Grp& g, int* lds_flag) {
+  OSH_LIBA_LOCALS
+  double* du = sh;                       // [kPB][kPB] row q: u_qp for p >= q (u_qq = d_q)
+  double* ddi = du + kPB * kPB;          // [kPB] 1 / d_q
+  double* wsh = ddi + kPB;               // [kLT/64][kPB*kPB] per wavefront: u_pi / d_p of the row tile it works on
+  double* xs = wsh + (kLT / 64) * kPB * kPB;   // [n] right-hand side -> solution (block 0)
+  double* red = xs + ((n + 15) & ~15);   // [kLT/64][kPB] partial sums of the back substitution
+  bool ok = true;
+  for (int k0 = 0; k0 < n; k0 += kPB) {
+    const int kb = min(kPB, n - k0);
+    // ---- the diagonal block, by wavefront 0 of every block: lane t holds column k0 + t (rows 0..t)
+    if (wave == 0) {
+      double col[kPB];
+#pragma unroll
+      for (int p = 0; p < kPB; ++p) col[p] = (lane < kb && p <= lane) ? S[(size_t)(k0 + p) * n + k0 + lane] : (p == lane ? 1.0 : 0.0);
+#pragma unroll
+      for (int q = 0; q < kPB; ++q) {
+        const double dq = __shfl(col[q], q);            // pivot: row q of column q, final after the earlier pivots
+        const double cq = col[q] * (1.0 / dq);           // l-form of this column's entry in row q
+#pragma unroll
+        for (int p = q + 1; p < kPB; ++p) {
+          const double uqp = __shfl(col[q], p);           // u_qp: row q of column p
+          if (p <= lane) col[p] -= uqp * cq;
+        }
+      }
+      if (lane < kPB) {
+#pragma unroll
+        for (int p = 0; p < kPB; ++p) du[p * kPB + lane] = col[p];      // column `lane`: u_p,lane (garbage below the diagonal, never read)
+        ddi[lane] = 1.0 / col[lane];
+      }
+    }
+    __syncthreads();
+    for (int q = 0; q < kb; ++q) if (du[q * kPB + q] == 0.0) ok = false;   // Eigen's LDLT fails on an exactly-zero pivot only
+    // ---- the row panel: column j of rows k0 .. k0+kb, one column per thread of the group
+    for (int j = k0 + kb + gt; j < n; j += GT) {
+      double col[kPB];
+#pragma unroll
+      for (int p = 0; p < kPB; ++p) col[p] = p < kb ? S[(size_t)(k0 + p) * n + j] : 0.0;
+#pragma unroll
+      for (int q = 0; q < kPB; ++q) {
+        const double cq = col[q] * ddi[q];
+#pragma unroll
+        for (int p = q + 1; p < kPB; ++p) col[p] -= du[q * kPB + p] * cq;
+      }
+#pragma unroll
+      for (int p = 0; p < kPB; ++p) if (p < kb) S[(size_t)(k0 + p) * n + j] = col[p];
+    }
+    if (!grp_sync(g, lds_flag)) return false;
+    // the factored diagonal block goes back only now: until the barrier the other blocks were still reading the unfactored one
+    if (m == 0) {
+      const int pp = tid >> 4, tt = tid & 15;
+      if (tid < kPB * kPB && pp <= tt && tt < kb) S[(size_t)(k0 + pp) * n + k0 + tt] = du[tid];
+    }
+    // ---- trailing update, tiles of 16 rows x 64 columns (upper part) over the wavefronts of the group
+    const int t0 = k0 + kb;
+    if (t0 < n && kb == kPB) {
+      double* wt = wsh + wave * kPB * kPB;
+      const int gw = m * (kLT / 64) + wave;
+      int base = 0;
+      for (int i0 = t0; i0 < n; i0 += kPB) {
+        const int nc = (n - i0 + 63) >> 6;
+        int first = (gw - base) % GW; if (first < 0) first += GW;
+        base = (base + nc) % GW;
+        if (first >= nc) continue;
+        // this wavefront has chunks of row tile i0: the multipliers u_pi / d_p of its 16 rows
+        for (int idx = lane; idx < kPB * kPB; idx += 64) {
+          const int pp = idx >> 4, ii = idx & 15;
+          wt[idx] = (i0 + ii < n) ? S[(size_t)(k0 + pp) * n + i0 + ii] * ddi[pp] : 0.0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int jc = first; jc < nc; jc += GW) {
+          const int j = i0 + (jc << 6) + lane;
+          if (j >= n) continue;
+          double uj[kPB];
+#pragma unroll
+          for (int p = 0; p < kPB; ++p) uj[p] = S[(size_t)(k0 + p) * n + j];
+#pragma unroll
+          for (int ii = 0; ii < kPB; ++ii) {
+            const int i = i0 + ii;
+            if (i >= n || j < i) continue;
+            double acc = 0.0;
+#pragma unroll
+            for (int p = 0; p < kPB; ++p) acc += wt[p * kPB + ii] * uj[p];
+            S[(size_t)i * n + j] -= acc;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (!grp_sync(g, lds_flag)) return false;
+  }
+  // ---- substitutions by block 0 (the other blocks wait at the caller's barrier)
+  if (m == 0) {
+    for (int k = tid; k < n; k += kLT) xs[k] = bs[k];
+    __syncthreads();
+    // forward: z_j = b_j - sum_{p<j} (u_pj / d_p) z_p, 16 pivots at a time
+    for (int k0 = 0; k0 < n; k0 += kPB) {
+      const int kb = min(kPB, n - k0);
+      for (int idx = tid; idx < kPB * kPB; idx += kLT) {
+        const int pp = idx >> 4, jj = idx & 15;
+        du[idx] = (pp < kb && jj < kb && jj >= pp) ? S[(size_t)(k0 + pp) * n + k0 + jj] : (pp == jj ? 1.0 : 0.0);
+      }
+      __syncthreads();
+      if (tid < kPB) ddi[tid] = 1.0 / du[tid * kPB + tid];
+      __syncthreads();
+      if (tid == 0)
+        for (int q = 0; q < kb; ++q) { const double zq = xs[k0 + q] * ddi[q]; for (int p = q + 1; p < kb; ++p) xs[k0 + p] -= du[q * kPB + p] * zq; }
+      __syncthreads();
+      for (int j = k0 + kb + tid; j < n; j += kLT) {
+        double acc = 0.0;
+        for (int p = 0; p < kb; ++p) acc += S[(size_t)(k0 + p) * n + j] * (xs[k0 + p] * ddi[p]);
+        xs[j] -= acc;
+      }
+      __syncthreads();
+    }
+    // backward: x_p = z_p / d_p - (sum_{j>p} u_pj x_j) / d_p, the last rows first
+    for (int k0 = ((n - 1) / kPB) * kPB; k0 >= 0; k0 -= kPB) {
+      const int kb = min(kPB, n - k0);
+      double part[kPB];
+#pragma unroll
+      for (int p = 0; p < kPB; ++p) part[p] = 0.0;
+      for (int j = k0 + kb + tid; j < n; j += kLT) {
+        const double xj = xs[j];
+#pragma unroll
+        for (int p = 0; p < kPB; ++p) if (p < kb) part[p] += S[(size_t)(k0 + p) * n + j] * xj;
+      }
+#pragma unroll
+      for (int p = 0; p < kPB; ++p) { const double t = dev::wave_sum_dpp(part[p]); if (lane == 0) red[wave * kPB + p] = t; }
+      for (int idx = tid; idx < kPB * kPB; idx += kLT) {
+        const int pp = idx >> 4, jj = idx & 15;
+        du[idx] = (pp < kb && jj < kb && jj >= pp) ? S[(size_t)(k0 + pp) * n + k0 + jj] : (pp == jj ? 1.0 : 0.0);
+      }
+      __syncthreads();
+      if (tid == 0)
+        for (int p = kb - 1; p >= 0; --p) {
+          double sum = 0.0;
+          for (int w = 0; w < kLT / 64; ++w) sum += red[w * kPB + p];
+          for (int j = p + 1; j < kb; ++j) sum += du[p * kPB + j] * xs[k0 + j];
+          xs[k0 + p] = (xs[k0 + p] - sum) / du[p * kPB + p];
+        }
+      __syncthreads();
+    }
+    for (int k = tid; k < n; k += kLT) xg[k] = xs[k];
+    if (tid == 0) ctrl[1] = ok ? 1.0 : 0.0;
+  }
+  return true;
+}
+
 // ---- landmark back-substitution and the update of every vertex into the trial buffers; returns this thread's share of computeScale
 __device__ __noinline__ double liba_backsub(const LibaCtx& c, int sel, double lambda, bool ok2) {
   OSH_LIBA_LOCALS
@@ -920,7 +1075,8 @@ __global__ __launch_bounds__(kLT) void k_liba(LibaView v, int W, int G) {
       liba_schur(c, lambda);
       OSH_GSYNC();
       OSH_PROF(3);
-      if (m == 0) liba_solve<NB>(c, sh);
+      if constexpr (NB == kLNB) { if (m == 0) liba_solve<NB>(c, sh); }
+      else { if (!liba_solve_group(c, g, lds_flag)) return; }
       OSH_GSYNC();
       const bool ok2 = ctrl[1] != 0.0;
       OSH_PROF(4);
@@ -1068,8 +1224,10 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
     n_max = std::max(n_max, d.n);
   }
   const int W = ldlt_row_stride(n_max);
-  int NB = kLNB;   // the widest panel whose LDL^T working set fits LDS
-  while (NB > 6 && (liba_scratch_doubles(NB, W) + kLT / 64 + 8) * sizeof(double) > 160 * 1024 - 64) NB /= 2;
+  // 24-wide panels in the LDS of one block while they fit (51 keyframes); beyond, the whole group factorises in global memory
+  // (liba_solve_group; k_liba<6> -- its LDS need, vectors of n doubles, stays below what 6-wide panels would take)
+  int NB = kLNB;
+  if ((liba_scratch_doubles(NB, W) + kLT / 64 + 8) * sizeof(double) > 160 * 1024 - 64) NB = 6;
   const size_t lds = (liba_scratch_doubles(NB, W) + kLT / 64 + 8) * sizeof(double);
   if (lds > 160 * 1024 - 64) {   // the panels of the reduced system's LDL^T live in LDS
     set_error("inertial window with %d optimisable keyframes: the device path handles up to %d (LocalInertialBA uses 10 or 25)", n_max / 15, kLibaMaxKeyframes);
@@ -1240,7 +1398,6 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
     std::lock_guard<std::mutex> attr_lock(attr_mu);
     if (std::find(attr_devices.begin(), attr_devices.end(), device) == attr_devices.end()) {
       OSH_HIP(hipFuncSetAttribute((const void*)k_liba<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-      OSH_HIP(hipFuncSetAttribute((const void*)k_liba<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
       OSH_HIP(hipFuncSetAttribute((const void*)k_liba<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
       attr_devices.push_back(device);
     }
@@ -1251,7 +1408,7 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
   if (const char* gs = getenv("OSH_LIBA_GROUP")) { const int gv = atoi(gs); if (gv == 1 || gv == 2 || gv == 4 || gv == 8 || gv == 16 || gv == 32) G = gv; }
   int W_arg = W;
   hipError_t le = hipSuccess;
-  const void* kfn = NB == 24 ? (const void*)k_liba<24> : NB == 12 ? (const void*)k_liba<12> : (const void*)k_liba<6>;
+  const void* kfn = NB == 24 ? (const void*)k_liba<24> : (const void*)k_liba<6>;
   if (G > 1) {
     void* args[] = {(void*)&v, (void*)&W_arg, (void*)&G};
     le = hipLaunchCooperativeKernel(kfn, dim3((unsigned)((nw + 7) / 8 * 8 * G)), dim3(kLT), args, (unsigned)lds, s);
