@@ -1,3 +1,5 @@
+"""Per-phase shader-clock breakdown of the inertial kernel on map-sized problems (FullInertialBA-shaped windows of 25..150 keyframes):
+`PYTHONPATH=. python profiles/liba_map_profile.py` on the GPU box.  Output of r02: profiles/r02_liba_map_profile.txt."""
 import numpy as np, dataclasses, time
 from orb_slam3_study_kr_amd import synth_inertial as si, lba
 names = ["linearise", "assembly", "Dinv", "Schur", "LDLT", "backsub", "errors", "outputs"]
