@@ -34,10 +34,14 @@ constexpr int kLNB = 24;      // LDL^T panel width (12 or 6 for windows whose 24
 constexpr int kLG = 32;       // blocks per window at most (one XCD's worth of a group)
 constexpr int kPoseChunks = 8;   // a pose row's edges are summed in at most this many chunks
 constexpr int kLinkQ = 832;   // per link: J^T W J (24x24), -J^T W r (24), then J (9x24), -W r (9), rho'
-// (liba_scratch_doubles(NB, ldlt_row_stride(15 N)) + kLT/64 + 8) doubles must fit 160 KB of LDS: 51 keyframes with 24-wide panels
-// (every LocalInertialBA / MergeInertialBA window, liba_solve); up to 192 keyframes the group factorises in global memory (liba_solve_group)
-constexpr int kLibaMaxKeyframes = 192;
-__host__ __device__ constexpr size_t liba_scratch_doubles(int NB, int W) { return ldlt_lds_doubles(NB, W, kLT) > 512 ? ldlt_lds_doubles(NB, W, kLT) : 512; }
+// LDS scratch: the LDL^T panels of the reduced system when they fit one block's LDS (NB = 24: up to 51 keyframes, every LocalInertialBA /
+// MergeInertialBA window, liba_solve); beyond that the group factorises in global memory (NB = 6 names that variant, liba_solve_group)
+// and LDS holds its 16 x 16 blocks and two vectors only.  600 keyframes = a dense 9000 x 9000 system (H and S: 1.3 GB).
+constexpr int kLibaMaxKeyframes = 600;
+__host__ __device__ constexpr size_t liba_scratch_doubles(int NB, int W) {
+  const size_t need = NB == kLNB ? ldlt_lds_doubles(NB, W, kLT) : (size_t)(6 * 256 + 64 + W + 32);
+  return need > 512 ? need : 512;
+}
 struct LibaOut {
   double chi2_initial, chi2_final;
   int iterations, trials, n_trace, sel;
@@ -1229,7 +1233,7 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
   int NB = kLNB;
   if ((liba_scratch_doubles(NB, W) + kLT / 64 + 8) * sizeof(double) > 160 * 1024 - 64) NB = 6;
   const size_t lds = (liba_scratch_doubles(NB, W) + kLT / 64 + 8) * sizeof(double);
-  if (lds > 160 * 1024 - 64) {   // the panels of the reduced system's LDL^T live in LDS
+  if (lds > 160 * 1024 - 64 || n_max > 15 * kLibaMaxKeyframes) {
     set_error("inertial window with %d optimisable keyframes: the device path handles up to %d (LocalInertialBA uses 10 or 25)", n_max / 15, kLibaMaxKeyframes);
     return OSH_ERR_UNSUPPORTED;
   }

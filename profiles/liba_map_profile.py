@@ -4,7 +4,7 @@ import numpy as np, dataclasses, time
 from orb_slam3_study_kr_amd import synth_inertial as si, lba
 names = ["linearise", "assembly", "Dinv", "Schur", "LDLT", "backsub", "errors", "outputs"]
 with lba.LbaSolver(0) as s:
-    for n_opt in (25, 50, 100, 150):
+    for n_opt in (25, 50, 100, 150, 200, 400):
         w = si.make_inertial_window(900 + n_opt, n_opt=n_opt, n_fixed=0, n_points=40 * n_opt, large=True)
         w = dataclasses.replace(w, lambda_init=1e-5, max_iterations=7, link_robust=np.ones_like(w.link_robust))
         s.solve_inertial([w]); t0 = time.perf_counter(); r = s.solve_inertial([w])[0]; ms = (time.perf_counter() - t0) * 1e3
