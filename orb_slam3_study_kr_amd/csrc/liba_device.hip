@@ -807,8 +807,17 @@ __device__ __noinline__ bool liba_solve_group(const LibaCtx& c, Grp& g, int* lds
       __syncthreads();
       if (tid < kPB) ddi[tid] = 1.0 / du[tid * kPB + tid];
       __syncthreads();
-      if (tid == 0)
-        for (int q = 0; q < kb; ++q) { const double zq = xs[k0 + q] * ddi[q]; for (int p = q + 1; p < kb; ++p) xs[k0 + p] -= du[q * kPB + p] * zq; }
+      if (tid < kPB) {   // lane p holds z_p and column p of the block; z_q is final once the pivots before q are through
+        double z = tid < kb ? xs[k0 + tid] : 0.0, u[kPB];
+#pragma unroll
+        for (int q = 0; q < kPB; ++q) u[q] = du[q * kPB + tid];
+#pragma unroll
+        for (int q = 0; q < kPB; ++q) {
+          const double zq = __shfl(z, q, kPB) * ddi[q];
+          if (tid > q) z -= u[q] * zq;
+        }
+        if (tid < kb) xs[k0 + tid] = z;
+      }
       __syncthreads();
       for (int j = k0 + kb + tid; j < n; j += kLT) {
         double acc = 0.0;
@@ -835,13 +844,21 @@ __device__ __noinline__ bool liba_solve_group(const LibaCtx& c, Grp& g, int* lds
         du[idx] = (pp < kb && jj < kb && jj >= pp) ? S[(size_t)(k0 + pp) * n + k0 + jj] : (pp == jj ? 1.0 : 0.0);
       }
       __syncthreads();
-      if (tid == 0)
-        for (int p = kb - 1; p >= 0; --p) {
-          double sum = 0.0;
-          for (int w = 0; w < kLT / 64; ++w) sum += red[w * kPB + p];
-          for (int j = p + 1; j < kb; ++j) sum += du[p * kPB + j] * xs[k0 + j];
-          xs[k0 + p] = (xs[k0 + p] - sum) / du[p * kPB + p];
+      if (tid < kPB) {   // lane p holds row p of the block: x_j of the higher rows arrives by shuffle, the last row first
+        double sum = 0.0, r[kPB];
+        for (int w = 0; w < kLT / 64; ++w) sum += red[w * kPB + tid];
+#pragma unroll
+        for (int j = 0; j < kPB; ++j) r[j] = du[tid * kPB + j];
+        const double z = tid < kb ? xs[k0 + tid] : 0.0, dinvp = 1.0 / du[tid * kPB + tid];
+        double x = 0.0;
+#pragma unroll
+        for (int j = kPB - 1; j >= 0; --j) {
+          if (tid == j) x = (z - sum) * dinvp;
+          const double xj = __shfl(x, j, kPB);
+          if (tid < j) sum += r[j] * xj;
         }
+        if (tid < kb) xs[k0 + tid] = x;
+      }
       __syncthreads();
     }
     for (int k = tid; k < n; k += kLT) xg[k] = xs[k];
