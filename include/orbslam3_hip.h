@@ -303,6 +303,11 @@ int osh_lba_pack_check(int32_t n_windows, const osh_lba_problem* problems, int32
  * Poses use the ImuCamPose parameterisation (src/G2oTypes.cc:25-71,187-220): body-frame right update
  *   twb += Rwb*ut ; Rwb = Rwb*ExpSO3(ur) ; Rcw = Rcb*Rbw ; tcw = Rcb*tbw + tcb.
  * link l is one EdgeInertial (+ EdgeGyroRW + EdgeAccRW) between keyframes link_prev[l] -> link_cur[l] (:2600-2667).
+ *
+ * The same structure carries Optimizer::FullInertialBA (src/Optimizer.cc:393-814: every keyframe of the map in n_opt, lambda_init 1e-5,
+ * one optimize(its); with bInit see link_bias) and Optimizer::MergeInertialBA (:3956-4498: lambda_init 1e3, optimize(8)).  A keyframe of
+ * n_opt that no link touches is a pose-only vertex (its velocity / bias entries come back unchanged).  Up to 600 optimisable keyframes;
+ * up to 51 the reduced system is factorised in the LDS of one thread block, beyond that by the window's whole block group in global memory.
  */
 #define OSH_PREINT_FLOATS 72
 /* layout of one preintegration record (IMU::Preintegrated members, all float32, src/ImuTypes.cc:147-237):
