@@ -225,6 +225,9 @@ _SIGNATURES = {
     "osh_pose_optimize": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(PoseProblem), C.POINTER(PoseResult)]),
     "osh_lba_get_plan_stats": (C.c_int, [C.c_void_p, c_int64_p]),
     "osh_lba_get_upload_times": (C.c_int, [C.c_void_p, c_double_p]),
+    "osh_lba_get_pack_profile": (C.c_int, [C.c_void_p, c_double_p]),
+    "osh_lba_set_pack_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "osh_lba_pack_compare": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(LbaProblem), c_int64_p]),
     "osh_lba_schur_plan_stats": (C.c_int, [C.POINTER(LbaProblem), c_int64_p]),
     "osh_lba_pack_check": (C.c_int, [C.c_int32, C.POINTER(LbaProblem), C.c_int32, c_int64_p, c_double_p]),
     "osh_orb_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),

@@ -41,6 +41,25 @@ struct DevBuf {
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// Pinned host buffer (grow-only).
+struct PinBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  PinBuf() = default;
+  PinBuf(const PinBuf&) = delete;
+  PinBuf& operator=(const PinBuf&) = delete;
+  ~PinBuf() { release(); }
+  void* reserve(size_t bytes) {
+    if (bytes <= cap) return p;
+    release();
+    const size_t want = bytes + bytes / 8 + 4096;
+    if (hipHostMalloc(&p, want) != hipSuccess) { p = nullptr; cap = 0; return nullptr; }
+    cap = want;
+    return p;
+  }
+  void release() { if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; } }
+};
+
 // Per-kernel HIP-event timing on one stream.
 struct KernelTimer {
   static constexpr int kMaxPending = 4096;

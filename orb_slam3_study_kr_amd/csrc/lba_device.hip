@@ -37,6 +37,7 @@
 #include "big_solve.h"
 #include "schur_plan.h"
 #include "lba_pack.h"
+#include "lba_pack_device.h"
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -1244,25 +1245,6 @@ __global__ __launch_bounds__(256) void k_widen_rec(const float4* src, double* ds
   d[1] = make_double2((double)v.z, (double)v.w);
 }
 
-// Pinned host buffer (grow-only).
-struct PinBuf {
-  void* p = nullptr;
-  size_t cap = 0;
-  PinBuf() = default;
-  PinBuf(const PinBuf&) = delete;
-  PinBuf& operator=(const PinBuf&) = delete;
-  ~PinBuf() { release(); }
-  void* reserve(size_t bytes) {
-    if (bytes <= cap) return p;
-    release();
-    const size_t want = bytes + bytes / 8 + 4096;
-    if (hipHostMalloc(&p, want) != hipSuccess) { p = nullptr; cap = 0; return nullptr; }
-    cap = want;
-    return p;
-  }
-  void release() { if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; } }
-};
-
 }  // namespace osh
 
 struct osh_lba_ctx {
@@ -1300,6 +1282,9 @@ struct osh_lba_ctx {
   size_t h_stop_cap = 0;
   BatchView bv{};
   bool optimized = false;
+  DevPackState dpack;                // lba_pack_device.hip: the packer on the device
+  int pack_mode = -1;                // -1: device unless the batch needs the host packer / the environment says otherwise; 0 device; 1 host
+  bool device_packed = false;        // the last upload's arenas exist on the device only (pb.arena[] are null)
   template <class T> T* dsec(int s) const { return reinterpret_cast<T*>(static_cast<unsigned char*>(d_arena[pb.sec_arena(s)].p) + pb.sec_off(s)); }
 };
 
@@ -1346,6 +1331,7 @@ extern "C" void osh_lba_destroy(osh_lba_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (int k = 0; k < 4; ++k) if (c->attach[k] && c->attach_free[k]) { c->attach_free[k](c->attach[k]); c->attach[k] = nullptr; }
   c->timer.destroy();
+  c->dpack.release_events();
   if (c->h_nactive) (void)hipHostFree(c->h_nactive);
   if (c->h_stop) (void)hipHostFree(c->h_stop);
   hipStream_t s = c->stream;
@@ -1363,16 +1349,28 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   c->any_stop = false;
   for (int w = 0; w < nw; ++w) { c->stop_ptr[w] = pr[w].stop_flag; if (pr[w].stop_flag) c->any_stop = true; }
 
-  // ---- host packing straight into pinned staging (lba_pack.h), then one copy per arena
+  // ---- packing: on the device (lba_pack_device.hip) from the caller's arrays in the caller's order, or -- fisheye-rig batches,
+  // OSH_LBA_PACK=host -- by host threads straight into pinned staging (lba_pack.h) and one copy per arena
   const auto t0 = std::chrono::steady_clock::now();
   PackedBatch& pb = c->pb;
-  const int rc = pack_batch(nw, pr, [&](int which, size_t bytes) { return c->h_arena[which].reserve(bytes); }, default_pack_threads(nw), pb);
-  if (rc != OSH_OK) { set_error("%s", pb.msg); return rc; }
-  const auto t1 = std::chrono::steady_clock::now();
   hipStream_t s = c->stream;
-  for (int a = 0; a < 2; ++a) {
-    OSH_TRY(c->d_arena[a].reserve(pb.arena_bytes[a]));
-    OSH_HIP(hipMemcpyAsync(c->d_arena[a].p, pb.arena[a], pb.arena_bytes[a], hipMemcpyHostToDevice, s));
+  bool on_device = device_pack_supported(nw, pr);
+  if (c->pack_mode >= 0) on_device = on_device && c->pack_mode == 0;
+  else if (const char* e = std::getenv("OSH_LBA_PACK")) on_device = on_device && std::strcmp(e, "host") != 0;
+  c->device_packed = on_device;
+  if (on_device) {
+    const int rc = device_pack_batch(c->dpack, s, nw, pr, default_pack_threads(nw), pb, c->d_arena, c->d_ptwin);
+    if (rc != OSH_OK) { set_error("%s", pb.msg); return rc; }
+  } else {
+    const int rc = pack_batch(nw, pr, [&](int which, size_t bytes) { return c->h_arena[which].reserve(bytes); }, default_pack_threads(nw), pb);
+    if (rc != OSH_OK) { set_error("%s", pb.msg); return rc; }
+  }
+  const auto t1 = std::chrono::steady_clock::now();
+  if (!on_device) {
+    for (int a = 0; a < 2; ++a) {
+      OSH_TRY(c->d_arena[a].reserve(pb.arena_bytes[a]));
+      OSH_HIP(hipMemcpyAsync(c->d_arena[a].p, pb.arena[a], pb.arena_bytes[a], hipMemcpyHostToDevice, s));
+    }
   }
   const size_t NP = pb.NP, NFP = pb.NFP, NL = pb.NL, NOUT = pb.NOUT;
 
@@ -1426,9 +1424,9 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
     c->h_stop_cap = nw;
   }
   OSH_HIP(hipMemsetAsync(c->d_xp.p, 0, std::max<size_t>(NFP * 6 * 8, 8), s));
-  {
-    // window of every landmark (for k_gather_out): filled on the device from the descriptors would need a scan; the host
-    // writes it into the tail of the pinned output staging instead (reused by the download later)
+  if (!on_device) {
+    // window of every landmark (for k_gather_out): the host packer writes it into the tail of the pinned output staging (reused
+    // by the download later); the device packer has filled d_ptwin itself
     int* h_ptwin = static_cast<int*>(c->h_out.reserve(std::max<size_t>(NL * 4, 8)));
     if (!h_ptwin) { set_error("cannot allocate pinned staging"); return OSH_ERR_DEVICE; }
     for (int w = 0; w < nw; ++w) std::fill(h_ptwin + pb.win[w].pt_off, h_ptwin + pb.win[w].pt_off + pb.win[w].L, w);
@@ -1471,8 +1469,8 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   bv.out_chi2 = c->d_out_chi2.as<double>(); bv.out_depth = c->d_out_depth.as<unsigned char>();
   OSH_HIP(hipStreamSynchronize(s));   // the staging arenas may be rewritten by the next upload
   const auto t2 = std::chrono::steady_clock::now();
-  c->upload_pack_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
-  c->upload_copy_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
+  c->upload_pack_ms = on_device ? c->dpack.host_ms : std::chrono::duration<double, std::milli>(t1 - t0).count();
+  c->upload_copy_ms = (on_device ? c->dpack.device_ms : 0.0) + std::chrono::duration<double, std::milli>(t2 - t1).count();
 
   const bool f32 = bv.e_rec32 != nullptr;
   if (pb.has_kb8) {
@@ -1722,6 +1720,15 @@ extern "C" int osh_lba_solve(osh_lba_ctx* c, int32_t nw, const osh_lba_problem* 
   return osh_lba_download(c, nw, res);
 }
 
+// Host view of an int section of arena 0: the host packer's staging, or a copy from the device when the batch was packed there.
+static int host_ints(osh_lba_ctx* c, int sec, size_t count, std::vector<int>& store, const int*& out) {
+  if (!c->device_packed) { out = c->pb.sec<int>(sec); return OSH_OK; }
+  store.resize(std::max<size_t>(count, 1));
+  if (count) OSH_HIP(hipMemcpy(store.data(), c->dsec<int>(sec), count * 4, hipMemcpyDeviceToHost));
+  out = store.data();
+  return OSH_OK;
+}
+
 // Debug / parity aid: one linearisation of `window` at the uploaded estimates.
 extern "C" int osh_lba_linearize(osh_lba_ctx* c, int32_t window, double* Hpp, double* bp, double* Hll, double* bl,
                                  double* Hpl, double* chi2, double* robust_chi2) {
@@ -1738,7 +1745,10 @@ extern "C" int osh_lba_linearize(osh_lba_ctx* c, int32_t window, double* Hpp, do
   if (robust_chi2) *robust_chi2 = h_lm[window].chi2_initial;
   if (Hpp && d.P) OSH_HIP(hipMemcpy(Hpp, c->d_Hpp.as<double>() + (size_t)d.fpose_off * 36, (size_t)d.P * 36 * 8, hipMemcpyDeviceToHost));
   if (bp && d.P) OSH_HIP(hipMemcpy(bp, c->d_bp.as<double>() + (size_t)d.fpose_off * 6, (size_t)d.P * 6 * 8, hipMemcpyDeviceToHost));
-  const int* perm = pb.sec<int>(PackedBatch::LMPERM) + d.pt_off;   // new -> caller landmark index
+  std::vector<int> perm_store, eo_store, eo2_store;
+  const int* perm = nullptr;   // new -> caller landmark index
+  OSH_TRY(host_ints(c, PackedBatch::LMPERM, pb.NL, perm_store, perm));
+  perm += d.pt_off;
   if (bl && d.L) {
     std::vector<double> t((size_t)d.L * 3);
     OSH_HIP(hipMemcpy(t.data(), c->d_bl.as<double>() + (size_t)d.pt_off * 3, t.size() * 8, hipMemcpyDeviceToHost));
@@ -1761,8 +1771,10 @@ extern "C" int osh_lba_linearize(osh_lba_ctx* c, int32_t window, double* Hpp, do
     std::vector<double> hs((size_t)d.E * 18);
     if (d.E) OSH_HIP(hipMemcpy(hs.data(), c->d_dbg.as<double>() + (size_t)d.edge_off * 18, hs.size() * 8, hipMemcpyDeviceToHost));
     std::memset(Hpl, 0, (size_t)d.in_edges * 18 * 8);
-    const int* eo = pb.sec<int>(PackedBatch::EORIG) + d.edge_off;
-    const int* eo2 = pb.has_rig ? pb.sec<int>(PackedBatch::EORIG2) + d.edge_off : nullptr;
+    const int *eo = nullptr, *eo2 = nullptr;
+    OSH_TRY(host_ints(c, PackedBatch::EORIG, pb.NE, eo_store, eo));
+    eo += d.edge_off;
+    if (pb.has_rig) { OSH_TRY(host_ints(c, PackedBatch::EORIG2, pb.NE, eo2_store, eo2)); eo2 += d.edge_off; }
     // the two edges of a merged fisheye-rig pair share one Hessian block: both report it (their sum)
     for (int x = 0; x < d.E; ++x) {
       std::memcpy(Hpl + (size_t)eo[x] * 18, &hs[(size_t)x * 18], 18 * 8);
@@ -1816,7 +1828,10 @@ extern "C" int osh_lba_debug_trial(osh_lba_ctx* c, int32_t window, double lambda
     // x_l = X_trial - X_cur, back in the caller's landmark order
     std::vector<double> a((size_t)d.L * 3), b((size_t)d.L * 3);
     if (d.L) {
-      const int* perm = pb.sec<int>(PackedBatch::LMPERM) + d.pt_off;
+      std::vector<int> perm_store;
+      const int* perm = nullptr;
+      OSH_TRY(host_ints(c, PackedBatch::LMPERM, pb.NL, perm_store, perm));
+      perm += d.pt_off;
       OSH_HIP(hipMemcpy(a.data(), c->d_pt[1].as<double>() + (size_t)d.pt_off * 3, a.size() * 8, hipMemcpyDeviceToHost));
       OSH_HIP(hipMemcpy(b.data(), c->d_pt[0].as<double>() + (size_t)d.pt_off * 3, b.size() * 8, hipMemcpyDeviceToHost));
       for (int j = 0; j < d.L; ++j)
@@ -1827,11 +1842,28 @@ extern "C" int osh_lba_debug_trial(osh_lba_ctx* c, int32_t window, double lambda
   return OSH_OK;
 }
 
+// 0: pack uploads on the device (default; fisheye-rig batches still take the host packer), 1: on the host (lba_pack.h), -1: default
+// rules (OSH_LBA_PACK=host in the environment selects the host packer)
+extern "C" int osh_lba_set_pack_mode(osh_lba_ctx* c, int mode) {
+  if (!c || mode < -1 || mode > 1) { set_error("osh_lba_set_pack_mode: bad arguments"); return OSH_ERR_INVALID; }
+  c->pack_mode = mode;
+  return OSH_OK;
+}
+
+// Test hook: packs the problems with the device packer AND the host packer and compares every section of the two layouts.
+extern "C" int osh_lba_pack_compare(osh_lba_ctx* c, int32_t nw, const osh_lba_problem* pr, int64_t stats[4]) {
+  if (!c || nw <= 0 || !pr) { set_error("osh_lba_pack_compare: bad arguments"); return OSH_ERR_INVALID; }
+  OSH_HIP(hipSetDevice(c->device));
+  OSH_HIP(hipStreamSynchronize(c->stream));
+  return device_pack_compare(c->dpack, c->stream, nw, pr, stats);
+}
+
 extern "C" int osh_lba_set_profiling(osh_lba_ctx* c, int enable) {
   if (!c) return OSH_ERR_INVALID;
   OSH_HIP(hipSetDevice(c->device));
   if (enable) OSH_TRY(c->timer.init());
   c->timer.enabled = enable != 0;
+  c->dpack.timing = enable != 0;
   c->timer.reset();
   return OSH_OK;
 }
@@ -1846,6 +1878,15 @@ extern "C" int osh_lba_get_plan_stats(osh_lba_ctx* c, int64_t stats[6]) {
   if (!c || !stats || c->n_windows <= 0) { set_error("osh_lba_get_plan_stats: nothing uploaded"); return OSH_ERR_INVALID; }
   stats[0] = (int64_t)c->pb.n_items; stats[1] = (int64_t)c->pb.n_sym; stats[2] = c->pb.tile_steps; stats[3] = c->pb.pair_blocks;
   stats[4] = (int64_t)c->pb.n_contrib; stats[5] = (int64_t)c->pb.n_rblk;
+  return OSH_OK;
+}
+
+// Device-side cost of the last upload packed on the device (HIP events; enable with osh_lba_set_profiling before the upload):
+// ms[0] H2D of the staged problem, ms[1..3] k_pack_pre1 / k_pack_pre2 / k_pack_post, ms[4] staged bytes, ms[5] 1 if the batch was packed on the device
+extern "C" int osh_lba_get_pack_profile(osh_lba_ctx* c, double ms[6]) {
+  if (!c || !ms) return OSH_ERR_INVALID;
+  for (int k = 0; k < 4; ++k) ms[k] = c->dpack.ev_ms[k];
+  ms[4] = (double)c->dpack.raw_bytes; ms[5] = c->device_packed ? 1.0 : 0.0;
   return OSH_OK;
 }
 

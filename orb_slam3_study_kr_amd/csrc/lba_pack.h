@@ -104,9 +104,9 @@ struct Scratch { std::vector<int> cnt, fill, order, second, tmp_epose, nfree, ol
 
 // Packs `nw` problems.  `alloc(which, bytes)` returns host memory for arena `which` (0, 1) that stays valid until the next
 // call with the same `which`.  Returns pb.err (OSH_OK on success), message in pb.msg.
-inline int pack_batch(int nw, const osh_lba_problem* pr, const std::function<void*(int, size_t)>& alloc, int n_threads, PackedBatch& pb,
-                      bool allow_f32 = true) {
-  using namespace pack_detail;
+// Pass 1 of every packer (host and device): validates the sizes and pointers of the problems and fills the part of the window
+// descriptors that follows from them (offsets of the fixed-size sections, camera models, controller parameters).
+inline int pack_describe(int nw, const osh_lba_problem* pr, PackedBatch& pb) {
   pb = PackedBatch();
   pb.nw = nw;
   pb.win.assign(nw, WinDesc{});
@@ -115,7 +115,6 @@ inline int pack_batch(int nw, const osh_lba_problem* pr, const std::function<voi
     if constexpr (sizeof...(a) == 0) std::snprintf(pb.msg, sizeof(pb.msg), "%s", fmt); else std::snprintf(pb.msg, sizeof(pb.msg), fmt, a...);
     return code;
   };
-  // ---- pass 1: validate + offsets of the fixed-size sections
   size_t NP = 0, NFP = 0, NL = 0, NE = 0, NLO = 0, NOUT = 0, S_total = 0;
   for (int w = 0; w < nw; ++w) {
     const osh_lba_problem& p = pr[w];
@@ -147,6 +146,54 @@ inline int pack_batch(int nw, const osh_lba_problem* pr, const std::function<voi
   // NE here is an upper bound (merged rig edges shrink it); the sorted edges of a window start at the caller's edge offset,
   // the tail of a window with merged edges stays unused.
   pb.NE = NE;
+  return OSH_OK;
+}
+
+// Offsets of the sections of arena 0 (sizes follow from the problem sizes and pb.rec_f32 / pb.has_rig); returns the arena size.
+inline size_t pack_layout0(PackedBatch& pb) {
+  size_t o = 0;
+  auto put = [&](int s, size_t b) { pb.off[s] = o; pb.bytes[s] = b; o += pack_detail::align_up(std::max<size_t>(b, 8)); };
+  const size_t NP = pb.NP, NL = pb.NL, NE = pb.NE;
+  put(PackedBatch::POSE, NP * 7 * 8); put(PackedBatch::CAM, NP * 5 * 8); put(PackedBatch::PT, NL * 3 * 8);
+  put(PackedBatch::EREC, NE * (pb.rec_f32 ? 16 : 32)); put(PackedBatch::EREC2, pb.has_rig ? NE * 32 : 0);
+  put(PackedBatch::EPOSE, NE * 4); put(PackedBatch::EPOINT, NE * 4); put(PackedBatch::EORIG, NE * 4);
+  put(PackedBatch::EORIG2, pb.has_rig ? NE * 4 : 0);
+  put(PackedBatch::LMOFF, pb.NLO * 4); put(PackedBatch::LMPERM, NL * 4); put(PackedBatch::FPW, pb.NFP * 4); put(PackedBatch::EKIND, NE);
+  pb.arena_bytes[0] = o;
+  return o;
+}
+
+// Offsets of the plan sections (arena 1) from the plan totals in pb; returns the arena size.
+inline size_t pack_layout1(PackedBatch& pb) {
+  size_t o = 0;
+  auto put = [&](int s, size_t b) { pb.off[s] = o; pb.bytes[s] = b; o += pack_detail::align_up(std::max<size_t>(b, 8)); };
+  put(PackedBatch::WIN, (size_t)pb.nw * sizeof(WinDesc)); put(PackedBatch::CHUNKS, pb.n_chunks * sizeof(Chunk));
+  put(PackedBatch::ITEMS, pb.n_items * sizeof(SItem)); put(PackedBatch::RECS, pb.n_recs * sizeof(SRec));
+  put(PackedBatch::SPAIR, pb.n_items * 64 * 4); put(PackedBatch::SCSLOT, pb.n_items * 8 * 4);
+  put(PackedBatch::POSEX, pb.n_items * 8 * 4); put(PackedBatch::POSEY, pb.n_items * 8 * 4);
+  put(PackedBatch::RBLK, pb.n_rblk * sizeof(RBlk)); put(PackedBatch::CRANGE, pb.NFP * sizeof(I2));
+  pb.arena_bytes[1] = o;
+  return o;
+}
+
+// g2o::SE3Quat(q,t) constructor: normalizeRotation (se3quat.h:61-63,280-285) -- the pose as every packer stores it
+inline void pack_pose(const double* in7, double* out7) {
+  double q[4] = {in7[0], in7[1], in7[2], in7[3]};
+  if (q[3] < 0) { q[0] *= -1; q[1] *= -1; q[2] *= -1; q[3] *= -1; }
+  const double nrm = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int k = 0; k < 4; ++k) out7[k] = q[k] / nrm;
+  for (int k = 0; k < 3; ++k) out7[4 + k] = in7[4 + k];
+}
+
+inline int pack_batch(int nw, const osh_lba_problem* pr, const std::function<void*(int, size_t)>& alloc, int n_threads, PackedBatch& pb,
+                      bool allow_f32 = true) {
+  using namespace pack_detail;
+  if (pack_describe(nw, pr, pb) != OSH_OK) return pb.err;
+  auto fail = [&](int code, const char* fmt, auto... a) {
+    pb.err = code;
+    if constexpr (sizeof...(a) == 0) std::snprintf(pb.msg, sizeof(pb.msg), "%s", fmt); else std::snprintf(pb.msg, sizeof(pb.msg), fmt, a...);
+    return code;
+  };
   n_threads = std::max(1, std::min(n_threads, nw));
   // Observation records travel as float32 when every value is one (what the reference stores: cv::KeyPoint::pt, mvuRight,
   // mvInvLevelSigma2).  Optimistic: the records are written as floats and checked on the way; a batch with a value that is not
@@ -154,14 +201,7 @@ inline int pack_batch(int nw, const osh_lba_problem* pr, const std::function<voi
   pb.rec_f32 = allow_f32 && !pb.has_rig;
   std::atomic<int> inexact{0};
   {
-    size_t o = 0;
-    auto put = [&](int s, size_t b) { pb.off[s] = o; pb.bytes[s] = b; o += align_up(std::max<size_t>(b, 8)); };
-    put(PackedBatch::POSE, NP * 7 * 8); put(PackedBatch::CAM, NP * 5 * 8); put(PackedBatch::PT, NL * 3 * 8);
-    put(PackedBatch::EREC, NE * (pb.rec_f32 ? 16 : 32)); put(PackedBatch::EREC2, pb.has_rig ? NE * 32 : 0);
-    put(PackedBatch::EPOSE, NE * 4); put(PackedBatch::EPOINT, NE * 4); put(PackedBatch::EORIG, NE * 4);
-    put(PackedBatch::EORIG2, pb.has_rig ? NE * 4 : 0);
-    put(PackedBatch::LMOFF, NLO * 4); put(PackedBatch::LMPERM, NL * 4); put(PackedBatch::FPW, NFP * 4); put(PackedBatch::EKIND, NE);
-    pb.arena_bytes[0] = o;
+    const size_t o = pack_layout0(pb);
     pb.arena[0] = static_cast<unsigned char*>(alloc(0, o));
     if (!pb.arena[0]) return fail(OSH_ERR_DEVICE, "cannot allocate %zu bytes of staging memory", o);
   }
@@ -189,13 +229,7 @@ inline int pack_batch(int nw, const osh_lba_problem* pr, const std::function<voi
     auto lfail = [&](int code, const char* fmt, auto... a) { L.err = code; std::snprintf(L.msg, sizeof(L.msg), fmt, a...); };
     const int NPw = p.n_free + p.n_fixed;
     for (int i = 0; i < NPw; ++i) {
-      double q[4] = {p.pose_qt[7 * i], p.pose_qt[7 * i + 1], p.pose_qt[7 * i + 2], p.pose_qt[7 * i + 3]};
-      // g2o::SE3Quat(q,t) constructor: normalizeRotation (se3quat.h:61-63,280-285)
-      if (q[3] < 0) { q[0] *= -1; q[1] *= -1; q[2] *= -1; q[3] *= -1; }
-      const double nrm = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-      double* o = &h_pose[((size_t)d.pose_off + i) * 7];
-      for (int k = 0; k < 4; ++k) o[k] = q[k] / nrm;
-      for (int k = 0; k < 3; ++k) o[4 + k] = p.pose_qt[7 * i + 4 + k];
+      pack_pose(p.pose_qt + 7 * (size_t)i, &h_pose[((size_t)d.pose_off + i) * 7]);
       for (int k = 0; k < 5; ++k) h_cam[((size_t)d.pose_off + i) * 5 + k] = p.pose_cam[5 * i + k];
     }
     for (int i = 0; i < p.n_free; ++i) h_fpw[(size_t)d.fpose_off + i] = w;
@@ -364,14 +398,7 @@ inline int pack_batch(int nw, const osh_lba_problem* pr, const std::function<voi
     pb.n_chunks = a.chunk; pb.n_sym = a.sym_item; pb.n_items = a.sym_item + a.cross_item; pb.n_recs = a.sym_rec + a.cross_rec;
     pb.n_rblk = a.rblk; pb.n_contrib = contrib; pb.n_ccontrib = ccontrib;
     if (contrib > 0x7fffff00u / 36 * 16 || pb.n_recs > 0x7fffff00u) return fail(OSH_ERR_UNSUPPORTED, "batch too large for 32-bit contribution offsets");
-    size_t o = 0;
-    auto put = [&](int s, size_t b) { pb.off[s] = o; pb.bytes[s] = b; o += align_up(std::max<size_t>(b, 8)); };
-    put(PackedBatch::WIN, (size_t)nw * sizeof(WinDesc)); put(PackedBatch::CHUNKS, pb.n_chunks * sizeof(Chunk));
-    put(PackedBatch::ITEMS, pb.n_items * sizeof(SItem)); put(PackedBatch::RECS, pb.n_recs * sizeof(SRec));
-    put(PackedBatch::SPAIR, pb.n_items * 64 * 4); put(PackedBatch::SCSLOT, pb.n_items * 8 * 4);
-    put(PackedBatch::POSEX, pb.n_items * 8 * 4); put(PackedBatch::POSEY, pb.n_items * 8 * 4);
-    put(PackedBatch::RBLK, pb.n_rblk * sizeof(RBlk)); put(PackedBatch::CRANGE, NFP * sizeof(I2));
-    pb.arena_bytes[1] = o;
+    const size_t o = pack_layout1(pb);
     pb.arena[1] = static_cast<unsigned char*>(alloc(1, o));
     if (!pb.arena[1]) return fail(OSH_ERR_DEVICE, "cannot allocate %zu bytes of staging memory", o);
   }

@@ -45,6 +45,19 @@ class LbaSolver:
     def optimize(self):
         capi.check(self.lib.osh_lba_optimize(self.ctx), "osh_lba_optimize", self.lib)
 
+    def set_pack_mode(self, mode: int):
+        """0: uploads are packed by HIP kernels (default), 1: by host threads (csrc/lba_pack.h), -1: default rules."""
+        capi.check(self.lib.osh_lba_set_pack_mode(self.ctx, mode), "osh_lba_set_pack_mode", self.lib)
+
+    def pack_compare(self, windows) -> dict:
+        """Packs ``windows`` with the device packer and the host packer and compares the two layouts byte by byte."""
+        arr = (capi.LbaProblem * len(windows))()
+        for i, w in enumerate(windows):
+            arr[i] = w.as_struct()
+        st = np.zeros(4, dtype=np.int64)
+        capi.check(self.lib.osh_lba_pack_compare(self.ctx, len(windows), arr, capi.ptr(st, capi.c_int64_p)), "osh_lba_pack_compare", self.lib)
+        return dict(bytes=int(st[0]), sections=int(st[1]), items=int(st[2]), records=int(st[3]))
+
     # -- the same life cycle on prepared ctypes arrays (bench.py's end-to-end pipeline: nothing but the C-ABI calls is timed) --
     def prepare(self, windows: list[LbaWindow]):
         """(problem array, result array, result holders) for upload_prepared / download_prepared."""
@@ -70,6 +83,11 @@ class LbaSolver:
         ms = np.zeros(2, dtype=np.float64)
         capi.check(self.lib.osh_lba_get_upload_times(self.ctx, capi.ptr(ms, capi.c_double_p)), "osh_lba_get_upload_times", self.lib)
         return dict(pack_ms=float(ms[0]), copy_ms=float(ms[1]))
+
+    def pack_profile(self) -> dict:
+        ms = np.zeros(6, dtype=np.float64)
+        capi.check(self.lib.osh_lba_get_pack_profile(self.ctx, capi.ptr(ms, capi.c_double_p)), "osh_lba_get_pack_profile", self.lib)
+        return dict(h2d_ms=float(ms[0]), pre1_ms=float(ms[1]), pre2_ms=float(ms[2]), post_ms=float(ms[3]), staged_bytes=int(ms[4]), on_device=bool(ms[5]))
 
     def download(self) -> list[LbaResultArrays]:
         n = len(self._windows)

@@ -1,0 +1,111 @@
+"""The device packer of osh_lba_upload (csrc/lba_pack_device.hip) against the host packer (csrc/lba_pack.h, the CPU checker of
+tests/test_lba_pack_cpu.py): ``osh_lba_pack_compare`` packs the same problems with both and compares every section of the two
+layouts byte for byte -- landmark renumbering, landmark-major edge order, observation records, chunks, Schur items, records, slot
+bytes, contribution slots, block ranges -- i.e. what SparseOptimizer::initializeOptimization + BlockSolver::buildStructure
+(Thirdparty/g2o/g2o/core/sparse_optimizer.cpp:199-267, block_solver.hpp:143-295) build inside the call this library replaces."""
+import numpy as np
+import pytest
+
+from orb_slam3_study_kr_amd import capi, lba, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def solver(hip_lib):
+    with lba.LbaSolver(0) as s:
+        yield s
+
+
+def _shuffled(w, seed=1):
+    perm = np.random.default_rng(seed).permutation(w.n_edges)
+    return synth.LbaWindow(n_free=w.n_free, n_fixed=w.n_fixed, pose_qt=w.pose_qt, pose_cam=w.pose_cam, points=w.points,
+                           edge_pose=np.ascontiguousarray(w.edge_pose[perm]), edge_point=np.ascontiguousarray(w.edge_point[perm]),
+                           edge_kind=np.ascontiguousarray(w.edge_kind[perm]), edge_obs=np.ascontiguousarray(w.edge_obs[perm]),
+                           edge_info=np.ascontiguousarray(w.edge_info[perm]), kb8=w.kb8).normalise()
+
+
+def test_small_windows_pack_identically(solver):
+    for w in (synth.make_config1(1), synth.make_window(3, n_free=6, n_fixed=2, n_points=400, stereo=True),
+              synth.make_window(9, n_free=12, n_fixed=3, n_points=300, stereo=False, mixed_mono_frac=0.0),
+              synth.make_window(10, n_free=12, n_fixed=3, n_points=300, stereo=True, mixed_mono_frac=0.4)):
+        st = solver.pack_compare([w])
+        assert st["records"] >= w.n_points and st["sections"] >= 20
+
+
+def test_config2_window_with_cross_items_packs_identically(solver):
+    w = synth.make_config2(100)
+    st = solver.pack_compare([w])
+    assert st["items"] > 300 and st["records"] > w.n_points     # long tracks are cut into parts: cross items exist
+
+
+def test_heterogeneous_batch_and_shuffled_edges(solver):
+    ws = [synth.make_window(200 + i, n_free=4 + 3 * i, n_fixed=1 + i, n_points=150 + 90 * i, stereo=bool(i % 2), obs_dropout=0.1 * (i % 3)) for i in range(7)]
+    ws.append(_shuffled(ws[3]))
+    ws.append(_shuffled(synth.make_config2(101), 2))
+    solver.pack_compare(ws)
+
+
+def test_double_records_and_degenerate_windows(solver):
+    w = synth.make_window(12, n_free=7, n_fixed=3, n_points=500, stereo=True)
+    w3 = synth.make_window(12, n_free=7, n_fixed=3, n_points=500, stereo=True)
+    w3.edge_obs = w3.edge_obs + 1e-9                     # not float32 values: the batch keeps 32-byte records
+    solver.pack_compare([w, w3])
+    base = synth.make_window(5, n_free=3, n_fixed=1, n_points=40, stereo=True)
+    keep = base.edge_point != 7                          # a landmark without any edge
+    w4 = synth.LbaWindow(n_free=base.n_free, n_fixed=base.n_fixed, pose_qt=base.pose_qt, pose_cam=base.pose_cam, points=base.points,
+                         edge_pose=base.edge_pose[keep], edge_point=base.edge_point[keep], edge_kind=base.edge_kind[keep],
+                         edge_obs=base.edge_obs[keep], edge_info=base.edge_info[keep]).normalise()
+    fixed_only = base.edge_pose >= base.n_free           # every edge on a fixed keyframe: no optimisable observer anywhere
+    w5 = synth.LbaWindow(n_free=base.n_free, n_fixed=base.n_fixed, pose_qt=base.pose_qt, pose_cam=base.pose_cam, points=base.points,
+                         edge_pose=base.edge_pose[fixed_only], edge_point=base.edge_point[fixed_only], edge_kind=base.edge_kind[fixed_only],
+                         edge_obs=base.edge_obs[fixed_only], edge_info=base.edge_info[fixed_only]).normalise()
+    solver.pack_compare([w4, w5, base])
+
+
+def test_fisheye_monocular_window(solver):
+    solver.pack_compare([synth.make_window(21, n_free=8, n_fixed=2, n_points=500, stereo=False, fisheye=True)])
+
+
+def test_map_sized_window_takes_the_global_memory_paths(solver):
+    """300 optimisable keyframes, 30 k landmarks with missed detections: thousands of distinct observer sets (sorted in global
+    memory instead of LDS) and more landmarks than the LDS chunk walk holds."""
+    w = synth.make_window(900, n_free=300, n_fixed=3, n_points=30000, stereo=True, track_len=(3, 30), obs_dropout=0.25, max_iterations=5)
+    st = solver.pack_compare([w])
+    assert st["items"] > 1024
+
+
+def test_refusals_match_the_host_packer(solver):
+    w = synth.make_window(3, n_free=4, n_fixed=1, n_points=50, stereo=True)
+    dup = synth.LbaWindow(n_free=w.n_free, n_fixed=w.n_fixed, pose_qt=w.pose_qt, pose_cam=w.pose_cam, points=w.points,
+                          edge_pose=np.concatenate([w.edge_pose, w.edge_pose[:1]]), edge_point=np.concatenate([w.edge_point, w.edge_point[:1]]),
+                          edge_kind=np.concatenate([w.edge_kind, w.edge_kind[:1]]), edge_obs=np.concatenate([w.edge_obs, w.edge_obs[:1]]),
+                          edge_info=np.concatenate([w.edge_info, w.edge_info[:1]])).normalise()
+    for mode in (0, 1):
+        solver.set_pack_mode(mode)
+        with pytest.raises(RuntimeError, match="observed twice"):
+            solver.upload([w, dup])
+    bad = synth.make_window(3, n_free=4, n_fixed=1, n_points=50, stereo=True)
+    bad.edge_point = bad.edge_point.copy()
+    bad.edge_point[5] = bad.n_points                     # landmark index out of range
+    msgs = []
+    for mode in (0, 1):
+        solver.set_pack_mode(mode)
+        with pytest.raises(RuntimeError, match="index or kind out of range") as ei:
+            solver.upload([bad])
+        msgs.append(str(ei.value))
+    assert msgs[0] == msgs[1]
+    solver.set_pack_mode(-1)
+    solver.upload([w])                                   # the context is usable after a refusal
+
+
+def test_both_packers_give_bitwise_equal_optimisations(solver):
+    ws = [synth.make_window(40 + i, n_free=5 + 2 * i, n_fixed=2, n_points=300 + 100 * i, stereo=True) for i in range(4)]
+    out = []
+    for mode in (0, 1):
+        solver.set_pack_mode(mode)
+        out.append(solver.solve(ws))
+    solver.set_pack_mode(-1)
+    for a, b in zip(*out):
+        assert a.iterations == b.iterations and a.trials == b.trials
+        assert np.array_equal(a.pose_qt, b.pose_qt) and np.array_equal(a.points, b.points) and np.array_equal(a.edge_chi2, b.edge_chi2)
