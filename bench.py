@@ -184,22 +184,31 @@ def run_end_to_end(args, info, windows):
     per_ctx = max(2, args.e2e_batches)
     n_batches = n_ctx * per_ctx
 
+    import threading
+    stage = [threading.Lock() for _ in range(3)]   # upload | optimize | download: one batch in each stage at a time
+
     def drive(k, n):
-        """One host thread owns one context and runs its batches one after the other (a context is not thread safe)."""
+        """One host thread owns one context and runs its batches one after the other (a context is not thread safe).  The three
+        stages of a batch use different resources (host cores + PCIe down, the GPU, PCIe up + host copies); a lock per stage keeps
+        ONE batch in each stage, so the contexts form a pipeline instead of all uploading, then all optimising, at the same time
+        (measured without the locks: the GPU ran no kernel for a third of the time, profiles/e2e_timeline.py)."""
         sv = solvers[k]
         probs, res, _ = prepared[k]
         ups = []
         for _ in range(n):
-            sv.upload_prepared(windows, probs)
+            with stage[0]:
+                sv.upload_prepared(windows, probs)
             ups.append(sv.upload_times())
-            sv.optimize()
-            sv.download_prepared(res)
+            with stage[1]:
+                sv.optimize()
+            with stage[2]:
+                sv.download_prepared(res)
         return ups
 
-    # packing threads per context: the contexts pack at the same time, so together they should not oversubscribe the cores by much
-    # (measured on the 16-core GPU box, profiles/e2e_sweep.sh: 2 x 16 threads 0.42-0.46 of the resident rate, 4 x 8 threads 0.48-0.55)
+    # staging threads of an upload: one batch is staged at a time, so it may take the host cores of this rank (all ranks of a node
+    # share them: divide by the world size)
     user_threads = os.environ.get("ORBSLAM3_HIP_UPLOAD_THREADS")
-    e2e_threads = int(user_threads) if user_threads else max(4, min(16, os.cpu_count() or 1) * 2 // n_ctx)
+    e2e_threads = int(user_threads) if user_threads else max(2, min(16, os.cpu_count() or 1) // max(1, info.world))
     os.environ["ORBSLAM3_HIP_UPLOAD_THREADS"] = str(e2e_threads)
     pool = ThreadPoolExecutor(n_ctx)
     list(pool.map(lambda k: drive(k, 1), range(n_ctx)))            # warm-up: staging buffers, device buffers
@@ -561,9 +570,10 @@ def main():
     if e2e_out is not None:
         e2e_windows = args.windows * n_gpus * e2e_out["n_batches"]
         out["value_end_to_end"] = e2e_windows / e2e_out["elapsed"]
-        out["end_to_end"] = {"what": "osh_lba_upload (host packing into pinned staging + H2D) + osh_lba_optimize + osh_lba_download of whole "
-                                     "batches of host-resident windows; several solver contexts, each driven by its own host thread, work on "
-                                     "different batches at once (packing of one batch overlaps the copies and the optimisation of the others)",
+        out["end_to_end"] = {"what": "osh_lba_upload (float32 staging of the caller's arrays + H2D + sort / Schur plan / record build as HIP kernels) + "
+                                     "osh_lba_optimize + osh_lba_download of whole batches of host-resident windows; several solver contexts, each "
+                                     "driven by its own host thread, form a three-stage pipeline (one batch uploading, one optimising, one "
+                                     "downloading at a time)",
                              "contexts": e2e_out["n_ctx"],
                              "batches": e2e_out["n_batches"], "windows_per_batch": args.windows, "ms_per_batch": e2e_out["elapsed"] / e2e_out["n_batches"] * 1e3,
                              "fraction_of_resident": (e2e_windows / e2e_out["elapsed"]) / value,

@@ -183,8 +183,9 @@ int osh_lba_set_pack_mode(osh_lba_ctx* ctx, int mode);
  * stats: bytes compared, sections compared, Schur items, landmark records. */
 int osh_lba_pack_compare(osh_lba_ctx* ctx, int32_t n_windows, const osh_lba_problem* problems, int64_t stats[4]);
 /* Device-side cost of the last osh_lba_upload packed on the device (HIP events, profiling enabled before the upload): ms[0] H2D of the
- * staged problem, ms[1..3] k_pack_pre1 / k_pack_pre2 / k_pack_post, ms[4] staged bytes, ms[5] 1.0 when the batch was packed on the device. */
-int osh_lba_get_pack_profile(osh_lba_ctx* ctx, double ms[6]);
+ * staged problem, ms[1..3] k_pack_pre1 / k_pack_pre2 / k_pack_post, ms[4] staged bytes, ms[5] 1.0 when the batch was packed on the device,
+ * ms[6..29] shader-clock cycles per phase of the three kernels (mean over the windows). */
+int osh_lba_get_pack_profile(osh_lba_ctx* ctx, double ms[30]);
 /* Host-side cost of the last osh_lba_upload: ms[0] packing (sort, Schur plan, staging), ms[1] host-to-device copies. */
 int osh_lba_get_upload_times(osh_lba_ctx* ctx, double ms[2]);
 const char* osh_lba_kernel_name(int kernel_id);

@@ -51,6 +51,7 @@ constexpr double kTau = 1e-5;      // OptimizationAlgorithmLevenberg::_tau
 constexpr int kMaxTrials = 10;     // maxTrialsAfterFailure
 constexpr int kSolveThreadsBatch = 256, kSolveThreadsLatency = 512;
 constexpr int kPoseRec = 21;       // staged pose: quaternion + translation (7), camera (5), rotation matrix (9)
+constexpr int kDevicePackMinWindows = 24;   // smaller batches are packed by host threads (osh_lba_upload)
 constexpr int kLdsPoses = 512;     // windows with more poses read them from global memory in the landmark-major kernels
 
 struct LmState {
@@ -1354,9 +1355,13 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   const auto t0 = std::chrono::steady_clock::now();
   PackedBatch& pb = c->pb;
   hipStream_t s = c->stream;
+  // Default rule: batches go to the device packer (one thread block per window: 512 windows pack in 6 ms of kernels against 65 ms of
+  // 16 host threads); a handful of windows stay on the host, where one thread packs a 50-keyframe window in 1.3 ms -- below the
+  // latency of three one-block kernels and two round trips (1.9 ms, profiles/pack_device.py).
   bool on_device = device_pack_supported(nw, pr);
   if (c->pack_mode >= 0) on_device = on_device && c->pack_mode == 0;
   else if (const char* e = std::getenv("OSH_LBA_PACK")) on_device = on_device && std::strcmp(e, "host") != 0;
+  else on_device = on_device && nw >= kDevicePackMinWindows;
   c->device_packed = on_device;
   if (on_device) {
     const int rc = device_pack_batch(c->dpack, s, nw, pr, default_pack_threads(nw), pb, c->d_arena, c->d_ptwin);
@@ -1882,11 +1887,13 @@ extern "C" int osh_lba_get_plan_stats(osh_lba_ctx* c, int64_t stats[6]) {
 }
 
 // Device-side cost of the last upload packed on the device (HIP events; enable with osh_lba_set_profiling before the upload):
-// ms[0] H2D of the staged problem, ms[1..3] k_pack_pre1 / k_pack_pre2 / k_pack_post, ms[4] staged bytes, ms[5] 1 if the batch was packed on the device
-extern "C" int osh_lba_get_pack_profile(osh_lba_ctx* c, double ms[6]) {
+// ms[0] H2D of the staged problem, ms[1..3] k_pack_pre1 / k_pack_pre2 / k_pack_post, ms[4] staged bytes, ms[5] 1 if the batch was packed on the
+// device, ms[6..29] shader-clock cycles per phase of the three kernels (mean over the windows)
+extern "C" int osh_lba_get_pack_profile(osh_lba_ctx* c, double ms[30]) {
   if (!c || !ms) return OSH_ERR_INVALID;
   for (int k = 0; k < 4; ++k) ms[k] = c->dpack.ev_ms[k];
   ms[4] = (double)c->dpack.raw_bytes; ms[5] = c->device_packed ? 1.0 : 0.0;
+  for (int k = 0; k < 24; ++k) ms[6 + k] = c->dpack.cyc_mean[k];
   return OSH_OK;
 }
 

@@ -20,6 +20,7 @@ struct DevPackState {
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool timing = false;
   double ev_ms[4] = {0, 0, 0, 0};
+  double cyc_mean[24] = {0};   // shader-clock cycles per phase of the three kernels, mean over the windows
   size_t raw_bytes = 0;
   void release_events() { for (hipEvent_t& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; } }
 };

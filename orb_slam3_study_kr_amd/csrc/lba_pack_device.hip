@@ -51,6 +51,7 @@ struct PSum {                  // device -> host, per window
   u64 err_d;                   // landmark << 32 | pose of the first duplicated (pose, landmark) pair
   int nu, ng, n_builds, n_sym, n_cross, recs_sym, recs_cross, n_contrib, n_ccontrib, n_chunks, internal, pad;
   long long tile_steps, pair_blocks;
+  long long cyc[24];           // shader-clock cycles per phase (thread 0): [0..7] k_pack_pre1, [8..17] k_pack_pre2, [18..23] k_pack_post
 };
 struct DBuild {                // one item being built (64 bytes)
   int base, n, cls_idx, rec_rel;
@@ -86,11 +87,11 @@ struct PackArgs {
 };
 
 // ---- scratch layouts (shared by host and device)
-struct S1 { int *lmo, *fill, *t_e, *t_key, *order, *sepose, *slm, *nfree, *unit_off; };
-__host__ __device__ inline size_t s1_ints(int L, int E) { return 4 * (size_t)L + 5 * (size_t)E + 8; }
+struct S1 { int *lmo, *fill, *t_e, *t_key, *t_lm, *order, *sepose, *slm, *nfree, *unit_off; };
+__host__ __device__ inline size_t s1_ints(int L, int E) { return 4 * (size_t)L + 6 * (size_t)E + 8; }
 __host__ __device__ inline S1 s1_of(int* b, int L, int E) {
   S1 s;
-  s.lmo = b; s.fill = s.lmo + (L + 1); s.t_e = s.fill + (L + 1); s.t_key = s.t_e + E; s.order = s.t_key + E; s.sepose = s.order + E;
+  s.lmo = b; s.fill = s.lmo + (L + 1); s.t_e = s.fill + (L + 1); s.t_key = s.t_e + E; s.t_lm = s.t_key + E; s.order = s.t_lm + E; s.sepose = s.order + E;
   s.slm = s.sepose + (E + 1); s.nfree = s.slm + E; s.unit_off = s.nfree + L;
   return s;
 }
@@ -131,6 +132,18 @@ __host__ __device__ inline S3 s3_of(int* b, int P, int nb, int nc, int ncc) {
 __device__ __forceinline__ int wg_add(int* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, OSH_WG); }
 // a value other threads of the block produced with atomics: read it where the atomics were performed (L2), not from the L1
 __device__ __forceinline__ int ld_l2(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Runs of equal keys in consecutive lanes of a wavefront (edges arrive landmark by landmark): `head` lane of the caller's run and the
+// run's length, so that one lane per run touches the landmark's counter (64 same-address atomics of one instruction serialise in L2).
+__device__ __forceinline__ void wave_runs(int key, int& head, int& len) {
+  const int lane = threadIdx.x & 63;
+  const int prev = __shfl_up(key, 1, 64);
+  const u64 hm = __ballot(lane == 0 || prev != key);
+  const u64 below = hm & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+  head = 63 - __clzll((long long)below);
+  const u64 above = (lane == 63) ? 0ull : (hm >> (lane + 1));
+  len = (above ? (lane + 1 + (__ffsll((long long)above) - 1)) : 64) - head;
+}
 
 __device__ __forceinline__ int block_excl_scan(int v, int* sh, int& total) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -281,15 +294,24 @@ __global__ __launch_bounds__(NT) void k_pack_pre1(PackArgs a) {
   __syncthreads();
   // ---- A: validation + landmark histogram
   const bool kb8 = pw.flags & 1, rig = pw.flags & 2;
+  long long tc_last = clock64();
+  int tc_i = 0;
+#define OSH_TC() do { if (tid == 0) { const long long _n = clock64(); sum.cyc[tc_i] = _n - tc_last; tc_last = _n; } ++tc_i; } while (0)
   unsigned bad = 0xffffffffu;
-  for (int e = tid; e < E; e += NT) {
-    const int ip = r_epose[e], il = r_epoint[e], kd = r_kind[e];
-    int cls = -1;
-    if (ip < 0 || ip >= NPw || il < 0 || il >= L || kd > OSH_EDGE_BODY) cls = 0;
-    else if (kb8 && kd == OSH_EDGE_STEREO) cls = 1;
-    else if (kd == OSH_EDGE_BODY && !rig) cls = 2;
-    if (cls >= 0) bad = min(bad, ((unsigned)e << 2) | (unsigned)cls);
-    else wg_add(&s.lmo[il], 1);
+  for (int base = 0; base < E; base += NT) {
+    const int e = base + tid;
+    int il = -1 - (tid & 63);           // lanes without a countable edge: a key of their own
+    if (e < E) {
+      const int ip = r_epose[e], jl = r_epoint[e], kd = r_kind[e];
+      int cls = -1;
+      if (ip < 0 || ip >= NPw || jl < 0 || jl >= L || kd > OSH_EDGE_BODY) cls = 0;
+      else if (kb8 && kd == OSH_EDGE_STEREO) cls = 1;
+      else if (kd == OSH_EDGE_BODY && !rig) cls = 2;
+      if (cls >= 0) bad = min(bad, ((unsigned)e << 2) | (unsigned)cls); else il = jl;
+    }
+    int head, len;
+    wave_runs(il, head, len);
+    if (il >= 0 && head == (tid & 63)) wg_add(&s.lmo[il], len);
   }
   if (bad != 0xffffffffu) atomicMin(&sh_bad, bad);
   __syncthreads();
@@ -297,23 +319,30 @@ __global__ __launch_bounds__(NT) void k_pack_pre1(PackArgs a) {
     if (tid == 0) { sum.err_a = sh_bad; sum.err_k = 0; sum.err_d = ~0ull; sum.nu = 0; sum.internal = 0; }
     return;
   }
+  OSH_TC();   // 0: histogram
   // ---- B: offsets
   block_scan_array(s.lmo, L + 1, shi);
   for (int j = tid; j <= L; j += NT) s.fill[j] = s.lmo[j];
   __syncthreads();
+  OSH_TC();   // 1: offsets
   // ---- C: scatter (any order inside a landmark)
-  for (int e = tid; e < E; e += NT) {
-    const int ip = r_epose[e], il = r_epoint[e], kd = r_kind[e];
-    const int x = wg_add(&s.fill[il], 1);
-    s.t_e[x] = e;
-    s.t_key[x] = (ip << 2) | kd;
+  for (int base = 0; base < E; base += NT) {
+    const int e = base + tid;
+    int il = -1 - (tid & 63), key = 0;
+    if (e < E) { il = r_epoint[e]; key = (r_epose[e] << 2) | r_kind[e]; }
+    int head, len;
+    wave_runs(il, head, len);
+    int x0 = 0;
+    if (il >= 0 && head == (tid & 63)) x0 = wg_add(&s.fill[il], len);
+    const int x = __shfl(x0, head, 64) + ((tid & 63) - head);
+    if (e < E) { s.t_e[x] = e; s.t_key[x] = key; s.t_lm[x] = il; }
   }
   __syncthreads();
+  OSH_TC();   // 2: scatter
   // ---- D: order inside a landmark = rank of the unique key (pose, kind); a pose twice on one landmark is refused
   u64 dup = ~0ull;
   for (int x = tid; x < E; x += NT) {
-    const int e = s.t_e[x], key = s.t_key[x];
-    const int il = r_epoint[e];
+    const int e = s.t_e[x], key = s.t_key[x], il = s.t_lm[x];
     const int lo = s.lmo[il], hi = s.lmo[il + 1];
     int rank = 0, nf = 0;
     bool twice = false;
@@ -332,6 +361,7 @@ __global__ __launch_bounds__(NT) void k_pack_pre1(PackArgs a) {
   if (tid == 0) s.sepose[E] = 0;
   if (dup != ~0ull) atomicMin(&sh_dup, dup);
   __syncthreads();
+  OSH_TC();   // 3: order inside the landmarks
   // ---- E: plan units per landmark
   long long pbk = 0;
   int toomany = 0;
@@ -346,6 +376,7 @@ __global__ __launch_bounds__(NT) void k_pack_pre1(PackArgs a) {
   atomicAdd((u64*)&sh_pb, (u64)pbk);
   __syncthreads();
   const int nu = block_scan_array(s.unit_off, L + 1, shi);
+  OSH_TC();   // 4: units per landmark
   if (tid == 0) {
     sum.err_a = 0xffffffffu; sum.err_d = sh_dup; sum.err_k = sh_k; sum.nu = nu; sum.pair_blocks = sh_pb; sum.internal = 0;
   }
@@ -449,6 +480,8 @@ __global__ __launch_bounds__(NT) void k_pack_pre2(PackArgs a) {
   const S2 z = s2_of(a.s2 + pw.s2, nu, tcap, L);
   if (tid < 16) sh_n[tid] = 0;
   if (tid == 0) sh_ts = 0;
+  long long tc_last = clock64();
+  int tc_i = 8;
   // ---- F: units and their keys
   for (int j = tid; j < L; j += NT) {
     const int k = s.nfree[j];
@@ -474,6 +507,7 @@ __global__ __launch_bounds__(NT) void k_pack_pre2(PackArgs a) {
   }
   for (int t = tid; t < tcap; t += NT) { z.table[t] = -1; z.gcount[t] = 0; }
   __syncthreads();
+  OSH_TC();   // 8: unit keys
   // ---- G: units with equal keys -> one table slot
   for (int i = tid; i < nu; i += NT) {
     u64 k[5];
@@ -501,6 +535,7 @@ __global__ __launch_bounds__(NT) void k_pack_pre2(PackArgs a) {
     wg_add(&z.gcount[slot], 1);
   }
   __syncthreads();
+  OSH_TC();   // 9: grouping
   // compact the used slots (any order: they are sorted next)
   for (int t = tid; t < tcap; t += NT) {
     const int rep = ld_l2(&z.table[t]);
@@ -517,6 +552,7 @@ __global__ __launch_bounds__(NT) void k_pack_pre2(PackArgs a) {
   int npad = 2;
   while (npad < ng) npad <<= 1;
   const bool in_lds = ng <= GL;
+  OSH_TC();   // 10: compaction
   // ---- H: sort the distinct keys (unit_less of schur_plan.h on the key words; keys are distinct, so the order is total)
   int* arr = in_lds ? shord : z.glist;
   for (int t = tid; t < npad; t += NT) arr[t] = t < ng ? t : -1;
@@ -543,12 +579,54 @@ __global__ __launch_bounds__(NT) void k_pack_pre2(PackArgs a) {
       return false;
     });
   }
+  OSH_TC();   // 11: sort of the distinct keys
   // rank of every slot, start of every key's run of units
   for (int g = tid; g < ng; g += NT) { const int c = arr[g]; z.grank[z.gslot[c]] = g; z.gfill[g] = z.gcnt[c]; }
   __syncthreads();
   block_scan_array(z.gfill, ng, shi);
-  // the sorted keys for the merge walk (LDS when they fit)
-  if (in_lds) {
+  const bool masks = pw.P <= 64;   // pose sets as 64-bit masks: the merge walk is a few scalar operations per key
+  u64* M0 = in_lds ? shK : z.uxs;                 // (uxs / uys / gcount are free until the slot bytes are formed)
+  u64* M1 = in_lds ? shK + GL : z.uys;
+  u64* M2 = in_lds ? shK + 2 * GL : reinterpret_cast<u64*>(z.uk[0]);   // unit keys of word 0 are no longer read
+  if (masks) {
+    // per sorted key: masks of its row / column poses, number of units, symmetry
+    u64 mx[(GL + NT - 1) / NT], my[(GL + NT - 1) / NT], sc[(GL + NT - 1) / NT];
+    if (in_lds) {
+#pragma unroll
+      for (int r = 0; r < (GL + NT - 1) / NT; ++r) {
+        const int g = tid + r * NT;
+        mx[r] = my[r] = sc[r] = 0;
+        if (g < ng) {
+          const int c = arr[g];
+          int tmp[8];
+          const int nx = unpack_poses_dev(z.gk[1][c], z.gk[2][c], tmp);
+          for (int q = 0; q < nx; ++q) mx[r] |= 1ull << tmp[q];
+          const int ny = unpack_poses_dev(z.gk[3][c], z.gk[4][c], tmp);
+          for (int q = 0; q < ny; ++q) my[r] |= 1ull << tmp[q];
+          sc[r] = (u64)(unsigned)z.gcnt[c] | ((z.gk[0][c] == 0) ? (1ull << 63) : 0ull);
+        }
+      }
+      __syncthreads();   // the unsorted keys in shK are dead
+#pragma unroll
+      for (int r = 0; r < (GL + NT - 1) / NT; ++r) {
+        const int g = tid + r * NT;
+        if (g < ng) { M0[g] = mx[r]; M1[g] = my[r]; M2[g] = sc[r]; }
+      }
+    } else {
+      for (int g = tid; g < ng; g += NT) {
+        const int c = arr[g];
+        int tmp[8];
+        u64 ax = 0, ay = 0;
+        const int nx = unpack_poses_dev(z.gk[1][c], z.gk[2][c], tmp);
+        for (int q = 0; q < nx; ++q) ax |= 1ull << tmp[q];
+        const int ny = unpack_poses_dev(z.gk[3][c], z.gk[4][c], tmp);
+        for (int q = 0; q < ny; ++q) ay |= 1ull << tmp[q];
+        M0[g] = ax; M1[g] = ay; M2[g] = (u64)(unsigned)z.gcnt[c] | ((z.gk[0][c] == 0) ? (1ull << 63) : 0ull);
+      }
+    }
+    __syncthreads();
+  } else if (in_lds) {
+    // the sorted keys for the generic merge walk
     u64 kq[5] = {0, 0, 0, 0, 0};
     int cn = 0;
     if (tid < ng) {
@@ -565,14 +643,90 @@ __global__ __launch_bounds__(NT) void k_pack_pre2(PackArgs a) {
     }
     __syncthreads();
   }
-  // ---- J: items (sequential by nature: thread 0 walks the sorted keys)
-  if (tid == 0) {
+  OSH_TC();   // 12: ranks, starts, staging
+  // ---- J: items.  The greedy merge of schur_plan.h:plan_window is sequential by nature: thread 0 walks the sorted keys.
+  if (masks) {
+    // spans of merged keys, written over the consumed inputs (span s is emitted after key s was read)
+    if (tid == 0) {
+      u64 cx = 0, cy = 0;
+      int cur0 = 0, cur1 = 0, ns = 0;
+      bool csym = true;
+      auto emit = [&]() { M0[ns] = cx; M1[ns] = cy; M2[ns] = (u64)(unsigned)cur0 | ((u64)(unsigned)(cur1 - cur0) << 32) | (csym ? (1ull << 63) : 0ull); ++ns; cur0 = cur1; };
+      u64 nx0 = ng ? M0[0] : 0, ny0 = ng ? M1[0] : 0, ns0 = ng ? M2[0] : 0;
+      for (int g = 0; g < ng; ++g) {
+        const u64 gx = nx0, gy = ny0, sc = ns0;
+        if (g + 1 < ng) { nx0 = M0[g + 1]; ny0 = M1[g + 1]; ns0 = M2[g + 1]; }
+        const bool gsym = (sc >> 63) != 0;
+        bool merged = false;
+        if (cur1 > cur0 && csym == gsym && (cur1 - cur0) < kItemMaxLm) {
+          const u64 ux = cx | gx, uy = cy | gy;
+          const int nux = __popcll(ux), nuy = __popcll(uy);
+          if (nux <= kItemPoses && nuy <= kItemPoses && tiles_of_dev(nux) == tiles_of_dev(__popcll(cx)) && tiles_of_dev(nux) == tiles_of_dev(__popcll(gx)) &&
+              tiles_of_dev(nuy) == tiles_of_dev(__popcll(cy)) && tiles_of_dev(nuy) == tiles_of_dev(__popcll(gy))) {
+            cx = ux; cy = uy;
+            merged = true;
+          }
+        }
+        if (!merged) {
+          if (cur1 > cur0) emit();
+          cx = gx; cy = gy; csym = gsym;
+        }
+        cur1 += (int)(unsigned)(sc & 0x7fffffffull);
+      }
+      if (cur1 > cur0) emit();
+      sh_n[9] = ns;
+    }
+    __syncthreads();
+    // spans -> items of at most 64 units, in order (symmetric spans come first: key word 0 sorts them so)
+    const int ns = sh_n[9];
+    int carry_b = 0;
+    for (int base = 0; base < ns; base += NT) {
+      const int sidx = base + tid;
+      int nbs = 0, n = 0, b0 = 0;
+      bool sym = false;
+      u64 mx = 0, my = 0;
+      if (sidx < ns) {
+        mx = M0[sidx]; my = M1[sidx];
+        const u64 sc = M2[sidx];
+        b0 = (int)(unsigned)sc; n = (int)((sc >> 32) & 0x7fffffffull); sym = (sc >> 63) != 0;
+        nbs = (n + kItemMaxLm - 1) / kItemMaxLm;
+        if (sym) { atomicAdd(&sh_n[2], nbs); atomicAdd(&sh_n[4], n); } else { atomicAdd(&sh_n[3], nbs); atomicAdd(&sh_n[5], n); }
+      }
+      int tot;
+      const int ex = block_excl_scan(nbs, shi, tot);
+      if (sidx < ns) {
+        DBuild bd;
+        int ncx = 0, ncy = 0;
+        for (int q = 0; q < 8; ++q) { bd.X[q] = 0xffff; bd.Y[q] = 0xffff; }
+        for (u64 m = mx; m; m &= m - 1) bd.X[ncx++] = (unsigned short)(__ffsll((long long)m) - 1);
+        for (u64 m = my; m; m &= m - 1) bd.Y[ncy++] = (unsigned short)(__ffsll((long long)m) - 1);
+        bd.shape = ncx | (ncy << 8) | ((sym ? 1 : 0) << 16);
+        bd.live = 0; bd.clive = 0;
+        for (int k = 0; k < nbs; ++k) {
+          bd.base = b0 + k * kItemMaxLm; bd.n = min(n - k * kItemMaxLm, kItemMaxLm);
+          bd.cls_idx = carry_b + ex + k;     // index among all items; rebased for cross items below
+          bd.rec_rel = bd.base;
+          z.builds[carry_b + ex + k] = bd;
+        }
+      }
+      carry_b += tot;
+    }
+    __syncthreads();
+    if (tid == 0) sh_n[1] = carry_b;
+    // cross items count from their own zero
+    const int nsymb = sh_n[2], nsymr = sh_n[4];
+    for (int b = tid; b < carry_b; b += NT) {
+      if (!((z.builds[b].shape >> 16) & 1)) { z.builds[b].cls_idx -= nsymb; z.builds[b].rec_rel -= nsymr; }
+    }
+  } else if (tid == 0) {
     if (in_lds) greedy_items(ng, [&](int q, int g) { return shK[q * GL + g]; }, [&](int g) { return shcnt[g]; }, z.builds, sh_wk, sh_n + 1);
     else greedy_items(ng, [&](int q, int g) { return z.gk[q][arr[g]]; }, [&](int g) { return z.gcnt[arr[g]]; }, z.builds, sh_wk, sh_n + 1);
   }
   __syncthreads();
+  OSH_TC();   // 13: greedy merge
   // ---- I: units behind their key, creation order (landmark, part pair) kept
   stable_place(nu, [&](int i) { return z.grank[z.ugid[i]]; }, z.gfill, [&](int i, int pos) { z.uorder[pos] = i; }, shk, shi);
+  OSH_TC();   // 14: stable placement of the units
   // ---- landmark renumbering along the owner units (part pair (0,0): one per landmark), then the new offsets
   int carry = 0;
   for (int base = 0; base < nu; base += NT) {
@@ -589,6 +743,7 @@ __global__ __launch_bounds__(NT) void k_pack_pre2(PackArgs a) {
   if (tid == 0) z.lmo_new[L] = 0;
   __syncthreads();
   block_scan_array(z.lmo_new, L + 1, shi);
+  OSH_TC();   // 15: renumbering + offsets
   // ---- chunks of the landmark-major kernels: consecutive landmarks, <= 1024 edges and <= 256 landmarks (lba_pack.h)
   int* nxt = (L <= LCH) ? reinterpret_cast<int*>(shK) : z.nextc;
   for (int j = tid; j < L; j += NT) {
@@ -607,6 +762,7 @@ __global__ __launch_bounds__(NT) void k_pack_pre2(PackArgs a) {
     sh_n[6] = n;
   }
   __syncthreads();
+  OSH_TC();   // 16: chunks
   // ---- K: slot bytes of every unit of every item, live pose pairs of the item
   const int nb = sh_n[1];
   for (int b = wv; b < nb; b += NWV) {
@@ -646,6 +802,7 @@ __global__ __launch_bounds__(NT) void k_pack_pre2(PackArgs a) {
     }
   }
   __syncthreads();
+  OSH_TC();   // 17: slot bytes, live pairs
   if (tid == 0) {
     sum.ng = ng; sum.n_builds = sh_n[1]; sum.n_sym = sh_n[2]; sum.n_cross = sh_n[3]; sum.recs_sym = sh_n[4]; sum.recs_cross = sh_n[5];
     sum.n_chunks = sh_n[6]; sum.n_contrib = sh_n[7]; sum.n_ccontrib = sh_n[8]; sum.tile_steps = sh_ts;
@@ -668,6 +825,9 @@ __global__ __launch_bounds__(NT) void k_pack_post(PackArgs a) {
   const int nb = sm.n_builds, nc = sm.n_contrib, ncc = sm.n_ccontrib;
   const S3 t = s3_of(a.s3 + pw.s3, P, nb, nc, ncc);
   const int nblk = P * (P + 1) / 2;
+  PSum& sum = a.sum[w];
+  long long tc_last = clock64();
+  int tc_i = 18;
   // ---- arena 0: poses, cameras, renumbered landmarks and their offsets
   for (int i = tid; i < NPw * 7; i += NT) a.a_pose[(size_t)pw.pose_off * 7 + i] = a.r_pose[(size_t)pw.pose_off * 7 + i];
   for (int i = tid; i < NPw * 5; i += NT) a.a_cam[(size_t)pw.pose_off * 5 + i] = a.r_cam[(size_t)pw.pose_off * 5 + i];
@@ -698,6 +858,8 @@ __global__ __launch_bounds__(NT) void k_pack_post(PackArgs a) {
     }
   }
   for (int c = tid; c < sm.n_chunks; c += NT) a.a_chunks[pw.chunk_off + c] = z.chunks[c];
+  __syncthreads();
+  OSH_TC();   // 18: arena 0
   // ---- contribution counts per block of S / per pose
   for (int k = tid; k <= nblk; k += NT) t.cnt[k] = 0;
   for (int k = tid; k <= P; k += NT) t.ccnt[k] = 0;
@@ -739,6 +901,7 @@ __global__ __launch_bounds__(NT) void k_pack_post(PackArgs a) {
   }
   block_scan_array(t.bpre, nb + 1, shi);
   block_scan_array(t.cpre, nb + 1, shi);
+  OSH_TC();   // 19: contribution counts + scans
   // ---- block ranges for k_schur_reduce / k_pose_reduce
   for (int i = tid; i < P; i += NT) {
     for (int j = i; j < P; ++j) {
@@ -782,6 +945,7 @@ __global__ __launch_bounds__(NT) void k_pack_post(PackArgs a) {
     if (lane < 8 && ((bd.clive >> lane) & 1)) t.cent[t.cpre[b] + __popc((unsigned)bd.clive & ((1u << lane) - 1u))] = (b << 3) | lane;
   }
   __syncthreads();
+  OSH_TC();   // 20: block ranges, items, records
   // ---- contribution slots: the contributions of one block of S are contiguous, in item order (schur_plan.h)
   stable_place(nc, [&](int q) { const int en = t.ent[q]; const DBuild* bd = z.builds + (en >> 6); return blk(bd->X[(en >> 3) & 7], bd->Y[en & 7]); }, t.cnt,
                [&](int q, int pos) {
@@ -798,6 +962,8 @@ __global__ __launch_bounds__(NT) void k_pack_post(PackArgs a) {
                  const size_t it = (size_t)pw.sym_item_off + bd->cls_idx;   // only symmetric items own rhs slots
                  a.a_scslot[it * 8 + (en & 7)] = pw.ccontrib_off + pos;
                }, shk, shi);
+  OSH_TC();   // 21: contribution slots
+#undef OSH_TC
 }
 
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1027,8 +1193,11 @@ int device_pack_batch(DevPackState& st, hipStream_t s, int nw, const osh_lba_pro
   mark(7);
   DP_HIP(hipGetLastError());
   DP_HIP(hipStreamSynchronize(s));   // pb.win (pageable) and the staging are free again
-  if (st.timing)
+  if (st.timing) {
     for (int k = 0; k < 4; ++k) { float ms = 0.f; if (hipEventElapsedTime(&ms, st.ev[2 * k], st.ev[2 * k + 1]) == hipSuccess) st.ev_ms[k] = ms; }
+    DP_HIP(hipMemcpy(hs, ds, (size_t)nw * sizeof(PSum), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 24; ++k) { double acc = 0; for (int w = 0; w < nw; ++w) acc += (double)hs[w].cyc[k]; st.cyc_mean[k] = acc / nw; }
+  }
   st.device_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
   return OSH_OK;
 }

@@ -85,9 +85,12 @@ class LbaSolver:
         return dict(pack_ms=float(ms[0]), copy_ms=float(ms[1]))
 
     def pack_profile(self) -> dict:
-        ms = np.zeros(6, dtype=np.float64)
+        ms = np.zeros(30, dtype=np.float64)
         capi.check(self.lib.osh_lba_get_pack_profile(self.ctx, capi.ptr(ms, capi.c_double_p)), "osh_lba_get_pack_profile", self.lib)
-        return dict(h2d_ms=float(ms[0]), pre1_ms=float(ms[1]), pre2_ms=float(ms[2]), post_ms=float(ms[3]), staged_bytes=int(ms[4]), on_device=bool(ms[5]))
+        names = ("histogram", "offsets", "scatter", "order", "units", "", "", "", "unit_keys", "grouping", "compaction", "key_sort", "ranks", "greedy_merge",
+                 "place_units", "renumber", "chunks", "slot_bytes", "arena0", "contrib_counts", "items_records", "contrib_slots", "", "")
+        return dict(h2d_ms=float(ms[0]), pre1_ms=float(ms[1]), pre2_ms=float(ms[2]), post_ms=float(ms[3]), staged_bytes=int(ms[4]), on_device=bool(ms[5]),
+                    kcycles={n: round(float(c) / 1e3, 1) for n, c in zip(names, ms[6:]) if n})
 
     def download(self) -> list[LbaResultArrays]:
         n = len(self._windows)

@@ -27,5 +27,6 @@ with lba.LbaSolver(0) as sv:
             print(f"{n:4d} windows, {name:6s} packer: upload {ms:7.2f} ms  host pass {up['pack_ms']:6.2f} ms  rest {up['copy_ms']:6.2f} ms", end="")
             if mode == 0:
                 print(f"  | H2D {pp['h2d_ms']:.2f} ms ({pp['staged_bytes'] / 1e6:.0f} MB)  k_pack_pre1 {pp['pre1_ms']:.3f}  k_pack_pre2 {pp['pre2_ms']:.3f}  k_pack_post {pp['post_ms']:.3f} ms")
+                print("      kilo-cycles per phase (mean over windows):", pp["kcycles"])
             else:
                 print()

@@ -109,3 +109,17 @@ def test_both_packers_give_bitwise_equal_optimisations(solver):
     for a, b in zip(*out):
         assert a.iterations == b.iterations and a.trials == b.trials
         assert np.array_equal(a.pose_qt, b.pose_qt) and np.array_equal(a.points, b.points) and np.array_equal(a.edge_chi2, b.edge_chi2)
+
+
+def test_default_rule_batches_on_the_device_single_windows_on_the_host(solver):
+    """The default rule sends batches to the device packer and a handful of windows to host threads; a batch packed on the device gives
+    the same bits as its windows solved one at a time (packed on the host)."""
+    ws = [synth.make_window(300 + i, n_free=4 + i % 5, n_fixed=1 + i % 3, n_points=120 + 15 * i, stereo=bool(i % 2)) for i in range(32)]
+    solver.set_pack_mode(-1)
+    batch = solver.solve(ws)
+    assert solver.pack_profile()["on_device"]
+    for i in (0, 7, 19, 31):
+        one = solver.solve([ws[i]])[0]
+        assert not solver.pack_profile()["on_device"]
+        assert one.iterations == batch[i].iterations
+        assert np.array_equal(one.pose_qt, batch[i].pose_qt) and np.array_equal(one.points, batch[i].points) and np.array_equal(one.edge_chi2, batch[i].edge_chi2)
