@@ -146,7 +146,8 @@ def run_lba(args, info, windows):
         step()
     torch.cuda.synchronize()
     osh_dist.barrier(info)
-    elapsed = osh_dist.all_reduce_max(info, time.perf_counter() - t0)
+    elapsed_local = time.perf_counter() - t0
+    elapsed = osh_dist.all_reduce_max(info, elapsed_local)
     results_parts = [sv.download() for sv in solvers]
     results = [None] * len(windows)
     for k, rp in enumerate(results_parts):
@@ -165,7 +166,101 @@ def run_lba(args, info, windows):
     solver.set_profiling(False)
     solver.close()
     alg, alg_impl = kernel_algorithmic_bytes(windows, results)
-    return dict(windows=windows, results=results, elapsed=elapsed, upload_s=upload_s, prof=prof, alg=alg, alg_impl=alg_impl, plan=plan)
+    return dict(windows=windows, results=results, elapsed=elapsed, elapsed_local=elapsed_local, upload_s=upload_s, prof=prof, alg=alg, alg_impl=alg_impl, plan=plan)
+
+
+def run_batch_sweep(args, info, windows):
+    """windows/s against the batch size B in {1, 8, 64, 256}: the HBM-resident optimize() and the whole
+    osh_lba_solve (upload + optimize + download) of one context, one batch at a time; B = 1 is the live-SLAM call pattern
+    (LocalMapping.cc:154-160), its times are the single-window latencies."""
+    from orb_slam3_study_kr_amd import lba
+    out = {}
+    with lba.LbaSolver(info.local_rank) as sv:
+        for B in (1, 8, 64, 256):
+            ws = windows[:B]
+            if len(ws) < B:
+                break
+            probs, res, _ = sv.prepare(ws)
+            sv.upload_prepared(ws, probs)
+            sv.optimize()
+            reps = 5 if B <= 8 else 3
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                sv.optimize()
+            opt_ms = (time.perf_counter() - t0) / reps * 1e3
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                sv.upload_prepared(ws, probs)
+                sv.optimize()
+                sv.download_prepared(res)
+            call_ms = (time.perf_counter() - t0) / reps * 1e3
+            out[str(B)] = dict(optimize_ms=opt_ms, windows_per_s_resident=B / (opt_ms * 1e-3), solve_call_ms=call_ms,
+                               windows_per_s_end_to_end=B / (call_ms * 1e-3), packed_on="device" if sv.pack_profile()["on_device"] else "host")
+    return out
+
+
+def run_orb_sweep(args, info):
+    """frame pairs/s of osh_orb_match_local_points against the batch size B in {1, 64, 1024}."""
+    from orb_slam3_study_kr_amd import orb
+    base = synth.make_orb_pair(7, 2000, 2000)
+    rng = np.random.Generator(np.random.PCG64(7100))
+    out = {}
+    for B in (1, 64, 1024):
+        pairs = []
+        for k in range(min(B, 64)):      # 64 distinct query sets, cycled
+            q = base.query_desc ^ np.packbits(rng.uniform(0, 1, (2000, 256)) < 0.01, axis=1)
+            pairs.append(synth.OrbPair(np.ascontiguousarray(q), base.train_desc, base.train_level))
+        pairs = [pairs[k % len(pairs)] for k in range(B)]
+        m = orb.OrbMatcher(info.local_rank)
+        m.upload(pairs)
+        m.match_local_points()
+        reps = 10 if B <= 64 else 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            n_matches, _, _, _ = m.match_local_points()
+        dt = (time.perf_counter() - t0) / reps
+        m.close()
+        out[str(B)] = dict(ms_per_call=dt * 1e3, frame_pairs_per_s=B / dt, matches_per_s=float(n_matches.sum()) / dt, pair_evals_per_s=B * 4.0e6 / dt)
+    return out
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_all_cores(windows, budget_s=10.0):
+    """SURVEY.md 8(d) CPU baseline (ii): every host core solves its own window (the oracle is one thread per solve; ctypes releases
+    the GIL), for a bounded time."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import binding as ob
+    try:
+        ob.load(native=True)
+        native = True
+    except Exception:
+        native = False
+    n_cores = os.cpu_count() or 1
+    deadline = time.perf_counter() + budget_s
+
+    def work(k):
+        n = 0
+        while time.perf_counter() < deadline:
+            ob.lba_solve(windows[(k + n * n_cores) % len(windows)], native=native)
+            n += 1
+        return n
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(n_cores) as pool:
+        done = sum(pool.map(work, range(n_cores)))
+    dt = time.perf_counter() - t0
+    return dict(value=done / dt, unit="windows/s", cores=n_cores, kind="port", nproc=n_cores, cpu_model=cpu_model(),
+                sample=f"{done} solves of the same config-2 windows, one window per core on {n_cores} threads ({dt:.1f} s)",
+                march="native" if native else "x86-64-v3")
 
 
 def run_end_to_end(args, info, windows):
@@ -296,15 +391,17 @@ def search_by_projection_end_to_end(n_kp=2000, n_mp=2000, reps=20):
     f = host.HostFrame(xy, octave, desc)
     try:
         n, _ = f.search_local_points(mp_desc, proj, level, viewcos, nnratio=0.8, th=3.0)
-        t0 = time.perf_counter()
+        ms = 0.0
         for _ in range(reps):
             f.search_local_points(mp_desc, proj, level, viewcos, nnratio=0.8, th=3.0)
-        ms = (time.perf_counter() - t0) / reps * 1e3
+            ms += f.lib.osh_host_last_call_ms()    # the ORBmatcher::SearchByProjection call alone, timed inside the C++ wrapper
+        ms /= reps
     finally:
         f.close()
     return dict(call="ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th=3, ...) through the drop-in ORBmatcher.cc",
                 keypoints=n_kp, map_points=n_mp, matches=int(n), ms_per_call=ms, matches_per_s=n / (ms * 1e-3),
-                includes="host gather + H2D + windowed device search + D2H + host replay of the slot occupancy; python harness call overhead too")
+                includes="the C++ call alone (steady_clock around it inside the harness wrapper: no Python, no construction of the map points): "
+                         "host gather + H2D + windowed device search + occupancy rounds + D2H")
 
 
 def fuse_end_to_end(n_kp=2000, n_mp=2000, reps=10):
@@ -335,21 +432,23 @@ def fuse_end_to_end(n_kp=2000, n_mp=2000, reps=10):
     try:
         args = (pos, mp_desc, np.stack([mind, maxd], axis=1), normal, nobs, slot_res, res_nobs)
         n, _ = f.fuse(*args)
-        t0 = time.perf_counter()
+        ms = 0.0
         for _ in range(reps):
             f.fuse(*args)
-        ms = (time.perf_counter() - t0) / reps * 1e3
+            ms += f.lib.osh_host_last_call_ms()    # the ORBmatcher::Fuse call alone, timed inside the C++ wrapper
+        ms /= reps
     finally:
         f.close()
     return dict(call="ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th=3) through the drop-in ORBmatcher.cc", keypoints=n_kp, map_points=n_mp,
                 fused=int(n), ms_per_call=ms,
-                includes="test harness (builds the keyframe, 2000 + 1000 map points and their observations: most of the time) + projection gates + "
-                         "candidate lists + H2D + device search + D2H + ordered replay")
+                includes="the C++ call alone (steady_clock around it inside the harness wrapper): projection gates + candidate lists + H2D + device "
+                         "search + D2H + ordered replace / add replay on the map")
 
 
 def make_inertial_inputs(args):
     from orb_slam3_study_kr_amd import synth_inertial as si
-    base = [si.make_inertial_window(11 + k) for k in range(8)]       # BASELINE.json configs[3] shape
+    # BASELINE.json configs[3] / SURVEY.md 8(d) config 4: 10 temporal + 1 + 20 fixed keyframes, ~2 000 landmarks (3 600 candidates, the visible ones stay)
+    base = [si.make_inertial_window(11 + k, n_points=3600) for k in range(8)]
     return [base[k % len(base)] for k in range(args.inertial_windows)]
 
 
@@ -383,7 +482,8 @@ def run_inertial(args, info, windows):
         r = solver.solve_inertial([w])[0]
         map_ba[name] = dict(ms=(time.perf_counter() - t0) * 1e3, keyframes=n_opt, landmarks=w.n_points, edges=w.n_edges, lm_iterations=int(r.iterations))
     solver.close()
-    out = dict(metric="LocalInertialBA windows/sec (10 temporal KF + 21 fixed, ~1.1k landmarks, ~16.7k stereo edges, IMU preintegration edges)",
+    out = dict(metric=f"LocalInertialBA windows/sec (10 temporal KF + 21 fixed, {int(np.mean([w.n_points for w in windows]))} landmarks, "
+                      f"{int(np.mean([w.n_edges for w in windows]))} stereo edges, IMU preintegration edges)",
                map_sized=map_ba,
                windows_per_s=len(windows) / batch_s, windows_per_batch=len(windows), single_window_latency_ms=single_ms,
                lm_iterations_mean=float(np.mean([r.iterations for r in res])), includes="H2D upload + D2H download", dtype="f64 (+f32 preintegration getters)")
@@ -446,12 +546,16 @@ def stub_main(args):
     for _ in range(args.steps):
         time.sleep(0.01)
     osh_dist.barrier(info)
-    elapsed = osh_dist.all_reduce_max(info, time.perf_counter() - t0)
+    elapsed_local = time.perf_counter() - t0
+    elapsed = osh_dist.all_reduce_max(info, elapsed_local)
     done = osh_dist.all_reduce_sum(info, [float(len(my))])[0]
+    ranks_seen = int(round(osh_dist.all_reduce_sum(info, [1.0])[0]))
+    per_rank = osh_dist.all_gather_floats(info, len(my) / (elapsed_local / args.steps))
     if info.rank == 0:
         ms = elapsed / args.steps * 1e3
         print(json.dumps({"metric": "stub", "stub": True, "value": done / (ms * 1e-3), "unit": "windows/s", "n_gpus": info.world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "scaling": "weak",
+                          "ranks_seen": ranks_seen, "windows_per_s_by_rank": per_rank,
                           "config": {"windows_per_gpu": args.windows, "global_windows": int(done)}}))
     osh_dist.finalize(info)
 
@@ -470,6 +574,7 @@ def main():
     ap.add_argument("--prepare-only", action="store_true", help="generate (and cache) the inputs, then exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-orb", action="store_true")
+    ap.add_argument("--no-sweeps", action="store_true", help="skip the batch-size sub-tables (config 2: B = 1, 8, 64, 256; config 3: B = 1, 64, 1024)")
     ap.add_argument("--inertial-windows", type=int, default=128, help="config-4 windows per osh_liba_solve call (0 = skip)")
     ap.add_argument("--e2e-contexts", type=int, default=4, help="solver contexts (each with its own host thread, stream and pinned staging) of the end-to-end run")
     ap.add_argument("--e2e-batches", type=int, default=6, help="batches per solver context in the end-to-end (upload + optimize + download) run; 0 = skip")
@@ -498,12 +603,17 @@ def main():
 
     lba_out = run_lba(args, info, windows)
     e2e_out = run_end_to_end(args, info, windows) if args.e2e_batches > 0 else None
+    sweep_out = run_batch_sweep(args, info, windows) if (info.rank == 0 and not args.no_sweeps) else None
+    orb_sweep_out = run_orb_sweep(args, info) if (info.rank == 0 and not args.no_sweeps and not args.no_orb) else None
     orb_out = None if args.no_orb else run_orb(args, info)
     inertial_out = run_inertial(args, info, inertial_windows) if inertial_windows else None
 
     n_gpus = info.world
     ms_per_step = lba_out["elapsed"] / args.steps * 1e3
     value = args.windows * n_gpus / (ms_per_step * 1e-3)
+    # what the process group saw: an all-reduce of 1 over RCCL (= the number of ranks that took part) and every rank's own rate
+    ranks_seen = int(round(osh_dist.all_reduce_sum(info, [1.0])[0]))
+    per_rank = osh_dist.all_gather_floats(info, args.windows / (lba_out["elapsed_local"] / args.steps))
 
     # roofline of the dominant step of the loop (largest total HIP-event time in one optimize()); a step is one or
     # more kernels (STEP_KERNELS), its launch time the sum of theirs, its algorithmic bytes SURVEY.md 8(d)'s figure
@@ -519,6 +629,7 @@ def main():
     roofline = dict(bound="hbm", kernel=dom + " = " + " + ".join(lba.kernel_symbol(k) for k in STEP_KERNELS[dom]),
                     achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=achieved / HBM_PEAK_GBS, traffic=measured_traffic(dom, args.windows),
+                    frac_measured=(measured_traffic(dom, args.windows) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (measured_traffic(dom, args.windows) and avg_ms > 0) else None,
                     avg_launch_ms=avg_ms, launches=launches, algorithmic_bytes_per_launch=alg[dom] / max(launches, 1),
                     bytes_this_implementation_needs_per_launch=alg_impl[dom] / max(launches, 1), frac_of_needed_bytes=achieved_impl / HBM_PEAK_GBS,
                     avg_ms_by_kernel={lba.kernel_symbol(k): prof[k][1] / max(prof[k][0], 1) for k in STEP_KERNELS[dom]},
@@ -566,7 +677,12 @@ def main():
         "kernels": kernels, "step_times": steps,
         "whole_job_alg_GBps_per_gpu": whole_bytes / (ms_per_step * 1e-3) / 1e9,
         "upload_s_per_batch": lba_out["upload_s"],
+        "ranks_seen": ranks_seen, "windows_per_s_by_rank": per_rank,
     }
+    if sweep_out:
+        out["config2_batch_sweep"] = sweep_out
+        if "1" in sweep_out:
+            out["single_window_latency_ms"] = {"local_ba_optimize": sweep_out["1"]["optimize_ms"], "local_ba_solve_call": sweep_out["1"]["solve_call_ms"]}
     if e2e_out is not None:
         e2e_windows = args.windows * n_gpus * e2e_out["n_batches"]
         out["value_end_to_end"] = e2e_windows / e2e_out["elapsed"]
@@ -595,18 +711,25 @@ def main():
                                   "unit": "T lane-ops/s", "frac": pe * 16 / 39.3e12, "ops_per_pair_eval_algorithmic": 16,
                                   "ops_per_pair_eval_measured": 23.4, "frac_of_issue_slots_measured": pe * 23.4 / 39.3e12,
                                   "pair_evals_per_s_kernel": pe, "traffic": None}
+        if orb_sweep_out:
+            out["orb"]["config3_batch_sweep"] = orb_sweep_out
         if orb_out.get("sbp"):
             out["orb"]["search_by_projection_end_to_end"] = orb_out["sbp"]
         if orb_out.get("fuse"):
             out["orb"]["fuse_end_to_end"] = orb_out["fuse"]
     if inertial_out is not None:
         out["inertial"] = inertial_out
+        out.setdefault("single_window_latency_ms", {})["local_inertial_ba_call"] = inertial_out["single_window_latency_ms"]
     if info.rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(lba_out["windows"])
         # like for like: the CPU path builds its structure inside the timed call, so the speed-up is quoted on the end-to-end rate
         out["speedup_vs_cpu_1thread"] = (out.get("value_end_to_end") or value) / out["cpu_baseline"]["value"]
         out["speedup_vs_cpu_1thread_resident_loop_only"] = value / out["cpu_baseline"]["value"]
         out["cpu_baseline"]["flags"] = "gcc -O3 -march=native -ffp-contract=off (the reference builds with -O3 -march=native, which allows contraction)"
+        out["cpu_baseline"]["nproc"] = os.cpu_count()
+        out["cpu_baseline"]["cpu_model"] = cpu_model()
+        out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(lba_out["windows"])
+        out["speedup_vs_cpu_all_cores"] = (out.get("value_end_to_end") or value) / out["cpu_baseline_all_cores"]["value"]
         if orb_out is not None:
             from oracle import binding as ob
             p = orb_out["pair0"]

@@ -15,6 +15,10 @@ extern "C" {
 
 typedef struct osh_host_graph osh_host_graph;
 
+/* Wall time (ms) of the product call (Optimizer:: / ORBmatcher:: entry point) inside the last harness wrapper on this thread,
+ * without the construction of the KeyFrame / MapPoint / Frame objects around it. */
+double osh_host_last_call_ms(void);
+
 /* Build a map: n_kf keyframes (ids kf_id, poses Tcw as qx qy qz qw tx ty tz floats, one shared pinhole
  * fx fy cx cy + bf), n_mp map points, n_obs observations (keyframe index, point index, u v ur with ur<0 for
  * monocular, octave).  Keypoint k of a keyframe is its k-th observation in array order. */

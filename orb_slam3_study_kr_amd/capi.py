@@ -255,6 +255,7 @@ _HOST_SIGNATURES = {
     "osh_host_graph_create": (C.c_void_p, [C.c_int32, c_int64_p, c_float_p, c_float_p, c_float_p, C.c_int32, C.c_int32, c_int64_p,
                                            c_float_p, C.c_int32, c_int32_p, c_int32_p, c_float_p, c_int32_p, C.c_int64, C.c_int32]),
     "osh_host_graph_destroy": (None, [C.c_void_p]),
+    "osh_host_last_call_ms": (C.c_double, []),
     "osh_host_graph_set_fisheye": (None, [C.c_void_p, c_float_p]),
     "osh_host_graph_set_rig": (C.c_int, [C.c_void_p, c_float_p, c_float_p, C.c_int32, c_int32_p, c_int32_p, c_float_p, c_int32_p]),
     "osh_host_last_pack_rig": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),

@@ -1,5 +1,6 @@
 // harness.cc -- extern "C" wrappers around the C++ host layer (include/orbslam3_hip_host.h).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <memory>
 #include <set>
@@ -30,6 +31,15 @@ struct osh_host_graph {
 static Sophus::SE3f pose_from(const float* qt) {
   return Sophus::SE3f(Eigen::Quaternionf(qt[3], qt[0], qt[1], qt[2]), Eigen::Vector3f(qt[4], qt[5], qt[6]));
 }
+
+// Wall time of the product call inside the last harness wrapper on this thread (the wrappers build KeyFrame / MapPoint / Frame
+// objects around it; bench.py reports the call alone).
+static thread_local double g_last_call_ms = 0.0;
+struct CallTimer {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  ~CallTimer() { g_last_call_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+extern "C" double osh_host_last_call_ms(void) { return g_last_call_ms; }
 
 extern "C" osh_host_graph* osh_host_graph_create(int32_t n_kf, const int64_t* kf_id, const float* kf_pose_qt, const float* cam5,
                                                  const float* inv_level_sigma2, int32_t n_levels, int32_t n_mp,
@@ -144,6 +154,7 @@ extern "C" int osh_host_pack_lba(osh_host_graph* g, int32_t kf_index, int32_t si
 }
 
 extern "C" int osh_host_run_lba(osh_host_graph* g, int32_t kf_index, unsigned char* stop_flag, int32_t counts[4]) {
+  CallTimer timed;
   if (!g || kf_index < 0 || kf_index >= (int)g->kfs.size()) return -1;
   static_assert(sizeof(bool) == 1, "bool is one byte");
   int a = -1, b = -1, c = -1, d = -1;
@@ -324,6 +335,7 @@ extern "C" int osh_host_pack_liba(osh_host_graph* g, int32_t kf_index, int32_t b
 extern "C" int osh_host_run_liba(osh_host_graph* g, int32_t kf_index, int32_t b_large, int32_t b_rec_init) {
   if (!g || kf_index < 0 || kf_index >= (int)g->kfs.size()) return -1;
   int a = -1, b = -1, c = -1, d = -1;
+  CallTimer timed;
   Optimizer::LocalInertialBA(g->kfs[kf_index].get(), nullptr, &g->map, a, b, c, d, b_large != 0, b_rec_init != 0);
   return (a == -1 && b == -1 && c == -1 && d == -1) ? 0 : 2;   // the reference never assigns the num_* outputs
 }
@@ -542,7 +554,8 @@ extern "C" int osh_host_search_local_points_rig(osh_host_frame* f, int32_t n_mp,
   }
   f->F.mvpMapPoints.assign(f->F.N, nullptr);
   ORBmatcher matcher(nnratio);
-  const int n = matcher.SearchByProjection(f->F, vp, th);
+  int n;
+  { CallTimer timed; n = matcher.SearchByProjection(f->F, vp, th); }
   for (int k = 0; k < f->F.N; ++k) assignment[k] = f->F.mvpMapPoints[k] ? (int32_t)f->F.mvpMapPoints[k]->mnId : -1;
   f->F.mvpMapPoints.assign(f->F.N, nullptr);
   return n;
@@ -566,7 +579,8 @@ extern "C" int osh_host_search_local_points(osh_host_frame* f, int32_t n_mp, con
   }
   f->F.mvpMapPoints.assign(f->F.N, nullptr);
   ORBmatcher matcher(nnratio);
-  const int n = matcher.SearchByProjection(f->F, vp, th);
+  int n;
+  { CallTimer timed; n = matcher.SearchByProjection(f->F, vp, th); }
   for (int k = 0; k < f->F.N; ++k) assignment[k] = f->F.mvpMapPoints[k] ? (int32_t)f->F.mvpMapPoints[k]->mnId : -1;
   f->F.mvpMapPoints.assign(f->F.N, nullptr);
   return n;
@@ -766,7 +780,8 @@ extern "C" int osh_host_fuse(osh_host_frame* f, int32_t n_mp, const float* mp_po
   std::vector<MapPoint*> vpMapPoints;
   for (int j = 0; j < n_mp; ++j) vpMapPoints.push_back((null_mask && null_mask[j]) ? nullptr : cands[j].get());
   ORBmatcher matcher(0.6f, true);
-  const int n = matcher.Fuse(&kf, vpMapPoints, th);
+  int n;
+  { CallTimer timed; n = matcher.Fuse(&kf, vpMapPoints, th); }
   for (int k = 0; k < F.N; ++k) slot_out[k] = kf.mvpMapPoints[k] ? (int32_t)kf.mvpMapPoints[k]->mnId : -1;
   for (int j = 0; j < n_mp; ++j) {
     cand_bad_out[j] = cands[j]->isBad() ? 1 : 0;

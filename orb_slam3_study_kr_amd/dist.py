@@ -74,6 +74,18 @@ def all_reduce_sum(info: RankInfo, values: list[float]) -> list[float]:
     return [float(x) for x in t.tolist()]
 
 
+def all_gather_floats(info: RankInfo, value: float) -> list[float]:
+    """One float of every rank, in rank order (an all_gather over the process group)."""
+    if not info.initialised:
+        return [float(value)]
+    import torch
+    import torch.distributed as dist
+    t = _tensor(info, [value])
+    out = [torch.zeros_like(t) for _ in range(info.world)]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]
+
+
 def finalize(info: RankInfo):
     if info.initialised:
         import torch.distributed as dist

@@ -39,6 +39,9 @@ def test_bench_gpus_2_starts_two_ranks():
     assert out["n_gpus"] == 2 and out["stub"] is True
     assert out["config"]["global_windows"] == 10           # 5 windows per rank, both ranks counted
     assert abs(out["value"] - 10 / (out["ms_per_step"] * 1e-3)) < 1e-6
+    # what the process group itself saw: an all-reduce of 1 counted both ranks, the all-gather returned one rate per rank
+    assert out["ranks_seen"] == 2
+    assert len(out["windows_per_s_by_rank"]) == 2 and all(v > 0 for v in out["windows_per_s_by_rank"])
 
 
 def test_wrong_world_size_fails_loudly():
