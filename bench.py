@@ -180,7 +180,7 @@ def run_batch_sweep(args, info, windows):
             ws = windows[:B]
             if len(ws) < B:
                 break
-            probs, res, _ = sv.prepare(ws)
+            probs, res, outs = sv.prepare(ws)     # `outs` owns the result arrays `res` points into: keep it alive
             sv.upload_prepared(ws, probs)
             sv.optimize()
             reps = 5 if B <= 8 else 3
@@ -196,6 +196,7 @@ def run_batch_sweep(args, info, windows):
             call_ms = (time.perf_counter() - t0) / reps * 1e3
             out[str(B)] = dict(optimize_ms=opt_ms, windows_per_s_resident=B / (opt_ms * 1e-3), solve_call_ms=call_ms,
                                windows_per_s_end_to_end=B / (call_ms * 1e-3), packed_on="device" if sv.pack_profile()["on_device"] else "host")
+            del outs
     return out
 
 
@@ -224,6 +225,22 @@ def run_orb_sweep(args, info):
     return out
 
 
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU box hands a 16-core share
+    of a 256-thread host to each GPU)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(round(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -244,7 +261,7 @@ def cpu_baseline_all_cores(windows, budget_s=10.0):
         native = True
     except Exception:
         native = False
-    n_cores = os.cpu_count() or 1
+    n_cores = usable_cores()
     deadline = time.perf_counter() + budget_s
 
     def work(k):
@@ -258,7 +275,7 @@ def cpu_baseline_all_cores(windows, budget_s=10.0):
     with ThreadPoolExecutor(n_cores) as pool:
         done = sum(pool.map(work, range(n_cores)))
     dt = time.perf_counter() - t0
-    return dict(value=done / dt, unit="windows/s", cores=n_cores, kind="port", nproc=n_cores, cpu_model=cpu_model(),
+    return dict(value=done / dt, unit="windows/s", cores=n_cores, kind="port", nproc=os.cpu_count(), usable_cores=n_cores, cpu_model=cpu_model(),
                 sample=f"{done} solves of the same config-2 windows, one window per core on {n_cores} threads ({dt:.1f} s)",
                 march="native" if native else "x86-64-v3")
 
@@ -303,7 +320,7 @@ def run_end_to_end(args, info, windows):
     # staging threads of an upload: one batch is staged at a time, so it may take the host cores of this rank (all ranks of a node
     # share them: divide by the world size)
     user_threads = os.environ.get("ORBSLAM3_HIP_UPLOAD_THREADS")
-    e2e_threads = int(user_threads) if user_threads else max(2, min(16, os.cpu_count() or 1) // max(1, info.world))
+    e2e_threads = int(user_threads) if user_threads else max(2, min(16, usable_cores()) // max(1, info.world))
     os.environ["ORBSLAM3_HIP_UPLOAD_THREADS"] = str(e2e_threads)
     pool = ThreadPoolExecutor(n_ctx)
     list(pool.map(lambda k: drive(k, 1), range(n_ctx)))            # warm-up: staging buffers, device buffers
@@ -727,6 +744,7 @@ def main():
         out["speedup_vs_cpu_1thread_resident_loop_only"] = value / out["cpu_baseline"]["value"]
         out["cpu_baseline"]["flags"] = "gcc -O3 -march=native -ffp-contract=off (the reference builds with -O3 -march=native, which allows contraction)"
         out["cpu_baseline"]["nproc"] = os.cpu_count()
+        out["cpu_baseline"]["usable_cores"] = usable_cores()
         out["cpu_baseline"]["cpu_model"] = cpu_model()
         out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(lba_out["windows"])
         out["speedup_vs_cpu_all_cores"] = (out.get("value_end_to_end") or value) / out["cpu_baseline_all_cores"]["value"]
