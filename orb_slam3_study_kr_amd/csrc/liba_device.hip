@@ -76,6 +76,7 @@ struct LibaView {
   int force_heavy;            // diagnostic: keep the agent-scope fences even when a group shares an XCD (OSH_LIBA_HEAVY_BARRIER=1)
   double* out_chi2; unsigned char* out_depth;   // result arena: per edge, caller's order
   int* res_abort; double* res_pose; double* res_vba; double* res_pts;   // result arena: abort word, final [sum N][24], [sum N][9], [sum L][3]
+  int test_abort;   // OSH_LIBA_TEST_ABORT: make the first group barrier of the launch give up (exercises the one-block retry)
 };
 
 // deterministic block reductions over kLT threads
@@ -124,6 +125,7 @@ struct Grp {
   int light;            // 1: every block of the group runs on the same XCD (checked at start), so they share one L2: a barrier then only
                         // has to drain this block's stores to L2 and drop this CU's L1, not write back and invalidate the L2
   unsigned gen, nred;
+  int test_abort;       // test hook (OSH_LIBA_TEST_ABORT): the first barrier of the launch gives up at once
 };
 constexpr unsigned kSpinLimit = 1u << 22;   // polls (about a microsecond each) before a barrier gives up
 
@@ -138,9 +140,9 @@ __device__ __forceinline__ bool grp_sync(Grp& g, int* lds_flag) {
     else __threadfence();
     atomicAdd(g.bar, 1u);
     const unsigned target = g.gen * (unsigned)g.G;
-    int good = 1;
+    int good = g.test_abort ? 0 : 1;
     unsigned spins = 0;
-    while (__hip_atomic_load(g.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    while (good && __hip_atomic_load(g.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
       if ((++spins & 255u) == 0 && (spins > kSpinLimit || __hip_atomic_load(g.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { good = 0; break; }
     }
@@ -1001,7 +1003,7 @@ __global__ __launch_bounds__(kLT) void k_liba(LibaView v, int W, int G) {
   const int tid = threadIdx.x;
   Grp g;
   g.bar = v.bar + win; g.abort_flag = v.abort_flag; g.res_abort = v.res_abort; g.red = v.red + (size_t)win * 4 * kLG * 2; g.G = G; g.m = (bid >> 3) % G;
-  g.gen = 0; g.nred = 0; g.light = 0;
+  g.gen = 0; g.nred = 0; g.light = 0; g.test_abort = v.test_abort;
   const int m = g.m, GT = G * kLT, gt = m * kLT + tid, GW = G * (kLT / 64);
   const int N = d.N, n = d.n, L = d.L, n6 = 6 * d.N;
   // LDS carve: [0, ldlt) the LDL^T scratch (reused as general scratch between solves), then control words
@@ -1424,26 +1426,41 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
     }
   }
   // blocks per window: the tracker's single window (and small batches) get a group of 32 = one whole XCD; a large batch fills the chip
-  // with one block per window.  A group needs all its blocks resident (they meet at barriers): cooperative launch checks that.
+  // with one block per window.  A group needs all its blocks resident (they meet at barriers): the grid is kept within what the device
+  // holds at once (occupancy query) and launched as an ordinary kernel.  (hipLaunchCooperativeKernel would check the same, but it
+  // makes the runtime create a second, cooperative HSA queue, and under rocprofv3 the process then faults at exit inside
+  // libhsa-runtime64's shutdown, called from libamdhip64's exit handler, on that queue's device mapping -- resolved from the fault
+  // report and /proc/self/maps by profiles/exit_probe.py; k_liba was the only cooperative launch of the library.)
   int G = nw <= 8 ? kLG : (nw <= 16 ? 16 : (nw <= 32 ? 8 : (nw <= 64 ? 4 : (nw <= 128 ? 2 : 1))));
   if (const char* gs = getenv("OSH_LIBA_GROUP")) { const int gv = atoi(gs); if (gv == 1 || gv == 2 || gv == 4 || gv == 8 || gv == 16 || gv == 32) G = gv; }
   int W_arg = W;
-  hipError_t le = hipSuccess;
   const void* kfn = NB == 24 ? (const void*)k_liba<24> : (const void*)k_liba<6>;
-  if (G > 1) {
-    void* args[] = {(void*)&v, (void*)&W_arg, (void*)&G};
-    le = hipLaunchCooperativeKernel(kfn, dim3((unsigned)((nw + 7) / 8 * 8 * G)), dim3(kLT), args, (unsigned)lds, s);
-    // not enough free CUs for every group to be resident, or no cooperative launches on this device: one block per window needs neither
-    if (le != hipSuccess) { (void)hipGetLastError(); G = 1; le = hipSuccess; }
+  {
+    int per_cu = 0, n_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, kLT, lds) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) {
+      (void)hipGetLastError();
+      per_cu = 0;
+    }
+    while (G > 1 && (long long)((nw + 7) / 8 * 8) * G > (long long)per_cu * n_cu) G >>= 1;
   }
-  if (G == 1) {
-    int one = 1;
-    void* args[] = {(void*)&v, (void*)&W_arg, (void*)&one};
-    le = hipLaunchKernel(kfn, dim3((unsigned)((nw + 7) / 8 * 8)), dim3(kLT), args, lds, s);
+  auto run = [&](int Gx, int test_abort) -> int {
+    v.test_abort = test_abort;
+    int g_arg = Gx;
+    void* args[] = {(void*)&v, (void*)&W_arg, (void*)&g_arg};
+    const hipError_t le = hipLaunchKernel(kfn, dim3((unsigned)((nw + 7) / 8 * 8 * Gx)), dim3(kLT), args, lds, s);
+    if (le != hipSuccess) { set_error("k_liba launch failed: %s", hipGetErrorString(le)); return OSH_ERR_DEVICE; }
+    OSH_HIP(hipMemcpyAsync(hr, dres, out_bytes, hipMemcpyDeviceToHost, s));
+    OSH_HIP(hipStreamSynchronize(s));
+    return OSH_OK;
+  };
+  OSH_TRY(run(G, (G > 1 && getenv("OSH_LIBA_TEST_ABORT")) ? 1 : 0));
+  if (*reinterpret_cast<const int*>(hr + r_abort) && G > 1) {
+    // A barrier of a block group gave up (blocks of other streams kept part of a group off the device for seconds): the same
+    // problem once more with one block per window, which has no barrier to wait at.  The estimates live in the input arena: upload again.
+    OSH_HIP(hipMemcpyAsync(din, hs, in_bytes, hipMemcpyHostToDevice, s));
+    G = 1;
+    OSH_TRY(run(1, 0));
   }
-  if (le != hipSuccess) { set_error("k_liba launch failed: %s", hipGetErrorString(le)); return OSH_ERR_DEVICE; }
-  OSH_HIP(hipMemcpyAsync(hr, dres, out_bytes, hipMemcpyDeviceToHost, s));
-  OSH_HIP(hipStreamSynchronize(s));
   if (*reinterpret_cast<const int*>(hr + r_abort)) { set_error("k_liba: a barrier of a window's block group did not complete (group of %d blocks)", G); return OSH_ERR_DEVICE; }
   const LibaOut* h_out = reinterpret_cast<const LibaOut*>(hr + r_out);
   g_liba_last_group = G;

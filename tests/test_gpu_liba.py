@@ -141,6 +141,24 @@ def test_agent_scope_barrier_path_agrees(solver, monkeypatch):
     np.testing.assert_array_equal(a.points, b.points)
 
 
+def test_a_barrier_that_gives_up_is_retried_with_one_block_per_window(solver, monkeypatch):
+    """A group barrier that times out (blocks of other streams kept part of the group off the device) sets the abort word; the call
+    then runs the same problem once more with one block per window instead of failing.  OSH_LIBA_TEST_ABORT makes the first barrier
+    of the first launch give up at once: the result must be the one-block result, bit for bit."""
+    w = si.make_inertial_window(47)
+    monkeypatch.setenv("OSH_LIBA_GROUP", "1")
+    one = solver.solve_inertial([w])[0]
+    monkeypatch.delenv("OSH_LIBA_GROUP")
+    monkeypatch.setenv("OSH_LIBA_TEST_ABORT", "1")
+    got = solver.solve_inertial([w])[0]
+    assert solver.inertial_profile()[0] == 1          # the launch that produced the result ran one block per window
+    np.testing.assert_array_equal(got.chi2_trace, one.chi2_trace)
+    np.testing.assert_array_equal(got.pose_twb, one.pose_twb)
+    np.testing.assert_array_equal(got.points, one.points)
+    monkeypatch.delenv("OSH_LIBA_TEST_ABORT")
+    assert solver.solve_inertial([w])[0].iterations == one.iterations and solver.inertial_profile()[0] == 32
+
+
 def test_large_window_of_25_keyframes(solver, ob):
     """LocalInertialBA's bLarge case: 25 temporal keyframes (src/Optimizer.cc:2394-2400), a 375 x 375 reduced system."""
     w = si.make_inertial_window(61, n_opt=25, n_fixed=10, n_points=1500, large=True)
