@@ -22,6 +22,10 @@ class MapPoint {
   void EraseObservation(KeyFrame* pKF);
   bool isBad() { return mbBad; }
   bool IsInKeyFrame(KeyFrame* pKF) { return mObservations.count(pKF) != 0; }   // src/MapPoint.cc:420-424
+  std::tuple<int, int> GetIndexInKeyFrame(KeyFrame* pKF) {                      // src/MapPoint.cc:411-418
+    const auto it = mObservations.find(pKF);
+    return it != mObservations.end() ? it->second : std::tuple<int, int>(-1, -1);
+  }
   void Replace(MapPoint* pMP);                                                  // src/MapPoint.cc:248-297
   MapPoint* GetReplaced() { return mpReplaced; }
   void IncreaseVisible(int n = 1) { mnVisible += n; }

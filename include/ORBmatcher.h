@@ -40,6 +40,9 @@ class ORBmatcher {
   // Matching to triangulate new MapPoints. Check Epipolar Constraint. (include/ORBmatcher.h:75-76, src/ORBmatcher.cc:907-1146)
   int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<std::pair<size_t, size_t>>& vMatchedPairs, const bool bOnlyStereo,
                              const bool bCoarse = false);
+  // Search matches between MapPoints seen in KF1 and KF2 transforming by a Sim3 [s12*R12|t12] (include/ORBmatcher.h:78-81,
+  // src/ORBmatcher.cc:1457-1674; LoopClosing::DetectCommonRegionsFromBoW after the Sim3 solver)
+  int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const Sophus::Sim3f& S12, const float th);
   // Project MapPoints into KeyFrame and search for duplicated MapPoints (include/ORBmatcher.h:87, src/ORBmatcher.cc:1148-1338)
   int Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const float th = 3.0, const bool bRight = false);
   // Project MapPoints into KeyFrame using a given Sim3 and search for duplicated MapPoints (include/ORBmatcher.h:90, src/ORBmatcher.cc:1340-1455)

@@ -132,7 +132,7 @@ class SE3 {
 };
 using SE3f = SE3<float>;
 using SE3d = SE3<double>;
-// Sim3 as rotation + translation + scale; only the accessors ORBmatcher::SearchByProjection(KeyFrame*, Sim3f&, ...) uses.
+// Sim3 as rotation + translation + scale; only what ORBmatcher::SearchByProjection(KeyFrame*, Sim3f&, ...) and SearchBySim3 use.
 template <class T>
 class Sim3 {
  public:
@@ -141,6 +141,19 @@ class Sim3 {
   Eigen::Matrix<T, 3, 3> rotationMatrix() const { return rot_.rotationMatrix(); }
   const Eigen::Matrix<T, 3>& translation() const { return t_; }
   T scale() const { return s_; }
+  // p_out = s R p + t (what ORBmatcher::SearchBySim3 applies to camera-frame points)
+  Eigen::Matrix<T, 3> operator*(const Eigen::Matrix<T, 3>& p) const {
+    const Eigen::Matrix<T, 3> r = rot_ * p;
+    return Eigen::Matrix<T, 3>(s_ * r(0) + t_(0), s_ * r(1) + t_(1), s_ * r(2) + t_(2));
+  }
+  // (s R, t)^-1 = (R^T / s, -R^T t / s)
+  Sim3 inverse() const {
+    const Eigen::Quaternion<T>& q = rot_.unit_quaternion();
+    const Eigen::Quaternion<T> qi(q.w(), -q.x(), -q.y(), -q.z());
+    const SE3<T> ri(qi, Eigen::Matrix<T, 3>(0, 0, 0));
+    const Eigen::Matrix<T, 3> rt = ri * t_;
+    return Sim3(qi, Eigen::Matrix<T, 3>(-rt(0) / s_, -rt(1) / s_, -rt(2) / s_), T(1) / s_);
+  }
  private:
   SE3<T> rot_;
   Eigen::Matrix<T, 3> t_;

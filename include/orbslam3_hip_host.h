@@ -223,6 +223,14 @@ int osh_host_posei_pack(osh_host_posei* h, int32_t rec_init, osh_posei_problem* 
 int osh_host_posei_run(osh_host_posei* h, int32_t rec_init, float pose_out[7], float Rwb_out[9], float twb_out[3], float vel_out[3],
                        float bias6_out[6], uint8_t* outlier_out, double* H225_out, int32_t* prev_cpi_deleted);
 
+/* ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, S12, th) (src/ORBmatcher.cc:1457-1674), two frames standing in for the keyframes.
+ * slot_mp_k[i]: index of the map point in keypoint slot i of keyframe k (into its own point list) or -1; matches_in[i1]: keyframe-2
+ * point already matched to slot i1 or -1; matches_out[i1]: keyframe-2 point index or -1.  s12 = qx qy qz qw tx ty tz s. */
+int osh_host_search_by_sim3(osh_host_frame* f1, osh_host_frame* f2, const float s12[8], float th,
+                            int32_t n_mp1, const float* mp_pos1, const uint8_t* mp_desc1, const float* mp_min_max1, const uint8_t* mp_bad1,
+                            const int32_t* slot_mp1, int32_t n_mp2, const float* mp_pos2, const uint8_t* mp_desc2, const float* mp_min_max2,
+                            const uint8_t* mp_bad2, const int32_t* slot_mp2, const int32_t* matches_in, int32_t* matches_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -472,6 +472,25 @@ def orb_fuse_sim3(q_desc, feat_desc, skip, cand_off, cand_idx, stereo, slot, slo
     return int(n), slot, nobs, replace
 
 
+def orb_search_by_sim3(desc_mp1, desc_mp2, desc_kf1, desc_kf2, skip1, off1, idx1, skip2, off2, idx2, th_high=100):
+    """ORBmatcher::SearchBySim3 after its projection gates (orb_oracle.c:oracle_orb_search_by_sim3): per keypoint slot of each keyframe the
+    descriptor of the map point it holds and the candidate slots of the other keyframe.  Returns nFound and match12 (slot of keyframe 2 or -1)."""
+    lib = load()
+    i32, u8 = C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+    lib.oracle_orb_search_by_sim3.restype = C.c_int
+    lib.oracle_orb_search_by_sim3.argtypes = [C.c_int, C.c_int, u8, u8, u8, u8, u8, i32, i32, u8, i32, i32, C.c_int, i32]
+    a = [np.ascontiguousarray(x, dtype=np.uint8) for x in (desc_mp1, desc_mp2, desc_kf1, desc_kf2)]
+    s1, s2 = np.ascontiguousarray(skip1, dtype=np.uint8), np.ascontiguousarray(skip2, dtype=np.uint8)
+    o1, o2 = np.ascontiguousarray(off1, dtype=np.int32), np.ascontiguousarray(off2, dtype=np.int32)
+    x1 = np.ascontiguousarray(idx1 if len(idx1) else [0], dtype=np.int32)
+    x2 = np.ascontiguousarray(idx2 if len(idx2) else [0], dtype=np.int32)
+    n1, n2 = len(s1), len(s2)
+    m12 = -np.ones(n1, dtype=np.int32)
+    n = lib.oracle_orb_search_by_sim3(n1, n2, _u8(a[0]), _u8(a[1]), _u8(a[2]), _u8(a[3]), _u8(s1), _i32(o1), _i32(x1), _u8(s2), _i32(o2), _i32(x2), int(th_high),
+                                      _i32(m12))
+    return int(n), m12
+
+
 def orb_search_for_triangulation(desc1, desc2, has_mp1, has_mp2, fv1, fv2, kp1, kp2, octave2, F12, ep, scale_factors, level_sigma2, only_stereo=False,
                                  coarse=False, th_low=50, check_ori=True):
     """ORBmatcher::SearchForTriangulation on two pinhole keyframes, restated (orb_oracle.c).  kp = x y angle uright per feature."""

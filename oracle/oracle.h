@@ -84,6 +84,9 @@ int  oracle_orb_search_for_initialization(int n1, int n2, const uint8_t* desc1, 
 int  oracle_orb_fuse(int n_q, int n_res, int n_feat, const uint8_t* q_desc, const uint8_t* feat_desc, const uint8_t* skip,
                      const int32_t* cand_off, const int32_t* cand_idx, const uint8_t* stereo, int th_low,
                      int32_t* slot, int32_t* nobs, uint8_t* bad, int32_t* replaced, uint8_t* in_kf);
+int  oracle_orb_search_by_sim3(int n1, int n2, const uint8_t* desc_mp1, const uint8_t* desc_mp2, const uint8_t* desc_kf1, const uint8_t* desc_kf2,
+                               const uint8_t* skip1, const int32_t* off1, const int32_t* idx1, const uint8_t* skip2, const int32_t* off2,
+                               const int32_t* idx2, int th_high, int32_t* match12);
 int  oracle_orb_fuse_sim3(int n_q, const uint8_t* q_desc, const uint8_t* feat_desc, const uint8_t* skip, const int32_t* cand_off,
                           const int32_t* cand_idx, const uint8_t* stereo, const uint8_t* slot_bad, int th_low, int32_t* slot, int32_t* nobs,
                           int32_t* replace);

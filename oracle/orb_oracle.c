@@ -522,6 +522,46 @@ int oracle_orb_fuse_sim3(int n_q, const uint8_t* q_desc, const uint8_t* feat_des
 }
 
 
+/* ORBmatcher::SearchBySim3 -- src/ORBmatcher.cc:1457-1674, after the projection gates (the caller lists, per keypoint slot of one
+ * keyframe that holds a usable map point, the candidates KeyFrame::GetFeaturesInArea returns in the OTHER keyframe, in its order,
+ * already restricted to the levels L-1 .. L; skipK[i] = the slot has no query: no point, bad point, already matched, or a gate failed).
+ * Per direction the first candidate at the smallest distance wins (`dist < bestDist`, :1549,1629) if that distance is <= TH_HIGH;
+ * a pair is a match when each side chose the other (:1659-1673).  match12[i1] = slot of keyframe 2 or -1; returns nFound. */
+int oracle_orb_search_by_sim3(int n1, int n2, const uint8_t* desc_mp1, const uint8_t* desc_mp2, const uint8_t* desc_kf1, const uint8_t* desc_kf2,
+                              const uint8_t* skip1, const int32_t* off1, const int32_t* idx1, const uint8_t* skip2, const int32_t* off2,
+                              const int32_t* idx2, int th_high, int32_t* match12) {
+  int32_t* m1 = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n1 + 1));
+  int32_t* m2 = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n2 + 1));
+  for (int i = 0; i < n1; ++i) {
+    m1[i] = -1;
+    if (skip1[i]) continue;
+    int best = 0x7fffffff, bi = -1;
+    for (int c = off1[i]; c < off1[i + 1]; ++c) {
+      const int d = oracle_descriptor_distance(desc_mp1 + 32 * (size_t)i, desc_kf2 + 32 * (size_t)idx1[c]);
+      if (d < best) { best = d; bi = idx1[c]; }
+    }
+    if (best <= th_high) m1[i] = bi;
+  }
+  for (int i = 0; i < n2; ++i) {
+    m2[i] = -1;
+    if (skip2[i]) continue;
+    int best = 0x7fffffff, bi = -1;
+    for (int c = off2[i]; c < off2[i + 1]; ++c) {
+      const int d = oracle_descriptor_distance(desc_mp2 + 32 * (size_t)i, desc_kf1 + 32 * (size_t)idx2[c]);
+      if (d < best) { best = d; bi = idx2[c]; }
+    }
+    if (best <= th_high) m2[i] = bi;
+  }
+  int n_found = 0;
+  for (int i1 = 0; i1 < n1; ++i1) {
+    match12[i1] = -1;
+    const int i2 = m1[i1];
+    if (i2 >= 0 && m2[i2] == i1) { match12[i1] = i2; ++n_found; }
+  }
+  free(m1); free(m2);
+  return n_found;
+}
+
 /* ORBmatcher::SearchForTriangulation -- src/ORBmatcher.cc:907-1146, two pinhole keyframes (no mpCamera2).  kp = x y angle uright per
  * feature (uright < 0: monocular), F12 = K1^-T [t12]x R12 K2^-1 row-major (src/CameraModels/Pinhole.cpp:107-112), ep = the epipole in
  * image 2, level_sigma2_2 / scale_factor_2 by octave of keyframe 2.  Per unmatched feature of keyframe 1, in the order of the

@@ -256,6 +256,8 @@ _HOST_SIGNATURES = {
                                            c_float_p, C.c_int32, c_int32_p, c_int32_p, c_float_p, c_int32_p, C.c_int64, C.c_int32]),
     "osh_host_graph_destroy": (None, [C.c_void_p]),
     "osh_host_last_call_ms": (C.c_double, []),
+    "osh_host_search_by_sim3": (C.c_int, [C.c_void_p, C.c_void_p, c_float_p, C.c_float, C.c_int32, c_float_p, c_uint8_p, c_float_p, c_uint8_p, c_int32_p,
+                                          C.c_int32, c_float_p, c_uint8_p, c_float_p, c_uint8_p, c_int32_p, c_int32_p, c_int32_p]),
     "osh_host_graph_set_fisheye": (None, [C.c_void_p, c_float_p]),
     "osh_host_graph_set_rig": (C.c_int, [C.c_void_p, c_float_p, c_float_p, C.c_int32, c_int32_p, c_int32_p, c_float_p, c_int32_p]),
     "osh_host_last_pack_rig": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),

@@ -672,6 +672,87 @@ int ORBmatcher::SearchByProjection(KeyFrame* pKF, Sophus::Sim3<float>& Scw, cons
 
 namespace {
 
+// the keypoints of a keyframe as a search target (mvKeysUn, mGrid: what KeyFrame::GetFeaturesInArea(x, y, r) walks)
+Train train_of(KeyFrame* pKF, int N) {
+  Train t;
+  t.desc = &pKF->mDescriptors;
+  t.level.resize(N); t.xy.resize((size_t)N * 2); t.skip.assign(N, 0);
+  for (int i = 0; i < N; ++i) { t.level[i] = pKF->mvKeysUn[i].octave; t.xy[2 * i] = pKF->mvKeysUn[i].pt.x; t.xy[2 * i + 1] = pKF->mvKeysUn[i].pt.y; }
+  t.min_x = (float)pKF->mnMinX; t.min_y = (float)pKF->mnMinY; t.winv = pKF->mfGridElementWidthInv; t.hinv = pKF->mfGridElementHeightInv;
+  t.cols = pKF->mnGridCols; t.rows = pKF->mnGridRows;
+  return t;
+}
+
+// One direction of SearchBySim3 (src/ORBmatcher.cc:1497-1576 / :1578-1657): the map points of keyframe `from` that are not matched
+// yet, moved into the camera of keyframe `to` by Tfw and then S, searched among `to`'s keypoints of levels L-1 .. L around the
+// projection.  No slot occupancy: every query is independent, so the device result IS the loop's result.
+bool sim3_direction(KeyFrame* to_kf, const float fx, const float fy, const float cx, const float cy, const Sophus::SE3f& Tfw, const Sophus::Sim3f& S,
+                    const std::vector<MapPoint*>& vpFrom, const std::vector<bool>& vbAlready, int n_to, float th, int th_high, std::vector<int>& vnMatch) {
+  Train t = train_of(to_kf, n_to);
+  Search s;
+  std::vector<int> qSlot;
+  for (int i = 0, n = (int)vpFrom.size(); i < n; ++i) {
+    MapPoint* pMP = vpFrom[i];
+    if (!pMP || vbAlready[i]) continue;
+    if (pMP->isBad()) continue;
+    const Eigen::Vector3f p3Dw = pMP->GetWorldPos();
+    const Eigen::Vector3f p3Df = Tfw * p3Dw;
+    const Eigen::Vector3f p3Dt = S * p3Df;
+    if (p3Dt(2) < 0.0) continue;                                   // depth must be positive
+    const float invz = 1.0 / p3Dt(2);
+    const float x = p3Dt(0) * invz, y = p3Dt(1) * invz;
+    const float u = fx * x + cx, v = fy * y + cy;
+    if (!to_kf->IsInImage(u, v)) continue;
+    const float maxDistance = pMP->GetMaxDistanceInvariance();
+    const float minDistance = pMP->GetMinDistanceInvariance();
+    const float dist3D = std::sqrt(p3Dt(0) * p3Dt(0) + p3Dt(1) * p3Dt(1) + p3Dt(2) * p3Dt(2));
+    if (dist3D < minDistance || dist3D > maxDistance) continue;   // inside the scale invariance region
+    const int nPredictedLevel = pMP->PredictScale(dist3D, to_kf);
+    const float radius = th * to_kf->mvScaleFactors[nPredictedLevel];
+    s.add(pMP->GetDescriptor(), u, v, radius, std::max(nPredictedLevel - 1, 0), nPredictedLevel);
+    qSlot.push_back(i);
+  }
+  if (!device_search(s, t)) return false;
+  for (int q = 0; q < s.nq(); ++q)
+    if (s.best_idx[q] >= 0 && s.best_dist[q] <= th_high) vnMatch[qSlot[q]] = s.best_idx[q];
+  return true;
+}
+
+}  // namespace
+
+// src/ORBmatcher.cc:1457-1674: both directions as one batched device search each, then the agreement check (:1659-1673).
+int ORBmatcher::SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const Sophus::Sim3f& S12, const float th) {
+  const Sophus::SE3f T1w = pKF1->GetPose();
+  const Sophus::SE3f T2w = pKF2->GetPose();
+  const Sophus::Sim3f S21 = S12.inverse();
+  const std::vector<MapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches();
+  const int N1 = (int)vpMapPoints1.size();
+  const std::vector<MapPoint*> vpMapPoints2 = pKF2->GetMapPointMatches();
+  const int N2 = (int)vpMapPoints2.size();
+  std::vector<bool> vbAlreadyMatched1(N1, false), vbAlreadyMatched2(N2, false);
+  for (int i = 0; i < N1; i++) {
+    MapPoint* pMP = vpMatches12[i];
+    if (pMP) {
+      vbAlreadyMatched1[i] = true;
+      const int idx2 = std::get<0>(pMP->GetIndexInKeyFrame(pKF2));
+      if (idx2 >= 0 && idx2 < N2) vbAlreadyMatched2[idx2] = true;
+    }
+  }
+  std::vector<int> vnMatch1(N1, -1), vnMatch2(N2, -1);
+  // the reference projects with pKF1's fx fy cx cy in BOTH directions (:1459-1462, 1520-1521, 1600-1601)
+  const float fx = pKF1->fx, fy = pKF1->fy, cx = pKF1->cx, cy = pKF1->cy;
+  if (!sim3_direction(pKF2, fx, fy, cx, cy, T1w, S21, vpMapPoints1, vbAlreadyMatched1, N2, th, TH_HIGH, vnMatch1)) return 0;
+  if (!sim3_direction(pKF1, fx, fy, cx, cy, T2w, S12, vpMapPoints2, vbAlreadyMatched2, N1, th, TH_HIGH, vnMatch2)) return 0;
+  int nFound = 0;
+  for (int i1 = 0; i1 < N1; i1++) {
+    const int idx2 = vnMatch1[i1];
+    if (idx2 >= 0 && vnMatch2[idx2] == i1) { vpMatches12[i1] = vpMapPoints2[idx2]; nFound++; }
+  }
+  return nFound;
+}
+
+namespace {
+
 // one batched device search over explicit candidate lists (osh_orb_upload with cand_off / cand_idx): best / second-best distance of
 // every query among its list, positions in list order
 bool device_search_lists(const std::vector<uint8_t>& qdesc, const cv::Mat& train, int n_train, const std::vector<int32_t>& off,

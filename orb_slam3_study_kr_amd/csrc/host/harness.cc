@@ -723,6 +723,55 @@ extern "C" int osh_host_search_sim3(osh_host_frame* f, const float scw[8], int32
   return n;
 }
 
+// The frame's keypoints, descriptors, pyramid, grid and pose as a KeyFrame (what the KeyFrame constructor copies from a Frame).
+static void keyframe_from_frame(KeyFrame& kf, osh_host_frame* f) {
+  Frame& F = f->F;
+  kf.N = F.N;
+  kf.mvKeys = F.mvKeys; kf.mvKeysUn = F.mvKeysUn; kf.mvuRight = F.mvuRight;
+  kf.mDescriptors = F.mDescriptors;
+  kf.mvScaleFactors = F.mvScaleFactors; kf.mnScaleLevels = F.mnScaleLevels; kf.mfLogScaleFactor = F.mfLogScaleFactor;
+  kf.mpCamera = F.mpCamera;
+  kf.fx = F.fx; kf.fy = F.fy; kf.cx = F.cx; kf.cy = F.cy; kf.mbf = F.mbf;
+  kf.mnGridCols = FRAME_GRID_COLS; kf.mnGridRows = FRAME_GRID_ROWS;
+  kf.mfGridElementWidthInv = F.mfGridElementWidthInv; kf.mfGridElementHeightInv = F.mfGridElementHeightInv;
+  kf.mnMinX = (int)F.mnMinX; kf.mnMinY = (int)F.mnMinY; kf.mnMaxX = (int)F.mnMaxX; kf.mnMaxY = (int)F.mnMaxY;
+  kf.mGrid.assign(FRAME_GRID_COLS, std::vector<std::vector<size_t>>(FRAME_GRID_ROWS));
+  for (int i = 0; i < FRAME_GRID_COLS; ++i)
+    for (int j = 0; j < FRAME_GRID_ROWS; ++j) kf.mGrid[i][j] = F.mGrid[i][j];
+  kf.mvpMapPoints.assign(F.N, nullptr);
+  kf.SetPose(F.GetPose());
+}
+
+// ORBmatcher(0.75, true).SearchBySim3(pKF1, pKF2, vpMatches12, S12, th) (src/ORBmatcher.cc:1457-1674) with two frames standing in for
+// the keyframes.  Map points of keyframe k sit in its keypoint slots (slot_mp_k[i] = index into that keyframe's point list or -1);
+// matches_in[i1] = index of a keyframe-2 point already matched to slot i1 or -1.  matches_out[i1] = keyframe-2 point index or -1.
+extern "C" int osh_host_search_by_sim3(osh_host_frame* f1, osh_host_frame* f2, const float s12[8], float th,
+                                       int32_t n_mp1, const float* mp_pos1, const uint8_t* mp_desc1, const float* mp_min_max1, const uint8_t* mp_bad1,
+                                       const int32_t* slot_mp1, int32_t n_mp2, const float* mp_pos2, const uint8_t* mp_desc2, const float* mp_min_max2,
+                                       const uint8_t* mp_bad2, const int32_t* slot_mp2, const int32_t* matches_in, int32_t* matches_out) {
+  if (!f1 || !f2) return -1;
+  KeyFrame kf1(1, &f1->map), kf2(2, &f1->map);
+  keyframe_from_frame(kf1, f1);
+  keyframe_from_frame(kf2, f2);
+  auto pts1 = make_points(&f1->map, n_mp1, mp_desc1, mp_pos1, nullptr);
+  auto pts2 = make_points(&f1->map, n_mp2, mp_desc2, mp_pos2, nullptr);
+  for (int j = 0; j < n_mp1; ++j) { pts1[j]->mfMinDistance = mp_min_max1[2 * j]; pts1[j]->mfMaxDistance = mp_min_max1[2 * j + 1]; pts1[j]->mbBad = mp_bad1 && mp_bad1[j]; }
+  for (int j = 0; j < n_mp2; ++j) {
+    pts2[j]->mnId = 100000 + (unsigned long)j;
+    pts2[j]->mfMinDistance = mp_min_max2[2 * j]; pts2[j]->mfMaxDistance = mp_min_max2[2 * j + 1]; pts2[j]->mbBad = mp_bad2 && mp_bad2[j];
+  }
+  for (int i = 0; i < kf1.N; ++i) if (slot_mp1[i] >= 0) { kf1.mvpMapPoints[i] = pts1[slot_mp1[i]].get(); pts1[slot_mp1[i]]->AddObservation(&kf1, i); }
+  for (int i = 0; i < kf2.N; ++i) if (slot_mp2[i] >= 0) { kf2.mvpMapPoints[i] = pts2[slot_mp2[i]].get(); pts2[slot_mp2[i]]->AddObservation(&kf2, i); }
+  std::vector<MapPoint*> vpMatches12(kf1.N, nullptr);
+  for (int i = 0; i < kf1.N; ++i) if (matches_in && matches_in[i] >= 0) vpMatches12[i] = pts2[matches_in[i]].get();
+  Sophus::Sim3f S12(Eigen::Quaternionf(s12[3], s12[0], s12[1], s12[2]), Eigen::Vector3f(s12[4], s12[5], s12[6]), s12[7]);
+  ORBmatcher matcher(0.75f, true);
+  int n;
+  { CallTimer timed; n = matcher.SearchBySim3(&kf1, &kf2, vpMatches12, S12, th); }
+  for (int i = 0; i < kf1.N; ++i) matches_out[i] = vpMatches12[i] ? (int32_t)(vpMatches12[i]->mnId - 100000) : -1;
+  return n;
+}
+
 // ORBmatcher::Fuse(pKF, vpMapPoints, th) with the frame standing in for the keyframe (pose = the frame's).  Candidates j in
 // [0, n_mp) (null_mask[j]: a null entry of vpMapPoints), residents r in [0, n_res) sitting in keypoint slots (slot_res[k] = r or
 // -1).  Every point starts with n_obs observations in keyframes of its own (monocular dummies), residents in this keyframe too.

@@ -394,6 +394,24 @@ class HostFrame:
         return n, slot, repl, nobs
 
 
+    def search_by_sim3(self, other: "HostFrame", s12, pts1: dict, pts2: dict, matches_in=None, th=7.5):
+        """ORBmatcher(0.75, true).SearchBySim3(pKF1, pKF2, vpMatches12, S12, th) (src/ORBmatcher.cc:1457-1674), this frame as keyframe 1
+        and ``other`` as keyframe 2.  ``pts_k``: pos [n,3], desc [n,32], min_max [n,2], bad [n], slot [N_k] (point index per keypoint
+        slot or -1).  Returns nFound and, per slot of keyframe 1, the matched keyframe-2 point index or -1."""
+        u8 = lambda a: np.ascontiguousarray(a, dtype=np.uint8)
+        fp, ip, bp = capi.c_float_p, capi.c_int32_p, capi.c_uint8_p
+        keep = [_f32(s12)]
+        for p in (pts1, pts2):
+            keep += [_f32(p["pos"]), u8(p["desc"]), _f32(p["min_max"]), u8(p["bad"]), _i32(p["slot"])]
+        keep.append(_i32(matches_in if matches_in is not None else -np.ones(self.n)))
+        out = -np.ones(self.n, dtype=np.int32)
+        n = self.lib.osh_host_search_by_sim3(self.f, other.f, capi.ptr(keep[0], fp), float(th),
+                                             len(pts1["pos"]), capi.ptr(keep[1], fp), capi.ptr(keep[2], bp), capi.ptr(keep[3], fp), capi.ptr(keep[4], bp), capi.ptr(keep[5], ip),
+                                             len(pts2["pos"]), capi.ptr(keep[6], fp), capi.ptr(keep[7], bp), capi.ptr(keep[8], fp), capi.ptr(keep[9], bp), capi.ptr(keep[10], ip),
+                                             capi.ptr(keep[11], ip), capi.ptr(out, ip))
+        return n, out
+
+
 def _quat_from_R(R):
     return synth._quat_from_R(np.asarray(R, dtype=np.float64))
 

@@ -561,6 +561,104 @@ def test_search_by_projection_sim3_equals_sequential_reference(ob, with_keyframe
     assert side.any() and bad.any()
 
 
+def test_search_by_sim3_equals_reference(ob):
+    """ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:1457-1674; LoopClosing after the Sim3 solver): the unmatched map points of each
+    keyframe are moved into the other camera (T1w then S21 = S12^-1; T2w then S12), gated (depth, image, scale-invariance distances),
+    searched among the keypoints of levels L-1 .. L around the projection -- first candidate at the smallest distance, accepted within
+    TH_HIGH -- and a pair is kept when both directions agree.  Both keyframes use keyframe 1's intrinsics (:1459-1462)."""
+    rng = np.random.Generator(np.random.PCG64(91))
+    f32 = np.float32
+    n_kp = 650
+    fx, fy, cx, cy = (f32(v) for v in (synth.FX, synth.FY, synth.CX, synth.CY))
+    xy1, oct1, desc1, _, _, _, _ = _frame_and_points(51, n_kp=n_kp, n_mp=10)
+    # keyframe 2 sees the same scene shifted by a few pixels; its keypoints are a shuffled subset plus clutter
+    perm = rng.permutation(n_kp)
+    xy2 = (xy1[perm] + rng.normal(0, 1.0, (n_kp, 2))).astype(f32)
+    xy2[:, 0] = np.clip(xy2[:, 0], 1, synth.IMG_W - 2); xy2[:, 1] = np.clip(xy2[:, 1], 1, synth.IMG_H - 2)
+    oct2 = np.clip(oct1[perm] + rng.integers(-1, 1, n_kp), 0, synth.N_LEVELS - 1).astype(np.int32)
+    desc2 = desc1[perm] ^ np.packbits(rng.uniform(0, 1, (n_kp, 256)) < 0.05, axis=1)
+    clutter = rng.uniform(0, 1, n_kp) < 0.2
+    desc2[clutter] = rng.integers(0, 256, (int(clutter.sum()), 32), dtype=np.uint8)
+    # S12 = (I, t12, s12): p1 = s12 p2 + t12; the poses are pure translations (T1w = (I, t1), T2w = (I, t2))
+    s12 = f32(0.9)
+    t12 = np.array([0.05, -0.02, 0.1], dtype=f32)
+    t1 = np.array([0.3, 0.1, -0.2], dtype=f32)
+    t2 = np.array([-0.4, 0.2, 0.1], dtype=f32)
+    s21 = f32(f32(1) / s12)
+    t21 = (-t12 / s12).astype(f32)
+
+    def points_seen_at(xy, octave, to_cam1, depth_lo=4, depth_hi=10):
+        """World positions of points that project near `xy`: chosen in camera 1 (`to_cam1`) or camera 2 coordinates."""
+        n = len(xy)
+        depth = rng.uniform(depth_lo, depth_hi, n)
+        noisy = xy + rng.normal(0, 0.7, xy.shape)
+        Xc = np.stack([(noisy[:, 0] - float(cx)) / float(fx) * depth, (noisy[:, 1] - float(cy)) / float(fy) * depth, depth], axis=1)
+        maxd = (depth * synth.SCALE_FACTORS[octave].astype(np.float64) * rng.uniform(0.9, 1.05, n)).astype(f32)
+        mind = (maxd / f32(synth.SCALE_FACTORS[-1]) * f32(0.5)).astype(f32)
+        return Xc, np.stack([mind, maxd], axis=1)
+
+    # points of keyframe 1 (slot i1 holds point i1 for 70 % of the slots): they should land on keyframe 2's keypoints -> choose their
+    # camera-2 coordinates from keyframe 2's keypoint they correspond to, then go back: p1 = s12 p2 + t12, world = p1 - t1
+    inv = np.argsort(perm)                                  # keypoint i1 of keyframe 1 is keypoint inv[i1] of keyframe 2
+    Xc2_for1, mm1 = points_seen_at(xy2[inv], oct2[inv], False)
+    pos1 = ((f32(s12) * Xc2_for1.astype(f32) + t12).astype(f32) - t1).astype(f32)
+    Xc1_for2, mm2 = points_seen_at(xy1[perm], oct1[perm], True)
+    pos2 = (((Xc1_for2.astype(f32) - t12) / s12).astype(f32) - t2).astype(f32)
+    mp_desc1 = desc1 ^ np.packbits(rng.uniform(0, 1, (n_kp, 256)) < 0.03, axis=1)
+    mp_desc2 = desc2 ^ np.packbits(rng.uniform(0, 1, (n_kp, 256)) < 0.03, axis=1)
+    slot1 = np.where(rng.uniform(0, 1, n_kp) < 0.7, np.arange(n_kp), -1).astype(np.int32)
+    slot2 = np.where(rng.uniform(0, 1, n_kp) < 0.7, np.arange(n_kp), -1).astype(np.int32)
+    bad1 = rng.uniform(0, 1, n_kp) < 0.03
+    bad2 = rng.uniform(0, 1, n_kp) < 0.03
+    # 40 pairs matched before the call: slot i1 of keyframe 1 <-> point j of keyframe 2 (sitting in slot j of keyframe 2)
+    matches_in = -np.ones(n_kp, dtype=np.int32)
+    pre = [i for i in rng.permutation(n_kp) if slot1[i] >= 0 and slot2[inv[i]] >= 0][:40]
+    for i in pre:
+        matches_in[i] = inv[i]
+    th = 7.5
+    k1, k2 = host.HostFrame(xy1, oct1, desc1, pose_qt=np.concatenate([[0, 0, 0, 1], t1])), host.HostFrame(xy2, oct2, desc2, pose_qt=np.concatenate([[0, 0, 0, 1], t2]))
+    try:
+        n, got = k1.search_by_sim3(k2, np.concatenate([[0, 0, 0, 1], t12, [s12]]), dict(pos=pos1, desc=mp_desc1, min_max=mm1, bad=bad1, slot=slot1),
+                                   dict(pos=pos2, desc=mp_desc2, min_max=mm2, bad=bad2, slot=slot2), matches_in=matches_in, th=th)
+    finally:
+        k1.close(); k2.close()
+
+    # ---- the reference's gates in float32
+    def direction(pos, t_from, s, t, mm, xy_to, oct_to, usable):
+        pf = (pos + t_from).astype(f32)
+        pt = ((f32(s) * pf).astype(f32) + t).astype(f32)
+        invz = (1.0 / pt[:, 2].astype(np.float64)).astype(f32)
+        u = ((fx * (pt[:, 0] * invz).astype(f32)).astype(f32) + cx).astype(f32)
+        v = ((fy * (pt[:, 1] * invz).astype(f32)).astype(f32) + cy).astype(f32)
+        d = np.sqrt(((pt[:, 0] * pt[:, 0]).astype(f32) + (pt[:, 1] * pt[:, 1]).astype(f32)).astype(f32) + (pt[:, 2] * pt[:, 2]).astype(f32)).astype(f32)
+        ok = usable & ~(pt[:, 2] < 0) & (u >= 0) & (u < synth.IMG_W) & (v >= 0) & (v < synth.IMG_H)
+        ok &= ~((d < f32(0.8) * mm[:, 0]) | (d > f32(1.2) * mm[:, 1]))
+        lvl = np.clip(np.ceil(np.log((mm[:, 1] / d).astype(f32)) / np.log(f32(synth.SCALE_FACTOR))).astype(np.int64), 0, synth.N_LEVELS - 1).astype(np.int32)
+        radius = (f32(th) * synth.SCALE_FACTORS[lvl]).astype(f32)
+        q = np.nonzero(ok)[0]
+        off0, idx0 = synth.features_in_area_lists(xy_to[:, 0], xy_to[:, 1], oct_to, u[q], v[q], radius[q], lvl[q] - 1, lvl[q])
+        n_slots = len(pos)
+        skip = np.ones(n_slots, dtype=np.uint8)
+        skip[q] = 0
+        off = np.zeros(n_slots + 1, dtype=np.int32)
+        lens = np.zeros(n_slots, dtype=np.int32)
+        lens[q] = np.diff(off0)
+        off[1:] = np.cumsum(lens)
+        return skip, off, idx0
+
+    already1 = matches_in >= 0
+    already2 = np.zeros(n_kp, dtype=bool)
+    already2[matches_in[already1]] = True                    # point j of keyframe 2 sits in slot j of keyframe 2 (when slot2[j] >= 0)
+    already2 &= slot2 >= 0
+    skip1, off1, idx1 = direction(pos1, t1, s21, t21, mm1, xy2, oct2, (slot1 >= 0) & ~already1 & ~bad1)
+    skip2, off2, idx2 = direction(pos2, t2, s12, t12, mm2, xy1, oct1, (slot2 >= 0) & ~already2 & ~bad2)
+    n_ref, m12 = ob.orb_search_by_sim3(mp_desc1, mp_desc2, desc1, desc2, skip1, off1, idx1, skip2, off2, idx2, th_high=100)
+    ref = np.where(m12 >= 0, m12, matches_in)               # slot of keyframe 2 == its point's index; earlier matches stay
+    assert n == n_ref and n > 100
+    np.testing.assert_array_equal(got, ref)
+    assert (skip1 == 0).sum() > 300 and (skip2 == 0).sum() > 300 and bad1.any() and bad2.any()
+
+
 def test_search_for_initialization_equals_sequential_reference(ob):
     """ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:648-763): level-0 keypoints only, windows around vbPrevMatched, a candidate
     passed over while its current match is at least as close, displaced matches, ratio test, orientation histogram, vbPrevMatched

@@ -161,3 +161,25 @@ def test_fuse_replay_by_hand():
     np.testing.assert_array_equal(bad_o, [1, 0, 1, 0, 0, 0, 1])
     np.testing.assert_array_equal(repl, [100000, -1, 3, -1, -1, -1, 1])
     np.testing.assert_array_equal(nobs_o, [3, 7, 3, 7, 1, 9, 2])
+
+
+def test_search_by_sim3_first_minimum_and_mutual_agreement():
+    """oracle_orb_search_by_sim3 (src/ORBmatcher.cc:1457-1674): per direction the FIRST candidate at the smallest distance wins and only
+    if it is within TH_HIGH; a pair counts when each side chose the other."""
+    z = np.zeros((4, 32), dtype=np.uint8)
+    kf1 = z.copy(); kf2 = z.copy()
+    kf2[0, 0] = 0b1; kf2[1, 0] = 0b1; kf2[2, 0] = 0b111     # slots 0 and 1 of keyframe 2 tie for point 0 of keyframe 1: slot 0 comes first in its list
+    mp1 = z.copy()                                         # the points of keyframe 1 (per slot) are all-zero descriptors
+    mp2 = z.copy(); mp2[:, 1] = 0xFF                       # points of keyframe 2: 8 bits from every keyframe-1 descriptor
+    kf1[1, 1] = 0xFF                                       # ... except slot 1 of keyframe 1, which equals them
+    off1 = np.array([0, 2, 3, 3, 3], dtype=np.int32); idx1 = np.array([1, 0, 2], dtype=np.int32)      # slot 0 -> [1, 0], slot 1 -> [2]
+    off2 = np.array([0, 1, 3, 4, 4], dtype=np.int32); idx2 = np.array([0, 1, 0, 1], dtype=np.int32)   # slot 0 -> [0], slot 1 -> [1, 0], slot 2 -> [1]
+    skip1 = np.array([0, 0, 1, 1], dtype=np.uint8); skip2 = np.array([0, 0, 0, 1], dtype=np.uint8)
+    n, m12 = ob.orb_search_by_sim3(mp1, mp2, kf1, kf2, skip1, off1, idx1, skip2, off2, idx2, th_high=100)
+    # direction 1: slot 0 of keyframe 1 -> candidates [1, 0] both at distance 1: the first (slot 1 of keyframe 2) wins; slot 1 -> slot 2 (distance 3)
+    # direction 2: slot 0 of keyframe 2 -> slot 0 (8); slot 1 -> [1, 0]: slot 1 of keyframe 1 at distance 0; slot 2 -> slot 1 (0)
+    # agreement: 0 -> 1 but 1 -> 1 (no); 1 -> 2 and 2 -> 1 (yes)
+    assert n == 1 and m12.tolist() == [-1, 2, -1, -1]
+    # TH_HIGH: with a threshold below the distance 3 the pair (1, 2) is gone
+    n, m12 = ob.orb_search_by_sim3(mp1, mp2, kf1, kf2, skip1, off1, idx1, skip2, off2, idx2, th_high=2)
+    assert n == 0 and (m12 == -1).all()
