@@ -110,6 +110,7 @@ struct BatchView {
   double* dmax_lin;          // [n_chunks] largest Hll diagonal entry of the chunk
   const RBlk* rblk;          // [n_rblk] blocks of S + rhs segments with their contribution ranges
   int n_rblk;
+  int* pose_lo;              // [NFP] first block row with a non-zero in block column p of the window's S (its column envelope), k_schur_env
   double* contrib;           // [n_contrib*36] per trial: 6x6 products of one item and pose pair
   double* ccontrib;          // [n_ccontrib*6] per trial: rhs products of one item and pose
   // system
@@ -864,7 +865,7 @@ __global__ __launch_bounds__(NT) void k_solve(BatchView bv, int W) {
   double* A = bv.S + wd.S_off;
   double* rhs = bv.bs + (size_t)wd.fpose_off * 6;
   double *xs, *shw;
-  const bool ok = ldlt_solve_block<NB, kSolveThreads>(A, rhs, n, W, sh, xs, shw);
+  const bool ok = ldlt_solve_block<NB, kSolveThreads>(A, rhs, n, W, sh, xs, shw, bv.pose_lo ? bv.pose_lo + wd.fpose_off : nullptr);
   solve_tail<kSolveThreads>(bv, wd, st, xs, shw, ok);
 }
 
@@ -1082,6 +1083,29 @@ __global__ __launch_bounds__(64) void k_control(BatchView bv, int phase) {
   if (st.active) atomicAdd(bv.n_active, 1);
 }
 
+// Column envelope of every window's reduced system, once per upload: block (i, j) of S is structurally non-zero when a landmark is
+// seen by both keyframes, i.e. when the plan gave it a contribution (RBlk::count > 0); the diagonal always is (Hpp + lambda I).
+// pose_lo[j] = smallest such i.  The factorisation of k_solve keeps this envelope and skips the tile columns outside it (ldlt_block.h).
+__global__ __launch_bounds__(256) void k_schur_env(BatchView bv) {
+  __shared__ int sh_off[4];
+  const int w = blockIdx.x, tid = threadIdx.x;
+  const WinDesc wd = bv.win[w];
+  int off = 0;
+  for (int k = tid; k < w; k += 256) { const int Pk = bv.win[k].P; off += Pk * (Pk + 1) / 2 + Pk; }
+  for (int o = 32; o > 0; o >>= 1) off += __shfl_xor(off, o, 64);
+  if ((tid & 63) == 0) sh_off[tid >> 6] = off;
+  __syncthreads();
+  const int base = sh_off[0] + sh_off[1] + sh_off[2] + sh_off[3];
+  const int P = wd.P;
+  for (int j = tid; j < P; j += 256) {
+    int lo = j;
+    for (int i = 0; i < j; ++i) {
+      if (bv.rblk[base + i * P - i * (i - 1) / 2 + (j - i)].count > 0) { lo = i; break; }
+    }
+    bv.pose_lo[wd.fpose_off + j] = lo;
+  }
+}
+
 // reset the controller before optimize()
 __global__ void k_reset(BatchView bv, const unsigned char* stop) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1277,7 +1301,7 @@ struct osh_lba_ctx {
   DevBuf d_arena[2], d_ptwin, d_erec;
   DevBuf d_lm, d_pose[2], d_pt[2], d_hcontrib, d_chi_lin, d_dmax_lin, d_contrib, d_ccontrib;
   DevBuf d_Hll, d_bl, d_DL, d_Hpp, d_bp, d_S, d_bs, d_xp, d_chi, d_scale, d_dmaxp, d_nactive, d_out_chi2, d_out_depth, d_stop;
-  DevBuf d_out_pose, d_out_pts, d_dbg;
+  DevBuf d_out_pose, d_out_pts, d_dbg, d_pose_lo;
   int* h_nactive = nullptr;          // pinned
   unsigned char* h_stop = nullptr;   // pinned [n_windows]
   size_t h_stop_cap = 0;
@@ -1422,7 +1446,7 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   OSH_TRY(R(c->d_chi, pb.n_chunks * kResidualSplit * 8)); OSH_TRY(R(c->d_scale, pb.n_chunks * 8));
   OSH_TRY(R(c->d_dmaxp, NFP * 8)); OSH_TRY(R(c->d_nactive, sizeof(int)));
   OSH_TRY(R(c->d_out_chi2, NOUT * 8)); OSH_TRY(R(c->d_out_depth, NOUT)); OSH_TRY(R(c->d_stop, nw));
-  OSH_TRY(R(c->d_out_pose, NFP * 7 * 8)); OSH_TRY(R(c->d_out_pts, NL * 3 * 8)); OSH_TRY(R(c->d_ptwin, NL * 4));
+  OSH_TRY(R(c->d_out_pose, NFP * 7 * 8)); OSH_TRY(R(c->d_out_pts, NL * 3 * 8)); OSH_TRY(R(c->d_ptwin, NL * 4)); OSH_TRY(R(c->d_pose_lo, NFP * 4));
   if (c->h_stop_cap < (size_t)nw) {
     if (c->h_stop) (void)hipHostFree(c->h_stop);
     OSH_HIP(hipHostMalloc((void**)&c->h_stop, nw));
@@ -1472,6 +1496,10 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   bv.dmax_pose = c->d_dmaxp.as<double>();
   bv.n_active = c->d_nactive.as<int>();
   bv.out_chi2 = c->d_out_chi2.as<double>(); bv.out_depth = c->d_out_depth.as<unsigned char>();
+  bv.pose_lo = c->d_pose_lo.as<int>();
+  hipLaunchKernelGGL(k_schur_env, dim3((unsigned)nw), dim3(256), 0, s, bv);
+  OSH_TRY(launch_check("k_schur_env"));
+  if (std::getenv("OSH_LBA_DENSE_SOLVE")) bv.pose_lo = nullptr;   // factor every tile column (the behaviour before the envelope was used)
   OSH_HIP(hipStreamSynchronize(s));   // the staging arenas may be rewritten by the next upload
   const auto t2 = std::chrono::steady_clock::now();
   c->upload_pack_ms = on_device ? c->dpack.host_ms : std::chrono::duration<double, std::milli>(t1 - t0).count();

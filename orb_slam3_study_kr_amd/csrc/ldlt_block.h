@@ -6,6 +6,11 @@
 //   rhs : n, read once (the forward substitution runs on a copy in LDS)
 //   sh  : dynamic LDS scratch, ldlt_lds_doubles(NB, W, NT) doubles, W = ldlt_row_stride(n_max)
 //   xs  : returns a pointer into `sh` holding the solution (n doubles) when the result is true
+//   lo_pose (optional): the sparsity the caller knows.  The unknowns come in blocks of six (one keyframe); lo_pose[p] is the first
+//         block row with a non-zero in block column p of the upper triangle (<= p).  No pivoting => the factor keeps this column
+//         envelope, so a panel only has to touch the columns whose envelope reaches up to it: the row panel and the trailing update
+//         run over the 16-wide tile columns that hold such a column and skip the others, whose entries are exact zeros and stay
+//         zeros (the skipped operations are 0 -= l * 0).  nullptr: dense.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "lba_math.h"
@@ -16,7 +21,8 @@ namespace osh {
 __host__ __device__ constexpr int ldlt_row_stride(int n) { return (n + 24 + 1) & ~1; }
 
 __host__ __device__ constexpr size_t ldlt_lds_doubles(int nb, int W, int nthreads) {
-  return (size_t)nb * W + W + 3 * nb + (size_t)nb * nb + nthreads / 64 + 8;
+  // two nb x nb blocks (factor rows, inverse of L); then ints: live tile columns of a panel, envelope of the block columns, last live column per panel
+  return (size_t)nb * W + W + 3 * nb + 2 * (size_t)nb * nb + nthreads / 64 + 8 + (W / 32 + 4) + (W / 12 + 2) + (W / (2 * nb) + 2);
 }
 
 // value of `v` in lane `lane` (compile-time constant after unrolling) as a wave-uniform scalar
@@ -28,7 +34,7 @@ __device__ __forceinline__ double ldlt_readlane(double v, int lane) {
 
 template <int NB, int NT>
 __device__ bool ldlt_solve_block(double* __restrict__ A, const double* __restrict__ rhs, const int n, const int W, double* sh,
-                                 double*& xs_out, double*& shw_out) {
+                                 double*& xs_out, double*& shw_out, const int* __restrict__ lo_pose = nullptr) {
   constexpr int nb = NB;
   constexpr int kSolveThreads = NT;
   const int tid = threadIdx.x;
@@ -40,8 +46,13 @@ __device__ bool ldlt_solve_block(double* __restrict__ A, const double* __restric
   double* ddi = dd + nb;             // [nb] reciprocals of the pivots
   double* part = ddi + nb;           // [nb]
   double* Ld = part + nb;            // [nb][nb] diagonal block: padded input, then its scaled factor rows
-  double* shw = Ld + nb * nb;        // [NT/64] cross-wave scratch for the caller
+  double* Mi = Ld + nb * nb;         // [nb][nb] inverse of the block's unit lower-triangular factor (row panel = Mi x A_panel on the matrix cores)
+  double* shw = Mi + nb * nb;        // [NT/64] cross-wave scratch for the caller
   int& sh_ok = *reinterpret_cast<int*>(shw + kSolveThreads / 64);
+  int* const tcl = reinterpret_cast<int*>(shw + kSolveThreads / 64 + 2);   // [0]: number of live tile columns of the panel, [1..]: their indices
+  int* const lo_sh = tcl + 2 * (W / 32 + 4);                               // lo_pose staged (the list is rebuilt for every panel)
+  int* const jhi = lo_sh + 2 * (W / 12 + 2);                               // per panel: one past its last live column (global index), for the back substitution
+  if (lo_pose) for (int k = tid; k < (n + 5) / 6; k += kSolveThreads) lo_sh[k] = lo_pose[k];
   xs_out = xs;
   shw_out = shw;
   if (tid == 0) sh_ok = 1;
@@ -66,6 +77,31 @@ __device__ bool ldlt_solve_block(double* __restrict__ A, const double* __restric
       const double a = A[in && c2 >= r ? (size_t)(k0 + r) * n + k0 + c2 : 0];
       Ld[idx] = in ? (c2 >= r ? a : 0.0) : (r == c2 ? 1.0 : 0.0);
     }
+    {
+      // live tile columns of this panel's trailing part (local tile t covers global columns k0 + kb + 16 t ...): those holding a
+      // column whose envelope starts above the panel's last row.  The last wavefront builds the list (the first one factors the block).
+      const int Trp = (m - kb + 15) >> 4;
+      if (tid >= kSolveThreads - 64) {
+        const int ln = tid - (kSolveThreads - 64);
+        int base = 0;
+        for (int c0 = 0; c0 < Trp; c0 += 64) {
+          const int ti = c0 + ln;
+          bool act = false;
+          if (ti < Trp) {
+            act = lo_pose == nullptr;
+            if (!act) {
+              const int g0 = k0 + kb + 16 * ti, g1 = min(g0 + 16, n) - 1;
+              for (int pz = g0 / 6; pz <= g1 / 6; ++pz) act |= 6 * lo_sh[pz] < k0 + kb;
+            }
+          }
+          const unsigned long long mk = __ballot(act);
+          if (act) tcl[1 + base + __popcll(mk & ((1ull << ln) - 1ull))] = ti;
+          base += __popcll(mk);
+        }
+        if (ln == 0) tcl[0] = base;
+        if (ln == 63) jhi[k0 / nb] = base ? min(n, k0 + kb + 16 * (tcl[base] + 1)) : k0 + kb;   // (lane 63 wrote or saw the list's last entry: same wavefront)
+      }
+    }
     __syncthreads();
     OSH_TR(0);
     if (tid < 64) {
@@ -73,10 +109,14 @@ __device__ bool ldlt_solve_block(double* __restrict__ A, const double* __restric
       // (an LDS round trip per pivot bounded this phase before): l_k,j = u_k,j / d_k is formed by lane j itself, then
       // u_i,j -= l_k,i * u_k,j for every row i > k.  Lanes j < i compute values of the unused lower triangle; nothing valid
       // reads them.  Same operations in the same order as the textbook loop; a padded pivot is 1 with zero multipliers.
+      // Lanes NB .. 2 NB - 1 carry the columns of the identity through the same row operations (they execute the instruction stream
+      // anyway): what they hold at the end is L^-1, the operator of the row panel below.
+      static_assert(2 * NB <= 64, "the identity columns ride in the upper lanes of the wavefront");
       double col[NB];
       const int cj = tid < NB ? tid : 0;
+      const bool idl = tid >= NB && tid < 2 * NB;
 #pragma unroll
-      for (int r = 0; r < NB; ++r) col[r] = Ld[r * NB + cj];
+      for (int r = 0; r < NB; ++r) { const double v = Ld[r * NB + cj]; col[r] = idl ? (r == tid - NB ? 1.0 : 0.0) : v; }
       double* lout = tid < NB ? Ld + tid : part;  // lanes beyond the block write to a slot nobody reads in this phase
       bool zero_pivot = false;
 #pragma unroll
@@ -96,78 +136,78 @@ __device__ bool ldlt_solve_block(double* __restrict__ A, const double* __restric
         if (tid == 0) { dd[k] = d; ddi[k] = rd; }
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (idl) {
+#pragma unroll
+        for (int r = 0; r < NB; ++r) Mi[r * NB + (tid - NB)] = col[r];
+      }
       if (zero_pivot && tid == 0) sh_ok = 0;
     }
     __syncthreads();
     OSH_TR(1);
     if (!sh_ok) break;
-    // ---- 2. row panel: every thread forward-substitutes whole columns (incl. the rhs column m) in registers.  Column
-    // sweep: once w_k is final it is removed from every later row, so the 23 + 22 + ... FMAs of a sweep are independent (the
-    // row-by-row order had one 276-long dependent chain); each w_r still receives its terms in the order k = 0, 1, ...
-    // Uniform (broadcast) LDS operands are read as 16-byte pairs through ONE base register with immediate offsets, and every
-    // store is unconditional: padded rows r >= kb carry zeros into panel rows nobody reads, and their global store goes to an
-    // entry of the block's unused lower triangle.  (With per-row branches and 8-byte reads this phase issued ~2.4 k
-    // instructions per column, a third of them address bookkeeping, and was bound by instruction issue.)
-    static_assert(NB % 2 == 0, "panel width must be even");
-    typedef double ldlt_f64x2 __attribute__((ext_vector_type(2)));
-    const ldlt_f64x2* const Ld2 = reinterpret_cast<const ldlt_f64x2*>(Ld);        // [NB][NB / 2]
-    const ldlt_f64x2* const ys2 = reinterpret_cast<const ldlt_f64x2*>(xs + k0);   // rhs entries of this panel
-    const ldlt_f64x2* const dd2 = reinterpret_cast<const ldlt_f64x2*>(ddi);   // reciprocals of the pivots
-    char* const Apanel = reinterpret_cast<char*>(A + (size_t)k0 * n + k0);
-    const unsigned n8p = (unsigned)n * 8u;
-    for (int jj = kb + tid; jj <= m; jj += kSolveThreads) {
-      double wv[NB];
-      const bool is_rhs = jj == m;
-      const unsigned j8 = is_rhs ? 0u : (unsigned)jj * 8u;
+    // ---- 2. row panel on the matrix cores: W = L^-1 A[panel rows][live columns], one wavefront per live 16-column tile;
+    // C[16 tr + i][j] = sum_k Mi[16 tr + i][k] A[k][j] as v_mfma_f64_16x16x4_f64 steps (Mi is lower triangular: tile row tr needs
+    // k < 16 (tr + 1) only).  The unscaled rows go to the LDS panel U for the trailing update, the scaled ones (the factor's rows)
+    // to global memory.  (Until round 3 every thread forward-substituted one column with 276 dependent-sweep FMAs and broadcast LDS
+    // reads: 12.7 k cycles per panel of a 300 x 300 system against ~2 k for this product.)  The rhs column is Mi y, one lane per row.
+    typedef double ldlt_f64x4 __attribute__((ext_vector_type(4)));
+    const int na = tcl[0];
+    {
+      const int wave_p = __builtin_amdgcn_readfirstlane(tid >> 6), lane_p = tid & 63;
+      const int prow = lane_p >> 4, pcol = lane_p & 15;
+      constexpr int nwaves_p = kSolveThreads / 64;
+      constexpr int KSp = (NB + 3) / 4, TRp = (NB + 15) / 16;
+      if (wave_p == nwaves_p - 1 && lane_p < NB) {
+        double acc = 0.0;
 #pragma unroll
-      for (int r2 = 0; r2 < NB / 2; ++r2) {
-        const ldlt_f64x2 y = ys2[r2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int r = 2 * r2 + h;
-          const unsigned roff = (unsigned)(r < kb ? r : kb - 1) * n8p;
-          const double v = *reinterpret_cast<const double*>(Apanel + (roff + j8));
-          wv[r] = r < kb ? (is_rhs ? y[h] : v) : 0.0;
-        }
+        for (int k = 0; k < NB; ++k) acc += Mi[lane_p * NB + k] * (k < kb ? xs[k0 + k] : 0.0);
+        U[lane_p * W + m] = acc;
+        if (lane_p < kb) xs[k0 + lane_p] = acc;
       }
-      // multipliers of sweep k + 1 are fetched while sweep k runs; the scheduling fence keeps the compiler from hoisting all
-      // the LDS reads to the top (that needs 552 registers)
-      ldlt_f64x2 lnext[NB / 2];
+      if (na > 0) {
+        double am[TRp][KSp];
 #pragma unroll
-      for (int p2 = 0; p2 < NB / 2; ++p2) lnext[p2] = Ld2[p2];
+        for (int tr = 0; tr < TRp; ++tr)
 #pragma unroll
-      for (int k = 0; k < NB - 1; ++k) {
-        ldlt_f64x2 lcur[NB / 2];
+          for (int ks = 0; ks < KSp; ++ks) {
+            const int i = 16 * tr + pcol, k = 4 * ks + prow;
+            const bool in = i < NB && k < NB;
+            am[tr][ks] = Mi[in ? i * NB + k : 0];
+            if (!in) am[tr][ks] = 0.0;
+          }
+        char* const Ab = reinterpret_cast<char*>(A + (size_t)k0 * n + k0);
+        const unsigned n8 = (unsigned)n * 8u;
+        for (int ai = wave_p; ai < na; ai += nwaves_p) {
+          const int jl = kb + 16 * tcl[1 + ai] + pcol;     // local column of this lane
+          const bool jin = jl < m;
+          const unsigned j8 = (unsigned)min(jl, m - 1) * 8u;
+          double bq[KSp];
 #pragma unroll
-        for (int p2 = (k + 1) / 2; p2 < NB / 2; ++p2) lcur[p2] = lnext[p2];
+          for (int ks = 0; ks < KSp; ++ks) {
+            const int k = 4 * ks + prow;
+            const double v = *reinterpret_cast<const double*>(Ab + ((unsigned)min(k, kb - 1) * n8 + j8));
+            bq[ks] = k < kb ? v : 0.0;
+          }
+          ldlt_f64x4 acc[TRp];
 #pragma unroll
-        for (int p2 = (k + 2) / 2; p2 < NB / 2; ++p2) lnext[p2] = Ld2[(k + 1) * (NB / 2) + p2];
+          for (int tr = 0; tr < TRp; ++tr) {
+            acc[tr] = (ldlt_f64x4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int r = k + 1; r < NB; ++r) {
-          wv[r] -= lcur[r / 2][r & 1] * wv[k];
-          asm volatile("" : "+v"(wv[r]));  // pins the FMA to this sweep (the optimiser otherwise sinks it into a row-order chain)
+            for (int ks = 0; ks < KSp; ++ks)
+              if (4 * ks < 16 * (tr + 1)) acc[tr] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[tr][ks], bq[ks], acc[tr], 0, 0, 0);
+          }
+#pragma unroll
+          for (int tr = 0; tr < TRp; ++tr)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+              const int r = 16 * tr + prow + 4 * reg;
+              if (r < NB && jin) {
+                const double wv = acc[tr][reg];
+                U[r * W + jl] = wv;
+                if (r < kb) *reinterpret_cast<double*>(Ab + ((unsigned)r * n8 + j8)) = wv * ddi[r];
+              }
+            }
         }
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // panels for the trailing update, and the final values of each row straight to the factor (no separate write-back pass)
-#pragma unroll
-      for (int r2 = 0; r2 < NB / 2; ++r2) {
-        const ldlt_f64x2 d2 = dd2[r2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int r = 2 * r2 + h;
-          const double q = wv[r] * d2[h];
-          const double l = is_rhs ? 0.0 : q;
-          U[r * W + jj] = wv[r];
-          unsigned o = (r < kb && !is_rhs) ? (unsigned)r * n8p + j8 : n8p;  // n8p: entry (1, 0) of the block
-          asm volatile("" : "+v"(o));
-          *reinterpret_cast<double*>(Apanel + o) = l;
-        }
-      }
-      if (is_rhs) {
-#pragma unroll
-        for (int r = 0; r < NB; ++r) if (r < kb) xs[k0 + r] = wv[r];
       }
     }
     // the factored diagonal block: pivots on the diagonal, l_rj to their right
@@ -190,14 +230,15 @@ __device__ bool ldlt_solve_block(double* __restrict__ A, const double* __restric
     const int tr = m - kb;  // trailing rows
     if (tr > 0) {
       // right-hand side: y_i -= sum_k l_ki y_k, one thread per row, panels read conflict-free
-      for (int ii = kb + tid; ii < m; ii += kSolveThreads) {
+      for (int q = tid; q < 16 * na; q += kSolveThreads) {
+        const int ii = kb + 16 * tcl[1 + (q >> 4)] + (q & 15);
+        if (ii >= m) continue;
         double acc = 0.0;
 #pragma unroll
         for (int k = 0; k < NB; ++k) acc += (U[k * W + ii] * ddi[k]) * U[k * W + m];
         xs[k0 + ii] -= acc;
       }
-      typedef double ldlt_f64x4 __attribute__((ext_vector_type(4)));
-      const int Tr = (tr + 15) >> 4;
+      const int Tr = na;                    // live tile columns only: a tile (a, b) is touched when both of its tile columns are live
       const int ntile = Tr * (Tr + 1) / 2;  // upper triangle of 16x16 tiles, diagonal tiles included
       const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // wave index as a scalar: tile decode on the SALU
       const int lrow = lane >> 4, lcol = lane & 15;
@@ -213,8 +254,8 @@ __device__ bool ldlt_solve_block(double* __restrict__ A, const double* __restric
       auto prep = [&](int t, Tile& T) {
         int ti = 0, rem = t;
         while (rem >= Tr - ti) { rem -= Tr - ti; ++ti; }
-        T.i0 = kb + 16 * ti;
-        T.j0 = kb + 16 * (ti + rem);
+        T.i0 = kb + 16 * tcl[1 + ti];
+        T.j0 = kb + 16 * tcl[1 + ti + rem];
         const unsigned j8 = (unsigned)min(T.j0 + lcol, m - 1) * 8u;
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
@@ -311,6 +352,7 @@ __device__ bool ldlt_solve_block(double* __restrict__ A, const double* __restric
       const int k0 = pi * nb;
       const int kb = min(nb, n - k0);
       const int tail0 = k0 + kb;  // x known for indices >= tail0
+      const int jend = jhi[pi];   // the rows of this panel are zero from here on (outside the envelope)
       // diagonal block of the factor, padded: row r right of the diagonal, zero elsewhere
       double dg[kDiagPerThread];
 #pragma unroll
@@ -328,7 +370,7 @@ __device__ bool ldlt_solve_block(double* __restrict__ A, const double* __restric
         const int r = wv + q * nwaves;
         const double* row = A + (size_t)(k0 + (r < kb ? r : 0)) * n;
         sacc[q] = 0.0;
-        for (int j = tail0 + lane; j < n; j += 64) sacc[q] += row[j] * xs[j];
+        for (int j = tail0 + lane; j < jend; j += 64) sacc[q] += row[j] * xs[j];
       }
 #pragma unroll
       for (int q = 0; q < kRowsPerWave; ++q) {

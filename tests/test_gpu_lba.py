@@ -313,3 +313,23 @@ def test_observations_that_are_not_float32_values_take_the_double_records(solver
     w.edge_info = w.edge_info * (1 + 1e-9)
     assert np.any(w.edge_obs.astype(np.float32).astype(np.float64) != w.edge_obs)
     _check_result(solver.solve([w])[0], ob.lba_solve(w), w)
+
+
+def test_envelope_factorisation_equals_the_dense_one_bit_for_bit(hip_lib, monkeypatch):
+    """k_solve skips the tile columns outside the column envelope of S (blocks no landmark connects: exact zeros that stay zeros under
+    LDL^T without pivoting).  OSH_LBA_DENSE_SOLVE=1 factors every tile column as before: same bits out, for a banded window (contiguous
+    tracks), a window with missed detections (ragged envelope) and a batch."""
+    ws = [synth.make_window(61, n_free=30, n_fixed=5, n_points=3000, stereo=True, track_len=(3, 8)),
+          synth.make_window(62, n_free=24, n_fixed=4, n_points=2000, stereo=True, track_len=(4, 20), obs_dropout=0.3),
+          synth.make_config1(5)]
+    out = []
+    for dense in (False, True):
+        if dense:
+            monkeypatch.setenv("OSH_LBA_DENSE_SOLVE", "1")
+        with lba.LbaSolver(0) as s:
+            out.append(s.solve(ws))
+    for a, b in zip(*out):
+        assert a.iterations == b.iterations and a.trials == b.trials
+        np.testing.assert_array_equal(a.chi2_trace, b.chi2_trace)
+        np.testing.assert_array_equal(a.pose_qt, b.pose_qt)
+        np.testing.assert_array_equal(a.points, b.points)
