@@ -32,6 +32,11 @@ __device__ __forceinline__ double ldlt_readlane(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
+// Block barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding GLOBAL access of the wavefront
+// (s_waitcnt vmcnt(0)), i.e. for the stores of the phase just finished and for loads requested ahead of time.  Used between the
+// phases of a panel whose hand-over is through LDS; the phase that writes the trailing matrix ends with a full __syncthreads().
+__device__ __forceinline__ void ldlt_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int NB, int NT>
 __device__ bool ldlt_solve_block(double* __restrict__ A, const double* __restrict__ rhs, const int n, const int W, double* sh,
                                  double*& xs_out, double*& shw_out, const int* __restrict__ lo_pose = nullptr) {
@@ -102,8 +107,27 @@ __device__ bool ldlt_solve_block(double* __restrict__ A, const double* __restric
         if (ln == 63) jhi[k0 / nb] = base ? min(n, k0 + kb + 16 * (tcl[base] + 1)) : k0 + kb;   // (lane 63 wrote or saw the list's last entry: same wavefront)
       }
     }
-    __syncthreads();
+    ldlt_lds_barrier();
     OSH_TR(0);
+    // The panel rows of the first live tile of every wavefront but the first are requested now: the loads are in flight while
+    // wavefront 0 factors the block (they do not depend on it), instead of after the next barrier.
+    constexpr int KSp0 = (NB + 3) / 4;
+    double bq0[KSp0];
+    bool pre0 = false;
+    {
+      const int wv0 = __builtin_amdgcn_readfirstlane(tid >> 6);
+      if (wv0 != 0 && wv0 < tcl[0]) {
+        const int jl = kb + 16 * tcl[1 + wv0] + (tid & 15);
+        const char* Ab0 = reinterpret_cast<const char*>(A + (size_t)k0 * n + k0);
+        const unsigned n8 = (unsigned)n * 8u, j8 = (unsigned)min(jl, m - 1) * 8u;
+#pragma unroll
+        for (int ks = 0; ks < KSp0; ++ks) {
+          const int k = 4 * ks + ((tid & 63) >> 4);
+          bq0[ks] = *reinterpret_cast<const double*>(Ab0 + ((unsigned)min(k, kb - 1) * n8 + j8));
+        }
+        pre0 = true;
+      }
+    }
     if (tid < 64) {
       // ONE wavefront factors the block.  Lane j keeps column j in registers and the pivot row is broadcast with v_readlane
       // (an LDS round trip per pivot bounded this phase before): l_k,j = u_k,j / d_k is formed by lane j itself, then
@@ -119,21 +143,30 @@ __device__ bool ldlt_solve_block(double* __restrict__ A, const double* __restric
       for (int r = 0; r < NB; ++r) { const double v = Ld[r * NB + cj]; col[r] = idl ? (r == tid - NB ? 1.0 : 0.0) : v; }
       double* lout = tid < NB ? Ld + tid : part;  // lanes beyond the block write to a slot nobody reads in this phase
       bool zero_pivot = false;
+      // Look-ahead: pivot k + 1 is final as soon as row k + 1 has received pivot k's update (the first of the step), so its
+      // reciprocal (hardware seed + two Newton steps: a chain of ~10 dependent operations) is started there and overlaps with the
+      // remaining row updates of step k instead of standing alone at the top of step k + 1.
+      double d = ldlt_readlane(col[0], 0);
+      double rd = dev::rcp_nr(d);
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
-        const double d = ldlt_readlane(col[k], k);
         zero_pivot |= d == 0.0;
-        // one reciprocal per pivot (hardware seed + two Newton steps, lba_math.h) instead of a divide per entry: the divide
-        // expansion sat on the critical path of every step here and cost 24 divides per column in the row panel below
-        const double rd = dev::rcp_nr(d);
         const double lk = col[k] * rd;
+        const double d_cur = d, rd_cur = rd;
+        if (k + 1 < NB) {
+          col[k + 1] -= ldlt_readlane(lk, k + 1) * col[k];
+          asm volatile("" : "+v"(col[k + 1]));
+          d = ldlt_readlane(col[k + 1], k + 1);
+          rd = dev::rcp_nr(d);
+          asm volatile("" : "+v"(rd));   // computed HERE (the optimiser otherwise sinks the chain to its first use in the next step)
+        }
 #pragma unroll
-        for (int ii = k + 1; ii < NB; ++ii) {
+        for (int ii = k + 2; ii < NB; ++ii) {
           col[ii] -= ldlt_readlane(lk, ii) * col[k];
           asm volatile("" : "+v"(col[ii]));  // keeps the update here: sunk to its use, all 276 multipliers stay live in SGPRs
         }
         lout[k * NB] = tid > k ? lk : 0.0;  // scaled row k of the block (l_kj)
-        if (tid == 0) { dd[k] = d; ddi[k] = rd; }
+        if (tid == 0) { dd[k] = d_cur; ddi[k] = rd_cur; }
         __builtin_amdgcn_sched_barrier(0);
       }
       if (idl) {
@@ -142,7 +175,7 @@ __device__ bool ldlt_solve_block(double* __restrict__ A, const double* __restric
       }
       if (zero_pivot && tid == 0) sh_ok = 0;
     }
-    __syncthreads();
+    ldlt_lds_barrier();
     OSH_TR(1);
     if (!sh_ok) break;
     // ---- 2. row panel on the matrix cores: W = L^-1 A[panel rows][live columns], one wavefront per live 16-column tile;
@@ -185,7 +218,9 @@ __device__ bool ldlt_solve_block(double* __restrict__ A, const double* __restric
 #pragma unroll
           for (int ks = 0; ks < KSp; ++ks) {
             const int k = 4 * ks + prow;
-            const double v = *reinterpret_cast<const double*>(Ab + ((unsigned)min(k, kb - 1) * n8 + j8));
+            double v;
+            if (pre0 && ai == wave_p) v = bq0[ks];   // requested before the block factorisation
+            else v = *reinterpret_cast<const double*>(Ab + ((unsigned)min(k, kb - 1) * n8 + j8));
             bq[ks] = k < kb ? v : 0.0;
           }
           ldlt_f64x4 acc[TRp];
@@ -220,14 +255,97 @@ __device__ bool ldlt_solve_block(double* __restrict__ A, const double* __restric
       const int r = idx >> 4, jj = m + 1 + (idx & 15);
       U[r * W + jj] = 0.0;
     }
-    __syncthreads();
+    const int tr = m - kb;  // trailing rows
+    const int Tr = na;                    // live tile columns only: a tile (a, b) is touched when both of its tile columns are live
+    const int ntile = Tr * (Tr + 1) / 2;  // upper triangle of 16x16 tiles, diagonal tiles included
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // wave index as a scalar: tile decode on the SALU
+    const int lrow = lane >> 4, lcol = lane & 15;
+    // All addressing is 32-bit byte offsets from the panel origin (uniform base in SGPRs), every load and store is
+    // unconditional: an out-of-range row or column is clamped for the load and its store goes to `sink_off`, an entry of the
+    // never-read lower triangle; lanes below the diagonal of a diagonal tile update their own (unused) lower-triangle entry.
+    // The per-element cost is what bounded this phase before: ~600 VALU/SALU instructions per pair of tiles against 12 MFMAs.
+    char* const Ab = reinterpret_cast<char*>(A + (size_t)k0 * n + k0);
+    const unsigned n8 = (unsigned)n * 8u;
+    const unsigned sink_off = (unsigned)kb * n8;
+    const int cA = lrow * W + lcol;
+    struct Tile { int i0, j0; unsigned off[4]; double old[4]; };
+    auto prep = [&](int t, Tile& T) {
+      int ti = 0, rem = t;
+      while (rem >= Tr - ti) { rem -= Tr - ti; ++ti; }
+      T.i0 = kb + 16 * tcl[1 + ti];
+      T.j0 = kb + 16 * tcl[1 + ti + rem];
+      const unsigned j8 = (unsigned)min(T.j0 + lcol, m - 1) * 8u;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int ii = min(T.i0 + lrow + 4 * reg, m - 1);
+        T.off[reg] = __umul24((unsigned)ii, n8) + j8;
+        T.old[reg] = *reinterpret_cast<const double*>(Ab + T.off[reg]);
+      }
+    };
+    auto finish = [&](const Tile& T, const ldlt_f64x4& acc) {
+      const bool jin = T.j0 + lcol < m;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const bool in = jin && T.i0 + lrow + 4 * reg < m;
+        unsigned o = in ? T.off[reg] : sink_off;
+        asm volatile("" : "+v"(o));  // one store through a selected offset, not two stores behind a branch
+        *reinterpret_cast<double*>(Ab + o) = T.old[reg] - acc[reg];
+      }
+    };
+    // two tiles per step: their MFMA chains are independent, so the matrix core issues back to back instead of waiting
+    // for each accumulator; all operand reads of a step are issued before its first MFMA
+    constexpr int KSq = (NB + 3) / 4;
+    double dq[KSq];   // 1 / d_k of the lane's operand rows k = 4 q + lrow: the A operand is l_ki = u_ki / d_k
+#pragma unroll
+    for (int q = 0; q < KSq; ++q) dq[q] = (4 * q + lrow < NB) ? ddi[4 * q + lrow] : 0.0;
+    auto run2 = [&](const Tile& T0, const Tile& T1) {
+      constexpr int KS = (NB + 3) / 4;
+      double a0[KS], b0[KS], a1[KS], b1[KS];
+      const double* pa0 = U + cA + T0.i0; const double* pb0 = U + cA + T0.j0;
+      const double* pa1 = U + cA + T1.i0; const double* pb1 = U + cA + T1.j0;
+#pragma unroll
+      for (int q = 0; q < KS; ++q) {
+        if (4 * q + 3 < NB) {
+          a0[q] = pa0[4 * q * W] * dq[q]; b0[q] = pb0[4 * q * W];
+          a1[q] = pa1[4 * q * W] * dq[q]; b1[q] = pb1[4 * q * W];
+        } else {
+          // last k step of a panel whose width is not a multiple of 4: rows >= NB do not exist, their lanes multiply zeros
+          const bool kin = 4 * q + lrow < NB;
+          const int back = kin ? 0 : lrow * W;
+          a0[q] = pa0[4 * q * W - back] * dq[q]; b0[q] = pb0[4 * q * W - back];
+          a1[q] = pa1[4 * q * W - back] * dq[q]; b1[q] = pb1[4 * q * W - back];
+          if (!kin) { a0[q] = 0.0; b0[q] = 0.0; a1[q] = 0.0; b1[q] = 0.0; }
+        }
+      }
+      ldlt_f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int q = 0; q < KS; ++q) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0[q], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b1[q], acc1, 0, 0, 0);
+      }
+      finish(T0, acc0);
+      finish(T1, acc1);
+    };
+    constexpr int nwaves = kSolveThreads / 64;
+    // wave w takes tiles w, w + nwaves, ... two at a time; the loads of the next pair are in flight during the current one.
+    // An odd tile out is paired with a copy of itself (both copies were loaded before either is stored, so the second
+    // store repeats the first), and past the last pair the prefetch re-reads the current one and is dropped.
+    Tile TA0, TA1, TB0, TB1;
+    auto prep_pair = [&](int t, Tile& X, Tile& Y) {
+      prep(t, X);
+      prep(t + nwaves < ntile ? t + nwaves : t, Y);
+    };
+    // the old values of every wavefront's first pair of trailing tiles are requested before the barrier (the row panel does not
+    // write them): in flight while the slower wavefronts finish the panel
+    const bool have_tiles = tr > 0 && wave < ntile;
+    if (have_tiles) prep_pair(wave, TA0, TA1);
+    ldlt_lds_barrier();   // (the factor rows stored above are read again only by the back substitution)
     OSH_TR(2);
     // ---- 3. trailing update of rows k0+kb .. n-1 (upper part) on the FP64 matrix cores: one wavefront per 16x16 tile of
     // the trailing block, C -= L[16 x NB] U[NB x 16] as NB/4 v_mfma_f64_16x16x4_f64 (a partial panel is the last one and has
     // no trailing block).  Operand lanes read straight from the panel in LDS: A[i = lane & 15][k = lane >> 4] = U[k][i0 + i] / d_k,
     // B[k][j] = U[k][j0 + j]; lane holds D[row = (lane >> 4) + 4 reg][col = lane & 15].  (A 4x4 register-tiled VALU version
     // spent 3 of 4 issue slots on operand traffic: 44 k cycles per panel on one CU against ~10 k for the first MFMA version.)
-    const int tr = m - kb;  // trailing rows
     if (tr > 0) {
       // right-hand side: y_i -= sum_k l_ki y_k, one thread per row, panels read conflict-free
       for (int q = tid; q < 16 * na; q += kSolveThreads) {
@@ -238,88 +356,8 @@ __device__ bool ldlt_solve_block(double* __restrict__ A, const double* __restric
         for (int k = 0; k < NB; ++k) acc += (U[k * W + ii] * ddi[k]) * U[k * W + m];
         xs[k0 + ii] -= acc;
       }
-      const int Tr = na;                    // live tile columns only: a tile (a, b) is touched when both of its tile columns are live
-      const int ntile = Tr * (Tr + 1) / 2;  // upper triangle of 16x16 tiles, diagonal tiles included
-      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // wave index as a scalar: tile decode on the SALU
-      const int lrow = lane >> 4, lcol = lane & 15;
-      // All addressing is 32-bit byte offsets from the panel origin (uniform base in SGPRs), every load and store is
-      // unconditional: an out-of-range row or column is clamped for the load and its store goes to `sink_off`, an entry of the
-      // never-read lower triangle; lanes below the diagonal of a diagonal tile update their own (unused) lower-triangle entry.
-      // The per-element cost is what bounded this phase before: ~600 VALU/SALU instructions per pair of tiles against 12 MFMAs.
-      char* const Ab = reinterpret_cast<char*>(A + (size_t)k0 * n + k0);
-      const unsigned n8 = (unsigned)n * 8u;
-      const unsigned sink_off = (unsigned)kb * n8;
-      const int cA = lrow * W + lcol;
-      struct Tile { int i0, j0; unsigned off[4]; double old[4]; };
-      auto prep = [&](int t, Tile& T) {
-        int ti = 0, rem = t;
-        while (rem >= Tr - ti) { rem -= Tr - ti; ++ti; }
-        T.i0 = kb + 16 * tcl[1 + ti];
-        T.j0 = kb + 16 * tcl[1 + ti + rem];
-        const unsigned j8 = (unsigned)min(T.j0 + lcol, m - 1) * 8u;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int ii = min(T.i0 + lrow + 4 * reg, m - 1);
-          T.off[reg] = __umul24((unsigned)ii, n8) + j8;
-          T.old[reg] = *reinterpret_cast<const double*>(Ab + T.off[reg]);
-        }
-      };
-      auto finish = [&](const Tile& T, const ldlt_f64x4& acc) {
-        const bool jin = T.j0 + lcol < m;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const bool in = jin && T.i0 + lrow + 4 * reg < m;
-          unsigned o = in ? T.off[reg] : sink_off;
-          asm volatile("" : "+v"(o));  // one store through a selected offset, not two stores behind a branch
-          *reinterpret_cast<double*>(Ab + o) = T.old[reg] - acc[reg];
-        }
-      };
-      // two tiles per step: their MFMA chains are independent, so the matrix core issues back to back instead of waiting
-      // for each accumulator; all operand reads of a step are issued before its first MFMA
-      constexpr int KSq = (NB + 3) / 4;
-      double dq[KSq];   // 1 / d_k of the lane's operand rows k = 4 q + lrow: the A operand is l_ki = u_ki / d_k
-#pragma unroll
-      for (int q = 0; q < KSq; ++q) dq[q] = (4 * q + lrow < NB) ? ddi[4 * q + lrow] : 0.0;
-      auto run2 = [&](const Tile& T0, const Tile& T1) {
-        constexpr int KS = (NB + 3) / 4;
-        double a0[KS], b0[KS], a1[KS], b1[KS];
-        const double* pa0 = U + cA + T0.i0; const double* pb0 = U + cA + T0.j0;
-        const double* pa1 = U + cA + T1.i0; const double* pb1 = U + cA + T1.j0;
-#pragma unroll
-        for (int q = 0; q < KS; ++q) {
-          if (4 * q + 3 < NB) {
-            a0[q] = pa0[4 * q * W] * dq[q]; b0[q] = pb0[4 * q * W];
-            a1[q] = pa1[4 * q * W] * dq[q]; b1[q] = pb1[4 * q * W];
-          } else {
-            // last k step of a panel whose width is not a multiple of 4: rows >= NB do not exist, their lanes multiply zeros
-            const bool kin = 4 * q + lrow < NB;
-            const int back = kin ? 0 : lrow * W;
-            a0[q] = pa0[4 * q * W - back] * dq[q]; b0[q] = pb0[4 * q * W - back];
-            a1[q] = pa1[4 * q * W - back] * dq[q]; b1[q] = pb1[4 * q * W - back];
-            if (!kin) { a0[q] = 0.0; b0[q] = 0.0; a1[q] = 0.0; b1[q] = 0.0; }
-          }
-        }
-        ldlt_f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int q = 0; q < KS; ++q) {
-          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0[q], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b1[q], acc1, 0, 0, 0);
-        }
-        finish(T0, acc0);
-        finish(T1, acc1);
-      };
-      constexpr int nwaves = kSolveThreads / 64;
-      // wave w takes tiles w, w + nwaves, ... two at a time; the loads of the next pair are in flight during the current one.
-      // An odd tile out is paired with a copy of itself (both copies were loaded before either is stored, so the second
-      // store repeats the first), and past the last pair the prefetch re-reads the current one and is dropped.
-      Tile TA0, TA1, TB0, TB1;
-      auto prep_pair = [&](int t, Tile& X, Tile& Y) {
-        prep(t, X);
-        prep(t + nwaves < ntile ? t + nwaves : t, Y);
-      };
-      if (wave < ntile) {
+      if (have_tiles) {
         int t = wave;
-        prep_pair(t, TA0, TA1);
         while (true) {
           const int tb = t + 2 * nwaves;
           const bool hasB = tb < ntile;
