@@ -31,7 +31,7 @@ class Optimizer {
   void static LocalInertialBA(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF, int& num_OptKF, int& num_MPs,
                               int& num_edges, bool bLarge = false, bool bRecInit = false);
   // src/Optimizer.cc:393-814 (csrc/host/OptimizerInertialMap.cc): visual-inertial BA of the whole map, one optimize(its) at lambda 1e-5.
-  // vSingVal / bHess are unused by the reference too.  Maps of up to 600 keyframes; bFixLocal: see INTEGRATION.md.
+  // vSingVal / bHess are unused by the reference too.  Maps of up to 1200 keyframes; bFixLocal: see INTEGRATION.md.
   void static FullInertialBA(Map* pMap, int its, const bool bFixLocal = false, const unsigned long nLoopKF = 0, bool* pbStopFlag = NULL,
                              bool bInit = false, float priorG = 1e2, float priorA = 1e6, Eigen::VectorXd* vSingVal = NULL, bool* bHess = NULL);
   // src/Optimizer.cc:3956-4498: the welding visual-inertial BA of a map merge (two temporal chains + up to 31 covisible keyframes)

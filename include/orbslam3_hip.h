@@ -316,7 +316,7 @@ int osh_lba_pack_check(int32_t n_windows, const osh_lba_problem* problems, int32
  *
  * The same structure carries Optimizer::FullInertialBA (src/Optimizer.cc:393-814: every keyframe of the map in n_opt, lambda_init 1e-5,
  * one optimize(its); with bInit see link_bias) and Optimizer::MergeInertialBA (:3956-4498: lambda_init 1e3, optimize(8)).  A keyframe of
- * n_opt that no link touches is a pose-only vertex (its velocity / bias entries come back unchanged).  Up to 600 optimisable keyframes;
+ * n_opt that no link touches is a pose-only vertex (its velocity / bias entries come back unchanged).  Up to 1200 optimisable keyframes;
  * up to 51 the reduced system is factorised in the LDS of one thread block, beyond that by the window's whole block group in global memory.
  */
 #define OSH_PREINT_FLOATS 72

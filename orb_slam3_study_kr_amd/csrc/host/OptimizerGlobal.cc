@@ -83,6 +83,7 @@ void PackBundleAdjustment(const std::vector<KeyFrame*>& vpKFs, const std::vector
       if (pKF->mpCamera2 && std::get<1>(ob.second) != -1 && std::get<1>(ob.second) < (int)pKF->mvKeysRight.size()) {
         // EdgeSE3ProjectXYZToBody (:235-283): right-camera observation; the (float) Huber delta is thHuber2D as for the left edge
         if (!pk.rig_camera(pKF)) return;
+        if (std::get<1>(ob.second) < pKF->NLeft) { pk.unsupported = "right-camera index below NLeft"; return; }   // (read unchecked at :236)
         Ed e;
         e.kf = pKF; e.mp = pMP; e.pose = pit->second; e.kind = OSH_EDGE_BODY; e.right = std::get<1>(ob.second);
         const cv::KeyPoint& kp = pKF->mvKeysRight[e.right - pKF->NLeft];

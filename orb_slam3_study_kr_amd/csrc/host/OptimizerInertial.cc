@@ -255,6 +255,9 @@ bool PackLocalInertialBA(KeyFrame* pKF, Map* pMap, bool bLarge, bool bRecInit, L
         int rightIndex = std::get<1>(ob.second);
         if (rightIndex != -1) {
           rightIndex -= pKFi->NLeft;
+          // (the reference reads mvKeysRight[rightIndex] without a check, :2803; an observation tuple whose right slot lies below NLeft
+          // would read out of bounds: declined like the same case of FullInertialBA)
+          if (rightIndex < 0 || rightIndex >= (int)pKFi->mvKeysRight.size()) { pk.unsupported = "right-camera index outside mvKeysRight"; return true; }
           if (pKFi->mpCamera->GetType() != GeometricCamera::CAM_FISHEYE || pKFi->mpCamera2->GetType() != GeometricCamera::CAM_FISHEYE) {
             pk.unsupported = "right-camera observation of a rig that is not a KannalaBrandt8 pair"; return true;
           }

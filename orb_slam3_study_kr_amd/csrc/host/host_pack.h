@@ -53,6 +53,7 @@ struct LbaPack {
   bool add_body_edge(KeyFrame* pKF, MapPoint* pMP, int rightIndex, int pose, int point) {
     if (!rig_camera(pKF)) return false;
     rightIndex -= pKF->NLeft;                                   // :1369
+    if (rightIndex < 0 || rightIndex >= (int)pKF->mvKeysRight.size()) { unsupported = "right-camera index outside mvKeysRight"; return false; }
     const cv::KeyPoint& kp = pKF->mvKeysRight[rightIndex];      // :1372
     edge_pose.push_back(pose);
     edge_point.push_back(point);

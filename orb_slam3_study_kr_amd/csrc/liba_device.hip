@@ -37,7 +37,7 @@ constexpr int kLinkQ = 832;   // per link: J^T W J (24x24), -J^T W r (24), then 
 // LDS scratch: the LDL^T panels of the reduced system when they fit one block's LDS (NB = 24: up to 51 keyframes, every LocalInertialBA /
 // MergeInertialBA window, liba_solve); beyond that the group factorises in global memory (NB = 6 names that variant, liba_solve_group)
 // and LDS holds its 16 x 16 blocks and two vectors only.  600 keyframes = a dense 9000 x 9000 system (H and S: 1.3 GB).
-constexpr int kLibaMaxKeyframes = 600;
+constexpr int kLibaMaxKeyframes = 1200;
 __host__ __device__ constexpr size_t liba_scratch_doubles(int NB, int W) {
   const size_t need = NB == kLNB ? ldlt_lds_doubles(NB, W, kLT) : (size_t)(6 * 256 + 64 + W + 32);
   return need > 512 ? need : 512;
@@ -101,12 +101,15 @@ __device__ __forceinline__ double blk_max(double v, double* shw) {
   return t;
 }
 
+// place of keyframe i's pose (6 unknowns) / velocity + biases (9 unknowns) in the reduced system, see LibaDesc::il
+__device__ __forceinline__ int off_pose(const LibaDesc& d, int i) { return d.il ? 15 * i : 6 * i; }
+__device__ __forceinline__ int off_vba(const LibaDesc& d, int i) { return d.il ? 15 * i + 6 : 6 * d.N + 9 * i; }
 // reduced-state offset of vertex v (0..5) of link (a -> c), or -1 when the vertex is fixed
-__device__ __forceinline__ int link_vertex_offset(int v, int a, int c, int ab, int N) {
+__device__ __forceinline__ int link_vertex_offset(const LibaDesc& d, int v, int a, int c, int ab) {
   const int kf = (v == 2 || v == 3) ? ab : (v < 4) ? a : c;   // ab: the keyframe that stores the edge's bias vertices (osh_liba_problem.link_bias)
-  if (kf >= N) return -1;
-  if (v == 0 || v == 4) return 6 * kf;
-  const int base = 6 * N + 9 * kf;
+  if (kf >= d.N) return -1;
+  if (v == 0 || v == 4) return off_pose(d, kf);
+  const int base = off_vba(d, kf);
   return (v == 1 || v == 5) ? base : (v == 2 ? base + 3 : base + 6);
 }
 
@@ -426,7 +429,7 @@ __device__ __noinline__ void liba_assemble_links(const LibaCtx& c, int sel, int 
           const int ca = sl / 24, cb = sl - ca * 24;
           const int va = vert_of(ca), vb = vert_of(cb);
           if (vb < va) continue;   // upper blocks + mirrored below
-          const int oa = link_vertex_offset(va, a, c, ab, N), ob = link_vertex_offset(vb, a, c, ab, N);
+          const int oa = link_vertex_offset(d, va, a, c, ab), ob = link_vertex_offset(d, vb, a, c, ab);
           if (oa < 0 || ob < 0) continue;
           double val = Q[sl];
           if (va == vb && (va == 2 || va == 3)) val += (va == 2 ? v.link_info_g : v.link_info_a)[(size_t)gl * 9 + (ca - vbase[va]) * 3 + (cb - vbase[vb])];
@@ -436,7 +439,7 @@ __device__ __noinline__ void liba_assemble_links(const LibaCtx& c, int sel, int 
         } else if (sl < 600) {
           const int ca = sl - 576;
           const int va = vert_of(ca);
-          const int oa = link_vertex_offset(va, a, c, ab, N);
+          const int oa = link_vertex_offset(d, va, a, c, ab);
           if (oa < 0) continue;
           double val = Q[sl];
           if (va == 2 || va == 3) {
@@ -450,8 +453,8 @@ __device__ __noinline__ void liba_assemble_links(const LibaCtx& c, int sel, int 
         } else if (sl < 642) {
           const int t = sl - 600, which = t / 21, u = t - which * 21;
           const double* Og = (which == 0 ? v.link_info_g : v.link_info_a) + (size_t)gl * 9;
-          const int o1 = (a < N) ? n6 + 9 * a + 3 + 3 * which : -1;
-          const int o2 = n6 + 9 * c + 3 + 3 * which;
+          const int o1 = (a < N) ? off_vba(d, a) + 3 + 3 * which : -1;
+          const int o2 = off_vba(d, c) + 3 + 3 * which;
           if (u < 9) {
             const int i = u / 3, j = u - i * 3;
             if (o1 >= 0) { H[(size_t)(o1 + i) * n + o2 + j] += -Og[u]; H[(size_t)(o2 + j) * n + o1 + i] += -Og[u]; }
@@ -475,7 +478,16 @@ __device__ __noinline__ void liba_linearise(const LibaCtx& c, int sel) {
   const double* poses = v.pose[sel] + (size_t)d.pose_off * 24;
   const double* vba = v.vba[sel] + (size_t)d.vel_off * 9;
   const double* pts = v.pts[sel] + (size_t)d.pt_off * 3;
-    for (int k = gt; k < n * n; k += GT) H[k] = 0.0;
+    if (d.il) {
+      // banded layout: only the entries within the band exist (both triangles of H are used by the link assembly)
+      const long long wrow = 2ll * d.bw + 1, tot = (long long)n * wrow;
+      for (long long k = gt; k < tot; k += GT) {
+        const int r = (int)(k / wrow), cc = r - d.bw + (int)(k - (long long)r * wrow);
+        if (cc >= 0 && cc < n) H[(size_t)r * n + cc] = 0.0;
+      }
+    } else {
+      for (int k = gt; k < n * n; k += GT) H[k] = 0.0;
+    }
     for (int k = gt; k < n; k += GT) b[k] = 0.0;
     // inertial links, Jacobians: link l belongs to block l mod G, one lane of that block's last wavefront each
     if (wave == kLT / 64 - 1) {
@@ -597,9 +609,91 @@ __device__ __noinline__ void liba_linearise(const LibaCtx& c, int sel) {
     }
 }
 
+// ---- the same for the banded layout of a map-sized problem (LibaDesc::il): S = H + lambda I only inside the band, the Schur products
+// only for keyframe pairs at most bw_kf apart, and for such a pair only over the landmarks keyframe i observes (its edge list)
+// instead of over all landmarks: O(N bw_kf deg) instead of O(N^2 L).
+__device__ __noinline__ void liba_schur_banded(const LibaCtx& c, double lambda) {
+  OSH_LIBA_LOCALS
+  {
+    const long long wrow = (long long)d.bw + 1, tot = (long long)n * wrow;
+    for (long long k = gt; k < tot; k += GT) {
+      const int r = (int)(k / wrow), cc = r + (int)(k - (long long)r * wrow);
+      if (cc >= n) continue;
+      if ((r % 15) < 6 && (cc % 15) < 6) {               // pose-pose blocks: written below for keyframes at most bw_kf apart
+        if (cc / 15 - r / 15 > d.bw_kf) S[(size_t)r * n + cc] = 0.0;
+        continue;
+      }
+      S[(size_t)r * n + cc] = H[(size_t)r * n + cc] + ((r == cc) ? lambda : 0.0);
+    }
+    for (int k = gt; k < n; k += GT) if ((k % 15) >= 6) { bfull[k] = b[k]; bs[k] = b[k]; }
+  }
+  const int wp = d.bw_kf + 1;
+  const long long npairs = (long long)N * wp;
+  for (long long pr = wave * G + m; pr < npairs; pr += GW) {
+    const int i = (int)(pr / wp), i2 = i + (int)(pr - (long long)i * wp);
+    if (i2 >= N) continue;
+    double acc[36], ci[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+    const int p_lo = po[i], p_hi = po[i + 1];
+    for (int p0 = p_lo + lane; p0 < p_hi; p0 += 64) {
+      const int e = v.pel_edge[(size_t)d.edge_off + p0];
+      const int j = v.e_point[(size_t)d.edge_off + e];
+      if (lmpe[(size_t)j * N + i] != p0) continue;       // the second edge of a (keyframe, landmark) pair shares the first one's block
+      const int e2 = (i2 == i) ? p0 : lmpe[(size_t)j * N + i2];
+      if (e2 < 0) continue;
+      double a1[18], b2[18];
+#pragma unroll
+      for (int k = 0; k < 18; ++k) { a1[k] = BD[k * PS + p0]; b2[k] = Hpl[k * PS + e2]; }
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const double a0 = a1[r * 3], a1v = a1[r * 3 + 1], a2 = a1[r * 3 + 2];
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) acc[r * 6 + cc] += a0 * b2[cc * 3] + a1v * b2[cc * 3 + 1] + a2 * b2[cc * 3 + 2];
+      }
+      if (i == i2) {
+        const double* Dj = dinv + (size_t)j * 9;
+        const double d0 = Dj[6], d1 = Dj[7], d2 = Dj[8];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) ci[r] += b2[r * 3] * d0 + b2[r * 3 + 1] * d1 + b2[r * 3 + 2] * d2;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 36; ++k) acc[k] = dev::wave_sum_dpp(acc[k]);
+    const int oi = off_pose(d, i), oi2 = off_pose(d, i2);
+    if (lane < 36) {
+      double val = acc[0];
+#pragma unroll
+      for (int k = 1; k < 36; ++k) val = (lane == k) ? acc[k] : val;
+      const int r = lane / 6, cc = lane - r * 6;
+      double base = H[(size_t)(oi + r) * n + oi2 + cc];
+      if (i == i2) {
+        const int qq = up21(r, cc);
+        for (int ch = 0; ch < C; ++ch) base += ppart[((size_t)i * kPoseChunks + ch) * 27 + qq];
+        if (r == cc) base += lambda;
+      }
+      S[(size_t)(oi + r) * n + oi2 + cc] = base - val;
+    }
+    if (i == i2) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) ci[r] = dev::wave_sum_dpp(ci[r]);
+      if (lane < 6) {
+        double cv = ci[0];
+        if (lane == 1) cv = ci[1]; else if (lane == 2) cv = ci[2]; else if (lane == 3) cv = ci[3];
+        else if (lane == 4) cv = ci[4]; else if (lane == 5) cv = ci[5];
+        double bf = b[oi + lane];
+        for (int ch = 0; ch < C; ++ch) bf += ppart[((size_t)i * kPoseChunks + ch) * 27 + 21 + lane];
+        bfull[oi + lane] = bf;
+        bs[oi + lane] = bf - cv;
+      }
+    }
+  }
+}
+
 // ---- S = H + lambda I, Schur complement of the landmarks, right-hand side
 __device__ __noinline__ void liba_schur(const LibaCtx& c, double lambda) {
   OSH_LIBA_LOCALS
+  if (d.il) { liba_schur_banded(c, lambda); return; }
       // S = H + lambda I and the rhs outside the pose-pose blocks (upper triangle)
       for (int k = gt; k < n * n; k += GT) {
         const int r = k / n, c = k - r * n;
@@ -662,7 +756,7 @@ __device__ __noinline__ void liba_schur(const LibaCtx& c, double lambda) {
 #pragma unroll
           for (int k = 1; k < 36; ++k) val = (lane == k) ? acc[k] : val;
           const int r = lane / 6, c = lane - r * 6;
-          double base = H[(size_t)(6 * i + r) * n + 6 * i2 + c];
+          double base = H[(size_t)(6 * i + r) * n + 6 * i2 + c];   // (il = 0 here: poses first)
           if (i == i2) {
             const int qq = up21(r, c);
             for (int ch = 0; ch < C; ++ch) base += ppart[((size_t)i * kPoseChunks + ch) * 27 + qq];
@@ -737,8 +831,10 @@ __device__ __noinline__ bool liba_solve_group(const LibaCtx& c, Grp& g, int* lds
     }
     __syncthreads();
     for (int q = 0; q < kb; ++q) if (du[q * kPB + q] == 0.0) ok = false;   // Eigen's LDLT fails on an exactly-zero pivot only
+    // banded layout: the pivot rows end bw columns right of the diagonal; what lies beyond is not stored
+    const int jend = d.il ? min(n, k0 + kb + d.bw) : n;
     // ---- the row panel: column j of rows k0 .. k0+kb, one column per thread of the group
-    for (int j = k0 + kb + gt; j < n; j += GT) {
+    for (int j = k0 + kb + gt; j < jend; j += GT) {
       double col[kPB];
 #pragma unroll
       for (int p = 0; p < kPB; ++p) col[p] = p < kb ? S[(size_t)(k0 + p) * n + j] : 0.0;
@@ -763,27 +859,27 @@ __device__ __noinline__ bool liba_solve_group(const LibaCtx& c, Grp& g, int* lds
       double* wt = wsh + wave * kPB * kPB;
       const int gw = m * (kLT / 64) + wave;
       int base = 0;
-      for (int i0 = t0; i0 < n; i0 += kPB) {
-        const int nc = (n - i0 + 63) >> 6;
+      for (int i0 = t0; i0 < jend; i0 += kPB) {
+        const int nc = (jend - i0 + 63) >> 6;
         int first = (gw - base) % GW; if (first < 0) first += GW;
         base = (base + nc) % GW;
         if (first >= nc) continue;
         // this wavefront has chunks of row tile i0: the multipliers u_pi / d_p of its 16 rows
         for (int idx = lane; idx < kPB * kPB; idx += 64) {
           const int pp = idx >> 4, ii = idx & 15;
-          wt[idx] = (i0 + ii < n) ? S[(size_t)(k0 + pp) * n + i0 + ii] * ddi[pp] : 0.0;
+          wt[idx] = (i0 + ii < jend) ? S[(size_t)(k0 + pp) * n + i0 + ii] * ddi[pp] : 0.0;
         }
         __builtin_amdgcn_wave_barrier();
         for (int jc = first; jc < nc; jc += GW) {
           const int j = i0 + (jc << 6) + lane;
-          if (j >= n) continue;
+          if (j >= jend) continue;
           double uj[kPB];
 #pragma unroll
           for (int p = 0; p < kPB; ++p) uj[p] = S[(size_t)(k0 + p) * n + j];
 #pragma unroll
           for (int ii = 0; ii < kPB; ++ii) {
             const int i = i0 + ii;
-            if (i >= n || j < i) continue;
+            if (i >= jend || j < i) continue;
             double acc = 0.0;
 #pragma unroll
             for (int p = 0; p < kPB; ++p) acc += wt[p * kPB + ii] * uj[p];
@@ -821,7 +917,8 @@ __device__ __noinline__ bool liba_solve_group(const LibaCtx& c, Grp& g, int* lds
         if (tid < kb) xs[k0 + tid] = z;
       }
       __syncthreads();
-      for (int j = k0 + kb + tid; j < n; j += kLT) {
+      const int jend = d.il ? min(n, k0 + kb + d.bw) : n;
+      for (int j = k0 + kb + tid; j < jend; j += kLT) {
         double acc = 0.0;
         for (int p = 0; p < kb; ++p) acc += S[(size_t)(k0 + p) * n + j] * (xs[k0 + p] * ddi[p]);
         xs[j] -= acc;
@@ -834,7 +931,8 @@ __device__ __noinline__ bool liba_solve_group(const LibaCtx& c, Grp& g, int* lds
       double part[kPB];
 #pragma unroll
       for (int p = 0; p < kPB; ++p) part[p] = 0.0;
-      for (int j = k0 + kb + tid; j < n; j += kLT) {
+      const int jend = d.il ? min(n, k0 + kb + d.bw) : n;
+      for (int j = k0 + kb + tid; j < jend; j += kLT) {
         const double xj = xs[j];
 #pragma unroll
         for (int p = 0; p < kPB; ++p) if (p < kb) part[p] += S[(size_t)(k0 + p) * n + j] * xj;
@@ -884,6 +982,18 @@ __device__ __noinline__ double liba_backsub(const LibaCtx& c, int sel, double la
         const int q = tid & (T - 1);
         for (int j = gt / T; j < L; j += GT / T) {
           double c0 = 0, c1 = 0, c2 = 0;
+          if (d.il) {
+            // map-sized problem: walk the landmark's own edges (a handful) instead of every keyframe's slot in lm_pose_edge
+            for (int x = lmo[j] + q; x < lmo[j + 1]; x += T) {
+              const int ip = v.e_pose[(size_t)d.edge_off + x];
+              if (ip >= N) continue;
+              const int pos = lmpe[(size_t)j * N + ip];
+              if (pos < 0 || v.pel_edge[(size_t)d.edge_off + pos] != x) continue;   // the second edge of a pair shares the first one's block
+              const double* xp = xg + off_pose(d, ip);
+#pragma unroll
+              for (int r = 0; r < 6; ++r) { const double mx = -xp[r]; c0 += Hpl[(r * 3) * PS + pos] * mx; c1 += Hpl[(r * 3 + 1) * PS + pos] * mx; c2 += Hpl[(r * 3 + 2) * PS + pos] * mx; }
+            }
+          } else
           for (int i0 = q; i0 < N; i0 += 2 * T) {   // two blocks in flight
             int eu[2];
 #pragma unroll
@@ -928,7 +1038,7 @@ __device__ __noinline__ double liba_backsub(const LibaCtx& c, int sel, double la
       double* vba_t = v.vba[trs] + (size_t)d.vel_off * 9;
       if (m == G - 1) {
         for (int k = kLT - 1 - tid; k < N; k += kLT) {
-          const double* pu = xg + 6 * k;
+          const double* pu = xg + off_pose(d, k);
           const double* P = poses + 24 * (size_t)k;
           double* Q = poses_t + 24 * (size_t)k;
           double tw[3], Ex[9], Rwb[9], Rbw[9], tbw[3], tc[3];
@@ -943,7 +1053,7 @@ __device__ __noinline__ double liba_backsub(const LibaCtx& c, int sel, double la
           imu::m3_mul(d.Rcb, Rbw, Q);
           imu::m3_vec(d.Rcb, tbw, tc);
           for (int i = 0; i < 3; ++i) Q[9 + i] = tc[i] + d.tcb[i];
-          for (int i = 0; i < 9; ++i) vba_t[9 * k + i] = vba[9 * k + i] + xg[n6 + 9 * k + i];
+          for (int i = 0; i < 9; ++i) vba_t[9 * k + i] = vba[9 * k + i] + xg[off_vba(d, k) + i];
         }
         for (int k = tid; k < n; k += kLT) sc += xg[k] * (lambda * xg[k] + bfull[k]);
       }
@@ -1071,7 +1181,8 @@ __global__ __launch_bounds__(kLT) void k_liba(LibaView v, int W, int G) {
         double mx = 0.0;
         for (int k = tid; k < n; k += kLT) {
           double hd = H[(size_t)k * n + k];
-          if (k < n6) { const int i = k / 6, r = k - i * 6; for (int ch = 0; ch < C; ++ch) hd += ppart[((size_t)i * kPoseChunks + ch) * 27 + up21(r, r)]; }
+          const bool is_pose = d.il ? (k % 15) < 6 : k < n6;
+          if (is_pose) { const int i = d.il ? k / 15 : k / 6, r = d.il ? k % 15 : k - i * 6; for (int ch = 0; ch < C; ++ch) hd += ppart[((size_t)i * kPoseChunks + ch) * 27 + up21(r, r)]; }
           mx = fmax(mx, fabs(hd));
         }
         for (int j = tid; j < L; j += kLT) mx = fmax(mx, fmax(fabs(Hll[(size_t)j * 6]), fmax(fabs(Hll[(size_t)j * 6 + 3]), fabs(Hll[(size_t)j * 6 + 5]))));
@@ -1193,7 +1304,7 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
         p.max_iterations > OSH_LBA_MAX_TRACE) { set_error("window %d: bad sizes", w); return OSH_ERR_INVALID; }
     LibaDesc& d = h_desc[w];
     d.N = p.n_opt; d.NV = p.n_opt + p.n_fixed_imu; d.K = d.NV + p.n_fixed; d.L = p.n_points; d.E = p.n_edges; d.NL = p.n_links;
-    d.n = 15 * d.N; d.max_iter = p.max_iterations; d.n_colours = 0; d.pad_ = 0;
+    d.n = 15 * d.N; d.max_iter = p.max_iterations; d.n_colours = 0; d.il = 0; d.bw = d.n; d.bw_kf = d.N;
     d.pose_off = (int)K; d.vel_off = (int)NV; d.pt_off = (int)L; d.edge_off = (int)E; d.link_off = (int)NL; d.lmoff_off = (int)LO;
     d.peloff_off = (int)PO; d.pel_off = (int)EF; d.lmpose_off = (int)LP; d.H_off = (long long)Htot; d.b_off = (int)btot;
     std::memcpy(d.Rcb, p.Rcb, 72); std::memcpy(d.tcb, p.tcb, 24); std::memcpy(d.tbc, p.tbc, 24); std::memcpy(d.cam, p.cam, 40);
@@ -1255,6 +1366,34 @@ extern "C" int osh_liba_solve(osh_lba_ctx* ctx, int32_t nw, const osh_liba_probl
   if (lds > 160 * 1024 - 64 || n_max > 15 * kLibaMaxKeyframes) {
     set_error("inertial window with %d optimisable keyframes: the device path handles up to %d (LocalInertialBA uses 10 or 25)", n_max / 15, kLibaMaxKeyframes);
     return OSH_ERR_UNSUPPORTED;
+  }
+  // Map-sized problems (the group factorisation in global memory): with the keyframes in temporal order a landmark is seen by nearby
+  // keyframes and an IMU link joins neighbours, so with the unknowns interleaved per keyframe the reduced system is banded.  The band is
+  // the largest keyframe distance any landmark or link spans; a loop closure or the one-bias-pair mode of FullInertialBA (every link on
+  // one keyframe's bias vertices) makes it the whole map, and the problem stays in the dense layout.
+  if (NB != kLNB && !getenv("OSH_LIBA_DENSE")) {
+    std::vector<int> lo, hi;
+    for (int w = 0; w < nw; ++w) {
+      const osh_liba_problem& p = pr[w];
+      LibaDesc& d = h_desc[w];
+      if (d.N < 32) continue;
+      int span = 1;
+      lo.assign(d.L, d.N); hi.assign(d.L, -1);
+      for (int e = 0; e < p.n_edges; ++e) {
+        const int ip = p.edge_pose[e], j = p.edge_point[e];
+        if (ip >= d.N) continue;
+        lo[j] = std::min(lo[j], ip); hi[j] = std::max(hi[j], ip);
+      }
+      for (int j = 0; j < d.L; ++j) if (hi[j] >= 0) span = std::max(span, hi[j] - lo[j]);
+      for (int l = 0; l < p.n_links; ++l) {
+        const int a = p.link_prev[l], c2 = p.link_cur[l], ab = p.link_bias ? p.link_bias[l] : a;
+        int mn = c2, mx = c2;
+        if (a < d.N) { mn = std::min(mn, a); mx = std::max(mx, a); }
+        if (ab < d.N) { mn = std::min(mn, ab); mx = std::max(mx, ab); }
+        span = std::max(span, mx - mn);
+      }
+      if (15 * (span + 1) <= d.n / 2) { d.il = 1; d.bw_kf = span; d.bw = 15 * (span + 1) - 1; }
+    }
   }
   // ---- pack: every input array goes into ONE pinned staging buffer and travels in ONE copy (an upload per array cost more than
   // the optimisation of a single window); the device pointers are offsets into the arena.

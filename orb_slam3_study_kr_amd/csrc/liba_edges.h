@@ -21,7 +21,11 @@ struct LibaDesc {
   int rig_on;      // 1: fisheye stereo rig, OSH_EDGE_RIGHT edges are EdgeMono(1) on camera 1 of ImuCamPose (src/G2oTypes.cc:56-66)
   double Rrl[9], trl[3], Rcb1[9], tbc1[3], cam2[8];   // Trl; Rcb[1] = Rrl Rcb[0]; tbc[1] = -Rbc[1] tcb[1]; right camera fx fy cx cy k1..k4
   double huber_mono, huber_stereo, huber_inertial, lambda_init;
-  int n_colours, pad_;   // inertial links are coloured so that the links of one colour share no keyframe (liba_device.hip)
+  int n_colours;         // inertial links are coloured so that the links of one colour share no keyframe (liba_device.hip)
+  int il;                // layout of the reduced unknowns: 0 = [pose 6] x N then [velocity, gyro bias, accelerometer bias 9] x N (every
+                         // LocalInertialBA window), 1 = [pose 6 | v bg ba 9] per keyframe (map-sized problems: with the keyframes in
+                         // temporal order the reduced system is then BANDED -- landmarks and IMU links couple nearby keyframes only)
+  int bw, bw_kf;         // il = 1: entries (r, c) with |r - c| > bw are structurally zero and never touched; bw_kf = the same in keyframes
 };
 
 struct VisEval { double r[3], chi2, Xc[3]; };

@@ -159,12 +159,30 @@ def test_a_barrier_that_gives_up_is_retried_with_one_block_per_window(solver, mo
     assert solver.solve_inertial([w])[0].iterations == one.iterations and solver.inertial_profile()[0] == 32
 
 
+def test_banded_layout_of_a_map_sized_problem_equals_the_dense_one(solver, monkeypatch):
+    """FullInertialBA over a map (src/Optimizer.cc:393-814): with the keyframes in temporal order the reduced system is banded (landmarks and
+    IMU links couple nearby keyframes), so the unknowns are interleaved per keyframe and only the band is formed and factored.
+    OSH_LIBA_DENSE=1 keeps the dense [poses | velocities, biases] system of round 2: same iterations, the same trace and the same states
+    up to the rounding of another elimination order.  One keyframe is fixed (n_fixed_imu) so the minimum is unique."""
+    import dataclasses
+    w = si.make_inertial_window(905, n_opt=90, n_fixed=0, n_points=3000, large=True)
+    w = dataclasses.replace(w, lambda_init=1e-5, max_iterations=5, link_robust=np.ones_like(w.link_robust))
+    a = solver.solve_inertial([w])[0]
+    monkeypatch.setenv("OSH_LIBA_DENSE", "1")
+    b = solver.solve_inertial([w])[0]
+    assert a.iterations == b.iterations and list(a.trials_trace[:a.iterations]) == list(b.trials_trace[:b.iterations])
+    np.testing.assert_allclose(a.chi2_trace[:a.iterations], b.chi2_trace[:b.iterations], rtol=1e-9)
+    np.testing.assert_allclose(a.pose_twb, b.pose_twb, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(a.vel, b.vel, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(a.points, b.points, rtol=0, atol=1e-7)
+
+
 def test_large_window_of_25_keyframes(solver, ob):
     """LocalInertialBA's bLarge case: 25 temporal keyframes (src/Optimizer.cc:2394-2400), a 375 x 375 reduced system."""
     w = si.make_inertial_window(61, n_opt=25, n_fixed=10, n_points=1500, large=True)
     _check(solver.solve_inertial([w])[0], ob.liba_solve(w), w)
-    with pytest.raises(RuntimeError, match="up to 600"):
-        solver.solve_inertial([si.make_inertial_window(62, n_opt=601, n_fixed=0, n_points=300, large=True)])
+    with pytest.raises(RuntimeError, match="up to 1200"):
+        solver.solve_inertial([si.make_inertial_window(62, n_opt=1201, n_fixed=0, n_points=300, large=True)])
 
 
 def _without_links_at(w, kfs):
