@@ -50,7 +50,7 @@ def generate_windows(seeds, workers=8):
 # products in the same pass (the 6x3 blocks Hpl exist only in registers), so their times cannot be told apart.
 STEP_KERNELS = {
     "lin_schur": ["linearize", "lin_aux", "lin_pose", "pose_hess", "schur", "schur_cross", "schur_reduce"],
-    "solve": ["solve"], "backsub": ["backsub"], "residual": ["residual"],
+    "solve": ["solve"], "backsub_residual": ["backsub", "residual"],   # k_backsub ends with the trial residual of its chunk (round 3): one pass
 }
 
 
@@ -62,8 +62,8 @@ def kernel_algorithmic_bytes(windows, results):
     144-byte Hpl block of every optimisable edge to linearise (write), Schur (read) and back-substitution (read).
     "impl": what THIS implementation's kernels need at least: Hpl is never stored, each of those passes reads the 32-byte
     observation record + 8 bytes of indices per edge instead and the landmark factor (72 B) per landmark."""
-    sv = dict(lin_schur=0, solve=0, backsub=0, residual=0)
-    im = dict(lin_schur=0, solve=0, backsub=0, residual=0)
+    sv = dict(lin_schur=0, solve=0, backsub_residual=0)
+    im = dict(lin_schur=0, solve=0, backsub_residual=0)
     for w, r in zip(windows, results):
         b = w.algorithmic_bytes()
         P, F, L, E, Ef = w.n_free, w.n_fixed, w.n_points, w.n_edges, w.n_free_edges
@@ -71,13 +71,11 @@ def kernel_algorithmic_bytes(windows, results):
         solve = (6 * P) * (6 * P + 1) * 8 + 2 * 6 * P * 8 + 2 * P * 56
         sv["lin_schur"] += it * b["lin"] + tr * b["schur"]
         sv["solve"] += tr * solve
-        sv["backsub"] += tr * (b["back"] + 2 * L * 24)
-        sv["residual"] += tr * b["resid"]
+        sv["backsub_residual"] += tr * (b["back"] + 2 * L * 24 + b["resid"])
         poses = (P + F) * 96
         im["lin_schur"] += it * (E * 40 + L * 24 + poses + L * 144 + P * 216) + tr * (Ef * 32 + L * 96 + (6 * P) * (6 * P + 1) * 8)
         im["solve"] += tr * solve
-        im["backsub"] += tr * (Ef * 40 + L * (72 + 24 + 24 + 24) + 6 * P * 8 + poses)
-        im["residual"] += tr * (E * 40 + L * 24 + poses)
+        im["backsub_residual"] += tr * (E * 40 + L * (72 + 24 + 24 + 24) + 6 * P * 8 + 2 * poses)   # every edge record once, both pose sets
     return sv, im
 
 

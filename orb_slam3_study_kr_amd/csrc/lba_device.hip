@@ -753,6 +753,9 @@ __global__ __launch_bounds__(256) void k_schur_reduce(BatchView bv) {
     bv.bs[gp * 6 + el] = v;
     return;
   }
+  // A block above the column envelope of S (no landmark joins keyframe i to j or to any keyframe before i, k_schur_env) is zero, is
+  // never touched by the envelope factorisation of k_solve and was zeroed at upload: nothing to write.
+  if (bv.pose_lo && i < bv.pose_lo[wd.fpose_off + j]) return;
   const int r = el / 6, cc = el - 6 * r;
   double v = 0.0;
   if (i == j) v = bv.Hpp[((size_t)wd.fpose_off + i) * 36 + el] + ((r == cc) ? st.lambda : 0.0);
@@ -990,6 +993,39 @@ __global__ __launch_bounds__(kBlock) void k_backsub(BatchView bv) {
   }
   sc = block_sum(sc, sh4);
   if (tid == 0) bv.scale_part[blockIdx.x] = sc;
+  // ---- the trial residual of the chunk's edges (computeActiveErrors + activeRobustChi2 at the trial estimates, what k_residual did in
+  // a pass of its own until round 3): the chunk's trial landmarks are in this block's registers, the trial poses were written by
+  // k_solve before this launch.  Same lane <-> edge mapping and the same sums as k_residual: the chunk's chi2 is the same number.
+  __syncthreads();
+  if (tid < nl) {
+    const double* Xt = bv.pt_state[st.sel ^ 1] + ((size_t)wd.pt_off + ch.lm0 + tid) * 3;   // (just written by this thread)
+    sh_X[tid * 3] = Xt[0]; sh_X[tid * 3 + 1] = Xt[1]; sh_X[tid * 3 + 2] = Xt[2];
+  }
+  const double* poses_t = bv.pose_state[st.sel ^ 1] + (size_t)wd.pose_off * 7;
+  const bool staged_t = (wd.P + wd.F) <= kLdsPoses;
+  double* sh_pose_t = sh_pose + (staged ? wd.P * kPoseRec : 0);
+  if (staged_t) stage_poses(sh_pose_t, poses_t, cams, wd.P + wd.F, tid, kBlock);
+  __syncthreads();
+  double chi_acc = 0.0;
+  for (int base = e0; base < e1; base += kChunkMaxEdges) {
+    LaneEdges le;
+    load_lane_edges<F32>(bv, wd, base, e1, tid, le);
+#pragma unroll
+    for (int p = 0; p < kPasses; ++p) {
+      const int e = base + p * kChunkEdges + tid;
+      if (e < e1) {
+        double qt[7], cam[5], R[9], X[3];
+        fetch_pose(staged_t, sh_pose_t, poses_t, cams, le.ip[p], qt, cam, R);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) X[k] = sh_X[(le.il[p] - ch.lm0) * 3 + k];
+        const double rec[4] = {le.ra[p].x, le.ra[p].y, le.rb[p].x, le.rb[p].y};
+        double cl, cr;
+        chi_acc += win_edge_rho<KB8>(wd, bv, (size_t)wd.edge_off + e, rec, qt, cam, R, X, cl, cr);
+      }
+    }
+  }
+  const double chi = block_sum(chi_acc, sh4);
+  if (tid == 0) bv.chi_part[blockIdx.x] = chi;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1409,7 +1445,7 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
     c->lin_lds = (size_t)(9 * kChunkEdges + 4 + 3 * kBlock + staged * kPoseRec) * sizeof(double);
     c->resid_lds = (size_t)(4 + 3 * kBlock + staged * kPoseRec) * sizeof(double);
     const int pmax = pb.n_max / 6;
-    c->backsub_lds = (size_t)(3 * kChunkEdges + 4 + 3 * kBlock + (pmax <= kLdsPoses ? pb.n_max + pmax * kPoseRec : 0)) * sizeof(double);
+    c->backsub_lds = (size_t)(3 * kChunkEdges + 4 + 3 * kBlock + (pmax <= kLdsPoses ? pb.n_max + pmax * kPoseRec : 0) + staged * kPoseRec) * sizeof(double);
     // One block per window with the widest panel that fits.  A batch takes 256-thread blocks: the one LDS panel of ldlt_block.h
     // (70 KB for 50 keyframes) lets two windows share a CU, and the factorisation is latency bound, so they overlap (measured:
     // 5.5 ms of solve per 512-window step against 6.0 with 512-thread blocks, profiles/solve_sweep.sh); a few windows take 512 threads.
@@ -1499,7 +1535,9 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   bv.pose_lo = c->d_pose_lo.as<int>();
   hipLaunchKernelGGL(k_schur_env, dim3((unsigned)nw), dim3(256), 0, s, bv);
   OSH_TRY(launch_check("k_schur_env"));
-  if (std::getenv("OSH_LBA_DENSE_SOLVE")) bv.pose_lo = nullptr;   // factor every tile column (the behaviour before the envelope was used)
+  // dense factorisations (OSH_LBA_DENSE_SOLVE, and big_solve.h for maps beyond the LDS-resident solve) read and fill every block
+  if (std::getenv("OSH_LBA_DENSE_SOLVE") || c->solve_big) bv.pose_lo = nullptr;
+  else OSH_HIP(hipMemsetAsync(c->d_S.p, 0, std::max<size_t>(pb.S_total * 8, 8), s));   // the blocks above the envelope stay zero from here on
   OSH_HIP(hipStreamSynchronize(s));   // the staging arenas may be rewritten by the next upload
   const auto t2 = std::chrono::steady_clock::now();
   c->upload_pack_ms = on_device ? c->dpack.host_ms : std::chrono::duration<double, std::milli>(t1 - t0).count();
@@ -1668,8 +1706,7 @@ extern "C" int osh_lba_optimize(osh_lba_ctx* c) {
       LAUNCH(OSH_K_LINEARIZE, c->kp_lin_lm, pb.n_chunks, kBlock, c->lin_lds, c->bv);
       LAUNCH(OSH_K_CONTROL, k_control, c->n_windows, 64, 0, c->bv, 0);
     }
-    OSH_TRY(trial_kernels(c, round > 0));
-    LAUNCH(OSH_K_RESIDUAL, c->kp_residual, pb.n_chunks * kResidualSplit, kBlock, c->resid_lds, c->bv);
+    OSH_TRY(trial_kernels(c, round > 0));   // (k_backsub ends with the trial residual of its chunk: no k_residual pass)
     if (c->any_stop) {
       // terminate() is polled after every trial (levenberg.cpp:149) and before every iteration
       snapshot_stop(c);

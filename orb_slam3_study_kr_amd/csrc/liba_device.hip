@@ -806,6 +806,12 @@ __device__ __noinline__ bool liba_solve_group(const LibaCtx& c, Grp& g, int* lds
   double* xs = wsh + (kLT / 64) * kPB * kPB;   // [n] right-hand side -> solution (block 0)
   double* red = xs + ((n + 15) & ~15);   // [kLT/64][kPB] partial sums of the back substitution
   bool ok = true;
+#ifdef OSH_LIBA_LDLT_TRACE
+  long long gt_t[6] = {0, 0, 0, 0, 0, 0}, gt_last = clock64();
+#define OSH_GT(i) do { const long long _n = clock64(); gt_t[i] += _n - gt_last; gt_last = _n; } while (0)
+#else
+#define OSH_GT(i) do {} while (0)
+#endif
   for (int k0 = 0; k0 < n; k0 += kPB) {
     const int kb = min(kPB, n - k0);
     // ---- the diagonal block, by wavefront 0 of every block: lane t holds column k0 + t (rows 0..t)
@@ -830,6 +836,7 @@ __device__ __noinline__ bool liba_solve_group(const LibaCtx& c, Grp& g, int* lds
       }
     }
     __syncthreads();
+    OSH_GT(0);
     for (int q = 0; q < kb; ++q) if (du[q * kPB + q] == 0.0) ok = false;   // Eigen's LDLT fails on an exactly-zero pivot only
     // banded layout: the pivot rows end bw columns right of the diagonal; what lies beyond is not stored
     const int jend = d.il ? min(n, k0 + kb + d.bw) : n;
@@ -847,7 +854,9 @@ __device__ __noinline__ bool liba_solve_group(const LibaCtx& c, Grp& g, int* lds
 #pragma unroll
       for (int p = 0; p < kPB; ++p) if (p < kb) S[(size_t)(k0 + p) * n + j] = col[p];
     }
+    OSH_GT(1);
     if (!grp_sync(g, lds_flag)) return false;
+    OSH_GT(2);
     // the factored diagonal block goes back only now: until the barrier the other blocks were still reading the unfactored one
     if (m == 0) {
       const int pp = tid >> 4, tt = tid & 15;
@@ -889,8 +898,13 @@ __device__ __noinline__ bool liba_solve_group(const LibaCtx& c, Grp& g, int* lds
         __builtin_amdgcn_wave_barrier();
       }
     }
+    OSH_GT(3);
     if (!grp_sync(g, lds_flag)) return false;
+    OSH_GT(4);
   }
+#ifdef OSH_LIBA_LDLT_TRACE
+  if (m == 0 && tid == 0) printf("group ldlt n=%d bw=%d: diag %lld  row_panel %lld  barrier1 %lld  trailing %lld  barrier2 %lld cycles\n", n, d.bw, gt_t[0], gt_t[1], gt_t[2], gt_t[3], gt_t[4]);
+#endif
   // ---- substitutions by block 0 (the other blocks wait at the caller's barrier)
   if (m == 0) {
     for (int k = tid; k < n; k += kLT) xs[k] = bs[k];
