@@ -116,6 +116,21 @@ def measured_traffic(step, windows_per_gpu):
     return float(sum(per[k] for k in names))
 
 
+def measured_other_traffic(kernel, launch_key, launch_value):
+    """HBM bytes per launch of a kernel outside the local-BA loop (profiles/traffic.json, "other_bytes_per_launch": uniform launches under
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/other_kernels.py --uniform), or None when the bench launch is another size."""
+    f = ROOT / "profiles" / "traffic.json"
+    if not f.exists():
+        return None
+    t = json.loads(f.read_text())
+    if launch_key != launch_value:
+        return None
+    for k, v in t.get("other_bytes_per_launch", {}).items():
+        if k.startswith(kernel):
+            return float(v)
+    return None
+
+
 def run_lba(args, info, windows):
     """Timed region: every window resident in HBM; `--streams` solver contexts (own HIP stream each, driven by a host
     thread each) run osh_lba_optimize concurrently so the latency-bound kernels of one half overlap the other half."""
@@ -517,7 +532,8 @@ def run_inertial(args, info, windows):
         upd = 2 * (P * 56 + L * 24)
         alg += r.iterations * (lin + resid) + r.trials * (schur + back + upd + resid)
     out["roofline"] = dict(bound="hbm", kernel="k_liba<24>", achieved=alg / batch_s / 1e9, peak=8000.0, unit="GB/s", frac=alg / batch_s / 8e12,
-                           traffic=None, note="whole call incl. upload / download; a group of thread blocks per window, latency bound (DESIGN.md 4b)")
+                           traffic=measured_other_traffic("k_liba", len(windows), 128),
+                           note="whole call incl. upload / download; a group of thread blocks per window, latency bound (DESIGN.md 4b)")
     if info.rank == 0 and info.world == 1 and not args.no_cpu_baseline:
         from oracle import binding as ob
         n, t0 = 0, time.perf_counter()
@@ -725,7 +741,7 @@ def main():
         out["orb"]["roofline"] = {"bound": "valu_int", "kernel": "k_orb_bruteforce", "achieved": pe * 16 / 1e12, "peak": 39.3,
                                   "unit": "T lane-ops/s", "frac": pe * 16 / 39.3e12, "ops_per_pair_eval_algorithmic": 16,
                                   "ops_per_pair_eval_measured": 23.4, "frac_of_issue_slots_measured": pe * 23.4 / 39.3e12,
-                                  "pair_evals_per_s_kernel": pe, "traffic": None}
+                                  "pair_evals_per_s_kernel": pe, "traffic": measured_other_traffic("k_orb_bruteforce", orb_out["pairs_per_gpu"], 64)}
         if orb_sweep_out:
             out["orb"]["config3_batch_sweep"] = orb_sweep_out
         if orb_out.get("sbp"):

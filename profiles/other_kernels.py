@@ -18,6 +18,7 @@ from orb_slam3_study_kr_amd import synth_inertial as si  # noqa: E402
 
 def main():
     out = {}
+    uniform = "--uniform" in sys.argv   # counter passes: every launch of a kernel does the same work (its per-launch mean is then a per-launch value)
     base = synth.make_orb_pair(7, 2000, 2000)
     pairs = [base] * 64
     m = orb.OrbMatcher(0)
@@ -28,6 +29,16 @@ def main():
         m.match()
     launches, ms = m.profile()
     out["orb_bruteforce_ms_per_launch_64_pairs"] = ms / max(launches, 1)
+    if uniform:
+        m.close()
+        ws = [si.make_inertial_window(11 + k, n_points=3600) for k in range(8)]
+        sv = lba.LbaSolver(0)
+        batch = [ws[k % 8] for k in range(128)]
+        for _ in range(3):
+            sv.solve_inertial(batch)
+        sv.close()
+        print(json.dumps(out))
+        return
     # the whole matching loop with the sequential slot occupancy resolved on the device (k_orb_claim / k_orb_research rounds)
     m.match_local_points()
     t0 = time.perf_counter()
@@ -36,7 +47,7 @@ def main():
     out["orb_match_local_points_ms_64_pairs"] = (time.perf_counter() - t0) / 5 * 1e3
     out["orb_occupancy_rounds"] = rounds
     m.close()
-    ws = [si.make_inertial_window(11 + k) for k in range(8)]
+    ws = [si.make_inertial_window(11 + k, n_points=3600) for k in range(8)]   # BASELINE.json configs[3] at ~2 000 landmarks
     sv = lba.LbaSolver(0)
     sv.solve_inertial(ws[:1])
     t0 = time.perf_counter()

@@ -5,14 +5,14 @@
 # Pass 1: local BA only (the headline loop).  Pass 2 (trace + one PMC group): the other kernels of the path -- ORB search,
 # LocalInertialBA (k_liba), PoseOptimization (k_pose_opt) -- through profiles/other_kernels.py.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 WIN=${2:-512}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $ROOT/bench.py --windows $WIN --cache-inputs /tmp/lba_inputs.pkl --prepare-only || exit 1
-BENCH="python3 $ROOT/bench.py --windows $WIN --cache-inputs /tmp/lba_inputs.pkl --workers 1 --streams 1 --steps 1 --warmup 1 --no-orb --no-cpu-baseline --inertial-windows 0 --e2e-batches 0"
+BENCH="python3 $ROOT/bench.py --windows $WIN --cache-inputs /tmp/lba_inputs.pkl --workers 1 --streams 1 --steps 1 --warmup 1 --no-orb --no-cpu-baseline --no-sweeps --inertial-windows 0 --e2e-batches 0"
 timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 echo "trace rc=$?"
 i=0
@@ -29,4 +29,9 @@ timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/o
 echo "other trace rc=$?"
 timeout -k 10 280 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/other_pmc1 -o pmc -- $OTHER > $OUT/other_pmc1.log 2>&1
 echo "other pmc rc=$?"
+# HBM traffic of k_orb_bruteforce (64 frame pairs per launch) and k_liba (128 windows per launch): uniform launches, one counter per pass
+timeout -k 10 280 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/other_pmc2 -o pmc -- $OTHER --uniform > $OUT/other_pmc2.log 2>&1
+echo "other FETCH_SIZE rc=$?"
+timeout -k 10 280 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/other_pmc3 -o pmc -- $OTHER --uniform > $OUT/other_pmc3.log 2>&1
+echo "other WRITE_SIZE rc=$?"
 python3 $ROOT/profiles/summarize.py $OUT $TAG $WIN
