@@ -54,14 +54,16 @@ STEP_KERNELS = {
 }
 
 
-def kernel_algorithmic_bytes(windows, results):
+def kernel_algorithmic_bytes(windows, results, plan=None):
     """Bytes each step of the loop has to move over one optimize().
 
     "survey": SURVEY.md 8(d)'s per-window byte formulas x the number of times the reference loop runs the step (linearise:
     once per iteration; Schur / solve / back-substitution / trial residual: once per LM trial).  Those formulas charge the
     144-byte Hpl block of every optimisable edge to linearise (write), Schur (read) and back-substitution (read).
     "impl": what THIS implementation's kernels need at least: Hpl is never stored, each of those passes reads the 32-byte
-    observation record + 8 bytes of indices per edge instead and the landmark factor (72 B) per landmark."""
+    observation record + 8 bytes of indices per edge instead and the landmark factor (72 B) per landmark; the Schur products
+    travel from k_schur_fused to k_schur_reduce as one 288-byte contribution per (item, pose pair) -- written once and read once per
+    trial -- and every item reads its 32-byte landmark records (`plan`: the totals of the uploaded plan)."""
     sv = dict(lin_schur=0, solve=0, backsub_residual=0)
     im = dict(lin_schur=0, solve=0, backsub_residual=0)
     for w, r in zip(windows, results):
@@ -76,6 +78,9 @@ def kernel_algorithmic_bytes(windows, results):
         im["lin_schur"] += it * (E * 40 + L * 24 + poses + L * 144 + P * 216) + tr * (Ef * 32 + L * 96 + (6 * P) * (6 * P + 1) * 8)
         im["solve"] += tr * solve
         im["backsub_residual"] += tr * (E * 40 + L * (72 + 24 + 24 + 24) + 6 * P * 8 + 2 * poses)   # every edge record once, both pose sets
+    if plan is not None and len(windows):
+        per_window = (plan["contributions"] * 288 * 2 + plan.get("records", 0) * 32) / len(windows)
+        im["lin_schur"] += per_window * float(sum(int(r.trials) for r in results))
     return sv, im
 
 
@@ -178,7 +183,7 @@ def run_lba(args, info, windows):
     plan = solver.plan_stats()
     solver.set_profiling(False)
     solver.close()
-    alg, alg_impl = kernel_algorithmic_bytes(windows, results)
+    alg, alg_impl = kernel_algorithmic_bytes(windows, results, plan)
     return dict(windows=windows, results=results, elapsed=elapsed, elapsed_local=elapsed_local, upload_s=upload_s, prof=prof, alg=alg, alg_impl=alg_impl, plan=plan)
 
 

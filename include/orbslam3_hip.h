@@ -285,8 +285,9 @@ typedef struct osh_posei_result {
 int osh_posei_optimize(osh_lba_ctx* ctx, int32_t n, const osh_posei_problem* problems, osh_posei_result* results);
 
 /* Statistics of the Schur work plan of the resident batch: {items, symmetric items, v_mfma_f64_16x16x4 instructions of one
- * pass over every window, useful 6x6x3 products of one pass (upper triangle), contribution slots, reduce entries}. */
-int osh_lba_get_plan_stats(osh_lba_ctx* ctx, int64_t stats[6]);
+ * pass over every window, useful 6x6x3 products of one pass (upper triangle), contribution slots, reduce entries, landmark records,
+ * right-hand-side contribution slots}. */
+int osh_lba_get_plan_stats(osh_lba_ctx* ctx, int64_t stats[8]);
 
 /* Host-only self check of the Schur work plan built at upload time (needs no GPU): groups the
  * landmarks of `problem` by observer set exactly as osh_lba_upload does, verifies that the plan

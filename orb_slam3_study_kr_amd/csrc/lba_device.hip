@@ -1944,10 +1944,10 @@ extern "C" int osh_lba_get_profile(osh_lba_ctx* c, int64_t launches[OSH_K_COUNT]
   return OSH_OK;
 }
 
-extern "C" int osh_lba_get_plan_stats(osh_lba_ctx* c, int64_t stats[6]) {
+extern "C" int osh_lba_get_plan_stats(osh_lba_ctx* c, int64_t stats[8]) {
   if (!c || !stats || c->n_windows <= 0) { set_error("osh_lba_get_plan_stats: nothing uploaded"); return OSH_ERR_INVALID; }
   stats[0] = (int64_t)c->pb.n_items; stats[1] = (int64_t)c->pb.n_sym; stats[2] = c->pb.tile_steps; stats[3] = c->pb.pair_blocks;
-  stats[4] = (int64_t)c->pb.n_contrib; stats[5] = (int64_t)c->pb.n_rblk;
+  stats[4] = (int64_t)c->pb.n_contrib; stats[5] = (int64_t)c->pb.n_rblk; stats[6] = (int64_t)c->pb.n_recs; stats[7] = (int64_t)c->pb.n_ccontrib;
   return OSH_OK;
 }
 

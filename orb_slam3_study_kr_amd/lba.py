@@ -178,10 +178,10 @@ class LbaSolver:
         return [a.read(r, f.mode) for r, a, f in zip(rs, res, frames)]
 
     def plan_stats(self) -> dict:
-        st = np.zeros(6, dtype=np.int64)
+        st = np.zeros(8, dtype=np.int64)
         capi.check(self.lib.osh_lba_get_plan_stats(self.ctx, capi.ptr(st, capi.c_int64_p)), "osh_lba_get_plan_stats", self.lib)
         return dict(items=int(st[0]), sym_items=int(st[1]), mfma_per_pass=int(st[2]), useful_blocks=int(st[3]), contributions=int(st[4]),
-                    reduce_entries=int(st[5]))
+                    reduce_entries=int(st[5]), records=int(st[6]), rhs_contributions=int(st[7]))
 
     def set_profiling(self, enable: bool):
         capi.check(self.lib.osh_lba_set_profiling(self.ctx, int(enable)), "osh_lba_set_profiling", self.lib)
