@@ -509,7 +509,8 @@ def run_inertial(args, info, windows):
     import dataclasses
     from orb_slam3_study_kr_amd import synth_inertial as si
     map_ba = {}
-    for name, n_opt, lam, its in (("full_inertial_ba_100_keyframes", 100, 1e-5, 7), ("merge_inertial_ba_43_keyframes", 43, 1e3, 8)):
+    for name, n_opt, lam, its in (("full_inertial_ba_100_keyframes", 100, 1e-5, 7), ("full_inertial_ba_400_keyframes", 400, 1e-5, 7),
+                                  ("merge_inertial_ba_43_keyframes", 43, 1e3, 8)):
         w = si.make_inertial_window(900 + n_opt, n_opt=n_opt, n_fixed=0, n_points=40 * n_opt, large=True)
         w = dataclasses.replace(w, lambda_init=lam, max_iterations=its, link_robust=np.ones_like(w.link_robust))
         solver.solve_inertial([w])
