@@ -230,6 +230,7 @@ def test_randomised_small_windows_in_one_batch(solver, ob):
     assert len(ws) > 30
     got = solver.solve(ws)
     worst = 0.0
+    n_numpy_checked = 0
     for w, g in zip(ws, got):
         r = ob.lba_solve(w)
         assert g.iterations == r.iterations
@@ -242,10 +243,20 @@ def test_randomised_small_windows_in_one_batch(solver, ob):
         all_mono = bool((w.edge_kind == 0).all())
         gauge_fixed = w.n_fixed >= (2 if all_mono else 1)
         np.testing.assert_allclose(g.chi2_trace, r.chi2_trace, rtol=1e-6 if gauge_fixed else 2e-5)
+        if not gauge_fixed and w.n_points <= 250:
+            # the wider bound above is the C oracle's own rounding (see the comment): against the independent numpy model
+            # (oracle/lm_numpy.py: dense full system, its own LM loop) the device holds the 1e-6 of every other window, so a
+            # regression of the fast-math edge cores cannot hide under the 2e-5
+            from oracle import lm_numpy
+            _, tr, _ = lm_numpy.lm_optimize(w)
+            assert tr["iterations"] == g.iterations and tr["trials"] == list(g.trials_trace[:g.iterations])
+            np.testing.assert_allclose(g.chi2_trace[:g.iterations], tr["chi2"], rtol=1e-6)
+            n_numpy_checked += 1
         if gauge_fixed:
             worst = max(worst, rel_translation_error(g.pose_qt, r.pose_qt))
             np.testing.assert_allclose(g.points, r.points, rtol=1e-5, atol=1e-5, err_msg=f"window {w.n_free}+{w.n_fixed} KF, {w.n_points} points")
     assert worst < 1e-6
+    assert n_numpy_checked >= 2
 
 
 def test_fisheye_monocular_window_kannala_brandt8(solver, ob):
