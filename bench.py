@@ -742,11 +742,13 @@ def main():
                               "resolved in fixed-point rounds on the device + D2H of the slot assignment; matches are the function's return values"}
         # integer-VALU bound: a 256-bit Hamming distance is 8 v_xor_b32 + 8 v_bcnt_u32_b32 (the add is folded into bcnt) per pair;
         # the best / second-best bookkeeping on top is overhead.  Peak = 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz (the FP32 vector
-        # peak of MI355X_MICROARCH.md, 157.3 TFLOP/s, is this rate x 2 flop x 2 packed).  SQ_INSTS_VALU measured 23.4 lane-ops/pair.
+        # peak of MI355X_MICROARCH.md, 157.3 TFLOP/s, is this rate x 2 flop x 2 packed).  Lane-ops per pair: 19.25 = the 77 vector
+        # instructions of the loop body over 4 train descriptors (8 xor + 8 chained v_bcnt + v_lshl_or + v_med3 + v_min each, one
+        # v_mov; round 2: 23.4 by SQ_INSTS_VALU, the counts summed by a tree of v_add3 and the second-best kept by max + min).
         pe = orb_out["pairs_per_gpu"] * 4.0e6 / (orb_out["kernel_ms"] * 1e-3)
         out["orb"]["roofline"] = {"bound": "valu_int", "kernel": "k_orb_bruteforce", "achieved": pe * 16 / 1e12, "peak": 39.3,
                                   "unit": "T lane-ops/s", "frac": pe * 16 / 39.3e12, "ops_per_pair_eval_algorithmic": 16,
-                                  "ops_per_pair_eval_measured": 23.4, "frac_of_issue_slots_measured": pe * 23.4 / 39.3e12,
+                                  "ops_per_pair_eval_measured": 19.25, "frac_of_issue_slots_measured": pe * 19.25 / 39.3e12,
                                   "pair_evals_per_s_kernel": pe, "traffic": measured_other_traffic("k_orb_bruteforce", orb_out["pairs_per_gpu"], 64)}
         if orb_sweep_out:
             out["orb"]["config3_batch_sweep"] = orb_sweep_out
