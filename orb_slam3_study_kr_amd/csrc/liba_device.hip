@@ -821,11 +821,11 @@ __device__ __noinline__ bool liba_solve_group(const LibaCtx& c, Grp& g, int* lds
       for (int p = 0; p < kPB; ++p) col[p] = (lane < kb && p <= lane) ? S[(size_t)(k0 + p) * n + k0 + lane] : (p == lane ? 1.0 : 0.0);
 #pragma unroll
       for (int q = 0; q < kPB; ++q) {
-        const double dq = __shfl(col[q], q);            // pivot: row q of column q, final after the earlier pivots
-        const double cq = col[q] * (1.0 / dq);           // l-form of this column's entry in row q
+        const double dq = ldlt_readlane(col[q], q);     // pivot: row q of column q, final after the earlier pivots (v_readlane: the lane is a
+        const double cq = col[q] * (1.0 / dq);           // compile-time constant; a shuffle is an LDS round trip, 1.4 k cycles per pivot before)
 #pragma unroll
         for (int p = q + 1; p < kPB; ++p) {
-          const double uqp = __shfl(col[q], p);           // u_qp: row q of column p
+          const double uqp = ldlt_readlane(col[q], p);    // u_qp: row q of column p
           if (p <= lane) col[p] -= uqp * cq;
         }
       }
@@ -854,6 +854,21 @@ __device__ __noinline__ bool liba_solve_group(const LibaCtx& c, Grp& g, int* lds
 #pragma unroll
       for (int p = 0; p < kPB; ++p) if (p < kb) S[(size_t)(k0 + p) * n + j] = col[p];
     }
+    // the right-hand side is one more column of the panel (forward substitution inside the factorisation, as ldlt_block.h does: a pass of
+    // its own by block 0 afterwards cost more than the factorisation): its entries of the pivot rows, by the last thread of the group
+    if (gt == GT - 1) {
+      double col[kPB];
+#pragma unroll
+      for (int p = 0; p < kPB; ++p) col[p] = p < kb ? bs[k0 + p] : 0.0;
+#pragma unroll
+      for (int q = 0; q < kPB; ++q) {
+        const double cq = col[q] * ddi[q];
+#pragma unroll
+        for (int p = q + 1; p < kPB; ++p) col[p] -= du[q * kPB + p] * cq;
+      }
+#pragma unroll
+      for (int p = 0; p < kPB; ++p) if (p < kb) bs[k0 + p] = col[p];
+    }
     OSH_GT(1);
     if (!grp_sync(g, lds_flag)) return false;
     OSH_GT(2);
@@ -864,6 +879,18 @@ __device__ __noinline__ bool liba_solve_group(const LibaCtx& c, Grp& g, int* lds
     }
     // ---- trailing update, tiles of 16 rows x 64 columns (upper part) over the wavefronts of the group
     const int t0 = k0 + kb;
+    if (t0 < n && kb == kPB && m == G - 1) {
+      // ... and its entries below the panel: z_i -= sum_p (u_pi / d_p) z_p, by the last block
+      double zs[kPB];
+#pragma unroll
+      for (int p = 0; p < kPB; ++p) zs[p] = bs[k0 + p] * ddi[p];
+      for (int i = t0 + tid; i < jend; i += kLT) {
+        double acc = 0.0;
+#pragma unroll
+        for (int p = 0; p < kPB; ++p) acc += S[(size_t)(k0 + p) * n + i] * zs[p];
+        bs[i] -= acc;
+      }
+    }
     if (t0 < n && kb == kPB) {
       double* wt = wsh + wave * kPB * kPB;
       const int gw = m * (kLT / 64) + wave;
@@ -909,36 +936,7 @@ __device__ __noinline__ bool liba_solve_group(const LibaCtx& c, Grp& g, int* lds
   if (m == 0) {
     for (int k = tid; k < n; k += kLT) xs[k] = bs[k];
     __syncthreads();
-    // forward: z_j = b_j - sum_{p<j} (u_pj / d_p) z_p, 16 pivots at a time
-    for (int k0 = 0; k0 < n; k0 += kPB) {
-      const int kb = min(kPB, n - k0);
-      for (int idx = tid; idx < kPB * kPB; idx += kLT) {
-        const int pp = idx >> 4, jj = idx & 15;
-        du[idx] = (pp < kb && jj < kb && jj >= pp) ? S[(size_t)(k0 + pp) * n + k0 + jj] : (pp == jj ? 1.0 : 0.0);
-      }
-      __syncthreads();
-      if (tid < kPB) ddi[tid] = 1.0 / du[tid * kPB + tid];
-      __syncthreads();
-      if (tid < kPB) {   // lane p holds z_p and column p of the block; z_q is final once the pivots before q are through
-        double z = tid < kb ? xs[k0 + tid] : 0.0, u[kPB];
-#pragma unroll
-        for (int q = 0; q < kPB; ++q) u[q] = du[q * kPB + tid];
-#pragma unroll
-        for (int q = 0; q < kPB; ++q) {
-          const double zq = __shfl(z, q, kPB) * ddi[q];
-          if (tid > q) z -= u[q] * zq;
-        }
-        if (tid < kb) xs[k0 + tid] = z;
-      }
-      __syncthreads();
-      const int jend = d.il ? min(n, k0 + kb + d.bw) : n;
-      for (int j = k0 + kb + tid; j < jend; j += kLT) {
-        double acc = 0.0;
-        for (int p = 0; p < kb; ++p) acc += S[(size_t)(k0 + p) * n + j] * (xs[k0 + p] * ddi[p]);
-        xs[j] -= acc;
-      }
-      __syncthreads();
-    }
+    // (the forward substitution z_j = b_j - sum_{p<j} (u_pj / d_p) z_p happened inside the factorisation: bs holds z)
     // backward: x_p = z_p / d_p - (sum_{j>p} u_pj x_j) / d_p, the last rows first
     for (int k0 = ((n - 1) / kPB) * kPB; k0 >= 0; k0 -= kPB) {
       const int kb = min(kPB, n - k0);
@@ -968,7 +966,7 @@ __device__ __noinline__ bool liba_solve_group(const LibaCtx& c, Grp& g, int* lds
 #pragma unroll
         for (int j = kPB - 1; j >= 0; --j) {
           if (tid == j) x = (z - sum) * dinvp;
-          const double xj = __shfl(x, j, kPB);
+          const double xj = ldlt_readlane(x, j);
           if (tid < j) sum += r[j] * xj;
         }
         if (tid < kb) xs[k0 + tid] = x;
@@ -977,6 +975,10 @@ __device__ __noinline__ bool liba_solve_group(const LibaCtx& c, Grp& g, int* lds
     }
     for (int k = tid; k < n; k += kLT) xg[k] = xs[k];
     if (tid == 0) ctrl[1] = ok ? 1.0 : 0.0;
+#ifdef OSH_LIBA_LDLT_TRACE
+    OSH_GT(5);
+    if (tid == 0) printf("group ldlt n=%d: back substitution %lld cycles\n", n, gt_t[5]);
+#endif
   }
   return true;
 }
