@@ -98,11 +98,11 @@ __host__ __device__ inline S1 s1_of(int* b, int L, int E) {
 struct S2 {
   u64 *uk[5], *uxs, *uys, *gk[5];
   DBuild* builds;
-  int *ulm, *uab, *ugid, *uorder, *gcnt, *gslot, *gfill, *table, *gcount, *grank, *glist, *old2new, *perm, *lmo_new, *nextc;
+  int *ulm, *uab, *ugid, *uorder, *plm, *pab, *gcnt, *gslot, *gfill, *table, *gcount, *grank, *glist, *old2new, *perm, *lmo_new, *nextc, *delta;
   Chunk* chunks;
 };
 __host__ __device__ inline size_t s2_bytes(int nu, int tcap, int L) {
-  return (size_t)nu * (12 * 8 + 64 + 7 * 4) + (size_t)tcap * 4 * 4 + ((size_t)L * 4 + 2) * 4 + (size_t)L * 12 + 64;
+  return (size_t)nu * (12 * 8 + 64 + 9 * 4) + (size_t)tcap * 4 * 4 + ((size_t)L * 5 + 2) * 4 + (size_t)L * 12 + 64;
 }
 __host__ __device__ inline S2 s2_of(unsigned char* b, int nu, int tcap, int L) {
   S2 s;
@@ -112,9 +112,9 @@ __host__ __device__ inline S2 s2_of(unsigned char* b, int nu, int tcap, int L) {
   for (int k = 0; k < 5; ++k) { s.gk[k] = q; q += nu; }
   s.builds = reinterpret_cast<DBuild*>(q); q += (size_t)nu * 8;
   int* p = reinterpret_cast<int*>(q);
-  s.ulm = p; p += nu; s.uab = p; p += nu; s.ugid = p; p += nu; s.uorder = p; p += nu; s.gcnt = p; p += nu; s.gslot = p; p += nu; s.gfill = p; p += nu;
+  s.ulm = p; p += nu; s.uab = p; p += nu; s.ugid = p; p += nu; s.uorder = p; p += nu; s.plm = p; p += nu; s.pab = p; p += nu; s.gcnt = p; p += nu; s.gslot = p; p += nu; s.gfill = p; p += nu;
   s.table = p; p += tcap; s.gcount = p; p += tcap; s.grank = p; p += tcap; s.glist = p; p += tcap;
-  s.old2new = p; p += L; s.perm = p; p += L; s.lmo_new = p; p += L + 1; s.nextc = p; p += L + 1;
+  s.old2new = p; p += L; s.perm = p; p += L; s.lmo_new = p; p += L + 1; s.nextc = p; p += L + 1; s.delta = p; p += L;
   s.chunks = reinterpret_cast<Chunk*>(p);
   return s;
 }
@@ -341,22 +341,30 @@ __global__ __launch_bounds__(NT) void k_pack_pre1(PackArgs a) {
   OSH_TC();   // 2: scatter
   // ---- D: order inside a landmark = rank of the unique key (pose, kind); a pose twice on one landmark is refused
   u64 dup = ~0ull;
-  for (int x = tid; x < E; x += NT) {
-    const int e = s.t_e[x], key = s.t_key[x], il = s.t_lm[x];
-    const int lo = s.lmo[il], hi = s.lmo[il + 1];
-    int rank = 0, nf = 0;
-    bool twice = false;
-    for (int y = lo; y < hi; ++y) {
-      const int ky = s.t_key[y];
-      rank += ky < key;
-      twice |= (y != x) && ((ky >> 2) == (key >> 2));
-      nf += (ky >> 2) < P;
+  for (int xb = tid; xb < E; xb += 2 * NT) {   // two positions per thread and step: their dependent gathers are in flight together
+    int e[2], key[2], il[2], lo[2], hi[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { const int x = min(xb + u * NT, E - 1); e[u] = s.t_e[x]; key[u] = s.t_key[x]; il[u] = s.t_lm[x]; }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { lo[u] = s.lmo[il[u]]; hi[u] = s.lmo[il[u] + 1]; }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int x = xb + u * NT;
+      if (x >= E) continue;
+      int rank = 0, nf = 0;
+      bool twice = false;
+      for (int y = lo[u]; y < hi[u]; ++y) {
+        const int ky = s.t_key[y];
+        rank += ky < key[u];
+        twice |= (y != x) && ((ky >> 2) == (key[u] >> 2));
+        nf += (ky >> 2) < P;
+      }
+      if (twice) dup = min(dup, ((u64)(unsigned)il[u] << 32) | (unsigned)(key[u] >> 2));
+      s.order[lo[u] + rank] = e[u];
+      s.sepose[lo[u] + rank] = key[u] >> 2;
+      s.slm[lo[u] + rank] = il[u];
+      if (x == lo[u]) s.nfree[il[u]] = nf;
     }
-    if (twice) dup = min(dup, ((u64)(unsigned)il << 32) | (unsigned)(key >> 2));
-    s.order[lo + rank] = e;
-    s.sepose[lo + rank] = key >> 2;
-    s.slm[lo + rank] = il;
-    if (x == lo) s.nfree[il] = nf;
   }
   if (tid == 0) s.sepose[E] = 0;
   if (dup != ~0ull) atomicMin(&sh_dup, dup);
@@ -725,17 +733,18 @@ __global__ __launch_bounds__(NT) void k_pack_pre2(PackArgs a) {
   __syncthreads();
   OSH_TC();   // 13: greedy merge
   // ---- I: units behind their key, creation order (landmark, part pair) kept
-  stable_place(nu, [&](int i) { return z.grank[z.ugid[i]]; }, z.gfill, [&](int i, int pos) { z.uorder[pos] = i; }, shk, shi);
+  stable_place(nu, [&](int i) { return z.grank[z.ugid[i]]; }, z.gfill,
+               [&](int i, int pos) { z.uorder[pos] = i; z.plm[pos] = z.ulm[i]; z.pab[pos] = z.uab[i]; }, shk, shi);   // (landmark, part pair) travel with the unit: read in placement order later
   OSH_TC();   // 14: stable placement of the units
   // ---- landmark renumbering along the owner units (part pair (0,0): one per landmark), then the new offsets
   int carry = 0;
   for (int base = 0; base < nu; base += NT) {
     const int p = base + tid;
     int u = 0, own = 0;
-    if (p < nu) { u = z.uorder[p]; own = z.uab[u] == 0 ? 1 : 0; }
+    if (p < nu) { u = z.plm[p]; own = z.pab[p] == 0 ? 1 : 0; }
     int tot;
     const int ex = block_excl_scan(own, shi, tot);
-    if (own) { const int j = z.ulm[u]; z.old2new[j] = carry + ex; z.perm[carry + ex] = j; }
+    if (own) { z.old2new[u] = carry + ex; z.perm[carry + ex] = u; }
     carry += tot;
   }
   __syncthreads();
@@ -743,6 +752,7 @@ __global__ __launch_bounds__(NT) void k_pack_pre2(PackArgs a) {
   if (tid == 0) z.lmo_new[L] = 0;
   __syncthreads();
   block_scan_array(z.lmo_new, L + 1, shi);
+  for (int jo = tid; jo < L; jo += NT) z.delta[jo] = z.lmo_new[z.old2new[jo]] - s.lmo[jo];   // new place of a sorted edge = old place + delta of its landmark
   OSH_TC();   // 15: renumbering + offsets
   // ---- chunks of the landmark-major kernels: consecutive landmarks, <= 1024 edges and <= 256 landmarks (lba_pack.h)
   int* nxt = (L <= LCH) ? reinterpret_cast<int*>(shK) : z.nextc;
@@ -772,8 +782,7 @@ __global__ __launch_bounds__(NT) void k_pack_pre2(PackArgs a) {
     u64 xs = ~0ull, ys = ~0ull;
     if (lane < bd.n) {
       const int p = bd.base + lane;
-      const int u = z.uorder[p];
-      const int lm = z.ulm[u], ab = z.uab[u];
+      const int lm = z.plm[p], ab = z.pab[p];
       const int pa = ab & 0xff, pb = ab >> 8;
       const int k = s.nfree[lm];
       const int* obs = s.sepose + s.lmo[lm];
@@ -842,12 +851,10 @@ __global__ __launch_bounds__(NT) void k_pack_post(PackArgs a) {
   for (int jn = tid; jn <= L; jn += NT) a.a_lmoff[pw.lmoff_off + jn] = z.lmo_new[jn];
   // ---- arena 0: edges at their renumbered places
   for (int xo = tid; xo < E; xo += NT) {
-    const int jo = s.slm[xo], jn = z.old2new[jo];
-    const int x = z.lmo_new[jn] + (xo - s.lmo[jo]);
-    const size_t g = (size_t)pw.edge_off + x;
-    const int e = s.order[xo];
+    const int jo = s.slm[xo], e = s.order[xo];
+    const size_t g = (size_t)pw.edge_off + xo + z.delta[jo];
     a.a_epose[g] = s.sepose[xo];
-    a.a_epoint[g] = jn;
+    a.a_epoint[g] = z.old2new[jo];
     a.a_eorig[g] = e;
     a.a_ekind[g] = a.r_kind[(size_t)pw.edge_off + e];
     if (a.rec_f32) reinterpret_cast<float4*>(a.a_rec)[g] = reinterpret_cast<const float4*>(a.r_rec)[(size_t)pw.edge_off + e];
@@ -927,8 +934,7 @@ __global__ __launch_bounds__(NT) void k_pack_post(PackArgs a) {
     }
     if (lane < bd.n) {
       const int p = bd.base + lane;
-      const int u = z.uorder[p];
-      const int lm = z.ulm[u], ab = z.uab[u];
+      const int lm = z.plm[p], ab = z.pab[p];
       const int pa = ab & 0xff, pb = ab >> 8;
       const int k = s.nfree[lm];
       const int a0 = pa * kItemPoses, a1 = min(k, a0 + kItemPoses);

@@ -34,6 +34,8 @@ import threading
 
 LOCKS = os.environ.get("E2E_STAGE_LOCKS", "1") != "0"
 stage = [threading.Lock() if LOCKS else contextlib.nullcontext() for _ in range(3)]
+if LOCKS and int(os.environ.get("E2E_OPT_PERMITS", "1")) > 1:
+    stage[1] = threading.Semaphore(int(os.environ["E2E_OPT_PERMITS"]))   # several batches may optimise at once
 
 
 def drive(k, n):
