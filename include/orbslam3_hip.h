@@ -177,7 +177,7 @@ int osh_lba_set_profiling(osh_lba_ctx* ctx, int enable);
 /* launches[k], total_ms[k] accumulated since profiling was (re)enabled */
 int osh_lba_get_profile(osh_lba_ctx* ctx, int64_t launches[OSH_K_COUNT], double total_ms[OSH_K_COUNT]);
 /* Where osh_lba_upload builds the index structure: 0 = HIP kernels (default: the caller's arrays travel in the caller's order,
- * csrc/lba_pack_device.hip), 1 = host threads (csrc/lba_pack.h; always used for fisheye-rig batches), -1 = default rules. */
+ * csrc/lba_pack_device.hip), 1 = host threads (csrc/lba_pack.h), -1 = default rules (device for batches of 24 windows or more). */
 int osh_lba_set_pack_mode(osh_lba_ctx* ctx, int mode);
 /* Test hook: pack `problems` with both packers and compare the two layouts section by section (OSH_OK = identical).
  * stats: bytes compared, sections compared, Schur items, landmark records. */

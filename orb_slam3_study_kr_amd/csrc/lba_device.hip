@@ -1410,7 +1410,7 @@ extern "C" int osh_lba_upload(osh_lba_ctx* c, int32_t nw, const osh_lba_problem*
   c->any_stop = false;
   for (int w = 0; w < nw; ++w) { c->stop_ptr[w] = pr[w].stop_flag; if (pr[w].stop_flag) c->any_stop = true; }
 
-  // ---- packing: on the device (lba_pack_device.hip) from the caller's arrays in the caller's order, or -- fisheye-rig batches,
+  // ---- packing: on the device (lba_pack_device.hip) from the caller's arrays in the caller's order, or -- a handful of windows,
   // OSH_LBA_PACK=host -- by host threads straight into pinned staging (lba_pack.h) and one copy per arena
   const auto t0 = std::chrono::steady_clock::now();
   PackedBatch& pb = c->pb;
@@ -1919,7 +1919,7 @@ extern "C" int osh_lba_debug_trial(osh_lba_ctx* c, int32_t window, double lambda
   return OSH_OK;
 }
 
-// 0: pack uploads on the device (default; fisheye-rig batches still take the host packer), 1: on the host (lba_pack.h), -1: default
+// 0: pack uploads on the device (default), 1: on the host (lba_pack.h), -1: default
 // rules (OSH_LBA_PACK=host in the environment selects the host packer)
 extern "C" int osh_lba_set_pack_mode(osh_lba_ctx* c, int mode) {
   if (!c || mode < -1 || mode > 1) { set_error("osh_lba_set_pack_mode: bad arguments"); return OSH_ERR_INVALID; }

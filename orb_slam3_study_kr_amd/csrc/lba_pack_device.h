@@ -4,7 +4,7 @@
 // Thirdparty/g2o/g2o/core/sparse_optimizer.cpp:199-267, block_solver.hpp:143-295), byte for byte, but produced by HIP kernels
 // from the caller's edges in the caller's order: the host only narrows the observation records to float32 on their way into
 // pinned staging.  lba_pack.h stays as the checker (tests compare the two section by section) and as the packer of
-// fisheye-rig batches (merged left / right edge pairs).
+// a handful of windows (one host thread packs a window faster than three one-block kernels and two round trips).
 #pragma once
 #include "common.h"
 #include "lba_pack.h"
@@ -25,7 +25,7 @@ struct DevPackState {
   void release_events() { for (hipEvent_t& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; } }
 };
 
-// true when the batch can be packed on the device (no fisheye-rig window)
+// true when the batch can be packed on the device (always, since fisheye-rig pairs are merged there too)
 bool device_pack_supported(int nw, const osh_lba_problem* pr);
 
 // Packs `nw` problems into d_arena[0..1] (layout of PackedBatch, host pointers pb.arena[] stay null) and d_ptwin (window of every

@@ -67,6 +67,35 @@ def test_fisheye_monocular_window(solver):
     solver.pack_compare([synth.make_window(21, n_free=8, n_fixed=2, n_points=500, stereo=False, fisheye=True)])
 
 
+def test_fisheye_stereo_rig_pairs_merge_on_the_device(solver):
+    """A fisheye stereo rig puts two edges on one (keyframe, landmark) Hessian block (left EdgeSE3ProjectXYZ + right EdgeSE3ProjectXYZToBody,
+    src/Optimizer.cc:1305-1399): the packers merge them into ONE sorted edge with two observation records.  On the device: the pair is
+    found by the rank counting (a pose twice on a landmark is only allowed as mono + body), the merged edges leave the sorted lists
+    through a prefix count, lone right-camera edges stay.  Same bytes as the host packer, alone and in a batch with other camera models;
+    same optimisation results."""
+    rig = synth.make_rig_window(71, n_free=7, n_fixed=2, n_points=400)
+    assert (rig.edge_kind == capi.OSH_EDGE_BODY).sum() > 100
+    solver.pack_compare([rig])
+    solver.pack_compare([rig, synth.make_window(72, n_free=5, n_fixed=2, n_points=300, stereo=False, fisheye=True),
+                         synth.make_window(73, n_free=6, n_fixed=2, n_points=300, stereo=True), _shuffled_rig(rig)])
+    out = []
+    for mode in (0, 1):
+        solver.set_pack_mode(mode)
+        out.append(solver.solve([rig, synth.make_rig_window(74, n_free=4, n_fixed=2, n_points=200)]))
+    solver.set_pack_mode(-1)
+    for a, b in zip(*out):
+        assert a.iterations == b.iterations
+        assert np.array_equal(a.pose_qt, b.pose_qt) and np.array_equal(a.points, b.points) and np.array_equal(a.edge_chi2, b.edge_chi2)
+
+
+def _shuffled_rig(w, seed=3):
+    perm = np.random.default_rng(seed).permutation(w.n_edges)
+    return synth.LbaWindow(n_free=w.n_free, n_fixed=w.n_fixed, pose_qt=w.pose_qt, pose_cam=w.pose_cam, points=w.points,
+                           edge_pose=np.ascontiguousarray(w.edge_pose[perm]), edge_point=np.ascontiguousarray(w.edge_point[perm]),
+                           edge_kind=np.ascontiguousarray(w.edge_kind[perm]), edge_obs=np.ascontiguousarray(w.edge_obs[perm]),
+                           edge_info=np.ascontiguousarray(w.edge_info[perm]), kb8=w.kb8, cam2=w.cam2, trl=w.trl).normalise()
+
+
 def test_map_sized_window_takes_the_global_memory_paths(solver):
     """300 optimisable keyframes, 30 k landmarks with missed detections: thousands of distinct observer sets (sorted in global
     memory instead of LDS) and more landmarks than the LDS chunk walk holds."""
