@@ -129,9 +129,8 @@ __device__ bool ldlt_solve_block(double* __restrict__ A, const double* __restric
       }
     }
     if (tid < 64) {
-      // ONE wavefront factors the block.  Lane j keeps column j in registers and the pivot row is broadcast with v_readlane
-      // (an LDS round trip per pivot bounded this phase before): l_k,j = u_k,j / d_k is formed by lane j itself, then
-      // u_i,j -= l_k,i * u_k,j for every row i > k.  Lanes j < i compute values of the unused lower triangle; nothing valid
+      // ONE wavefront factors the block.  Lane j keeps column j in registers: l_k,j = u_k,j / d_k is formed by lane j itself, then
+      // u_i,j -= l_k,i * u_k,j for every row i > k with the multiplier l_k,i broadcast (below).  Lanes j < i compute values of the unused lower triangle; nothing valid
       // reads them.  Same operations in the same order as the textbook loop; a padded pivot is 1 with zero multipliers.
       // Lanes NB .. 2 NB - 1 carry the columns of the identity through the same row operations (they execute the instruction stream
       // anyway): what they hold at the end is L^-1, the operator of the row panel below.
@@ -143,29 +142,40 @@ __device__ bool ldlt_solve_block(double* __restrict__ A, const double* __restric
       for (int r = 0; r < NB; ++r) { const double v = Ld[r * NB + cj]; col[r] = idl ? (r == tid - NB ? 1.0 : 0.0) : v; }
       double* lout = tid < NB ? Ld + tid : part;  // lanes beyond the block write to a slot nobody reads in this phase
       bool zero_pivot = false;
-      // Look-ahead: pivot k + 1 is final as soon as row k + 1 has received pivot k's update (the first of the step), so its
-      // reciprocal (hardware seed + two Newton steps: a chain of ~10 dependent operations) is started there and overlaps with the
-      // remaining row updates of step k instead of standing alone at the top of step k + 1.
+      // Per pivot k: l_k,j = u_k,j / d_k by lane j, stored as row k of the block's factor.  Only the NEXT row takes its multiplier through
+      // v_readlane (its diagonal entry is the next pivot, whose reciprocal -- hardware seed + two Newton steps -- is started at once);
+      // the other rows take theirs from the row just stored, as broadcast LDS reads (ds_read_b128: two multipliers per instruction)
+      // requested now and used one step later, between the start of the next reciprocal and its first use.  A single wavefront
+      // issues one FP64 instruction per ~10 cycles whatever it depends on (profiles/ubench/pivot_chain.hip: 402 cycles per pivot with two
+      // v_readlane_b32 + v_fma_f64 per row, 297 this way, same bits), so the step is as long as its instruction count.
       double d = ldlt_readlane(col[0], 0);
       double rd = dev::rcp_nr(d);
+      double mprev[NB];     // multipliers of the previous pivot for rows k + 1 .. NB - 1
+      double uprev = 0.0;   // the previous pivot's row entry of this lane's column
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
         zero_pivot |= d == 0.0;
         const double lk = col[k] * rd;
         const double d_cur = d, rd_cur = rd;
+        lout[k * NB] = tid > k ? lk : 0.0;  // scaled row k of the block (l_kj)
         if (k + 1 < NB) {
+          if (k > 0) col[k + 1] -= mprev[k + 1] * uprev;   // the older update first, as in the textbook loop
           col[k + 1] -= ldlt_readlane(lk, k + 1) * col[k];
           asm volatile("" : "+v"(col[k + 1]));
           d = ldlt_readlane(col[k + 1], k + 1);
           rd = dev::rcp_nr(d);
           asm volatile("" : "+v"(rd));   // computed HERE (the optimiser otherwise sinks the chain to its first use in the next step)
         }
+        if (k > 0) {
 #pragma unroll
-        for (int ii = k + 2; ii < NB; ++ii) {
-          col[ii] -= ldlt_readlane(lk, ii) * col[k];
-          asm volatile("" : "+v"(col[ii]));  // keeps the update here: sunk to its use, all 276 multipliers stay live in SGPRs
+          for (int ii = k + 2; ii < NB; ++ii) {
+            col[ii] -= mprev[ii] * uprev;
+            asm volatile("" : "+v"(col[ii]));
+          }
         }
-        lout[k * NB] = tid > k ? lk : 0.0;  // scaled row k of the block (l_kj)
+#pragma unroll
+        for (int ii = k + 2; ii < NB; ++ii) mprev[ii] = Ld[k * NB + ii];
+        uprev = col[k];
         if (tid == 0) { dd[k] = d_cur; ddi[k] = rd_cur; }
         __builtin_amdgcn_sched_barrier(0);
       }
