@@ -1228,8 +1228,8 @@ def test_full_inertial_ba_first_step_equals_the_restatement(ob, init, n_opt):
     np.testing.assert_allclose(got[0], want[0], atol=3e-8)
     np.testing.assert_allclose(got[1], want[1], atol=3e-7)
     np.testing.assert_allclose(got[2], want[2], atol=3e-7)
-    assert np.mean(np.abs(got[3] - want[3]) > 3e-7) < 1e-2    # low-parallax landmarks: their depth is the flattest direction of all
-    np.testing.assert_allclose(got[3], want[3], atol=3e-5)
+    assert np.median(np.abs(got[3] - want[3])) < 1e-7         # (measured: max 2e-6, on low-parallax landmarks, whose depth is the flattest
+    np.testing.assert_allclose(got[3], want[3], atol=1e-5)    # direction of all)
     np.testing.assert_allclose(dev.bias_g, ref.bias_g, atol=2e-8)
     np.testing.assert_allclose(dev.bias_a, ref.bias_a, atol=3e-6)
 
