@@ -37,6 +37,67 @@ __device__ __forceinline__ double ldlt_readlane(double v, int lane) {
 // phases of a panel whose hand-over is through LDS; the phase that writes the trailing matrix ends with a full __syncthreads().
 __device__ __forceinline__ void ldlt_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// ONE wavefront factors an NB x NB diagonal block (threads 0..63 of the block call this).  Lane j keeps column j in registers:
+// l_k,j = u_k,j / d_k is formed by lane j itself, then u_i,j -= l_k,i * u_k,j for every row i > k with the multiplier l_k,i broadcast
+// (below).  Lanes j < i compute values of the unused lower triangle; nothing valid reads them.  Same operations in the same order as
+// the textbook loop; a padded pivot is 1 with zero multipliers.  Lanes NB .. 2 NB - 1 carry the columns of the identity through the
+// same row operations (they execute the instruction stream anyway): what they hold at the end is L^-1, the operator of the row panel.
+//   Ld  : in, the block padded with the identity to NB x NB (upper triangle); out, the scaled rows l_kj (k < j), zeros left of the diagonal
+//   Mi  : out, L^-1       dd, ddi : out, pivots and their reciprocals (NB each)       part : NB doubles of scratch
+template <int NB>
+__device__ __forceinline__ void ldlt_factor_diag(double* Ld, double* Mi, double* dd, double* ddi, double* part, const int tid, int& sh_ok) {
+  static_assert(2 * NB <= 64, "the identity columns ride in the upper lanes of the wavefront");
+  double col[NB];
+  const int cj = tid < NB ? tid : 0;
+  const bool idl = tid >= NB && tid < 2 * NB;
+#pragma unroll
+  for (int r = 0; r < NB; ++r) { const double v = Ld[r * NB + cj]; col[r] = idl ? (r == tid - NB ? 1.0 : 0.0) : v; }
+  double* lout = tid < NB ? Ld + tid : part;  // lanes beyond the block write to a slot nobody reads in this phase
+  bool zero_pivot = false;
+  // Per pivot k: l_k,j = u_k,j / d_k by lane j, stored as row k of the block's factor.  Only the NEXT row takes its multiplier through
+  // v_readlane (its diagonal entry is the next pivot, whose reciprocal -- hardware seed + two Newton steps -- is started at once);
+  // the other rows take theirs from the row just stored, as broadcast LDS reads (ds_read_b128: two multipliers per instruction)
+  // requested now and used one step later, between the start of the next reciprocal and its first use.  A single wavefront
+  // issues one FP64 instruction per ~10 cycles whatever it depends on (profiles/ubench/pivot_chain.hip: 402 cycles per pivot with two
+  // v_readlane_b32 + v_fma_f64 per row, 297 this way, same bits), so the step is as long as its instruction count.
+  double d = ldlt_readlane(col[0], 0);
+  double rd = dev::rcp_nr(d);
+  double mprev[NB];     // multipliers of the previous pivot for rows k + 1 .. NB - 1
+  double uprev = 0.0;   // the previous pivot's row entry of this lane's column
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    zero_pivot |= d == 0.0;
+    const double lk = col[k] * rd;
+    const double d_cur = d, rd_cur = rd;
+    lout[k * NB] = tid > k ? lk : 0.0;  // scaled row k of the block (l_kj)
+    if (k + 1 < NB) {
+      if (k > 0) col[k + 1] -= mprev[k + 1] * uprev;   // the older update first, as in the textbook loop
+      col[k + 1] -= ldlt_readlane(lk, k + 1) * col[k];
+      asm volatile("" : "+v"(col[k + 1]));
+      d = ldlt_readlane(col[k + 1], k + 1);
+      rd = dev::rcp_nr(d);
+      asm volatile("" : "+v"(rd));   // computed HERE (the optimiser otherwise sinks the chain to its first use in the next step)
+    }
+    if (k > 0) {
+#pragma unroll
+      for (int ii = k + 2; ii < NB; ++ii) {
+        col[ii] -= mprev[ii] * uprev;
+        asm volatile("" : "+v"(col[ii]));
+      }
+    }
+#pragma unroll
+    for (int ii = k + 2; ii < NB; ++ii) mprev[ii] = Ld[k * NB + ii];
+    uprev = col[k];
+    if (tid == 0) { dd[k] = d_cur; ddi[k] = rd_cur; }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (idl) {
+#pragma unroll
+    for (int r = 0; r < NB; ++r) Mi[r * NB + (tid - NB)] = col[r];
+  }
+  if (zero_pivot && tid == 0) sh_ok = 0;
+}
+
 template <int NB, int NT>
 __device__ bool ldlt_solve_block(double* __restrict__ A, const double* __restrict__ rhs, const int n, const int W, double* sh,
                                  double*& xs_out, double*& shw_out, const int* __restrict__ lo_pose = nullptr) {
@@ -128,63 +189,7 @@ __device__ bool ldlt_solve_block(double* __restrict__ A, const double* __restric
         pre0 = true;
       }
     }
-    if (tid < 64) {
-      // ONE wavefront factors the block.  Lane j keeps column j in registers: l_k,j = u_k,j / d_k is formed by lane j itself, then
-      // u_i,j -= l_k,i * u_k,j for every row i > k with the multiplier l_k,i broadcast (below).  Lanes j < i compute values of the unused lower triangle; nothing valid
-      // reads them.  Same operations in the same order as the textbook loop; a padded pivot is 1 with zero multipliers.
-      // Lanes NB .. 2 NB - 1 carry the columns of the identity through the same row operations (they execute the instruction stream
-      // anyway): what they hold at the end is L^-1, the operator of the row panel below.
-      static_assert(2 * NB <= 64, "the identity columns ride in the upper lanes of the wavefront");
-      double col[NB];
-      const int cj = tid < NB ? tid : 0;
-      const bool idl = tid >= NB && tid < 2 * NB;
-#pragma unroll
-      for (int r = 0; r < NB; ++r) { const double v = Ld[r * NB + cj]; col[r] = idl ? (r == tid - NB ? 1.0 : 0.0) : v; }
-      double* lout = tid < NB ? Ld + tid : part;  // lanes beyond the block write to a slot nobody reads in this phase
-      bool zero_pivot = false;
-      // Per pivot k: l_k,j = u_k,j / d_k by lane j, stored as row k of the block's factor.  Only the NEXT row takes its multiplier through
-      // v_readlane (its diagonal entry is the next pivot, whose reciprocal -- hardware seed + two Newton steps -- is started at once);
-      // the other rows take theirs from the row just stored, as broadcast LDS reads (ds_read_b128: two multipliers per instruction)
-      // requested now and used one step later, between the start of the next reciprocal and its first use.  A single wavefront
-      // issues one FP64 instruction per ~10 cycles whatever it depends on (profiles/ubench/pivot_chain.hip: 402 cycles per pivot with two
-      // v_readlane_b32 + v_fma_f64 per row, 297 this way, same bits), so the step is as long as its instruction count.
-      double d = ldlt_readlane(col[0], 0);
-      double rd = dev::rcp_nr(d);
-      double mprev[NB];     // multipliers of the previous pivot for rows k + 1 .. NB - 1
-      double uprev = 0.0;   // the previous pivot's row entry of this lane's column
-#pragma unroll
-      for (int k = 0; k < NB; ++k) {
-        zero_pivot |= d == 0.0;
-        const double lk = col[k] * rd;
-        const double d_cur = d, rd_cur = rd;
-        lout[k * NB] = tid > k ? lk : 0.0;  // scaled row k of the block (l_kj)
-        if (k + 1 < NB) {
-          if (k > 0) col[k + 1] -= mprev[k + 1] * uprev;   // the older update first, as in the textbook loop
-          col[k + 1] -= ldlt_readlane(lk, k + 1) * col[k];
-          asm volatile("" : "+v"(col[k + 1]));
-          d = ldlt_readlane(col[k + 1], k + 1);
-          rd = dev::rcp_nr(d);
-          asm volatile("" : "+v"(rd));   // computed HERE (the optimiser otherwise sinks the chain to its first use in the next step)
-        }
-        if (k > 0) {
-#pragma unroll
-          for (int ii = k + 2; ii < NB; ++ii) {
-            col[ii] -= mprev[ii] * uprev;
-            asm volatile("" : "+v"(col[ii]));
-          }
-        }
-#pragma unroll
-        for (int ii = k + 2; ii < NB; ++ii) mprev[ii] = Ld[k * NB + ii];
-        uprev = col[k];
-        if (tid == 0) { dd[k] = d_cur; ddi[k] = rd_cur; }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (idl) {
-#pragma unroll
-        for (int r = 0; r < NB; ++r) Mi[r * NB + (tid - NB)] = col[r];
-      }
-      if (zero_pivot && tid == 0) sh_ok = 0;
-    }
+    if (tid < 64) ldlt_factor_diag<NB>(Ld, Mi, dd, ddi, part, tid, sh_ok);
     ldlt_lds_barrier();
     OSH_TR(1);
     if (!sh_ok) break;
@@ -412,13 +417,33 @@ __device__ bool ldlt_solve_block(double* __restrict__ A, const double* __restric
         if (!in) dg[q] = 0.0;
       }
       // part[r] = sum_{j>=tail0} L[k0+r][j] x[j] : one wavefront per group of rows, lanes stride the columns
+      // (the tails of ALL rows of the wavefront, four chunks of 64 columns at a time, are requested before the first is used: written
+      // row by row -- `for (j ...) sacc += row[j] * xs[j]` inside the loop over the rows -- every row and every 64 columns of it was a
+      // round trip to L2 of its own, 7 to 15 per panel; the sums run over j in the same order)
+      constexpr int kTailChunks = 4;
       double sacc[kRowsPerWave];
+      unsigned rowb[kRowsPerWave];
 #pragma unroll
       for (int q = 0; q < kRowsPerWave; ++q) {
         const int r = wv + q * nwaves;
-        const double* row = A + (size_t)(k0 + (r < kb ? r : 0)) * n;
+        rowb[q] = (unsigned)(k0 + (r < kb ? r : 0)) * (unsigned)n;
         sacc[q] = 0.0;
-        for (int j = tail0 + lane; j < jend; j += 64) sacc[q] += row[j] * xs[j];
+      }
+      for (int j0 = tail0 + lane; j0 < jend; j0 += 64 * kTailChunks) {
+        double av[kRowsPerWave][kTailChunks];
+#pragma unroll
+        for (int q = 0; q < kRowsPerWave; ++q)
+#pragma unroll
+          for (int u = 0; u < kTailChunks; ++u) av[q][u] = A[rowb[q] + (unsigned)min(j0 + 64 * u, jend - 1)];
+#pragma unroll
+        for (int u = 0; u < kTailChunks; ++u) {
+          const int j = j0 + 64 * u;
+          if (j < jend) {
+            const double xj = xs[j];
+#pragma unroll
+            for (int q = 0; q < kRowsPerWave; ++q) sacc[q] += av[q][u] * xj;
+          }
+        }
       }
 #pragma unroll
       for (int q = 0; q < kRowsPerWave; ++q) {

@@ -780,15 +780,27 @@ __device__ __noinline__ void liba_schur(const LibaCtx& c, double lambda) {
       }
 }
 
-// ---- LDL^T + solve of the reduced system by block 0 of the group (inlined: its panels live in LDS, and only inside the kernel does the
-// compiler know that pointer for what it is)
+// ---- LDL^T + solve of the reduced system by block 0 of the group.  A function of its own, NOT inlined: inside k_liba the sixty-odd
+// pointers of the view are live across the whole kernel, and inlined there the factorisation's inner loops reloaded spilled scalar
+// registers at every step (s_or_saveexec / v_accvgpr_read / v_readlane: 75 instructions per pivot for 45, 15.7 k cycles per diagonal
+// block against 8.8 k for the same source in k_solve).  The LDS scratch travels as an address_space(3) pointer so that the body still
+// addresses it with ds_ instructions.
+typedef __attribute__((address_space(3))) double lds_double;
+typedef __attribute__((address_space(1))) double glb_double;
+template <int NB>
+__device__ __noinline__ void liba_solve_fn(glb_double* S1, const glb_double* bs1, const int n, const int W, lds_double* sh3, glb_double* xg1, glb_double* ctrl1) {
+  double* const sh_lds = (double*)sh3;
+  double* const S = (double*)S1; const double* const bs = (const double*)bs1; double* const xg = (double*)xg1; double* const ctrl = (double*)ctrl1;
+  const int tid = threadIdx.x;
+  double *xs, *shw2;
+  const bool okb = ldlt_solve_block<NB, kLT>(S, bs, n, W, sh_lds, xs, shw2);
+  for (int k = tid; k < n; k += kLT) xg[k] = xs[k];
+  if (tid == 0) ctrl[1] = okb ? 1.0 : 0.0;
+}
 template <int NB>
 __device__ __forceinline__ void liba_solve(const LibaCtx& c, double* sh_lds) {
   OSH_LIBA_LOCALS
-  double *xs, *shw2;
-  const bool okb = ldlt_solve_block<NB, kLT>(S, bs, n, c.W, sh_lds, xs, shw2);
-  for (int k = tid; k < n; k += kLT) xg[k] = xs[k];
-  if (tid == 0) ctrl[1] = okb ? 1.0 : 0.0;
+  liba_solve_fn<NB>((glb_double*)S, (const glb_double*)bs, n, c.W, (lds_double*)sh_lds, (glb_double*)xg, (glb_double*)ctrl);
 }
 
 // ---- LDL^T + solve of a reduced system too wide for the LDS panels above (FullInertialBA over a map: up to 2880 unknowns), by the WHOLE
