@@ -512,7 +512,7 @@ __device__ void greedy_items(int ng, KeyF KF, CntF CF, DBuild* builds, int* wk, 
   out5[0] = nb; out5[1] = n_sym; out5[2] = n_cross; out5[3] = recs_sym; out5[4] = recs_cross;
 }
 
-__global__ __launch_bounds__(NT) void k_pack_pre2(PackArgs a) {
+__global__ __launch_bounds__(NT, 8) void k_pack_pre2(PackArgs a) {
   __shared__ u64 shk[NT];
   __shared__ u64 shK[5 * GL];
   __shared__ int shcnt[GL];
