@@ -464,14 +464,20 @@ __global__ __launch_bounds__(kBlock) void k_lin_lm(BatchView bv) {
 //   mode 1: Schur products, and the pose side when this round opened an iteration other than the first
 // --------------------------------------------------------------------------------------------
 typedef double f64x4 __attribute__((ext_vector_type(4)));
-constexpr int kSiLm = 8;               // landmarks per chunk
-constexpr int kSiKS = 3 * kSiLm + 1;   // LDS row stride (doubles)
+constexpr int kSiLm = 8;               // landmarks per chunk, items of 6 .. 8 row poses (and every cross item)
 constexpr int kSiRows = 6 * kItemPoses;
+// Lane mappings of a chunk, LM landmarks x PS pose lanes (lane = l * PS + s): 8 x 8, and for symmetric items of at most 5 / at most 4
+// row poses 12 x 5 / 16 x 4 -- on the headline window 26 % / 24 % of the symmetric chunks belong to such items and left 3 / 4..7 of their
+// 8 pose lanes empty.  The image is [6 PS rows, padded to whole 16-row tiles][3 LM + 1]: 48 x 25, 32 x 37, 32 x 49 doubles.  The k
+// steps run over the same sequence of (landmark, component) columns whatever the chunk size (24, 36 and 48 are multiples of 4), so
+// the Schur products are the same bits as with 8 x 8 chunks.  (32 x 2 for items of one or two poses -- 18 % of the chunks -- was
+// measured too and gained nothing over 16 x 4: with one tile the 24 k steps of such a chunk are one dependent MFMA chain.)
+constexpr int kSiImage = 32 * 49;
 
 template <bool SYM, bool KB8>
 __global__ __launch_bounds__(64, KB8 ? 1 : 2) void k_schur_fused(BatchView bv, int item_base, int mode) {
-  __shared__ double shA[kSiRows * kSiKS];
-  __shared__ double shB[SYM ? 1 : kSiRows * kSiKS];
+  __shared__ double shA[(SYM && !KB8) ? kSiImage : kSiRows * (3 * kSiLm + 1)];   // (the wider mappings: symmetric pinhole items only)
+  __shared__ double shB[SYM ? 1 : kSiRows * (3 * kSiLm + 1)];
   __shared__ double shPose[(SYM ? 1 : 2) * 8 * kPoseRec];
   __shared__ int shP[64 + 8];
   const int item_idx = item_base + blockIdx.x;
@@ -483,7 +489,6 @@ __global__ __launch_bounds__(64, KB8 ? 1 : 2) void k_schur_fused(BatchView bv, i
   const bool do_schur = mode != 0;
   if (!do_hpp && !do_schur) return;
   const int lane = threadIdx.x;
-  const int l = lane >> 3, s = lane & 7;
   const int nx = it.shape & 0xff, ny = (it.shape >> 8) & 0xff;
   const int TX = (6 * nx + 15) >> 4, TY = (6 * ny + 15) >> 4;
   shP[lane] = bv.spair[(size_t)item_idx * 64 + lane];
@@ -492,16 +497,16 @@ __global__ __launch_bounds__(64, KB8 ? 1 : 2) void k_schur_fused(BatchView bv, i
     // poses of the item's slots -> LDS (lanes 0..7: row poses, lanes 8..15: column poses of a cross item)
     const double* poses = bv.pose_state[st.sel] + (size_t)wd.pose_off * 7;
     const double* cams = bv.pose_cam + (size_t)wd.pose_off * 5;
-    const int side = lane >> 3;
+    const int side = lane >> 3, s8 = lane & 7;
     if (side < (SYM ? 1 : 2)) {
-      const int ip = side == 0 ? bv.sposex[(size_t)item_idx * 8 + s] : bv.sposey[(size_t)item_idx * 8 + s];
+      const int ip = side == 0 ? bv.sposex[(size_t)item_idx * 8 + s8] : bv.sposey[(size_t)item_idx * 8 + s8];
       double qt[7], cam[5], Rm[9];
 #pragma unroll
       for (int k = 0; k < 7; ++k) qt[k] = ip >= 0 ? poses[(size_t)ip * 7 + k] : 0.0;
 #pragma unroll
       for (int k = 0; k < 5; ++k) cam[k] = ip >= 0 ? cams[(size_t)ip * 5 + k] : 0.0;
       dev::quat_to_R(qt, Rm);
-      double* dst = shPose + (side * 8 + s) * kPoseRec;
+      double* dst = shPose + (side * 8 + s8) * kPoseRec;
 #pragma unroll
       for (int k = 0; k < 7; ++k) dst[k] = qt[k];
 #pragma unroll
@@ -513,211 +518,236 @@ __global__ __launch_bounds__(64, KB8 ? 1 : 2) void k_schur_fused(BatchView bv, i
   const SRec* __restrict__ recs = bv.srecs + it.rec_off;
   const double* pts = bv.pt_state[st.sel] + (size_t)wd.pt_off * 3;
   const double* DL = bv.DL + (size_t)wd.pt_off * 9;
-  f64x4 acc[3][3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int b = 0; b < 3; ++b) acc[a][b] = (f64x4){0.0, 0.0, 0.0, 0.0};
-  double csum[6] = {0, 0, 0, 0, 0, 0};
-  double H[21], hb[6];
-#pragma unroll
-  for (int k = 0; k < 21; ++k) H[k] = 0.0;
-#pragma unroll
-  for (int k = 0; k < 6; ++k) hb[k] = 0.0;
   const int mrow = lane & 15, mk = lane >> 4;
-
-  // Software pipeline over the chunks: the data of chunk c+1 are requested right after chunk c's operands are parked in LDS,
-  // so they are in flight during chunk c's MFMA phase, and the record of chunk c+2 with them.  Every load is unconditional
-  // on a clamped index (a load inside a divergent branch is waited for at the end of the branch); validity is applied
-  // when the values are used.
-  struct Dat { double2 ex[2]; double2 ey[2]; double X[3]; double dl[9]; };
-  const int last_rec = it.n_lm - 1;
-  const size_t last_edge = (size_t)wd.edge_off + (size_t)max(wd.E - 1, 0);
-  auto load_rec = [&](int c0, int4& ra, int4& rb) {
-    const int4* src = reinterpret_cast<const int4*>(recs + min(c0 + l, last_rec));
-    ra = src[0]; rb = src[1];          // {lm, e_first, x_lo, x_hi} {y_lo, y_hi, flags, pad}
-  };
-  auto slot_of = [&](unsigned lo, unsigned hi) { return (((s < 4) ? lo : hi) >> (8 * (s & 3))) & 0xffu; };
-  auto edge_of = [&](const int4& ra, unsigned o) { return min((size_t)wd.edge_off + (size_t)(ra.y + (o != kAbsent ? (int)o : 0)), last_edge); };
-  auto load_dat = [&](const int4& ra, const int4& rb, Dat& d) {
-    const double2* src = reinterpret_cast<const double2*>(bv.e_rec + edge_of(ra, slot_of((unsigned)ra.z, (unsigned)ra.w)) * 4);
-    d.ex[0] = src[0]; d.ex[1] = src[1];
-    if (!SYM) {
-      const double2* sy = reinterpret_cast<const double2*>(bv.e_rec + edge_of(ra, slot_of((unsigned)rb.x, (unsigned)rb.y)) * 4);
-      d.ey[0] = sy[0]; d.ey[1] = sy[1];
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) d.X[k] = pts[(size_t)ra.x * 3 + k];
-    if (do_schur) {
-#pragma unroll
-      for (int k = 0; k < 9; ++k) d.dl[k] = DL[(size_t)ra.x * 9 + k];
-    }
-  };
-  // rows of W F of the lane's edge on one side of the item (side 0: row poses, 1: column poses) -> the side's LDS image
-  auto side_rows = [&](int side, bool present, const int4& ra, unsigned o, const double2* er, const Dat& d, double* img) __attribute__((always_inline)) {
-    const double* ps = shPose + (side * 8 + s) * kPoseRec;
-    double qt[7], cam[5], Rm[9];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) qt[k] = ps[k];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) cam[k] = ps[7 + k];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) Rm[k] = ps[12 + k];
-    const double rec[4] = {er[0].x, er[0].y, er[1].x, er[1].y};
-    double Xc[3], Q[6], g[3], rho0;
-    win_edge_core<KB8>(wd, bv, edge_of(ra, o), rec, qt, cam, Rm, d.X, Xc, Q, g, rho0);
-    // an empty slot computes on another edge's data: its result is discarded here (select, not multiply: it may be NaN)
-#pragma unroll
-    for (int k = 0; k < 6; ++k) Q[k] = present ? Q[k] : 0.0;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) g[k] = present ? g[k] : 0.0;
-    if (SYM && do_hpp && side == 0) dev::core_pose_side<KB8>(Xc, Q, g, H, hb);
-    if (do_schur) {
-      double WF[18];
-      dev::core_WF<KB8>(Xc, Q, Rm, d.dl, WF);
-      double* row = img + (6 * s) * kSiKS + 3 * l;
-#pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        row[r * kSiKS + 0] = WF[r * 3]; row[r * kSiKS + 1] = WF[r * 3 + 1]; row[r * kSiKS + 2] = WF[r * 3 + 2];
-        if (SYM) csum[r] += WF[r * 3] * d.dl[6] + WF[r * 3 + 1] * d.dl[7] + WF[r * 3 + 2] * d.dl[8];
-      }
-    }
-  };
-  // (always inlined: as a call, in the fisheye instantiation, every accumulator it touches by reference would live in scratch memory)
-  auto park = [&](int c0, const int4& ra, const int4& rb, const Dat& d) __attribute__((always_inline)) {
-    const bool valid = (c0 + l) < it.n_lm;
-    const unsigned xo = valid ? slot_of((unsigned)ra.z, (unsigned)ra.w) : kAbsent;
-    wave_sync();   // the previous chunk's MFMA reads are done
-    side_rows(0, xo != kAbsent, ra, xo, d.ex, d, shA);
-    if (!SYM) {
-      const unsigned yo = valid ? slot_of((unsigned)rb.x, (unsigned)rb.y) : kAbsent;
-      side_rows(1, yo != kAbsent, ra, yo, d.ey, d, shB);
-    }
-  };
-  // The tile counts are compile-time constants inside each instantiation (dispatched once per chunk): with run-time tile tests
-  // every MFMA and every operand read sat behind its own scalar branch.
-  auto multiply_t = [&](auto txc, auto tyc) {
-    constexpr int TXc = decltype(txc)::value, TYc = decltype(tyc)::value;
-    const double* imgB = SYM ? shA : shB;
-#pragma unroll
-    for (int ks = 0; ks < (3 * kSiLm) / 4; ++ks) {
-      double a[3], b[3];
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        a[t] = (t < TXc) ? shA[(16 * t + mrow) * kSiKS + 4 * ks + mk] : 0.0;
-        b[t] = SYM ? a[t] : ((t < TYc) ? imgB[(16 * t + mrow) * kSiKS + 4 * ks + mk] : 0.0);
-      }
-#pragma unroll
-      for (int ti = 0; ti < 3; ++ti)
-#pragma unroll
-        for (int tj = SYM ? ti : 0; tj < 3; ++tj)
-          if (ti < TXc && tj < TYc) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
-      if (ks & 1) __builtin_amdgcn_sched_barrier(0);   // operands of two k-steps in flight at most (the prefetched chunk needs the registers)
-    }
-  };
   using std::integral_constant;
-  auto multiply_cross = [&]() {
-    // cross items keep run-time tile tests: nine instantiations cost registers for no gain
+
+  auto body = [&](auto lmc, auto psc) __attribute__((always_inline)) {
+    constexpr int LM = decltype(lmc)::value, PS = decltype(psc)::value;   // landmarks per chunk, pose lanes
+    constexpr int KS = 3 * LM + 1;                                        // LDS row stride (doubles): odd, conflict-free MFMA reads
+    constexpr int KST = (3 * LM) / 4;                                     // k steps per chunk
+    static_assert(LM * PS <= 64 && (3 * LM) % 4 == 0 && ((6 * PS + 15) / 16) * 16 * KS <= ((SYM && !KB8) ? kSiImage : kSiRows * (3 * kSiLm + 1)), "chunk mapping");
+    const int l = lane / PS, s = lane - l * PS;
+    const bool lane_on = LM * PS == 64 || l < LM;
+    f64x4 acc[3][3];
 #pragma unroll
-    for (int ks = 0; ks < (3 * kSiLm) / 4; ++ks) {
-      double a[3], b[3];
+    for (int a = 0; a < 3; ++a)
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        a[t] = (t < TX) ? shA[(16 * t + mrow) * kSiKS + 4 * ks + mk] : 0.0;
-        b[t] = (t < TY) ? shB[(16 * t + mrow) * kSiKS + 4 * ks + mk] : 0.0;
+      for (int b = 0; b < 3; ++b) acc[a][b] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    double csum[6] = {0, 0, 0, 0, 0, 0};
+    double H[21], hb[6];
+#pragma unroll
+    for (int k = 0; k < 21; ++k) H[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) hb[k] = 0.0;
+    if (PS < 8) {
+      // image rows past the pose lanes (up to the end of the last tile): nobody writes them
+      for (int idx = lane; idx < (((6 * PS + 15) / 16) * 16 - 6 * PS) * KS; idx += 64) shA[6 * PS * KS + idx] = 0.0;
+    }
+
+    // Software pipeline over the chunks: the data of chunk c+1 are requested right after chunk c's operands are parked in LDS,
+    // so they are in flight during chunk c's MFMA phase, and the record of chunk c+2 with them.  Every load is unconditional
+    // on a clamped index (a load inside a divergent branch is waited for at the end of the branch); validity is applied
+    // when the values are used.
+    struct Dat { double2 ex[2]; double2 ey[2]; double X[3]; double dl[9]; };
+    const int last_rec = it.n_lm - 1;
+    const size_t last_edge = (size_t)wd.edge_off + (size_t)max(wd.E - 1, 0);
+    auto load_rec = [&](int c0, int4& ra, int4& rb) {
+      const int4* src = reinterpret_cast<const int4*>(recs + min(c0 + l, last_rec));
+      ra = src[0]; rb = src[1];          // {lm, e_first, x_lo, x_hi} {y_lo, y_hi, flags, pad}
+    };
+    auto slot_of = [&](unsigned lo, unsigned hi) { return (((s < 4) ? lo : hi) >> (8 * (s & 3))) & 0xffu; };
+    auto edge_of = [&](const int4& ra, unsigned o) { return min((size_t)wd.edge_off + (size_t)(ra.y + (o != kAbsent ? (int)o : 0)), last_edge); };
+    auto load_dat = [&](const int4& ra, const int4& rb, Dat& d) {
+      const double2* src = reinterpret_cast<const double2*>(bv.e_rec + edge_of(ra, slot_of((unsigned)ra.z, (unsigned)ra.w)) * 4);
+      d.ex[0] = src[0]; d.ex[1] = src[1];
+      if (!SYM) {
+        const double2* sy = reinterpret_cast<const double2*>(bv.e_rec + edge_of(ra, slot_of((unsigned)rb.x, (unsigned)rb.y)) * 4);
+        d.ey[0] = sy[0]; d.ey[1] = sy[1];
       }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) d.X[k] = pts[(size_t)ra.x * 3 + k];
+      if (do_schur) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) d.dl[k] = DL[(size_t)ra.x * 9 + k];
+      }
+    };
+    // rows of W F of the lane's edge on one side of the item (side 0: row poses, 1: column poses) -> the side's LDS image
+    auto side_rows = [&](int side, bool present, const int4& ra, unsigned o, const double2* er, const Dat& d, double* img) __attribute__((always_inline)) {
+      const double* ps = shPose + (side * 8 + s) * kPoseRec;
+      double qt[7], cam[5], Rm[9];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) qt[k] = ps[k];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) cam[k] = ps[7 + k];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Rm[k] = ps[12 + k];
+      const double rec[4] = {er[0].x, er[0].y, er[1].x, er[1].y};
+      double Xc[3], Q[6], g[3], rho0;
+      win_edge_core<KB8>(wd, bv, edge_of(ra, o), rec, qt, cam, Rm, d.X, Xc, Q, g, rho0);
+      // an empty slot computes on another edge's data: its result is discarded here (select, not multiply: it may be NaN)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Q[k] = present ? Q[k] : 0.0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) g[k] = present ? g[k] : 0.0;
+      if (SYM && do_hpp && side == 0) dev::core_pose_side<KB8>(Xc, Q, g, H, hb);
+      if (do_schur) {
+        double WF[18];
+        dev::core_WF<KB8>(Xc, Q, Rm, d.dl, WF);
+        double* row = img + (6 * s) * KS + 3 * l;
+        if (lane_on) {
+#pragma unroll
+          for (int r = 0; r < 6; ++r) { row[r * KS + 0] = WF[r * 3]; row[r * KS + 1] = WF[r * 3 + 1]; row[r * KS + 2] = WF[r * 3 + 2]; }
+        }
+        if (SYM) {
+#pragma unroll
+          for (int r = 0; r < 6; ++r) csum[r] += WF[r * 3] * d.dl[6] + WF[r * 3 + 1] * d.dl[7] + WF[r * 3 + 2] * d.dl[8];
+        }
+      }
+    };
+    // (always inlined: as a call, in the fisheye instantiation, every accumulator it touches by reference would live in scratch memory)
+    auto park = [&](int c0, const int4& ra, const int4& rb, const Dat& d) __attribute__((always_inline)) {
+      const bool valid = lane_on && (c0 + l) < it.n_lm;
+      const unsigned xo = valid ? slot_of((unsigned)ra.z, (unsigned)ra.w) : kAbsent;
+      wave_sync();   // the previous chunk's MFMA reads are done
+      side_rows(0, xo != kAbsent, ra, xo, d.ex, d, shA);
+      if (!SYM) {
+        const unsigned yo = valid ? slot_of((unsigned)rb.x, (unsigned)rb.y) : kAbsent;
+        side_rows(1, yo != kAbsent, ra, yo, d.ey, d, shB);
+      }
+    };
+    // The tile counts are compile-time constants inside each instantiation (dispatched once per chunk): with run-time tile tests
+    // every MFMA and every operand read sat behind its own scalar branch.
+    auto multiply_t = [&](auto txc, auto tyc) {
+      constexpr int TXc = decltype(txc)::value, TYc = decltype(tyc)::value;
+      const double* imgB = SYM ? shA : shB;
+#pragma unroll
+      for (int ks = 0; ks < KST; ++ks) {
+        double a[3], b[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          a[t] = (t < TXc) ? shA[(16 * t + mrow) * KS + 4 * ks + mk] : 0.0;
+          b[t] = SYM ? a[t] : ((t < TYc) ? imgB[(16 * t + mrow) * KS + 4 * ks + mk] : 0.0);
+        }
+#pragma unroll
+        for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+          for (int tj = SYM ? ti : 0; tj < 3; ++tj)
+            if (ti < TXc && tj < TYc) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+        if (ks & 1) __builtin_amdgcn_sched_barrier(0);   // operands of two k-steps in flight at most (the prefetched chunk needs the registers)
+      }
+    };
+    auto multiply_cross = [&]() {
+      // cross items keep run-time tile tests: nine instantiations cost registers for no gain
+#pragma unroll
+      for (int ks = 0; ks < KST; ++ks) {
+        double a[3], b[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          a[t] = (t < TX) ? shA[(16 * t + mrow) * KS + 4 * ks + mk] : 0.0;
+          b[t] = (t < TY) ? shB[(16 * t + mrow) * KS + 4 * ks + mk] : 0.0;
+        }
+#pragma unroll
+        for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < 3; ++tj)
+            if (ti < TX && tj < TY) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+      }
+    };
+    int4 rc0, rc1, rn0, rn1;
+    Dat d;
+    load_rec(0, rc0, rc1);
+    load_rec(LM, rn0, rn1);
+    load_dat(rc0, rc1, d);
+    wave_sync();   // the staged poses are visible
+    // The chunk loop is instantiated per tile count (dispatched ONCE per item): a dispatch inside the loop makes the compiler
+    // reconcile the register assignment of the accumulators at every merge (dozens of 64-bit moves per chunk).
+    auto chunk_loop = [&](auto txc) {
+      for (int c0 = 0; c0 < it.n_lm; c0 += LM) {
+        park(c0, rc0, rc1, d);                 // edge descriptions, W F rows of chunk c0 -> LDS (consumes d)
+        wave_sync();
+        rc0 = rn0; rc1 = rn1;                  // loaded one iteration ago
+        load_dat(rc0, rc1, d);                 // chunk c0 + 1: in flight during the MFMAs below
+        load_rec(c0 + 2 * LM, rn0, rn1);
+        if (do_schur) {
+          if (SYM) multiply_t(txc, txc); else multiply_cross();
+        }
+      }
+    };
+    if (SYM && do_schur) {   // TX == TY
+      if (PS > 5 && TX == 3) chunk_loop(integral_constant<int, 3>{});
+      else if (PS > 2 && TX == 2) chunk_loop(integral_constant<int, 2>{});
+      else chunk_loop(integral_constant<int, 1>{});
+    } else {
+      chunk_loop(integral_constant<int, 0>{});
+    }
+    wave_sync();
+    if (do_schur) {
+      // contributions: lane holds D[row = (lane >> 4) + 4 reg][col = lane & 15] of each tile
 #pragma unroll
       for (int ti = 0; ti < 3; ++ti)
 #pragma unroll
-        for (int tj = 0; tj < 3; ++tj)
-          if (ti < TX && tj < TY) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
-    }
-  };
-  int4 rc0, rc1, rn0, rn1;
-  Dat d;
-  load_rec(0, rc0, rc1);
-  load_rec(kSiLm, rn0, rn1);
-  load_dat(rc0, rc1, d);
-  wave_sync();   // the staged poses are visible
-  // The chunk loop is instantiated per tile count (dispatched ONCE per item): a dispatch inside the loop makes the compiler
-  // reconcile the register assignment of the accumulators at every merge (dozens of 64-bit moves per chunk).
-  auto chunk_loop = [&](auto txc) {
-    for (int c0 = 0; c0 < it.n_lm; c0 += kSiLm) {
-      park(c0, rc0, rc1, d);                 // edge descriptions, W F rows of chunk c0 -> LDS (consumes d)
-      wave_sync();
-      rc0 = rn0; rc1 = rn1;                  // loaded one iteration ago
-      load_dat(rc0, rc1, d);                 // chunk c0 + 1: in flight during the MFMAs below
-      load_rec(c0 + 2 * kSiLm, rn0, rn1);
-      if (do_schur) {
-        if (SYM) multiply_t(txc, txc); else multiply_cross();
+        for (int tj = SYM ? ti : 0; tj < 3; ++tj) {
+          if (ti < TX && tj < TY) {
+            const int C = 16 * tj + (lane & 15);
+            const int sb = C / 6, cc = C - 6 * sb;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+              const int R = 16 * ti + (lane >> 4) + 4 * reg;
+              const int sa = R / 6, rr = R - 6 * sa;
+              const int slot = shP[sa * 8 + sb];
+              if (slot >= 0) bv.contrib[(size_t)slot * 36 + rr * 6 + cc] = acc[ti][tj][reg];
+            }
+          }
+        }
+      if (SYM) {
+        // rhs term of row pose s: sum over the landmark lanes in fixed order
+        if (lane_on) {
+#pragma unroll
+          for (int r = 0; r < 6; ++r) shA[l * (6 * PS) + 6 * s + r] = csum[r];
+        }
+        wave_sync();
+        if (lane < 6 * PS) {
+          double v = 0.0;
+#pragma unroll
+          for (int k = 0; k < LM; ++k) v += shA[k * (6 * PS) + lane];
+          const int sa = lane / 6;
+          const int slot = shP[64 + sa];
+          if (slot >= 0) bv.ccontrib[(size_t)slot * 6 + (lane - 6 * sa)] = v;
+        }
+        wave_sync();
       }
     }
-  };
-  if (SYM && do_schur) {   // TX == TY
-    if (TX == 3) chunk_loop(integral_constant<int, 3>{});
-    else if (TX == 2) chunk_loop(integral_constant<int, 2>{});
-    else chunk_loop(integral_constant<int, 1>{});
-  } else {
-    chunk_loop(integral_constant<int, 0>{});
-  }
-  wave_sync();
-  if (do_schur) {
-    // contributions: lane holds D[row = (lane >> 4) + 4 reg][col = lane & 15] of each tile
+    if (SYM && do_hpp) {
+      // Hpp / b_p of row pose s: sum over the landmark lanes in fixed order (two halves through the image buffer)
 #pragma unroll
-    for (int ti = 0; ti < 3; ++ti)
+      for (int half = 0; half < 2; ++half) {
+        const int k0 = half * 14, nk = half ? 13 : 14;
+        wave_sync();
 #pragma unroll
-      for (int tj = SYM ? ti : 0; tj < 3; ++tj) {
-        if (ti < TX && tj < TY) {
-          const int C = 16 * tj + (lane & 15);
-          const int sb = C / 6, cc = C - 6 * sb;
+        for (int k = 0; k < 14; ++k) {
+          const int kk = k0 + k;
+          if (k < nk) shA[k * 64 + lane] = (kk < 21) ? H[kk < 21 ? kk : 0] : hb[(kk - 21) < 0 ? 0 : ((kk - 21) > 5 ? 5 : (kk - 21))];
+        }
+        wave_sync();
+        for (int o = lane; o < PS * nk; o += 64) {
+          const int k = o / PS, sa = o - k * PS;
+          const int slot = shP[64 + sa];
+          if (slot >= 0) {
+            double v = 0.0;
 #pragma unroll
-          for (int reg = 0; reg < 4; ++reg) {
-            const int R = 16 * ti + (lane >> 4) + 4 * reg;
-            const int sa = R / 6, rr = R - 6 * sa;
-            const int slot = shP[sa * 8 + sb];
-            if (slot >= 0) bv.contrib[(size_t)slot * 36 + rr * 6 + cc] = acc[ti][tj][reg];
+            for (int ll = 0; ll < LM; ++ll) v += shA[k * 64 + ll * PS + sa];
+            bv.hcontrib[(size_t)slot * 27 + k0 + k] = v;
           }
         }
       }
-    if (SYM) {
-      // rhs term of row pose s: sum over the 8 landmark lanes in fixed order
-#pragma unroll
-      for (int r = 0; r < 6; ++r) shA[l * kSiRows + 6 * s + r] = csum[r];
-      wave_sync();
-      if (lane < kSiRows) {
-        double v = 0.0;
-#pragma unroll
-        for (int k = 0; k < kSiLm; ++k) v += shA[k * kSiRows + lane];
-        const int sa = lane / 6;
-        const int slot = shP[64 + sa];
-        if (slot >= 0) bv.ccontrib[(size_t)slot * 6 + (lane - 6 * sa)] = v;
-      }
-      wave_sync();
     }
-  }
-  if (SYM && do_hpp) {
-    // Hpp / b_p of row pose s: sum over the 8 landmark lanes in fixed order (two halves through the image buffer)
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int k0 = half * 14, nk = half ? 13 : 14;
-      wave_sync();
-#pragma unroll
-      for (int k = 0; k < 14; ++k) {
-        const int kk = k0 + k;
-        if (k < nk) shA[k * 64 + lane] = (kk < 21) ? H[kk < 21 ? kk : 0] : hb[(kk - 21) < 0 ? 0 : ((kk - 21) > 5 ? 5 : (kk - 21))];
-      }
-      wave_sync();
-      for (int o = lane; o < 8 * nk; o += 64) {
-        const int k = o >> 3, sa = o & 7;
-        const int slot = shP[64 + sa];
-        if (slot >= 0) {
-          double v = 0.0;
-#pragma unroll
-          for (int ll = 0; ll < 8; ++ll) v += shA[k * 64 + ll * 8 + sa];
-          bv.hcontrib[(size_t)slot * 27 + k0 + k] = v;
-        }
-      }
-    }
+  };
+  if constexpr (SYM && !KB8) {
+    if (nx <= 4) body(integral_constant<int, 16>{}, integral_constant<int, 4>{});
+    else if (nx == 5) body(integral_constant<int, 12>{}, integral_constant<int, 5>{});
+    else body(integral_constant<int, kSiLm>{}, integral_constant<int, 8>{});
+  } else {
+    body(integral_constant<int, kSiLm>{}, integral_constant<int, 8>{});
   }
 }
 
