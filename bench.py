@@ -95,7 +95,7 @@ def make_lba_inputs(args, rank, world):
             got = pickle.load(f)
         if got["seeds"] == seeds:
             return got["windows"]
-    workers = args.workers if args.workers > 0 else max(1, min(16, (os.cpu_count() or 8) // max(1, world)))
+    workers = args.workers if args.workers > 0 else max(1, min(16, usable_cores() // max(1, world)))   # (the cgroup's share, not the machine's cores)
     windows = generate_windows(seeds, workers=workers)
     if cache is not None:
         import pickle
