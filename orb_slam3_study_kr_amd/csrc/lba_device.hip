@@ -1068,6 +1068,9 @@ __global__ __launch_bounds__(64) void k_control(BatchView bv, int phase) {
   const WinDesc& wd = bv.win[w];
   LmState& st = bv.lm[w];
   const int lane = threadIdx.x;
+  // the count of active windows is taken by phase 1; phase 0 of the same round (an earlier launch, no increments of its own) clears it
+  // (a hipMemsetAsync per round was a 4.4 us fill kernel of its own: 2 % of a single window's optimize())
+  if (phase == 0 && w == 0 && lane == 0) *bv.n_active = 0;
   if (!st.active) return;
   // robust chi2 of the state evaluated last = sum of the partials (fixed order): chunk partials of k_lin_lm after a
   // linearisation, of k_residual after a trial
@@ -1744,8 +1747,7 @@ extern "C" int osh_lba_optimize(osh_lba_ctx* c) {
       hipLaunchKernelGGL(k_set_stop, dim3((c->n_windows + 63) / 64), dim3(64), 0, s, c->bv, c->d_stop.as<unsigned char>());
       OSH_TRY(launch_check("k_set_stop"));
     }
-    OSH_HIP(hipMemsetAsync(c->d_nactive.p, 0, sizeof(int), s));
-    LAUNCH(OSH_K_CONTROL, k_control, c->n_windows, 64, 0, c->bv, 1);
+    LAUNCH(OSH_K_CONTROL, k_control, c->n_windows, 64, 0, c->bv, 1);   // (counts the windows still active; cleared by this round's phase 0)
     // A round is one trial; an iteration takes at least one, so no window can finish before `max_iter` rounds unless it converges
     // early -- and every kernel of a round leaves at once for a window that is no longer active.  The first max_iter rounds are
     // therefore queued without waiting for the count of active windows (ten host round trips of an optimize(10) were 0.2 ms of a
