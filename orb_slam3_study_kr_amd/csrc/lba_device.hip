@@ -771,7 +771,15 @@ __global__ __launch_bounds__(256) void k_schur_reduce(BatchView bv) {
     double v = bv.bp[gp * 6 + el];
     const double* c = bv.ccontrib + (size_t)rb.start * 6 + el;
     int k = 0;
-    for (; k + 8 <= rb.count; k += 8) {   // eight contributions in flight, subtracted in plan order
+    for (; k + 24 <= rb.count; k += 24) {   // 24, then eight contributions in flight, subtracted in plan order
+      double t[24];
+#pragma unroll
+      for (int u = 0; u < 24; ++u) t[u] = c[(size_t)(k + u) * 6];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 24; ++u) v -= t[u];
+    }
+    for (; k + 8 <= rb.count; k += 8) {
       double t[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) t[u] = c[(size_t)(k + u) * 6];
@@ -791,6 +799,14 @@ __global__ __launch_bounds__(256) void k_schur_reduce(BatchView bv) {
   if (i == j) v = bv.Hpp[((size_t)wd.fpose_off + i) * 36 + el] + ((r == cc) ? st.lambda : 0.0);
   const double* c = bv.contrib + (size_t)rb.start * 36 + el;
   int k = 0;
+  for (; k + 24 <= rb.count; k += 24) {   // 24 contributions in flight where a block has that many (a single window cut into small items),
+    double t[24];
+#pragma unroll
+    for (int u = 0; u < 24; ++u) t[u] = c[(size_t)(k + u) * 36];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 24; ++u) v -= t[u];
+  }
   for (; k + 8 <= rb.count; k += 8) {   // eight contributions in flight (one load per iteration left every memory round trip exposed),
     double t[8];                        // subtracted in plan order: the sum is the same number as before
 #pragma unroll
@@ -819,6 +835,14 @@ __global__ __launch_bounds__(64) void k_pose_reduce(BatchView bv, int mode) {
   if (k < 27) {
     const double* src = bv.hcontrib + (size_t)rg.x * 27 + k;
     int c = 0;
+    for (; c + 16 <= rg.y; c += 16) {   // sixteen contributions in flight (a single window cut into small items has ~100 per pose), added in plan order
+      double t[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) t[u] = src[(size_t)(c + u) * 27];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) a += t[u];
+    }
     for (; c + 4 <= rg.y; c += 4) {
       const double v0 = src[(size_t)c * 27], v1 = src[(size_t)(c + 1) * 27], v2 = src[(size_t)(c + 2) * 27], v3 = src[(size_t)(c + 3) * 27];
       a += v0; a += v1; a += v2; a += v3;

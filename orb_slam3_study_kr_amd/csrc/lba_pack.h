@@ -304,7 +304,7 @@ inline int pack_batch(int nw, const osh_lba_problem* pr, const std::function<voi
     d.E = n_sorted;
     // Schur work plan on the old numbering (schur_plan.h)
     L.recs.reserve((size_t)p.n_points + p.n_points / 4);
-    if (!plan_window(w, p.n_free, p.n_points, old_lmo.data(), nfree.data(), tmp_epose.data(), L.builds, L.recs, L.plan, sc.plan))
+    if (!plan_window(w, p.n_free, p.n_points, old_lmo.data(), nfree.data(), tmp_epose.data(), L.builds, L.recs, L.plan, sc.plan, item_max_lm(nw)))
       return lfail(OSH_ERR_UNSUPPORTED, "window %d: a landmark has more than 254 optimisable observers", w);
     // renumber the landmarks in the order of the plan's owner records (symmetric builds, in build order)
     std::vector<int>& old2new = sc.old2new;

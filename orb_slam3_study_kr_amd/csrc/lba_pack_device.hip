@@ -79,6 +79,7 @@ struct PackArgs {
   int *a_epose, *a_epoint, *a_eorig, *a_eorig2, *a_lmoff, *a_lmperm, *a_fpw;
   double* a_rec2;
   int has_rig;
+  int item_max;   // landmarks per item at most (schur_plan.h:item_max_lm)
   unsigned char* a_ekind;
   Chunk* a_chunks;
   SItem* a_items;
@@ -466,14 +467,14 @@ __device__ __forceinline__ u64 pack_slots_dev(const unsigned short* S, int ns, c
 // The greedy merge of schur_plan.h:plan_window (one thread): consecutive keys whose pose sets unite to <= 8 poses without
 // changing the tile count share an item; an item takes at most 64 units.  KF(q, g): word q of the g-th smallest key, CF(g): its units.
 template <class KeyF, class CntF>
-__device__ void greedy_items(int ng, KeyF KF, CntF CF, DBuild* builds, int* wk, int* out5) {
+__device__ void greedy_items(int ng, KeyF KF, CntF CF, DBuild* builds, int* wk, int* out5, const int item_max) {
   int* curX = wk; int* curY = wk + 16; int* gX = wk + 32; int* gY = wk + 40; int* ux = wk + 48; int* uy = wk + 64;
   int ncx = 0, ncy = 0, cur0 = 0, cur1 = 0, nb = 0, n_sym = 0, n_cross = 0, recs_sym = 0, recs_cross = 0;
   bool cur_sym = true;
   auto flush = [&]() {
-    for (int base = cur0; base < cur1; base += kItemMaxLm) {
+    for (int base = cur0; base < cur1; base += item_max) {
       DBuild bd;
-      bd.base = base; bd.n = min(cur1, base + kItemMaxLm) - base;
+      bd.base = base; bd.n = min(cur1, base + item_max) - base;
       bd.shape = ncx | (ncy << 8) | ((cur_sym ? 1 : 0) << 16);
       for (int q = 0; q < 8; ++q) { bd.X[q] = q < ncx ? (unsigned short)curX[q] : (unsigned short)0xffff; bd.Y[q] = q < ncy ? (unsigned short)curY[q] : (unsigned short)0xffff; }
       if (cur_sym) { bd.cls_idx = n_sym++; bd.rec_rel = recs_sym; recs_sym += bd.n; } else { bd.cls_idx = n_cross++; bd.rec_rel = recs_cross; recs_cross += bd.n; }
@@ -488,7 +489,7 @@ __device__ void greedy_items(int ng, KeyF KF, CntF CF, DBuild* builds, int* wk, 
     const int ngx = unpack_poses_dev(KF(1, g), KF(2, g), gX), ngy = unpack_poses_dev(KF(3, g), KF(4, g), gY);
     const bool g_sym = KF(0, g) == 0;
     bool merged = false;
-    if (cur1 > cur0 && cur_sym == g_sym && (cur1 - cur0) < kItemMaxLm) {
+    if (cur1 > cur0 && cur_sym == g_sym && (cur1 - cur0) < item_max) {
       const int nux = set_union_dev(curX, ncx, gX, ngx, ux), nuy = set_union_dev(curY, ncy, gY, ngy, uy);
       if (nux <= kItemPoses && nuy <= kItemPoses && tiles_of_dev(nux) == tiles_of_dev(ncx) && tiles_of_dev(nux) == tiles_of_dev(ngx) &&
           tiles_of_dev(nuy) == tiles_of_dev(ncy) && tiles_of_dev(nuy) == tiles_of_dev(ngy)) {
@@ -708,7 +709,7 @@ __global__ __launch_bounds__(NT, 8) void k_pack_pre2(PackArgs a) {
         if (g + 1 < ng) { nx0 = M0[g + 1]; ny0 = M1[g + 1]; ns0 = M2[g + 1]; }
         const bool gsym = (sc >> 63) != 0;
         bool merged = false;
-        if (cur1 > cur0 && csym == gsym && (cur1 - cur0) < kItemMaxLm) {
+        if (cur1 > cur0 && csym == gsym && (cur1 - cur0) < a.item_max) {
           const u64 ux = cx | gx, uy = cy | gy;
           const int nux = __popcll(ux), nuy = __popcll(uy);
           if (nux <= kItemPoses && nuy <= kItemPoses && tiles_of_dev(nux) == tiles_of_dev(__popcll(cx)) && tiles_of_dev(nux) == tiles_of_dev(__popcll(gx)) &&
@@ -739,7 +740,7 @@ __global__ __launch_bounds__(NT, 8) void k_pack_pre2(PackArgs a) {
         mx = M0[sidx]; my = M1[sidx];
         const u64 sc = M2[sidx];
         b0 = (int)(unsigned)sc; n = (int)((sc >> 32) & 0x7fffffffull); sym = (sc >> 63) != 0;
-        nbs = (n + kItemMaxLm - 1) / kItemMaxLm;
+        nbs = (n + a.item_max - 1) / a.item_max;
         if (sym) { atomicAdd(&sh_n[2], nbs); atomicAdd(&sh_n[4], n); } else { atomicAdd(&sh_n[3], nbs); atomicAdd(&sh_n[5], n); }
       }
       int tot;
@@ -753,7 +754,7 @@ __global__ __launch_bounds__(NT, 8) void k_pack_pre2(PackArgs a) {
         bd.shape = ncx | (ncy << 8) | ((sym ? 1 : 0) << 16);
         bd.live = 0; bd.clive = 0;
         for (int k = 0; k < nbs; ++k) {
-          bd.base = b0 + k * kItemMaxLm; bd.n = min(n - k * kItemMaxLm, kItemMaxLm);
+          bd.base = b0 + k * a.item_max; bd.n = min(n - k * a.item_max, a.item_max);
           bd.cls_idx = carry_b + ex + k;     // index among all items; rebased for cross items below
           bd.rec_rel = bd.base;
           z.builds[carry_b + ex + k] = bd;
@@ -769,8 +770,8 @@ __global__ __launch_bounds__(NT, 8) void k_pack_pre2(PackArgs a) {
       if (!((z.builds[b].shape >> 16) & 1)) { z.builds[b].cls_idx -= nsymb; z.builds[b].rec_rel -= nsymr; }
     }
   } else if (tid == 0) {
-    if (in_lds) greedy_items(ng, [&](int q, int g) { return shK[q * GL + g]; }, [&](int g) { return shcnt[g]; }, z.builds, sh_wk, sh_n + 1);
-    else greedy_items(ng, [&](int q, int g) { return z.gk[q][arr[g]]; }, [&](int g) { return z.gcnt[arr[g]]; }, z.builds, sh_wk, sh_n + 1);
+    if (in_lds) greedy_items(ng, [&](int q, int g) { return shK[q * GL + g]; }, [&](int g) { return shcnt[g]; }, z.builds, sh_wk, sh_n + 1, a.item_max);
+    else greedy_items(ng, [&](int q, int g) { return z.gk[q][arr[g]]; }, [&](int g) { return z.gcnt[arr[g]]; }, z.builds, sh_wk, sh_n + 1, a.item_max);
   }
   __syncthreads();
   OSH_TC();   // 13: greedy merge
@@ -1158,6 +1159,7 @@ int device_pack_batch(DevPackState& st, hipStream_t s, int nw, const osh_lba_pro
   a.r_pose = reinterpret_cast<const double*>(dr + o_pose); a.r_cam = reinterpret_cast<const double*>(dr + o_cam); a.r_pt = reinterpret_cast<const double*>(dr + o_pt);
   a.r_epose = reinterpret_cast<const int*>(dr + o_ep); a.r_epoint = reinterpret_cast<const int*>(dr + o_el); a.r_kind = dr + o_kind; a.r_rec = dr + o_rec;
   a.rec_f32 = f32 ? 1 : 0;
+  a.item_max = item_max_lm(nw);
   a.s1 = st.d_s1.as<int>();
   mark(2);
   hipLaunchKernelGGL(k_pack_pre1, dim3((unsigned)nw), dim3(NT), 0, s, a);

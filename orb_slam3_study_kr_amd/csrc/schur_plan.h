@@ -21,12 +21,22 @@
 #include <cstdint>
 #include <iterator>
 #include <utility>
+#include <cstdlib>
 #include <vector>
 
 namespace osh {
 
 constexpr int kItemPoses = 8;     // row / column poses of one item
-constexpr int kItemMaxLm = 64;    // landmarks per item (load balance; partial sums are per item)
+constexpr int kItemMaxLm = 64;    // landmarks per item at most (load balance; partial sums are per item)
+// Landmarks per item for a batch of nw windows.  One wavefront walks an item's chunks one after the other, so in a call with one or two
+// windows -- the live-SLAM pattern, where every item has a CU to itself anyway -- an item of 64 landmarks is the latency of the Schur
+// launches (28 us per launch for the cross items of a config-2 window): such calls cut their items at 24 landmarks, up to eight
+// windows at 32.  More items mean more 6x6 contributions for k_schur_reduce and k_pose_reduce, which is why a large batch keeps 64
+// (one config-2 window, optimize(): 2.55 ms at 64, 2.40 at 32, 2.34 at 24, 2.37 at 16, 2.41 at 8).
+inline int item_max_lm(int nw) {
+  if (const char* e = std::getenv("OSH_LBA_ITEM_MAX")) { const int v = std::atoi(e); if (v >= 8 && v <= kItemMaxLm) return v; }   // (tuning aid)
+  return nw <= 2 ? 24 : (nw <= 8 ? 32 : kItemMaxLm);
+}
 constexpr unsigned kAbsent = 0xffu;
 
 struct SItem { int win, rec_off, n_lm, shape; };  // shape = nx | ny << 8 | sym << 16
@@ -133,7 +143,7 @@ inline unsigned long long pack_slots(const int* S, int ns, const int* obs, int r
 // Returns false when a landmark has more optimisable observers than a record can index.
 inline bool plan_window(int w, int P, int L, const int* lmo, const int* nfree, const int* epose,
                         std::vector<plan_detail::Build>& out_builds, std::vector<SRec>& out_recs, SchurPlan& plan,
-                        plan_detail::PlanScratch& sc) {
+                        plan_detail::PlanScratch& sc, const int item_max = kItemMaxLm) {
   using namespace plan_detail;
   std::vector<Unit>& units = sc.units;
   units.clear();
@@ -203,14 +213,14 @@ inline bool plan_window(int w, int P, int L, const int* lmo, const int* nfree, c
   size_t cur0 = 0, cur1 = 0;      // [cur0, cur1) of uorder: the units of the item(s) being collected
   bool cur_sym = true;
   auto flush = [&]() {
-    for (size_t base = cur0; base < cur1; base += kItemMaxLm) {
+    for (size_t base = cur0; base < cur1; base += (size_t)item_max) {
       out_builds.emplace_back();
       Build& bd = out_builds.back();
       bd.sym = cur_sym; bd.nx = ncx; bd.ny = ncy;
       for (int s2 = 0; s2 < kItemPoses; ++s2) { bd.X[s2] = s2 < ncx ? curX[s2] : -1; bd.Y[s2] = s2 < ncy ? curY[s2] : -1; }
       std::fill(bd.pair_slot, bd.pair_slot + 64, -1);
       std::fill(bd.c_slot, bd.c_slot + 8, -1);
-      const size_t end = std::min(cur1, base + kItemMaxLm);
+      const size_t end = std::min(cur1, base + (size_t)item_max);
       bd.rec_off = (int)out_recs.size(); bd.n_rec = (int)(end - base);
       const Unit* prev = nullptr;
       unsigned long long xs = 0, ys = 0;
@@ -254,7 +264,7 @@ inline bool plan_window(int w, int P, int L, const int* lmo, const int* nfree, c
     const int ngx = unpack_poses(&u0.k[1], gX), ngy = unpack_poses(&u0.k[3], gY);
     const bool g_sym = u0.k[0] == 0;
     bool merged = false;
-    if (cur1 > cur0 && cur_sym == g_sym && (cur1 - cur0) < (size_t)kItemMaxLm) {
+    if (cur1 > cur0 && cur_sym == g_sym && (cur1 - cur0) < (size_t)item_max) {
       const int nux = set_union(curX, ncx, gX, ngx, ux), nuy = set_union(curY, ncy, gY, ngy, uy);
       if (nux <= kItemPoses && nuy <= kItemPoses && tiles_of(nux) == tiles_of(ncx) && tiles_of(nux) == tiles_of(ngx) &&
           tiles_of(nuy) == tiles_of(ncy) && tiles_of(nuy) == tiles_of(ngy)) {

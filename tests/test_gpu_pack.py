@@ -141,8 +141,9 @@ def test_both_packers_give_bitwise_equal_optimisations(solver):
 
 
 def test_default_rule_batches_on_the_device_single_windows_on_the_host(solver):
-    """The default rule sends batches to the device packer and a handful of windows to host threads; a batch packed on the device gives
-    the same bits as its windows solved one at a time (packed on the host)."""
+    """The default rule sends batches to the device packer and a handful of windows to host threads.  A window solved alone is cut into
+    smaller Schur items than in a batch (schur_plan.h:item_max_lm: the latency of a single call), so its sums run in another order: the
+    same iterations and trials, the same results to rounding (the two packers give the same BITS for the same batch: the tests above)."""
     ws = [synth.make_window(300 + i, n_free=4 + i % 5, n_fixed=1 + i % 3, n_points=120 + 15 * i, stereo=bool(i % 2)) for i in range(32)]
     solver.set_pack_mode(-1)
     batch = solver.solve(ws)
@@ -150,5 +151,7 @@ def test_default_rule_batches_on_the_device_single_windows_on_the_host(solver):
     for i in (0, 7, 19, 31):
         one = solver.solve([ws[i]])[0]
         assert not solver.pack_profile()["on_device"]
-        assert one.iterations == batch[i].iterations
-        assert np.array_equal(one.pose_qt, batch[i].pose_qt) and np.array_equal(one.points, batch[i].points) and np.array_equal(one.edge_chi2, batch[i].edge_chi2)
+        assert one.iterations == batch[i].iterations and one.trials == batch[i].trials
+        np.testing.assert_allclose(one.pose_qt, batch[i].pose_qt, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(one.points, batch[i].points, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(one.edge_chi2, batch[i].edge_chi2, rtol=1e-6, atol=1e-9)
