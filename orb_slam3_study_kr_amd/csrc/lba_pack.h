@@ -30,7 +30,14 @@ namespace osh {
 
 constexpr int kBlock = 256;            // threads per block of the edge/landmark kernels
 constexpr int kChunkEdges = 256;       // edges handled per pass of a chunk (== kBlock)
-constexpr int kChunkMaxEdges = 1024;   // edges of one chunk (= one block of the landmark-major kernels)
+constexpr int kChunkMaxEdges = 1024;   // edges of one chunk at most (= one block of the landmark-major kernels)
+// Edges per chunk for a batch of nw windows: a call with one or two windows spreads its landmark-major kernels over four times as
+// many blocks (a config-2 window: 74 blocks of 1024 edges take 11-12 us per launch, 300 of 256 edges ...), as item_max_lm() does for the
+// Schur items.  A multiple of kChunkEdges.
+inline int chunk_max_edges(int nw) {
+  if (const char* e = std::getenv("OSH_LBA_CHUNK_EDGES")) { const int v = std::atoi(e); if (v >= kChunkEdges && v <= kChunkMaxEdges && v % kChunkEdges == 0) return v; }   // (tuning aid)
+  return nw <= 2 ? 256 : (nw <= 8 ? 512 : kChunkMaxEdges);
+}
 
 // internal edge kinds of the sorted edge list (the C-ABI kinds OSH_EDGE_* plus the merged rig edge)
 constexpr int kKindMono = 0, kKindStereo = 1, kKindBody = 2, kKindBoth = 3;
@@ -356,12 +363,13 @@ inline int pack_batch(int nw, const osh_lba_problem* pr, const std::function<voi
     for (const plan_detail::Build& bd : L.builds) {
       if (bd.sym) { L.n_sym++; L.recs_sym += bd.n_rec; } else { L.n_cross++; L.recs_cross += bd.n_rec; }
     }
-    // chunks of the landmark-major kernels: consecutive landmarks, <= kChunkMaxEdges edges and <= kBlock landmarks (a single
+    // chunks of the landmark-major kernels: consecutive landmarks, <= chunk_max_edges(nw) edges and <= kBlock landmarks (a single
     // landmark with more edges gets its own multi-pass chunk)
+    const int chunk_edges = chunk_max_edges(nw);
     int j = 0;
     while (j < p.n_points) {
       int j1 = j + 1;
-      while (j1 < p.n_points && (j1 - j) < kBlock && (lmo[j1 + 1] - lmo[j]) <= kChunkMaxEdges) ++j1;
+      while (j1 < p.n_points && (j1 - j) < kBlock && (lmo[j1 + 1] - lmo[j]) <= chunk_edges) ++j1;
       L.chunks.push_back(Chunk{w, j, j1});
       j = j1;
     }

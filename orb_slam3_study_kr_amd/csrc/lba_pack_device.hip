@@ -80,6 +80,7 @@ struct PackArgs {
   double* a_rec2;
   int has_rig;
   int item_max;   // landmarks per item at most (schur_plan.h:item_max_lm)
+  int chunk_edges;   // edges per chunk at most (lba_pack.h:chunk_max_edges)
   unsigned char* a_ekind;
   Chunk* a_chunks;
   SItem* a_items;
@@ -802,9 +803,9 @@ __global__ __launch_bounds__(NT, 8) void k_pack_pre2(PackArgs a) {
   for (int j = tid; j < L; j += NT) {
     int lo = j + 1, hi = min(L, j + kBlock);
     const int e0 = z.lmo_new[j];
-    while (lo < hi) {   // largest m in [j+1, hi] with m == j+1 or lmo[m] - lmo[j] <= kChunkMaxEdges
+    while (lo < hi) {   // largest m in [j+1, hi] with m == j+1 or lmo[m] - lmo[j] <= chunk_max_edges(nw)
       const int mid = (lo + hi + 1) >> 1;
-      if (z.lmo_new[mid] - e0 <= kChunkMaxEdges) lo = mid; else hi = mid - 1;
+      if (z.lmo_new[mid] - e0 <= a.chunk_edges) lo = mid; else hi = mid - 1;
     }
     nxt[j] = lo;
   }
@@ -1160,6 +1161,7 @@ int device_pack_batch(DevPackState& st, hipStream_t s, int nw, const osh_lba_pro
   a.r_epose = reinterpret_cast<const int*>(dr + o_ep); a.r_epoint = reinterpret_cast<const int*>(dr + o_el); a.r_kind = dr + o_kind; a.r_rec = dr + o_rec;
   a.rec_f32 = f32 ? 1 : 0;
   a.item_max = item_max_lm(nw);
+  a.chunk_edges = chunk_max_edges(nw);
   a.s1 = st.d_s1.as<int>();
   mark(2);
   hipLaunchKernelGGL(k_pack_pre1, dim3((unsigned)nw), dim3(NT), 0, s, a);
