@@ -756,6 +756,9 @@ __global__ __launch_bounds__(64, KB8 ? 1 : 2) void k_schur_fused(BatchView bv, i
 // b_s(i) = b_p(i) - sum of the pose's rhs contributions; 7 blocks of S per 256-thread group,
 // one thread per entry, contributions in plan order.
 // --------------------------------------------------------------------------------------------
+// DEEP: 24 contributions in flight where a block has that many -- a call with few windows cuts its Schur items small (item_max_lm) and
+// has four times as many contributions per block; in a large batch (about six per block) the extra registers only cost (0.315 -> 0.33 ms).
+template <bool DEEP>
 __global__ __launch_bounds__(256) void k_schur_reduce(BatchView bv) {
   const int t = threadIdx.x / 36, el = threadIdx.x - 36 * t;
   const int idx = blockIdx.x * 7 + t;
@@ -771,13 +774,15 @@ __global__ __launch_bounds__(256) void k_schur_reduce(BatchView bv) {
     double v = bv.bp[gp * 6 + el];
     const double* c = bv.ccontrib + (size_t)rb.start * 6 + el;
     int k = 0;
-    for (; k + 24 <= rb.count; k += 24) {   // 24, then eight contributions in flight, subtracted in plan order
-      double t[24];
+    if constexpr (DEEP) {
+      for (; k + 24 <= rb.count; k += 24) {
+        double t[24];
 #pragma unroll
-      for (int u = 0; u < 24; ++u) t[u] = c[(size_t)(k + u) * 6];
-      __builtin_amdgcn_sched_barrier(0);
+        for (int u = 0; u < 24; ++u) t[u] = c[(size_t)(k + u) * 6];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int u = 0; u < 24; ++u) v -= t[u];
+        for (int u = 0; u < 24; ++u) v -= t[u];
+      }
     }
     for (; k + 8 <= rb.count; k += 8) {
       double t[8];
@@ -799,13 +804,15 @@ __global__ __launch_bounds__(256) void k_schur_reduce(BatchView bv) {
   if (i == j) v = bv.Hpp[((size_t)wd.fpose_off + i) * 36 + el] + ((r == cc) ? st.lambda : 0.0);
   const double* c = bv.contrib + (size_t)rb.start * 36 + el;
   int k = 0;
-  for (; k + 24 <= rb.count; k += 24) {   // 24 contributions in flight where a block has that many (a single window cut into small items),
-    double t[24];
+  if constexpr (DEEP) {
+    for (; k + 24 <= rb.count; k += 24) {
+      double t[24];
 #pragma unroll
-    for (int u = 0; u < 24; ++u) t[u] = c[(size_t)(k + u) * 36];
-    __builtin_amdgcn_sched_barrier(0);
+      for (int u = 0; u < 24; ++u) t[u] = c[(size_t)(k + u) * 36];
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < 24; ++u) v -= t[u];
+      for (int u = 0; u < 24; ++u) v -= t[u];
+    }
   }
   for (; k + 8 <= rb.count; k += 8) {   // eight contributions in flight (one load per iteration left every memory round trip exposed),
     double t[8];                        // subtracted in plan order: the sum is the same number as before
@@ -1733,7 +1740,7 @@ static int trial_kernels(osh_lba_ctx* c, bool later_round) {
   LAUNCH(OSH_K_SCHUR, c->kp_schur_sym, pb.n_sym, 64, 0, c->bv, 0, 1);
   LAUNCH(OSH_K_SCHUR_CROSS, c->kp_schur_cross, pb.n_items - pb.n_sym, 64, 0, c->bv, (int)pb.n_sym, 1);
   if (later_round) LAUNCH(OSH_K_POSE_HESS, k_pose_reduce, (pb.NFP + 1) / 2, 64, 0, c->bv, 1);
-  LAUNCH(OSH_K_SCHUR_REDUCE, k_schur_reduce, (pb.n_rblk + 6) / 7, 256, 0, c->bv);
+  if (c->n_windows <= 8) { LAUNCH(OSH_K_SCHUR_REDUCE, k_schur_reduce<true>, (pb.n_rblk + 6) / 7, 256, 0, c->bv); } else { LAUNCH(OSH_K_SCHUR_REDUCE, k_schur_reduce<false>, (pb.n_rblk + 6) / 7, 256, 0, c->bv); }
   {
     const bool _t = c->timer.begin(OSH_K_SOLVE, s);
     OSH_TRY(launch_solve(c, s));
@@ -1948,7 +1955,7 @@ extern "C" int osh_lba_debug_trial(osh_lba_ctx* c, int32_t window, double lambda
   LAUNCH(OSH_K_LIN_AUX, c->kp_lin_lm, pb.n_chunks, kBlock, c->lin_lds, c->bv);
   LAUNCH(OSH_K_SCHUR, c->kp_schur_sym, pb.n_sym, 64, 0, c->bv, 0, 1);
   LAUNCH(OSH_K_SCHUR_CROSS, c->kp_schur_cross, pb.n_items - pb.n_sym, 64, 0, c->bv, (int)pb.n_sym, 1);
-  LAUNCH(OSH_K_SCHUR_REDUCE, k_schur_reduce, (pb.n_rblk + 6) / 7, 256, 0, c->bv);
+  if (c->n_windows <= 8) { LAUNCH(OSH_K_SCHUR_REDUCE, k_schur_reduce<true>, (pb.n_rblk + 6) / 7, 256, 0, c->bv); } else { LAUNCH(OSH_K_SCHUR_REDUCE, k_schur_reduce<false>, (pb.n_rblk + 6) / 7, 256, 0, c->bv); }
   OSH_HIP(hipStreamSynchronize(s));
   if (S && d.n) OSH_HIP(hipMemcpy(S, c->d_S.as<double>() + d.S_off, (size_t)d.n * d.n * 8, hipMemcpyDeviceToHost));
   if (bs && d.n) OSH_HIP(hipMemcpy(bs, c->d_bs.as<double>() + (size_t)d.fpose_off * 6, (size_t)d.n * 8, hipMemcpyDeviceToHost));
@@ -2034,7 +2041,7 @@ extern "C" int osh_lba_get_upload_times(osh_lba_ctx* c, double ms[2]) {
 extern "C" const char* osh_lba_kernel_name(int k) {
   // pinhole instantiations reading float32 records (<true, ..> for a fisheye batch, <.., false> when a record is not exact in float32)
   static const char* names[OSH_K_COUNT] = {"k_lin_lm<false, true>", "k_pose_reduce", "k_schur_fused<true, false> (mode 1)", "k_solve", "k_backsub<false, true>",
-                                           "k_residual<false, true>", "k_control", "k_schur_reduce", "k_schur_fused<false, false>",
+                                           "k_residual<false, true>", "k_control", "k_schur_reduce<false>", "k_schur_fused<false, false>",
                                            "k_lin_lm<false, true> (factors only)", "k_schur_fused<true, false> (mode 0)"};
   return (k >= 0 && k < OSH_K_COUNT) ? names[k] : "?";
 }

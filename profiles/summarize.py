@@ -55,6 +55,7 @@ if rows:
              "void k_residual<false>": "residual", "void k_residual<true>": "residual", "k_pose_reduce": "pose_hess",
              "void k_backsub<false>": "backsub", "void k_backsub<true>": "backsub",
              "void k_schur_items<true>": "schur", "void k_schur_items<false>": "schur_cross", "k_schur_reduce": "schur_reduce",
+             "void k_schur_reduce<false>": "schur_reduce", "void k_schur_reduce<true>": "schur_reduce",
              "void k_solve<24, 256>": "solve", "void k_solve<12, 256>": "solve", "void k_solve<6, 256>": "solve", "void k_solve<24, 512>": "solve",
              "void k_solve<12, 512>": "solve", "void k_solve<6, 512>": "solve", "k_backsub": "backsub", "k_residual": "residual",
              "dpack::k_pack_pre1": "pack_pre1", "dpack::k_pack_pre2": "pack_pre2", "dpack::k_pack_post": "pack_post", "k_widen_rec": "widen_rec"}
