@@ -32,6 +32,7 @@ constexpr int kLT = 256;      // threads of a block: one wavefront per SIMD, so 
                               // per-edge code spilled: 1.2 KB of scratch per lane)
 constexpr int kLNB = 24;      // LDL^T panel width (12 or 6 for windows whose 24-wide panels do not fit LDS: k_liba<NB>)
 constexpr int kLG = 32;       // blocks per window at most (one XCD's worth of a group)
+constexpr int kPB = 16;       // pivots per step of the group factorisation (liba_solve_group)
 constexpr int kPoseChunks = 8;   // a pose row's edges are summed in at most this many chunks
 constexpr int kLinkQ = 832;   // per link: J^T W J (24x24), -J^T W r (24), then J (9x24), -W r (9), rho'
 // LDS scratch: the LDL^T panels of the reduced system when they fit one block's LDS (NB = 24: up to 51 keyframes, every LocalInertialBA /
@@ -615,10 +616,14 @@ __device__ __noinline__ void liba_linearise(const LibaCtx& c, int sel) {
 __device__ __noinline__ void liba_schur_banded(const LibaCtx& c, double lambda) {
   OSH_LIBA_LOCALS
   {
-    const long long wrow = (long long)d.bw + 1, tot = (long long)n * wrow;
+    // (kPB - 1 columns past the band too: the row panel of a 16-pivot step of liba_solve_group reads its first row that far -- structural
+    // zeros, but zeros that have to be there: left unwritten they were whatever an earlier, larger call had put in the arena, and a
+    // 400-keyframe map solved after a 128-window batch in the same context ended on another cost with 20 trials instead of 5)
+    const long long wrow = (long long)d.bw + kPB, tot = (long long)n * wrow;
     for (long long k = gt; k < tot; k += GT) {
       const int r = (int)(k / wrow), cc = r + (int)(k - (long long)r * wrow);
       if (cc >= n) continue;
+      if (cc - r > d.bw) { S[(size_t)r * n + cc] = 0.0; continue; }
       if ((r % 15) < 6 && (cc % 15) < 6) {               // pose-pose blocks: written below for keyframes at most bw_kf apart
         if (cc / 15 - r / 15 > d.bw_kf) S[(size_t)r * n + cc] = 0.0;
         continue;
@@ -809,7 +814,6 @@ __device__ __forceinline__ void liba_solve(const LibaCtx& c, double* sh_lds) {
 // wavefront, the columns in registers, pivots and multipliers passed by lane shuffles), the row panel is divided among all threads of
 // the group, a group barrier, the trailing update A_ij -= sum_p u_pi u_pj / d_p in tiles of 16 rows x 64 columns divided among all
 // wavefronts of the group, a group barrier.  Forward and back substitution by block 0, 16 rows at a time, the vectors in LDS.
-constexpr int kPB = 16;
 __device__ __noinline__ bool liba_solve_group(const LibaCtx& c, Grp& g, int* lds_flag) {
   OSH_LIBA_LOCALS
   double* du = sh;                       // [kPB][kPB] row q: u_qp for p >= q (u_qq = d_q)

@@ -177,6 +177,27 @@ def test_banded_layout_of_a_map_sized_problem_equals_the_dense_one(solver, monke
     np.testing.assert_allclose(a.points, b.points, rtol=0, atol=1e-7)
 
 
+def test_banded_problem_does_not_depend_on_what_the_context_ran_before(hip_lib):
+    """The banded layout forms only the band of S, but a 16-pivot step of the group factorisation reads its first row 15 columns further:
+    structural zeros that have to be written (r03: left unwritten, they were whatever an earlier call had put in the arena -- a map solved
+    after a batch of 128 windows in the same context ended on another cost; `bench.py` does exactly that).  Same bits in a fresh context
+    and after a batch that has filled the arena."""
+    import dataclasses
+    w = si.make_inertial_window(1300, n_opt=400, n_fixed=0, n_points=16000, large=True)      # (the map bench.py solves)
+    w = dataclasses.replace(w, lambda_init=1e-5, max_iterations=7, link_robust=np.ones_like(w.link_robust))
+    with lba.LbaSolver(0) as s:
+        a = s.solve_inertial([w])[0]
+    with lba.LbaSolver(0) as s:
+        base = [si.make_inertial_window(11 + k, n_points=3600) for k in range(8)]
+        s.solve_inertial([base[k % 8] for k in range(128)])
+        b = s.solve_inertial([w])[0]
+        c = s.solve_inertial([w])[0]
+    for x in (b, c):
+        assert x.iterations == a.iterations and x.trials == a.trials
+        for f in ("chi2_trace", "pose_twb", "vel", "bias_g", "bias_a", "points"):
+            np.testing.assert_array_equal(getattr(x, f), getattr(a, f), err_msg=f)
+
+
 def test_large_window_of_25_keyframes(solver, ob):
     """LocalInertialBA's bLarge case: 25 temporal keyframes (src/Optimizer.cc:2394-2400), a 375 x 375 reduced system."""
     w = si.make_inertial_window(61, n_opt=25, n_fixed=10, n_points=1500, large=True)
