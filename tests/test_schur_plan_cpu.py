@@ -36,7 +36,10 @@ def observer_counts(w):
     lambda: synth.make_window(6, n_free=40, n_fixed=4, n_points=2000, track_len=(10, 30), obs_dropout=0.3),
     lambda: synth.make_window(7, n_free=1, n_fixed=2, n_points=50, track_len=(2, 3)),
 ])
-def test_plan_covers_every_observer_pair_once(maker):
+@pytest.mark.parametrize("item_max", [8, 24, 64])
+def test_plan_covers_every_observer_pair_once(maker, item_max, monkeypatch):
+    # (the landmarks per item follow the number of windows of the call -- schur_plan.h:item_max_lm -- 24, 32 or 64)
+    monkeypatch.setenv("OSH_LBA_ITEM_MAX", str(item_max))
     w = maker()
     st = plan_stats(w)
     k = observer_counts(w)
@@ -76,7 +79,7 @@ def test_plan_landmark_without_optimisable_observer():
 
 def test_plan_efficiency_of_the_headline_window():
     """The MFMA work of config 2 stays within 2x of the useful 6x6x3 products (tile padding + zero fill)."""
-    st = plan_stats(synth.make_config2(100))
+    st = plan_stats(synth.make_config2(100))      # (a single window: items of at most 24 landmarks)
     useful = st["blocks"] * 36 * 3
     issued = st["mfma"] * 16 * 16 * 4
     assert issued < 2.0 * useful
