@@ -63,6 +63,23 @@ def test_double_records_and_degenerate_windows(solver):
     solver.pack_compare([w4, w5, base])
 
 
+def test_sliced_upload_of_a_large_batch_and_its_restaging_with_double_records(solver):
+    """From 128 windows on the staging pass and the host-to-device copy overlap slice by slice (lba_pack_device.hip:device_pack_batch).  A batch of
+    140 windows packs to the host packer's bytes; so does the same batch with ONE observation that is not a float32 value in its last window
+    -- found while the earlier slices' float32 records are already on their way, the whole batch is staged and sent again as doubles."""
+    ws = [synth.make_window(700 + i, n_free=3 + i % 4, n_fixed=1 + i % 2, n_points=60 + 7 * (i % 9), stereo=bool(i % 2)) for i in range(140)]
+    st = solver.pack_compare(ws)
+    assert st["records"] > 140 * 60
+    ws[-1].edge_obs = ws[-1].edge_obs + 1e-9
+    solver.pack_compare(ws)
+    a = solver.solve(ws)
+    solver.set_pack_mode(0)
+    b = solver.solve(ws)
+    solver.set_pack_mode(-1)
+    for x, y in zip(a, b):
+        assert x.iterations == y.iterations and np.array_equal(x.pose_qt, y.pose_qt) and np.array_equal(x.points, y.points)
+
+
 def test_fisheye_monocular_window(solver):
     solver.pack_compare([synth.make_window(21, n_free=8, n_fixed=2, n_points=500, stereo=False, fisheye=True)])
 
